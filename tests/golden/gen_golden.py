@@ -1,0 +1,356 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference; torchvision is
+replaced by the test-only stand-in ``_tv_standin.py``).  For every case it
+
+  1. runs the reference's own function (file:line cited per case),
+  2. asserts the CPU oracle (``oracle/rn_oracle.c``) reproduces it -- this is
+     what pins the oracle -- and
+  3. writes inputs (or their seed + sha256) and expected outputs as ``.npz``.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, HERE)
+sys.dont_write_bytecode = True
+warnings.filterwarnings("ignore", message="torch.meshgrid")
+
+import torch  # noqa: E402
+
+import _tv_standin  # noqa: E402
+import oracle  # noqa: E402
+import synth  # noqa: E402
+
+R = _tv_standin.import_reference("/root/reference")
+from retinanet import box_utils as ref_box_utils  # noqa: E402
+from retinanet import losses as ref_losses  # noqa: E402
+from retinanet import models as ref_models  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def ref_anchor_set(h, w, **kw):
+    """Reference anchors for a padded (h, w) input: anchors.py:172-197 + cat (:228)."""
+    ag = R.AnchorGenerator(**kw)
+    grids = synth.fpn_grid_sizes(h, w)[: ag.num_features]
+    per_level = ag.grid_anchors([list(g) for g in grids], device=torch.device("cpu"))
+    cells = [b.numpy().copy() for b in ag.cell_anchors]
+    return torch.cat(per_level).numpy().copy(), cells, ag
+
+
+# --------------------------------------------------------------------------- #
+def gen_anchors():
+    print("[anchors]  retinanet/anchors.py:110-228")
+    out = {}
+    for tag, (h, w) in {"r18_512": (512, 512), "r50_800x1344": (800, 1344), "r101_1344": (1344, 1344)}.items():
+        ref, cells, _ = ref_anchor_set(h, w)
+        levels = synth.levels_for(h, w)
+        oc = [oracle.cell_anchors(s, synth.ANCHOR_RATIOS) for s in synth.ANCHOR_SIZES]
+        for a, b in zip(oc, cells):
+            assert np.array_equal(a, b), "oracle cell anchors != reference"
+        got = oracle.anchors_emit(levels, oc, 0.0)
+        assert got.shape == ref.shape and np.array_equal(got, ref), f"oracle anchors != reference ({tag})"
+        out[f"{tag}_sha"] = np.array(synth.sha(ref))
+        out[f"{tag}_count"] = np.array(ref.shape[0])
+        out[f"{tag}_head"] = ref[:32]
+        out[f"{tag}_tail"] = ref[-32:]
+        out[f"{tag}_levels"] = np.array(levels, dtype=np.int32)
+        print(f"  {tag}: A={ref.shape[0]} bit-exact")
+    out["cells"] = np.stack(cells)
+    # non-default generator: 2 levels, offset 0.5 / 0.3, custom sizes & ratios (anchors.py:69-99)
+    for tag, off in (("toy_off05", 0.5), ("toy_off03", 0.3)):
+        sizes = [[20.0, 33.5], [70.0, 91.25]]
+        ratios = [0.4, 1.0, 3.0]
+        strides = [8, 16]
+        ag = R.AnchorGenerator(sizes=sizes, aspect_ratios=ratios, strides=strides, offset=off)
+        grids = [[5, 7], [3, 4]]
+        ref = torch.cat(ag.grid_anchors(grids, device=torch.device("cpu"))).numpy()
+        oc = [oracle.cell_anchors(s, ratios) for s in sizes]
+        got = oracle.anchors_emit([(5, 7, 8), (3, 4, 16)], oc, off)
+        assert np.array_equal(got, ref), f"oracle anchors != reference ({tag})"
+        out[f"{tag}_full"] = ref
+    save("anchors.npz", **out)
+
+
+# --------------------------------------------------------------------------- #
+def ref_match(anchors, gt):
+    return ref_box_utils.matcher(torch.from_numpy(anchors), torch.from_numpy(gt).reshape(-1, 4)).numpy()
+
+
+def gen_match():
+    print("[match]  retinanet/box_utils.py:51-80 + torchvision box_iou")
+    out = {}
+    anc18, _, _ = ref_anchor_set(512, 512)
+    anc50, _, _ = ref_anchor_set(800, 1344)
+    for T in (0, 1, 8, 64, 500):
+        rng = np.random.default_rng(1000 + T)
+        gt, _ = synth.gt_boxes(rng, T, 512, 512)
+        ref = ref_match(anc18, gt)
+        got, nfg = oracle.iou_match(anc18, [gt])
+        assert np.array_equal(got[0], ref), f"oracle matcher != reference (T={T})"
+        assert nfg[0] == (ref >= 0).sum()
+        out[f"r18_T{T}_gt"] = gt
+        out[f"r18_T{T}_matches"] = ref.astype(np.int16)
+        print(f"  r18 T={T}: fg={int((ref >= 0).sum())} bg={int((ref == -1).sum())} ign={int((ref == -2).sum())} bit-exact")
+    rng = np.random.default_rng(2008)
+    gt, _ = synth.gt_boxes(rng, 8, 800, 1333)
+    ref = ref_match(anc50, gt)
+    got, _ = oracle.iou_match(anc50, [gt])
+    assert np.array_equal(got[0], ref)
+    out["r50_T8_gt"] = gt
+    out["r50_T8_matches"] = ref.astype(np.int16)
+    print(f"  r50 T=8: fg={int((ref >= 0).sum())} bit-exact")
+    # handcrafted: ties, exact thresholds, degenerate / NaN
+    hand_anchors = np.array([
+        [0, 0, 10, 10],      # 0: vs gt0 IoU exactly 0.5 -> ignore; vs gt1 0.4 -> ignore
+        [100, 100, 110, 110],  # 1: identical to gt2 and gt3 (tie) -> lowest index 2
+        [200, 200, 200, 200],  # 2: zero-area anchor on zero-area gt4 -> 0/0 NaN -> ignore
+        [300, 300, 310, 310],  # 3: no overlap -> bg
+        [0, 0, 10, 6],       # 4: vs gt0: inter 50, union 60 -> 0.8333 -> gt0
+        [100, 100, 110, 104],  # 5: vs gt2/gt3 0.4 exactly -> ignore (not < 0.4)
+        [100, 100, 110, 103.9],  # 6: just under 0.4 -> bg
+        [100, 100, 110, 105.1],  # 7: just over 0.5 -> 2
+    ], dtype=np.float32)
+    hand_gt = np.array([
+        [0, 0, 10, 5],
+        [0, 0, 10, 4],
+        [100, 100, 110, 110],
+        [100, 100, 110, 110],
+        [200, 200, 200, 200],
+    ], dtype=np.float32)
+    ref = ref_match(hand_anchors, hand_gt)
+    got, _ = oracle.iou_match(hand_anchors, [hand_gt])
+    assert np.array_equal(got[0], ref), (got[0], ref)
+    print("  handcrafted:", ref.tolist())
+    out["hand_anchors"], out["hand_gt"], out["hand_matches"] = hand_anchors, hand_gt, ref.astype(np.int16)
+    # NaN-first ordering: gt with NaN IoU not in first position
+    hand_gt2 = hand_gt[[4, 0, 2]]
+    ref = ref_match(hand_anchors, hand_gt2)
+    got, _ = oracle.iou_match(hand_anchors, [hand_gt2])
+    assert np.array_equal(got[0], ref), (got[0], ref)
+    out["hand2_gt"], out["hand2_matches"] = hand_gt2, ref.astype(np.int16)
+    save("match.npz", **out)
+
+
+# --------------------------------------------------------------------------- #
+def ref_losses_with_grads(cls, box, anchors, gtb, gtl, K):
+    """RetinaNetLosses.forward  retinanet/losses.py:113-145, with autograd grads of each loss."""
+    B = cls.shape[0]
+    crit = ref_losses.RetinaNetLosses(K)
+    c = torch.from_numpy(cls).clone().requires_grad_(True)
+    b = torch.from_numpy(box).clone().requires_grad_(True)
+    targets = [{"boxes": torch.from_numpy(gtb[i]).reshape(-1, 4), "labels": torch.from_numpy(gtl[i]).reshape(-1)}
+               for i in range(B)]
+    ancs = [torch.from_numpy(anchors) for _ in range(B)]
+    out = crit(targets, {"cls_preds": c, "bbox_preds": b}, ancs)
+    cl, rl = out["classification_loss"], out["regression_loss"]
+    gc = torch.autograd.grad(cl, c, retain_graph=True)[0].numpy()
+    gb = torch.autograd.grad(rl, b, allow_unused=True)[0] if rl.requires_grad else None
+    gb = gb.numpy() if gb is not None else np.zeros_like(box)
+    per = []
+    for i in range(B):
+        bb, cc = crit.calc_loss(ancs[i], torch.from_numpy(cls[i]), torch.from_numpy(box[i]),
+                                targets[i]["labels"], targets[i]["boxes"])
+        per.append([float(bb), float(cc)])
+    return np.array([float(cl), float(rl)], np.float32), np.array(per, np.float32), gc, gb
+
+
+def check_loss_oracle(tag, cls, box, anchors, gtb, gtl, K, ref):
+    loss, per, gc, gb = ref
+    matches, nfg = oracle.iou_match(anchors, gtb)
+    o = oracle.loss_fwd_bwd(cls, box, anchors, gtb, gtl, matches)
+    np.testing.assert_allclose(o["loss"], loss, rtol=1e-5, atol=1e-7, err_msg=tag)
+    np.testing.assert_allclose(o["per_image"], per, rtol=1e-5, atol=1e-7, err_msg=tag)
+    np.testing.assert_allclose(o["gcls"], gc, rtol=1e-5, atol=1e-9, err_msg=tag)
+    np.testing.assert_allclose(o["gbox"], gb, rtol=1e-5, atol=1e-9, err_msg=tag)
+    print(f"  {tag}: loss={loss.tolist()} nfg={nfg.tolist()} oracle within 1e-5")
+    return matches, nfg
+
+
+def gen_loss():
+    print("[loss]  retinanet/losses.py:19-145 (+ box_utils.py:25-34)")
+    out = {}
+    # toy: B=3, 64x64 input, K=3; image 1 has EMPTY GT (Q7), image 2 has GT that matches nothing
+    anc, _, _ = ref_anchor_set(64, 64)
+    A, K = anc.shape[0], 3
+    rng = np.random.default_rng(7)
+    cls, box = synth.head_outputs(rng, 3, A, K, cls_mean=-2.0, cls_std=1.5, box_std=0.3)
+    gtb = [np.array([[4, 6, 40, 44], [20, 10, 60, 58]], np.float32), np.zeros((0, 4), np.float32),
+           np.array([[1, 1, 3, 3]], np.float32)]
+    gtl = [np.array([1, 3], np.int64), np.zeros((0,), np.int64), np.array([2], np.int64)]
+    ref = ref_losses_with_grads(cls, box, anc, gtb, gtl, K)
+    matches, nfg = check_loss_oracle("toy", cls, box, anc, gtb, gtl, K, ref)
+    assert nfg[0] > 0 and nfg[1] == 0
+    assert ref[1][1, 1] == 0.0, "Q7: empty GT must give zero classification loss"
+    out.update(toy_anchors=anc, toy_cls=cls, toy_box=box, toy_gtb0=gtb[0], toy_gtb2=gtb[2], toy_gtl0=gtl[0],
+               toy_gtl2=gtl[2], toy_loss=ref[0], toy_per_image=ref[1], toy_gcls=ref[2], toy_gbox=ref[3],
+               toy_matches=matches.astype(np.int16), toy_nfg=nfg)
+    # R18 config (BASELINE.json configs[0]): B=2, A=49104, K=90; inputs regenerated from the seed in-test
+    anc, _, _ = ref_anchor_set(512, 512)
+    A, K, B = anc.shape[0], 90, 2
+    for variant in ("f32", "bf16", "f16"):
+        rng = np.random.default_rng(18)
+        cls, box = synth.head_outputs(rng, B, A, K)
+        gtb, gtl = [], []
+        for T in (8, 3):
+            g, l = synth.gt_boxes(rng, T, 512, 512)
+            gtb.append(g)
+            gtl.append(l)
+        if variant == "bf16":
+            cls, box = synth.round_bf16(cls), synth.round_bf16(box)
+        elif variant == "f16":
+            cls, box = synth.round_f16(cls), synth.round_f16(box)
+        ref = ref_losses_with_grads(cls, box, anc, gtb, gtl, K)
+        matches, nfg = check_loss_oracle(f"r18/{variant}", cls, box, anc, gtb, gtl, K, ref)
+        idx_c = synth.sample_idx(cls.size, 2048, seed=5)
+        # make sure positives' grads are in the sample: add every element of the fg rows' target class
+        fg_rows = np.argwhere(matches >= 0)
+        pos = np.array([(b * A + a) * K + (gtl[b][matches[b, a]] - 1) for b, a in fg_rows], dtype=np.int64)
+        idx_c = np.unique(np.concatenate([idx_c, pos]))
+        idx_b = np.unique(np.concatenate([synth.sample_idx(box.size, 512, seed=6),
+                                          np.array([(b * A + a) * 4 + j for b, a in fg_rows for j in range(4)],
+                                                   dtype=np.int64)]))
+        pre = f"r18_{variant}_"
+        out.update({
+            pre + "in_sha": np.array(synth.sha(cls) + synth.sha(box) + synth.sha(np.concatenate(gtb))),
+            pre + "loss": ref[0], pre + "per_image": ref[1], pre + "nfg": nfg,
+            pre + "gcls_idx": idx_c, pre + "gcls_val": ref[2].reshape(-1)[idx_c],
+            pre + "gbox_idx": idx_b, pre + "gbox_val": ref[3].reshape(-1)[idx_b],
+            pre + "gcls_sum": np.array([ref[2].astype(np.float64).sum(), np.abs(ref[2]).astype(np.float64).sum()]),
+            pre + "gbox_sum": np.array([ref[3].astype(np.float64).sum(), np.abs(ref[3]).astype(np.float64).sum()]),
+        })
+    save("loss.npz", **out)
+
+
+# --------------------------------------------------------------------------- #
+def gen_decode():
+    print("[decode]  retinanet/box_utils.py:37-48 (Q4) + clip_boxes_to_image (models.py:189)")
+    anc, _, _ = ref_anchor_set(512, 512)
+    rows = synth.sample_idx(anc.shape[0], 1024, seed=9)
+    a = anc[rows]
+    rng = np.random.default_rng(9)
+    d = (rng.standard_normal((1024, 4), dtype=np.float32) * np.float32(0.5)).astype(np.float32)
+    dec = ref_box_utils.activ_2_bbox(torch.from_numpy(d).clone(), torch.from_numpy(a)).numpy()
+    from torchvision.ops import boxes as tvops
+    clip = tvops.clip_boxes_to_image(torch.from_numpy(dec), (480, 500)).numpy()
+    got = oracle.decode_clip(d, a, None)
+    np.testing.assert_allclose(got, dec, rtol=1e-5, atol=1e-3)
+    got = oracle.decode_clip(d, a, [(480, 500)])
+    np.testing.assert_allclose(got, clip, rtol=1e-5, atol=1e-3)
+    # Q4: w,h come from exp(dx), exp(dy); dw,dh are ignored
+    d2 = d.copy()
+    d2[:, 2:] = 7.0
+    dec2 = ref_box_utils.activ_2_bbox(torch.from_numpy(d2).clone(), torch.from_numpy(a)).numpy()
+    assert np.array_equal(dec2, dec), "Q4 expected dw,dh to be ignored"
+    # encode (bbox_2_activ, box_utils.py:25-34) on the same rows against shifted GT
+    g = a + rng.uniform(-6, 6, size=a.shape).astype(np.float32)
+    g[:, 2:] = np.maximum(g[:, 2:], g[:, :2] + 1.0)
+    enc = ref_box_utils.bbox_2_activ(torch.from_numpy(g), torch.from_numpy(a)).numpy()
+    np.testing.assert_allclose(oracle.encode(g, a), enc, rtol=1e-5, atol=1e-6)
+    print("  oracle decode/clip/encode within tolerance")
+    save("decode.npz", anchors=a, deltas=d, decoded=dec, clipped=clip, clip_hw=np.array([480, 500]), enc_gt=g, encoded=enc)
+
+
+# --------------------------------------------------------------------------- #
+def ref_detect(cls, box, anchors, hw, score_thr=0.05, nms_thr=0.5, max_det=100):
+    """Retinanet.process_detections  retinanet/models.py:160-243 (unbound, on a namespace)."""
+    ns = types.SimpleNamespace(score_thres=score_thr, nms_thres=nms_thr, detections_per_img=max_det)
+    B = cls.shape[0]
+    outputs = {"cls_preds": torch.from_numpy(cls).clone(), "bbox_preds": torch.from_numpy(box).clone()}
+    dets = ref_models.Retinanet.process_detections(ns, outputs, [torch.from_numpy(anchors)] * B, hw)
+    return [{k: v.numpy() for k, v in d.items()} for d in dets]
+
+
+def compare_dets(tag, got, ref):
+    for b, (g, r) in enumerate(zip(got, ref)):
+        assert g["labels"].shape == r["labels"].shape, (tag, b, g["labels"].shape, r["labels"].shape)
+        assert np.array_equal(g["labels"], r["labels"]), (tag, b)
+        np.testing.assert_allclose(g["scores"], r["scores"], rtol=1e-6, atol=1e-7, err_msg=tag)
+        np.testing.assert_allclose(g["boxes"], r["boxes"], rtol=1e-5, atol=1e-3, err_msg=tag)
+
+
+def gen_detect():
+    print("[detect]  retinanet/models.py:160-243 + torchvision nms/remove_small/clip")
+    out = {}
+    anc, _, _ = ref_anchor_set(64, 64)
+    A, K = anc.shape[0], 3
+    rng = np.random.default_rng(11)
+    cls, box = synth.head_outputs(rng, 2, A, K, cls_mean=-2.0, cls_std=1.5, box_std=0.2)
+    hw = [(60, 64), (64, 50)]
+    ref = ref_detect(cls, box, anc, hw)
+    compare_dets("toy", oracle.detect(cls, box, anc, hw), ref)
+    print(f"  toy: dets/img={[len(r['scores']) for r in ref]} oracle ok")
+    out.update(toy_anchors=anc, toy_cls=cls, toy_box=box, toy_hw=np.array(hw))
+    for b, r in enumerate(ref):
+        out.update({f"toy_boxes{b}": r["boxes"], f"toy_scores{b}": r["scores"], f"toy_labels{b}": r["labels"]})
+    # max_det smaller than survivors + different thresholds
+    ref = ref_detect(cls, box, anc, hw, score_thr=0.2, nms_thr=0.3, max_det=7)
+    compare_dets("toy2", oracle.detect(cls, box, anc, hw, oracle.default_detect_params(0.2, 1e-2, 0.3, 7)), ref)
+    for b, r in enumerate(ref):
+        out.update({f"toy2_boxes{b}": r["boxes"], f"toy2_scores{b}": r["scores"], f"toy2_labels{b}": r["labels"]})
+    # R18 config, sparse and denser regimes, inputs regenerated from seed in-test
+    anc, _, _ = ref_anchor_set(512, 512)
+    A, K = anc.shape[0], 90
+    hw = [(512, 512), (480, 500)]
+    for tag, mean, std, seed in (("sparse", -7.0, 1.2, 21), ("dense", -6.0, 1.5, 22)):
+        rng = np.random.default_rng(seed)
+        cls, box = synth.head_outputs(rng, 2, A, K, cls_mean=mean, cls_std=std, box_std=0.1)
+        ref = ref_detect(cls, box, anc, hw)
+        compare_dets(tag, oracle.detect(cls, box, anc, hw), ref)
+        ncand = int((1 / (1 + np.exp(-cls.astype(np.float64))) > 0.05).sum())
+        print(f"  r18 {tag}: candidates={ncand} dets/img={[len(r['scores']) for r in ref]} oracle ok")
+        out[f"r18_{tag}_in_sha"] = np.array(synth.sha(cls) + synth.sha(box))
+        out[f"r18_{tag}_hw"] = np.array(hw)
+        for b, r in enumerate(ref):
+            out.update({f"r18_{tag}_boxes{b}": r["boxes"], f"r18_{tag}_scores{b}": r["scores"],
+                        f"r18_{tag}_labels{b}": r["labels"]})
+    save("detect.npz", **out)
+
+
+def gen_nms():
+    print("[nms]  torchvision.ops.nms as called at retinanet/models.py:210")
+    from torchvision.ops import boxes as tvops
+    out = {}
+    for n in (0, 1, 5, 200, 1500):
+        rng = np.random.default_rng(300 + n)
+        ctr = rng.uniform(0, 200, size=(max(n // 6, 1), 2))
+        c = ctr[rng.integers(0, len(ctr), size=n)] + rng.normal(0, 4, size=(n, 2))
+        wh = rng.uniform(10, 60, size=(n, 2))
+        boxes = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+        scores = rng.uniform(0.05, 1, size=n).astype(np.float32)
+        if n >= 200:
+            scores[::7] = scores[3]          # score ties: stable order decides
+            boxes[5] = boxes[4]              # identical boxes
+        for thr in (0.5, 0.3):
+            ref = tvops.nms(torch.from_numpy(boxes), torch.from_numpy(scores), thr).numpy()
+            got = oracle.nms(boxes, scores, thr)
+            assert np.array_equal(got, ref), (n, thr)
+            out[f"n{n}_keep_{int(thr * 10)}"] = ref
+        out[f"n{n}_boxes"], out[f"n{n}_scores"] = boxes, scores
+        print(f"  n={n}: keep={len(ref)} bit-exact")
+    save("nms.npz", **out)
+
+
+if __name__ == "__main__":
+    oracle.build()
+    which = sys.argv[1:] or ["anchors", "match", "loss", "decode", "detect", "nms"]
+    for w in which:
+        globals()["gen_" + w]()
+    print("done")

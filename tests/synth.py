@@ -1,0 +1,81 @@
+"""Seeded synthetic inputs shared by gen_golden.py, the parity tests and bench.py.
+
+numpy's PCG64 ``default_rng`` is used (not torch's RNG) so the same seed gives
+the same bytes in the build container and on the GPU box; fixtures carry an
+input checksum so a drift would be detected rather than silently compared.
+
+Distributions follow SURVEY.md section 8d / BASELINE.md section 2.
+"""
+import hashlib
+import math
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+ANCHOR_SIZES = [[x, x * 2 ** (1 / 3), x * 2 ** (2 / 3)] for x in [32, 64, 128, 256, 512]]
+ANCHOR_RATIOS = [0.5, 1.0, 2.0]
+ANCHOR_STRIDES = [8, 16, 32, 64, 128]
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def fpn_grid_sizes(h: int, w: int) -> List[Tuple[int, int]]:
+    """Feature-map sizes P3..P7 for a padded input of (h, w) (both multiples of 32).
+
+    C3/C4/C5 are /8,/16,/32; P6,P7 follow a 3x3 stride-2 pad-1 conv: floor((n-1)/2)+1.
+    """
+    p3 = (h // 8, w // 8)
+    p4 = (h // 16, w // 16)
+    p5 = (h // 32, w // 32)
+    nxt = lambda n: (n - 1) // 2 + 1
+    p6 = (nxt(p5[0]), nxt(p5[1]))
+    p7 = (nxt(p6[0]), nxt(p6[1]))
+    return [p3, p4, p5, p6, p7]
+
+
+def levels_for(h: int, w: int) -> List[Tuple[int, int, int]]:
+    return [(gh, gw, s) for (gh, gw), s in zip(fpn_grid_sizes(h, w), ANCHOR_STRIDES)]
+
+
+def gt_boxes(rng: np.random.Generator, T: int, img_h: int, img_w: int, num_classes: int = 90,
+             wh_lo: float = 16.0, wh_hi: float = 316.0):
+    """T boxes: centre uniform over the image, w,h ~ U(wh_lo, wh_hi), xyxy clamped, non-degenerate."""
+    boxes = np.zeros((T, 4), dtype=np.float32)
+    for i in range(T):
+        while True:
+            cx = rng.uniform(0, img_w)
+            cy = rng.uniform(0, img_h)
+            bw = rng.uniform(wh_lo, wh_hi)
+            bh = rng.uniform(wh_lo, wh_hi)
+            x1, y1 = max(cx - bw / 2, 0.0), max(cy - bh / 2, 0.0)
+            x2, y2 = min(cx + bw / 2, float(img_w)), min(cy + bh / 2, float(img_h))
+            b = np.array([x1, y1, x2, y2], dtype=np.float32)
+            if b[2] > b[0] and b[3] > b[1]:
+                boxes[i] = b
+                break
+    labels = rng.integers(1, num_classes + 1, size=(T,)).astype(np.int64)
+    return boxes, labels
+
+
+def head_outputs(rng: np.random.Generator, B: int, A: int, K: int, cls_mean: float = -4.6, cls_std: float = 1.0,
+                 box_std: float = 0.1):
+    cls = (rng.standard_normal((B, A, K), dtype=np.float32) * np.float32(cls_std) + np.float32(cls_mean)).astype(np.float32)
+    box = (rng.standard_normal((B, A, 4), dtype=np.float32) * np.float32(box_std)).astype(np.float32)
+    return cls, box
+
+
+def round_bf16(a: np.ndarray) -> np.ndarray:
+    """Round-to-nearest-even fp32 -> bf16 -> fp32 (values stay fp32)."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32).reshape(a.shape)
+
+
+def round_f16(a: np.ndarray) -> np.ndarray:
+    return a.astype(np.float16).astype(np.float32)
+
+
+def sample_idx(n: int, k: int, seed: int = 123) -> np.ndarray:
+    return np.sort(np.random.default_rng(seed).choice(n, size=min(k, n), replace=False)).astype(np.int64)
