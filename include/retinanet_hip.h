@@ -1,0 +1,154 @@
+/*
+ * retinanet_hip.h -- C ABI of libretinanet_hip.so, the MI355X (gfx950) dense-head
+ * path of RetinaNet: anchor emission, IoU + anchor/GT matching, fused focal +
+ * smooth-L1 loss (value and gradient in one pass), box decode/clip and batched
+ * per-class NMS + top-k.
+ *
+ * The reference (benihime91/pytorch_retinanet, pure Python) has no FFI of its
+ * own; each entry point below replaces the torch / torchvision op sequence at the
+ * cited reference lines (paths relative to the reference root).  Signatures are
+ * plain C: raw device pointers, sizes, one opaque hipStream_t.  No torch types.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer unless marked (host).  The caller owns all
+ *     buffers including workspaces; the library allocates nothing and keeps no state.
+ *   - All work is enqueued on `stream` (a hipStream_t, NULL = default stream); no
+ *     entry point synchronises with the host.
+ *   - Return value: 0 = RN_OK, negative = argument error (RN_E*), positive =
+ *     hipError_t from a launch.
+ *   - Tensors are dense, row-major, in the layouts written next to each argument.
+ *     `cls`/`grad_cls` base pointers must be 16-byte aligned, `box`/`grad_box`
+ *     8-byte (16-bit dtypes) or 16-byte (fp32) aligned.
+ *   - `anchor_bstride`: element stride between images' anchor sets; 0 = one anchor
+ *     set [A][4] shared by every image (the reference recomputes identical anchors
+ *     per image, retinanet/anchors.py:223-228).
+ *   - gt_off: int32[B+1] prefix offsets of each image's rows in gt_boxes/gt_labels.
+ */
+#ifndef RETINANET_HIP_H
+#define RETINANET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RN_ABI_VERSION 1
+#define RN_MAX_LEVELS 8
+
+enum rn_dtype { RN_F32 = 0, RN_BF16 = 1, RN_F16 = 2 };
+
+enum rn_status {
+    RN_OK = 0,
+    RN_EINVAL = -1,       /* null pointer / non-positive size / bad enum */
+    RN_EALIGN = -2,       /* pointer alignment requirement not met */
+    RN_EWORKSPACE = -3,   /* workspace too small */
+    RN_EUNSUPPORTED = -4, /* shape outside the supported range (see entry point) */
+    RN_ETHRESH = -5       /* fg_thr <= bg_thr (retinanet/box_utils.py:66 assert) */
+};
+
+/* One pyramid level: feature-map size, stride and anchors per location. */
+typedef struct rn_level { int32_t H, W, stride, num_cell; } rn_level;
+
+/* retinanet/config.py:85-87 (gamma, alpha, beta), losses.py:84 (logit_shift = 1),
+ * box_utils.py:32 (log_eps = 1e-8), config.py:67 (reg_w). */
+typedef struct rn_loss_params {
+    float alpha, gamma, beta, logit_shift, log_eps;
+    float reg_w[4];
+} rn_loss_params;
+
+/* retinanet/config.py:71-75 (score_thr, nms_thr, max_det), models.py:203 (min_box = 1e-2). */
+typedef struct rn_detect_params {
+    float score_thr, min_box, nms_thr;
+    int32_t max_det;
+    float reg_w[4];
+} rn_detect_params;
+
+int rn_version(void);
+const char *rn_status_string(int status);
+
+/* ---- K1 anchors_emit --------------------------------------------------------
+ * Replaces AnchorGenerator._compute_grid_offsets / grid_anchors / forward's cat,
+ * retinanet/anchors.py:151-170, :172-197, :228.  Bit-exact with the CPU path.
+ * levels (host)[L]; cell_anchors (host array of L device pointers, each
+ * f32[num_cell][4], = the module's `cell_anchors.{l}` buffers); out f32[A][4]
+ * with A = rn_anchors_count(levels, L), levels concatenated in order, row-major
+ * (y, x), cell anchor fastest. */
+int64_t rn_anchors_count(const rn_level *levels, int L);
+int rn_anchors_emit(const rn_level *levels, int L, const float *const *cell_anchors,
+                    double offset, float *out, void *stream);
+
+/* ---- K2 iou_match -----------------------------------------------------------
+ * Replaces matcher(), retinanet/box_utils.py:51-80, and the torchvision
+ * box_iou it calls (:74); the [T,A] IoU matrix is never materialised.
+ * matches i64[B][A]: -2 ignore, -1 background, >=0 index of the matched GT row
+ * within its image (lowest index on ties).  num_fg (nullable) i32[B] = count of
+ * matches >= 0 per image.  Bit-exact with the CPU path for fp32 inputs. */
+int rn_iou_match(const float *anchors, int64_t anchor_bstride,
+                 const float *gt_boxes, const int32_t *gt_off, int B, int64_t A,
+                 float fg_thr, float bg_thr, int64_t *matches, int32_t *num_fg, void *stream);
+
+/* ---- K3 loss_fwd_bwd --------------------------------------------------------
+ * Replaces RetinaNetLosses.forward / calc_loss / focal_loss / smooth_l1_loss,
+ * retinanet/losses.py:19-145, and bbox_2_activ, retinanet/box_utils.py:25-34:
+ * one pass over cls [B][A][K] and box [B][A][4] (dtype in {f32,bf16,f16}) that
+ * produces out_loss f32[2] = {classification_loss, regression_loss} (batch means
+ * of the per-image normalised sums) AND the gradients of those two scalars w.r.t.
+ * cls / box (same dtype and shape; grad_* may be NULL for value-only).
+ * gt_labels i64 in 1..K.  num_fg i32[B] as produced by rn_iou_match.
+ * workspace: rn_loss_workspace_bytes(B, A, K) bytes, 16-byte aligned. */
+size_t rn_loss_workspace_bytes(int B, int64_t A, int K);
+int rn_loss_fwd_bwd(const void *cls, const void *box, int dtype, int B, int64_t A, int K,
+                    const float *anchors, int64_t anchor_bstride,
+                    const float *gt_boxes, const int64_t *gt_labels, const int32_t *gt_off,
+                    const int64_t *matches, const int32_t *num_fg, const rn_loss_params *params,
+                    float *out_loss, void *grad_cls, void *grad_box,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* In-place data[i] *= *scale (device scalar); returns immediately on the device
+ * when *scale == 1.  Used by autograd's backward to apply the upstream gradient to
+ * the gradients rn_loss_fwd_bwd already wrote, without a host sync. */
+int rn_scale_inplace(void *data, int dtype, int64_t n, const float *scale, void *stream);
+
+/* ---- K4 decode_clip ---------------------------------------------------------
+ * Replaces activ_2_bbox, retinanet/box_utils.py:37-48 (including its use of
+ * dx,dy for the sizes, :46) and torchvision clip_boxes_to_image at
+ * retinanet/models.py:189.  deltas [B][A][4] (dtype), image_hw i32[B][2] = resized
+ * unpadded (h, w) per image, NULL = no clipping.  out f32[B][A][4]. */
+int rn_decode_clip(const void *deltas, int dtype, int B, int64_t A,
+                   const float *anchors, int64_t anchor_bstride, const int32_t *image_hw,
+                   const float reg_w[4], float *out, void *stream);
+
+/* ---- K6 nms (op boundary) ---------------------------------------------------
+ * Replaces torchvision.ops.nms as called at retinanet/models.py:210, batched over
+ * S independent segments: seg_off i32[S+1]; boxes f32[N][4], scores f32[N].
+ * keep i64[N]: for segment s, keep[seg_off[s] .. +keep_count[s]) are the kept
+ * indices RELATIVE to the segment start, in descending score order (stable).
+ * workspace: rn_nms_workspace_bytes(N, S). */
+size_t rn_nms_workspace_bytes(int64_t N, int S);
+int rn_nms_segments(const float *boxes, const float *scores, const int32_t *seg_off, int S, int64_t N,
+                    float iou_thr, int64_t *keep, int32_t *keep_count,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- K4-K7 detect -----------------------------------------------------------
+ * Replaces Retinanet.process_detections, retinanet/models.py:160-243: sigmoid,
+ * decode + clip, per class {score > thr, remove_small_boxes, nms}, class-major
+ * concat, labels + 1, stable sort by score, first max_det.
+ * Outputs are padded to max_det rows per image: out_boxes f32[B][max_det][4],
+ * out_scores f32[B][max_det], out_labels i64[B][max_det], out_count i32[B].
+ * max_candidates = per-image capacity for (anchor, class) pairs passing the score
+ * and size filters; if exceeded, out_status[b] (i32[B]) is set to 1 and that
+ * image's result is truncated -- the caller re-runs with a larger capacity
+ * (A*K always suffices). */
+size_t rn_detect_workspace_bytes(int B, int64_t A, int K, int64_t max_candidates);
+int rn_detect(const void *cls, const void *deltas, int dtype, int B, int64_t A, int K,
+              const float *anchors, int64_t anchor_bstride, const int32_t *image_hw,
+              const rn_detect_params *params, int64_t max_candidates,
+              float *out_boxes, float *out_scores, int64_t *out_labels, int32_t *out_count,
+              int32_t *out_status, void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RETINANET_HIP_H */

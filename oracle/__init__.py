@@ -94,7 +94,7 @@ def anchors_emit(levels: Sequence[Tuple[int, int, int]], cells: List[np.ndarray]
     n = lib().rno_anchors_count(lv, L)
     out = np.empty((n, 4), dtype=np.float32)
     ptrs = (C.POINTER(C.c_float) * L)(*[_p(c, C.c_float) for c in cells])
-    lib().rno_anchors_emit(lv, L, ptrs, C.c_float(offset), _p(out, C.c_float))
+    lib().rno_anchors_emit(lv, L, ptrs, C.c_double(offset), _p(out, C.c_float))
     return out
 
 

@@ -95,12 +95,12 @@ RNO_API int64_t rno_anchors_count(const rno_level *lv, int L)
     return n;
 }
 
-RNO_API void rno_anchors_emit(const rno_level *lv, int L, const float *const *cell, float offset, float *out)
+RNO_API void rno_anchors_emit(const rno_level *lv, int L, const float *const *cell, double offset, float *out)
 {
     int64_t base = 0;
     for (int l = 0; l < L; ++l) {
         const int H = lv[l].H, W = lv[l].W, S = lv[l].stride, C = lv[l].num_cell;
-        const double start = (double)offset * (double)S;   /* python: offset * stride */
+        const double start = offset * (double)S;   /* python: offset * stride */
         const float *ca = cell[l];
 #pragma omp parallel for schedule(static)
         for (int y = 0; y < H; ++y) {

@@ -1,0 +1,83 @@
+"""ctypes binding of ``libretinanet_hip.so`` (C ABI: ``include/retinanet_hip.h``).
+
+There is NO fallback: if the shared library is missing this module raises at
+import, and every op refuses non-device tensors.  The product path never
+touches ``oracle/``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libretinanet_hip.so")
+
+RN_F32, RN_BF16, RN_F16 = 0, 1, 2
+RN_MAX_LEVELS = 8
+
+
+class RnLevel(C.Structure):
+    _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("stride", C.c_int32), ("num_cell", C.c_int32)]
+
+
+class RnLossParams(C.Structure):
+    _fields_ = [("alpha", C.c_float), ("gamma", C.c_float), ("beta", C.c_float),
+                ("logit_shift", C.c_float), ("log_eps", C.c_float), ("reg_w", C.c_float * 4)]
+
+
+class RnDetectParams(C.Structure):
+    _fields_ = [("score_thr", C.c_float), ("min_box", C.c_float), ("nms_thr", C.c_float),
+                ("max_det", C.c_int32), ("reg_w", C.c_float * 4)]
+
+
+_vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/retinanet_hip.h one to one
+SIGNATURES = {
+    "rn_version": (C.c_int, []),
+    "rn_status_string": (C.c_char_p, [C.c_int]),
+    "rn_anchors_count": (_i64, [C.POINTER(RnLevel), C.c_int]),
+    "rn_anchors_emit": (C.c_int, [C.POINTER(RnLevel), C.c_int, C.POINTER(_vp), C.c_double, _vp, _vp]),
+    "rn_iou_match": (C.c_int, [_vp, _i64, _vp, _vp, C.c_int, _i64, _f32, _f32, _vp, _vp, _vp]),
+    "rn_loss_workspace_bytes": (_sz, [C.c_int, _i64, C.c_int]),
+    "rn_loss_fwd_bwd": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _i64, C.c_int, _vp, _i64, _vp, _vp, _vp, _vp, _vp,
+                                  C.POINTER(RnLossParams), _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rn_scale_inplace": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp]),
+    "rn_decode_clip": (C.c_int, [_vp, C.c_int, C.c_int, _i64, _vp, _i64, _vp, C.POINTER(_f32), _vp, _vp]),
+    # --DETECT-PENDING--
+    "rn_nms_workspace_bytes": (_sz, [_i64, C.c_int]),
+    "rn_nms_segments": (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, _f32, _vp, _vp, _vp, _sz, _vp]),
+    "rn_detect_workspace_bytes": (_sz, [C.c_int, _i64, C.c_int, _i64]),
+    "rn_detect": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _i64, C.c_int, _vp, _i64, _vp, C.POINTER(RnDetectParams),
+                            _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+}
+
+
+_PENDING = {"rn_nms_workspace_bytes", "rn_nms_segments", "rn_detect_workspace_bytes", "rn_detect"}  # TODO remove
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the MI355X HIP library has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `make -C pytorch_retinanet_amd/csrc`). "
+            "There is no CPU fallback for the dense-head path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        if name in _PENDING and not hasattr(lib, name):
+            continue
+        fn = getattr(lib, name)          # AttributeError here = ABI/header mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class RetinanetHipError(RuntimeError):
+    pass
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = lib.rn_status_string(int(status))
+        raise RetinanetHipError(f"{what} failed: status {status} ({msg.decode() if msg else '?'})")

@@ -1,0 +1,171 @@
+"""Tensor-level wrappers over the C ABI (``include/retinanet_hip.h``).
+
+PyTorch is plumbing here: it owns device memory and the stream.  Every wrapper
+passes ``tensor.data_ptr()`` and ``torch.cuda.current_stream().cuda_stream`` to
+the HIP library, never synchronises with the host, and REFUSES CPU tensors --
+there is no CPU implementation of this path in the product.
+"""
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import RN_BF16, RN_F16, RN_F32, RnDetectParams, RnLevel, RnLossParams, check, lib
+
+_DT = {torch.float32: RN_F32, torch.bfloat16: RN_BF16, torch.float16: RN_F16}
+
+
+def _need_dev(*tensors: Tensor) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "pytorch_retinanet_amd: the dense-head path runs only as HIP kernels on an MI355X; "
+                f"got a {t.device} tensor (there is no CPU fallback).")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev
+
+
+def _stream(dev: torch.device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _ptr(t: Optional[Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None or t.numel() == 0 else t.data_ptr())
+
+
+def _dtype_code(t: Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype}; expected float32, bfloat16 or float16")
+
+
+def _c(t: Tensor) -> Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _anchor_args(anchors: Tensor, B: int, A: int) -> Tuple[Tensor, int]:
+    """anchors [A,4] shared or [B,A,4] per image -> (contiguous fp32 tensor, batch stride in elements)."""
+    anchors = _c(anchors)
+    if anchors.dtype != torch.float32:
+        anchors = anchors.float()
+    if anchors.dim() == 2:
+        if anchors.shape != (A, 4):
+            raise ValueError(f"anchors shape {tuple(anchors.shape)} != ({A}, 4)")
+        return anchors, 0
+    if anchors.shape != (B, A, 4):
+        raise ValueError(f"anchors shape {tuple(anchors.shape)} != ({B}, {A}, 4)")
+    return anchors, A * 4
+
+
+# --------------------------------------------------------------------------- #
+def anchors_emit(levels: Sequence[Tuple[int, int, int]], cells: Sequence[Tensor], offset: float) -> Tensor:
+    """K1.  levels: [(H, W, stride)], cells: per-level device f32 [num_cell,4].  -> f32 [A,4]."""
+    L = len(levels)
+    if L == 0 or L > _lib.RN_MAX_LEVELS or len(cells) != L:
+        raise ValueError("need 1..8 levels and one cell-anchor tensor per level")
+    dev = _need_dev(*cells)
+    cells = [_c(c.float()) for c in cells]
+    lv = (RnLevel * L)(*[RnLevel(int(h), int(w), int(s), int(c.shape[0])) for (h, w, s), c in zip(levels, cells)])
+    total = lib.rn_anchors_count(lv, L)
+    out = torch.empty((total, 4), dtype=torch.float32, device=dev)
+    ptrs = (C.c_void_p * L)(*[c.data_ptr() for c in cells])
+    with torch.cuda.device(dev):
+        check(lib.rn_anchors_emit(lv, L, ptrs, float(offset), _ptr(out), _stream(dev)), "rn_anchors_emit")
+    return out
+
+
+def gt_offsets(counts: Sequence[int], device: torch.device) -> Tensor:
+    off = [0]
+    for c in counts:
+        off.append(off[-1] + int(c))
+    return torch.tensor(off, dtype=torch.int32, device=device)
+
+
+def iou_match(anchors: Tensor, gt_boxes: Tensor, gt_off: Tensor, B: int, fg_thr: float, bg_thr: float,
+              want_num_fg: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+    """K2.  anchors [A,4] or [B,A,4]; gt_boxes f32 [sum T,4]; gt_off i32 [B+1] (device).
+    -> (matches i64 [B,A], num_fg i32 [B])."""
+    dev = _need_dev(anchors, gt_boxes, gt_off)
+    A = anchors.shape[-2]
+    anchors, bstride = _anchor_args(anchors, B, A)
+    gt_boxes = _c(gt_boxes.float()).reshape(-1, 4)
+    if not fg_thr > bg_thr:
+        raise AssertionError("match_thr must be greater than back_thr")   # box_utils.py:66
+    matches = torch.empty((B, A), dtype=torch.int64, device=dev)
+    num_fg = torch.empty((B,), dtype=torch.int32, device=dev) if want_num_fg else None
+    with torch.cuda.device(dev):
+        check(lib.rn_iou_match(_ptr(anchors), bstride, _ptr(gt_boxes), _ptr(gt_off), B, A, fg_thr, bg_thr,
+                               _ptr(matches), _ptr(num_fg), _stream(dev)), "rn_iou_match")
+    return matches, num_fg
+
+
+def make_loss_params(alpha: float, gamma: float, beta: float, logit_shift: float = 1.0, log_eps: float = 1e-8,
+                     reg_w: Sequence[float] = (1.0, 1.0, 1.0, 1.0)) -> RnLossParams:
+    return RnLossParams(alpha, gamma, beta, logit_shift, log_eps, (C.c_float * 4)(*reg_w))
+
+
+def loss_fwd_bwd(cls: Tensor, box: Tensor, anchors: Tensor, gt_boxes: Tensor, gt_labels: Tensor, gt_off: Tensor,
+                 matches: Tensor, num_fg: Tensor, params: RnLossParams, want_grad: bool = True):
+    """K3.  cls [B,A,K], box [B,A,4] (same dtype) -> (loss f32[2] = (cls, reg), grad_cls, grad_box)."""
+    dev = _need_dev(cls, box, anchors, gt_boxes, gt_labels, gt_off, matches, num_fg)
+    if cls.dim() != 3 or box.dim() != 3 or box.shape[-1] != 4 or cls.shape[:2] != box.shape[:2]:
+        raise ValueError(f"bad head output shapes {tuple(cls.shape)} / {tuple(box.shape)}")
+    if box.dtype != cls.dtype:
+        box = box.to(cls.dtype)
+    B, A, K = cls.shape
+    cls, box = _c(cls), _c(box)
+    anchors, bstride = _anchor_args(anchors, B, A)
+    gt_boxes = _c(gt_boxes.float()).reshape(-1, 4)
+    gt_labels = _c(gt_labels.to(torch.int64)).reshape(-1)
+    code = _dtype_code(cls)
+    out = torch.empty((2,), dtype=torch.float32, device=dev)
+    gcls = torch.empty_like(cls) if want_grad else None
+    gbox = torch.empty_like(box) if want_grad else None
+    ws_bytes = lib.rn_loss_workspace_bytes(B, A, K)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.rn_loss_fwd_bwd(_ptr(cls), _ptr(box), code, B, A, K, _ptr(anchors), bstride, _ptr(gt_boxes),
+                                  _ptr(gt_labels), _ptr(gt_off), _ptr(matches), _ptr(num_fg), C.byref(params),
+                                  _ptr(out), _ptr(gcls), _ptr(gbox), _ptr(ws), ws_bytes, _stream(dev)),
+              "rn_loss_fwd_bwd")
+    return out, gcls, gbox
+
+
+def scale_inplace(t: Tensor, scale: Tensor) -> Tensor:
+    """t *= scale (device scalar, f32); a no-op on the device when scale == 1."""
+    dev = _need_dev(t, scale)
+    if not t.is_contiguous():
+        raise ValueError("scale_inplace needs a contiguous tensor")
+    scale = _c(scale.detach().to(torch.float32)).reshape(1)
+    with torch.cuda.device(dev):
+        check(lib.rn_scale_inplace(_ptr(t), _dtype_code(t), t.numel(), _ptr(scale), _stream(dev)), "rn_scale_inplace")
+    return t
+
+
+def image_hw_tensor(sizes: Sequence[Tuple[int, int]], device: torch.device) -> Tensor:
+    return torch.tensor([[int(h), int(w)] for h, w in sizes], dtype=torch.int32, device=device)
+
+
+def decode_clip(deltas: Tensor, anchors: Tensor, image_hw: Optional[Tensor],
+                reg_w: Sequence[float] = (1.0, 1.0, 1.0, 1.0)) -> Tensor:
+    """K4.  deltas [B,A,4] or [A,4]; image_hw i32 [B,2] (device) or None.  -> f32 boxes, same leading shape."""
+    dev = _need_dev(deltas, anchors, image_hw)
+    squeeze = deltas.dim() == 2
+    d = _c(deltas[None] if squeeze else deltas)
+    B, A, _ = d.shape
+    anchors, bstride = _anchor_args(anchors, B, A)
+    out = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
+    rw = (C.c_float * 4)(*reg_w)
+    with torch.cuda.device(dev):
+        check(lib.rn_decode_clip(_ptr(d), _dtype_code(d), B, A, _ptr(anchors), bstride, _ptr(image_hw), rw,
+                                 _ptr(out), _stream(dev)), "rn_decode_clip")
+    return out[0] if squeeze else out
