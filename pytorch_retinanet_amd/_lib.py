@@ -42,16 +42,12 @@ SIGNATURES = {
                                   C.POINTER(RnLossParams), _vp, _vp, _vp, _vp, _sz, _vp]),
     "rn_scale_inplace": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp]),
     "rn_decode_clip": (C.c_int, [_vp, C.c_int, C.c_int, _i64, _vp, _i64, _vp, C.POINTER(_f32), _vp, _vp]),
-    # --DETECT-PENDING--
     "rn_nms_workspace_bytes": (_sz, [_i64, C.c_int]),
     "rn_nms_segments": (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, _f32, _vp, _vp, _vp, _sz, _vp]),
     "rn_detect_workspace_bytes": (_sz, [C.c_int, _i64, C.c_int, _i64]),
     "rn_detect": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _i64, C.c_int, _vp, _i64, _vp, C.POINTER(RnDetectParams),
                             _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
-
-
-_PENDING = {"rn_nms_workspace_bytes", "rn_nms_segments", "rn_detect_workspace_bytes", "rn_detect"}  # TODO remove
 
 
 def _load():
@@ -62,8 +58,6 @@ def _load():
             "There is no CPU fallback for the dense-head path.")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
-        if name in _PENDING and not hasattr(lib, name):
-            continue
         fn = getattr(lib, name)          # AttributeError here = ABI/header mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args

@@ -1,0 +1,188 @@
+"""ResNet feature extractors C3/C4/C5 (reference ``retinanet/backbone.py:20-381``).
+
+Module/parameter names follow torchvision's ResNet (``conv1, bn1, layer{1..4}.{i}.
+conv{1,2,3}/bn{1,2,3}/downsample.{0,1}``) under ``backbone.backbone.*`` so ImageNet
+and reference checkpoints load unchanged.  Stride placement is ResNet v1.5 (stride
+on the 3x3 of a bottleneck).  The convolutions are PyTorch-ROCm / MIOpen; run the
+model in ``channels_last`` + bf16 autocast on MI355X (see ``models.Retinanet``).
+"""
+import os
+from typing import Dict, List, Optional, Type, Union
+
+import torch
+from torch import Tensor, nn
+
+__all__ = ["resnet18", "resnet34", "resnet50", "resnet101", "resnet152"]
+
+model_urls = {
+    "resnet18": "https://download.pytorch.org/models/resnet18-5c106cde.pth",
+    "resnet34": "https://download.pytorch.org/models/resnet34-333f7ec4.pth",
+    "resnet50": "https://download.pytorch.org/models/resnet50-19c8e357.pth",
+    "resnet101": "https://download.pytorch.org/models/resnet101-5d3b4d8f.pth",
+    "resnet152": "https://download.pytorch.org/models/resnet152-b121ed2d.pth",
+}
+
+
+def _conv3x3(cin: int, cout: int, stride: int = 1) -> nn.Conv2d:
+    return nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=1, bias=False)
+
+
+def _conv1x1(cin: int, cout: int, stride: int = 1) -> nn.Conv2d:
+    return nn.Conv2d(cin, cout, kernel_size=1, stride=stride, bias=False)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes: int, planes: int, stride: int = 1, downsample: Optional[nn.Module] = None):
+        super().__init__()
+        self.conv1 = _conv3x3(inplanes, planes, stride)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = _conv3x3(planes, planes)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x: Tensor) -> Tensor:
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        out = out + (x if self.downsample is None else self.downsample(x))
+        return self.relu(out)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes: int, planes: int, stride: int = 1, downsample: Optional[nn.Module] = None):
+        super().__init__()
+        self.conv1 = _conv1x1(inplanes, planes)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = _conv3x3(planes, planes, stride)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = _conv1x1(planes, planes * self.expansion)
+        self.bn3 = nn.BatchNorm2d(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x: Tensor) -> Tensor:
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        out = out + (x if self.downsample is None else self.downsample(x))
+        return self.relu(out)
+
+
+class ResNetBackbone(nn.Module):
+    "ResNet trunk without avgpool/fc; returns layer2/3/4 outputs (backbone.py:139-263)."
+
+    def __init__(self, block: Type[Union[BasicBlock, Bottleneck]], layers: List[int], zero_init_residual: bool = False):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, Bottleneck):
+                    nn.init.constant_(m.bn3.weight, 0)
+                elif isinstance(m, BasicBlock):
+                    nn.init.constant_(m.bn2.weight, 0)
+
+    def _make_layer(self, block, planes: int, blocks: int, stride: int = 1) -> nn.Sequential:
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(_conv1x1(self.inplanes, planes * block.expansion, stride),
+                                       nn.BatchNorm2d(planes * block.expansion))
+        stack = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        stack += [block(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*stack)
+
+    def _forward_impl(self, x: Tensor) -> Dict[str, Tensor]:
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer1(x)
+        c3 = self.layer2(x)
+        c4 = self.layer3(c3)
+        c5 = self.layer4(c4)
+        return {"layer_2": c3, "layer_3": c4, "layer_4": c5}
+
+    def forward(self, x: Tensor) -> Dict[str, Tensor]:
+        return self._forward_impl(x)
+
+
+_SPECS = {
+    "resnet18": (BasicBlock, [2, 2, 2, 2]),
+    "resnet34": (BasicBlock, [3, 4, 6, 3]),
+    "resnet50": (Bottleneck, [3, 4, 6, 3]),
+    "resnet101": (Bottleneck, [3, 4, 23, 3]),
+    "resnet152": (Bottleneck, [3, 8, 36, 3]),
+}
+
+
+def _load_pretrained(model: nn.Module, arch: str, progress: bool) -> None:
+    """ImageNet weights (backbone.py:269-274).  Uses ``torch.hub`` (the reference's
+    ``torchvision.models.utils`` loader no longer exists); a local file named by
+    ``RETINANET_PRETRAINED_DIR/<basename>`` is preferred so air-gapped nodes work."""
+    url = model_urls[arch]
+    local_dir = os.environ.get("RETINANET_PRETRAINED_DIR")
+    if local_dir and os.path.exists(os.path.join(local_dir, os.path.basename(url))):
+        state = torch.load(os.path.join(local_dir, os.path.basename(url)), map_location="cpu")
+    else:
+        state = torch.hub.load_state_dict_from_url(url, progress=progress)
+    model.load_state_dict(state, strict=False)
+
+
+def _resnet(arch: str, pretrained: bool, progress: bool, **kwargs) -> ResNetBackbone:
+    block, layers = _SPECS[arch]
+    model = ResNetBackbone(block, layers, **kwargs)
+    if pretrained:
+        _load_pretrained(model, arch, progress)
+    return model
+
+
+def resnet18(pretrained: bool = False, progress: bool = True, **kw): return _resnet("resnet18", pretrained, progress, **kw)
+def resnet34(pretrained: bool = False, progress: bool = True, **kw): return _resnet("resnet34", pretrained, progress, **kw)
+def resnet50(pretrained: bool = False, progress: bool = True, **kw): return _resnet("resnet50", pretrained, progress, **kw)
+def resnet101(pretrained: bool = False, progress: bool = True, **kw): return _resnet("resnet101", pretrained, progress, **kw)
+def resnet152(pretrained: bool = False, progress: bool = True, **kw): return _resnet("resnet152", pretrained, progress, **kw)
+
+
+loaders = {"resnet18": resnet18, "resnet34": resnet34, "resnet50": resnet50, "resnet101": resnet101, "resnet152": resnet152}
+
+
+class BackBone(nn.Module):
+    """``BackBone(kind, pretrained, freeze_bn)`` -> [C3, C4, C5] (backbone.py:340-360).
+
+    ``freeze_bn`` only puts the BN layers in eval mode at construction, exactly like
+    the reference: a later ``.train()`` un-freezes them."""
+
+    def __init__(self, kind: str = "resnet18", pretrained: bool = True, freeze_bn: bool = True, **kwargs):
+        super().__init__()
+        self.backbone = loaders[kind](pretrained=pretrained, **kwargs)
+        if freeze_bn:
+            for layer in self.modules():
+                if isinstance(layer, nn.BatchNorm2d):
+                    layer.eval()
+
+    def forward(self, xb: Tensor) -> List[Tensor]:
+        out = self.backbone(xb)
+        return [out["layer_2"], out["layer_3"], out["layer_4"]]
+
+
+def get_backbone(kind: str = "resnet50", pretrained: bool = True, freeze_bn: bool = True) -> nn.Module:
+    if kind not in __all__:
+        raise ValueError(f"`kind` must be one of {__all__} got {kind}")
+    return BackBone(kind=kind, pretrained=pretrained, freeze_bn=freeze_bn)

@@ -1,0 +1,283 @@
+// K6 segmented sort + greedy NMS -- replaces torchvision.ops.nms as the reference
+// calls it once per (image, class) at retinanet/models.py:210.  One workgroup per
+// segment, all B*K segments in flight at once (the reference issues them one by
+// one, each with host syncs).
+//
+// Semantics (bit-exact keep indices given identical boxes/scores): stable sort by
+// score descending (ties: lower input index first), greedy scan, box j dropped when
+//   inter / ((area_i + area_j) - inter) > thr,  w = max(0, xx2 - xx1), h likewise,
+// fp32, IEEE divide, no FMA contraction (file compiled with -ffp-contract=off).
+//
+// Layout: a segment's 64-bit keys (inverted ordered score << 32 | payload) are
+// sorted in LDS with a bitonic network (keys are unique, so "stable" = key order),
+// boxes are gathered once into LDS, and the suppression flags live in LDS; the
+// greedy loop costs one workgroup barrier per KEPT box.  Segments longer than
+// 2048 entries fall back to an LDS-chunk sort + in-HBM merge passes and HBM-resident
+// boxes/flags (correct for any length; slower).
+#include "rn_internal.hpp"
+
+namespace {
+
+using rn::f32x4;
+
+constexpr int SMALL_CAP = 512;     // one wave per segment, 14.5 KiB LDS -> many segments per CU
+constexpr int MED_CAP = 2048;      // 256 threads, 58 KiB LDS
+constexpr int BIG_THREADS = 1024;
+
+__device__ __forceinline__ bool overlaps(const f32x4 bi, const float ai, const f32x4 bj, const float aj, const float thr)
+{
+    const float xx1 = bi.x > bj.x ? bi.x : bj.x;
+    const float yy1 = bi.y > bj.y ? bi.y : bj.y;
+    const float xx2 = bi.z < bj.z ? bi.z : bj.z;
+    const float yy2 = bi.w < bj.w ? bi.w : bj.w;
+    float w = xx2 - xx1; w = w > 0.0f ? w : 0.0f;
+    float h = yy2 - yy1; h = h > 0.0f ? h : 0.0f;
+    const float inter = w * h;
+    const float ovr = inter / ((ai + aj) - inter);
+    return ovr > thr;
+}
+
+template <int THREADS>
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t *keys, const int n_pad)
+{
+    for (int k = 2; k <= n_pad; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n_pad; i += THREADS) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const uint64_t x = keys[i], y = keys[p];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { keys[i] = y; keys[p] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// Exclusive scan of per-thread counts through LDS; returns this thread's offset and the total.
+template <int THREADS>
+__device__ __forceinline__ int block_excl_scan(int *s_scan, const int mine, int &total)
+{
+    s_scan[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int t = 0; t < THREADS; ++t) { const int c = s_scan[t]; s_scan[t] = run; run += c; }
+        s_scan[THREADS] = run;
+    }
+    __syncthreads();
+    total = s_scan[THREADS];
+    return s_scan[threadIdx.x];
+}
+
+template <int THREADS, int CAP>
+__global__ __launch_bounds__(THREADS) void nms_lds_kernel(const rn::NmsLaunch a, const int min_len, const int max_len)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f32x4 *s_box = (f32x4 *)smem;
+    uint64_t *s_key = (uint64_t *)(smem + (size_t)CAP * 16);
+    float *s_area = (float *)(smem + (size_t)CAP * 24);
+    uint8_t *s_supp = smem + (size_t)CAP * 28;
+    int *s_scan = (int *)(smem + (size_t)CAP * 29);        // CAP % 4 == 0
+
+    const int s = blockIdx.x;
+    const int n = a.seg_len[s];
+    if (n < min_len || n > max_len) return;
+    if (n == 0) {
+        if (threadIdx.x == 0) a.kept_count[s] = 0;
+        return;
+    }
+    const int64_t start = a.seg_start[s];
+    const int64_t box_base = a.box_mode ? (int64_t)(s / a.K) * a.A : start;
+
+    int n_pad = 1;
+    while (n_pad < n) n_pad <<= 1;
+    for (int i = threadIdx.x; i < n_pad; i += THREADS) s_key[i] = (i < n) ? a.keys[start + i] : ~0ull;
+    __syncthreads();
+    bitonic_sort_lds<THREADS>(s_key, n_pad);
+
+    for (int i = threadIdx.x; i < n; i += THREADS) {
+        const f32x4 b = a.boxes[box_base + (uint32_t)s_key[i]];
+        s_box[i] = b;
+        s_area[i] = (b.z - b.x) * (b.w - b.y);
+        s_supp[i] = 0;
+    }
+    __syncthreads();
+
+    for (int i = 0; i < n; ++i) {
+        if (s_supp[i]) continue;                       // same value in every thread: no writes since the last barrier
+        const f32x4 bi = s_box[i];
+        const float ai = s_area[i];
+        for (int j = i + 1 + threadIdx.x; j < n; j += THREADS)
+            if (!s_supp[j] && overlaps(bi, ai, s_box[j], s_area[j], a.iou_thr)) s_supp[j] = 1;
+        __syncthreads();
+    }
+
+    const int per = (n + THREADS - 1) / THREADS;
+    const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+    int cnt = 0;
+    for (int i = lo; i < hi; ++i) cnt += s_supp[i] ? 0 : 1;
+    int total;
+    int off = block_excl_scan<THREADS>(s_scan, cnt, total);
+    for (int i = lo; i < hi; ++i) {
+        if (!s_supp[i]) {
+            a.kept[start + off] = s_key[i];
+            if (a.keep_idx) a.keep_idx[start + off] = (int64_t)(uint32_t)s_key[i];
+            ++off;
+        }
+    }
+    if (threadIdx.x == 0) a.kept_count[s] = total;
+}
+
+// Segments longer than MED_CAP: chunk sort in LDS, merge passes and NMS state in HBM.
+__global__ __launch_bounds__(BIG_THREADS) void nms_big_kernel(const rn::NmsLaunch a)
+{
+    __shared__ uint64_t s_key[MED_CAP];
+    __shared__ int s_scan[BIG_THREADS + 1];
+
+    const int s = blockIdx.x;
+    const int n = a.seg_len[s];
+    if (n <= MED_CAP) return;
+    const int64_t start = a.seg_start[s];
+    const int64_t box_base = a.box_mode ? (int64_t)(s / a.K) * a.A : start;
+    uint64_t *buf0 = a.keys + start, *buf1 = a.kept + start;
+
+    // phase 1: sort each MED_CAP chunk in LDS
+    for (int c0 = 0; c0 < n; c0 += MED_CAP) {
+        const int m = min(MED_CAP, n - c0);
+        int m_pad = 1;
+        while (m_pad < m) m_pad <<= 1;
+        for (int i = threadIdx.x; i < m_pad; i += BIG_THREADS) s_key[i] = (i < m) ? buf0[c0 + i] : ~0ull;
+        __syncthreads();
+        bitonic_sort_lds<BIG_THREADS>(s_key, m_pad);
+        for (int i = threadIdx.x; i < m; i += BIG_THREADS) buf0[c0 + i] = s_key[i];
+        __syncthreads();
+    }
+    // phase 2: pairwise merges, each element finds its rank in the sibling run (keys are unique)
+    uint64_t *src = buf0, *dst = buf1;
+    for (int64_t w = MED_CAP; w < n; w <<= 1) {
+        for (int i = threadIdx.x; i < n; i += BIG_THREADS) {
+            const int64_t pair0 = ((int64_t)i / (2 * w)) * (2 * w);
+            const int64_t mid = min(pair0 + w, (int64_t)n), end = min(pair0 + 2 * w, (int64_t)n);
+            const uint64_t key = src[i];
+            int64_t lo, hi;
+            if (i < mid) { lo = mid; hi = end; } else { lo = pair0; hi = mid; }
+            const int64_t sib0 = lo;
+            while (lo < hi) {                          // count sibling keys < key
+                const int64_t md = (lo + hi) >> 1;
+                if (src[md] < key) lo = md + 1; else hi = md;
+            }
+            const int64_t rank_sib = lo - sib0;
+            const int64_t rank_own = (i < mid) ? (i - pair0) : (i - mid);
+            dst[pair0 + rank_own + rank_sib] = key;
+        }
+        __syncthreads();
+        uint64_t *t = src; src = dst; dst = t;
+    }
+    if (src != buf0) {                                   // sorted keys must end in a.keys, survivors go to a.kept
+        for (int i = threadIdx.x; i < n; i += BIG_THREADS) buf0[i] = src[i];
+        __syncthreads();
+    }
+
+    f32x4 *g_box = a.scratch_boxes + start;
+    uint8_t *g_supp = a.scratch_supp + start;
+    for (int i = threadIdx.x; i < n; i += BIG_THREADS) {
+        g_box[i] = a.boxes[box_base + (uint32_t)buf0[i]];
+        g_supp[i] = 0;
+    }
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+        if (g_supp[i]) continue;
+        const f32x4 bi = g_box[i];
+        const float ai = (bi.z - bi.x) * (bi.w - bi.y);
+        for (int j = i + 1 + threadIdx.x; j < n; j += BIG_THREADS) {
+            if (g_supp[j]) continue;
+            const f32x4 bj = g_box[j];
+            if (overlaps(bi, ai, bj, (bj.z - bj.x) * (bj.w - bj.y), a.iou_thr)) g_supp[j] = 1;
+        }
+        __syncthreads();
+    }
+    const int per = (n + BIG_THREADS - 1) / BIG_THREADS;
+    const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+    int cnt = 0;
+    for (int i = lo; i < hi; ++i) cnt += g_supp[i] ? 0 : 1;
+    int total;
+    int off = block_excl_scan<BIG_THREADS>(s_scan, cnt, total);
+    for (int i = lo; i < hi; ++i) {
+        if (!g_supp[i]) {
+            buf1[off] = buf0[i];
+            if (a.keep_idx) a.keep_idx[start + off] = (int64_t)(uint32_t)buf0[i];
+            ++off;
+        }
+    }
+    if (threadIdx.x == 0) a.kept_count[s] = total;
+}
+
+// op-boundary helpers: build keys from (scores, seg_off)
+__global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__ scores, const int32_t *__restrict__ seg_off,
+                                                       const int S, const int64_t N, uint64_t *__restrict__ keys,
+                                                       int64_t *__restrict__ seg_start, int32_t *__restrict__ seg_len)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < S) { seg_start[i] = seg_off[i]; seg_len[i] = seg_off[i + 1] - seg_off[i]; }
+    if (i < N) {
+        int lo = 0, hi = S;                       // segment of element i: last s with seg_off[s] <= i
+        while (hi - lo > 1) { const int md = (lo + hi) >> 1; if (seg_off[md] <= i) lo = md; else hi = md; }
+        keys[i] = ((uint64_t)rn::inv_ordered(scores[i]) << 32) | (uint32_t)(i - seg_off[lo]);
+    }
+}
+
+size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+int rn::launch_nms(const rn::NmsLaunch &a, hipStream_t st)
+{
+    if (a.S <= 0) return RN_OK;
+    const size_t lds_small = (size_t)SMALL_CAP * 29 + sizeof(int) * (64 + 1);
+    const size_t lds_med = (size_t)MED_CAP * 29 + sizeof(int) * (256 + 1);
+    hipLaunchKernelGGL((nms_lds_kernel<64, SMALL_CAP>), dim3((unsigned)a.S), dim3(64), lds_small, st, a, 0, SMALL_CAP);
+    RN_LAUNCH_CHECK();
+    hipLaunchKernelGGL((nms_lds_kernel<256, MED_CAP>), dim3((unsigned)a.S), dim3(256), lds_med, st, a, SMALL_CAP + 1, MED_CAP);
+    RN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nms_big_kernel, dim3((unsigned)a.S), dim3(BIG_THREADS), 0, st, a);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+// workspace (op mode): keys u64[N] | kept u64[N] | seg_start i64[S] | seg_len i32[S] | scratch boxes f32x4[N] | supp u8[N]
+RN_API size_t rn_nms_workspace_bytes(int64_t N, int S)
+{
+    if (N < 0 || S < 0) return 0;
+    return al256((size_t)N * 8) * 2 + al256((size_t)S * 8) + al256((size_t)S * 4) + al256((size_t)N * 16) + al256((size_t)N) + 256;
+}
+
+RN_API int rn_nms_segments(const float *boxes, const float *scores, const int32_t *seg_off, int S, int64_t N,
+                           float iou_thr, int64_t *keep, int32_t *keep_count, void *workspace, size_t workspace_bytes,
+                           void *stream)
+{
+    if (!seg_off || !keep_count || S <= 0 || N < 0) return RN_EINVAL;
+    if (N > 0 && (!boxes || !scores || !keep)) return RN_EINVAL;
+    if (N >= ((int64_t)1 << 31)) return RN_EUNSUPPORTED;
+    if (!workspace || workspace_bytes < rn_nms_workspace_bytes(N, S)) return RN_EWORKSPACE;
+    if ((boxes && !rn::aligned(boxes, 16)) || !rn::aligned(workspace, 16)) return RN_EALIGN;
+    unsigned char *w = (unsigned char *)workspace;
+    rn::NmsLaunch a;
+    a.keys = (uint64_t *)w; w += al256((size_t)N * 8);
+    a.kept = (uint64_t *)w; w += al256((size_t)N * 8);
+    int64_t *seg_start = (int64_t *)w; w += al256((size_t)S * 8);
+    int32_t *seg_len = (int32_t *)w; w += al256((size_t)S * 4);
+    a.scratch_boxes = (rn::f32x4 *)w; w += al256((size_t)N * 16);
+    a.scratch_supp = (uint8_t *)w;
+    a.keep_idx = keep;
+    a.boxes = (const rn::f32x4 *)boxes;
+    a.seg_start = seg_start; a.seg_len = seg_len; a.kept_count = keep_count;
+    a.S = S; a.box_mode = 0; a.K = 1; a.A = 0; a.iou_thr = iou_thr;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t work = N > S ? N : S;
+    hipLaunchKernelGGL(nms_prep_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, scores, seg_off, S, N,
+                       a.keys, seg_start, seg_len);
+    RN_LAUNCH_CHECK();
+    return rn::launch_nms(a, st);
+}

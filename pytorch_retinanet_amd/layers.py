@@ -1,0 +1,123 @@
+"""FPN and the RetinaNet head (reference ``retinanet/layers.py:12-260``).
+
+Parameter names, shapes and initialisation match the reference so its
+checkpoints load unchanged (``fpn.conv_c{3,4,5}_{1x1,3x3}``,
+``fpn.conv_c6_3x3``, ``fpn.conv_c7_3x3``, ``retinanet_head.*_head.*_subnet.{0,2,4,6}``,
+``*_subnet_output``).  The convolutions run on PyTorch-ROCm (MIOpen); what is
+MI355X-specific here is the output layout: with ``channels_last`` activations the
+conv result ``[N, A*K, H, W]`` is *already* ``[N, H, W, A, K]`` in memory, so the
+reference's ``view -> permute -> contiguous`` (layers.py:189-191, :253-255) is a
+zero-copy reshape and the loss / detection kernels stream it directly.
+"""
+import math
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from .losses import RetinaNetLosses
+
+
+class FeaturePyramid(nn.Module):
+    """P3-P7 from C3-C5 (layers.py:12-64): lateral 1x1 + top-down nearest 2x +
+    3x3 smoothing; P6 = 3x3/s2 on **C5**; P7 = 3x3/s2 on relu(P6)."""
+
+    def __init__(self, C_3_size: int, C_4_size: int, C_5_size: int, out_channels: int = 256) -> None:
+        super().__init__()
+        self.conv_c3_1x1 = nn.Conv2d(C_3_size, out_channels, 1, 1, padding=0)
+        self.conv_c3_3x3 = nn.Conv2d(out_channels, out_channels, 3, 1, padding=1)
+        self.conv_c4_1x1 = nn.Conv2d(C_4_size, out_channels, 1, 1, padding=0)
+        self.conv_c4_3x3 = nn.Conv2d(out_channels, out_channels, 3, 1, padding=1)
+        self.conv_c5_1x1 = nn.Conv2d(C_5_size, out_channels, 1, 1, padding=0)
+        self.conv_c5_3x3 = nn.Conv2d(out_channels, out_channels, 3, 1, padding=1)
+        self.conv_c6_3x3 = nn.Conv2d(C_5_size, out_channels, 3, stride=2, padding=1)
+        self.conv_c7_3x3 = nn.Conv2d(out_channels, out_channels, 3, stride=2, padding=1)
+        self.upsample_2x = nn.Upsample(scale_factor=2, mode="nearest")
+        for m in self.children():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, a=1)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, inps: List[Tensor]) -> List[Tensor]:
+        c3, c4, c5 = inps
+        p5 = self.conv_c5_1x1(c5)
+        p4 = self.conv_c4_1x1(c4) + self.upsample_2x(p5)
+        p3 = self.conv_c3_1x1(c3) + self.upsample_2x(p4)
+        p6 = self.conv_c6_3x3(c5)
+        p7 = self.conv_c7_3x3(F.relu(p6))
+        return [self.conv_c3_3x3(p3), self.conv_c4_3x3(p4), self.conv_c5_3x3(p5), p6, p7]
+
+
+def _tower(in_channels: int, out_channels: int) -> nn.Sequential:
+    "4 x [3x3 conv + ReLU]; module indices 0,2,4,6 hold the convs like the reference."
+    mods = []
+    for i in range(4):
+        mods += [nn.Conv2d(in_channels if i == 0 else out_channels, out_channels, 3, stride=1, padding=1),
+                 nn.ReLU(inplace=True)]
+    return nn.Sequential(*mods)
+
+
+def _init_head(*modules: nn.Module) -> None:
+    for mod in modules:
+        for layer in mod.modules():
+            if isinstance(layer, nn.Conv2d):
+                nn.init.normal_(layer.weight, mean=0, std=0.01)
+                nn.init.constant_(layer.bias, 0)
+
+
+def _to_anchor_major(x: Tensor, last: int) -> Tensor:
+    """[N, A*last, H, W] -> [N, H*W*A, last], anchor index (h*W + w)*A + a
+    (layers.py:189-191).  Zero-copy when `x` is channels_last."""
+    n = x.shape[0]
+    return x.permute(0, 2, 3, 1).reshape(n, -1, last)
+
+
+class RetinaNetClassSubnet(nn.Module):
+    """Classification tower -> ``[N, sum(H*W*A), num_classes]`` logits (layers.py:118-196)."""
+
+    def __init__(self, in_channels: int, out_channels: int, num_anchors: int, num_classes: int, prior: float) -> None:
+        super().__init__()
+        self.num_classes = num_classes
+        self.num_anchors = num_anchors
+        self.class_subnet = _tower(in_channels, out_channels)
+        self.class_subnet_output = nn.Conv2d(out_channels, num_anchors * num_classes, 3, stride=1, padding=1)
+        _init_head(self.class_subnet, self.class_subnet_output)
+        # prior-probability bias (layers.py:175-178)
+        nn.init.constant_(self.class_subnet_output.bias, -math.log((1 - prior) / prior))
+
+    def forward(self, feature_maps: List[Tensor]) -> Tensor:
+        outs = [_to_anchor_major(self.class_subnet_output(self.class_subnet(f)), self.num_classes) for f in feature_maps]
+        return torch.cat(outs, dim=1)
+
+
+class RetinaNetBoxSubnet(nn.Module):
+    """Box tower -> ``[N, sum(H*W*A), 4]`` deltas (layers.py:199-260)."""
+
+    def __init__(self, in_channels: int, out_channels: int, num_anchors: int) -> None:
+        super().__init__()
+        self.num_anchors = num_anchors
+        self.box_subnet = _tower(in_channels, out_channels)
+        self.box_subnet_output = nn.Conv2d(out_channels, num_anchors * 4, 3, padding=1, stride=1)
+        _init_head(self.box_subnet, self.box_subnet_output)
+
+    def forward(self, feature_maps: List[Tensor]) -> Tensor:
+        outs = [_to_anchor_major(self.box_subnet_output(self.box_subnet(f)), 4) for f in feature_maps]
+        return torch.cat(outs, dim=1)
+
+
+class RetinaNetHead(nn.Module):
+    """Both subnets + the loss module (layers.py:67-115)."""
+
+    def __init__(self, in_channels: int, out_channels: int, num_anchors: int, num_classes: int, prior: float) -> None:
+        super().__init__()
+        self.classification_head = RetinaNetClassSubnet(in_channels, out_channels, num_anchors, num_classes, prior)
+        self.regression_head = RetinaNetBoxSubnet(in_channels, out_channels, num_anchors)
+        self.losses = RetinaNetLosses(num_classes)
+
+    def compute_loss(self, targets: List[Dict[str, Tensor]], outputs: Dict[str, Tensor],
+                     anchors: List[Tensor]) -> Dict[str, Tensor]:
+        return self.losses(targets, outputs, anchors)
+
+    def forward(self, xb: List[Tensor]) -> Dict[str, Tensor]:
+        return {"cls_preds": self.classification_head(xb), "bbox_preds": self.regression_head(xb)}

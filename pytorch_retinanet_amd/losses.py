@@ -1,0 +1,115 @@
+"""``RetinaNetLosses`` with the reference's surface (``retinanet/losses.py:11-145``).
+
+``forward`` / ``calc_loss`` run as two HIP launches for the whole batch -- K2
+``rn_iou_match`` and K3 ``rn_loss_fwd_bwd`` -- instead of the reference's per-image
+Python loop of ~40 torch ops with 4 host syncs each (losses.py:126, :66-97).  K3
+writes the gradients in the same pass that computes the loss values, so
+``backward`` only has to apply the upstream scalar (a device-side no-op when it
+is 1, the ``loss.backward()`` case).
+"""
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from . import ops
+from .config import (BBOX_REG_WEIGHTS, ENCODE_LOG_EPS, FOCAL_LOSS_ALPHA, FOCAL_LOSS_GAMMA,
+                     IOU_THRESHOLDS_BACKGROUND, IOU_THRESHOLDS_FOREGROUND, LOGIT_SHIFT, SMOOTH_L1_LOSS_BETA)
+
+
+class _FusedDenseHeadLoss(torch.autograd.Function):
+    """(cls [B,A,K], box [B,A,4]) -> f32[2] = (classification_loss, regression_loss)."""
+
+    @staticmethod
+    def forward(ctx, cls, box, anchors, gt_boxes, gt_labels, gt_off, params, fg_thr, bg_thr):
+        B = cls.shape[0]
+        matches, num_fg = ops.iou_match(anchors, gt_boxes, gt_off, B, fg_thr, bg_thr)
+        want_grad = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        loss, gcls, gbox = ops.loss_fwd_bwd(cls, box, anchors, gt_boxes, gt_labels, gt_off, matches, num_fg,
+                                            params, want_grad)
+        ctx.gcls, ctx.gbox = gcls, gbox
+        ctx.box_dtype, ctx.cls_shape, ctx.box_shape = box.dtype, cls.shape, box.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.gcls is None:
+            raise RuntimeError("fused RetinaNet loss: backward called twice (or without gradients recorded); "
+                               "re-run the forward pass instead of retain_graph=True")
+        gcls, gbox = ctx.gcls, ctx.gbox
+        ctx.gcls = ctx.gbox = None
+        g = g.to(torch.float32)
+        ops.scale_inplace(gcls, g[0:1])
+        ops.scale_inplace(gbox, g[1:2])
+        if gbox.dtype != ctx.box_dtype:
+            gbox = gbox.to(ctx.box_dtype)
+        return gcls.view(ctx.cls_shape), gbox.view(ctx.box_shape), None, None, None, None, None, None, None
+
+
+def _stack_anchors(anchors) -> Tensor:
+    """List of per-image [A,4] tensors -> one shared [A,4] (the usual case: the
+    generator hands out the same cached tensor per image) or a stacked [B,A,4]."""
+    if isinstance(anchors, Tensor):
+        return anchors
+    first = anchors[0]
+    if all(a is first or a.data_ptr() == first.data_ptr() for a in anchors):
+        return first
+    return torch.stack(list(anchors))
+
+
+class RetinaNetLosses(nn.Module):
+    def __init__(self, num_classes: int) -> None:
+        super().__init__()
+        self.n_c = num_classes
+        self.alpha = FOCAL_LOSS_ALPHA
+        self.gamma = FOCAL_LOSS_GAMMA
+        self.beta = SMOOTH_L1_LOSS_BETA
+
+    # -- stand-alone helpers (surface parity; the fused kernel does not call them) ----
+    def smooth_l1_loss(self, input: Tensor, target: Tensor) -> Tensor:
+        "Summed smooth-L1 with threshold `beta` (losses.py:19-27)."
+        n = torch.abs(input - target)
+        if self.beta < 1e-5:
+            return n.sum()
+        return torch.where(n < self.beta, 0.5 * n ** 2 / self.beta, n - 0.5 * self.beta).sum()
+
+    def focal_loss(self, clas_pred: Tensor, clas_tgt: Tensor) -> Tensor:
+        """Summed focal loss of logits vs {0,1} targets exactly as the reference
+        defines it (losses.py:29-47): constant (detached) modulating weight, and
+        alpha applied to the NEGATIVES' complement (positives get 1 - alpha)."""
+        p = torch.sigmoid(clas_pred.detach())
+        w = clas_tgt * (1 - p) + (1 - clas_tgt) * p
+        a = (1 - clas_tgt) * self.alpha + clas_tgt * (1 - self.alpha)
+        w = w.pow(self.gamma).mul(a)
+        return F.binary_cross_entropy_with_logits(clas_pred, clas_tgt, w, reduction="sum")
+
+    # -- fused path ----------------------------------------------------------------------
+    def _params(self):
+        return ops.make_loss_params(self.alpha, self.gamma, self.beta, LOGIT_SHIFT, ENCODE_LOG_EPS, BBOX_REG_WEIGHTS)
+
+    def _fused(self, cls: Tensor, box: Tensor, anchors, boxes: Sequence[Tensor], labels: Sequence[Tensor]) -> Tensor:
+        dev = cls.device
+        counts = [int(b.reshape(-1, 4).shape[0]) for b in boxes]
+        gt_boxes = torch.cat([b.reshape(-1, 4).to(device=dev, dtype=torch.float32) for b in boxes]) \
+            if counts else torch.zeros((0, 4), device=dev)
+        gt_labels = torch.cat([l.reshape(-1).to(device=dev, dtype=torch.int64) for l in labels]) \
+            if counts else torch.zeros((0,), dtype=torch.int64, device=dev)
+        gt_off = ops.gt_offsets(counts, dev)
+        return _FusedDenseHeadLoss.apply(cls, box, _stack_anchors(anchors), gt_boxes, gt_labels, gt_off,
+                                         self._params(), IOU_THRESHOLDS_FOREGROUND, IOU_THRESHOLDS_BACKGROUND)
+
+    def calc_loss(self, anchors: Tensor, clas_pred: Tensor, bbox_pred: Tensor, clas_tgt: Tensor,
+                  bbox_tgt: Tensor) -> Tuple[Tensor, Tensor]:
+        "One image: returns (bb_loss, clas_loss), each already / clamp(num_fg, 1) (losses.py:49-111)."
+        out = self._fused(clas_pred[None], bbox_pred[None], anchors, [bbox_tgt], [clas_tgt])
+        return out[1], out[0]
+
+    def forward(self, targets: List[Dict[str, Tensor]], head_outputs: Dict[str, Tensor],
+                anchors: List[Tensor]) -> Dict[str, Tensor]:
+        "Batch means of the per-image normalised losses (losses.py:113-145)."
+        clas_preds, bbox_preds = head_outputs["cls_preds"], head_outputs["bbox_preds"]
+        if len(targets) != clas_preds.shape[0]:
+            raise ValueError(f"{len(targets)} targets for a batch of {clas_preds.shape[0]}")
+        out = self._fused(clas_preds, bbox_preds, anchors, [t["boxes"] for t in targets], [t["labels"] for t in targets])
+        return {"classification_loss": out[0], "regression_loss": out[1]}

@@ -87,7 +87,11 @@ def gt_offsets(counts: Sequence[int], device: torch.device) -> Tensor:
     off = [0]
     for c in counts:
         off.append(off[-1] + int(c))
-    return torch.tensor(off, dtype=torch.int32, device=device)
+    host = torch.tensor(off, dtype=torch.int32)
+    if torch.device(device).type != "cuda":
+        raise RuntimeError("pytorch_retinanet_amd: gt offsets are a device array (there is no CPU fallback)")
+    # pinned + non_blocking: the copy is stream-ordered and does not drain the launch queue
+    return host.pin_memory().to(device, non_blocking=True)
 
 
 def iou_match(anchors: Tensor, gt_boxes: Tensor, gt_off: Tensor, B: int, fg_thr: float, bg_thr: float,
@@ -152,7 +156,8 @@ def scale_inplace(t: Tensor, scale: Tensor) -> Tensor:
 
 
 def image_hw_tensor(sizes: Sequence[Tuple[int, int]], device: torch.device) -> Tensor:
-    return torch.tensor([[int(h), int(w)] for h, w in sizes], dtype=torch.int32, device=device)
+    host = torch.tensor([[int(h), int(w)] for h, w in sizes], dtype=torch.int32)
+    return host.pin_memory().to(device, non_blocking=True)
 
 
 def decode_clip(deltas: Tensor, anchors: Tensor, image_hw: Optional[Tensor],
@@ -169,3 +174,74 @@ def decode_clip(deltas: Tensor, anchors: Tensor, image_hw: Optional[Tensor],
         check(lib.rn_decode_clip(_ptr(d), _dtype_code(d), B, A, _ptr(anchors), bstride, _ptr(image_hw), rw,
                                  _ptr(out), _stream(dev)), "rn_decode_clip")
     return out[0] if squeeze else out
+
+
+def nms_segments(boxes: Tensor, scores: Tensor, seg_off: Tensor, iou_thr: float) -> Tuple[Tensor, Tensor]:
+    """K6 at the op boundary (torchvision.ops.nms batched over segments).
+    boxes f32 [N,4], scores f32 [N], seg_off i32 [S+1] (device).
+    -> (keep i64 [N] (per segment: indices relative to the segment start, score order), keep_count i32 [S])."""
+    dev = _need_dev(boxes, scores, seg_off)
+    boxes = _c(boxes.float()).reshape(-1, 4)
+    scores = _c(scores.float()).reshape(-1)
+    N, S = boxes.shape[0], seg_off.numel() - 1
+    keep = torch.empty((max(N, 1),), dtype=torch.int64, device=dev)
+    count = torch.empty((S,), dtype=torch.int32, device=dev)
+    ws_bytes = lib.rn_nms_workspace_bytes(N, S)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.rn_nms_segments(_ptr(boxes), _ptr(scores), _ptr(seg_off), S, N, iou_thr, _ptr(keep), _ptr(count),
+                                  _ptr(ws), ws_bytes, _stream(dev)), "rn_nms_segments")
+    return keep[:N], count
+
+
+def nms(boxes: Tensor, scores: Tensor, iou_threshold: float) -> Tensor:
+    """Drop-in for ``torchvision.ops.nms(boxes, scores, iou_threshold) -> int64[k]`` (one segment).
+    Reading the kept count is the one host sync, exactly as in the op it replaces."""
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    off = torch.tensor([0, n], dtype=torch.int32, device=boxes.device)
+    keep, count = nms_segments(boxes, scores, off, iou_threshold)
+    return keep[: int(count.item())]
+
+
+def detect(cls: Tensor, deltas: Tensor, anchors, image_sizes: Sequence[Tuple[int, int]], score_thr: float,
+           min_box: float, nms_thr: float, max_det: int, reg_w: Sequence[float] = (1.0, 1.0, 1.0, 1.0),
+           max_candidates: Optional[int] = None) -> List[dict]:
+    """K4-K7 for a batch: -> [{"boxes" f32[n,4], "scores" f32[n], "labels" i64[n]}], n <= max_det.
+
+    One host sync at the end (the ragged result sizes have to reach Python, as in the
+    reference's list-of-dicts contract).  If an image has more candidates than the workspace
+    was sized for, the call is repeated once with the exact worst case (A*K)."""
+    dev = _need_dev(cls, deltas)
+    if cls.dim() != 3 or deltas.dim() != 3 or cls.shape[:2] != deltas.shape[:2] or deltas.shape[-1] != 4:
+        raise ValueError(f"bad head output shapes {tuple(cls.shape)} / {tuple(deltas.shape)}")
+    if deltas.dtype != cls.dtype:
+        deltas = deltas.to(cls.dtype)
+    B, A, K = cls.shape
+    cls, deltas = _c(cls), _c(deltas)
+    if not isinstance(anchors, Tensor):
+        first = anchors[0]
+        anchors = first if all(a is first or a.data_ptr() == first.data_ptr() for a in anchors) else torch.stack(list(anchors))
+    anchors, bstride = _anchor_args(anchors.to(dev), B, A)
+    hw = image_hw_tensor(image_sizes, dev)
+    params = RnDetectParams(score_thr, min_box, nms_thr, int(max_det), (C.c_float * 4)(*reg_w))
+    cap = int(max_candidates) if max_candidates else min(A * K, 1 << 18)
+    out_boxes = torch.empty((B, max_det, 4), dtype=torch.float32, device=dev)
+    out_scores = torch.empty((B, max_det), dtype=torch.float32, device=dev)
+    out_labels = torch.empty((B, max_det), dtype=torch.int64, device=dev)
+    meta = torch.empty((2, B), dtype=torch.int32, device=dev)          # [0] = count, [1] = status
+    while True:
+        ws_bytes = lib.rn_detect_workspace_bytes(B, A, K, cap)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            check(lib.rn_detect(_ptr(cls), _ptr(deltas), _dtype_code(cls), B, A, K, _ptr(anchors), bstride, _ptr(hw),
+                                C.byref(params), cap, _ptr(out_boxes), _ptr(out_scores), _ptr(out_labels),
+                                _ptr(meta[0]), _ptr(meta[1]), _ptr(ws), ws_bytes, _stream(dev)), "rn_detect")
+        meta_h = meta.cpu()                                              # the one sync
+        if not bool(meta_h[1].any()) or cap >= A * K:
+            break
+        cap = A * K
+    counts = meta_h[0].tolist()
+    return [{"boxes": out_boxes[b, :n], "scores": out_scores[b, :n], "labels": out_labels[b, :n]}
+            for b, n in enumerate(counts)]
