@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of a full RetinaNet-R50-FPN train step @800x1333 (BASELINE.json).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = transform -> ResNet50+FPN+heads forward (bf16 autocast, channels_last, MIOpen) ->
+K1 anchors / K2 iou_match / K3 fused loss+grad (hand-written HIP) -> backward -> bucketed RCCL
+all-reduce (N > 1) -> SGD step, on a per-GPU batch of 8 synthetic 3x800x1333 images resident in HBM.
+Weak scaling: per-GPU batch is fixed, `value` = all ranks' images / max-over-ranks wall time.
+
+The JSON line also carries
+  roofline     -- the dominant dense-head kernel (K3 loss fwd+bwd): algorithmic bytes per launch /
+                  its average duration measured with events on the launch stream inside the timed steps;
+  cpu_baseline -- the CPU oracle (oracle/rn_oracle.c, OpenMP) timed on this box's host cores on the
+                  same dense-head workload (rank 0, N=1 only; bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")          # bounded warm-up on a fresh box (no perf-db cache there)
+os.environ.setdefault("MIOPEN_LOG_LEVEL", "1")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE configs[1]: 8)")
+    ap.add_argument("--backbone", default="resnet50")
+    ap.add_argument("--gt", type=int, default=8, help="GT boxes per image")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-reps", type=int, default=3)
+    return ap.parse_args()
+
+
+def synth_batch(batch, gt, seed, device):
+    import synth
+    rng = np.random.default_rng(seed)
+    g = torch.Generator().manual_seed(seed)
+    images = [torch.rand(3, 800, 1333, generator=g).to(device) for _ in range(batch)]
+    targets = []
+    for _ in range(batch):
+        b, l = synth.gt_boxes(rng, gt, 800, 1333)
+        targets.append({"boxes": torch.from_numpy(b).to(device), "labels": torch.from_numpy(l).to(device)})
+    return images, targets
+
+
+def k3_bytes(B, A, K, T, s):
+    "Algorithmic bytes of one K3 launch (SURVEY 8d): logits r+w, box r+w, matches, GT rows."
+    return B * (2 * A * K * s + 2 * A * 4 * s + A * 8 + T * 24)
+
+
+def cpu_baseline(args, A, K):
+    """Dense-head path (K1 anchors + K2 match + K3 loss fwd+bwd) of ONE batch of `args.batch` images on the host."""
+    import oracle
+    import synth
+    oracle.build()
+    rng = np.random.default_rng(0)
+    B = args.batch
+    cls, box = synth.head_outputs(rng, B, A, K)
+    gtb, gtl = zip(*[synth.gt_boxes(rng, args.gt, 800, 1333) for _ in range(B)])
+    cells = [oracle.cell_anchors(s, synth.ANCHOR_RATIOS) for s in synth.ANCHOR_SIZES]
+    levels = synth.levels_for(800, 1344)
+    times = []
+    for _ in range(1 + args.cpu_baseline_reps):
+        t0 = time.perf_counter()
+        anc = oracle.anchors_emit(levels, cells, 0.0)
+        m, _ = oracle.iou_match(anc, list(gtb))
+        oracle.loss_fwd_bwd(cls, box, anc, list(gtb), list(gtl), m)
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times[1:]))
+    return {"value": round(B / t, 3), "unit": "images/sec (dense-head K1-K3 only, fp32)", "cores": oracle.num_threads(),
+            "kind": "port",
+            "sample": f"{args.cpu_baseline_reps} reps of one batch of {B} images: anchors + iou_match + loss fwd/bwd at "
+                      f"A={A}, K={K}, T={args.gt} (oracle/rn_oracle.c, OpenMP); conv stack NOT included",
+            "ms_per_batch": round(t * 1e3, 2)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the dense-head path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    if args.gpus != world and rank == 0:
+        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
+
+    import pytorch_retinanet_amd as P
+    from pytorch_retinanet_amd import ops
+
+    torch.manual_seed(0)
+    net = P.Retinanet(num_classes=90, backbone_kind=args.backbone, pretrained=False, min_size=800, max_size=1333)
+    net = net.to(device).to(memory_format=torch.channels_last).train()
+    optimizer = torch.optim.SGD(net.parameters(), lr=1e-3, weight_decay=1e-3, momentum=0.9)   # hparams.yaml:63-68
+    ddp = P.BucketedGradAllReduce(net) if world > 1 else None
+    images, targets = synth_batch(args.batch, args.gt, seed=rank, device=device)
+
+    def step():
+        if ddp:
+            ddp.zero_grad()
+        else:
+            optimizer.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            losses = net(images, targets)
+            loss = losses["classification_loss"] + losses["regression_loss"]
+        loss.backward()
+        if ddp:
+            ddp.finish()
+        optimizer.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ops.enable_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ev = ops.timing_events() or {}
+    ops.enable_timing(False)
+    final_loss = float(loss)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        A = sum(h * w * 9 for h, w in [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)])
+        K, s = 90, 2
+        kms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items() if v}
+        nbytes = k3_bytes(args.batch, A, K, args.gt, s)
+        k3_ms = kms.get("loss_fwd_bwd")
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_k3_pmc.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:          # noqa: BLE001
+                traffic = None
+        roof = {"bound": "hbm", "kernel": "loss_fwd_bwd_kernel<bf16> (K3, rn_loss_fwd_bwd incl. 1-block finalize)",
+                "achieved": round(nbytes / (k3_ms * 1e-3) / 1e9, 1) if k3_ms else None, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(nbytes / (k3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k3_ms else None,
+                "traffic": traffic, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": round(k3_ms, 4) if k3_ms else None,
+                "other_kernels_ms": {k: round(v, 4) for k, v in kms.items() if k != "loss_fwd_bwd"}}
+        line = {
+            "metric": "images/sec RetinaNet-R50-FPN train step @800x1333",
+            "value": round(world * args.batch * args.steps / elapsed, 3),
+            "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"RetinaNet-{args.backbone.replace('resnet', 'R')}-FPN bf16 train step, per-GPU batch "
+                                   f"{args.batch} x 3x800x1333 (padded 800x1344), A=201600 anchors, K=90, T={args.gt} GT/img, "
+                                   f"SGD(momentum); random-init weights",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, A, K)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

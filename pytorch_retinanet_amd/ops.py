@@ -17,6 +17,38 @@ from ._lib import RN_BF16, RN_F16, RN_F32, RnDetectParams, RnLevel, RnLossParams
 _DT = {torch.float32: RN_F32, torch.bfloat16: RN_BF16, torch.float16: RN_F16}
 
 
+# Optional per-op device timing (bench.py): name -> list of (start_event, end_event) recorded on the
+# stream the kernels are launched on (torch's current stream).  None = disabled (default).
+_TIMERS = None
+
+
+def enable_timing(on: bool = True) -> None:
+    global _TIMERS
+    _TIMERS = {} if on else None
+
+
+def timing_events():
+    return _TIMERS
+
+
+class _timed:
+    def __init__(self, name: str, dev: torch.device):
+        self.name, self.dev = name, dev
+
+    def __enter__(self):
+        if _TIMERS is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream(self.dev))
+        return self
+
+    def __exit__(self, *exc):
+        if _TIMERS is not None:
+            self.e1.record(torch.cuda.current_stream(self.dev))
+            _TIMERS.setdefault(self.name, []).append((self.e0, self.e1))
+        return False
+
+
 def _need_dev(*tensors: Tensor) -> torch.device:
     dev = None
     for t in tensors:
@@ -106,7 +138,7 @@ def iou_match(anchors: Tensor, gt_boxes: Tensor, gt_off: Tensor, B: int, fg_thr:
         raise AssertionError("match_thr must be greater than back_thr")   # box_utils.py:66
     matches = torch.empty((B, A), dtype=torch.int64, device=dev)
     num_fg = torch.empty((B,), dtype=torch.int32, device=dev) if want_num_fg else None
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("iou_match", dev):
         check(lib.rn_iou_match(_ptr(anchors), bstride, _ptr(gt_boxes), _ptr(gt_off), B, A, fg_thr, bg_thr,
                                _ptr(matches), _ptr(num_fg), _stream(dev)), "rn_iou_match")
     return matches, num_fg
@@ -136,7 +168,7 @@ def loss_fwd_bwd(cls: Tensor, box: Tensor, anchors: Tensor, gt_boxes: Tensor, gt
     gbox = torch.empty_like(box) if want_grad else None
     ws_bytes = lib.rn_loss_workspace_bytes(B, A, K)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("loss_fwd_bwd" if want_grad else "loss_fwd", dev):
         check(lib.rn_loss_fwd_bwd(_ptr(cls), _ptr(box), code, B, A, K, _ptr(anchors), bstride, _ptr(gt_boxes),
                                   _ptr(gt_labels), _ptr(gt_off), _ptr(matches), _ptr(num_fg), C.byref(params),
                                   _ptr(out), _ptr(gcls), _ptr(gbox), _ptr(ws), ws_bytes, _stream(dev)),
@@ -234,7 +266,7 @@ def detect(cls: Tensor, deltas: Tensor, anchors, image_sizes: Sequence[Tuple[int
     while True:
         ws_bytes = lib.rn_detect_workspace_bytes(B, A, K, cap)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _timed("detect", dev):
             check(lib.rn_detect(_ptr(cls), _ptr(deltas), _dtype_code(cls), B, A, K, _ptr(anchors), bstride, _ptr(hw),
                                 C.byref(params), cap, _ptr(out_boxes), _ptr(out_scores), _ptr(out_labels),
                                 _ptr(meta[0]), _ptr(meta[1]), _ptr(ws), ws_bytes, _stream(dev)), "rn_detect")
