@@ -27,7 +27,6 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")          # bounded warm-up on a fresh box (no perf-db cache there)
 os.environ.setdefault("MIOPEN_LOG_LEVEL", "1")
 
 import numpy as np  # noqa: E402
@@ -108,8 +107,10 @@ def main():
         print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
 
     import pytorch_retinanet_amd as P
-    from pytorch_retinanet_amd import ops
+    from pytorch_retinanet_amd import ops, tuning
 
+    tuning.use_shipped_miopen_db(rank)        # before the first conv: skip MIOpen's exhaustive search on a cold box
+    tuning.enable_conv_autotune()             # channels_last needs find-mode picks (tuning.py has the numbers)
     torch.manual_seed(0)
     net = P.Retinanet(num_classes=90, backbone_kind=args.backbone, pretrained=False, min_size=800, max_size=1333)
     net = net.to(device).to(memory_format=torch.channels_last).train()

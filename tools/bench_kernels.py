@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Isolated timings of the dense-head HIP kernels at BASELINE.json's shapes (events on the launch stream).
+
+    python tools/bench_kernels.py [k2] [k3] [k3f32] [detect] [detect_stress] [--reps N]
+
+Prints one JSON line per kernel: average launch time, algorithmic bytes, achieved GB/s and
+the fraction of the 8 TB/s HBM peak; pairs/s for the matcher.
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import synth  # noqa: E402
+from pytorch_retinanet_amd import ops  # noqa: E402
+
+DEV = torch.device("cuda:0")
+PEAK = 8000.0
+
+
+def timeit(fn, reps, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    ts = np.array([a.elapsed_time(b) for a, b in evs])
+    return float(np.median(ts)), float(ts.min()), float(ts.mean())
+
+
+def anchors_for(h, w):
+    import oracle
+    cells = [torch.from_numpy(oracle.cell_anchors(s, synth.ANCHOR_RATIOS)).to(DEV) for s in synth.ANCHOR_SIZES]
+    return ops.anchors_emit(synth.levels_for(h, w), cells, 0.0)
+
+
+def gts(rng, B, T, h, w):
+    b, l = zip(*[synth.gt_boxes(rng, T, h, w) for _ in range(B)])
+    gt = torch.from_numpy(np.concatenate(b)).to(DEV)
+    gl = torch.from_numpy(np.concatenate(l)).to(DEV)
+    off = ops.gt_offsets([T] * B, DEV)
+    return gt, gl, off
+
+
+def report(name, ms, nbytes, extra=None):
+    med, mn, mean = ms
+    d = {"kernel": name, "ms_median": round(med, 4), "ms_min": round(mn, 4), "ms_mean": round(mean, 4),
+         "algorithmic_MB": round(nbytes / 1e6, 2), "GBps": round(nbytes / (med * 1e-3) / 1e9, 1),
+         "frac_of_8TBps": round(nbytes / (med * 1e-3) / 1e9 / PEAK, 4)}
+    if extra:
+        d.update(extra)
+    print(json.dumps(d), flush=True)
+
+
+def bench_k2(reps, T):
+    B, A = 8, 201600
+    rng = np.random.default_rng(0)
+    anc = anchors_for(800, 1344)
+    gt, gl, off = gts(rng, B, T, 800, 1333)
+    ms = timeit(lambda: ops.iou_match(anc, gt, off, B, 0.5, 0.4), reps)
+    nbytes = B * (A * 16 + T * 16 + A * 8)
+    report(f"K2 iou_match B={B} A={A} T={T}", ms, nbytes, {"Gpairs_per_s": round(B * A * T / (ms[0] * 1e-3) / 1e9, 2)})
+
+
+def bench_k3(reps, dtype, B=8, want_grad=True):
+    A, K, T = 201600, 90, 8
+    rng = np.random.default_rng(0)
+    anc = anchors_for(800, 1344)
+    gt, gl, off = gts(rng, B, T, 800, 1333)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    cls = (torch.randn((B, A, K), device=DEV, generator=g) - 4.6).to(dtype)
+    box = (torch.randn((B, A, 4), device=DEV, generator=g) * 0.1).to(dtype)
+    m, nfg = ops.iou_match(anc, gt, off, B, 0.5, 0.4)
+    p = ops.make_loss_params(0.25, 2.0, 0.1)
+    ms = timeit(lambda: ops.loss_fwd_bwd(cls, box, anc, gt, gl, off, m, nfg, p, want_grad), reps)
+    s = cls.element_size()
+    nbytes = B * ((2 if want_grad else 1) * (A * K * s + A * 4 * s) + A * 8 + T * 24)
+    report(f"K3 loss_{'fwd_bwd' if want_grad else 'fwd'} {str(dtype).split('.')[-1]} B={B} A={A} K={K}", ms, nbytes)
+
+
+def bench_detect(reps, mean, std, tag, B=16):
+    A, K = 338454, 90
+    anc = anchors_for(1344, 1344)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    cls = (torch.randn((B, A, K), device=DEV, generator=g) * std + mean).to(torch.float16)
+    box = (torch.randn((B, A, 4), device=DEV, generator=g) * 0.1).to(torch.float16)
+    hw = [(1333, 1333)] * B
+    ncand = int((torch.sigmoid(cls.float()) > 0.05).sum())
+    t0 = time.perf_counter()
+    ops.enable_timing(True)
+    for _ in range(reps):
+        ops.detect(cls, box, anc, hw, 0.05, 1e-2, 0.5, 100, max_candidates=max(1 << 18, 2 * ncand // B))
+    torch.cuda.synchronize()
+    ev = ops.timing_events()["detect"]
+    ops.enable_timing(False)
+    ts = np.array([a.elapsed_time(b) for a, b in ev])[1:]
+    nbytes = B * (A * K * 2 + A * 4 * 2 + A * 16)
+    report(f"K4-K7 rn_detect {tag} fp16 B={B} A={A} K={K}", (float(np.median(ts)), float(ts.min()), float(ts.mean())), nbytes,
+           {"candidates_per_image": ncand // B, "wall_ms_per_call_incl_sync": round((time.perf_counter() - t0) / reps * 1e3, 3)})
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    reps = 30
+    if "--reps" in sys.argv:
+        reps = int(sys.argv[sys.argv.index("--reps") + 1])
+        args = [a for a in args if a != str(reps)]
+    which = args or ["k2", "k2_500", "k3", "k3f32", "k3fwd", "detect"]
+    for w in which:
+        if w == "k2":
+            bench_k2(reps, 8)
+        elif w == "k2_500":
+            bench_k2(reps, 500)
+        elif w == "k3":
+            bench_k3(reps, torch.bfloat16)
+        elif w == "k3f16":
+            bench_k3(reps, torch.float16)
+        elif w == "k3f32":
+            bench_k3(reps, torch.float32)
+        elif w == "k3fwd":
+            bench_k3(reps, torch.bfloat16, want_grad=False)
+        elif w == "detect":
+            bench_detect(max(reps // 5, 4), -7.0, 1.2, "sparse")
+        elif w == "detect_stress":
+            bench_detect(3, -6.0, 1.5, "stress")
+
+
+if __name__ == "__main__":
+    main()
