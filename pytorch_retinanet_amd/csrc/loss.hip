@@ -1,6 +1,6 @@
 // K3 loss_fwd_bwd -- replaces RetinaNetLosses (retinanet/losses.py:19-145) and
-// bbox_2_activ (retinanet/box_utils.py:25-34): one streaming pass over the head
-// outputs that yields both loss scalars AND their gradients.
+// bbox_2_activ (retinanet/box_utils.py:25-34): the loss scalars AND their gradients
+// from one streaming pass over the head outputs plus a sparse fix-up.
 //
 // Reference semantics kept: logit shift x+1 (Q1), reversed
 // alpha (Q2), detached focal weight so d/dx = w*(sigmoid(x+1)-t) (Q3), ignore
@@ -8,28 +8,32 @@
 // per-image /clamp(num_fg,1) then mean over images (Q8), smooth-L1 beta form
 // (Q10), log(gw/aw + 1e-8) (Q11).
 //
-// Data movement (HBM-bound; per image A*K*s read + A*K*s written for the class
-// tensor, A*4*s + A*4*s for the box tensor, A*8 for matches):
-//   - [B,A,K] is treated as B*A rows of K contiguous elements.  Each WAVE owns a
-//     contiguous range of rows (a multiple of 8 rows, so its first byte is
-//     16-byte aligned for every K and element size) and streams it with 16-byte
-//     loads/stores: 1 KiB per wave instruction, fully coalesced.
-//   - Row metadata (target class code, 1/(max(num_fg,1)*B)) is staged per wave in LDS
-//     (8 B/row) and read back per vector; 4 loads (4 KiB) per wave stay in flight so the
-//     stream is bandwidth- not latency-bound; no block barrier inside the loop.
-//   - ~99% of wave-iterations touch only plain background rows of one image: those run a
-//     select-free body (12 VALU + exp/rcp/log per element); rows with positives, ignored
-//     rows, image seams and ragged ends take the general body.
-//   - Loss sums: per-lane fp32 accumulators -> wave shuffle reduction -> one
-//     partial per block -> a second tiny kernel adds the partials in double in a
-//     fixed order (deterministic; no float atomics).
+// Structure (HBM-bound; per image A*K*s read + A*K*s written for the class tensor,
+// A*4*s + A*4*s for the box tensor, A*8 for matches).  One kernel, each wave owns one contiguous
+// element range of the flattened [B*A*K] tensor:
+//
+//   phase A (stream)  Treats EVERY class element as a plain background element (t = 0) of its
+//                     image: no metadata, no LDS, no selects -- 10 VALU + exp/rcp/log per element,
+//                     16-byte non-temporal loads / 16-byte stores, two groups of PF KiB of loads in
+//                     flight per wave.  Exact for > 99% of the rows.
+//   phase B (repair)  The same wave then visits the rows of its range that are NOT plain background
+//                     (matched rows: one positive element each; ignored rows: whole row; about
+//                     0.3% of the rows at the reference's settings; their `matches` were prefetched
+//                     before phase A), rewrites those gradient elements, adds the loss corrections
+//                     (correct term minus the background term phase A added, computed with the same
+//                     instructions) and does the regression branch (encode + smooth-L1 + box
+//                     gradient) of matched rows; every other box-gradient row is written as zeros.
+//   finalize          A one-block kernel adds the per-block partial sums in double in a fixed
+//                     order (deterministic; no float atomics).
+#include <cstdlib>
+
 #include "rn_common.hpp"
 
 namespace {
 
 constexpr int LOSS_BLOCK = 256;
 constexpr int LOSS_WAVES = LOSS_BLOCK / RN_WAVE;
-constexpr int LOSS_MAX_BLOCKS = 4096;   // upper bound on resident blocks (256 CUs x 8) with headroom; sizes the partials workspace
+constexpr int LOSS_MAX_BLOCKS = 4096;   // bound on resident blocks (256 CUs x 8, with headroom): sizes the partials workspace
 
 struct LossArgs {
     const void *cls, *box;
@@ -41,25 +45,39 @@ struct LossArgs {
     const int32_t *gt_off;
     const int64_t *matches;
     const int32_t *num_fg;
-    int64_t A, R;            // anchors per image, total rows B*A
+    int64_t A, R, N;         // anchors per image, rows B*A, elements R*K
+    int64_t per_image;       // A*K elements
+    int64_t vec_per_wave;    // stream kernel: 16-byte vectors per wave (multiple of 64)
     int32_t K, B;
-    int64_t rows_per_wave;   // multiple of 8
-    uint32_t magicK;         // floor(2^32/K)+1 : (n*magicK)>>32 == n/K for n < 2^32/K
     float inv_B;
     rn_loss_params p;
     float alpha_pos;         // weight of t=1 elements: 1-alpha (Q2)
-    float2 *partials;        // [gridDim.x] (cls, reg)
+    float2 *part_stream;     // [stream blocks] (cls, 0)
+    float2 *part_fix;        // [fix blocks]    (cls correction, reg)
+    unsigned *arrive;        // fix-up arrival counter (zeroed by the stream kernel)
+    float *out_loss;         // [2]
+    int n_stream;            // stream grid size (partials to add)
 };
 
-// ln(x) for x in [1, 2]: bare v_log_f32 (log2) times ln 2.  __logf() would add ~10 instructions of
-// denormal-range handling per call, which dominated the loop.
-__device__ __forceinline__ float ln_1to2(const float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
-// max(z, 0) = (z + |z|) / 2: one add with an |.| source modifier + a multiply (fmaxf costs two
-// v_max because of sNaN canonicalisation).
-__device__ __forceinline__ float relu(const float z) { return (z + fabsf(z)) * 0.5f; }
+// ---- background element (t = 0) ------------------------------------------------------
+// With E = exp(-z):  sigmoid(z) = 1/(1+E),  softplus(z) = z + ln(1+E)  -- no |z|, no select.
+// z is clamped at -80 so E stays finite (sigmoid(-80) = 1.8e-35; its weight p^gamma underflows
+// either way).  v_exp/v_log are the bare base-2 instructions (__expf/__logf would add ~10
+// instructions of range handling each).  Returns wb = p^gamma * bce and g = p^gamma * p, both
+// still to be multiplied by alpha * scale.
+template <bool GAMMA2>
+__device__ __forceinline__ void bg_elem(const float x, const rn_loss_params &p, float &wb, float &g)
+{
+    const float z = __builtin_amdgcn_fmed3f(x + p.logit_shift, -80.0f, __builtin_inff());
+    const float den = 1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f);
+    const float ps = __builtin_amdgcn_rcpf(den);
+    const float w = GAMMA2 ? ps * ps : ((p.gamma == 0.0f) ? 1.0f : __powf(ps, p.gamma));
+    const float bce = fmaf(__builtin_amdgcn_logf(den), 0.6931471805599453f, z);
+    wb = w * bce;
+    g = w * ps;
+}
 
-// ---- per-element focal term ---------------------------------------------------
-// Returns loss and d loss/dx (both unscaled).  t in {0,1} as `pos`.
+// ---- general element (fix-up kernel only): loss and d loss/dx, unscaled -------------------
 template <bool GAMMA2>
 __device__ __forceinline__ void focal_elem(const float x, const bool pos, const LossArgs &a, float &loss, float &grad)
 {
@@ -76,8 +94,8 @@ __device__ __forceinline__ void focal_elem(const float x, const bool pos, const 
     float w = GAMMA2 ? q * q : ((a.p.gamma == 0.0f) ? 1.0f : __powf(q, a.p.gamma));
     w *= pos ? a.alpha_pos : a.p.alpha;                // losses.py:44-45
     // log1p(e) = log(den) + (e - (den-1))/den   (correction recovers the bits lost in 1+e)
-    const float l1p = ln_1to2(den) + (e - (den - 1.0f)) * r;
-    const float bce = relu(pos ? -z : z) + l1p;        // (1-t)*z - log_sigmoid(z)
+    const float l1p = __builtin_amdgcn_logf(den) * 0.6931471805599453f + (e - (den - 1.0f)) * r;
+    const float bce = fmaxf(pos ? -z : z, 0.0f) + l1p; // (1-t)*z - log_sigmoid(z)
     loss = w * bce;
     grad = pos ? -(w * om) : (w * ps);                 // w * (sigmoid(z) - t)
 }
@@ -139,217 +157,263 @@ __device__ __forceinline__ float reg_row(const rn::f32x4 g, const rn::f32x4 an, 
     return l;
 }
 
-// Window of rows whose metadata a wave keeps in LDS (8 B per row, 4 KiB per wave).
-constexpr int WIN_ROWS = 512;
-constexpr int PF = 4;                       // 16-byte loads in flight per lane (4 KiB per wave)
-
-struct RowMeta { int code; float scale; };  // code: -2 ignore, -1 background, >=0 positive class; scale = 1/(max(nfg,1)*B)
-
-// General element: any row kind; metadata looked up in the wave's LDS window.
-template <int DT, bool GAMMA2, bool WRITE_GRAD>
-__device__ __forceinline__ void slow_vector(const LossArgs &a, const RowMeta *meta, const int nrows, const rn::u32x4 *src_vec,
-                                            const uint32_t le, rn::u32x4 *dst_vec, float &acc_cls)
+// alpha / (max(num_fg,1) * B) of image b; 0 for an image without GT (every row ignored, Q7)
+__device__ __forceinline__ float image_gmul(const LossArgs &a, const int b)
 {
-    typedef rn::dt<DT> D;
-    constexpr int VEC = D::VEC;
-    const int K = a.K;
-    float x[VEC], g[VEC];
-    D::unpack(*src_vec, x);          // (re)loaded here: the general body is rare, its data is L2-hot
-    uint32_t row = (K == 1) ? le : __umulhi(le, a.magicK);
-    int k = (int)(le - row * (uint32_t)K);
-    RowMeta m = meta[row];
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        if (k >= K) {                       // crossed into the next row (possibly several times when K < VEC)
-            k = 0;
-            row = min(row + 1u, (uint32_t)nrows - 1u);
-            m = meta[row];
-        }
-        float l, gr;
-        focal_elem<GAMMA2>(x[j], m.code == k, a, l, gr);
-        const bool use = m.code != -2;
-        acc_cls += use ? l * m.scale : 0.0f;
-        g[j] = use ? gr * m.scale : 0.0f;
-        ++k;
-    }
-    if (WRITE_GRAD) *dst_vec = D::pack(g);
+    const int T = a.gt_off[b + 1] - a.gt_off[b];
+    const int nf = a.num_fg[b];
+    return (T > 0) ? a.p.alpha * ((1.0f / (float)(nf > 1 ? nf : 1)) * a.inv_B) : 0.0f;
 }
 
-// Background-only vector: every element has t = 0 and the same scale (wave-uniform `gmul`).
-// With E = exp(-z):  sigmoid(z) = 1/(1+E),  softplus(z) = z + ln(1+E)  -- no |z|, no select.
-// z is clamped at -80 so E stays finite (sigmoid(-80) = 1.8e-35; its weight p^2 underflows to 0
-// either way).  Per element: 10 VALU + v_exp + v_rcp + v_log.
-template <int DT, bool GAMMA2, bool WRITE_GRAD>
-__device__ __forceinline__ void fast_vector(const LossArgs &a, const rn::u32x4 raw, const float gmul, rn::u32x4 *dst_vec,
-                                            float &acc_fast)
-{
-    typedef rn::dt<DT> D;
-    constexpr int VEC = D::VEC;
-    float x[VEC], g[VEC];
-    D::unpack(raw, x);
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        const float z = __builtin_amdgcn_fmed3f(x[j] + a.p.logit_shift, -80.0f, __builtin_inff());
-        const float den = 1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f);
-        const float ps = __builtin_amdgcn_rcpf(den);               // sigmoid(z)
-        const float w = GAMMA2 ? ps * ps : ((a.p.gamma == 0.0f) ? 1.0f : __powf(ps, a.p.gamma));
-        const float bce = fmaf(__builtin_amdgcn_logf(den), 0.6931471805599453f, z);   // softplus(z)
-        acc_fast = fmaf(w, bce, acc_fast);
-        g[j] = (w * ps) * gmul;
-    }
-    if (WRITE_GRAD) *dst_vec = D::pack(g);
-}
+// ================================= loss kernel =======================================
+// Phase A (stream): every class element of the wave's range is processed as a plain background
+// element.  Phase B (epilogue): the same wave repairs the few elements of ITS OWN range that are not
+// plain background (positive element of a matched row, whole ignored rows) and emits the box
+// gradient / regression term of the rows whose first element it owns.  Both phases write from one
+// wave, so program order gives the right final value without any cross-wave ordering.
+constexpr int PREF_CHUNKS = 4;      // 64-row chunks of `matches` prefetched before the stream (256 rows)
+constexpr int IGN_U = 8;            // independent element loads per lane per round in the ignored-row repair
 
-template <int DT, bool GAMMA2, bool WRITE_GRAD>
-__global__ __launch_bounds__(LOSS_BLOCK) void loss_fwd_bwd_kernel(const LossArgs a)
+template <int DT, bool GAMMA2, bool WRITE_GRAD, int PF, int NT>
+__global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs a)
 {
     typedef rn::dt<DT> D;
     constexpr int VEC = D::VEC;
-    __shared__ RowMeta s_meta[LOSS_WAVES][WIN_ROWS];
     __shared__ float s_part[LOSS_WAVES][2];
+    __shared__ unsigned char s_ign_row[LOSS_WAVES][RN_WAVE];   // ignored rows of the current 64-row chunk (lane offsets)
+    __shared__ float s_ign_gm[LOSS_WAVES][RN_WAVE];            // their alpha/(max(nfg,1)*B)
 
     const int lane = threadIdx.x & (RN_WAVE - 1);
-    // readfirstlane: tells the compiler the wave index (and every range / trip count derived from
-    // it) is wave-uniform, so loop control and address bases live in SGPRs and branches on them
-    // are scalar branches instead of EXEC-masked regions.
+    // readfirstlane: the wave index and everything derived from it (ranges, trip counts, image
+    // seams) is wave-uniform -> SGPRs and scalar branches.
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t gwave = (int64_t)blockIdx.x * LOSS_WAVES + wave;
-    const int64_t rbeg = gwave * a.rows_per_wave;
-    const int64_t rend = min(rbeg + a.rows_per_wave, a.R);
+    const int64_t nvec = a.N / VEC;                              // full vectors in the tensor
+    const int64_t v_beg = gwave * a.vec_per_wave;
+    const int64_t v_end = min(v_beg + a.vec_per_wave, nvec);
+    const rn::u32x4 *src = (const rn::u32x4 *)a.cls;
+    rn::u32x4 *dst = (rn::u32x4 *)a.gcls;
     const int K = a.K;
-    RowMeta *meta = s_meta[wave];
 
-    float acc_cls = 0.0f, acc_reg = 0.0f;
+    float acc = 0.0f, reg = 0.0f;                                // acc: already scaled by alpha*scale
+    // element range owned by this wave; the wave that ends at nvec also owns the ragged tail (< VEC elements)
+    const bool active = v_beg < nvec || (gwave == 0 && nvec == 0);
+    const int64_t e_beg = v_beg * VEC;
+    const int64_t e_end = !active ? e_beg : ((v_end == nvec) ? a.N : v_end * VEC);
+    const int64_t row_lo = e_beg / K;
+    const int64_t row_hi = active && e_end > e_beg ? (e_end - 1) / K : row_lo - 1;     // inclusive
 
-    for (int64_t w0 = rbeg; w0 < rend; w0 += WIN_ROWS) {
-        const int nrows = (int)min((int64_t)WIN_ROWS, rend - w0);
-        // first loads of the stream go out before the (dependent) metadata loads
-        const int ne = nrows * K;                    // elements in the window
-        const int nvec = ne / VEC;                   // full 16-byte vectors
-        const int64_t e0 = w0 * (int64_t)K;          // 16-byte aligned (w0 % 8 == 0)
-        const rn::u32x4 *src = (const rn::u32x4 *)((const typename D::elem *)a.cls + e0);
-        rn::u32x4 *dst = WRITE_GRAD ? (rn::u32x4 *)((typename D::elem *)a.gcls + e0) : nullptr;
-        const int iters = nvec / RN_WAVE;            // full wave-iterations (64 vectors = 1 KiB each)
-        const rn::u32x4 zero4 = {0u, 0u, 0u, 0u};
+    // prefetch this wave's slice of `matches` (epilogue input) so its latency hides under the stream
+    int pm[PREF_CHUNKS];
+#pragma unroll
+    for (int c = 0; c < PREF_CHUNKS; ++c) {
+        const int64_t r = row_lo + c * RN_WAVE + lane;
+        pm[c] = (r <= row_hi) ? (int)a.matches[r] : -1;
+    }
+
+    if (v_beg < v_end) {
+        int b = (int)(e_beg / a.per_image);                      // image of the first element
+        int64_t img_end_v = ((int64_t)(b + 1) * a.per_image) / VEC;   // vectors [.., img_end_v) lie entirely in image b
+        float gmul = image_gmul(a, b);
+
+        const int64_t last = v_end - 1;
+        const int64_t groups = (v_end - v_beg) / (PF * RN_WAVE);      // full groups of PF wave-iterations
         rn::u32x4 q[PF];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) q[u] = (nvec > 0) ? src[min(u * RN_WAVE + lane, nvec - 1)] : zero4;
+        for (int u = 0; u < PF; ++u) q[u] = (NT & 1) ? __builtin_nontemporal_load(&src[min(v_beg + u * RN_WAVE + lane, last)]) : src[min(v_beg + u * RN_WAVE + lane, last)];
 
-        // ---- phase 1: row metadata -> LDS, regression term + box gradients ------------
-        for (int i = lane; i < nrows; i += RN_WAVE) {
-            const int64_t r = w0 + i;
-            const int b = (int)((uint32_t)r / (uint32_t)a.A);        // R < 2^31 (checked on the host)
-            const int64_t ai = r - (int64_t)b * a.A;
-            const int64_t m = a.matches[r];
-            const int nf = a.num_fg[b];
-            RowMeta rm;
-            rm.scale = (1.0f / (float)(nf > 1 ? nf : 1)) * a.inv_B;
-            float gb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (m >= 0) {
-                const int gi = a.gt_off[b] + (int)m;
-                rm.code = (int)a.gt_labels[gi] - 1;
-                float pred[4];
-                box4<DT>::ld(a.box, r, pred);
-                const float l = reg_row(a.gt_boxes[gi], a.anchors[(int64_t)b * a.anchor_bstride4 + ai], pred, a.p, gb);
-                acc_reg += l * rm.scale;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) gb[j] *= rm.scale;
-            } else {
-                rm.code = (m == -1) ? -1 : -2;
-            }
-            meta[i] = rm;
-            if (WRITE_GRAD) box4<DT>::st(a.gbox, r, gb);
-        }
-        // LDS traffic of one wave is processed in order; the fence keeps the compiler from moving
-        // the metadata reads above the writes (no block barrier: waves run independent trip counts).
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        // ---- phase 2: stream the class logits, PF loads in flight per lane ------------------
-        // Straight-line chunks of PF iterations: every refill load is unconditional (index clamped
-        // to the window's last vector) so the compiler can count outstanding loads and wait with
-        // vmcnt(N) for just the oldest one instead of draining the ring with vmcnt(0).
-        const int last_v = nvec - 1;
-        int it = 0;
-        for (; it + PF <= iters; it += PF) {
-            const int v0 = it * RN_WAVE + lane;
-            // next chunk's loads go out first: they have this whole chunk's compute to land
+        int64_t v0 = v_beg;
+        for (int64_t gi = 0; gi < groups; ++gi, v0 += PF * RN_WAVE) {
+            // next group's loads first (index clamped: straight-line code, countable vmcnt)
             rn::u32x4 qn[PF];
 #pragma unroll
-            for (int u = 0; u < PF; ++u) qn[u] = src[min(v0 + (PF + u) * RN_WAVE, last_v)];
-            // Is every row touched by these PF iterations plain background with one scale?
-            const uint32_t e_lo = (uint32_t)it * RN_WAVE * VEC, e_hi = (uint32_t)(it + PF) * RN_WAVE * VEC - 1u;
-            const uint32_t row_lo = (K == 1) ? e_lo : __umulhi(e_lo, a.magicK);
-            const uint32_t row_hi = (K == 1) ? e_hi : __umulhi(e_hi, a.magicK);
-            const uint32_t nr = row_hi - row_lo + 1u;
-            bool fast = false;
-            float sc_u = 0.0f;
-            if (nr <= (uint32_t)RN_WAVE) {
-                const RowMeta mine = meta[row_lo + min((uint32_t)lane, nr - 1u)];
-                sc_u = meta[row_lo].scale;
-                fast = __all(mine.code == -1 && mine.scale == sc_u);
-            }
-            if (fast) {
-                const float gmul = a.p.alpha * sc_u;                      // alpha / (max(nfg,1) * B)
-                float acc_fast = 0.0f;
+            for (int u = 0; u < PF; ++u) qn[u] = (NT & 1) ? __builtin_nontemporal_load(&src[min(v0 + (PF + u) * RN_WAVE + lane, last)]) : src[min(v0 + (PF + u) * RN_WAVE + lane, last)];
+
+            if (v0 + PF * RN_WAVE <= img_end_v) {                    // whole group inside image b (scalar test)
+                float acc_g = 0.0f;
 #pragma unroll
-                for (int u = 0; u < PF; ++u)
-                    fast_vector<DT, GAMMA2, WRITE_GRAD>(a, q[u], gmul, WRITE_GRAD ? dst + v0 + u * RN_WAVE : nullptr, acc_fast);
-                acc_cls = fmaf(acc_fast, gmul, acc_cls);
-            } else {
+                for (int u = 0; u < PF; ++u) {
+                    float x[VEC], g[VEC];
+                    D::unpack(q[u], x);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        float wb, gg;
+                        bg_elem<GAMMA2>(x[j], a.p, wb, gg);
+                        acc_g += wb;
+                        g[j] = gg * gmul;
+                    }
+                    if (WRITE_GRAD) { if (NT & 2) __builtin_nontemporal_store(D::pack(g), &dst[v0 + u * RN_WAVE + lane]); else dst[v0 + u * RN_WAVE + lane] = D::pack(g); }
+                }
+                acc = fmaf(acc_g, gmul, acc);
+            } else {                                                 // an image seam crosses this group (<= B-1 times overall)
 #pragma unroll 1
-                for (int u = 0; u < PF; ++u)
-                    slow_vector<DT, GAMMA2, WRITE_GRAD>(a, meta, nrows, src + v0 + u * RN_WAVE, (uint32_t)(v0 + u * RN_WAVE) * VEC,
-                                                        WRITE_GRAD ? dst + v0 + u * RN_WAVE : nullptr, acc_cls);
+                for (int u = 0; u < PF; ++u) {
+                    const int64_t v = v0 + u * RN_WAVE + lane;
+                    float x[VEC], g[VEC];
+                    D::unpack(src[v], x);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const float gm = image_gmul(a, (int)((v * VEC + j) / a.per_image));
+                        float wb, gg;
+                        bg_elem<GAMMA2>(x[j], a.p, wb, gg);
+                        acc = fmaf(wb, gm, acc);
+                        g[j] = gg * gm;
+                    }
+                    if (WRITE_GRAD) dst[v] = D::pack(g);
+                }
+                b = (int)(((v0 + PF * RN_WAVE) * VEC) / a.per_image);
+                if (b > a.B - 1) b = a.B - 1;
+                img_end_v = ((int64_t)(b + 1) * a.per_image) / VEC;
+                gmul = image_gmul(a, b);
             }
 #pragma unroll
             for (int u = 0; u < PF; ++u) q[u] = qn[u];
         }
-        // leftover full iterations (< PF), the partial one, then the ragged tail: general body
+        // leftover vectors of the range (< one group), per-element image lookup
 #pragma unroll 1
-        for (int v = it * RN_WAVE + lane; v < nvec; v += RN_WAVE)
-            slow_vector<DT, GAMMA2, WRITE_GRAD>(a, meta, nrows, src + v, (uint32_t)v * VEC, WRITE_GRAD ? dst + v : nullptr, acc_cls);
-        // ---- partial last iteration (< 64 vectors) and ragged tail (< VEC elements) ---------
-        {
-            const uint32_t le = (uint32_t)(nvec * VEC + lane);
-            if ((int)le < ne) {
-                const uint32_t row = le / (uint32_t)K;
-                const int k = (int)(le - row * (uint32_t)K);
-                const RowMeta m = meta[row];
-                float l, gr;
-                focal_elem<GAMMA2>(D::ld(a.cls, e0 + le), m.code == k, a, l, gr);
-                const bool use = m.code != -2;
-                acc_cls += use ? l * m.scale : 0.0f;
-                if (WRITE_GRAD) D::st(a.gcls, e0 + le, use ? gr * m.scale : 0.0f);
+        for (int64_t v = v0 + lane; v < v_end; v += RN_WAVE) {
+            float x[VEC], g[VEC];
+            D::unpack(src[v], x);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float gm = image_gmul(a, (int)((v * VEC + j) / a.per_image));
+                float wb, gg;
+                bg_elem<GAMMA2>(x[j], a.p, wb, gg);
+                acc = fmaf(wb, gm, acc);
+                g[j] = gg * gm;
             }
+            if (WRITE_GRAD) dst[v] = D::pack(g);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");             // metadata reads done before the next window's writes
-        __builtin_amdgcn_wave_barrier();
+    }
+    // ragged tail of the tensor (< VEC elements), owned by the wave that ends at nvec
+    if (active && v_end == nvec) {
+        const int64_t e = nvec * VEC + lane;
+        if (lane < VEC && e < a.N) {
+            const float gm = image_gmul(a, (int)(e / a.per_image));
+            float wb, gg;
+            bg_elem<GAMMA2>(D::ld(a.cls, e), a.p, wb, gg);
+            acc = fmaf(wb, gm, acc);
+            if (WRITE_GRAD) D::st(a.gcls, e, gg * gm);
+        }
     }
 
-    // ---- block partial ----------------------------------------------------------
-    acc_cls = rn::wave_sum(acc_cls);
-    acc_reg = rn::wave_sum(acc_reg);
-    if (lane == 0) { s_part[wave][0] = acc_cls; s_part[wave][1] = acc_reg; }
+    // ---- Phase B: repair this wave's special elements; box gradients of the rows it owns ----------
+    for (int64_t c0 = row_lo, c = 0; c0 <= row_hi; c0 += RN_WAVE, ++c) {
+        const int64_t r = c0 + lane;
+        bool ignored = false;
+        float ign_gm = 0.0f;
+        if (r <= row_hi) {
+            int64_t m = -1;
+            if (c < PREF_CHUNKS) {
+#pragma unroll
+                for (int k = 0; k < PREF_CHUNKS; ++k) if (c == k) m = pm[k];
+            } else {
+                m = a.matches[r];
+            }
+            const int64_t r_e0 = r * K;
+            const bool own_row = r_e0 >= e_beg;                       // the row's first element is ours
+            float gb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (m != -1) {                                            // rare: ~0.3% of the rows
+                const int b = (int)((uint32_t)r / (uint32_t)a.A);
+                const int t0 = a.gt_off[b], T = a.gt_off[b + 1] - t0;
+                if (T > 0) {                                          // images without GT: phase A already wrote zeros
+                    const int nf = a.num_fg[b];
+                    const float scale = (1.0f / (float)(nf > 1 ? nf : 1)) * a.inv_B;
+                    const float gmul = a.p.alpha * scale;
+                    if (m >= 0) {
+                        const int gi = t0 + (int)m;
+                        const int code = (int)a.gt_labels[gi] - 1;
+                        const int64_t e_pos = r_e0 + code;
+                        if (code >= 0 && code < K && e_pos >= e_beg && e_pos < e_end) {
+                            // matched row: only the positive element differs from what phase A did
+                            const float x = D::ld(a.cls, e_pos);
+                            float wb, gbg, l, gr;
+                            bg_elem<GAMMA2>(x, a.p, wb, gbg);
+                            focal_elem<GAMMA2>(x, true, a, l, gr);
+                            acc += l * scale - wb * gmul;
+                            if (WRITE_GRAD) D::st(a.gcls, e_pos, gr * scale);
+                        }
+                        if (own_row) {
+                            const int64_t ai = r - (int64_t)b * a.A;
+                            float pred[4];
+                            box4<DT>::ld(a.box, r, pred);
+                            const float l = reg_row(a.gt_boxes[gi], a.anchors[(int64_t)b * a.anchor_bstride4 + ai], pred, a.p, gb);
+                            reg += l * scale;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) gb[j] *= scale;
+                        }
+                    } else {
+                        ignored = true;
+                        ign_gm = gmul;
+                    }
+                }
+            }
+            if (WRITE_GRAD && own_row) box4<DT>::st(a.gbox, r, gb);
+        }
+        // ignored rows: remove their background contribution and zero their gradient.  The rows are
+        // compacted into a wave-private LDS list and their elements are spread over all lanes,
+        // IGN_U independent loads per lane per round (elements outside this wave's range are masked).
+        const unsigned long long imask = __ballot(ignored);
+        if (imask) {                                                   // wave-uniform
+            if (ignored) {
+                const int pos = __popcll(imask & ((1ull << lane) - 1ull));
+                s_ign_row[wave][pos] = (unsigned char)lane;
+                s_ign_gm[wave][pos] = ign_gm;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int total = __popcll(imask) * K;
+            for (int t0 = 0; t0 < total; t0 += RN_WAVE * IGN_U) {
+                float xs[IGN_U], gms[IGN_U];
+                int64_t es[IGN_U];
+                bool ok[IGN_U];
+#pragma unroll
+                for (int u = 0; u < IGN_U; ++u) {
+                    const int t = min(t0 + u * RN_WAVE + lane, total - 1);
+                    const int j = t / K, k = t - j * K;
+                    es[u] = (c0 + s_ign_row[wave][j]) * K + k;
+                    gms[u] = s_ign_gm[wave][j];
+                    ok[u] = (t0 + u * RN_WAVE + lane < total) && es[u] >= e_beg && es[u] < e_end;
+                    xs[u] = D::ld(a.cls, es[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < IGN_U; ++u) {
+                    if (ok[u]) {
+                        float wb, gbg;
+                        bg_elem<GAMMA2>(xs[u], a.p, wb, gbg);
+                        acc -= wb * gms[u];
+                        if (WRITE_GRAD) D::st(a.gcls, es[u], 0.0f);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    acc = rn::wave_sum(acc);
+    reg = rn::wave_sum(reg);
+    if (lane == 0) { s_part[wave][0] = acc; s_part[wave][1] = reg; }
     __syncthreads();
     if (threadIdx.x == 0) {
         float c = 0.0f, rg = 0.0f;
 #pragma unroll
         for (int w = 0; w < LOSS_WAVES; ++w) { c += s_part[w][0]; rg += s_part[w][1]; }
-        a.partials[blockIdx.x] = make_float2(c, rg);
+        a.part_stream[blockIdx.x] = make_float2(c, rg);
     }
 }
 
-__global__ __launch_bounds__(256) void loss_finalize_kernel(const float2 *__restrict__ partials, const int n,
-                                                            float *__restrict__ out)
+// One block adds the per-block partial sums in double in a fixed order (deterministic; no float atomics).
+__global__ __launch_bounds__(1024) void loss_finalize_kernel(const float2 *__restrict__ partials, const int n,
+                                                             float *__restrict__ out)
 {
-    __shared__ double s[2][256];
+    __shared__ double s[2][1024];
     double c = 0.0, r = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) { c += (double)partials[i].x; r += (double)partials[i].y; }
+    for (int i = threadIdx.x; i < n; i += 1024) { const float2 v = partials[i]; c += (double)v.x; r += (double)v.y; }
     s[0][threadIdx.x] = c; s[1][threadIdx.x] = r;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) { s[0][threadIdx.x] += s[0][threadIdx.x + o]; s[1][threadIdx.x] += s[1][threadIdx.x + o]; }
         __syncthreads();
     }
@@ -379,44 +443,61 @@ __global__ __launch_bounds__(256) void scale_inplace_kernel(void *data, const in
 }
 
 // Grid = what is co-resident (CUs x blocks/CU from the occupancy query), never more: a second,
-// partially filled round of blocks would idle most of the chip for a whole block lifetime.  Rows
-// are split evenly over the resident waves in multiples of 8 (16-byte alignment of each range).
-int loss_grid(int64_t R, int resident_blocks, int64_t *rows_per_wave)
-{
-    if (resident_blocks < 1) resident_blocks = 1;
-    if (resident_blocks > LOSS_MAX_BLOCKS) resident_blocks = LOSS_MAX_BLOCKS;
-    const int64_t waves = (int64_t)resident_blocks * LOSS_WAVES;
-    int64_t rpw = (R + waves - 1) / waves;
-    rpw = ((rpw + 7) / 8) * 8;
-    if (rpw < 8) rpw = 8;
-    *rows_per_wave = rpw;
-    const int64_t need_waves = (R + rpw - 1) / rpw;
-    return (int)((need_waves + LOSS_WAVES - 1) / LOSS_WAVES);
-}
-
+// partially filled round of blocks would idle most of the chip for a whole block lifetime.
 template <typename KernelT>
-int launch_sized(KernelT kernel, LossArgs &a, hipStream_t st, int *blocks_out)
+int resident_blocks(KernelT kernel, int *out)
 {
     int dev = 0, cus = 0, per_cu = 0;
     RN_HIP(hipGetDevice(&dev));
     RN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     RN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, LOSS_BLOCK, 0));
-    const int blocks = loss_grid(a.R, cus * per_cu, &a.rows_per_wave);
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(LOSS_BLOCK), 0, st, a);
+    int n = cus * per_cu;
+    if (n < 1) n = 1;
+    if (n > LOSS_MAX_BLOCKS) n = LOSS_MAX_BLOCKS;
+    *out = n;
+    return RN_OK;
+}
+
+template <typename StreamT>
+int launch_stream(StreamT stream_k, LossArgs &a, int vec, hipStream_t st, int *n_stream)
+{
+    int res = 0;
+    int rc = resident_blocks(stream_k, &res);
+    if (rc != RN_OK) return rc;
+    if (const char *e = getenv("RN_K3_BLOCKS")) { int v = atoi(e); if (v > 0 && v < res) res = v; }
+    // even split of the vectors over the resident waves, in whole wave-iterations (64 vectors = 1 KiB)
+    const int64_t nvec = a.N / vec;
+    const int64_t waves = (int64_t)res * LOSS_WAVES;
+    int64_t vpw = (nvec + waves - 1) / waves;
+    vpw = ((vpw + RN_WAVE - 1) / RN_WAVE) * RN_WAVE;
+    if (vpw < RN_WAVE) vpw = RN_WAVE;
+    a.vec_per_wave = vpw;
+    int64_t need = ((nvec + vpw - 1) / vpw + LOSS_WAVES - 1) / LOSS_WAVES;
+    if (need < 1) need = 1;
+    hipLaunchKernelGGL(stream_k, dim3((unsigned)need), dim3(LOSS_BLOCK), 0, st, a);
     RN_LAUNCH_CHECK();
-    *blocks_out = blocks;
+    *n_stream = (int)need;
     return RN_OK;
 }
 
 template <int DT>
-int launch_loss(LossArgs &a, bool gamma2, bool write_grad, hipStream_t st, int *blocks)
+int launch_loss(LossArgs &a, bool gamma2, bool wg, hipStream_t st, int *ns)
 {
+    constexpr int VEC = rn::dt<DT>::VEC;
+    int pf = 2, nt = 1;
+    if (const char *e = getenv("RN_K3_PF")) pf = atoi(e);
+    if (const char *e = getenv("RN_K3_NT")) nt = atoi(e);
     if (gamma2) {
-        if (write_grad) return launch_sized(loss_fwd_bwd_kernel<DT, true, true>, a, st, blocks);
-        return launch_sized(loss_fwd_bwd_kernel<DT, true, false>, a, st, blocks);
+        if (wg) {
+#define RN_K3_CASE(P, N) if (pf == P && nt == N) return launch_stream(loss_stream_kernel<DT, true, true, P, N>, a, VEC, st, ns);
+            RN_K3_CASE(2, 0) RN_K3_CASE(4, 0) RN_K3_CASE(4, 1) RN_K3_CASE(8, 1)
+#undef RN_K3_CASE
+            return launch_stream(loss_stream_kernel<DT, true, true, 2, 1>, a, VEC, st, ns);
+        }
+        return launch_stream(loss_stream_kernel<DT, true, false, 2, 1>, a, VEC, st, ns);
     }
-    if (write_grad) return launch_sized(loss_fwd_bwd_kernel<DT, false, true>, a, st, blocks);
-    return launch_sized(loss_fwd_bwd_kernel<DT, false, false>, a, st, blocks);
+    if (wg) return launch_stream(loss_stream_kernel<DT, false, true, 2, 1>, a, VEC, st, ns);
+    return launch_stream(loss_stream_kernel<DT, false, false, 2, 1>, a, VEC, st, ns);
 }
 
 }  // namespace
@@ -424,7 +505,7 @@ int launch_loss(LossArgs &a, bool gamma2, bool write_grad, hipStream_t st, int *
 RN_API size_t rn_loss_workspace_bytes(int B, int64_t A, int K)
 {
     (void)B; (void)A; (void)K;
-    return sizeof(float2) * (size_t)LOSS_MAX_BLOCKS;
+    return sizeof(float2) * (size_t)LOSS_MAX_BLOCKS * 2 + 16;
 }
 
 RN_API int rn_loss_fwd_bwd(const void *cls, const void *box, int dtype, int B, int64_t A, int K,
@@ -436,6 +517,7 @@ RN_API int rn_loss_fwd_bwd(const void *cls, const void *box, int dtype, int B, i
     if (!cls || !box || !anchors || !gt_off || !matches || !num_fg || !params || !out_loss || !workspace) return RN_EINVAL;
     if (B <= 0 || A <= 0 || K <= 0) return RN_EINVAL;
     if ((grad_cls == nullptr) != (grad_box == nullptr)) return RN_EINVAL;
+    if (dtype != RN_F32 && dtype != RN_BF16 && dtype != RN_F16) return RN_EINVAL;
     if (K > 4096 || (int64_t)B * A >= ((int64_t)1 << 31)) return RN_EUNSUPPORTED;
     if (workspace_bytes < rn_loss_workspace_bytes(B, A, K)) return RN_EWORKSPACE;
     const size_t box_al = (dtype == RN_F32) ? 16 : 8;
@@ -450,24 +532,27 @@ RN_API int rn_loss_fwd_bwd(const void *cls, const void *box, int dtype, int B, i
     a.gt_boxes = (const rn::f32x4 *)gt_boxes; a.gt_labels = gt_labels; a.gt_off = gt_off;
     a.matches = matches; a.num_fg = num_fg;
     a.A = A; a.R = (int64_t)B * A; a.K = K; a.B = B;
-    a.magicK = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)K) + 1u;
+    a.N = a.R * K; a.per_image = A * (int64_t)K;
+    a.vec_per_wave = RN_WAVE;
     a.inv_B = 1.0f / (float)B;
     a.p = *params;
     a.alpha_pos = (float)(1.0 - (double)params->alpha);
-    a.partials = (float2 *)workspace;
-    int blocks = 0;
+    a.part_stream = (float2 *)workspace;
+    a.part_fix = a.part_stream + LOSS_MAX_BLOCKS;
+    a.arrive = (unsigned *)(a.part_fix + LOSS_MAX_BLOCKS);
+    a.out_loss = out_loss;
+    a.n_stream = 0;
     const bool gamma2 = params->gamma == 2.0f;
     const bool wg = grad_cls != nullptr;
     hipStream_t st = (hipStream_t)stream;
-    int rc;
+    int ns = 0, rc;
     switch (dtype) {
-        case RN_F32: rc = launch_loss<RN_F32>(a, gamma2, wg, st, &blocks); break;
-        case RN_BF16: rc = launch_loss<RN_BF16>(a, gamma2, wg, st, &blocks); break;
-        case RN_F16: rc = launch_loss<RN_F16>(a, gamma2, wg, st, &blocks); break;
-        default: return RN_EINVAL;
+        case RN_F32: rc = launch_loss<RN_F32>(a, gamma2, wg, st, &ns); break;
+        case RN_BF16: rc = launch_loss<RN_BF16>(a, gamma2, wg, st, &ns); break;
+        default: rc = launch_loss<RN_F16>(a, gamma2, wg, st, &ns); break;
     }
     if (rc != RN_OK) return rc;
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, (const float2 *)workspace, blocks, out_loss);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float2 *)a.part_stream, ns, out_loss);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
