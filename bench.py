@@ -169,7 +169,7 @@ def main():
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:          # noqa: BLE001
                 traffic = None
-        roof = {"bound": "hbm", "kernel": "loss_fwd_bwd_kernel<bf16> (K3, rn_loss_fwd_bwd incl. 1-block finalize)",
+        roof = {"bound": "hbm", "kernel": "loss_stream_kernel<bf16> (K3; timed around rn_loss_fwd_bwd = stream+repair kernel and the 1-block finalize)",
                 "achieved": round(nbytes / (k3_ms * 1e-3) / 1e9, 1) if k3_ms else None, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(nbytes / (k3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k3_ms else None,
                 "traffic": traffic, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": round(k3_ms, 4) if k3_ms else None,

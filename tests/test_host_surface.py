@@ -1,0 +1,206 @@
+"""CPU suite: the host-side mirror of the reference surface, the C-ABI library's symbols, and the
+no-CPU-fallback rule.  (Numerical parity of the HIP path is in test_hip_parity.py, -m gpu.)"""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_library_loads_and_exports_every_declared_symbol():
+    """Every function declared in include/retinanet_hip.h is exported by libretinanet_hip.so and bound."""
+    from pytorch_retinanet_amd import _lib
+    header = open(os.path.join(ROOT, "include", "retinanet_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(rn_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    for name in declared:
+        assert hasattr(_lib.lib, name), name
+    assert _lib.lib.rn_version() == 1
+    assert b"alignment" in _lib.lib.rn_status_string(-2)
+
+
+def test_no_cpu_fallback_and_no_oracle_import_in_product():
+    import pytorch_retinanet_amd as P
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        P.matcher(torch.zeros(4, 4), torch.zeros(1, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        P.AnchorGenerator().grid_anchors([[4, 4]] * 5, torch.device("cpu"))
+    # the product package never references the oracle
+    pkg = os.path.join(ROOT, "pytorch_retinanet_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "rn_oracle" not in src, f
+
+
+def test_config_defaults_and_ifnone():
+    from pytorch_retinanet_amd import config as c
+    from pytorch_retinanet_amd.utilities import ifnone
+    assert (c.NUM_CLASSES, c.BACKBONE, c.PRIOR) == (90, "resnet50", 0.01)
+    assert (c.SCORE_THRES, c.NMS_THRES, c.MAX_DETECTIONS_PER_IMAGE) == (0.05, 0.5, 100)
+    assert (c.IOU_THRESHOLDS_FOREGROUND, c.IOU_THRESHOLDS_BACKGROUND) == (0.5, 0.4)
+    assert (c.FOCAL_LOSS_GAMMA, c.FOCAL_LOSS_ALPHA, c.SMOOTH_L1_LOSS_BETA) == (2.0, 0.25, 0.1)
+    assert c.ANCHOR_STRIDES == [8, 16, 32, 64, 128] and c.ANCHOR_OFFSET == 0.0
+    assert np.allclose(c.ANCHOR_SIZES, synth.ANCHOR_SIZES)
+    assert ifnone(None, 3) == 3 and ifnone(0, 3) == 0
+
+
+def test_cell_anchors_match_golden(golden):
+    """A1 (anchors.py:110-135): size-major, double arithmetic -> fp32; state-dict buffer names."""
+    from pytorch_retinanet_amd import AnchorGenerator
+    ag = AnchorGenerator()
+    cells = np.stack([b.numpy() for b in ag.cell_anchors])
+    assert np.array_equal(cells, golden("anchors.npz")["cells"])
+    assert ag.num_cell_anchors == [9] * 5 == ag.num_anchors
+    assert list(ag.state_dict()) == [f"cell_anchors.{i}" for i in range(5)]
+    ag2 = AnchorGenerator(sizes=[[20.0, 33.5]], aspect_ratios=[0.4, 1.0, 3.0], strides=[8, 16], offset=0.5)
+    assert ag2.num_anchors == [6, 6] and len(ag2.sizes) == 2
+    with pytest.raises(AssertionError):
+        AnchorGenerator(sizes=[[1.0], [2.0], [3.0]], strides=[8, 16])
+
+
+STATE_KEYS_R18_HEAD = [
+    "fpn.conv_c3_1x1.weight", "fpn.conv_c3_3x3.bias", "fpn.conv_c6_3x3.weight", "fpn.conv_c7_3x3.bias",
+    "anchor_generator.cell_anchors.0", "anchor_generator.cell_anchors.4",
+    "retinanet_head.classification_head.class_subnet.0.weight", "retinanet_head.classification_head.class_subnet.6.bias",
+    "retinanet_head.classification_head.class_subnet_output.bias",
+    "retinanet_head.regression_head.box_subnet.4.weight", "retinanet_head.regression_head.box_subnet_output.weight",
+    "backbone.backbone.conv1.weight", "backbone.backbone.layer4.1.bn2.running_var",
+]
+
+
+def test_retinanet_construction_and_state_dict_surface():
+    import pytorch_retinanet_amd as P
+    with pytest.raises(ValueError, match="backbone_kind"):
+        P.Retinanet(backbone_kind="vgg16", pretrained=False)
+    net = P.Retinanet(num_classes=7, backbone_kind="resnet18", pretrained=False)
+    sd = net.state_dict()
+    for k in STATE_KEYS_R18_HEAD:
+        assert k in sd, k
+    assert sd["retinanet_head.classification_head.class_subnet_output.weight"].shape == (9 * 7, 256, 3, 3)
+    assert sd["retinanet_head.regression_head.box_subnet_output.weight"].shape == (36, 256, 3, 3)
+    prior_bias = sd["retinanet_head.classification_head.class_subnet_output.bias"]
+    assert torch.allclose(prior_bias, torch.full_like(prior_bias, -np.log(99.0)))          # layers.py:175-178
+    # freeze_bn only flips BN to eval at construction (Q18); .train() un-freezes
+    bn = net.backbone.backbone.bn1
+    assert not bn.training
+    net.train()
+    assert bn.training
+    assert net._get_backbone_ouputs() == [128, 256, 512]
+    assert P.Retinanet(backbone_kind="resnet50", pretrained=False)._get_backbone_ouputs() == [512, 1024, 2048]
+
+
+def test_head_layout_matches_reference_permutation():
+    """Q20: [N, A*K, H, W] -> [N, H*W*A, K] with anchor index (h*W+w)*A+a; zero-copy for channels_last."""
+    from pytorch_retinanet_amd.layers import _to_anchor_major
+    n, a, k, h, w = 2, 9, 5, 3, 4
+    x = torch.randn(n, a * k, h, w)
+    ref = x.view(n, a, k, h, w).permute(0, 3, 4, 1, 2).contiguous().view(n, -1, k)      # layers.py:189-191
+    assert torch.equal(_to_anchor_major(x, k), ref)
+    xc = x.contiguous(memory_format=torch.channels_last)
+    out = _to_anchor_major(xc, k)
+    assert torch.equal(out, ref) and out.data_ptr() == xc.data_ptr()
+
+
+def test_transform_resize_pad_and_postprocess():
+    from pytorch_retinanet_amd.transform import GeneralizedRCNNTransform
+    t = GeneralizedRCNNTransform(800, 1333, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]).eval()
+    imgs = [torch.rand(3, 800, 1333), torch.rand(3, 400, 500)]
+    tg = [{"boxes": torch.tensor([[10., 20., 100., 200.]]), "labels": torch.tensor([1])},
+          {"boxes": torch.tensor([[10., 20., 100., 200.]]), "labels": torch.tensor([2])}]
+    il, out = t(imgs, tg)
+    assert il.tensors.shape == (2, 3, 800, 1344) and il.image_sizes == [(800, 1333), (800, 1000)]
+    assert torch.equal(out[0]["boxes"], tg[0]["boxes"])                      # scale 1: untouched
+    assert torch.allclose(out[1]["boxes"], tg[1]["boxes"] * 2.0)
+    assert tg[1]["boxes"][0, 0] == 10.0                                      # caller's targets not mutated
+    ref0 = (imgs[0] - torch.tensor(t.image_mean)[:, None, None]) / torch.tensor(t.image_std)[:, None, None]
+    assert torch.equal(il.tensors[0, :, :800, :1333], ref0) and not il.tensors[0, :, :, 1333:].any()
+    dets = t.postprocess([{"boxes": torch.tensor([[0., 0., 1000., 800.]])}] * 2, il.image_sizes, [(800, 1333), (400, 500)])
+    assert torch.allclose(dets[1]["boxes"], torch.tensor([[0., 0., 500., 400.]]))
+    with pytest.raises(ValueError):
+        t([torch.rand(800, 1333)])
+
+
+def test_hparams_utils_and_lightning_surface():
+    import pytorch_retinanet_amd as P
+    conf = P.load_hparams()
+    assert conf.model.backbone_kind == "resnet50" and conf.optimizer.params.lr == 0.001
+    assert conf.scheduler.monitor == "val_loss" and conf.dataloader.args.num_workers == 0
+    assert P.load_obj("torch.optim.SGD") is torch.optim.SGD
+    with pytest.raises(AttributeError):
+        P.load_obj("torch.optim.NoSuchOptimizer")
+    assert P.collate_fn([(1, "a", 0), (2, "b", 1)]) == ((1, 2), ("a", "b"), (0, 1))
+    conf.model.pretrained = False
+    conf.model.backbone_kind = "resnet18"
+    m = P.RetinaNetModel(conf)
+    for hook in ("forward", "prepare_data", "configure_optimizers", "train_dataloader", "val_dataloader", "test_dataloader",
+                 "training_step", "validation_step", "test_step", "test_epoch_end"):
+        assert callable(getattr(m, hook)), hook
+    opts, scheds = m.configure_optimizers()
+    assert isinstance(opts[0], torch.optim.SGD) and scheds[0]["monitor"] == "val_loss"
+    conf.dataset.kind = "coco"
+    with pytest.raises(NotImplementedError):
+        m.prepare_data()
+    conf.dataset.kind = "synthetic"
+    conf.dataset.length, conf.dataset.height, conf.dataset.width = 4, 64, 96
+    m.prepare_data()
+    img, tgt, idx = m.trn_ds[1]
+    assert img.shape == (3, 64, 96) and tgt["boxes"].shape == (8, 4) and tgt["labels"].min() >= 1
+    batch = next(iter(m.train_dataloader()))
+    assert len(batch) == 3 and len(batch[0]) == 2
+
+
+def test_helper_losses_match_their_definitions():
+    """The stand-alone focal / smooth-L1 helpers keep the reference's definitions (Q2, Q3, Q10)."""
+    import pytorch_retinanet_amd as P
+    crit = P.RetinaNetLosses(3)
+    x = torch.tensor([[0.3, -1.2, 2.0]], requires_grad=True)
+    t = torch.tensor([[1.0, 0.0, 0.0]])
+    loss = crit.focal_loss(x, t)
+    p = torch.sigmoid(x.detach())
+    w = torch.where(t > 0, 0.75 * (1 - p) ** 2, 0.25 * p ** 2)                       # positives get 1-alpha (Q2)
+    ref = (w * torch.nn.functional.binary_cross_entropy_with_logits(x.detach(), t, reduction="none")).sum()
+    assert torch.allclose(loss, ref)
+    loss.backward()
+    assert torch.allclose(x.grad, w * (p - t))                                        # detached weight (Q3)
+    d = torch.tensor([0.05, -0.3])
+    assert torch.allclose(crit.smooth_l1_loss(d, torch.zeros(2)), torch.tensor(0.5 * 0.05 ** 2 / 0.1 + 0.3 - 0.05))
+
+
+@pytest.mark.reference
+def test_conv_stack_equals_reference_with_same_weights():
+    """Live check in the build container: load the reference's state dict into this framework's model and
+    compare head outputs (covers key names, FPN wiring incl. P6-from-C5, head layout)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import _tv_standin
+    R = _tv_standin.import_reference()
+    import pytorch_retinanet_amd as P
+    torch.manual_seed(0)
+    ref = R.Retinanet(num_classes=4, backbone_kind="resnet18", pretrained=False, min_size=96, max_size=128).eval()
+    mine = P.Retinanet(num_classes=4, backbone_kind="resnet18", pretrained=False, min_size=96, max_size=128).eval()
+    assert list(ref.state_dict()) == list(mine.state_dict())
+    mine.load_state_dict(ref.state_dict())
+    imgs = [torch.rand(3, 96, 120), torch.rand(3, 80, 128)]
+    with torch.no_grad():
+        il_r, _ = ref.transform(imgs, None)
+        il_m, _ = mine.transform(imgs, None)
+        assert torch.allclose(il_r.tensors, il_m.tensors, atol=1e-6) and list(il_r.image_sizes) == list(il_m.image_sizes)
+        f_r = ref.fpn(ref.backbone(il_r.tensors))
+        out_r = ref.retinanet_head(f_r)
+        f_m, out_m = mine._features(il_m.tensors)
+    for a, b in zip(f_r, f_m):
+        assert torch.allclose(a, b, atol=1e-5)
+    assert torch.allclose(out_r["cls_preds"], out_m["cls_preds"], atol=1e-5)
+    assert torch.allclose(out_r["bbox_preds"], out_m["bbox_preds"], atol=1e-5)
+    # R50 key parity too (bottleneck blocks)
+    assert list(R.Retinanet(backbone_kind="resnet50", pretrained=False).state_dict()) == \
+        list(P.Retinanet(backbone_kind="resnet50", pretrained=False).state_dict())

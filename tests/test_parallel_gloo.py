@@ -1,0 +1,87 @@
+"""CPU suite: the data-parallel gradient exchange (parallel.BucketedGradAllReduce) with 2 gloo ranks."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model():
+    torch.manual_seed(7)
+    return nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.ReLU(), nn.Conv2d(8, 8, 3, padding=1), nn.ReLU(),
+                         nn.Flatten(), nn.Linear(8 * 6 * 6, 5))
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pytorch_retinanet_amd.parallel import BucketedGradAllReduce
+    model = _model()
+    if rank == 1:                      # start from different weights: sync_parameters must fix that
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    ddp = BucketedGradAllReduce(model, bucket_mb=0.002)      # tiny buckets -> several collectives
+    assert ddp.num_buckets >= 3
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    g = torch.Generator().manual_seed(100)
+    data = torch.randn(3, 4, 3, 6, 6, generator=g)           # [step, global batch 4, ...]
+    tgt = torch.randn(3, 4, 5, generator=g)
+    for step in range(3):
+        x, y = data[step, rank * 2:(rank + 1) * 2], tgt[step, rank * 2:(rank + 1) * 2]
+        ddp.zero_grad() if step != 1 else opt.zero_grad(set_to_none=True)    # both zeroing styles
+        loss = ((model(x) - y) ** 2).mean()
+        loss.backward()
+        ddp.finish()
+        opt.step()
+    torch.save([p.detach().clone() for p in model.parameters()], os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_equals_single_process_global_batch(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    p0 = torch.load(tmp_path / "rank0.pt")
+    p1 = torch.load(tmp_path / "rank1.pt")
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b), "ranks diverged"
+    # single process, whole global batch: mean over 4 samples == average of the two ranks' means over 2
+    model = _model()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    g = torch.Generator().manual_seed(100)
+    data = torch.randn(3, 4, 3, 6, 6, generator=g)
+    tgt = torch.randn(3, 4, 5, generator=g)
+    for step in range(3):
+        opt.zero_grad()
+        ((model(data[step]) - tgt[step]) ** 2).mean().backward()
+        opt.step()
+    for a, b in zip(p0, model.parameters()):
+        assert torch.allclose(a, b.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_bucket_layout_single_process():
+    from pytorch_retinanet_amd.parallel import BucketedGradAllReduce
+    model = _model()
+    ddp = BucketedGradAllReduce(model, bucket_mb=0.002)
+    params = [p for p in model.parameters()]
+    # reverse registration order (~ reverse forward): the last layer's parameters land in the first bucket
+    assert ddp.buckets[0].params[0] is params[-1]
+    assert sum(ddp.bucket_bytes()) == sum(p.numel() * 4 for p in params)
+    for p in params:                       # grads are views into the buckets
+        assert p.grad is not None and p.grad.data_ptr() >= min(b.flat.data_ptr() for b in ddp.buckets)
+    model(torch.randn(2, 3, 6, 6)).sum().backward()
+    ddp.finish()                           # world size 1: no collective, state resets
+    assert all(b.pending == len(b.params) for b in ddp.buckets)
+    ddp.zero_grad()
+    assert all(not b.flat.any() for b in ddp.buckets)
