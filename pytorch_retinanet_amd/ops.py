@@ -81,7 +81,13 @@ def _dtype_code(t: Tensor) -> int:
 
 
 def _c(t: Tensor) -> Tensor:
-    return t if t.is_contiguous() else t.contiguous()
+    """Dense and 16-byte aligned (the kernels use 16-byte vector accesses): views into the middle of a
+    tensor (e.g. ``cls_preds[1]``) are copied to a fresh allocation."""
+    if not t.is_contiguous():
+        return t.contiguous()
+    if t.numel() and t.data_ptr() % 16:
+        return t.clone()
+    return t
 
 
 def _anchor_args(anchors: Tensor, B: int, A: int) -> Tuple[Tensor, int]:

@@ -1,0 +1,123 @@
+"""GPU: the reference's Python surface end to end on the HIP path (autograd, Retinanet, RetinaNetModel)."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _toy(golden):
+    g = golden("loss.npz")
+    gtb = [g["toy_gtb0"], np.zeros((0, 4), np.float32), g["toy_gtb2"]]
+    gtl = [g["toy_gtl0"], np.zeros((0,), np.int64), g["toy_gtl2"]]
+    targets = [{"boxes": torch.from_numpy(b).to(DEV), "labels": torch.from_numpy(l).to(DEV)} for b, l in zip(gtb, gtl)]
+    return g, targets
+
+
+def test_retinanet_losses_module_autograd_matches_reference(golden):
+    """RetinaNetLosses.forward + loss.backward() == the reference's losses and autograd gradients (toy golden)."""
+    import pytorch_retinanet_amd as P
+    g, targets = _toy(golden)
+    cls = torch.from_numpy(g["toy_cls"]).to(DEV).requires_grad_(True)
+    box = torch.from_numpy(g["toy_box"]).to(DEV).requires_grad_(True)
+    anc = torch.from_numpy(g["toy_anchors"]).to(DEV)
+    crit = P.RetinaNetLosses(3)
+    out = crit(targets, {"cls_preds": cls, "bbox_preds": box}, [anc] * 3)
+    assert set(out) == {"classification_loss", "regression_loss"}
+    np.testing.assert_allclose([float(out["classification_loss"]), float(out["regression_loss"])], g["toy_loss"], rtol=1e-5)
+    (out["classification_loss"] + out["regression_loss"]).backward()
+    np.testing.assert_allclose(cls.grad.cpu().numpy(), g["toy_gcls"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(box.grad.cpu().numpy(), g["toy_gbox"], rtol=1e-5, atol=1e-7)
+    # upstream gradients other than 1 (and different per loss) go through the device-side scale
+    cls2 = cls.detach().clone().requires_grad_(True)
+    box2 = box.detach().clone().requires_grad_(True)
+    out = crit(targets, {"cls_preds": cls2, "bbox_preds": box2}, [anc] * 3)
+    (3.0 * out["classification_loss"] - 0.5 * out["regression_loss"]).backward()
+    np.testing.assert_allclose(cls2.grad.cpu().numpy(), 3.0 * g["toy_gcls"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(box2.grad.cpu().numpy(), -0.5 * g["toy_gbox"], rtol=1e-5, atol=1e-7)
+    # calc_loss: one image, returns (bb_loss, clas_loss) like the reference
+    bb, cl = crit.calc_loss(anc, cls.detach()[0], box.detach()[0], targets[0]["labels"], targets[0]["boxes"])
+    np.testing.assert_allclose([float(bb), float(cl)], g["toy_per_image"][0], rtol=1e-5)
+    bb, cl = crit.calc_loss(anc, cls.detach()[1], box.detach()[1], targets[1]["labels"], targets[1]["boxes"])
+    assert float(bb) == 0.0 and float(cl) == 0.0                       # Q7
+
+
+def test_box_utils_surface(golden):
+    import pytorch_retinanet_amd as P
+    g = golden("match.npz")
+    m = P.matcher(torch.from_numpy(g["hand_anchors"]).to(DEV), torch.from_numpy(g["hand_gt"]).to(DEV))
+    assert m.dtype == torch.int64 and m.tolist() == [-2, 2, -2, -1, 0, -2, -1, 2]
+    assert P.matcher(torch.from_numpy(g["hand_anchors"]).to(DEV), torch.zeros((0, 4), device=DEV)).tolist() == [-2] * 8
+    d = golden("decode.npz")
+    dec = P.activ_2_bbox(torch.from_numpy(d["deltas"]).to(DEV), torch.from_numpy(d["anchors"]).to(DEV))
+    np.testing.assert_allclose(dec.cpu().numpy(), d["decoded"], rtol=1e-5, atol=1e-3)
+    enc = P.bbox_2_activ(torch.from_numpy(d["enc_gt"]).to(DEV), torch.from_numpy(d["anchors"]).to(DEV))
+    np.testing.assert_allclose(enc.cpu().numpy(), d["encoded"], rtol=1e-5, atol=1e-6)
+
+
+def test_anchor_generator_module_on_device(golden):
+    import pytorch_retinanet_amd as P
+    from pytorch_retinanet_amd.transform import ImageList
+    g = golden("anchors.npz")
+    ag = P.AnchorGenerator().to(DEV)
+    fmaps = [torch.zeros(2, 256, h, w, device=DEV) for h, w in synth.fpn_grid_sizes(512, 512)]
+    out = ag(ImageList(torch.zeros(2, 3, 512, 512, device=DEV), [(512, 512), (480, 500)]), fmaps)
+    assert len(out) == 2 and out[0] is out[1]                          # one cached tensor per shape set (Q12)
+    assert synth.sha(out[0].cpu().numpy()) == str(g["r18_512_sha"])
+    per_level = ag.grid_anchors([f.shape[-2:] for f in fmaps], torch.device(DEV))
+    assert [p.shape[0] for p in per_level] == [36864, 9216, 2304, 576, 144]
+
+
+def test_retinanet_train_step_and_predict_r18():
+    """BASELINE configs[0] (R18-FPN, 2 x 3x512x512): forward + loss + backward, then predict, on the device."""
+    import pytorch_retinanet_amd as P
+    torch.manual_seed(0)
+    net = P.Retinanet(backbone_kind="resnet18", pretrained=False, min_size=512, max_size=512).to(DEV)
+    net = net.to(memory_format=torch.channels_last).train()
+    rng = np.random.default_rng(0)
+    images = [torch.rand(3, 512, 512, device=DEV) for _ in range(2)]
+    targets = []
+    for T in (2, 1):
+        b, l = synth.gt_boxes(rng, T, 512, 512)
+        targets.append({"boxes": torch.from_numpy(b).to(DEV), "labels": torch.from_numpy(l).to(DEV)})
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = net(images, targets)
+    loss = sum(out.values())
+    loss.backward()
+    assert torch.isfinite(loss) and out["classification_loss"].dtype == torch.float32
+    g = net.retinanet_head.classification_head.class_subnet_output.weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0
+    assert net.backbone.backbone.conv1.weight.grad.abs().sum() > 0
+    net.eval()
+    dets = net.predict(images)
+    assert len(dets) == 2
+    for d in dets:
+        assert d["boxes"].shape[1] == 4 and d["labels"].dtype == torch.int64 and len(d["scores"]) <= 100
+        assert (d["scores"][:-1] >= d["scores"][1:]).all()
+        if len(d["labels"]):
+            assert d["labels"].min() >= 1 and d["labels"].max() <= 90
+    assert net(images) is not None                                     # targets=None -> predict (Q19)
+
+
+def test_lightning_module_with_simple_trainer():
+    import pytorch_retinanet_amd as P
+    conf = P.load_hparams()
+    conf.model.update(backbone_kind="resnet18", pretrained=False, num_classes=5, min_size=128, max_size=160)
+    conf.dataset.kind = "synthetic"
+    conf.dataset.update(length=4, height=128, width=160, boxes_per_image=3)
+    conf.dataloader.train_bs = 2
+    conf.dataloader.valid_bs = 2
+    conf.dataloader.test_bs = 2
+    conf.dataloader.args.pin_memory = False
+    model = P.RetinaNetModel(conf)
+    trainer = P.SimpleTrainer(max_epochs=1, device=DEV)
+    before = model.net.retinanet_head.regression_head.box_subnet_output.weight.detach().clone()
+    steps = trainer.fit(model)
+    assert steps == 2
+    after = model.net.retinanet_head.regression_head.box_subnet_output.weight.detach().cpu()
+    assert not torch.equal(before, after)
+    res, outs = trainer.test(model)
+    assert len(outs) == 2 and all("detections" in o for o in outs)
