@@ -16,6 +16,11 @@ namespace {
 constexpr int MATCH_BLOCK = 256;
 constexpr int GT_TILE = 256;
 
+// IoU of one (GT, anchor) pair, bit-for-bit the CPU sequence.  The IEEE divide is ~15 instructions
+// and dominates the kernel, but most pairs do not overlap: when NO lane of the wave has a non-zero
+// (or NaN) intersection the quotient is known without dividing -- 0/uni is +-0 for uni != 0 (the sign
+// never matters to the comparisons below) and NaN for uni == 0 or NaN -- so the divide sits behind a
+// wave-uniform branch.
 __device__ __forceinline__ float iou_pair(const rn::f32x4 t, const float area_t, const rn::f32x4 a, const float area_a)
 {
     const float ltx = t.x > a.x ? t.x : a.x;
@@ -28,7 +33,8 @@ __device__ __forceinline__ float iou_pair(const rn::f32x4 t, const float area_t,
     if (!(h > 0.0f)) h = (h != h) ? h : 0.0f;
     const float inter = w * h;
     const float uni = (area_t + area_a) - inter;
-    return inter / uni;
+    if (__any(inter != 0.0f)) return inter / uni;          // (NaN != 0) is true: NaN takes the exact path
+    return (uni != 0.0f && uni == uni) ? 0.0f : __builtin_nanf("");
 }
 
 __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_kernel(
