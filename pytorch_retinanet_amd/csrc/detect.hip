@@ -74,79 +74,88 @@ __global__ __launch_bounds__(256) void decode_clip_kernel(const void *__restrict
 
 
 // ---- K5 score scan + candidate compaction ---------------------------------------
-// Streams the class logits once (A*K*s bytes per image, 16-byte loads).  An element is
-// a candidate when sigmoid(x) > score_thr (models.py:196) and its decoded box passes
-// remove_small_boxes (models.py:203; boxes are per anchor, so the size test commutes
-// with the per-class loop).  Candidates (~4e-4 of the elements at the reference's
-// prior) are staged in LDS and flushed with ONE global atomic per (block, image).
+// Streams the class logits once (A*K*s bytes per image, 16-byte non-temporal loads, two groups in
+// flight per wave; each wave owns one contiguous range of the flattened tensor).  An element is a
+// candidate when sigmoid(x) > score_thr (models.py:196) and its decoded box passes
+// remove_small_boxes (models.py:203; boxes are per anchor, so the size test commutes with the
+// per-class loop).  Candidates (~4e-4 of the elements at the reference's prior) are staged in a
+// wave-private LDS list and flushed with ONE global atomic per (wave, image): no block barrier
+// anywhere in the stream.
 constexpr int SCAN_THREADS = 256;
-constexpr int SCAN_CAP = 2560;   // > SCAN_THREADS*8 (one iteration's worst case) with room to batch flushes
+constexpr int SCAN_WAVES = SCAN_THREADS / RN_WAVE;
+constexpr int SCAN_CAP = 128;            // wave-private list entries (>= 64: one ballot's worth always fits after a flush)
+constexpr int SCAN_PF = 2;
 
 struct ScanArgs {
     const void *cls;
     const rn::f32x4 *boxes;
-    int64_t A, R, rows_per_block, C;
+    int64_t A, N, vec_per_wave, C;
     int32_t K, B;
-    uint32_t magicK;
     float score_thr, pre_thr, min_box;
     uint64_t *cand;          // [B][C]  (inv_ordered(score) << 32) | (anchor*K + k)
     int32_t *cand_count;     // [B]
     int32_t *seg_count;      // [B][K]
 };
 
-struct ScanShared {
-    uint64_t key[SCAN_CAP];
-    uint16_t img[SCAN_CAP];
-    int count, nb, base, fill;
-};
+struct ScanList { uint64_t key[SCAN_CAP]; int img[SCAN_CAP]; };
 
-__device__ __forceinline__ void scan_flush(ScanShared &sh, const ScanArgs &a, const int b_lo, const int b_hi)
+// wave-level flush: one atomic per distinct image in the list
+__device__ __forceinline__ void scan_flush(ScanList &sl, const int fill, const ScanArgs &a, const int lane)
 {
-    __syncthreads();
-    const int n = min(sh.count, SCAN_CAP);
-    for (int b = b_lo; b <= b_hi; ++b) {
-        if (threadIdx.x == 0) { sh.nb = 0; sh.fill = 0; }
-        __syncthreads();
-        int local = 0;
-        for (int i = threadIdx.x; i < n; i += SCAN_THREADS) local += (sh.img[i] == (uint16_t)(b - b_lo)) ? 1 : 0;
-        if (local) atomicAdd(&sh.nb, local);
-        __syncthreads();
-        if (threadIdx.x == 0) sh.base = sh.nb ? atomicAdd(&a.cand_count[b], sh.nb) : 0;
-        __syncthreads();
-        const int base = sh.base;
-        for (int i = threadIdx.x; i < n; i += SCAN_THREADS) {
-            if (sh.img[i] != (uint16_t)(b - b_lo)) continue;
-            const int64_t pos = (int64_t)base + atomicAdd(&sh.fill, 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    bool done0 = lane >= fill, done1 = lane + RN_WAVE >= fill;                 // entries lane, lane+64
+    const uint64_t k0 = done0 ? 0 : sl.key[lane], k1 = done1 ? 0 : sl.key[lane + RN_WAVE];
+    const int b0 = done0 ? -1 : sl.img[lane], b1 = done1 ? -1 : sl.img[lane + RN_WAVE];
+    while (true) {
+        const unsigned long long pend = __ballot(!done0 || !done1);
+        if (!pend) break;
+        const int src = __ffsll((long long)pend) - 1;
+        const int bsel_local = !done0 ? b0 : b1;
+        const int b = __shfl(bsel_local, src, RN_WAVE);                        // image handled this round (wave-uniform)
+        const bool m0 = !done0 && b0 == b, m1 = !done1 && b1 == b;
+        const unsigned long long mk0 = __ballot(m0), mk1 = __ballot(m1);
+        const int n0 = __popcll(mk0), n = n0 + __popcll(mk1);
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&a.cand_count[b], n);
+        base = __shfl(base, 0, RN_WAVE);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        if (m0) {
+            const int64_t pos = (int64_t)base + __popcll(mk0 & lt);
             if (pos < a.C) {
-                const uint64_t key = sh.key[i];
-                a.cand[(int64_t)b * a.C + pos] = key;
-                atomicAdd(&a.seg_count[(int64_t)b * a.K + (int)((uint32_t)key % (uint32_t)a.K)], 1);
+                a.cand[(int64_t)b * a.C + pos] = k0;
+                atomicAdd(&a.seg_count[(int64_t)b * a.K + (int)((uint32_t)k0 % (uint32_t)a.K)], 1);
             }
+            done0 = true;
         }
-        __syncthreads();
+        if (m1) {
+            const int64_t pos = (int64_t)base + n0 + __popcll(mk1 & lt);
+            if (pos < a.C) {
+                a.cand[(int64_t)b * a.C + pos] = k1;
+                atomicAdd(&a.seg_count[(int64_t)b * a.K + (int)((uint32_t)k1 % (uint32_t)a.K)], 1);
+            }
+            done1 = true;
+        }
     }
-    if (threadIdx.x == 0) sh.count = 0;
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ void scan_elem(ScanShared &sh, const ScanArgs &a, const float x, const uint32_t le,
-                                          const int64_t r0, const int b_lo)
+// exact candidate test of one element (rare path)
+__device__ __forceinline__ bool scan_test(const ScanArgs &a, const float x, const int64_t e, uint64_t &key, int &img)
 {
-    if (!(x > a.pre_thr)) return;
     const float s = 1.0f / (1.0f + expf(-x));                 // models.py:170
-    if (!(s > a.score_thr)) return;
-    const uint32_t row = (a.K == 1) ? le : __umulhi(le, a.magicK);
-    const uint32_t k = le - row * (uint32_t)a.K;
-    const int64_t r = r0 + row;
+    if (!(s > a.score_thr)) return false;
+    const int64_t r = e / a.K;
+    const uint32_t k = (uint32_t)(e - r * a.K);
     const int b = (int)((uint32_t)r / (uint32_t)a.A);
     const uint32_t anchor = (uint32_t)(r - (int64_t)b * a.A);
     const rn::f32x4 bx = a.boxes[r];
-    if (!((bx.z - bx.x) >= a.min_box && (bx.w - bx.y) >= a.min_box)) return;
-    const int idx = atomicAdd(&sh.count, 1);
-    if (idx < SCAN_CAP) {
-        sh.key[idx] = ((uint64_t)rn::inv_ordered(s) << 32) | (uint32_t)(anchor * (uint32_t)a.K + k);
-        sh.img[idx] = (uint16_t)(b - b_lo);
-    }
+    if (!((bx.z - bx.x) >= a.min_box && (bx.w - bx.y) >= a.min_box)) return false;
+    key = ((uint64_t)rn::inv_ordered(s) << 32) | (uint32_t)(anchor * (uint32_t)a.K + k);
+    img = b;
+    return true;
 }
 
 template <int DT>
@@ -154,35 +163,86 @@ __global__ __launch_bounds__(SCAN_THREADS) void score_scan_kernel(const ScanArgs
 {
     typedef rn::dt<DT> D;
     constexpr int VEC = D::VEC;
-    __shared__ ScanShared sh;
-    const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
-    const int64_t r1 = min(r0 + a.rows_per_block, a.R);
-    if (r0 >= r1) return;
-    const int b_lo = (int)((uint32_t)r0 / (uint32_t)a.A), b_hi = (int)((uint32_t)(r1 - 1) / (uint32_t)a.A);
-    if (threadIdx.x == 0) sh.count = 0;
-    __syncthreads();
-    const int64_t e0 = r0 * a.K;
-    const uint32_t ne = (uint32_t)((r1 - r0) * a.K);
-    const uint32_t nvec = ne / VEC;
-    const rn::u32x4 *src = (const rn::u32x4 *)((const typename D::elem *)a.cls + e0);
-    const rn::u32x4 zero4 = {0u, 0u, 0u, 0u};
-    rn::u32x4 nxt = (threadIdx.x < nvec) ? src[threadIdx.x] : zero4;
-    for (uint32_t vb = 0; vb < nvec; vb += SCAN_THREADS) {          // block-uniform trip count
-        const uint32_t v = vb + threadIdx.x;
-        const rn::u32x4 raw = nxt;
-        nxt = (v + SCAN_THREADS < nvec) ? src[v + SCAN_THREADS] : zero4;
-        if (v < nvec) {
-            float x[VEC];
-            D::unpack(raw, x);
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) scan_elem(sh, a, x[j], v * VEC + j, r0, b_lo);
+    __shared__ ScanList s_list[SCAN_WAVES];
+    const int lane = threadIdx.x & (RN_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    ScanList &sl = s_list[wave];
+    const int64_t gwave = (int64_t)blockIdx.x * SCAN_WAVES + wave;
+    const int64_t nvec = a.N / VEC;
+    const int64_t v_beg = gwave * a.vec_per_wave;
+    const int64_t v_end = min(v_beg + a.vec_per_wave, nvec);
+    const rn::u32x4 *src = (const rn::u32x4 *)a.cls;
+    int fill = 0;                                              // wave-uniform
+
+    // append the candidates selected by `pred` (at most one per lane): ballot, maybe flush, write
+    auto append = [&](const bool pred, const uint64_t key, const int img) {
+        const unsigned long long mk = __ballot(pred);
+        if (!mk) return;
+        const int n = __popcll(mk);
+        if (fill + n > SCAN_CAP) { scan_flush(sl, fill, a, lane); fill = 0; }
+        if (pred) {
+            const int pos = fill + __popcll(mk & ((1ull << lane) - 1ull));
+            sl.key[pos] = key; sl.img[pos] = img;
         }
-        __syncthreads();
-        if (sh.count > SCAN_CAP - SCAN_THREADS * VEC) scan_flush(sh, a, b_lo, b_hi);   // uniform decision
+        fill += n;
+    };
+    auto do_vec = [&](const rn::u32x4 raw, const int64_t v) {
+        float x[VEC];
+        D::unpack(raw, x);
+        bool any_lane = false;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) any_lane |= (x[j] > a.pre_thr);
+        if (__any(any_lane)) {                                // rare: ~0.2 candidates per 512 elements
+#pragma unroll 1
+            for (int j = 0; j < VEC; ++j) {
+                uint64_t key = 0; int img = 0;
+                const bool c = (x[j] > a.pre_thr) && scan_test(a, x[j], v * VEC + j, key, img);
+                append(c, key, img);
+            }
+        }
+    };
+
+    if (v_beg < v_end) {
+        const int64_t last = v_end - 1;
+        const int64_t groups = (v_end - v_beg) / (SCAN_PF * RN_WAVE);
+        rn::u32x4 q[SCAN_PF];
+#pragma unroll
+        for (int u = 0; u < SCAN_PF; ++u) q[u] = __builtin_nontemporal_load(&src[min(v_beg + u * RN_WAVE + lane, last)]);
+        int64_t v0 = v_beg;
+        for (int64_t gi = 0; gi < groups; ++gi, v0 += SCAN_PF * RN_WAVE) {
+            rn::u32x4 qn[SCAN_PF];
+#pragma unroll
+            for (int u = 0; u < SCAN_PF; ++u) qn[u] = __builtin_nontemporal_load(&src[min(v0 + (SCAN_PF + u) * RN_WAVE + lane, last)]);
+#pragma unroll
+            for (int u = 0; u < SCAN_PF; ++u) do_vec(q[u], v0 + u * RN_WAVE + lane);
+#pragma unroll
+            for (int u = 0; u < SCAN_PF; ++u) q[u] = qn[u];
+        }
+        for (int64_t vb = v0; vb < v_end; vb += RN_WAVE) {           // leftover iterations (wave-uniform trip count)
+            const int64_t v = vb + lane;
+            const rn::u32x4 zero4 = {0u, 0u, 0u, 0u};
+            rn::u32x4 raw = (v < v_end) ? src[v] : zero4;
+            if (v >= v_end) {                                         // lanes past the end must not produce candidates
+                float lowv[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) lowv[j] = -INFINITY;
+                raw = D::pack(lowv);
+            }
+            do_vec(raw, min(v, last));
+        }
     }
-    const uint32_t le = nvec * VEC + threadIdx.x;                      // ragged tail (< VEC elements)
-    if (le < ne) scan_elem(sh, a, D::ld(a.cls, e0 + le), le, r0, b_lo);
-    scan_flush(sh, a, b_lo, b_hi);
+    // ragged tail of the tensor (< VEC elements): the wave that ends at nvec (or wave 0 when there are no full vectors)
+    if ((v_beg < v_end && v_end == nvec) || (nvec == 0 && gwave == 0)) {
+        const int64_t e = nvec * VEC + lane;
+        uint64_t key = 0; int img = 0;
+        bool c = false;
+        if (lane < VEC && e < a.N) {
+            const float x = D::ld(a.cls, e);
+            c = (x > a.pre_thr) && scan_test(a, x, e, key, img);
+        }
+        append(c, key, img);
+    }
+    if (fill) scan_flush(sl, fill, a, lane);
 }
 
 // ---- per-image segment offsets -----------------------------------------------------
@@ -224,63 +284,136 @@ __global__ __launch_bounds__(256) void seg_scatter_kernel(const uint64_t *__rest
 // key (inv score << 32 | class*A + anchor) reproduces it.  Only the first max_det survivors of
 // each class can reach the global top max_det.
 constexpr int TOPK_THREADS = 1024;
-constexpr int TOPK_CAP = 4096;
+constexpr int TOPK_CHUNK = 1024;          // keys sorted together (one per thread)
+constexpr int TOPK_GROUP = 4;             // chunks resident at once (one key per thread per chunk, in registers)
+constexpr int TOPK_SURV = 2048;           // survivors (top max_det of every chunk so far)
+constexpr int TOPK_MAXK = 4096;
 
+__device__ __forceinline__ uint64_t shfl_xor_u64(const uint64_t v, const int j)
+{
+    const uint32_t lo = __shfl_xor((uint32_t)v, j, RN_WAVE), hi = __shfl_xor((uint32_t)(v >> 32), j, RN_WAVE);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Ascending bitonic sort of NPT*1024 keys held in registers, key r of thread t = element r*1024 + t.
+// JOINT = false: NPT independent 1024-element arrays; JOINT = true: one NPT*1024-element array.
+// Exchange distance j < 64 stays inside a wave (shuffles, no LDS, no barrier); 64 <= j < 1024 goes
+// through LDS (two block barriers); j >= 1024 pairs two registers of the same thread.
+template <int NPT, bool JOINT>
+__device__ __forceinline__ void bitonic_regs(uint64_t (&k)[NPT], uint64_t *lds)
+{
+    const int t = threadIdx.x;
+    constexpr int N = JOINT ? NPT * TOPK_CHUNK : TOPK_CHUNK;
+    for (int kk = 2; kk <= N; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            if (j >= TOPK_CHUNK) {                      // JOINT only: partner is another register of this thread
+#pragma unroll
+                for (int r = 0; r < NPT; ++r) {
+                    const int pr = r ^ (j / TOPK_CHUNK);
+                    if (pr > r) {
+                        const bool up = (((r * TOPK_CHUNK + t) & kk) == 0);
+                        const uint64_t x = k[r], y = k[pr];
+                        if ((x > y) == up) { k[r] = y; k[pr] = x; }
+                    }
+                }
+            } else if (j >= RN_WAVE) {
+#pragma unroll
+                for (int r = 0; r < NPT; ++r) lds[r * TOPK_CHUNK + t] = k[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < NPT; ++r) {
+                    const int e = (JOINT ? r * TOPK_CHUNK : 0) + t;
+                    const uint64_t y = lds[r * TOPK_CHUNK + (t ^ j)];
+                    const bool keep_min = (((t & j) == 0) == ((e & kk) == 0));
+                    k[r] = keep_min ? (k[r] < y ? k[r] : y) : (k[r] > y ? k[r] : y);
+                }
+                __syncthreads();
+            } else {
+#pragma unroll
+                for (int r = 0; r < NPT; ++r) {
+                    const int e = (JOINT ? r * TOPK_CHUNK : 0) + t;
+                    const uint64_t y = shfl_xor_u64(k[r], j);
+                    const bool keep_min = (((t & j) == 0) == ((e & kk) == 0));
+                    k[r] = keep_min ? (k[r] < y ? k[r] : y) : (k[r] > y ? k[r] : y);
+                }
+            }
+        }
+    }
+}
+
+// One workgroup per image.  Counts / offsets of all classes are fetched in parallel (one latency),
+// the first max_det survivors of every class are gathered by flat index, sorted 1024 at a time, and
+// only the best max_det of every chunk survive to the final sort: O(M log^2 1024) instead of
+// O(M log^2 M), for any number of candidates M.
 __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const uint64_t *__restrict__ kept, const int64_t *__restrict__ seg_start,
                                                             const int32_t *__restrict__ kept_count, const rn::f32x4 *__restrict__ boxes,
                                                             const int K, const int64_t A, const int max_det,
                                                             rn::f32x4 *__restrict__ out_boxes, float *__restrict__ out_scores,
                                                             int64_t *__restrict__ out_labels, int32_t *__restrict__ out_count)
 {
-    __shared__ uint64_t s_key[TOPK_CAP];
+    __shared__ uint64_t s_key[TOPK_GROUP * TOPK_CHUNK];      // exchange buffer of the sorts
+    __shared__ uint64_t s_surv[TOPK_SURV];
+    __shared__ int s_pre[TOPK_MAXK + 1];       // exclusive prefix of min(kept_count, max_det) over classes
     const int b = blockIdx.x;
-    int cur = 0;
-    for (int k = 0; k < K; ++k) {
-        const int m = min(kept_count[(int64_t)b * K + k], max_det);
-        if (m == 0) continue;
-        if (cur + m > TOPK_CAP) {            // compact to the best max_det so far (uniform branch)
-            __syncthreads();
-            for (int i = cur + threadIdx.x; i < TOPK_CAP; i += TOPK_THREADS) s_key[i] = ~0ull;
-            __syncthreads();
-            for (int kk = 2; kk <= TOPK_CAP; kk <<= 1)
-                for (int j = kk >> 1; j > 0; j >>= 1) {
-                    for (int i = threadIdx.x; i < TOPK_CAP; i += TOPK_THREADS) {
-                        const int p = i ^ j;
-                        if (p > i) {
-                            const uint64_t x = s_key[i], y = s_key[p];
-                            if ((x > y) == ((i & kk) == 0)) { s_key[i] = y; s_key[p] = x; }
-                        }
-                    }
-                    __syncthreads();
-                }
-            cur = min(cur, max_det);
-        }
-        const int64_t st = seg_start[(int64_t)b * K + k];
-        for (int i = threadIdx.x; i < m; i += TOPK_THREADS) {
-            const uint64_t key = kept[st + i];
-            s_key[cur + i] = (key & 0xffffffff00000000ull) | (uint32_t)((uint32_t)k * (uint32_t)A + (uint32_t)key);
-        }
-        cur += m;
+    const int t = threadIdx.x;
+
+    for (int k = t; k < K; k += TOPK_THREADS) s_pre[k + 1] = min(kept_count[(int64_t)b * K + k], max_det);
+    if (t == 0) s_pre[0] = 0;
+    __syncthreads();
+    if (t == 0) {
+        int run = 0;
+        for (int k = 1; k <= K; ++k) { run += s_pre[k]; s_pre[k] = run; }
     }
+    for (int i = t; i < TOPK_SURV; i += TOPK_THREADS) s_surv[i] = ~0ull;
     __syncthreads();
-    for (int i = cur + threadIdx.x; i < TOPK_CAP; i += TOPK_THREADS) s_key[i] = ~0ull;
-    __syncthreads();
-    for (int kk = 2; kk <= TOPK_CAP; kk <<= 1)
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < TOPK_CAP; i += TOPK_THREADS) {
-                const int p = i ^ j;
-                if (p > i) {
-                    const uint64_t x = s_key[i], y = s_key[p];
-                    if ((x > y) == ((i & kk) == 0)) { s_key[i] = y; s_key[p] = x; }
-                }
+    const int M = s_pre[K];
+    int n_surv = 0;
+
+    // chunks per round: (1 + group) * max_det survivors must fit in s_surv (max_det <= 1024 -> group >= 1)
+    const int group = max(1, min(TOPK_GROUP, TOPK_SURV / max_det - 1));
+    for (int g0 = 0; g0 < M; g0 += group * TOPK_CHUNK) {
+        const int n_here = min(group * TOPK_CHUNK, M - g0);
+        const int n_chunks = (n_here + TOPK_CHUNK - 1) / TOPK_CHUNK;
+        uint64_t kr[TOPK_GROUP];
+#pragma unroll
+        for (int r = 0; r < TOPK_GROUP; ++r) {
+            kr[r] = ~0ull;
+            const int i = r * TOPK_CHUNK + t;
+            if (i < n_here) {
+                const int f = g0 + i;
+                int lo = 0, hi = K;                                 // class k with s_pre[k] <= f < s_pre[k+1]
+                while (hi - lo > 1) { const int md = (lo + hi) >> 1; if (s_pre[md] <= f) lo = md; else hi = md; }
+                const uint64_t key = kept[seg_start[(int64_t)b * K + lo] + (f - s_pre[lo])];
+                kr[r] = (key & 0xffffffff00000000ull) | (uint32_t)((uint32_t)lo * (uint32_t)A + (uint32_t)key);
             }
+        }
+        bitonic_regs<TOPK_GROUP, false>(kr, s_key);
+        if (n_surv + n_chunks * max_det > TOPK_SURV) {              // uniform: compact the survivors first
+            uint64_t sr[2] = {s_surv[t], s_surv[TOPK_CHUNK + t]};
+            __syncthreads();
+            bitonic_regs<2, true>(sr, s_key);
+            s_surv[t] = (t < max_det) ? sr[0] : ~0ull;
+            s_surv[TOPK_CHUNK + t] = ~0ull;
+            n_surv = min(n_surv, max_det);
             __syncthreads();
         }
-    const int nout = min(cur, max_det);
-    for (int i = threadIdx.x; i < max_det; i += TOPK_THREADS) {
-        const int64_t o = (int64_t)b * max_det + i;
-        if (i < nout) {
-            const uint64_t key = s_key[i];
+        if (t < max_det) {
+#pragma unroll
+            for (int r = 0; r < TOPK_GROUP; ++r)
+                if (r < n_chunks) s_surv[n_surv + r * max_det + t] = kr[r];      // padded slots carry ~0 and sort to the end
+        }
+        n_surv += n_chunks * max_det;
+        __syncthreads();
+    }
+    uint64_t sr[2] = {s_surv[t], s_surv[TOPK_CHUNK + t]};
+    __syncthreads();
+    bitonic_regs<2, true>(sr, s_key);
+
+    const int nout = min(M, max_det);
+    if (t < max_det) {
+        const int64_t o = (int64_t)b * max_det + t;
+        if (t < nout) {
+            const uint64_t key = sr[0];                              // max_det <= 1024: the winners are elements 0..1023
             const uint32_t ka = (uint32_t)key;
             const uint32_t k = ka / (uint32_t)A, anchor = ka - k * (uint32_t)A;
             out_boxes[o] = boxes[(int64_t)b * A + anchor];
@@ -291,7 +424,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const uint64_t *__re
             out_boxes[o] = z; out_scores[o] = 0.0f; out_labels[o] = 0;
         }
     }
-    if (threadIdx.x == 0) out_count[b] = nout;
+    if (t == 0) out_count[b] = nout;
 }
 
 size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -383,8 +516,7 @@ RN_API int rn_detect(const void *cls, const void *deltas, int dtype, int B, int6
     RN_HIP(hipMemsetAsync(w.cand_count, 0, w.zero_bytes, st));
 
     ScanArgs sa;
-    sa.cls = cls; sa.boxes = w.boxes; sa.A = A; sa.R = R; sa.C = C; sa.K = K; sa.B = B;
-    sa.magicK = (K > 1) ? (uint32_t)(((uint64_t)1 << 32) / (uint64_t)K) + 1u : 0u;
+    sa.cls = cls; sa.boxes = w.boxes; sa.A = A; sa.N = R * K; sa.C = C; sa.K = K; sa.B = B;
     sa.score_thr = params->score_thr;
     sa.min_box = params->min_box;
     {   // logit-space pre-filter with a safety margin; the exact test is still sigmoid(x) > thr
@@ -393,18 +525,31 @@ RN_API int rn_detect(const void *cls, const void *deltas, int dtype, int B, int6
         if (t >= 1.0) sa.pre_thr = INFINITY;
     }
     sa.cand = w.cand; sa.cand_count = w.cand_count; sa.seg_count = w.seg_count;
-    // contiguous multiple-of-8 row ranges per block; few enough rows that <= 65535 images... and magic-div range holds
-    int64_t rpb = (R + 4095) / 4096;
-    rpb = ((rpb + 7) / 8) * 8;
-    const int64_t max_rpb = (((int64_t)1 << 32) / ((int64_t)K * K)) & ~(int64_t)7;   // le < 2^32/K for the magic divide
-    if (rpb > max_rpb) rpb = max_rpb > 8 ? max_rpb : 8;
-    sa.rows_per_block = rpb;
-    const unsigned blocks = (unsigned)((R + rpb - 1) / rpb);
-    if ((rpb + A - 1) / A + 1 > 65535) return RN_EUNSUPPORTED;
+    // resident-sized grid, even split of the 16-byte vectors over the waves (whole wave-iterations)
+    int dev = 0, cus = 0, per_cu = 0;
+    RN_HIP(hipGetDevice(&dev));
+    RN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int vec = (dtype == RN_F32) ? 4 : 8;
+    const int64_t nvec = sa.N / vec;
+    unsigned blocks = 1;
+    auto size_grid = [&](auto kernel) -> int {
+        RN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, SCAN_THREADS, 0));
+        const int64_t waves = (int64_t)(cus * per_cu > 0 ? cus * per_cu : 1) * SCAN_WAVES;
+        int64_t vpw = (nvec + waves - 1) / waves;
+        vpw = ((vpw + RN_WAVE - 1) / RN_WAVE) * RN_WAVE;
+        if (vpw < RN_WAVE) vpw = RN_WAVE;
+        sa.vec_per_wave = vpw;
+        int64_t need = ((nvec + vpw - 1) / vpw + SCAN_WAVES - 1) / SCAN_WAVES;
+        blocks = (unsigned)(need < 1 ? 1 : need);
+        return RN_OK;
+    };
     switch (dtype) {
-        case RN_F32: hipLaunchKernelGGL((score_scan_kernel<RN_F32>), dim3(blocks), dim3(SCAN_THREADS), 0, st, sa); break;
-        case RN_BF16: hipLaunchKernelGGL((score_scan_kernel<RN_BF16>), dim3(blocks), dim3(SCAN_THREADS), 0, st, sa); break;
-        case RN_F16: hipLaunchKernelGGL((score_scan_kernel<RN_F16>), dim3(blocks), dim3(SCAN_THREADS), 0, st, sa); break;
+        case RN_F32: rc = size_grid(score_scan_kernel<RN_F32>); if (rc) return rc;
+            hipLaunchKernelGGL((score_scan_kernel<RN_F32>), dim3(blocks), dim3(SCAN_THREADS), 0, st, sa); break;
+        case RN_BF16: rc = size_grid(score_scan_kernel<RN_BF16>); if (rc) return rc;
+            hipLaunchKernelGGL((score_scan_kernel<RN_BF16>), dim3(blocks), dim3(SCAN_THREADS), 0, st, sa); break;
+        case RN_F16: rc = size_grid(score_scan_kernel<RN_F16>); if (rc) return rc;
+            hipLaunchKernelGGL((score_scan_kernel<RN_F16>), dim3(blocks), dim3(SCAN_THREADS), 0, st, sa); break;
         default: return RN_EINVAL;
     }
     RN_LAUNCH_CHECK();
