@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--backbone", default="resnet50")
     ap.add_argument("--gt", type=int, default=8, help="GT boxes per image")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-ddp", action="store_true", help="use the bucketed all-reduce path even at world size 1 (validation)")
     ap.add_argument("--cpu-baseline-reps", type=int, default=3)
     return ap.parse_args()
 
@@ -101,7 +102,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the dense-head path)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_ddp:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
     if args.gpus != world and rank == 0:
         print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
@@ -115,7 +118,7 @@ def main():
     net = P.Retinanet(num_classes=90, backbone_kind=args.backbone, pretrained=False, min_size=800, max_size=1333)
     net = net.to(device).to(memory_format=torch.channels_last).train()
     optimizer = torch.optim.SGD(net.parameters(), lr=1e-3, weight_decay=1e-3, momentum=0.9)   # hparams.yaml:63-68
-    ddp = P.BucketedGradAllReduce(net) if world > 1 else None
+    ddp = P.BucketedGradAllReduce(net) if (world > 1 or args.force_ddp) else None
     images, targets = synth_batch(args.batch, args.gt, seed=rank, device=device)
 
     def step():
@@ -189,7 +192,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, A, K)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

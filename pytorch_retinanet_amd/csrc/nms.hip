@@ -8,19 +8,21 @@
 //   inter / ((area_i + area_j) - inter) > thr,  w = max(0, xx2 - xx1), h likewise,
 // fp32, IEEE divide, no FMA contraction (file compiled with -ffp-contract=off).
 //
-// Layout: a segment's 64-bit keys (inverted ordered score << 32 | payload) are
-// sorted in LDS with a bitonic network (keys are unique, so "stable" = key order),
-// boxes are gathered once into LDS, and the suppression flags live in LDS; the
-// greedy loop costs one workgroup barrier per KEPT box.  Segments longer than
-// 2048 entries fall back to an LDS-chunk sort + in-HBM merge passes and HBM-resident
-// boxes/flags (correct for any length; slower).
+// Three size classes, all launched over every segment (a block exits at once when the segment
+// is not in its class):
+//   n <= 256   nms_mask_kernel: rank sort, pairwise suppression matrix as 64-bit ballot words in
+//              LDS, register-resident scan -- no serial loop over boxes except 4-word ORs.
+//   n <= 2048  nms_lds_kernel: bitonic sort of the 64-bit keys in LDS (keys are unique, so
+//              "stable" = key order), boxes gathered once into LDS, greedy loop with one
+//              workgroup barrier per KEPT box.
+//   larger     nms_big_kernel: LDS-chunk sort + in-HBM merge passes, HBM-resident boxes/flags
+//              (correct for any length; slower).
 #include "rn_internal.hpp"
 
 namespace {
 
 using rn::f32x4;
 
-constexpr int SMALL_CAP = 512;     // one wave per segment, 14.5 KiB LDS -> many segments per CU
 constexpr int MED_CAP = 2048;      // 256 threads, 58 KiB LDS
 constexpr int BIG_THREADS = 1024;
 
@@ -130,6 +132,108 @@ __global__ __launch_bounds__(THREADS) void nms_lds_kernel(const rn::NmsLaunch a,
     if (threadIdx.x == 0) a.kept_count[s] = total;
 }
 
+// Segments of up to MASK_CAP entries (the common case: ~100 candidates per (image, class) at the
+// reference's prior): rank sort, the full pairwise suppression matrix as 64-bit ballot words, then
+// a register-resident scan.  Nothing in it is serial except the n-step scan of 4 words.
+constexpr int MASK_CAP = 256;
+constexpr int MASK_WORDS = MASK_CAP / 64;
+
+__global__ __launch_bounds__(MASK_CAP) void nms_mask_kernel(const rn::NmsLaunch a)
+{
+    __shared__ uint64_t s_in[MASK_CAP];
+    __shared__ uint64_t s_key[MASK_CAP];
+    __shared__ f32x4 s_box[MASK_CAP];
+    __shared__ float s_area[MASK_CAP];
+    __shared__ uint64_t s_mask[MASK_CAP][MASK_WORDS];
+    __shared__ uint64_t s_keep[MASK_WORDS];
+
+    const int s = blockIdx.x;
+    const int n = a.seg_len[s];
+    if (n > MASK_CAP) return;
+    if (n == 0) {
+        if (threadIdx.x == 0) a.kept_count[s] = 0;
+        return;
+    }
+    const int t = threadIdx.x;
+    const int lane = t & (RN_WAVE - 1), wave = t >> 6;
+    const int64_t start = a.seg_start[s];
+    const int64_t box_base = a.box_mode ? (int64_t)(s / a.K) * a.A : start;
+
+    const uint64_t key = (t < n) ? a.keys[start + t] : ~0ull;
+    s_in[t] = key;
+    __syncthreads();
+    if (t < n) {                                       // rank sort: keys are unique
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += (s_in[j] < key) ? 1 : 0;
+        s_key[rank] = key;
+    }
+    __syncthreads();
+    if (t < n) {
+        const f32x4 b = a.boxes[box_base + (uint32_t)s_key[t]];
+        s_box[t] = b;
+        s_area[t] = (b.z - b.x) * (b.w - b.y);
+    }
+    __syncthreads();
+    // suppression matrix: bit j of s_mask[i][w] (j = 64w + bit) <=> j > i and IoU(i, j) > thr
+    const int nw = (n + 63) >> 6;
+    for (int i = wave; i < n; i += MASK_CAP / RN_WAVE) {
+        const f32x4 bi = s_box[i];
+        const float ai = s_area[i];
+        for (int w = 0; w < nw; ++w) {
+            const int j = w * 64 + lane;
+            bool sup = false;
+            if (j > i && j < n) sup = overlaps(bi, ai, s_box[j], s_area[j], a.iou_thr);
+            const unsigned long long m = __ballot(sup);
+            if (lane == 0) s_mask[i][w] = m;
+        }
+    }
+    __syncthreads();
+    // greedy scan: every lane of wave 0 carries the same 4-word "removed" set (no cross-lane traffic)
+    if (wave == 0) {
+        uint64_t rem[MASK_WORDS];
+#pragma unroll
+        for (int w = 0; w < MASK_WORDS; ++w) rem[w] = 0;
+#pragma unroll
+        for (int w = 0; w < MASK_WORDS; ++w) {
+            const int i0 = w * 64;
+            if (i0 < n) {
+                const int cnt = min(64, n - i0);
+                for (int bit = 0; bit < cnt; ++bit) {
+                    const int i = i0 + bit;
+                    if (!((rem[w] >> bit) & 1ull)) {
+#pragma unroll
+                        for (int ww = 0; ww < MASK_WORDS; ++ww)
+                            if (ww >= w && ww < nw) rem[ww] |= s_mask[i][ww];
+                    }
+                }
+            }
+        }
+        if (lane < MASK_WORDS) {
+            uint64_t r = 0;
+#pragma unroll
+            for (int w = 0; w < MASK_WORDS; ++w) if (lane == w) r = rem[w];
+            const int lo = lane * 64;
+            const uint64_t valid = (n - lo >= 64) ? ~0ull : ((n - lo > 0) ? ((1ull << (n - lo)) - 1ull) : 0ull);
+            s_keep[lane] = ~r & valid;
+        }
+    }
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < MASK_WORDS; ++w) {
+        const int c = __popcll(s_keep[w]);
+        if (w < wave) before += c;
+        total += c;
+    }
+    const uint64_t mine = s_keep[wave];
+    if ((mine >> lane) & 1ull) {
+        const int pos = before + __popcll(mine & ((1ull << lane) - 1ull));
+        a.kept[start + pos] = s_key[t];
+        if (a.keep_idx) a.keep_idx[start + pos] = (int64_t)(uint32_t)s_key[t];
+    }
+    if (t == 0) a.kept_count[s] = total;
+}
+
 // Segments longer than MED_CAP: chunk sort in LDS, merge passes and NMS state in HBM.
 __global__ __launch_bounds__(BIG_THREADS) void nms_big_kernel(const rn::NmsLaunch a)
 {
@@ -235,11 +339,10 @@ size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 int rn::launch_nms(const rn::NmsLaunch &a, hipStream_t st)
 {
     if (a.S <= 0) return RN_OK;
-    const size_t lds_small = (size_t)SMALL_CAP * 29 + sizeof(int) * (64 + 1);
     const size_t lds_med = (size_t)MED_CAP * 29 + sizeof(int) * (256 + 1);
-    hipLaunchKernelGGL((nms_lds_kernel<64, SMALL_CAP>), dim3((unsigned)a.S), dim3(64), lds_small, st, a, 0, SMALL_CAP);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)a.S), dim3(MASK_CAP), 0, st, a);                 // n <= 256
     RN_LAUNCH_CHECK();
-    hipLaunchKernelGGL((nms_lds_kernel<256, MED_CAP>), dim3((unsigned)a.S), dim3(256), lds_med, st, a, SMALL_CAP + 1, MED_CAP);
+    hipLaunchKernelGGL((nms_lds_kernel<256, MED_CAP>), dim3((unsigned)a.S), dim3(256), lds_med, st, a, MASK_CAP + 1, MED_CAP);
     RN_LAUNCH_CHECK();
     hipLaunchKernelGGL(nms_big_kernel, dim3((unsigned)a.S), dim3(BIG_THREADS), 0, st, a);
     RN_LAUNCH_CHECK();
