@@ -195,7 +195,11 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
     rn::u32x4 *dst = (rn::u32x4 *)a.gcls;
     const int K = a.K;
 
-    float acc = 0.0f, reg = 0.0f;                                // acc: already scaled by alpha*scale
+    // acc is carried in double: phase A adds the background term of rows that phase B later takes out
+    // again, and that cancellation must not cost precision when such a row holds large logits.
+    // (One DP fma per 4 KiB group per lane: free.)
+    double acc = 0.0;                                            // already scaled by alpha*scale
+    float reg = 0.0f;
     // element range owned by this wave; the wave that ends at nvec also owns the ragged tail (< VEC elements)
     const bool active = v_beg < nvec || (gwave == 0 && nvec == 0);
     const int64_t e_beg = v_beg * VEC;
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                     }
                     if (WRITE_GRAD) { if (NT & 2) __builtin_nontemporal_store(D::pack(g), &dst[v0 + u * RN_WAVE + lane]); else dst[v0 + u * RN_WAVE + lane] = D::pack(g); }
                 }
-                acc = fmaf(acc_g, gmul, acc);
+                acc += (double)acc_g * (double)gmul;
             } else {                                                 // an image seam crosses this group (<= B-1 times overall)
 #pragma unroll 1
                 for (int u = 0; u < PF; ++u) {
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                         const float gm = image_gmul(a, (int)((v * VEC + j) / a.per_image));
                         float wb, gg;
                         bg_elem<GAMMA2>(x[j], a.p, wb, gg);
-                        acc = fmaf(wb, gm, acc);
+                        acc += (double)wb * (double)gm;
                         g[j] = gg * gm;
                     }
                     if (WRITE_GRAD) dst[v] = D::pack(g);
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                 const float gm = image_gmul(a, (int)((v * VEC + j) / a.per_image));
                 float wb, gg;
                 bg_elem<GAMMA2>(x[j], a.p, wb, gg);
-                acc = fmaf(wb, gm, acc);
+                acc += (double)wb * (double)gm;
                 g[j] = gg * gm;
             }
             if (WRITE_GRAD) dst[v] = D::pack(g);
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
             const float gm = image_gmul(a, (int)(e / a.per_image));
             float wb, gg;
             bg_elem<GAMMA2>(D::ld(a.cls, e), a.p, wb, gg);
-            acc = fmaf(wb, gm, acc);
+            acc += (double)wb * (double)gm;
             if (WRITE_GRAD) D::st(a.gcls, e, gg * gm);
         }
     }
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                             float wb, gbg, l, gr;
                             bg_elem<GAMMA2>(x, a.p, wb, gbg);
                             focal_elem<GAMMA2>(x, true, a, l, gr);
-                            acc += l * scale - wb * gmul;
+                            acc += (double)l * (double)scale - (double)wb * (double)gmul;
                             if (WRITE_GRAD) D::st(a.gcls, e_pos, gr * scale);
                         }
                         if (own_row) {
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                     if (ok[u]) {
                         float wb, gbg;
                         bg_elem<GAMMA2>(xs[u], a.p, wb, gbg);
-                        acc -= wb * gms[u];
+                        acc -= (double)wb * (double)gms[u];
                         if (WRITE_GRAD) D::st(a.gcls, es[u], 0.0f);
                     }
                 }
@@ -392,9 +396,9 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
         }
     }
 
-    acc = rn::wave_sum(acc);
+    float accf = (float)rn::wave_sum_d(acc);
     reg = rn::wave_sum(reg);
-    if (lane == 0) { s_part[wave][0] = acc; s_part[wave][1] = reg; }
+    if (lane == 0) { s_part[wave][0] = accf; s_part[wave][1] = reg; }
     __syncthreads();
     if (threadIdx.x == 0) {
         float c = 0.0f, rg = 0.0f;

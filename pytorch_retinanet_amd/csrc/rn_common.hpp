@@ -101,6 +101,15 @@ static __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, RN_WAVE);
     return v;
 }
+static __device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+        const unsigned lo = __shfl_xor((unsigned)u, o, RN_WAVE), hi = __shfl_xor((unsigned)(u >> 32), o, RN_WAVE);
+        v += __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    }
+    return v;
+}
 static __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, RN_WAVE);
