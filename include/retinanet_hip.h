@@ -106,6 +106,20 @@ int rn_loss_fwd_bwd(const void *cls, const void *box, int dtype, int B, int64_t 
                     float *out_loss, void *grad_cls, void *grad_box,
                     void *workspace, size_t workspace_bytes, void *stream);
 
+/* Same, reading the head outputs where the convolutions left them: L per-level tensors
+ * cls_levels[l] [B][A_l][K], box_levels[l] [B][A_l][4] (host arrays of L device pointers;
+ * level_anchors (host) = A_l; sum A_l = A, the row length of `matches` and of `anchors`, levels in
+ * anchor order) instead of their concatenation -- removes the reference's torch.cat at
+ * retinanet/layers.py:195, :259 and its backward.  grad_*_levels: per-level outputs (both NULL for
+ * value-only). */
+int rn_loss_fwd_bwd_levels(const void *const *cls_levels, const void *const *box_levels,
+                           const int64_t *level_anchors, int L, int dtype, int B, int K,
+                           const float *anchors, int64_t anchor_bstride,
+                           const float *gt_boxes, const int64_t *gt_labels, const int32_t *gt_off,
+                           const int64_t *matches, const int32_t *num_fg, const rn_loss_params *params,
+                           float *out_loss, void *const *grad_cls_levels, void *const *grad_box_levels,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
 /* In-place data[i] *= *scale (device scalar); returns immediately on the device
  * when *scale == 1.  Used by autograd's backward to apply the upstream gradient to
  * the gradients rn_loss_fwd_bwd already wrote, without a host sync. */

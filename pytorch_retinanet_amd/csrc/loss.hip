@@ -35,9 +35,21 @@ constexpr int LOSS_BLOCK = 256;
 constexpr int LOSS_WAVES = LOSS_BLOCK / RN_WAVE;
 constexpr int LOSS_MAX_BLOCKS = 4096;   // bound on resident blocks (256 CUs x 8, with headroom): sizes the partials workspace
 
-struct LossArgs {
+// One pyramid level's head outputs: cls [B][A_l][K], box [B][A_l][4] (dense).  A single tensor
+// [B][A][K] is the L = 1 case.  Levels are laid end to end in a virtual 16-byte-vector index space
+// (voff = first vector of the level) that is split evenly over the waves.
+struct LossLevel {
     const void *cls, *box;
     void *gcls, *gbox;
+    int64_t A_l, base;       // anchors per image in this level, offset of the level in the per-image anchor axis
+    int64_t N, nvec, voff;   // elements B*A_l*K, full vectors N/VEC, virtual vector offset
+    int64_t per_image;       // A_l*K elements
+};
+
+struct LossArgs {
+    int32_t L;
+    int64_t total_vec;
+    LossLevel lv[RN_MAX_LEVELS];
     const rn::f32x4 *anchors;
     int64_t anchor_bstride4;
     const rn::f32x4 *gt_boxes;
@@ -45,18 +57,13 @@ struct LossArgs {
     const int32_t *gt_off;
     const int64_t *matches;
     const int32_t *num_fg;
-    int64_t A, R, N;         // anchors per image, rows B*A, elements R*K
-    int64_t per_image;       // A*K elements
+    int64_t A;               // anchors per image over all levels (row length of `matches`)
     int64_t vec_per_wave;    // stream kernel: 16-byte vectors per wave (multiple of 64)
     int32_t K, B;
     float inv_B;
     rn_loss_params p;
     float alpha_pos;         // weight of t=1 elements: 1-alpha (Q2)
-    float2 *part_stream;     // [stream blocks] (cls, 0)
-    float2 *part_fix;        // [fix blocks]    (cls correction, reg)
-    unsigned *arrive;        // fix-up arrival counter (zeroed by the stream kernel)
-    float *out_loss;         // [2]
-    int n_stream;            // stream grid size (partials to add)
+    float2 *part_stream;     // [blocks] (cls, reg) partial sums
 };
 
 // ---- background element (t = 0) ------------------------------------------------------
@@ -188,211 +195,224 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
     // seams) is wave-uniform -> SGPRs and scalar branches.
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t gwave = (int64_t)blockIdx.x * LOSS_WAVES + wave;
-    const int64_t nvec = a.N / VEC;                              // full vectors in the tensor
-    const int64_t v_beg = gwave * a.vec_per_wave;
-    const int64_t v_end = min(v_beg + a.vec_per_wave, nvec);
-    const rn::u32x4 *src = (const rn::u32x4 *)a.cls;
-    rn::u32x4 *dst = (rn::u32x4 *)a.gcls;
+    const int64_t gv_beg = gwave * a.vec_per_wave;                // this wave's range in the virtual vector space
+    const int64_t gv_end = min(gv_beg + a.vec_per_wave, a.total_vec);  // (levels laid end to end)
     const int K = a.K;
 
     // acc is carried in double: phase A adds the background term of rows that phase B later takes out
     // again, and that cancellation must not cost precision when such a row holds large logits.
-    // (One DP fma per 4 KiB group per lane: free.)
+    // (One DP fma per group per lane: free.)
     double acc = 0.0;                                            // already scaled by alpha*scale
     float reg = 0.0f;
-    // element range owned by this wave; the wave that ends at nvec also owns the ragged tail (< VEC elements)
-    const bool active = v_beg < nvec || (gwave == 0 && nvec == 0);
-    const int64_t e_beg = v_beg * VEC;
-    const int64_t e_end = !active ? e_beg : ((v_end == nvec) ? a.N : v_end * VEC);
-    const int64_t row_lo = e_beg / K;
-    const int64_t row_hi = active && e_end > e_beg ? (e_end - 1) / K : row_lo - 1;     // inclusive
 
-    // prefetch this wave's slice of `matches` (epilogue input) so its latency hides under the stream
-    int pm[PREF_CHUNKS];
-#pragma unroll
-    for (int c = 0; c < PREF_CHUNKS; ++c) {
-        const int64_t r = row_lo + c * RN_WAVE + lane;
-        pm[c] = (r <= row_hi) ? (int)a.matches[r] : -1;
-    }
+    for (int li = 0; li < a.L; ++li) {                           // a wave's range rarely spans more than one level
+        const LossLevel &lv = a.lv[li];
+        const int64_t nvec = lv.nvec;                            // full vectors of this level's tensor
+        if (gv_end <= lv.voff && nvec > 0) break;
+        const int64_t v_beg = max(gv_beg, lv.voff) - lv.voff;
+        const int64_t v_end = min(gv_end, lv.voff + nvec) - lv.voff;
+        // the wave that ends at nvec also owns the level's ragged tail (< VEC elements)
+        const bool active = (nvec > 0) ? (v_beg < v_end) : (gwave == 0);
+        if (!active) continue;
+        const rn::u32x4 *src = (const rn::u32x4 *)lv.cls;
+        rn::u32x4 *dst = (rn::u32x4 *)lv.gcls;
+        const int64_t e_beg = v_beg * VEC;
+        const int64_t e_end = (nvec == 0 || v_end == nvec) ? lv.N : v_end * VEC;
+        const int64_t row_lo = e_beg / K;                        // rows are local to the level: r = b * A_l + a_local
+        const int64_t row_hi = e_end > e_beg ? (e_end - 1) / K : row_lo - 1;     // inclusive
 
-    if (v_beg < v_end) {
-        int b = (int)(e_beg / a.per_image);                      // image of the first element
-        int64_t img_end_v = ((int64_t)(b + 1) * a.per_image) / VEC;   // vectors [.., img_end_v) lie entirely in image b
-        float gmul = image_gmul(a, b);
-
-        const int64_t last = v_end - 1;
-        const int64_t groups = (v_end - v_beg) / (PF * RN_WAVE);      // full groups of PF wave-iterations
-        rn::u32x4 q[PF];
+        // prefetch this range's slice of `matches` (phase B input) so its latency hides under the stream
+        int pm[PREF_CHUNKS];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) q[u] = (NT & 1) ? __builtin_nontemporal_load(&src[min(v_beg + u * RN_WAVE + lane, last)]) : src[min(v_beg + u * RN_WAVE + lane, last)];
-
-        int64_t v0 = v_beg;
-        for (int64_t gi = 0; gi < groups; ++gi, v0 += PF * RN_WAVE) {
-            // next group's loads first (index clamped: straight-line code, countable vmcnt)
-            rn::u32x4 qn[PF];
-#pragma unroll
-            for (int u = 0; u < PF; ++u) qn[u] = (NT & 1) ? __builtin_nontemporal_load(&src[min(v0 + (PF + u) * RN_WAVE + lane, last)]) : src[min(v0 + (PF + u) * RN_WAVE + lane, last)];
-
-            if (v0 + PF * RN_WAVE <= img_end_v) {                    // whole group inside image b (scalar test)
-                float acc_g = 0.0f;
-#pragma unroll
-                for (int u = 0; u < PF; ++u) {
-                    float x[VEC], g[VEC];
-                    D::unpack(q[u], x);
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j) {
-                        float wb, gg;
-                        bg_elem<GAMMA2>(x[j], a.p, wb, gg);
-                        acc_g += wb;
-                        g[j] = gg * gmul;
-                    }
-                    if (WRITE_GRAD) { if (NT & 2) __builtin_nontemporal_store(D::pack(g), &dst[v0 + u * RN_WAVE + lane]); else dst[v0 + u * RN_WAVE + lane] = D::pack(g); }
-                }
-                acc += (double)acc_g * (double)gmul;
-            } else {                                                 // an image seam crosses this group (<= B-1 times overall)
-#pragma unroll 1
-                for (int u = 0; u < PF; ++u) {
-                    const int64_t v = v0 + u * RN_WAVE + lane;
-                    float x[VEC], g[VEC];
-                    D::unpack(src[v], x);
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j) {
-                        const float gm = image_gmul(a, (int)((v * VEC + j) / a.per_image));
-                        float wb, gg;
-                        bg_elem<GAMMA2>(x[j], a.p, wb, gg);
-                        acc += (double)wb * (double)gm;
-                        g[j] = gg * gm;
-                    }
-                    if (WRITE_GRAD) dst[v] = D::pack(g);
-                }
-                b = (int)(((v0 + PF * RN_WAVE) * VEC) / a.per_image);
-                if (b > a.B - 1) b = a.B - 1;
-                img_end_v = ((int64_t)(b + 1) * a.per_image) / VEC;
-                gmul = image_gmul(a, b);
+        for (int c = 0; c < PREF_CHUNKS; ++c) {
+            const int64_t r = row_lo + c * RN_WAVE + lane;
+            int m = -1;
+            if (r <= row_hi) {
+                const int b = (int)((uint32_t)r / (uint32_t)lv.A_l);
+                m = (int)a.matches[(int64_t)b * a.A + lv.base + (r - (int64_t)b * lv.A_l)];
             }
-#pragma unroll
-            for (int u = 0; u < PF; ++u) q[u] = qn[u];
+            pm[c] = m;
         }
-        // leftover vectors of the range (< one group), per-element image lookup
-#pragma unroll 1
-        for (int64_t v = v0 + lane; v < v_end; v += RN_WAVE) {
-            float x[VEC], g[VEC];
-            D::unpack(src[v], x);
+
+        if (v_beg < v_end) {
+            int b = (int)(e_beg / lv.per_image);                      // image of the first element
+            int64_t img_end_v = ((int64_t)(b + 1) * lv.per_image) / VEC;   // vectors [.., img_end_v) lie entirely in image b
+            float gmul = image_gmul(a, b);
+
+            const int64_t last = v_end - 1;
+            const int64_t groups = (v_end - v_beg) / (PF * RN_WAVE);      // full groups of PF wave-iterations
+            rn::u32x4 q[PF];
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const float gm = image_gmul(a, (int)((v * VEC + j) / a.per_image));
+            for (int u = 0; u < PF; ++u) q[u] = (NT & 1) ? __builtin_nontemporal_load(&src[min(v_beg + u * RN_WAVE + lane, last)]) : src[min(v_beg + u * RN_WAVE + lane, last)];
+
+            int64_t v0 = v_beg;
+            for (int64_t gi = 0; gi < groups; ++gi, v0 += PF * RN_WAVE) {
+                // next group's loads first (index clamped: straight-line code, countable vmcnt)
+                rn::u32x4 qn[PF];
+#pragma unroll
+                for (int u = 0; u < PF; ++u) qn[u] = (NT & 1) ? __builtin_nontemporal_load(&src[min(v0 + (PF + u) * RN_WAVE + lane, last)]) : src[min(v0 + (PF + u) * RN_WAVE + lane, last)];
+
+                if (v0 + PF * RN_WAVE <= img_end_v) {                    // whole group inside image b (scalar test)
+                    float acc_g = 0.0f;
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) {
+                        float x[VEC], g[VEC];
+                        D::unpack(q[u], x);
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) {
+                            float wb, gg;
+                            bg_elem<GAMMA2>(x[j], a.p, wb, gg);
+                            acc_g += wb;
+                            g[j] = gg * gmul;
+                        }
+                        if (WRITE_GRAD) { if (NT & 2) __builtin_nontemporal_store(D::pack(g), &dst[v0 + u * RN_WAVE + lane]); else dst[v0 + u * RN_WAVE + lane] = D::pack(g); }
+                    }
+                    acc += (double)acc_g * (double)gmul;
+                } else {                                                 // an image seam crosses this group (<= B-1 times per level)
+#pragma unroll 1
+                    for (int u = 0; u < PF; ++u) {
+                        const int64_t v = v0 + u * RN_WAVE + lane;
+                        float x[VEC], g[VEC];
+                        D::unpack(src[v], x);
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) {
+                            const float gm = image_gmul(a, (int)((v * VEC + j) / lv.per_image));
+                            float wb, gg;
+                            bg_elem<GAMMA2>(x[j], a.p, wb, gg);
+                            acc += (double)wb * (double)gm;
+                            g[j] = gg * gm;
+                        }
+                        if (WRITE_GRAD) dst[v] = D::pack(g);
+                    }
+                    b = (int)(((v0 + PF * RN_WAVE) * VEC) / lv.per_image);
+                    if (b > a.B - 1) b = a.B - 1;
+                    img_end_v = ((int64_t)(b + 1) * lv.per_image) / VEC;
+                    gmul = image_gmul(a, b);
+                }
+#pragma unroll
+                for (int u = 0; u < PF; ++u) q[u] = qn[u];
+            }
+            // leftover vectors of the range (< one group), per-element image lookup
+#pragma unroll 1
+            for (int64_t v = v0 + lane; v < v_end; v += RN_WAVE) {
+                float x[VEC], g[VEC];
+                D::unpack(src[v], x);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float gm = image_gmul(a, (int)((v * VEC + j) / lv.per_image));
+                    float wb, gg;
+                    bg_elem<GAMMA2>(x[j], a.p, wb, gg);
+                    acc += (double)wb * (double)gm;
+                    g[j] = gg * gm;
+                }
+                if (WRITE_GRAD) dst[v] = D::pack(g);
+            }
+        }
+        // ragged tail of the level's tensor (< VEC elements), owned by the wave that ends at nvec
+        if (nvec == 0 || v_end == nvec) {
+            const int64_t e = nvec * VEC + lane;
+            if (lane < VEC && e < lv.N) {
+                const float gm = image_gmul(a, (int)(e / lv.per_image));
                 float wb, gg;
-                bg_elem<GAMMA2>(x[j], a.p, wb, gg);
+                bg_elem<GAMMA2>(D::ld(lv.cls, e), a.p, wb, gg);
                 acc += (double)wb * (double)gm;
-                g[j] = gg * gm;
+                if (WRITE_GRAD) D::st(lv.gcls, e, gg * gm);
             }
-            if (WRITE_GRAD) dst[v] = D::pack(g);
         }
-    }
-    // ragged tail of the tensor (< VEC elements), owned by the wave that ends at nvec
-    if (active && v_end == nvec) {
-        const int64_t e = nvec * VEC + lane;
-        if (lane < VEC && e < a.N) {
-            const float gm = image_gmul(a, (int)(e / a.per_image));
-            float wb, gg;
-            bg_elem<GAMMA2>(D::ld(a.cls, e), a.p, wb, gg);
-            acc += (double)wb * (double)gm;
-            if (WRITE_GRAD) D::st(a.gcls, e, gg * gm);
-        }
-    }
 
-    // ---- Phase B: repair this wave's special elements; box gradients of the rows it owns ----------
-    for (int64_t c0 = row_lo, c = 0; c0 <= row_hi; c0 += RN_WAVE, ++c) {
-        const int64_t r = c0 + lane;
-        bool ignored = false;
-        float ign_gm = 0.0f;
-        if (r <= row_hi) {
-            int64_t m = -1;
-            if (c < PREF_CHUNKS) {
+        // ---- Phase B: repair this range's special elements; box gradients of the rows it owns --------
+        for (int64_t c0 = row_lo, c = 0; c0 <= row_hi; c0 += RN_WAVE, ++c) {
+            const int64_t r = c0 + lane;
+            bool ignored = false;
+            float ign_gm = 0.0f;
+            if (r <= row_hi) {
+                const int b = (int)((uint32_t)r / (uint32_t)lv.A_l);
+                const int64_t ag = lv.base + (r - (int64_t)b * lv.A_l);   // anchor index within the image
+                int64_t m = -1;
+                if (c < PREF_CHUNKS) {
 #pragma unroll
-                for (int k = 0; k < PREF_CHUNKS; ++k) if (c == k) m = pm[k];
-            } else {
-                m = a.matches[r];
-            }
-            const int64_t r_e0 = r * K;
-            const bool own_row = r_e0 >= e_beg;                       // the row's first element is ours
-            float gb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (m != -1) {                                            // rare: ~0.3% of the rows
-                const int b = (int)((uint32_t)r / (uint32_t)a.A);
-                const int t0 = a.gt_off[b], T = a.gt_off[b + 1] - t0;
-                if (T > 0) {                                          // images without GT: phase A already wrote zeros
-                    const int nf = a.num_fg[b];
-                    const float scale = (1.0f / (float)(nf > 1 ? nf : 1)) * a.inv_B;
-                    const float gmul = a.p.alpha * scale;
-                    if (m >= 0) {
-                        const int gi = t0 + (int)m;
-                        const int code = (int)a.gt_labels[gi] - 1;
-                        const int64_t e_pos = r_e0 + code;
-                        if (code >= 0 && code < K && e_pos >= e_beg && e_pos < e_end) {
-                            // matched row: only the positive element differs from what phase A did
-                            const float x = D::ld(a.cls, e_pos);
-                            float wb, gbg, l, gr;
-                            bg_elem<GAMMA2>(x, a.p, wb, gbg);
-                            focal_elem<GAMMA2>(x, true, a, l, gr);
-                            acc += (double)l * (double)scale - (double)wb * (double)gmul;
-                            if (WRITE_GRAD) D::st(a.gcls, e_pos, gr * scale);
-                        }
-                        if (own_row) {
-                            const int64_t ai = r - (int64_t)b * a.A;
-                            float pred[4];
-                            box4<DT>::ld(a.box, r, pred);
-                            const float l = reg_row(a.gt_boxes[gi], a.anchors[(int64_t)b * a.anchor_bstride4 + ai], pred, a.p, gb);
-                            reg += l * scale;
+                    for (int k = 0; k < PREF_CHUNKS; ++k) if (c == k) m = pm[k];
+                } else {
+                    m = a.matches[(int64_t)b * a.A + ag];
+                }
+                const int64_t r_e0 = r * K;
+                const bool own_row = r_e0 >= e_beg;                       // the row's first element is ours
+                float gb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (m != -1) {                                            // rare: ~0.3% of the rows
+                    const int t0 = a.gt_off[b], T = a.gt_off[b + 1] - t0;
+                    if (T > 0) {                                          // images without GT: phase A already wrote zeros
+                        const int nf = a.num_fg[b];
+                        const float scale = (1.0f / (float)(nf > 1 ? nf : 1)) * a.inv_B;
+                        const float gmul = a.p.alpha * scale;
+                        if (m >= 0) {
+                            const int gi = t0 + (int)m;
+                            const int code = (int)a.gt_labels[gi] - 1;
+                            const int64_t e_pos = r_e0 + code;
+                            if (code >= 0 && code < K && e_pos >= e_beg && e_pos < e_end) {
+                                // matched row: only the positive element differs from what phase A did
+                                const float x = D::ld(lv.cls, e_pos);
+                                float wb, gbg, l, gr;
+                                bg_elem<GAMMA2>(x, a.p, wb, gbg);
+                                focal_elem<GAMMA2>(x, true, a, l, gr);
+                                acc += (double)l * (double)scale - (double)wb * (double)gmul;
+                                if (WRITE_GRAD) D::st(lv.gcls, e_pos, gr * scale);
+                            }
+                            if (own_row) {
+                                float pred[4];
+                                box4<DT>::ld(lv.box, r, pred);
+                                const float l = reg_row(a.gt_boxes[gi], a.anchors[(int64_t)b * a.anchor_bstride4 + ag], pred, a.p, gb);
+                                reg += l * scale;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) gb[j] *= scale;
+                                for (int j = 0; j < 4; ++j) gb[j] *= scale;
+                            }
+                        } else {
+                            ignored = true;
+                            ign_gm = gmul;
                         }
-                    } else {
-                        ignored = true;
-                        ign_gm = gmul;
                     }
                 }
+                if (WRITE_GRAD && own_row) box4<DT>::st(lv.gbox, r, gb);
             }
-            if (WRITE_GRAD && own_row) box4<DT>::st(a.gbox, r, gb);
-        }
-        // ignored rows: remove their background contribution and zero their gradient.  The rows are
-        // compacted into a wave-private LDS list and their elements are spread over all lanes,
-        // IGN_U independent loads per lane per round (elements outside this wave's range are masked).
-        const unsigned long long imask = __ballot(ignored);
-        if (imask) {                                                   // wave-uniform
-            if (ignored) {
-                const int pos = __popcll(imask & ((1ull << lane) - 1ull));
-                s_ign_row[wave][pos] = (unsigned char)lane;
-                s_ign_gm[wave][pos] = ign_gm;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int total = __popcll(imask) * K;
-            for (int t0 = 0; t0 < total; t0 += RN_WAVE * IGN_U) {
-                float xs[IGN_U], gms[IGN_U];
-                int64_t es[IGN_U];
-                bool ok[IGN_U];
-#pragma unroll
-                for (int u = 0; u < IGN_U; ++u) {
-                    const int t = min(t0 + u * RN_WAVE + lane, total - 1);
-                    const int j = t / K, k = t - j * K;
-                    es[u] = (c0 + s_ign_row[wave][j]) * K + k;
-                    gms[u] = s_ign_gm[wave][j];
-                    ok[u] = (t0 + u * RN_WAVE + lane < total) && es[u] >= e_beg && es[u] < e_end;
-                    xs[u] = D::ld(a.cls, es[u]);
+            // ignored rows: remove their background contribution and zero their gradient.  The rows are
+            // compacted into a wave-private LDS list and their elements are spread over all lanes,
+            // IGN_U independent loads per lane per round (elements outside this wave's range are masked).
+            const unsigned long long imask = __ballot(ignored);
+            if (imask) {                                                   // wave-uniform
+                if (ignored) {
+                    const int pos = __popcll(imask & ((1ull << lane) - 1ull));
+                    s_ign_row[wave][pos] = (unsigned char)lane;
+                    s_ign_gm[wave][pos] = ign_gm;
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int total = __popcll(imask) * K;
+                for (int t0 = 0; t0 < total; t0 += RN_WAVE * IGN_U) {
+                    float xs[IGN_U], gms[IGN_U];
+                    int64_t es[IGN_U];
+                    bool ok[IGN_U];
 #pragma unroll
-                for (int u = 0; u < IGN_U; ++u) {
-                    if (ok[u]) {
-                        float wb, gbg;
-                        bg_elem<GAMMA2>(xs[u], a.p, wb, gbg);
-                        acc -= (double)wb * (double)gms[u];
-                        if (WRITE_GRAD) D::st(a.gcls, es[u], 0.0f);
+                    for (int u = 0; u < IGN_U; ++u) {
+                        const int t = min(t0 + u * RN_WAVE + lane, total - 1);
+                        const int j = t / K, k = t - j * K;
+                        es[u] = (c0 + s_ign_row[wave][j]) * K + k;
+                        gms[u] = s_ign_gm[wave][j];
+                        ok[u] = (t0 + u * RN_WAVE + lane < total) && es[u] >= e_beg && es[u] < e_end;
+                        xs[u] = D::ld(lv.cls, es[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < IGN_U; ++u) {
+                        if (ok[u]) {
+                            float wb, gbg;
+                            bg_elem<GAMMA2>(xs[u], a.p, wb, gbg);
+                            acc -= (double)wb * (double)gms[u];
+                            if (WRITE_GRAD) D::st(lv.gcls, es[u], 0.0f);
+                        }
                     }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
         }
     }
 
@@ -470,7 +490,8 @@ int launch_stream(StreamT stream_k, LossArgs &a, int vec, hipStream_t st, int *n
     if (rc != RN_OK) return rc;
     if (const char *e = getenv("RN_K3_BLOCKS")) { int v = atoi(e); if (v > 0 && v < res) res = v; }
     // even split of the vectors over the resident waves, in whole wave-iterations (64 vectors = 1 KiB)
-    const int64_t nvec = a.N / vec;
+    (void)vec;
+    const int64_t nvec = a.total_vec;
     const int64_t waves = (int64_t)res * LOSS_WAVES;
     int64_t vpw = (nvec + waves - 1) / waves;
     vpw = ((vpw + RN_WAVE - 1) / RN_WAVE) * RN_WAVE;
@@ -512,42 +533,63 @@ RN_API size_t rn_loss_workspace_bytes(int B, int64_t A, int K)
     return sizeof(float2) * (size_t)LOSS_MAX_BLOCKS * 2 + 16;
 }
 
-RN_API int rn_loss_fwd_bwd(const void *cls, const void *box, int dtype, int B, int64_t A, int K,
-                           const float *anchors, int64_t anchor_bstride, const float *gt_boxes,
-                           const int64_t *gt_labels, const int32_t *gt_off, const int64_t *matches,
-                           const int32_t *num_fg, const rn_loss_params *params, float *out_loss, void *grad_cls,
-                           void *grad_box, void *workspace, size_t workspace_bytes, void *stream)
+RN_API int rn_loss_fwd_bwd_levels(const void *const *cls_levels, const void *const *box_levels,
+                                  const int64_t *level_anchors, int L, int dtype, int B, int K,
+                                  const float *anchors, int64_t anchor_bstride, const float *gt_boxes,
+                                  const int64_t *gt_labels, const int32_t *gt_off, const int64_t *matches,
+                                  const int32_t *num_fg, const rn_loss_params *params, float *out_loss,
+                                  void *const *grad_cls_levels, void *const *grad_box_levels, void *workspace,
+                                  size_t workspace_bytes, void *stream)
 {
-    if (!cls || !box || !anchors || !gt_off || !matches || !num_fg || !params || !out_loss || !workspace) return RN_EINVAL;
-    if (B <= 0 || A <= 0 || K <= 0) return RN_EINVAL;
-    if ((grad_cls == nullptr) != (grad_box == nullptr)) return RN_EINVAL;
+    if (!cls_levels || !box_levels || !level_anchors || !anchors || !gt_off || !matches || !num_fg || !params || !out_loss ||
+        !workspace)
+        return RN_EINVAL;
+    if (L <= 0 || L > RN_MAX_LEVELS || B <= 0 || K <= 0) return RN_EINVAL;
+    if ((grad_cls_levels == nullptr) != (grad_box_levels == nullptr)) return RN_EINVAL;
     if (dtype != RN_F32 && dtype != RN_BF16 && dtype != RN_F16) return RN_EINVAL;
-    if (K > 4096 || (int64_t)B * A >= ((int64_t)1 << 31)) return RN_EUNSUPPORTED;
-    if (workspace_bytes < rn_loss_workspace_bytes(B, A, K)) return RN_EWORKSPACE;
+    if (K > 4096) return RN_EUNSUPPORTED;
+    if (workspace_bytes < rn_loss_workspace_bytes(B, 1, K)) return RN_EWORKSPACE;
     const size_t box_al = (dtype == RN_F32) ? 16 : 8;
-    if (!rn::aligned(cls, 16) || (grad_cls && !rn::aligned(grad_cls, 16)) || !rn::aligned(box, box_al) ||
-        (grad_box && !rn::aligned(grad_box, box_al)) || !rn::aligned(anchors, 16) ||
-        (gt_boxes && !rn::aligned(gt_boxes, 16)) || !rn::aligned(workspace, 16) || (anchor_bstride & 3))
+    const int vec = (dtype == RN_F32) ? 4 : 8;
+    if (!rn::aligned(anchors, 16) || (gt_boxes && !rn::aligned(gt_boxes, 16)) || !rn::aligned(workspace, 16) || (anchor_bstride & 3))
         return RN_EALIGN;
 
     LossArgs a;
-    a.cls = cls; a.box = box; a.gcls = grad_cls; a.gbox = grad_box;
+    a.L = L;
+    int64_t A = 0, voff = 0;
+    for (int l = 0; l < RN_MAX_LEVELS; ++l) {
+        LossLevel &lv = a.lv[l];
+        if (l < L) {
+            if (!cls_levels[l] || !box_levels[l] || level_anchors[l] <= 0) return RN_EINVAL;
+            if (grad_cls_levels && (!grad_cls_levels[l] || !grad_box_levels[l])) return RN_EINVAL;
+            if (!rn::aligned(cls_levels[l], 16) || !rn::aligned(box_levels[l], box_al) ||
+                (grad_cls_levels && (!rn::aligned(grad_cls_levels[l], 16) || !rn::aligned(grad_box_levels[l], box_al))))
+                return RN_EALIGN;
+            lv.cls = cls_levels[l]; lv.box = box_levels[l];
+            lv.gcls = grad_cls_levels ? grad_cls_levels[l] : nullptr;
+            lv.gbox = grad_box_levels ? grad_box_levels[l] : nullptr;
+            lv.A_l = level_anchors[l]; lv.base = A;
+            lv.N = (int64_t)B * lv.A_l * K; lv.nvec = lv.N / vec; lv.voff = voff;
+            lv.per_image = lv.A_l * (int64_t)K;
+            if ((int64_t)B * lv.A_l >= ((int64_t)1 << 31)) return RN_EUNSUPPORTED;
+            A += lv.A_l; voff += lv.nvec;
+        } else {
+            lv.cls = lv.box = nullptr; lv.gcls = lv.gbox = nullptr;
+            lv.A_l = 1; lv.base = 0; lv.N = 0; lv.nvec = 0; lv.voff = voff; lv.per_image = K;
+        }
+    }
+    a.total_vec = voff;
     a.anchors = (const rn::f32x4 *)anchors; a.anchor_bstride4 = anchor_bstride / 4;
     a.gt_boxes = (const rn::f32x4 *)gt_boxes; a.gt_labels = gt_labels; a.gt_off = gt_off;
     a.matches = matches; a.num_fg = num_fg;
-    a.A = A; a.R = (int64_t)B * A; a.K = K; a.B = B;
-    a.N = a.R * K; a.per_image = A * (int64_t)K;
+    a.A = A; a.K = K; a.B = B;
     a.vec_per_wave = RN_WAVE;
     a.inv_B = 1.0f / (float)B;
     a.p = *params;
     a.alpha_pos = (float)(1.0 - (double)params->alpha);
     a.part_stream = (float2 *)workspace;
-    a.part_fix = a.part_stream + LOSS_MAX_BLOCKS;
-    a.arrive = (unsigned *)(a.part_fix + LOSS_MAX_BLOCKS);
-    a.out_loss = out_loss;
-    a.n_stream = 0;
     const bool gamma2 = params->gamma == 2.0f;
-    const bool wg = grad_cls != nullptr;
+    const bool wg = grad_cls_levels != nullptr;
     hipStream_t st = (hipStream_t)stream;
     int ns = 0, rc;
     switch (dtype) {
@@ -559,6 +601,22 @@ RN_API int rn_loss_fwd_bwd(const void *cls, const void *box, int dtype, int B, i
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float2 *)a.part_stream, ns, out_loss);
     RN_LAUNCH_CHECK();
     return RN_OK;
+}
+
+RN_API int rn_loss_fwd_bwd(const void *cls, const void *box, int dtype, int B, int64_t A, int K,
+                           const float *anchors, int64_t anchor_bstride, const float *gt_boxes,
+                           const int64_t *gt_labels, const int32_t *gt_off, const int64_t *matches,
+                           const int32_t *num_fg, const rn_loss_params *params, float *out_loss, void *grad_cls,
+                           void *grad_box, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!cls || !box || A <= 0) return RN_EINVAL;
+    if ((grad_cls == nullptr) != (grad_box == nullptr)) return RN_EINVAL;
+    const void *c1[1] = {cls}, *b1[1] = {box};
+    void *gc1[1] = {grad_cls}, *gb1[1] = {grad_box};
+    const int64_t a1[1] = {A};
+    return rn_loss_fwd_bwd_levels(c1, b1, a1, 1, dtype, B, K, anchors, anchor_bstride, gt_boxes, gt_labels, gt_off, matches,
+                                  num_fg, params, out_loss, grad_cls ? gc1 : nullptr, grad_cls ? gb1 : nullptr, workspace,
+                                  workspace_bytes, stream);
 }
 
 RN_API int rn_scale_inplace(void *data, int dtype, int64_t n, const float *scale, void *stream)

@@ -86,9 +86,12 @@ class RetinaNetClassSubnet(nn.Module):
         # prior-probability bias (layers.py:175-178)
         nn.init.constant_(self.class_subnet_output.bias, -math.log((1 - prior) / prior))
 
+    def forward_levels(self, feature_maps: List[Tensor]) -> List[Tensor]:
+        "Per-level logits [N, H*W*A, K]; views of the conv outputs when the activations are channels_last."
+        return [_to_anchor_major(self.class_subnet_output(self.class_subnet(f)), self.num_classes) for f in feature_maps]
+
     def forward(self, feature_maps: List[Tensor]) -> Tensor:
-        outs = [_to_anchor_major(self.class_subnet_output(self.class_subnet(f)), self.num_classes) for f in feature_maps]
-        return torch.cat(outs, dim=1)
+        return torch.cat(self.forward_levels(feature_maps), dim=1)
 
 
 class RetinaNetBoxSubnet(nn.Module):
@@ -101,9 +104,11 @@ class RetinaNetBoxSubnet(nn.Module):
         self.box_subnet_output = nn.Conv2d(out_channels, num_anchors * 4, 3, padding=1, stride=1)
         _init_head(self.box_subnet, self.box_subnet_output)
 
+    def forward_levels(self, feature_maps: List[Tensor]) -> List[Tensor]:
+        return [_to_anchor_major(self.box_subnet_output(self.box_subnet(f)), 4) for f in feature_maps]
+
     def forward(self, feature_maps: List[Tensor]) -> Tensor:
-        outs = [_to_anchor_major(self.box_subnet_output(self.box_subnet(f)), 4) for f in feature_maps]
-        return torch.cat(outs, dim=1)
+        return torch.cat(self.forward_levels(feature_maps), dim=1)
 
 
 class RetinaNetHead(nn.Module):
@@ -121,3 +126,11 @@ class RetinaNetHead(nn.Module):
 
     def forward(self, xb: List[Tensor]) -> Dict[str, Tensor]:
         return {"cls_preds": self.classification_head(xb), "bbox_preds": self.regression_head(xb)}
+
+    def forward_levels(self, xb: List[Tensor]) -> Dict[str, List[Tensor]]:
+        "Head outputs left per pyramid level (no concatenation); consumed by ``compute_loss_levels``."
+        return {"cls_levels": self.classification_head.forward_levels(xb),
+                "bbox_levels": self.regression_head.forward_levels(xb)}
+
+    def compute_loss_levels(self, targets, outputs: Dict[str, List[Tensor]], anchors) -> Dict[str, Tensor]:
+        return self.losses.forward_levels(targets, outputs["cls_levels"], outputs["bbox_levels"], anchors)

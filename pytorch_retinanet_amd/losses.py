@@ -47,6 +47,37 @@ class _FusedDenseHeadLoss(torch.autograd.Function):
         return gcls.view(ctx.cls_shape), gbox.view(ctx.box_shape), None, None, None, None, None, None, None
 
 
+class _FusedDenseHeadLossLevels(torch.autograd.Function):
+    """Per-level head outputs (cls_0..cls_{L-1}, box_0..box_{L-1}) -> f32[2]; no concatenation."""
+
+    @staticmethod
+    def forward(ctx, anchors, gt_boxes, gt_labels, gt_off, params, fg_thr, bg_thr, L, *levels):
+        cls_levels, box_levels = levels[:L], levels[L:]
+        B = cls_levels[0].shape[0]
+        matches, num_fg = ops.iou_match(anchors, gt_boxes, gt_off, B, fg_thr, bg_thr)
+        want_grad = any(ctx.needs_input_grad[8:])
+        loss, gcls, gbox = ops.loss_fwd_bwd_levels(cls_levels, box_levels, anchors, gt_boxes, gt_labels, gt_off, matches,
+                                                   num_fg, params, want_grad)
+        ctx.grads = (gcls, gbox)
+        ctx.meta = [(c.shape, c.dtype) for c in cls_levels] + [(b.shape, b.dtype) for b in box_levels]
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.grads is None or ctx.grads[0] is None:
+            raise RuntimeError("fused RetinaNet loss: backward called twice (or without gradients recorded); "
+                               "re-run the forward pass instead of retain_graph=True")
+        gcls, gbox = ctx.grads
+        ctx.grads = None
+        g = g.to(torch.float32)
+        for t in gcls:
+            ops.scale_inplace(t, g[0:1])
+        for t in gbox:
+            ops.scale_inplace(t, g[1:2])
+        outs = [t.view(shape) if t.dtype == dt else t.to(dt).view(shape) for t, (shape, dt) in zip(list(gcls) + list(gbox), ctx.meta)]
+        return (None,) * 8 + tuple(outs)
+
+
 def _stack_anchors(anchors) -> Tensor:
     """List of per-image [A,4] tensors -> one shared [A,4] (the usual case: the
     generator hands out the same cached tensor per image) or a stacked [B,A,4]."""
@@ -98,6 +129,21 @@ class RetinaNetLosses(nn.Module):
         gt_off = ops.gt_offsets(counts, dev)
         return _FusedDenseHeadLoss.apply(cls, box, _stack_anchors(anchors), gt_boxes, gt_labels, gt_off,
                                          self._params(), IOU_THRESHOLDS_FOREGROUND, IOU_THRESHOLDS_BACKGROUND)
+
+    def forward_levels(self, targets: List[Dict[str, Tensor]], cls_levels: Sequence[Tensor], box_levels: Sequence[Tensor],
+                       anchors) -> Dict[str, Tensor]:
+        """Same result as ``forward`` on ``torch.cat(levels, dim=1)``, without materialising the cat
+        (the loss kernel reads the per-level conv outputs where they are)."""
+        dev = cls_levels[0].device
+        boxes, labels = [t["boxes"] for t in targets], [t["labels"] for t in targets]
+        counts = [int(b.reshape(-1, 4).shape[0]) for b in boxes]
+        gt_boxes = torch.cat([b.reshape(-1, 4).to(device=dev, dtype=torch.float32) for b in boxes])
+        gt_labels = torch.cat([l.reshape(-1).to(device=dev, dtype=torch.int64) for l in labels])
+        gt_off = ops.gt_offsets(counts, dev)
+        out = _FusedDenseHeadLossLevels.apply(_stack_anchors(anchors), gt_boxes, gt_labels, gt_off, self._params(),
+                                              IOU_THRESHOLDS_FOREGROUND, IOU_THRESHOLDS_BACKGROUND, len(cls_levels),
+                                              *cls_levels, *box_levels)
+        return {"classification_loss": out[0], "regression_loss": out[1]}
 
     def calc_loss(self, anchors: Tensor, clas_pred: Tensor, bbox_pred: Tensor, clas_tgt: Tensor,
                   bbox_tgt: Tensor) -> Tuple[Tensor, Tensor]:

@@ -115,9 +115,15 @@ class Retinanet(nn.Module):
         if targets is None:
             return self.predict(images)
         images, targets = self.transform(images, targets)
-        feature_maps, outputs = self._features(images.tensors)
+        batch = images.tensors
+        if self.backbone.backbone.conv1.weight.is_contiguous(memory_format=torch.channels_last):
+            batch = batch.contiguous(memory_format=torch.channels_last)
+        feature_maps = self.fpn(self.backbone(batch))
         anchors = self.anchor_generator(images, feature_maps)
-        return self.compute_loss(targets, outputs, anchors)
+        # same losses as compute_loss(targets, retinanet_head(feature_maps), anchors), but the loss kernel
+        # reads the five per-level conv outputs in place instead of their torch.cat (layers.py:195, :259)
+        outputs = self.retinanet_head.forward_levels(feature_maps)
+        return self.retinanet_head.compute_loss_levels(targets, outputs, anchors)
 
     # -- inference ---------------------------------------------------------------------------
     def process_detections(self, outputs: Dict[str, Tensor], anchors: List[Tensor],

@@ -182,6 +182,42 @@ def loss_fwd_bwd(cls: Tensor, box: Tensor, anchors: Tensor, gt_boxes: Tensor, gt
     return out, gcls, gbox
 
 
+def loss_fwd_bwd_levels(cls_levels: Sequence[Tensor], box_levels: Sequence[Tensor], anchors: Tensor, gt_boxes: Tensor,
+                        gt_labels: Tensor, gt_off: Tensor, matches: Tensor, num_fg: Tensor, params: RnLossParams,
+                        want_grad: bool = True):
+    """K3 on per-level head outputs (no concatenation): cls_levels[l] [B,A_l,K], box_levels[l] [B,A_l,4].
+    -> (loss f32[2], [grad_cls_l], [grad_box_l])."""
+    L = len(cls_levels)
+    if L == 0 or L > _lib.RN_MAX_LEVELS or len(box_levels) != L:
+        raise ValueError("need 1..8 levels of (cls, box) outputs")
+    dev = _need_dev(*cls_levels, *box_levels, anchors, gt_boxes, gt_labels, gt_off, matches, num_fg)
+    dt = cls_levels[0].dtype
+    cls_levels = [_c(c) for c in cls_levels]
+    box_levels = [_c(b if b.dtype == dt else b.to(dt)) for b in box_levels]
+    B, _, K = cls_levels[0].shape
+    counts = [int(c.shape[1]) for c in cls_levels]
+    for c, b in zip(cls_levels, box_levels):
+        if c.dim() != 3 or b.shape != (B, c.shape[1], 4) or c.shape[0] != B or c.shape[2] != K or c.dtype != dt:
+            raise ValueError(f"bad level shapes {tuple(c.shape)} / {tuple(b.shape)}")
+    A = sum(counts)
+    anchors, bstride = _anchor_args(anchors, B, A)
+    gt_boxes = _c(gt_boxes.float()).reshape(-1, 4)
+    gt_labels = _c(gt_labels.to(torch.int64)).reshape(-1)
+    out = torch.empty((2,), dtype=torch.float32, device=dev)
+    gcls = [torch.empty_like(c) for c in cls_levels] if want_grad else None
+    gbox = [torch.empty_like(b) for b in box_levels] if want_grad else None
+    ws_bytes = lib.rn_loss_workspace_bytes(B, A, K)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    arr = lambda ts: (C.c_void_p * L)(*[t.data_ptr() for t in ts])
+    with torch.cuda.device(dev), _timed("loss_fwd_bwd" if want_grad else "loss_fwd", dev):
+        check(lib.rn_loss_fwd_bwd_levels(arr(cls_levels), arr(box_levels), (C.c_int64 * L)(*counts), L, _dtype_code(cls_levels[0]),
+                                         B, K, _ptr(anchors), bstride, _ptr(gt_boxes), _ptr(gt_labels), _ptr(gt_off),
+                                         _ptr(matches), _ptr(num_fg), C.byref(params), _ptr(out),
+                                         arr(gcls) if want_grad else None, arr(gbox) if want_grad else None,
+                                         _ptr(ws), ws_bytes, _stream(dev)), "rn_loss_fwd_bwd_levels")
+    return out, gcls, gbox
+
+
 def scale_inplace(t: Tensor, scale: Tensor) -> Tensor:
     """t *= scale (device scalar, f32); a no-op on the device when scale == 1."""
     dev = _need_dev(t, scale)

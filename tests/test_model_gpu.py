@@ -121,3 +121,53 @@ def test_lightning_module_with_simple_trainer():
     assert not torch.equal(before, after)
     res, outs = trainer.test(model)
     assert len(outs) == 2 and all("detections" in o for o in outs)
+
+
+def test_per_level_loss_equals_concatenated(golden):
+    """rn_loss_fwd_bwd_levels (head outputs left per pyramid level) == rn_loss_fwd_bwd on their concatenation:
+    values and gradients bit-identical per element, incl. ragged level sizes and an image without GT."""
+    import pytorch_retinanet_amd as P
+    rng = np.random.default_rng(12)
+    B, K = 3, 7
+    counts = [333, 90, 27, 9, 2]                     # odd sizes: every level has a ragged tail somewhere
+    A = sum(counts)
+    anc = np.sort(rng.uniform(0, 300, (A, 2, 2)).astype(np.float32), axis=1).reshape(A, 4)
+    targets = []
+    for T in (5, 0, 3):
+        b, l = synth.gt_boxes(rng, T, 300, 300, num_classes=K, wh_lo=30, wh_hi=200)
+        targets.append({"boxes": torch.from_numpy(b).to(DEV), "labels": torch.from_numpy(l).to(DEV)})
+    crit = P.RetinaNetLosses(K)
+    for dtype in (torch.float32, torch.bfloat16):
+        cls_l = [torch.randn(B, n, K, device=DEV).mul(1.5).sub(1.0).to(dtype).requires_grad_(True) for n in counts]
+        box_l = [torch.randn(B, n, 4, device=DEV).mul(0.4).to(dtype).requires_grad_(True) for n in counts]
+        anchors = torch.from_numpy(anc).to(DEV)
+        out_l = crit.forward_levels(targets, cls_l, box_l, [anchors] * B)
+        (out_l["classification_loss"] + 2.0 * out_l["regression_loss"]).backward()
+        cls_c = torch.cat([c.detach() for c in cls_l], 1).requires_grad_(True)
+        box_c = torch.cat([b.detach() for b in box_l], 1).requires_grad_(True)
+        out_c = crit(targets, {"cls_preds": cls_c, "bbox_preds": box_c}, [anchors] * B)
+        (out_c["classification_loss"] + 2.0 * out_c["regression_loss"]).backward()
+        np.testing.assert_allclose(float(out_l["classification_loss"]), float(out_c["classification_loss"]), rtol=1e-6)
+        np.testing.assert_allclose(float(out_l["regression_loss"]), float(out_c["regression_loss"]), rtol=1e-6)
+        assert torch.equal(torch.cat([c.grad for c in cls_l], 1), cls_c.grad)
+        assert torch.equal(torch.cat([b.grad for b in box_l], 1), box_c.grad)
+
+
+def test_train_path_uses_level_outputs_and_matches_cat_path():
+    """Retinanet.forward (per-level loss path) == compute_loss on the concatenated head outputs."""
+    import pytorch_retinanet_amd as P
+    torch.manual_seed(1)
+    net = P.Retinanet(num_classes=6, backbone_kind="resnet18", pretrained=False, min_size=128, max_size=160).to(DEV)
+    net = net.to(memory_format=torch.channels_last).train()
+    images = [torch.rand(3, 128, 160, device=DEV) for _ in range(2)]
+    targets = [{"boxes": torch.tensor([[10., 12., 90., 100.]], device=DEV), "labels": torch.tensor([2], device=DEV)},
+               {"boxes": torch.tensor([[20., 20., 70., 110.], [60., 30., 150., 120.]], device=DEV), "labels": torch.tensor([3, 6], device=DEV)}]
+    net.eval()   # same BN statistics for both passes
+    a = net(images, targets)
+    il, tg = net.transform(images, targets)
+    fmaps, outputs = net._features(il.tensors)
+    b = net.compute_loss(tg, outputs, net.anchor_generator(il, fmaps))
+    for k in a:
+        np.testing.assert_allclose(float(a[k]), float(b[k]), rtol=1e-5)
+    lv = net.retinanet_head.forward_levels(fmaps)["cls_levels"][0]
+    assert lv.is_contiguous()          # a view of the channels_last conv output: nothing was copied
