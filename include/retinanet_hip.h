@@ -125,6 +125,27 @@ int rn_loss_fwd_bwd_levels(const void *const *cls_levels, const void *const *box
  * the gradients rn_loss_fwd_bwd already wrote, without a host sync. */
 int rn_scale_inplace(void *data, int dtype, int64_t n, const float *scale, void *stream);
 
+/* ---- fused BatchNorm2d (+ residual) (+ ReLU), channels-last ---------------------------------
+ * Conv-stack widening.  Replaces the bn -> (+identity) -> relu sequences of the
+ * reference's residual blocks, retinanet/backbone.py:70-80 and :118-136, and the stem :248-250:
+ *   y = relu?( (x - mean) * invstd * gamma + beta  (+ residual) )
+ * x, residual, y: [M = N*H*W][C] (channels_last [N,C,H,W]), dtype in {f32, bf16, f16}, C % 8 == 0;
+ * gamma, beta, running_*, save_*: f32[C] (gamma/beta may be NULL = 1/0).  training != 0: batch
+ * statistics, running stats updated with `momentum` (unbiased variance), *num_batches_tracked += 1
+ * (nullable); training == 0: running statistics.  save_mean / save_invstd / coef ([2][C] forward,
+ * [3][C] backward scratch) are caller-owned; workspace: rn_bn_workspace_bytes(C).
+ * Backward returns dx, dresidual (nullable; = gradient after the ReLU mask), dgamma, dbeta. */
+size_t rn_bn_workspace_bytes(int C);
+int rn_bn_act_forward(const void *x, const void *residual, void *y, int dtype, int64_t M, int C,
+                      const float *gamma, const float *beta, float *running_mean, float *running_var,
+                      int64_t *num_batches_tracked, int training, float momentum, float eps, int relu,
+                      float *save_mean, float *save_invstd, float *coef, void *workspace,
+                      size_t workspace_bytes, void *stream);
+int rn_bn_act_backward(const void *dy, const void *y, const void *x, void *dx, void *dresidual, int dtype,
+                       int64_t M, int C, const float *gamma, const float *save_mean, const float *save_invstd,
+                       int training, int relu, float *dgamma, float *dbeta, float *coef, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
 /* ---- K4 decode_clip ---------------------------------------------------------
  * Replaces activ_2_bbox, retinanet/box_utils.py:37-48 (including its use of
  * dx,dy for the sizes, :46) and torchvision clip_boxes_to_image at

@@ -12,6 +12,8 @@ from typing import Dict, List, Optional, Type, Union
 import torch
 from torch import Tensor, nn
 
+from .norm import FusedBatchNorm2d
+
 __all__ = ["resnet18", "resnet34", "resnet50", "resnet101", "resnet152"]
 
 model_urls = {
@@ -37,18 +39,17 @@ class BasicBlock(nn.Module):
     def __init__(self, inplanes: int, planes: int, stride: int = 1, downsample: Optional[nn.Module] = None):
         super().__init__()
         self.conv1 = _conv3x3(inplanes, planes, stride)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = FusedBatchNorm2d(planes)
         self.relu = nn.ReLU(inplace=True)
         self.conv2 = _conv3x3(planes, planes)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = FusedBatchNorm2d(planes)
         self.downsample = downsample
         self.stride = stride
 
     def forward(self, x: Tensor) -> Tensor:
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        out = out + (x if self.downsample is None else self.downsample(x))
-        return self.relu(out)
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.bn1(self.conv1(x), relu=True)
+        return self.bn2(self.conv2(out), relu=True, residual=identity)      # relu(bn2(.) + identity), one kernel
 
 
 class Bottleneck(nn.Module):
@@ -57,21 +58,20 @@ class Bottleneck(nn.Module):
     def __init__(self, inplanes: int, planes: int, stride: int = 1, downsample: Optional[nn.Module] = None):
         super().__init__()
         self.conv1 = _conv1x1(inplanes, planes)
-        self.bn1 = nn.BatchNorm2d(planes)
+        self.bn1 = FusedBatchNorm2d(planes)
         self.conv2 = _conv3x3(planes, planes, stride)
-        self.bn2 = nn.BatchNorm2d(planes)
+        self.bn2 = FusedBatchNorm2d(planes)
         self.conv3 = _conv1x1(planes, planes * self.expansion)
-        self.bn3 = nn.BatchNorm2d(planes * self.expansion)
+        self.bn3 = FusedBatchNorm2d(planes * self.expansion)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
         self.stride = stride
 
     def forward(self, x: Tensor) -> Tensor:
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
-        out = out + (x if self.downsample is None else self.downsample(x))
-        return self.relu(out)
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        return self.bn3(self.conv3(out), relu=True, residual=identity)      # relu(bn3(.) + identity), one kernel
 
 
 class ResNetBackbone(nn.Module):
@@ -81,7 +81,7 @@ class ResNetBackbone(nn.Module):
         super().__init__()
         self.inplanes = 64
         self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
-        self.bn1 = nn.BatchNorm2d(64)
+        self.bn1 = FusedBatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
         self.layer1 = self._make_layer(block, 64, layers[0])
@@ -91,7 +91,7 @@ class ResNetBackbone(nn.Module):
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
-            elif isinstance(m, nn.BatchNorm2d):
+            elif isinstance(m, nn.BatchNorm2d):        # (FusedBatchNorm2d is a BatchNorm2d)
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
         if zero_init_residual:
@@ -105,14 +105,14 @@ class ResNetBackbone(nn.Module):
         downsample = None
         if stride != 1 or self.inplanes != planes * block.expansion:
             downsample = nn.Sequential(_conv1x1(self.inplanes, planes * block.expansion, stride),
-                                       nn.BatchNorm2d(planes * block.expansion))
+                                       FusedBatchNorm2d(planes * block.expansion))
         stack = [block(self.inplanes, planes, stride, downsample)]
         self.inplanes = planes * block.expansion
         stack += [block(self.inplanes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*stack)
 
     def _forward_impl(self, x: Tensor) -> Dict[str, Tensor]:
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(self.bn1(self.conv1(x), relu=True))
         x = self.layer1(x)
         c3 = self.layer2(x)
         c4 = self.layer3(c3)

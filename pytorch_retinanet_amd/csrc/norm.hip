@@ -1,0 +1,415 @@
+// Fused BatchNorm2d (+ residual add) (+ ReLU) for channels-last activations -- conv-stack widening
+// ("fused bias+ReLU / BN").  rocprof on the R50-FPN train step shows MIOpen's
+// batch norm (7 kernels per layer) plus the stand-alone ReLU and residual-add kernels around it at
+// ~30% of the GPU time and ~20% of the host launch time; they are all HBM-bound passes over the same
+// [N*H*W, C] activation.  This file does the same arithmetic as
+//   y = relu(batch_norm(x, running stats / batch stats, gamma, beta) + residual)
+// (reference call sites: retinanet/backbone.py:70-80, :118-136, :248-250) in
+//   forward  : 1 read of x for the statistics + 1 read of x (+ residual) and 1 write of y
+//   backward : 1 read of (dy, y, x) for the two channel sums + 1 read of (dy, y, x), 1 write of dx
+//              (+ 1 write of the residual branch's gradient)
+// i.e. 3 + 5 (+1) tensor passes instead of 5 + 8 (+3), in 3 + 3 launches instead of ~13.
+//
+// Layout: x is [N, C, H, W] in channels_last memory format = dense [M = N*H*W][C]; every thread
+// owns 8 consecutive channels (one 16-byte bf16 vector, two for fp32) so loads/stores are coalesced
+// and the per-channel coefficients live in registers.  Statistics: per-thread fp32 sums over a
+// block's rows, LDS tree over the block's row lanes, one partial per block, combined in double by a
+// per-channel kernel (deterministic; no float atomics).  Requires C % 8 == 0.
+#include "rn_common.hpp"
+
+namespace {
+
+constexpr int BN_BLOCK = 256;
+constexpr int BN_MAX_BLOCKS = 1024;
+
+template <int DT> struct vec8;          // 8 consecutive channels <-> float[8]
+template <> struct vec8<RN_BF16> {
+    static __device__ __forceinline__ void ld(const void *p, int64_t v, float (&f)[8]) { rn::dt<RN_BF16>::unpack(((const rn::u32x4 *)p)[v], f); }
+    static __device__ __forceinline__ void st(void *p, int64_t v, const float (&f)[8]) { ((rn::u32x4 *)p)[v] = rn::dt<RN_BF16>::pack(f); }
+};
+template <> struct vec8<RN_F16> {
+    static __device__ __forceinline__ void ld(const void *p, int64_t v, float (&f)[8]) { rn::dt<RN_F16>::unpack(((const rn::u32x4 *)p)[v], f); }
+    static __device__ __forceinline__ void st(void *p, int64_t v, const float (&f)[8]) { ((rn::u32x4 *)p)[v] = rn::dt<RN_F16>::pack(f); }
+};
+template <> struct vec8<RN_F32> {
+    static __device__ __forceinline__ void ld(const void *p, int64_t v, float (&f)[8]) {
+        const rn::f32x4 a = ((const rn::f32x4 *)p)[2 * v], b = ((const rn::f32x4 *)p)[2 * v + 1];
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    }
+    static __device__ __forceinline__ void st(void *p, int64_t v, const float (&f)[8]) {
+        rn::f32x4 a, b;
+        a.x = f[0]; a.y = f[1]; a.z = f[2]; a.w = f[3]; b.x = f[4]; b.y = f[5]; b.z = f[6]; b.w = f[7];
+        ((rn::f32x4 *)p)[2 * v] = a; ((rn::f32x4 *)p)[2 * v + 1] = b;
+    }
+};
+
+// Work split shared by the two reduction kernels: thread = (channel group cg, row lane rl); blocks own
+// contiguous row ranges.  C8 = C/8 channel groups; when C8 > 256 a thread loops over channel groups.
+struct Split { int C8, lanes, groups_per_thread; };
+__device__ __forceinline__ Split split_of(const int C)
+{
+    Split s;
+    s.C8 = C / 8;
+    if (s.C8 >= BN_BLOCK) { s.lanes = 1; s.groups_per_thread = (s.C8 + BN_BLOCK - 1) / BN_BLOCK; }
+    else { s.lanes = BN_BLOCK / s.C8; s.groups_per_thread = 1; }
+    return s;
+}
+
+// ---------------------------------------------------------------- forward statistics
+// partial[block][0][c] = sum x, partial[block][1][c] = sum x^2 over the block's rows
+template <int DT>
+__global__ __launch_bounds__(BN_BLOCK) void bn_stats_partial_kernel(const void *__restrict__ x, const int64_t M, const int C,
+                                                                    float *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [lanes][2][C]  (only when lanes > 1)
+    const Split sp = split_of(C);
+    const int64_t rows_per_block = (M + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, M);
+    for (int gi = 0; gi < sp.groups_per_thread; ++gi) {
+        const int cg = (sp.lanes > 1) ? (int)(threadIdx.x % sp.C8) : (int)threadIdx.x + gi * BN_BLOCK;
+        const int rl = (sp.lanes > 1) ? (int)(threadIdx.x / sp.C8) : 0;
+        float s[8], q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
+        if (cg < sp.C8 && rl < sp.lanes) {
+            for (int64_t r = r0 + rl; r < r1; r += sp.lanes) {
+                float f[8];
+                vec8<DT>::ld(x, r * sp.C8 + cg, f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] = fmaf(f[j], f[j], q[j]); }
+            }
+        }
+        if (sp.lanes > 1) {
+            if (cg < sp.C8 && rl < sp.lanes) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { smem[(rl * 2 + 0) * C + cg * 8 + j] = s[j]; smem[(rl * 2 + 1) * C + cg * 8 + j] = q[j]; }
+            }
+            __syncthreads();
+            for (int c = threadIdx.x; c < 2 * C; c += BN_BLOCK) {      // c indexes [2][C]
+                float t = 0.0f;
+                for (int l = 0; l < sp.lanes; ++l) t += smem[l * 2 * C + c];
+                partial[(int64_t)blockIdx.x * 2 * C + c] = t;
+            }
+        } else if (cg < sp.C8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                partial[(int64_t)blockIdx.x * 2 * C + cg * 8 + j] = s[j];
+                partial[(int64_t)blockIdx.x * 2 * C + C + cg * 8 + j] = q[j];
+            }
+        }
+    }
+}
+
+// per channel: mean / inverse std of the batch, the affine coefficients y = x*a + b, running-stat update
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float *__restrict__ partial, const int nblocks, const int64_t M,
+                                                             const int C, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                             float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                             int64_t *__restrict__ num_batches_tracked, const float momentum,
+                                                             const float eps, float *__restrict__ save_mean, float *__restrict__ save_invstd,
+                                                             float *__restrict__ coef_a, float *__restrict__ coef_b)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblocks; ++b) { s += (double)partial[(int64_t)b * 2 * C + c]; q += (double)partial[(int64_t)b * 2 * C + C + c]; }
+    const double mean = s / (double)M;
+    double var = q / (double)M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[c] = (float)mean;
+    save_invstd[c] = invstd;
+    const float a = (gamma ? gamma[c] : 1.0f) * invstd;
+    coef_a[c] = a;
+    coef_b[c] = (beta ? beta[c] : 0.0f) - (float)mean * a;
+    if (running_mean) {
+        const double unbiased = (M > 1) ? var * (double)M / (double)(M - 1) : var;
+        running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// eval mode: coefficients from the running statistics
+__global__ __launch_bounds__(256) void bn_eval_coef_kernel(const int C, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                           const float *__restrict__ running_mean, const float *__restrict__ running_var,
+                                                           const float eps, float *__restrict__ save_mean, float *__restrict__ save_invstd,
+                                                           float *__restrict__ coef_a, float *__restrict__ coef_b)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = 1.0f / sqrtf(running_var[c] + eps);
+    const float a = (gamma ? gamma[c] : 1.0f) * invstd;
+    save_mean[c] = running_mean[c];
+    save_invstd[c] = invstd;
+    coef_a[c] = a;
+    coef_b[c] = (beta ? beta[c] : 0.0f) - running_mean[c] * a;
+}
+
+// ---------------------------------------------------------------- forward apply: y = act(x*a + b (+ res))
+template <int DT, bool RELU, bool RES>
+__global__ __launch_bounds__(BN_BLOCK) void bn_apply_kernel(const void *__restrict__ x, const void *__restrict__ res, void *__restrict__ y,
+                                                            const int64_t nvec, const int C8, const float *__restrict__ coef_a,
+                                                            const float *__restrict__ coef_b)
+{
+    // C8 | 256 (every ResNet width): a thread always lands on the same channel group -> coefficients in registers
+    const bool fixed = (BN_BLOCK % C8) == 0;
+    float a[8], b[8];
+    if (fixed) { vec8<RN_F32>::ld(coef_a, threadIdx.x % C8, a); vec8<RN_F32>::ld(coef_b, threadIdx.x % C8, b); }
+    for (int64_t v = (int64_t)blockIdx.x * BN_BLOCK + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * BN_BLOCK) {
+        float f[8], r[8];
+        vec8<DT>::ld(x, v, f);
+        if (RES) vec8<DT>::ld(res, v, r);
+        if (!fixed) { const int cg = (int)(v % C8); vec8<RN_F32>::ld(coef_a, cg, a); vec8<RN_F32>::ld(coef_b, cg, b); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = fmaf(f[j], a[j], b[j]);
+            if (RES) t += r[j];
+            if (RELU) t = t > 0.0f ? t : 0.0f;
+            f[j] = t;
+        }
+        vec8<DT>::st(y, v, f);
+    }
+}
+
+// ---------------------------------------------------------------- backward sums
+// g = dy * (y > 0) (RELU) ; partial[block][0][c] = sum g, partial[block][1][c] = sum g * xhat
+template <int DT, bool RELU>
+__global__ __launch_bounds__(BN_BLOCK) void bn_bwd_partial_kernel(const void *__restrict__ dy, const void *__restrict__ y,
+                                                                  const void *__restrict__ x, const int64_t M, const int C,
+                                                                  const float *__restrict__ save_mean, const float *__restrict__ save_invstd,
+                                                                  float *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Split sp = split_of(C);
+    const int64_t rows_per_block = (M + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, M);
+    for (int gi = 0; gi < sp.groups_per_thread; ++gi) {
+        const int cg = (sp.lanes > 1) ? (int)(threadIdx.x % sp.C8) : (int)threadIdx.x + gi * BN_BLOCK;
+        const int rl = (sp.lanes > 1) ? (int)(threadIdx.x / sp.C8) : 0;
+        float s[8], q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
+        if (cg < sp.C8 && rl < sp.lanes) {
+            float mu[8], is[8];
+            vec8<RN_F32>::ld(save_mean, cg, mu);
+            vec8<RN_F32>::ld(save_invstd, cg, is);
+            for (int64_t r = r0 + rl; r < r1; r += sp.lanes) {
+                const int64_t v = r * sp.C8 + cg;
+                float g[8], yy[8], xx[8];
+                vec8<DT>::ld(dy, v, g);
+                vec8<DT>::ld(x, v, xx);
+                if (RELU) vec8<DT>::ld(y, v, yy);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float gj = (RELU && !(yy[j] > 0.0f)) ? 0.0f : g[j];
+                    s[j] += gj;
+                    q[j] = fmaf(gj, (xx[j] - mu[j]) * is[j], q[j]);
+                }
+            }
+        }
+        if (sp.lanes > 1) {
+            if (cg < sp.C8 && rl < sp.lanes) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { smem[(rl * 2 + 0) * C + cg * 8 + j] = s[j]; smem[(rl * 2 + 1) * C + cg * 8 + j] = q[j]; }
+            }
+            __syncthreads();
+            for (int c = threadIdx.x; c < 2 * C; c += BN_BLOCK) {
+                float t = 0.0f;
+                for (int l = 0; l < sp.lanes; ++l) t += smem[l * 2 * C + c];
+                partial[(int64_t)blockIdx.x * 2 * C + c] = t;
+            }
+        } else if (cg < sp.C8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                partial[(int64_t)blockIdx.x * 2 * C + cg * 8 + j] = s[j];
+                partial[(int64_t)blockIdx.x * 2 * C + C + cg * 8 + j] = q[j];
+            }
+        }
+    }
+}
+
+// per channel: dgamma, dbeta and the coefficients of dx = a*g + k0 + k1*x
+//   training: dx = a*(g - mean(g) - xhat*mean(g*xhat));  eval (frozen statistics): dx = a*g
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float *__restrict__ partial, const int nblocks, const int64_t M, const int C,
+                                                           const float *__restrict__ gamma, const float *__restrict__ save_mean,
+                                                           const float *__restrict__ save_invstd, const int training,
+                                                           float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                           float *__restrict__ coef_a, float *__restrict__ coef_k0, float *__restrict__ coef_k1)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblocks; ++b) { s += (double)partial[(int64_t)b * 2 * C + c]; q += (double)partial[(int64_t)b * 2 * C + C + c]; }
+    if (dbeta) dbeta[c] = (float)s;
+    if (dgamma) dgamma[c] = (float)q;
+    const float a = (gamma ? gamma[c] : 1.0f) * save_invstd[c];
+    coef_a[c] = a;
+    if (training) {
+        const double c1 = -(double)a * s / (double)M, c2 = -(double)a * q / (double)M;
+        coef_k1[c] = (float)(c2 * (double)save_invstd[c]);
+        coef_k0[c] = (float)(c1 - c2 * (double)save_mean[c] * (double)save_invstd[c]);
+    } else {
+        coef_k0[c] = 0.0f; coef_k1[c] = 0.0f;
+    }
+}
+
+// dx = a*g + k0 + k1*x ; dres = g
+template <int DT, bool RELU, bool RES>
+__global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(const void *__restrict__ dy, const void *__restrict__ y, const void *__restrict__ x,
+                                                                void *__restrict__ dx, void *__restrict__ dres, const int64_t nvec, const int C8,
+                                                                const float *__restrict__ coef_a, const float *__restrict__ coef_k0,
+                                                                const float *__restrict__ coef_k1)
+{
+    const bool fixed = (BN_BLOCK % C8) == 0;
+    float a[8], k0[8], k1[8];
+    if (fixed) {
+        const int cg = threadIdx.x % C8;
+        vec8<RN_F32>::ld(coef_a, cg, a); vec8<RN_F32>::ld(coef_k0, cg, k0); vec8<RN_F32>::ld(coef_k1, cg, k1);
+    }
+    for (int64_t v = (int64_t)blockIdx.x * BN_BLOCK + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * BN_BLOCK) {
+        float g[8], yy[8], xx[8];
+        vec8<DT>::ld(dy, v, g);
+        vec8<DT>::ld(x, v, xx);
+        if (RELU) vec8<DT>::ld(y, v, yy);
+        if (!fixed) {
+            const int cg = (int)(v % C8);
+            vec8<RN_F32>::ld(coef_a, cg, a); vec8<RN_F32>::ld(coef_k0, cg, k0); vec8<RN_F32>::ld(coef_k1, cg, k1);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (RELU && !(yy[j] > 0.0f)) g[j] = 0.0f;
+            xx[j] = fmaf(a[j], g[j], fmaf(k1[j], xx[j], k0[j]));
+        }
+        vec8<DT>::st(dx, v, xx);
+        if (RES) vec8<DT>::st(dres, v, g);
+    }
+}
+
+int reduce_blocks(const int64_t M)
+{
+    int64_t b = (M + 255) / 256;               // at least ~256 rows per block
+    if (b > BN_MAX_BLOCKS) b = BN_MAX_BLOCKS;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+size_t reduce_lds(const int C)
+{
+    const int C8 = C / 8;
+    const int lanes = (C8 >= BN_BLOCK) ? 1 : BN_BLOCK / C8;
+    return lanes > 1 ? sizeof(float) * (size_t)lanes * 2 * C : 0;
+}
+
+int apply_blocks(const int64_t nvec)
+{
+    int64_t b = (nvec + BN_BLOCK - 1) / BN_BLOCK;
+    if (b > 8192) b = 8192;
+    return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+// workspace: partial f32[BN_MAX_BLOCKS][2][C]
+RN_API size_t rn_bn_workspace_bytes(int C) { return C > 0 ? sizeof(float) * (size_t)BN_MAX_BLOCKS * 2 * (size_t)C : 0; }
+
+RN_API int rn_bn_act_forward(const void *x, const void *residual, void *y, int dtype, int64_t M, int C,
+                             const float *gamma, const float *beta, float *running_mean, float *running_var,
+                             int64_t *num_batches_tracked, int training, float momentum, float eps, int relu,
+                             float *save_mean, float *save_invstd, float *coef /*[2][C]*/, void *workspace,
+                             size_t workspace_bytes, void *stream)
+{
+    if (!x || !y || !save_mean || !save_invstd || !coef || M <= 0 || C <= 0) return RN_EINVAL;
+    if (C % 8) return RN_EUNSUPPORTED;
+    if (dtype != RN_F32 && dtype != RN_BF16 && dtype != RN_F16) return RN_EINVAL;
+    if (!rn::aligned(x, 16) || !rn::aligned(y, 16) || (residual && !rn::aligned(residual, 16)) || !rn::aligned(coef, 16) ||
+        !rn::aligned(save_mean, 16) || !rn::aligned(save_invstd, 16))
+        return RN_EALIGN;
+    if (!training && (!running_mean || !running_var)) return RN_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    float *ca = coef, *cb = coef + C;
+    if (training) {
+        if (!workspace || workspace_bytes < rn_bn_workspace_bytes(C)) return RN_EWORKSPACE;
+        const int nb = reduce_blocks(M);
+        const size_t lds = reduce_lds(C);
+        float *partial = (float *)workspace;
+        switch (dtype) {
+            case RN_F32: hipLaunchKernelGGL((bn_stats_partial_kernel<RN_F32>), dim3(nb), dim3(BN_BLOCK), lds, st, x, M, C, partial); break;
+            case RN_BF16: hipLaunchKernelGGL((bn_stats_partial_kernel<RN_BF16>), dim3(nb), dim3(BN_BLOCK), lds, st, x, M, C, partial); break;
+            default: hipLaunchKernelGGL((bn_stats_partial_kernel<RN_F16>), dim3(nb), dim3(BN_BLOCK), lds, st, x, M, C, partial); break;
+        }
+        RN_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, nb, M, C, gamma, beta, running_mean,
+                           running_var, num_batches_tracked, momentum, eps, save_mean, save_invstd, ca, cb);
+        RN_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(bn_eval_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, C, gamma, beta, running_mean, running_var, eps,
+                           save_mean, save_invstd, ca, cb);
+        RN_LAUNCH_CHECK();
+    }
+    const int64_t nvec = M * (C / 8);
+    const dim3 g(apply_blocks(nvec)), b(BN_BLOCK);
+    const int C8 = C / 8;
+#define RN_BN_APPLY(DT)                                                                                                          \
+    if (relu) { if (residual) hipLaunchKernelGGL((bn_apply_kernel<DT, true, true>), g, b, 0, st, x, residual, y, nvec, C8, ca, cb);    \
+                else hipLaunchKernelGGL((bn_apply_kernel<DT, true, false>), g, b, 0, st, x, residual, y, nvec, C8, ca, cb); }           \
+    else      { if (residual) hipLaunchKernelGGL((bn_apply_kernel<DT, false, true>), g, b, 0, st, x, residual, y, nvec, C8, ca, cb);   \
+                else hipLaunchKernelGGL((bn_apply_kernel<DT, false, false>), g, b, 0, st, x, residual, y, nvec, C8, ca, cb); }
+    switch (dtype) {
+        case RN_F32: RN_BN_APPLY(RN_F32) break;
+        case RN_BF16: RN_BN_APPLY(RN_BF16) break;
+        default: RN_BN_APPLY(RN_F16) break;
+    }
+#undef RN_BN_APPLY
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+RN_API int rn_bn_act_backward(const void *dy, const void *y, const void *x, void *dx, void *dresidual, int dtype, int64_t M,
+                              int C, const float *gamma, const float *save_mean, const float *save_invstd, int training,
+                              int relu, float *dgamma, float *dbeta, float *coef /*[3][C]*/, void *workspace,
+                              size_t workspace_bytes, void *stream)
+{
+    if (!dy || !x || !dx || !save_mean || !save_invstd || !coef || M <= 0 || C <= 0) return RN_EINVAL;
+    if (relu && !y) return RN_EINVAL;
+    if (C % 8) return RN_EUNSUPPORTED;
+    if (dtype != RN_F32 && dtype != RN_BF16 && dtype != RN_F16) return RN_EINVAL;
+    if (!workspace || workspace_bytes < rn_bn_workspace_bytes(C)) return RN_EWORKSPACE;
+    if (!rn::aligned(dy, 16) || !rn::aligned(x, 16) || !rn::aligned(dx, 16) || (y && !rn::aligned(y, 16)) ||
+        (dresidual && !rn::aligned(dresidual, 16)) || !rn::aligned(coef, 16) || !rn::aligned(save_mean, 16) ||
+        !rn::aligned(save_invstd, 16))
+        return RN_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = reduce_blocks(M);
+    const size_t lds = reduce_lds(C);
+    float *partial = (float *)workspace;
+    float *ca = coef, *k0 = coef + C, *k1 = coef + 2 * C;
+#define RN_BN_BWD_PART(DT)                                                                                                             \
+    if (relu) hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, true>), dim3(nb), dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, partial); \
+    else hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, false>), dim3(nb), dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, partial);
+    switch (dtype) {
+        case RN_F32: RN_BN_BWD_PART(RN_F32) break;
+        case RN_BF16: RN_BN_BWD_PART(RN_BF16) break;
+        default: RN_BN_BWD_PART(RN_F16) break;
+    }
+#undef RN_BN_BWD_PART
+    RN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, nb, M, C, gamma, save_mean, save_invstd,
+                       training, dgamma, dbeta, ca, k0, k1);
+    RN_LAUNCH_CHECK();
+    const int64_t nvec = M * (C / 8);
+    const dim3 g(apply_blocks(nvec)), b(BN_BLOCK);
+    const int C8 = C / 8;
+#define RN_BN_BWD_APPLY(DT)                                                                                                                  \
+    if (relu) { if (dresidual) hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, true, true>), g, b, 0, st, dy, y, x, dx, dresidual, nvec, C8, ca, k0, k1);   \
+                else hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, true, false>), g, b, 0, st, dy, y, x, dx, dresidual, nvec, C8, ca, k0, k1); }         \
+    else      { if (dresidual) hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, false, true>), g, b, 0, st, dy, y, x, dx, dresidual, nvec, C8, ca, k0, k1);  \
+                else hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, false, false>), g, b, 0, st, dy, y, x, dx, dresidual, nvec, C8, ca, k0, k1); }
+    switch (dtype) {
+        case RN_F32: RN_BN_BWD_APPLY(RN_F32) break;
+        case RN_BF16: RN_BN_BWD_APPLY(RN_BF16) break;
+        default: RN_BN_BWD_APPLY(RN_F16) break;
+    }
+#undef RN_BN_BWD_APPLY
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
