@@ -20,7 +20,9 @@
 namespace {
 
 constexpr int BN_BLOCK = 256;
-constexpr int BN_MAX_BLOCKS = 1024;
+constexpr int BN_MAX_BLOCKS = 512;
+constexpr int FIN_CH = 16;                // channels per block of the per-channel kernels
+constexpr int FIN_LANES = 256 / FIN_CH;    // threads that split the partial sums of one channel
 
 template <int DT> struct vec8;          // 8 consecutive channels <-> float[8]
 template <> struct vec8<RN_BF16> {
@@ -100,6 +102,22 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_stats_partial_kernel(const void *
     }
 }
 
+// Sum of the per-block partials of one channel pair, split over FIN_LANES threads and combined in
+// double through LDS (fixed order: deterministic).  Returns the totals to the lane-0 thread of each channel.
+__device__ __forceinline__ void channel_totals(const float *__restrict__ partial, const int nblocks, const int C, const int c,
+                                               const int ln, double (*sh)[FIN_LANES][FIN_CH], double &s, double &q)
+{
+    double ls = 0.0, lq = 0.0;
+    if (c < C)
+        for (int b = ln; b < nblocks; b += FIN_LANES) { ls += (double)partial[(int64_t)b * 2 * C + c]; lq += (double)partial[(int64_t)b * 2 * C + C + c]; }
+    const int ch = threadIdx.x % FIN_CH;
+    sh[0][ln][ch] = ls; sh[1][ln][ch] = lq;
+    __syncthreads();
+    s = 0.0; q = 0.0;
+    if (ln == 0)
+        for (int l = 0; l < FIN_LANES; ++l) { s += sh[0][l][ch]; q += sh[1][l][ch]; }
+}
+
 // per channel: mean / inverse std of the batch, the affine coefficients y = x*a + b, running-stat update
 __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float *__restrict__ partial, const int nblocks, const int64_t M,
                                                              const int C, const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -108,11 +126,12 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float *__rest
                                                              const float eps, float *__restrict__ save_mean, float *__restrict__ save_invstd,
                                                              float *__restrict__ coef_a, float *__restrict__ coef_b)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblocks; ++b) { s += (double)partial[(int64_t)b * 2 * C + c]; q += (double)partial[(int64_t)b * 2 * C + C + c]; }
+    __shared__ double sh[2][FIN_LANES][FIN_CH];
+    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, ln = threadIdx.x / FIN_CH;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
+    double s, q;
+    channel_totals(partial, nblocks, C, c, ln, sh, s, q);
+    if (ln != 0 || c >= C) return;
     const double mean = s / (double)M;
     double var = q / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -236,10 +255,11 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float *__restri
                                                            float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                            float *__restrict__ coef_a, float *__restrict__ coef_k0, float *__restrict__ coef_k1)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblocks; ++b) { s += (double)partial[(int64_t)b * 2 * C + c]; q += (double)partial[(int64_t)b * 2 * C + C + c]; }
+    __shared__ double sh[2][FIN_LANES][FIN_CH];
+    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, ln = threadIdx.x / FIN_CH;
+    double s, q;
+    channel_totals(partial, nblocks, C, c, ln, sh, s, q);
+    if (ln != 0 || c >= C) return;
     if (dbeta) dbeta[c] = (float)s;
     if (dgamma) dgamma[c] = (float)q;
     const float a = (gamma ? gamma[c] : 1.0f) * save_invstd[c];
@@ -338,7 +358,7 @@ RN_API int rn_bn_act_forward(const void *x, const void *residual, void *y, int d
             default: hipLaunchKernelGGL((bn_stats_partial_kernel<RN_F16>), dim3(nb), dim3(BN_BLOCK), lds, st, x, M, C, partial); break;
         }
         RN_LAUNCH_CHECK();
-        hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, nb, M, C, gamma, beta, running_mean,
+        hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, st, partial, nb, M, C, gamma, beta, running_mean,
                            running_var, num_batches_tracked, momentum, eps, save_mean, save_invstd, ca, cb);
         RN_LAUNCH_CHECK();
     } else {
@@ -393,7 +413,7 @@ RN_API int rn_bn_act_backward(const void *dy, const void *y, const void *x, void
     }
 #undef RN_BN_BWD_PART
     RN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, nb, M, C, gamma, save_mean, save_invstd,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, st, partial, nb, M, C, gamma, save_mean, save_invstd,
                        training, dgamma, dbeta, ca, k0, k1);
     RN_LAUNCH_CHECK();
     const int64_t nvec = M * (C / 8);

@@ -10,16 +10,33 @@ activations this runs the fused HIP kernels of ``csrc/norm.hip`` (3 launches for
 instead of MIOpen's 7 batch-norm kernels plus separate add / ReLU / ReLU-backward kernels); anything
 else (CPU tensors, NCHW layout, odd channel counts) takes the ordinary PyTorch ops, so the conv stack
 still runs anywhere -- the *dense head* is the part that has no CPU path.
+
+The wrapper is on the host's critical path (53 layers x forward/backward per step), so it keeps the
+Python work per call small: one scratch allocation, one shared reduction workspace per device
+(kernels of one stream are ordered, the workspace is dead when a call's last kernel has run), raw
+pointers, no device-context switch when the tensor already lives on the current device.
 """
 import ctypes as C
-from typing import Optional
+from typing import Dict, Optional
 
 import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
 
-from ._lib import check, lib
-from .ops import _dtype_code, _ptr, _stream
+from ._lib import RN_BF16, RN_F16, RN_F32, check, lib
+
+_DT = {torch.float32: RN_F32, torch.bfloat16: RN_BF16, torch.float16: RN_F16}
+_WS: Dict[tuple, Tensor] = {}          # (device index, stream) -> reduction workspace
+_fwd, _bwd = lib.rn_bn_act_forward, lib.rn_bn_act_backward
+
+
+def _workspace(dev: torch.device, stream: int, C_: int):
+    need = lib.rn_bn_workspace_bytes(C_)
+    key = (dev.index, stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _WS[key] = torch.empty((max(need, lib.rn_bn_workspace_bytes(2048)),), dtype=torch.uint8, device=dev)
+    return ws.data_ptr(), ws.numel()
 
 
 def _cl(t: Tensor) -> bool:
@@ -32,15 +49,17 @@ class _BNAct(torch.autograd.Function):
         N, Cc, H, W = x.shape
         M = N * H * W
         dev = x.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        stream = torch.cuda.current_stream().cuda_stream
         y = torch.empty_like(x)                                   # keeps the channels_last strides
-        stats = torch.empty((4, Cc), dtype=torch.float32, device=dev)   # save_mean, save_invstd, coef a, coef b
-        ws_bytes = lib.rn_bn_workspace_bytes(Cc)
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev) if training else None
-        with torch.cuda.device(dev):
-            check(lib.rn_bn_act_forward(_ptr(x), _ptr(residual), _ptr(y), _dtype_code(x), M, Cc, _ptr(weight), _ptr(bias),
-                                        _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), int(training),
-                                        float(momentum), float(eps), int(relu), _ptr(stats[0]), _ptr(stats[1]), _ptr(stats[2]),
-                                        _ptr(ws), ws_bytes if training else 0, _stream(dev)), "rn_bn_act_forward")
+        stats = torch.empty((4 * Cc,), dtype=torch.float32, device=dev)   # save_mean | save_invstd | coef a | coef b
+        sp = stats.data_ptr()
+        wp, wn = _workspace(dev, stream, Cc) if training else (0, 0)
+        check(_fwd(x.data_ptr(), residual.data_ptr() if residual is not None else 0, y.data_ptr(), _DT[x.dtype], M, Cc,
+                   weight.data_ptr(), bias.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
+                   num_batches_tracked.data_ptr() if num_batches_tracked is not None else 0, int(training), momentum, eps,
+                   int(relu), sp, sp + 4 * Cc, sp + 8 * Cc, wp, wn, stream), "rn_bn_act_forward")
         ctx.save_for_backward(x, y if relu else None, weight, stats)
         ctx.cfg = (bool(training), bool(relu), residual is not None, M, Cc)
         return y
@@ -50,29 +69,27 @@ class _BNAct(torch.autograd.Function):
         x, y, weight, stats = ctx.saved_tensors
         training, relu, has_res, M, Cc = ctx.cfg
         dev = x.device
-        if not _cl(dy) or dy.dtype != x.dtype:
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        if dy.dtype != x.dtype or not _cl(dy):
             dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if has_res else None
-        grads = torch.empty((5, Cc), dtype=torch.float32, device=dev)     # dgamma, dbeta, coef a, k0, k1
-        ws_bytes = lib.rn_bn_workspace_bytes(Cc)
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
-            check(lib.rn_bn_act_backward(_ptr(dy), _ptr(y), _ptr(x), _ptr(dx), _ptr(dres), _dtype_code(x), M, Cc, _ptr(weight),
-                                         _ptr(stats[0]), _ptr(stats[1]), int(training), int(relu), _ptr(grads[0]), _ptr(grads[1]),
-                                         _ptr(grads[2]), _ptr(ws), ws_bytes, _stream(dev)), "rn_bn_act_backward")
-        dgamma = grads[0].to(weight.dtype) if weight is not None else None
-        dbeta = grads[1].to(weight.dtype) if weight is not None else None
-        return dx, dres, dgamma, dbeta, None, None, None, None, None, None, None
+        grads = torch.empty((5 * Cc,), dtype=torch.float32, device=dev)     # dgamma | dbeta | coef a | k0 | k1
+        gp, sp = grads.data_ptr(), stats.data_ptr()
+        wp, wn = _workspace(dev, stream, Cc)
+        check(_bwd(dy.data_ptr(), y.data_ptr() if y is not None else 0, x.data_ptr(), dx.data_ptr(),
+                   dres.data_ptr() if dres is not None else 0, _DT[x.dtype], M, Cc, weight.data_ptr(), sp, sp + 4 * Cc,
+                   int(training), int(relu), gp, gp + 4 * Cc, gp + 8 * Cc, wp, wn, stream), "rn_bn_act_backward")
+        return dx, dres, grads[:Cc], grads[Cc:2 * Cc], None, None, None, None, None, None, None
 
 
 class FusedBatchNorm2d(nn.BatchNorm2d):
     def _fusable(self, x: Tensor, residual: Optional[Tensor]) -> bool:
-        if not (x.is_cuda and _cl(x) and x.shape[1] % 8 == 0 and x.dtype in (torch.float32, torch.bfloat16, torch.float16)):
+        if not (x.is_cuda and x.dtype in _DT and x.shape[1] % 8 == 0 and _cl(x) and x.numel()):
             return False
-        if not (self.affine and self.track_running_stats and self.momentum is not None):
-            return False
-        if self.weight.dtype != torch.float32 or x.numel() == 0:
+        if not (self.affine and self.track_running_stats and self.momentum is not None and self.weight.dtype == torch.float32):
             return False
         if residual is not None and not (residual.shape == x.shape and residual.dtype == x.dtype and _cl(residual)):
             return False
