@@ -74,7 +74,17 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_stats_partial_kernel(const void *
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
         if (cg < sp.C8 && rl < sp.lanes) {
-            for (int64_t r = r0 + rl; r < r1; r += sp.lanes) {
+            int64_t r = r0 + rl;
+            for (; r + 3 * sp.lanes < r1; r += 4 * sp.lanes) {          // 4 independent 16-byte loads in flight per thread
+                float f[4][8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) vec8<DT>::ld(x, (r + u * sp.lanes) * sp.C8 + cg, f[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { s[j] += f[u][j]; q[j] = fmaf(f[u][j], f[u][j], q[j]); }
+            }
+            for (; r < r1; r += sp.lanes) {
                 float f[8];
                 vec8<DT>::ld(x, r * sp.C8 + cg, f);
 #pragma unroll
@@ -212,7 +222,26 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_partial_kernel(const void *__
             float mu[8], is[8];
             vec8<RN_F32>::ld(save_mean, cg, mu);
             vec8<RN_F32>::ld(save_invstd, cg, is);
-            for (int64_t r = r0 + rl; r < r1; r += sp.lanes) {
+            int64_t r = r0 + rl;
+            for (; r + sp.lanes < r1; r += 2 * sp.lanes) {              // 2 rows x 3 tensors = 6 loads in flight per thread
+                float g[2][8], yy[2][8], xx[2][8];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int64_t v = (r + u * sp.lanes) * sp.C8 + cg;
+                    vec8<DT>::ld(dy, v, g[u]);
+                    vec8<DT>::ld(x, v, xx[u]);
+                    if (RELU) vec8<DT>::ld(y, v, yy[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float gj = (RELU && !(yy[u][j] > 0.0f)) ? 0.0f : g[u][j];
+                        s[j] += gj;
+                        q[j] = fmaf(gj, (xx[u][j] - mu[j]) * is[j], q[j]);
+                    }
+            }
+            for (; r < r1; r += sp.lanes) {
                 const int64_t v = r * sp.C8 + cg;
                 float g[8], yy[8], xx[8];
                 vec8<DT>::ld(dy, v, g);
