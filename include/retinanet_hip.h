@@ -183,6 +183,17 @@ int rn_detect(const void *cls, const void *deltas, int dtype, int B, int64_t A, 
               float *out_boxes, float *out_scores, int64_t *out_labels, int32_t *out_count,
               int32_t *out_status, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Same chain on the per-level head outputs: cls_levels[l] [B][A_l][K], box_levels[l] [B][A_l][4]
+ * (level_anchors[l] = A_l, levels in anchor order, L <= RN_MAX_LEVELS), i.e. the conv outputs of
+ * retinanet/layers.py:189-195 / :253-259 before their torch.cat.  Results are
+ * identical to rn_detect on the concatenation; workspace: rn_detect_workspace_bytes(B, sum A_l, K, max_candidates). */
+int rn_detect_levels(const void *const *cls_levels, const void *const *box_levels,
+                     const int64_t *level_anchors, int L, int dtype, int B, int K,
+                     const float *anchors, int64_t anchor_bstride, const int32_t *image_hw,
+                     const rn_detect_params *params, int64_t max_candidates,
+                     float *out_boxes, float *out_scores, int64_t *out_labels, int32_t *out_count,
+                     int32_t *out_status, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,8 @@ SIGNATURES = {
     "rn_detect_workspace_bytes": (_sz, [C.c_int, _i64, C.c_int, _i64]),
     "rn_detect": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _i64, C.c_int, _vp, _i64, _vp, C.POINTER(RnDetectParams),
                             _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rn_detect_levels": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _i64, _vp,
+                                   C.POINTER(RnDetectParams), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 

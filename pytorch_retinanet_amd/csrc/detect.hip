@@ -52,14 +52,16 @@ __device__ __forceinline__ rn::f32x4 decode_one(const float (&d)[4], const rn::f
 }
 
 template <int DT>
-__global__ __launch_bounds__(256) void decode_clip_kernel(const void *__restrict__ deltas, const int64_t A, const int64_t R,
+// deltas: one pyramid level [B][A_l][4]; its anchors are rows base .. base+A_l of the A per image.
+__global__ __launch_bounds__(256) void decode_clip_kernel(const void *__restrict__ deltas, const int64_t A_l, const int64_t base,
+                                                          const int64_t A, const int64_t R,
                                                           const rn::f32x4 *__restrict__ anchors, const int64_t anchor_bstride4,
                                                           const int32_t *__restrict__ image_hw, const RegW rw,
                                                           rn::f32x4 *__restrict__ out)
 {
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
-        const int b = (int)((uint32_t)r / (uint32_t)A);
-        const int64_t ai = r - (int64_t)b * A;
+        const int b = (int)((uint32_t)r / (uint32_t)A_l);
+        const int64_t ai = base + (r - (int64_t)b * A_l);
         float d[4];
         delta4<DT>::ld(deltas, r, d);
         rn::f32x4 o = decode_one(d, anchors[(int64_t)b * anchor_bstride4 + ai], rw);
@@ -68,8 +70,26 @@ __global__ __launch_bounds__(256) void decode_clip_kernel(const void *__restrict
             o.x = clampf(o.x, 0.0f, ww); o.z = clampf(o.z, 0.0f, ww);
             o.y = clampf(o.y, 0.0f, hh); o.w = clampf(o.w, 0.0f, hh);
         }
-        out[r] = o;
+        out[(int64_t)b * A + ai] = o;
     }
+}
+
+int launch_decode(const void *deltas, const int dtype, const int B, const int64_t A_l, const int64_t base, const int64_t A,
+                  const float *anchors, const int64_t anchor_bstride, const int32_t *image_hw, const RegW rw, float *out,
+                  hipStream_t st)
+{
+    const int64_t R = (int64_t)B * A_l;
+    int64_t blocks = (R + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    const dim3 g((unsigned)blocks), blk(256);
+    switch (dtype) {
+        case RN_F32: hipLaunchKernelGGL((decode_clip_kernel<RN_F32>), g, blk, 0, st, deltas, A_l, base, A, R, (const rn::f32x4 *)anchors, anchor_bstride / 4, image_hw, rw, (rn::f32x4 *)out); break;
+        case RN_BF16: hipLaunchKernelGGL((decode_clip_kernel<RN_BF16>), g, blk, 0, st, deltas, A_l, base, A, R, (const rn::f32x4 *)anchors, anchor_bstride / 4, image_hw, rw, (rn::f32x4 *)out); break;
+        case RN_F16: hipLaunchKernelGGL((decode_clip_kernel<RN_F16>), g, blk, 0, st, deltas, A_l, base, A, R, (const rn::f32x4 *)anchors, anchor_bstride / 4, image_hw, rw, (rn::f32x4 *)out); break;
+        default: return RN_EINVAL;
+    }
+    RN_LAUNCH_CHECK();
+    return RN_OK;
 }
 
 
@@ -86,10 +106,19 @@ constexpr int SCAN_WAVES = SCAN_THREADS / RN_WAVE;
 constexpr int SCAN_CAP = 128;            // wave-private list entries (>= 64: one ballot's worth always fits after a flush)
 constexpr int SCAN_PF = 2;
 
-struct ScanArgs {
+// One pyramid level of the class logits, [B][A_l][K] dense; the levels are scanned as one virtual
+// sequence of 16-byte vectors (level l = vectors voff .. voff + nvec), like K3 (loss.hip).
+struct ScanLevel {
     const void *cls;
+    int64_t A_l, base;       // anchors of this level per image; index of its first anchor among the A
+    int64_t N, nvec, voff;   // elements, whole vectors, first virtual vector
+};
+
+struct ScanArgs {
+    int L;
+    ScanLevel lv[RN_MAX_LEVELS];
     const rn::f32x4 *boxes;
-    int64_t A, N, vec_per_wave, C;
+    int64_t A, total_vec, vec_per_wave, C;
     int32_t K, B;
     float score_thr, pre_thr, min_box;
     uint64_t *cand;          // [B][C]  (inv_ordered(score) << 32) | (anchor*K + k)
@@ -143,15 +172,16 @@ __device__ __forceinline__ void scan_flush(ScanList &sl, const int fill, const S
 }
 
 // exact candidate test of one element (rare path)
-__device__ __forceinline__ bool scan_test(const ScanArgs &a, const float x, const int64_t e, uint64_t &key, int &img)
+__device__ __forceinline__ bool scan_test(const ScanArgs &a, const ScanLevel &lv, const float x, const int64_t e, uint64_t &key,
+                                          int &img)
 {
     const float s = 1.0f / (1.0f + expf(-x));                 // models.py:170
     if (!(s > a.score_thr)) return false;
-    const int64_t r = e / a.K;
+    const int64_t r = e / a.K;                                // row of this level's [B*A_l][K]
     const uint32_t k = (uint32_t)(e - r * a.K);
-    const int b = (int)((uint32_t)r / (uint32_t)a.A);
-    const uint32_t anchor = (uint32_t)(r - (int64_t)b * a.A);
-    const rn::f32x4 bx = a.boxes[r];
+    const int b = (int)((uint32_t)r / (uint32_t)lv.A_l);
+    const uint32_t anchor = (uint32_t)(lv.base + (r - (int64_t)b * lv.A_l));
+    const rn::f32x4 bx = a.boxes[(int64_t)b * a.A + anchor];
     if (!((bx.z - bx.x) >= a.min_box && (bx.w - bx.y) >= a.min_box)) return false;
     key = ((uint64_t)rn::inv_ordered(s) << 32) | (uint32_t)(anchor * (uint32_t)a.K + k);
     img = b;
@@ -168,10 +198,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void score_scan_kernel(const ScanArgs
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     ScanList &sl = s_list[wave];
     const int64_t gwave = (int64_t)blockIdx.x * SCAN_WAVES + wave;
-    const int64_t nvec = a.N / VEC;
-    const int64_t v_beg = gwave * a.vec_per_wave;
-    const int64_t v_end = min(v_beg + a.vec_per_wave, nvec);
-    const rn::u32x4 *src = (const rn::u32x4 *)a.cls;
+    const int64_t w_beg = gwave * a.vec_per_wave;
+    const int64_t w_end = min(w_beg + a.vec_per_wave, a.total_vec);
     int fill = 0;                                              // wave-uniform
 
     // append the candidates selected by `pred` (at most one per lane): ballot, maybe flush, write
@@ -186,61 +214,67 @@ __global__ __launch_bounds__(SCAN_THREADS) void score_scan_kernel(const ScanArgs
         }
         fill += n;
     };
-    auto do_vec = [&](const rn::u32x4 raw, const int64_t v) {
-        float x[VEC];
-        D::unpack(raw, x);
-        bool any_lane = false;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) any_lane |= (x[j] > a.pre_thr);
-        if (__any(any_lane)) {                                // rare: ~0.2 candidates per 512 elements
-#pragma unroll 1
-            for (int j = 0; j < VEC; ++j) {
-                uint64_t key = 0; int img = 0;
-                const bool c = (x[j] > a.pre_thr) && scan_test(a, x[j], v * VEC + j, key, img);
-                append(c, key, img);
-            }
-        }
-    };
 
-    if (v_beg < v_end) {
-        const int64_t last = v_end - 1;
-        const int64_t groups = (v_end - v_beg) / (SCAN_PF * RN_WAVE);
-        rn::u32x4 q[SCAN_PF];
+    for (int l = 0; l < a.L; ++l) {                            // wave-uniform: the levels this wave's range touches
+        const ScanLevel &lv = a.lv[l];
+        const int64_t v_beg = max(w_beg, lv.voff) - lv.voff, v_end = min(w_end, lv.voff + lv.nvec) - lv.voff;
+        const rn::u32x4 *src = (const rn::u32x4 *)lv.cls;
+        auto do_vec = [&](const rn::u32x4 raw, const int64_t v) {
+            float x[VEC];
+            D::unpack(raw, x);
+            bool any_lane = false;
 #pragma unroll
-        for (int u = 0; u < SCAN_PF; ++u) q[u] = __builtin_nontemporal_load(&src[min(v_beg + u * RN_WAVE + lane, last)]);
-        int64_t v0 = v_beg;
-        for (int64_t gi = 0; gi < groups; ++gi, v0 += SCAN_PF * RN_WAVE) {
-            rn::u32x4 qn[SCAN_PF];
-#pragma unroll
-            for (int u = 0; u < SCAN_PF; ++u) qn[u] = __builtin_nontemporal_load(&src[min(v0 + (SCAN_PF + u) * RN_WAVE + lane, last)]);
-#pragma unroll
-            for (int u = 0; u < SCAN_PF; ++u) do_vec(q[u], v0 + u * RN_WAVE + lane);
-#pragma unroll
-            for (int u = 0; u < SCAN_PF; ++u) q[u] = qn[u];
-        }
-        for (int64_t vb = v0; vb < v_end; vb += RN_WAVE) {           // leftover iterations (wave-uniform trip count)
-            const int64_t v = vb + lane;
-            const rn::u32x4 zero4 = {0u, 0u, 0u, 0u};
-            rn::u32x4 raw = (v < v_end) ? src[v] : zero4;
-            if (v >= v_end) {                                         // lanes past the end must not produce candidates
-                float lowv[VEC];
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) lowv[j] = -INFINITY;
-                raw = D::pack(lowv);
+            for (int j = 0; j < VEC; ++j) any_lane |= (x[j] > a.pre_thr);
+            if (__any(any_lane)) {                            // rare: ~0.2 candidates per 512 elements
+#pragma unroll 1
+                for (int j = 0; j < VEC; ++j) {
+                    uint64_t key = 0; int img = 0;
+                    const bool c = (x[j] > a.pre_thr) && scan_test(a, lv, x[j], v * VEC + j, key, img);
+                    append(c, key, img);
+                }
             }
-            do_vec(raw, min(v, last));
+        };
+        if (v_beg < v_end) {
+            const int64_t last = v_end - 1;
+            const int64_t groups = (v_end - v_beg) / (SCAN_PF * RN_WAVE);
+            rn::u32x4 q[SCAN_PF];
+#pragma unroll
+            for (int u = 0; u < SCAN_PF; ++u) q[u] = __builtin_nontemporal_load(&src[min(v_beg + u * RN_WAVE + lane, last)]);
+            int64_t v0 = v_beg;
+            for (int64_t gi = 0; gi < groups; ++gi, v0 += SCAN_PF * RN_WAVE) {
+                rn::u32x4 qn[SCAN_PF];
+#pragma unroll
+                for (int u = 0; u < SCAN_PF; ++u) qn[u] = __builtin_nontemporal_load(&src[min(v0 + (SCAN_PF + u) * RN_WAVE + lane, last)]);
+#pragma unroll
+                for (int u = 0; u < SCAN_PF; ++u) do_vec(q[u], v0 + u * RN_WAVE + lane);
+#pragma unroll
+                for (int u = 0; u < SCAN_PF; ++u) q[u] = qn[u];
+            }
+            for (int64_t vb = v0; vb < v_end; vb += RN_WAVE) {       // leftover iterations (wave-uniform trip count)
+                const int64_t v = vb + lane;
+                const rn::u32x4 zero4 = {0u, 0u, 0u, 0u};
+                rn::u32x4 raw = (v < v_end) ? src[v] : zero4;
+                if (v >= v_end) {                                     // lanes past the end must not produce candidates
+                    float lowv[VEC];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) lowv[j] = -INFINITY;
+                    raw = D::pack(lowv);
+                }
+                do_vec(raw, min(v, last));
+            }
         }
-    }
-    // ragged tail of the tensor (< VEC elements): the wave that ends at nvec (or wave 0 when there are no full vectors)
-    if ((v_beg < v_end && v_end == nvec) || (nvec == 0 && gwave == 0)) {
-        const int64_t e = nvec * VEC + lane;
-        uint64_t key = 0; int img = 0;
-        bool c = false;
-        if (lane < VEC && e < a.N) {
-            const float x = D::ld(a.cls, e);
-            c = (x > a.pre_thr) && scan_test(a, x, e, key, img);
+        // ragged tail of the level (< VEC elements): the wave whose range ends the level (wave 0 if it has no whole vector)
+        const bool owns_tail = lv.nvec ? (w_beg < lv.voff + lv.nvec && lv.voff + lv.nvec <= w_end) : (gwave == 0);
+        if (owns_tail && lv.nvec * VEC < lv.N) {
+            const int64_t e = lv.nvec * VEC + lane;
+            uint64_t key = 0; int img = 0;
+            bool c = false;
+            if (lane < VEC && e < lv.N) {
+                const float x = D::ld(lv.cls, e);
+                c = (x > a.pre_thr) && scan_test(a, lv, x, e, key, img);
+            }
+            append(c, key, img);
         }
-        append(c, key, img);
     }
     if (fill) scan_flush(sl, fill, a, lane);
 }
@@ -472,18 +506,7 @@ RN_API int rn_decode_clip(const void *deltas, int dtype, int B, int64_t A, const
         (anchor_bstride & 3))
         return RN_EALIGN;
     RegW rw = {{reg_w[0], reg_w[1], reg_w[2], reg_w[3]}};
-    int64_t blocks = (R + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    const dim3 g((unsigned)blocks), blk(256);
-    hipStream_t st = (hipStream_t)stream;
-    switch (dtype) {
-        case RN_F32: hipLaunchKernelGGL((decode_clip_kernel<RN_F32>), g, blk, 0, st, deltas, A, R, (const rn::f32x4 *)anchors, anchor_bstride / 4, image_hw, rw, (rn::f32x4 *)out); break;
-        case RN_BF16: hipLaunchKernelGGL((decode_clip_kernel<RN_BF16>), g, blk, 0, st, deltas, A, R, (const rn::f32x4 *)anchors, anchor_bstride / 4, image_hw, rw, (rn::f32x4 *)out); break;
-        case RN_F16: hipLaunchKernelGGL((decode_clip_kernel<RN_F16>), g, blk, 0, st, deltas, A, R, (const rn::f32x4 *)anchors, anchor_bstride / 4, image_hw, rw, (rn::f32x4 *)out); break;
-        default: return RN_EINVAL;
-    }
-    RN_LAUNCH_CHECK();
-    return RN_OK;
+    return launch_decode(deltas, dtype, B, A, 0, A, anchors, anchor_bstride, image_hw, rw, out, (hipStream_t)stream);
 }
 
 RN_API size_t rn_detect_workspace_bytes(int B, int64_t A, int K, int64_t max_candidates)
@@ -492,31 +515,55 @@ RN_API size_t rn_detect_workspace_bytes(int B, int64_t A, int K, int64_t max_can
     return carve(nullptr, B, A, K, max_candidates).total;
 }
 
-RN_API int rn_detect(const void *cls, const void *deltas, int dtype, int B, int64_t A, int K, const float *anchors,
-                     int64_t anchor_bstride, const int32_t *image_hw, const rn_detect_params *params,
-                     int64_t max_candidates, float *out_boxes, float *out_scores, int64_t *out_labels,
-                     int32_t *out_count, int32_t *out_status, void *workspace, size_t workspace_bytes, void *stream)
+RN_API int rn_detect_levels(const void *const *cls_levels, const void *const *box_levels, const int64_t *level_anchors, int L,
+                            int dtype, int B, int K, const float *anchors, int64_t anchor_bstride, const int32_t *image_hw,
+                            const rn_detect_params *params, int64_t max_candidates, float *out_boxes, float *out_scores,
+                            int64_t *out_labels, int32_t *out_count, int32_t *out_status, void *workspace,
+                            size_t workspace_bytes, void *stream)
 {
-    if (!cls || !deltas || !anchors || !params || !out_boxes || !out_scores || !out_labels || !out_count || !out_status ||
-        !workspace)
+    if (!cls_levels || !box_levels || !level_anchors || !anchors || !params || !out_boxes || !out_scores || !out_labels ||
+        !out_count || !out_status || !workspace)
         return RN_EINVAL;
-    if (B <= 0 || A <= 0 || K <= 0 || max_candidates <= 0 || params->max_det <= 0) return RN_EINVAL;
+    if (L <= 0 || L > RN_MAX_LEVELS || B <= 0 || K <= 0 || max_candidates <= 0 || params->max_det <= 0) return RN_EINVAL;
+    if (dtype != RN_F32 && dtype != RN_BF16 && dtype != RN_F16) return RN_EINVAL;
+    int64_t A = 0;
+    for (int l = 0; l < L; ++l) {
+        if (!cls_levels[l] || !box_levels[l] || level_anchors[l] <= 0) return RN_EINVAL;
+        A += level_anchors[l];
+    }
     const int64_t R = (int64_t)B * A, C = max_candidates;
-    // payloads are 32-bit: anchor*K + k and class*A + anchor; scan tags images with 16 bits per block
+    // payloads are 32-bit: anchor*K + k and class*A + anchor
     if (R >= ((int64_t)1 << 31) || A * (int64_t)K >= ((int64_t)1 << 32) || K > 4096 || params->max_det > TOPK_THREADS ||
         (int64_t)B * C >= ((int64_t)1 << 40) || (int64_t)B * K >= ((int64_t)1 << 31))
         return RN_EUNSUPPORTED;
     if (workspace_bytes < rn_detect_workspace_bytes(B, A, K, C)) return RN_EWORKSPACE;
-    if (!rn::aligned(cls, 16) || !rn::aligned(workspace, 256) || !rn::aligned(out_boxes, 16)) return RN_EALIGN;
+    if (!rn::aligned(workspace, 256) || !rn::aligned(out_boxes, 16) || !rn::aligned(anchors, 16) || (anchor_bstride & 3))
+        return RN_EALIGN;
+    for (int l = 0; l < L; ++l)
+        if (!rn::aligned(cls_levels[l], 16) || !rn::aligned(box_levels[l], dtype == RN_F32 ? 16 : 8)) return RN_EALIGN;
     hipStream_t st = (hipStream_t)stream;
     DetectWs w = carve(workspace, B, A, K, C);
-
-    int rc = rn_decode_clip(deltas, dtype, B, A, anchors, anchor_bstride, image_hw, params->reg_w, (float *)w.boxes, stream);
-    if (rc != RN_OK) return rc;
-    RN_HIP(hipMemsetAsync(w.cand_count, 0, w.zero_bytes, st));
+    const RegW rw = {{params->reg_w[0], params->reg_w[1], params->reg_w[2], params->reg_w[3]}};
 
     ScanArgs sa;
-    sa.cls = cls; sa.boxes = w.boxes; sa.A = A; sa.N = R * K; sa.C = C; sa.K = K; sa.B = B;
+    const int vec = (dtype == RN_F32) ? 4 : 8;
+    sa.L = L;
+    int64_t base = 0, voff = 0;
+    int rc = RN_OK;
+    for (int l = 0; l < L; ++l) {
+        rc = launch_decode(box_levels[l], dtype, B, level_anchors[l], base, A, anchors, anchor_bstride, image_hw, rw,
+                           (float *)w.boxes, st);
+        if (rc != RN_OK) return rc;
+        ScanLevel &lv = sa.lv[l];
+        lv.cls = cls_levels[l]; lv.A_l = level_anchors[l]; lv.base = base;
+        lv.N = (int64_t)B * level_anchors[l] * K; lv.nvec = lv.N / vec; lv.voff = voff;
+        base += level_anchors[l];
+        voff += lv.nvec;
+    }
+    sa.total_vec = voff;
+    RN_HIP(hipMemsetAsync(w.cand_count, 0, w.zero_bytes, st));
+
+    sa.boxes = w.boxes; sa.A = A; sa.C = C; sa.K = K; sa.B = B;
     sa.score_thr = params->score_thr;
     sa.min_box = params->min_box;
     {   // logit-space pre-filter with a safety margin; the exact test is still sigmoid(x) > thr
@@ -529,8 +576,7 @@ RN_API int rn_detect(const void *cls, const void *deltas, int dtype, int B, int6
     int dev = 0, cus = 0, per_cu = 0;
     RN_HIP(hipGetDevice(&dev));
     RN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const int vec = (dtype == RN_F32) ? 4 : 8;
-    const int64_t nvec = sa.N / vec;
+    const int64_t nvec = sa.total_vec;
     unsigned blocks = 1;
     auto size_grid = [&](auto kernel) -> int {
         RN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, SCAN_THREADS, 0));
@@ -540,7 +586,7 @@ RN_API int rn_detect(const void *cls, const void *deltas, int dtype, int B, int6
         if (vpw < RN_WAVE) vpw = RN_WAVE;
         sa.vec_per_wave = vpw;
         int64_t need = ((nvec + vpw - 1) / vpw + SCAN_WAVES - 1) / SCAN_WAVES;
-        blocks = (unsigned)(need < 1 ? 1 : need);
+        blocks = (unsigned)(need < 1 ? 1 : need);             // >= 1: wave 0 also owns the tails of vector-less levels
         return RN_OK;
     };
     switch (dtype) {
@@ -574,4 +620,16 @@ RN_API int rn_detect(const void *cls, const void *deltas, int dtype, int B, int6
                        K, A, params->max_det, (rn::f32x4 *)out_boxes, out_scores, out_labels, out_count);
     RN_LAUNCH_CHECK();
     return RN_OK;
+}
+
+RN_API int rn_detect(const void *cls, const void *deltas, int dtype, int B, int64_t A, int K, const float *anchors,
+                     int64_t anchor_bstride, const int32_t *image_hw, const rn_detect_params *params,
+                     int64_t max_candidates, float *out_boxes, float *out_scores, int64_t *out_labels,
+                     int32_t *out_count, int32_t *out_status, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!cls || !deltas || A <= 0) return RN_EINVAL;
+    const void *c1[1] = {cls}, *d1[1] = {deltas};
+    const int64_t a1[1] = {A};
+    return rn_detect_levels(c1, d1, a1, 1, dtype, B, K, anchors, anchor_bstride, image_hw, params, max_candidates, out_boxes,
+                            out_scores, out_labels, out_count, out_status, workspace, workspace_bytes, stream);
 }

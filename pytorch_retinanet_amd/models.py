@@ -137,6 +137,13 @@ class Retinanet(nn.Module):
         return ops.detect(class_logits, bboxes, anchors, im_szs, self.score_thres, MIN_BOX_SIZE, self.nms_thres,
                           self.detections_per_img)
 
+    def process_detections_levels(self, outputs: Dict[str, List[Tensor]], anchors: List[Tensor],
+                                  im_szs: List[Tuple[int, int]]) -> List[Dict[str, Tensor]]:
+        """``process_detections`` on the per-level head outputs of ``retinanet_head.forward_levels``: the scan
+        and decode kernels read the five conv outputs in place (no ``torch.cat``, layers.py:195, :259)."""
+        return ops.detect_levels(outputs["cls_levels"], outputs["bbox_levels"], anchors, im_szs, self.score_thres,
+                                 MIN_BOX_SIZE, self.nms_thres, self.detections_per_img, reg_w=BBOX_REG_WEIGHTS)
+
     def predict(self, images: List[Tensor]) -> List[Dict[str, Tensor]]:
         """Detections in original image coordinates (models.py:245-272).  Like the
         reference this only flips the TOP module's ``training`` flag (Q17): call
@@ -151,7 +158,11 @@ class Retinanet(nn.Module):
             original_image_sizes.append((int(val[0]), int(val[1])))
         with torch.no_grad():
             images, _ = self.transform(images, None)
-            feature_maps, outputs = self._features(images.tensors)
+            batch = images.tensors
+            if self.backbone.backbone.conv1.weight.is_contiguous(memory_format=torch.channels_last):
+                batch = batch.contiguous(memory_format=torch.channels_last)
+            feature_maps = self.fpn(self.backbone(batch))
             anchors = self.anchor_generator(images, feature_maps)
-            detections = self.process_detections(outputs, anchors, images.image_sizes)
+            detections = self.process_detections_levels(self.retinanet_head.forward_levels(feature_maps), anchors,
+                                                        images.image_sizes)
             return self.transform.postprocess(detections, images.image_sizes, original_image_sizes)

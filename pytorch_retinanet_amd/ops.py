@@ -287,13 +287,28 @@ def detect(cls: Tensor, deltas: Tensor, anchors, image_sizes: Sequence[Tuple[int
     One host sync at the end (the ragged result sizes have to reach Python, as in the
     reference's list-of-dicts contract).  If an image has more candidates than the workspace
     was sized for, the call is repeated once with the exact worst case (A*K)."""
-    dev = _need_dev(cls, deltas)
-    if cls.dim() != 3 or deltas.dim() != 3 or cls.shape[:2] != deltas.shape[:2] or deltas.shape[-1] != 4:
-        raise ValueError(f"bad head output shapes {tuple(cls.shape)} / {tuple(deltas.shape)}")
-    if deltas.dtype != cls.dtype:
-        deltas = deltas.to(cls.dtype)
-    B, A, K = cls.shape
-    cls, deltas = _c(cls), _c(deltas)
+    return detect_levels([cls], [deltas], anchors, image_sizes, score_thr, min_box, nms_thr, max_det, reg_w, max_candidates)
+
+
+def detect_levels(cls_levels: Sequence[Tensor], box_levels: Sequence[Tensor], anchors, image_sizes: Sequence[Tuple[int, int]],
+                  score_thr: float, min_box: float, nms_thr: float, max_det: int,
+                  reg_w: Sequence[float] = (1.0, 1.0, 1.0, 1.0), max_candidates: Optional[int] = None) -> List[dict]:
+    """``detect`` on per-level head outputs (cls_levels[l] [B,A_l,K], box_levels[l] [B,A_l,4]) without
+    concatenating them; identical results to ``detect(torch.cat(cls_levels, 1), torch.cat(box_levels, 1), ...)``."""
+    L = len(cls_levels)
+    if L == 0 or L > _lib.RN_MAX_LEVELS or len(box_levels) != L:
+        raise ValueError("need 1..8 levels of (cls, box) outputs")
+    dev = _need_dev(*cls_levels, *box_levels)
+    dt = cls_levels[0].dtype
+    for c, d in zip(cls_levels, box_levels):
+        if c.dim() != 3 or d.dim() != 3 or c.shape[:2] != d.shape[:2] or d.shape[-1] != 4 or c.dtype != dt \
+                or c.shape[0] != cls_levels[0].shape[0] or c.shape[2] != cls_levels[0].shape[2]:
+            raise ValueError(f"bad head output shapes {tuple(c.shape)} / {tuple(d.shape)}")
+    cls_levels = [_c(c) for c in cls_levels]
+    box_levels = [_c(d if d.dtype == dt else d.to(dt)) for d in box_levels]
+    B, _, K = cls_levels[0].shape
+    counts = [int(c.shape[1]) for c in cls_levels]
+    A = sum(counts)
     if not isinstance(anchors, Tensor):
         first = anchors[0]
         anchors = first if all(a is first or a.data_ptr() == first.data_ptr() for a in anchors) else torch.stack(list(anchors))
@@ -305,13 +320,15 @@ def detect(cls: Tensor, deltas: Tensor, anchors, image_sizes: Sequence[Tuple[int
     out_scores = torch.empty((B, max_det), dtype=torch.float32, device=dev)
     out_labels = torch.empty((B, max_det), dtype=torch.int64, device=dev)
     meta = torch.empty((2, B), dtype=torch.int32, device=dev)          # [0] = count, [1] = status
+    arr = lambda ts: (C.c_void_p * L)(*[t.data_ptr() for t in ts])
     while True:
         ws_bytes = lib.rn_detect_workspace_bytes(B, A, K, cap)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev), _timed("detect", dev):
-            check(lib.rn_detect(_ptr(cls), _ptr(deltas), _dtype_code(cls), B, A, K, _ptr(anchors), bstride, _ptr(hw),
-                                C.byref(params), cap, _ptr(out_boxes), _ptr(out_scores), _ptr(out_labels),
-                                _ptr(meta[0]), _ptr(meta[1]), _ptr(ws), ws_bytes, _stream(dev)), "rn_detect")
+            check(lib.rn_detect_levels(arr(cls_levels), arr(box_levels), (C.c_int64 * L)(*counts), L, _dtype_code(cls_levels[0]),
+                                       B, K, _ptr(anchors), bstride, _ptr(hw), C.byref(params), cap, _ptr(out_boxes),
+                                       _ptr(out_scores), _ptr(out_labels), _ptr(meta[0]), _ptr(meta[1]), _ptr(ws), ws_bytes,
+                                       _stream(dev)), "rn_detect_levels")
         meta_h = meta.cpu()                                              # the one sync
         if not bool(meta_h[1].any()) or cap >= A * K:
             break

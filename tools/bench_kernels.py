@@ -110,6 +110,21 @@ def bench_detect(reps, mean, std, tag, B=16):
     nbytes = B * (A * K * 2 + A * 4 * 2 + A * 16)
     report(f"K4-K7 rn_detect {tag} fp16 B={B} A={A} K={K}", (float(np.median(ts)), float(ts.min()), float(ts.mean())), nbytes,
            {"candidates_per_image": ncand // B, "wall_ms_per_call_incl_sync": round((time.perf_counter() - t0) / reps * 1e3, 3)})
+    # the same data as five per-level tensors (what the conv stack produces) -> rn_detect_levels, and the cat it avoids
+    counts = [254016, 63504, 15876, 3969, 1089]
+    cl, bl, o = [], [], 0
+    for n in counts:
+        cl.append(cls[:, o:o + n].contiguous()); bl.append(box[:, o:o + n].contiguous()); o += n
+    ops.enable_timing(True)
+    for _ in range(reps):
+        ops.detect_levels(cl, bl, anc, hw, 0.05, 1e-2, 0.5, 100, max_candidates=max(1 << 18, 2 * ncand // B))
+    torch.cuda.synchronize()
+    ev = ops.timing_events()["detect"]
+    ops.enable_timing(False)
+    ts = np.array([a.elapsed_time(b) for a, b in ev])[1:]
+    report(f"K4-K7 rn_detect_levels {tag} fp16 B={B} A={A} K={K} L=5", (float(np.median(ts)), float(ts.min()), float(ts.mean())), nbytes)
+    cat_ms = timeit(lambda: (torch.cat(cl, dim=1), torch.cat(bl, dim=1)), reps)
+    report(f"torch.cat of the 5 levels (avoided) B={B}", cat_ms, 2 * B * (A * K * 2 + A * 4 * 2))
 
 
 def main():

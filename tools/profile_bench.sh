@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_kernel_trace.log 2>&1
 cp /tmp/pb/*/*kernel_stats.csv $out/bench_kernel_stats.csv
 python tools/steady_stats.py /tmp/pb/*/*kernel_trace.csv $out/bench_kernel_stats_steady.csv 3 | tee $out/steady_summary.txt
-tail -1 $out/bench_kernel_trace.log | cut -c1-2000 > $out/bench_line_under_rocprof.json
+grep "^{\"metric" $out/bench_kernel_trace.log | tail -1 > $out/bench_line_under_rocprof.json
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pc; rocprofv3 --pmc $ctr --output-format csv -d /tmp/pc -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline > /tmp/pc.log 2>&1
   python - $ctr >> $out/k3_pmc.txt <<PY
