@@ -96,11 +96,11 @@ int launch_decode(const void *deltas, const int dtype, const int B, const int64_
 // ---- K5 score scan + candidate compaction ---------------------------------------
 // Streams the class logits once (A*K*s bytes per image, 16-byte non-temporal loads, two groups in
 // flight per wave; each wave owns one contiguous range of the flattened tensor).  An element is a
-// candidate when sigmoid(x) > score_thr (models.py:196) and its decoded box passes
-// remove_small_boxes (models.py:203; boxes are per anchor, so the size test commutes with the
-// per-class loop).  Candidates (~4e-4 of the elements at the reference's prior) are staged in a
-// wave-private LDS list and flushed with ONE global atomic per (wave, image): no block barrier
-// anywhere in the stream.
+// candidate when sigmoid(x) > score_thr (models.py:196).  Candidates (~4e-4 of the elements at the
+// reference's prior) are staged in a wave-private LDS list and flushed with ONE global atomic per
+// (wave, image): no block barrier and no dependent global load anywhere in the stream.  The box
+// side of the filter (remove_small_boxes, models.py:203) runs afterwards on the candidates only
+// (cand_filter_kernel), which is also where their boxes are decoded.
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_WAVES = SCAN_THREADS / RN_WAVE;
 constexpr int SCAN_CAP = 128;            // wave-private list entries (>= 64: one ballot's worth always fits after a flush)
@@ -117,13 +117,11 @@ struct ScanLevel {
 struct ScanArgs {
     int L;
     ScanLevel lv[RN_MAX_LEVELS];
-    const rn::f32x4 *boxes;
     int64_t A, total_vec, vec_per_wave, C;
     int32_t K, B;
-    float score_thr, pre_thr, min_box;
+    float score_thr, pre_thr;
     uint64_t *cand;          // [B][C]  (inv_ordered(score) << 32) | (anchor*K + k)
     int32_t *cand_count;     // [B]
-    int32_t *seg_count;      // [B][K]
 };
 
 struct ScanList { uint64_t key[SCAN_CAP]; int img[SCAN_CAP]; };
@@ -152,18 +150,12 @@ __device__ __forceinline__ void scan_flush(ScanList &sl, const int fill, const S
         const unsigned long long lt = (1ull << lane) - 1ull;
         if (m0) {
             const int64_t pos = (int64_t)base + __popcll(mk0 & lt);
-            if (pos < a.C) {
-                a.cand[(int64_t)b * a.C + pos] = k0;
-                atomicAdd(&a.seg_count[(int64_t)b * a.K + (int)((uint32_t)k0 % (uint32_t)a.K)], 1);
-            }
+            if (pos < a.C) a.cand[(int64_t)b * a.C + pos] = k0;
             done0 = true;
         }
         if (m1) {
             const int64_t pos = (int64_t)base + n0 + __popcll(mk1 & lt);
-            if (pos < a.C) {
-                a.cand[(int64_t)b * a.C + pos] = k1;
-                atomicAdd(&a.seg_count[(int64_t)b * a.K + (int)((uint32_t)k1 % (uint32_t)a.K)], 1);
-            }
+            if (pos < a.C) a.cand[(int64_t)b * a.C + pos] = k1;
             done1 = true;
         }
     }
@@ -171,21 +163,19 @@ __device__ __forceinline__ void scan_flush(ScanList &sl, const int fill, const S
     __builtin_amdgcn_wave_barrier();
 }
 
-// exact candidate test of one element (rare path)
-__device__ __forceinline__ bool scan_test(const ScanArgs &a, const ScanLevel &lv, const float x, const int64_t e, uint64_t &key,
-                                          int &img)
+// exact score of one element (rare path), models.py:170
+__device__ __forceinline__ float scan_score(const float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// key and image of element e of level lv, whose score s passed
+__device__ __forceinline__ void scan_key(const ScanArgs &a, const ScanLevel &lv, const float s, const int64_t e, uint64_t &key,
+                                         int &img)
 {
-    const float s = 1.0f / (1.0f + expf(-x));                 // models.py:170
-    if (!(s > a.score_thr)) return false;
     const int64_t r = e / a.K;                                // row of this level's [B*A_l][K]
     const uint32_t k = (uint32_t)(e - r * a.K);
     const int b = (int)((uint32_t)r / (uint32_t)lv.A_l);
     const uint32_t anchor = (uint32_t)(lv.base + (r - (int64_t)b * lv.A_l));
-    const rn::f32x4 bx = a.boxes[(int64_t)b * a.A + anchor];
-    if (!((bx.z - bx.x) >= a.min_box && (bx.w - bx.y) >= a.min_box)) return false;
     key = ((uint64_t)rn::inv_ordered(s) << 32) | (uint32_t)(anchor * (uint32_t)a.K + k);
     img = b;
-    return true;
 }
 
 template <int DT>
@@ -222,14 +212,37 @@ __global__ __launch_bounds__(SCAN_THREADS) void score_scan_kernel(const ScanArgs
         auto do_vec = [&](const rn::u32x4 raw, const int64_t v) {
             float x[VEC];
             D::unpack(raw, x);
-            bool any_lane = false;
+            uint32_t m = 0;                                   // bit j: element j of this lane's vector may be a candidate
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) any_lane |= (x[j] > a.pre_thr);
-            if (__any(any_lane)) {                            // rare: ~0.2 candidates per 512 elements
-#pragma unroll 1
+            for (int j = 0; j < VEC; ++j) m |= (x[j] > a.pre_thr) ? (1u << j) : 0u;
+            if (!__any(m != 0)) return;                       // common case: ~0.2 candidates per 512 elements
+#pragma unroll
+            for (int j = 0; j < VEC; ++j)                     // exact test, only where the pre-filter fired
+                if ((m >> j) & 1u) { if (!(scan_score(x[j]) > a.score_thr)) m &= ~(1u << j); }
+            const int cnt = __popc(m);
+            int incl = cnt;                                   // inclusive prefix over the lanes
+#pragma unroll
+            for (int d = 1; d < RN_WAVE; d <<= 1) { const int up = __shfl_up(incl, d, RN_WAVE); if (lane >= d) incl += up; }
+            const int total = __shfl(incl, RN_WAVE - 1, RN_WAVE);
+            if (total == 0) return;
+            if (total <= RN_WAVE) {                           // one reservation for the whole vector group
+                if (fill + total > SCAN_CAP) { scan_flush(sl, fill, a, lane); fill = 0; }
+                int pos = fill + incl - cnt;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    if ((m >> j) & 1u) {
+                        uint64_t key; int img;
+                        scan_key(a, lv, scan_score(x[j]), v * VEC + j, key, img);
+                        sl.key[pos] = key; sl.img[pos] = img;
+                        ++pos;
+                    }
+                fill += total;
+            } else {                                          // dense group: one ballot per element slot
+#pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     uint64_t key = 0; int img = 0;
-                    const bool c = (x[j] > a.pre_thr) && scan_test(a, lv, x[j], v * VEC + j, key, img);
+                    const bool c = (m >> j) & 1u;
+                    if (c) scan_key(a, lv, scan_score(x[j]), v * VEC + j, key, img);
                     append(c, key, img);
                 }
             }
@@ -271,7 +284,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void score_scan_kernel(const ScanArgs
             bool c = false;
             if (lane < VEC && e < lv.N) {
                 const float x = D::ld(lv.cls, e);
-                c = (x > a.pre_thr) && scan_test(a, lv, x, e, key, img);
+                c = (x > a.pre_thr) && (scan_score(x) > a.score_thr);
+                if (c) scan_key(a, lv, scan_score(x), e, key, img);
             }
             append(c, key, img);
         }
@@ -279,36 +293,120 @@ __global__ __launch_bounds__(SCAN_THREADS) void score_scan_kernel(const ScanArgs
     if (fill) scan_flush(sl, fill, a, lane);
 }
 
-// ---- per-image segment offsets -----------------------------------------------------
-__global__ __launch_bounds__(64) void seg_offsets_kernel(const int32_t *__restrict__ cand_count, const int32_t *__restrict__ seg_count,
-                                                         const int K, const int64_t C, int64_t *__restrict__ seg_start,
-                                                         int32_t *__restrict__ seg_len, int32_t *__restrict__ out_status)
-{
-    const int b = blockIdx.x;
-    if (threadIdx.x != 0) return;
-    int64_t run = (int64_t)b * C;
-    for (int k = 0; k < K; ++k) {
-        const int c = seg_count[(int64_t)b * K + k];
-        seg_start[(int64_t)b * K + k] = run;
-        seg_len[(int64_t)b * K + k] = c;
-        run += c;
-    }
-    out_status[b] = cand_count[b] > C ? 1 : 0;
-}
+// ---- candidates -> per-(image, class) segments ----------------------------------------------
+// One workgroup per image, everything between the score scan and NMS in one launch:
+//  pass 1  decode + clip the box of every candidate's anchor (K4's arithmetic, decode_one), apply
+//          remove_small_boxes (models.py:203; boxes are per anchor, so the size test commutes with
+//          the per-class loop), count survivors per class in LDS, mark the rest dead;
+//  scan    class counts -> segment offsets (seg_start / seg_len, what NMS consumes);
+//  pass 2  scatter the survivors into their class segment (LDS counters hand out the slots).
+// Only ~1e-3 of the anchors are ever decoded; candidates of one anchor in several classes write the
+// same box.  No global atomics: the per-class counters of an image live in 3 cache lines, and
+// ~1e4 global atomics on them serialise in L2 (measured 25 us per pass).
+struct FilterLevel { const void *box; int64_t A_l, base; };
+struct SegArgs {
+    int L;
+    FilterLevel lv[RN_MAX_LEVELS];
+    const rn::f32x4 *anchors;
+    int64_t anchor_bstride4;
+    const int32_t *image_hw;
+    RegW rw;
+    int64_t A, C;
+    int32_t K;
+    float min_box;
+    uint64_t *cand;              // [B][C] candidates (dead ones are overwritten with DEAD_KEY)
+    const int32_t *cand_count;   // [B]
+    rn::f32x4 *boxes;            // [B][A] decoded boxes, written only at candidate anchors
+    uint64_t *seg;               // [B][C] (inv score << 32 | anchor), grouped by class
+    int64_t *seg_start;          // [B][K]
+    int32_t *seg_len;            // [B][K]
+    int32_t *out_status;         // [B] 1 = more candidates than C
+};
+constexpr uint64_t DEAD_KEY = ~0ull;      // not a valid key: its score field would be the smallest float
+constexpr int SEG_THREADS = 1024;
+constexpr int SEG_UNROLL = 4;             // candidates per thread in flight (independent load chains)
+constexpr int SEG_MAXK = 4096;
 
-// ---- scatter candidates into their (image, class) segments ---------------------------
-__global__ __launch_bounds__(256) void seg_scatter_kernel(const uint64_t *__restrict__ cand, const int32_t *__restrict__ cand_count,
-                                                          const int K, const int64_t C, const int64_t *__restrict__ seg_start,
-                                                          int32_t *__restrict__ seg_fill, uint64_t *__restrict__ seg)
+template <int DT>
+__global__ __launch_bounds__(SEG_THREADS) void seg_build_kernel(const SegArgs a)
 {
-    const int b = blockIdx.y;
-    const int64_t n = min((int64_t)cand_count[b], C);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t key = cand[(int64_t)b * C + i];
-        const uint32_t ak = (uint32_t)key;
-        const uint32_t anchor = ak / (uint32_t)K, k = ak - anchor * (uint32_t)K;
-        const int pos = atomicAdd(&seg_fill[(int64_t)b * K + k], 1);
-        seg[seg_start[(int64_t)b * K + k] + pos] = (key & 0xffffffff00000000ull) | anchor;
+    __shared__ int s_cnt[SEG_MAXK];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int64_t n = min((int64_t)a.cand_count[b], a.C);
+    for (int k = t; k < a.K; k += SEG_THREADS) s_cnt[k] = 0;
+    __syncthreads();
+    float hh = 0.0f, ww = 0.0f;
+    if (a.image_hw) { hh = (float)a.image_hw[2 * b]; ww = (float)a.image_hw[2 * b + 1]; }
+    uint64_t *cand = a.cand + (int64_t)b * a.C;
+
+    for (int64_t i0 = 0; i0 < n; i0 += SEG_UNROLL * SEG_THREADS) {
+        uint64_t key[SEG_UNROLL];
+        uint32_t anchor[SEG_UNROLL], k[SEG_UNROLL];
+        float d[SEG_UNROLL][4];
+        rn::f32x4 an[SEG_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SEG_UNROLL; ++u) key[u] = cand[min(i0 + u * SEG_THREADS + t, n - 1)];
+#pragma unroll
+        for (int u = 0; u < SEG_UNROLL; ++u) {
+            const uint32_t ak = (uint32_t)key[u];
+            anchor[u] = ak / (uint32_t)a.K; k[u] = ak - anchor[u] * (uint32_t)a.K;
+            const void *bp = a.lv[0].box;
+            int64_t A_l = a.lv[0].A_l, base = 0;
+#pragma unroll
+            for (int l = 1; l < RN_MAX_LEVELS; ++l)
+                if (l < a.L && (int64_t)anchor[u] >= a.lv[l].base) { bp = a.lv[l].box; A_l = a.lv[l].A_l; base = a.lv[l].base; }
+            delta4<DT>::ld(bp, (int64_t)b * A_l + ((int64_t)anchor[u] - base), d[u]);
+            an[u] = a.anchors[(int64_t)b * a.anchor_bstride4 + anchor[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < SEG_UNROLL; ++u) {
+            const int64_t i = i0 + u * SEG_THREADS + t;
+            if (i >= n) continue;
+            rn::f32x4 o = decode_one(d[u], an[u], a.rw);
+            if (a.image_hw) {
+                o.x = clampf(o.x, 0.0f, ww); o.z = clampf(o.z, 0.0f, ww);
+                o.y = clampf(o.y, 0.0f, hh); o.w = clampf(o.w, 0.0f, hh);
+            }
+            if ((o.z - o.x) >= a.min_box && (o.w - o.y) >= a.min_box) {
+                a.boxes[(int64_t)b * a.A + anchor[u]] = o;
+                atomicAdd(&s_cnt[k[u]], 1);
+            } else {
+                cand[i] = DEAD_KEY;
+            }
+        }
+    }
+    __syncthreads();
+    if (t < RN_WAVE) {                                        // wave 0: exclusive scan of the class counts
+        int run = 0;
+        for (int k0 = 0; k0 < a.K; k0 += RN_WAVE) {
+            const int kk = k0 + t;
+            const int c = kk < a.K ? s_cnt[kk] : 0;
+            int incl = c;
+#pragma unroll
+            for (int dd = 1; dd < RN_WAVE; dd <<= 1) { const int up = __shfl_up(incl, dd, RN_WAVE); if (t >= dd) incl += up; }
+            if (kk < a.K) {
+                a.seg_start[(int64_t)b * a.K + kk] = (int64_t)b * a.C + run + (incl - c);
+                a.seg_len[(int64_t)b * a.K + kk] = c;
+                s_cnt[kk] = run + (incl - c);                 // becomes the fill pointer of pass 2
+            }
+            run += __shfl(incl, RN_WAVE - 1, RN_WAVE);
+        }
+        if (t == 0) a.out_status[b] = a.cand_count[b] > a.C ? 1 : 0;
+    }
+    __syncthreads();
+    uint64_t *seg = a.seg + (int64_t)b * a.C;
+    for (int64_t i0 = 0; i0 < n; i0 += SEG_UNROLL * SEG_THREADS) {
+        uint64_t key[SEG_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SEG_UNROLL; ++u) key[u] = cand[min(i0 + u * SEG_THREADS + t, n - 1)];   // this thread's own writes
+#pragma unroll
+        for (int u = 0; u < SEG_UNROLL; ++u) {
+            if (i0 + u * SEG_THREADS + t >= n || key[u] == DEAD_KEY) continue;
+            const uint32_t ak = (uint32_t)key[u];
+            const uint32_t anchor = ak / (uint32_t)a.K, k = ak - anchor * (uint32_t)a.K;
+            const int pos = atomicAdd(&s_cnt[k], 1);
+            seg[pos] = (key[u] & 0xffffffff00000000ull) | anchor;
+        }
     }
 }
 
@@ -375,10 +473,37 @@ __device__ __forceinline__ void bitonic_regs(uint64_t (&k)[NPT], uint64_t *lds)
     }
 }
 
+// Ascending bitonic sort of the first n (power of two, <= 1024) of one key per thread; all threads call.
+__device__ __forceinline__ void bitonic_one(uint64_t &k, uint64_t *lds, const int n)
+{
+    const int t = threadIdx.x;
+    for (int kk = 2; kk <= n; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            uint64_t y;
+            if (j >= RN_WAVE) {
+                lds[t] = k;
+                __syncthreads();
+                y = lds[t ^ j];
+                __syncthreads();
+            } else {
+                y = shfl_xor_u64(k, j);
+            }
+            const bool keep_min = (((t & j) == 0) == ((t & kk) == 0));
+            k = keep_min ? (k < y ? k : y) : (k > y ? k : y);
+        }
+    }
+}
+
+constexpr int TOPK_FAST_PT = 12;          // keys per thread the histogram path keeps in registers
+constexpr int TOPK_BINS = 2048;
+
 // One workgroup per image.  Counts / offsets of all classes are fetched in parallel (one latency),
 // the first max_det survivors of every class are gathered by flat index, sorted 1024 at a time, and
 // only the best max_det of every chunk survive to the final sort: O(M log^2 1024) instead of
 // O(M log^2 M), for any number of candidates M.
+// Usual case (M <= 12288, e.g. 90 classes x 100): no sort of the M keys at all -- a 2048-bin
+// histogram of the score field finds the bin holding the max_det-th best key, the keys up to that bin
+// (about max_det of them) are compacted and only those are sorted.
 __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const uint64_t *__restrict__ kept, const int64_t *__restrict__ seg_start,
                                                             const int32_t *__restrict__ kept_count, const rn::f32x4 *__restrict__ boxes,
                                                             const int K, const int64_t A, const int max_det,
@@ -402,6 +527,81 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const uint64_t *__re
     __syncthreads();
     const int M = s_pre[K];
     int n_surv = 0;
+    uint64_t win = ~0ull;                  // final key of output row t
+    bool done = false;                     // block-uniform
+
+    if (M <= TOPK_FAST_PT * TOPK_THREADS) {
+        int *s_hist = (int *)s_key;                            // [TOPK_BINS]
+        int *s_wave = s_hist + TOPK_BINS;                      // [16] wave totals | [32..] min, max, bin, nsel, fill
+        uint64_t kr[TOPK_FAST_PT];
+        uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+        for (int r = 0; r < TOPK_FAST_PT; ++r) {
+            kr[r] = ~0ull;
+            const int f = r * TOPK_THREADS + t;
+            if (f < M) {
+                int a_ = 0, b_ = K;                                 // class k with s_pre[k] <= f < s_pre[k+1]
+                while (b_ - a_ > 1) { const int md = (a_ + b_) >> 1; if (s_pre[md] <= f) a_ = md; else b_ = md; }
+                const uint64_t key = kept[seg_start[(int64_t)b * K + a_] + (f - s_pre[a_])];
+                kr[r] = (key & 0xffffffff00000000ull) | (uint32_t)((uint32_t)a_ * (uint32_t)A + (uint32_t)key);
+                const uint32_t h = (uint32_t)(key >> 32);
+                lo = min(lo, h); hi = max(hi, h);
+            }
+        }
+        for (int i = t; i < TOPK_BINS + 64; i += TOPK_THREADS) s_hist[i] = (i == TOPK_BINS + 32) ? (int)0x7fffffff : 0;
+        __syncthreads();
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, RN_WAVE)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, RN_WAVE)); }
+        if ((t & (RN_WAVE - 1)) == 0 && lo <= hi) {            // min/max of the score field (non-negative after >> 1)
+            atomicMin(&s_wave[32], (int)(lo >> 1));
+            atomicMax(&s_wave[33], (int)(hi >> 1));
+        }
+        __syncthreads();
+        const uint32_t lo1 = (uint32_t)s_wave[32], range = (uint32_t)s_wave[33] - lo1;     // in units of 2 ulps of the field
+        const int shift = range >= (uint32_t)TOPK_BINS ? (32 - __clz((int)range)) - 11 : 0;
+#pragma unroll
+        for (int r = 0; r < TOPK_FAST_PT; ++r)
+            if (kr[r] != ~0ull) atomicAdd(&s_hist[(((uint32_t)(kr[r] >> 33)) - lo1) >> shift], 1);
+        __syncthreads();
+        // inclusive scan of the bins: two per thread, wave shuffles, 16 wave totals
+        const int h0 = s_hist[2 * t], h1 = s_hist[2 * t + 1];
+        int incl = h0 + h1;
+        const int lane = t & (RN_WAVE - 1), wv = t >> 6;
+#pragma unroll
+        for (int d = 1; d < RN_WAVE; d <<= 1) { const int up = __shfl_up(incl, d, RN_WAVE); if (lane >= d) incl += up; }
+        if (lane == RN_WAVE - 1) s_wave[wv] = incl;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wv; ++w) before += s_wave[w];
+        const int c1 = before + incl, c0 = c1 - h1, cm = c0 - h0;      // cumulative after bin 2t+1, after 2t, before 2t
+        const int need = min(M, max_det);
+        if (need > 0) {
+            if (cm < need && c0 >= need) { s_wave[34] = 2 * t; s_wave[35] = c0; }
+            else if (c0 < need && c1 >= need) { s_wave[34] = 2 * t + 1; s_wave[35] = c1; }
+        }
+        __syncthreads();
+        const int tbin = s_wave[34], nsel = s_wave[35];
+        if (nsel <= TOPK_CHUNK) {                               // else: too many ties in one bin, take the general path
+            if (need > 0) {
+#pragma unroll
+                for (int r = 0; r < TOPK_FAST_PT; ++r)
+                    if (kr[r] != ~0ull && (int)((((uint32_t)(kr[r] >> 33)) - lo1) >> shift) <= tbin)
+                        s_surv[atomicAdd(&s_wave[36], 1)] = kr[r];
+            }
+            __syncthreads();
+            win = t < nsel ? s_surv[t] : ~0ull;
+            int npow = RN_WAVE;
+            while (npow < nsel) npow <<= 1;
+            __syncthreads();                                    // s_key is reused as the exchange buffer
+            bitonic_one(win, s_key, npow);
+            done = true;
+        } else {
+            __syncthreads();
+            for (int i = t; i < TOPK_SURV; i += TOPK_THREADS) s_surv[i] = ~0ull;
+            __syncthreads();
+        }
+    }
+    if (!done) {
 
     // chunks per round: (1 + group) * max_det survivors must fit in s_surv (max_det <= 1024 -> group >= 1)
     const int group = max(1, min(TOPK_GROUP, TOPK_SURV / max_det - 1));
@@ -442,12 +642,14 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const uint64_t *__re
     uint64_t sr[2] = {s_surv[t], s_surv[TOPK_CHUNK + t]};
     __syncthreads();
     bitonic_regs<2, true>(sr, s_key);
+    win = sr[0];                                                 // max_det <= 1024: the winners are elements 0..1023
+    }
 
     const int nout = min(M, max_det);
     if (t < max_det) {
         const int64_t o = (int64_t)b * max_det + t;
         if (t < nout) {
-            const uint64_t key = sr[0];                              // max_det <= 1024: the winners are elements 0..1023
+            const uint64_t key = win;
             const uint32_t ka = (uint32_t)key;
             const uint32_t k = ka / (uint32_t)A, anchor = ka - k * (uint32_t)A;
             out_boxes[o] = boxes[(int64_t)b * A + anchor];
@@ -465,7 +667,7 @@ size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct DetectWs {
     rn::f32x4 *boxes; uint64_t *cand, *seg; rn::f32x4 *sbox; uint8_t *supp;
-    int32_t *cand_count, *seg_count, *seg_fill, *kept_count, *seg_len; int64_t *seg_start;
+    int32_t *cand_count, *kept_count, *seg_len; int64_t *seg_start;
     size_t zero_bytes, total;
 };
 
@@ -481,11 +683,9 @@ DetectWs carve(void *base, int B, int64_t A, int K, int64_t C)
     w.seg = (uint64_t *)take(BC * 8);
     w.sbox = (rn::f32x4 *)take(BC * 16);
     w.supp = (uint8_t *)take(BC);
-    // zeroed every call: cand_count | seg_count | seg_fill (contiguous)
+    // zeroed every call
     const size_t z0 = off;
     w.cand_count = (int32_t *)take((size_t)B * 4);
-    w.seg_count = (int32_t *)take(BK * 4);
-    w.seg_fill = (int32_t *)take(BK * 4);
     w.zero_bytes = off - z0;
     w.kept_count = (int32_t *)take(BK * 4);
     w.seg_len = (int32_t *)take(BK * 4);
@@ -550,10 +750,10 @@ RN_API int rn_detect_levels(const void *const *cls_levels, const void *const *bo
     sa.L = L;
     int64_t base = 0, voff = 0;
     int rc = RN_OK;
+    SegArgs fa;
+    fa.L = L;
     for (int l = 0; l < L; ++l) {
-        rc = launch_decode(box_levels[l], dtype, B, level_anchors[l], base, A, anchors, anchor_bstride, image_hw, rw,
-                           (float *)w.boxes, st);
-        if (rc != RN_OK) return rc;
+        fa.lv[l].box = box_levels[l]; fa.lv[l].A_l = level_anchors[l]; fa.lv[l].base = base;
         ScanLevel &lv = sa.lv[l];
         lv.cls = cls_levels[l]; lv.A_l = level_anchors[l]; lv.base = base;
         lv.N = (int64_t)B * level_anchors[l] * K; lv.nvec = lv.N / vec; lv.voff = voff;
@@ -563,15 +763,19 @@ RN_API int rn_detect_levels(const void *const *cls_levels, const void *const *bo
     sa.total_vec = voff;
     RN_HIP(hipMemsetAsync(w.cand_count, 0, w.zero_bytes, st));
 
-    sa.boxes = w.boxes; sa.A = A; sa.C = C; sa.K = K; sa.B = B;
+    for (int l = L; l < RN_MAX_LEVELS; ++l) fa.lv[l] = fa.lv[L - 1];
+    fa.anchors = (const rn::f32x4 *)anchors; fa.anchor_bstride4 = anchor_bstride / 4; fa.image_hw = image_hw; fa.rw = rw;
+    fa.A = A; fa.C = C; fa.K = K; fa.min_box = params->min_box;
+    fa.cand = w.cand; fa.cand_count = w.cand_count; fa.boxes = w.boxes;
+    fa.seg = w.seg; fa.seg_start = w.seg_start; fa.seg_len = w.seg_len; fa.out_status = out_status;
+    sa.A = A; sa.C = C; sa.K = K; sa.B = B;
     sa.score_thr = params->score_thr;
-    sa.min_box = params->min_box;
     {   // logit-space pre-filter with a safety margin; the exact test is still sigmoid(x) > thr
         const double t = (double)params->score_thr;
         sa.pre_thr = (t > 0.0 && t < 1.0) ? (float)(log(t / (1.0 - t)) - 1e-2) : (t <= 0.0 ? -INFINITY : 40.0f);
         if (t >= 1.0) sa.pre_thr = INFINITY;
     }
-    sa.cand = w.cand; sa.cand_count = w.cand_count; sa.seg_count = w.seg_count;
+    sa.cand = w.cand; sa.cand_count = w.cand_count;
     // resident-sized grid, even split of the 16-byte vectors over the waves (whole wave-iterations)
     int dev = 0, cus = 0, per_cu = 0;
     RN_HIP(hipGetDevice(&dev));
@@ -599,14 +803,13 @@ RN_API int rn_detect_levels(const void *const *cls_levels, const void *const *bo
         default: return RN_EINVAL;
     }
     RN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(seg_offsets_kernel, dim3((unsigned)B), dim3(64), 0, st, w.cand_count, w.seg_count, K, C, w.seg_start,
-                       w.seg_len, out_status);
-    RN_LAUNCH_CHECK();
     {
-        int64_t sb = (C + 255) / 256;
-        if (sb > 1024) sb = 1024;
-        hipLaunchKernelGGL(seg_scatter_kernel, dim3((unsigned)sb, (unsigned)B), dim3(256), 0, st, w.cand, w.cand_count, K, C,
-                           w.seg_start, w.seg_fill, w.seg);
+        const dim3 fg((unsigned)B), fb(SEG_THREADS);
+        switch (dtype) {
+            case RN_F32: hipLaunchKernelGGL((seg_build_kernel<RN_F32>), fg, fb, 0, st, fa); break;
+            case RN_BF16: hipLaunchKernelGGL((seg_build_kernel<RN_BF16>), fg, fb, 0, st, fa); break;
+            default: hipLaunchKernelGGL((seg_build_kernel<RN_F16>), fg, fb, 0, st, fa); break;
+        }
         RN_LAUNCH_CHECK();
     }
     rn::NmsLaunch na;

@@ -149,6 +149,8 @@ def main():
             bench_k3(reps, torch.bfloat16, want_grad=False)
         elif w == "detect":
             bench_detect(max(reps // 5, 4), -7.0, 1.2, "sparse")
+        elif w == "detect_empty":
+            bench_detect(6, -20.0, 0.5, "empty")
         elif w == "detect_stress":
             bench_detect(3, -6.0, 1.5, "stress")
 

@@ -5,6 +5,6 @@ rm -rf /tmp/ks; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks 
 python - <<PY
 import csv,glob
 f=glob.glob("/tmp/ks/*/*kernel_stats.csv")[0]
-for r in list(csv.DictReader(open(f)))[:12]:
+for r in list(csv.DictReader(open(f)))[:28]:
     print(r["Calls"].rjust(5), str(round(float(r["AverageNs"])/1e3,1)).rjust(8), "us  min", str(round(float(r["MinNs"])/1e3,1)).rjust(8), r["Name"][:100])
 PY
