@@ -98,13 +98,19 @@ int launch_decode(const void *deltas, const int dtype, const int B, const int64_
 // flight per wave; each wave owns one contiguous range of the flattened tensor).  An element is a
 // candidate when sigmoid(x) > score_thr (models.py:196).  Candidates (~4e-4 of the elements at the
 // reference's prior) are staged in a wave-private LDS list and flushed with ONE global atomic per
-// (wave, image): no block barrier and no dependent global load anywhere in the stream.  The box
+// (wave, image): no block barrier and no dependent global load anywhere in the stream.  The
+// streaming loop itself only spots 16-byte vectors that contain an element above a logit-space
+// pre-threshold and parks them (raw bits + position) in a wave-private LDS queue; the exact test
+// sigmoid(x) > thr, the index arithmetic and the key are done later for 64 parked vectors at a
+// time with all lanes busy, instead of with 1-2 active lanes at every hit.  The box
 // side of the filter (remove_small_boxes, models.py:203) runs afterwards on the candidates only
 // (cand_filter_kernel), which is also where their boxes are decoded.
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_WAVES = SCAN_THREADS / RN_WAVE;
 constexpr int SCAN_CAP = 128;            // wave-private list entries (>= 64: one ballot's worth always fits after a flush)
 constexpr int SCAN_PF = 2;
+constexpr int SCAN_QCAP = 128;           // parked vectors per wave
+constexpr int SCAN_SHARDS = 128;         // candidate-list shards per image
 
 // One pyramid level of the class logits, [B][A_l][K] dense; the levels are scanned as one virtual
 // sequence of 16-byte vectors (level l = vectors voff .. voff + nvec), like K3 (loss.hip).
@@ -119,15 +125,20 @@ struct ScanArgs {
     ScanLevel lv[RN_MAX_LEVELS];
     int64_t A, total_vec, vec_per_wave, C;
     int32_t K, B;
+    int32_t S;               // candidate-list shards per image (power of two)
+    int64_t Cs;              // capacity of one shard; S * Cs <= C
     float score_thr, pre_thr;
-    uint64_t *cand;          // [B][C]  (inv_ordered(score) << 32) | (anchor*K + k)
-    int32_t *cand_count;     // [B]
+    uint64_t *cand;          // [B][S][Cs]  (inv_ordered(score) << 32) | (anchor*K + k)
+    int32_t *cand_count;     // [B][S]
 };
 
 struct ScanList { uint64_t key[SCAN_CAP]; int img[SCAN_CAP]; };
+struct HitQueue { rn::u32x4 raw[SCAN_QCAP]; int64_t vv[SCAN_QCAP]; };     // vv: virtual vector index (level voff + v)
 
-// wave-level flush: one atomic per distinct image in the list
-__device__ __forceinline__ void scan_flush(ScanList &sl, const int fill, const ScanArgs &a, const int lane)
+// wave-level flush: one atomic per distinct image in the list.  The list of an image is split into S
+// shards (wave g appends to shard g mod S): returning atomics on one address cost ~130 ns each on
+// MI355X, and with one counter per image the ~8000 end-of-kernel flushes took 65 us.
+__device__ __forceinline__ void scan_flush(ScanList &sl, const int fill, const ScanArgs &a, const int lane, const int shard)
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -145,17 +156,18 @@ __device__ __forceinline__ void scan_flush(ScanList &sl, const int fill, const S
         const unsigned long long mk0 = __ballot(m0), mk1 = __ballot(m1);
         const int n0 = __popcll(mk0), n = n0 + __popcll(mk1);
         int base = 0;
-        if (lane == 0) base = atomicAdd(&a.cand_count[b], n);
+        const int64_t list = (int64_t)b * a.S + shard;
+        if (lane == 0) base = atomicAdd(&a.cand_count[list], n);
         base = __shfl(base, 0, RN_WAVE);
         const unsigned long long lt = (1ull << lane) - 1ull;
         if (m0) {
             const int64_t pos = (int64_t)base + __popcll(mk0 & lt);
-            if (pos < a.C) a.cand[(int64_t)b * a.C + pos] = k0;
+            if (pos < a.Cs) a.cand[list * a.Cs + pos] = k0;
             done0 = true;
         }
         if (m1) {
             const int64_t pos = (int64_t)base + n0 + __popcll(mk1 & lt);
-            if (pos < a.C) a.cand[(int64_t)b * a.C + pos] = k1;
+            if (pos < a.Cs) a.cand[list * a.Cs + pos] = k1;
             done1 = true;
         }
     }
@@ -166,14 +178,14 @@ __device__ __forceinline__ void scan_flush(ScanList &sl, const int fill, const S
 // exact score of one element (rare path), models.py:170
 __device__ __forceinline__ float scan_score(const float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// key and image of element e of level lv, whose score s passed
-__device__ __forceinline__ void scan_key(const ScanArgs &a, const ScanLevel &lv, const float s, const int64_t e, uint64_t &key,
-                                         int &img)
+// key and image of element e of a level (A_l anchors per image, the first one is anchor `base`), whose score s passed
+__device__ __forceinline__ void scan_key(const ScanArgs &a, const int64_t A_l, const int64_t base, const float s, const int64_t e,
+                                         uint64_t &key, int &img)
 {
     const int64_t r = e / a.K;                                // row of this level's [B*A_l][K]
     const uint32_t k = (uint32_t)(e - r * a.K);
-    const int b = (int)((uint32_t)r / (uint32_t)lv.A_l);
-    const uint32_t anchor = (uint32_t)(lv.base + (r - (int64_t)b * lv.A_l));
+    const int b = (int)((uint32_t)r / (uint32_t)A_l);
+    const uint32_t anchor = (uint32_t)(base + (r - (int64_t)b * A_l));
     key = ((uint64_t)rn::inv_ordered(s) << 32) | (uint32_t)(anchor * (uint32_t)a.K + k);
     img = b;
 }
@@ -184,25 +196,59 @@ __global__ __launch_bounds__(SCAN_THREADS) void score_scan_kernel(const ScanArgs
     typedef rn::dt<DT> D;
     constexpr int VEC = D::VEC;
     __shared__ ScanList s_list[SCAN_WAVES];
+    __shared__ HitQueue s_queue[SCAN_WAVES];
     const int lane = threadIdx.x & (RN_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     ScanList &sl = s_list[wave];
+    HitQueue &hq = s_queue[wave];
     const int64_t gwave = (int64_t)blockIdx.x * SCAN_WAVES + wave;
     const int64_t w_beg = gwave * a.vec_per_wave;
     const int64_t w_end = min(w_beg + a.vec_per_wave, a.total_vec);
-    int fill = 0;                                              // wave-uniform
+    int fill = 0, qfill = 0;                                   // wave-uniform
+    const int shard = (int)(gwave & (int64_t)(a.S - 1));
+    const unsigned long long lt = (1ull << lane) - 1ull;
 
     // append the candidates selected by `pred` (at most one per lane): ballot, maybe flush, write
     auto append = [&](const bool pred, const uint64_t key, const int img) {
         const unsigned long long mk = __ballot(pred);
         if (!mk) return;
         const int n = __popcll(mk);
-        if (fill + n > SCAN_CAP) { scan_flush(sl, fill, a, lane); fill = 0; }
+        if (fill + n > SCAN_CAP) { scan_flush(sl, fill, a, lane, shard); fill = 0; }
         if (pred) {
-            const int pos = fill + __popcll(mk & ((1ull << lane) - 1ull));
+            const int pos = fill + __popcll(mk & lt);
             sl.key[pos] = key; sl.img[pos] = img;
         }
         fill += n;
+    };
+    // exact test + keys of the parked vectors, one vector per lane
+    auto drain = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int q0 = 0; q0 < qfill; q0 += RN_WAVE) {
+            const bool valid = q0 + lane < qfill;
+            const int qi = valid ? q0 + lane : 0;
+            const int64_t vv = hq.vv[qi];
+            int64_t voff = 0, A_l = a.lv[0].A_l, abase = 0;   // level of this vector
+#pragma unroll
+            for (int l = 1; l < RN_MAX_LEVELS; ++l)
+                if (l < a.L && vv >= a.lv[l].voff) { voff = a.lv[l].voff; A_l = a.lv[l].A_l; abase = a.lv[l].base; }
+            const int64_t e0 = (vv - voff) * VEC;
+#pragma unroll 1
+            for (int j = 0; j < VEC; ++j) {                   // rolled: element j is re-read from the parked bits
+                const float xj = D::ld((const void *)&hq.raw[qi], j);
+                bool c = valid && (xj > a.pre_thr);
+                uint64_t key = 0; int img = 0;
+                if (c) {
+                    const float sc = scan_score(xj);
+                    c = sc > a.score_thr;
+                    if (c) scan_key(a, A_l, abase, sc, e0 + j, key, img);
+                }
+                append(c, key, img);
+            }
+        }
+        qfill = 0;
+        __builtin_amdgcn_wave_barrier();
     };
 
     for (int l = 0; l < a.L; ++l) {                            // wave-uniform: the levels this wave's range touches
@@ -212,40 +258,18 @@ __global__ __launch_bounds__(SCAN_THREADS) void score_scan_kernel(const ScanArgs
         auto do_vec = [&](const rn::u32x4 raw, const int64_t v) {
             float x[VEC];
             D::unpack(raw, x);
-            uint32_t m = 0;                                   // bit j: element j of this lane's vector may be a candidate
+            bool hit = false;
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) m |= (x[j] > a.pre_thr) ? (1u << j) : 0u;
-            if (!__any(m != 0)) return;                       // common case: ~0.2 candidates per 512 elements
-#pragma unroll
-            for (int j = 0; j < VEC; ++j)                     // exact test, only where the pre-filter fired
-                if ((m >> j) & 1u) { if (!(scan_score(x[j]) > a.score_thr)) m &= ~(1u << j); }
-            const int cnt = __popc(m);
-            int incl = cnt;                                   // inclusive prefix over the lanes
-#pragma unroll
-            for (int d = 1; d < RN_WAVE; d <<= 1) { const int up = __shfl_up(incl, d, RN_WAVE); if (lane >= d) incl += up; }
-            const int total = __shfl(incl, RN_WAVE - 1, RN_WAVE);
-            if (total == 0) return;
-            if (total <= RN_WAVE) {                           // one reservation for the whole vector group
-                if (fill + total > SCAN_CAP) { scan_flush(sl, fill, a, lane); fill = 0; }
-                int pos = fill + incl - cnt;
-#pragma unroll
-                for (int j = 0; j < VEC; ++j)
-                    if ((m >> j) & 1u) {
-                        uint64_t key; int img;
-                        scan_key(a, lv, scan_score(x[j]), v * VEC + j, key, img);
-                        sl.key[pos] = key; sl.img[pos] = img;
-                        ++pos;
-                    }
-                fill += total;
-            } else {                                          // dense group: one ballot per element slot
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) {
-                    uint64_t key = 0; int img = 0;
-                    const bool c = (m >> j) & 1u;
-                    if (c) scan_key(a, lv, scan_score(x[j]), v * VEC + j, key, img);
-                    append(c, key, img);
-                }
+            for (int j = 0; j < VEC; ++j) hit |= (x[j] > a.pre_thr);
+            const unsigned long long mk = __ballot(hit);
+            if (!mk) return;                                  // common case: ~0.2 candidates per 512 elements
+            const int n = __popcll(mk);
+            if (qfill + n > SCAN_QCAP) drain();
+            if (hit) {
+                const int pos = qfill + __popcll(mk & lt);
+                hq.raw[pos] = raw; hq.vv[pos] = lv.voff + v;
             }
+            qfill += n;
         };
         if (v_beg < v_end) {
             const int64_t last = v_end - 1;
@@ -285,12 +309,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void score_scan_kernel(const ScanArgs
             if (lane < VEC && e < lv.N) {
                 const float x = D::ld(lv.cls, e);
                 c = (x > a.pre_thr) && (scan_score(x) > a.score_thr);
-                if (c) scan_key(a, lv, scan_score(x), e, key, img);
+                if (c) scan_key(a, lv.A_l, lv.base, scan_score(x), e, key, img);
             }
             append(c, key, img);
         }
     }
-    if (fill) scan_flush(sl, fill, a, lane);
+    if (qfill) drain();
+    if (fill) scan_flush(sl, fill, a, lane, shard);
 }
 
 // ---- candidates -> per-(image, class) segments ----------------------------------------------
@@ -314,8 +339,10 @@ struct SegArgs {
     int64_t A, C;
     int32_t K;
     float min_box;
-    uint64_t *cand;              // [B][C] candidates (dead ones are overwritten with DEAD_KEY)
-    const int32_t *cand_count;   // [B]
+    int32_t S;                   // shards of the candidate list (see ScanArgs)
+    int64_t Cs;
+    uint64_t *cand;              // [B][S][Cs] candidates (dead ones are overwritten with DEAD_KEY)
+    const int32_t *cand_count;   // [B][S]
     rn::f32x4 *boxes;            // [B][A] decoded boxes, written only at candidate anchors
     uint64_t *seg;               // [B][C] (inv score << 32 | anchor), grouped by class
     int64_t *seg_start;          // [B][K]
@@ -331,21 +358,46 @@ template <int DT>
 __global__ __launch_bounds__(SEG_THREADS) void seg_build_kernel(const SegArgs a)
 {
     __shared__ int s_cnt[SEG_MAXK];
+    __shared__ int s_shard[SCAN_SHARDS + 1];                  // exclusive prefix of the shard fills
+    __shared__ int s_over;
     const int b = blockIdx.x, t = threadIdx.x;
-    const int64_t n = min((int64_t)a.cand_count[b], a.C);
     for (int k = t; k < a.K; k += SEG_THREADS) s_cnt[k] = 0;
+    if (t == 0) s_over = 0;
     __syncthreads();
+    if (t < RN_WAVE) {                                        // wave 0: shard fills -> prefix (S <= 128: two rounds)
+        int run = 0;
+        for (int s0 = 0; s0 < a.S; s0 += RN_WAVE) {
+            const int sh = s0 + t;
+            int c = sh < a.S ? a.cand_count[(int64_t)b * a.S + sh] : 0;
+            if ((int64_t)c > a.Cs) { c = (int)a.Cs; s_over = 1; }
+            int incl = c;
+#pragma unroll
+            for (int dd = 1; dd < RN_WAVE; dd <<= 1) { const int up = __shfl_up(incl, dd, RN_WAVE); if (t >= dd) incl += up; }
+            if (sh < a.S) s_shard[sh] = run + (incl - c);
+            run += __shfl(incl, RN_WAVE - 1, RN_WAVE);
+        }
+        if (t == 0) s_shard[a.S] = run;
+    }
+    __syncthreads();
+    const int64_t n = s_shard[a.S];
+    // candidate i of the image -> its slot in the sharded list
+    auto slot_of = [&](const int64_t i) -> int64_t {
+        int lo = 0, hi = a.S;                                  // shard sh with s_shard[sh] <= i < s_shard[sh + 1]
+        while (hi - lo > 1) { const int md = (lo + hi) >> 1; if (s_shard[md] <= i) lo = md; else hi = md; }
+        return (int64_t)lo * a.Cs + (i - s_shard[lo]);
+    };
     float hh = 0.0f, ww = 0.0f;
     if (a.image_hw) { hh = (float)a.image_hw[2 * b]; ww = (float)a.image_hw[2 * b + 1]; }
-    uint64_t *cand = a.cand + (int64_t)b * a.C;
+    uint64_t *cand = a.cand + (int64_t)b * a.S * a.Cs;
 
     for (int64_t i0 = 0; i0 < n; i0 += SEG_UNROLL * SEG_THREADS) {
         uint64_t key[SEG_UNROLL];
         uint32_t anchor[SEG_UNROLL], k[SEG_UNROLL];
         float d[SEG_UNROLL][4];
         rn::f32x4 an[SEG_UNROLL];
+        int64_t slot[SEG_UNROLL];
 #pragma unroll
-        for (int u = 0; u < SEG_UNROLL; ++u) key[u] = cand[min(i0 + u * SEG_THREADS + t, n - 1)];
+        for (int u = 0; u < SEG_UNROLL; ++u) { slot[u] = slot_of(min(i0 + u * SEG_THREADS + t, n - 1)); key[u] = cand[slot[u]]; }
 #pragma unroll
         for (int u = 0; u < SEG_UNROLL; ++u) {
             const uint32_t ak = (uint32_t)key[u];
@@ -371,7 +423,7 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_build_kernel(const SegArgs a)
                 a.boxes[(int64_t)b * a.A + anchor[u]] = o;
                 atomicAdd(&s_cnt[k[u]], 1);
             } else {
-                cand[i] = DEAD_KEY;
+                cand[slot[u]] = DEAD_KEY;
             }
         }
     }
@@ -391,14 +443,14 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_build_kernel(const SegArgs a)
             }
             run += __shfl(incl, RN_WAVE - 1, RN_WAVE);
         }
-        if (t == 0) a.out_status[b] = a.cand_count[b] > a.C ? 1 : 0;
+        if (t == 0) a.out_status[b] = s_over;
     }
     __syncthreads();
     uint64_t *seg = a.seg + (int64_t)b * a.C;
     for (int64_t i0 = 0; i0 < n; i0 += SEG_UNROLL * SEG_THREADS) {
         uint64_t key[SEG_UNROLL];
 #pragma unroll
-        for (int u = 0; u < SEG_UNROLL; ++u) key[u] = cand[min(i0 + u * SEG_THREADS + t, n - 1)];   // this thread's own writes
+        for (int u = 0; u < SEG_UNROLL; ++u) key[u] = cand[slot_of(min(i0 + u * SEG_THREADS + t, n - 1))];   // this thread's own writes
 #pragma unroll
         for (int u = 0; u < SEG_UNROLL; ++u) {
             if (i0 + u * SEG_THREADS + t >= n || key[u] == DEAD_KEY) continue;
@@ -685,7 +737,7 @@ DetectWs carve(void *base, int B, int64_t A, int K, int64_t C)
     w.supp = (uint8_t *)take(BC);
     // zeroed every call
     const size_t z0 = off;
-    w.cand_count = (int32_t *)take((size_t)B * 4);
+    w.cand_count = (int32_t *)take((size_t)B * SCAN_SHARDS * 4);
     w.zero_bytes = off - z0;
     w.kept_count = (int32_t *)take(BK * 4);
     w.seg_len = (int32_t *)take(BK * 4);
@@ -769,6 +821,11 @@ RN_API int rn_detect_levels(const void *const *cls_levels, const void *const *bo
     fa.cand = w.cand; fa.cand_count = w.cand_count; fa.boxes = w.boxes;
     fa.seg = w.seg; fa.seg_start = w.seg_start; fa.seg_len = w.seg_len; fa.out_status = out_status;
     sa.A = A; sa.C = C; sa.K = K; sa.B = B;
+    // shards of the per-image candidate list; the worst-case capacity (the caller's retry) is one list so
+    // that "A*K always suffices" holds however the candidates are distributed over the waves
+    sa.S = (C >= A * (int64_t)K || C / SCAN_SHARDS < 64) ? 1 : SCAN_SHARDS;
+    sa.Cs = C / sa.S;
+    fa.S = sa.S; fa.Cs = sa.Cs;
     sa.score_thr = params->score_thr;
     {   // logit-space pre-filter with a safety margin; the exact test is still sigmoid(x) > thr
         const double t = (double)params->score_thr;
