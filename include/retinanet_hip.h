@@ -155,6 +155,18 @@ int rn_decode_clip(const void *deltas, int dtype, int B, int64_t A,
                    const float *anchors, int64_t anchor_bstride, const int32_t *image_hw,
                    const float reg_w[4], float *out, void *stream);
 
+/* ---- T1 transform (normalise + resize + pad + batch) -------------------------------------------
+ * Replaces torchvision's GeneralizedRCNNTransform as the reference runs it at
+ * retinanet/models.py:116 (construction), :262 and :279 (calls): per image (x - mean) / std, bilinear
+ * resize (align_corners=False, scale recomputed from the integer sizes) to out_hw[b], zero padding
+ * into one batch [B][3][Hp][Wp].  images: HOST array of B device pointers, each f32 [3][h][w]
+ * contiguous; in_hw / out_hw: HOST i32[B][2] = (h, w) before / after the resize (the caller computes
+ * the sizes exactly as torchvision does, floor(size * scale) in double); mean / std: HOST f32[3].
+ * out: dtype out_dtype, NCHW or (channels_last != 0) NHWC memory order; Wp % 4 == 0. */
+int rn_transform_batch(const void *const *images, const int32_t *in_hw, const int32_t *out_hw, int B,
+                       const float mean[3], const float std[3], int Hp, int Wp,
+                       void *out, int out_dtype, int channels_last, void *stream);
+
 /* ---- K6 nms (op boundary) ---------------------------------------------------
  * Replaces torchvision.ops.nms as called at retinanet/models.py:210, batched over
  * S independent segments: seg_off i32[S+1]; boxes f32[N][4], scores f32[N].

@@ -8,6 +8,7 @@ All entry points take/return numpy arrays (C-contiguous).  See ``rn_oracle.c``
 for the reference file:line each function restates.
 """
 import ctypes as C
+import math
 import os
 import subprocess
 from typing import List, Optional, Sequence, Tuple
@@ -193,3 +194,31 @@ def detect(cls: np.ndarray, deltas: np.ndarray, anchors: np.ndarray, image_hw: S
                      _p(ob, C.c_float), _p(os_, C.c_float), _p(ol, C.c_int64), _p(oc, C.c_int32))
     return [{"boxes": ob[b, :oc[b]].copy(), "scores": os_[b, :oc[b]].copy(), "labels": ol[b, :oc[b]].copy()}
             for b in range(B)]
+
+
+def transform_sizes(h: int, w: int, min_size: float, max_size: float) -> Tuple[int, int]:
+    """Resized (h, w) as torchvision's GeneralizedRCNNTransform.resize computes them: scale =
+    min(min_size / short, max_size / long) in double, size = floor(side * scale)."""
+    lo, hi = float(min(h, w)), float(max(h, w))
+    scale = float(min_size) / lo
+    if hi * scale > float(max_size):
+        scale = float(max_size) / hi
+    return int(math.floor(h * scale)), int(math.floor(w * scale))
+
+
+def transform_batch(images: Sequence[np.ndarray], min_size: float, max_size: float, mean: Sequence[float],
+                    std: Sequence[float], size_divisible: int = 32):
+    """T1 -> (batch f32 [B,3,Hp,Wp], [(h, w) after the resize])."""
+    imgs = [_f32(im) for im in images]
+    B = len(imgs)
+    in_hw = np.asarray([[im.shape[1], im.shape[2]] for im in imgs], dtype=np.int32)
+    sizes = [transform_sizes(int(h), int(w), min_size, max_size) for h, w in in_hw]
+    out_hw = np.asarray(sizes, dtype=np.int32).reshape(B, 2)
+    d = float(size_divisible)
+    Hp = int(math.ceil(max(s[0] for s in sizes) / d) * d)
+    Wp = int(math.ceil(max(s[1] for s in sizes) / d) * d)
+    out = np.empty((B, 3, Hp, Wp), np.float32)
+    ptrs = (C.c_void_p * B)(*[im.ctypes.data for im in imgs])
+    lib().rno_transform_batch(ptrs, _p(in_hw, C.c_int32), _p(out_hw, C.c_int32), B, _p(_f32(np.asarray(mean)), C.c_float),
+                              _p(_f32(np.asarray(std)), C.c_float), Hp, Wp, _p(out, C.c_float))
+    return out, sizes

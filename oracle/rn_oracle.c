@@ -459,3 +459,52 @@ RNO_API void rno_detect(const float *cls, const float *deltas, int B, int64_t A,
         free(ord); free(ab); free(as); free(al); free(keep); free(cs); free(cb); free(boxes);
     }
 }
+
+/* ------------------------------------------------------------------------ */
+/* T1: torchvision GeneralizedRCNNTransform as the reference runs it         */
+/* (retinanet/models.py:116, :262, :279): per image (x - mean) / std, then    */
+/* F.interpolate(..., mode="bilinear", align_corners=False,                   */
+/* recompute_scale_factor=True) to out_hw (the caller computes the sizes,     */
+/* floor(size * scale) in double, like torchvision), then zero padding into   */
+/* one [B][3][Hp][Wp] batch.  Sampling follows ATen's upsample_bilinear2d:    */
+/* scale = in / out (fp32), src = scale * (dst + 0.5) - 0.5 clamped at 0,     */
+/* taps i0 = (int)src and i0 + (i0 < in - 1), weights (1 - l, l).             */
+/* ------------------------------------------------------------------------ */
+static void tap_axis(int dst, int in, int out, int *i0, int *i1, float *l0, float *l1)
+{
+    const float scale = (in == out) ? 1.0f : (float)in / (float)out;
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.0f) src = 0.0f;
+    int a = (int)src;
+    if (a > in - 1) a = in - 1;
+    *i0 = a;
+    *i1 = a + (a < in - 1 ? 1 : 0);
+    *l1 = src - (float)a;
+    *l0 = 1.0f - *l1;
+}
+
+RNO_API void rno_transform_batch(const float *const *images, const int32_t *in_hw, const int32_t *out_hw, int B,
+                                 const float *mean, const float *std, int Hp, int Wp, float *out /* [B][3][Hp][Wp] */)
+{
+    memset(out, 0, sizeof(float) * (size_t)B * 3 * (size_t)Hp * (size_t)Wp);
+    for (int b = 0; b < B; ++b) {
+        const int ih = in_hw[2 * b], iw = in_hw[2 * b + 1], oh = out_hw[2 * b], ow = out_hw[2 * b + 1];
+        const float *img = images[b];
+#pragma omp parallel for schedule(static)
+        for (int y = 0; y < oh; ++y) {
+            int y0, y1; float ly0, ly1;
+            tap_axis(y, ih, oh, &y0, &y1, &ly0, &ly1);
+            for (int x = 0; x < ow; ++x) {
+                int x0, x1; float lx0, lx1;
+                tap_axis(x, iw, ow, &x0, &x1, &lx0, &lx1);
+                for (int c = 0; c < 3; ++c) {
+                    const float *pl = img + (size_t)c * ih * iw;
+                    const float m = mean[c], s = std[c];
+                    const float p00 = (pl[(size_t)y0 * iw + x0] - m) / s, p01 = (pl[(size_t)y0 * iw + x1] - m) / s;
+                    const float p10 = (pl[(size_t)y1 * iw + x0] - m) / s, p11 = (pl[(size_t)y1 * iw + x1] - m) / s;
+                    out[(((size_t)b * 3 + c) * Hp + y) * Wp + x] = ly0 * (lx0 * p00 + lx1 * p01) + ly1 * (lx0 * p10 + lx1 * p11);
+                }
+            }
+        }
+    }
+}

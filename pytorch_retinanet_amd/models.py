@@ -103,6 +103,15 @@ class Retinanet(nn.Module):
         feature_maps = self.fpn(self.backbone(batch))
         return feature_maps, self.retinanet_head(feature_maps)
 
+    def _batch_layout(self) -> Dict[str, object]:
+        """Layout / dtype the conv stack will consume, for the fused transform kernel: channels-last when
+        the model is, and autocast's dtype when autocast is on (conv1 would cast its input to it anyway,
+        with the same round-to-nearest-even)."""
+        w = self.backbone.backbone.conv1.weight
+        cl = w.is_contiguous(memory_format=torch.channels_last)
+        dt = torch.get_autocast_dtype("cuda") if (w.is_cuda and torch.is_autocast_enabled("cuda")) else None
+        return {"out_dtype": dt, "channels_last": cl}
+
     # -- training ----------------------------------------------------------------------------
     def compute_loss(self, targets: List[Dict[str, Tensor]], outputs: Dict[str, Tensor],
                      anchors: List[Tensor]) -> Dict[str, Tensor]:
@@ -114,10 +123,10 @@ class Retinanet(nn.Module):
         ``targets=None`` means inference and returns ``predict(images)``."""
         if targets is None:
             return self.predict(images)
-        images, targets = self.transform(images, targets)
+        images, targets = self.transform(images, targets, **self._batch_layout())
         batch = images.tensors
         if self.backbone.backbone.conv1.weight.is_contiguous(memory_format=torch.channels_last):
-            batch = batch.contiguous(memory_format=torch.channels_last)
+            batch = batch.contiguous(memory_format=torch.channels_last)        # no-op after the fused transform
         feature_maps = self.fpn(self.backbone(batch))
         anchors = self.anchor_generator(images, feature_maps)
         # same losses as compute_loss(targets, retinanet_head(feature_maps), anchors), but the loss kernel
@@ -157,7 +166,7 @@ class Retinanet(nn.Module):
             assert len(val) == 2
             original_image_sizes.append((int(val[0]), int(val[1])))
         with torch.no_grad():
-            images, _ = self.transform(images, None)
+            images, _ = self.transform(images, None, **self._batch_layout())
             batch = images.tensors
             if self.backbone.backbone.conv1.weight.is_contiguous(memory_format=torch.channels_last):
                 batch = batch.contiguous(memory_format=torch.channels_last)

@@ -234,6 +234,34 @@ def image_hw_tensor(sizes: Sequence[Tuple[int, int]], device: torch.device) -> T
     return host.pin_memory().to(device, non_blocking=True)
 
 
+def transform_batch(images: Sequence[Tensor], out_sizes: Sequence[Tuple[int, int]], mean: Sequence[float],
+                    std: Sequence[float], Hp: int, Wp: int, out_dtype: torch.dtype = torch.float32,
+                    channels_last: bool = False) -> Tensor:
+    """T1: (x - mean) / std -> bilinear resize of image b to out_sizes[b] -> zero-padded batch
+    ``[B, 3, Hp, Wp]`` (``out_dtype``; channels_last memory format on request) in one launch.
+    images: CUDA f32 ``[3, h, w]`` tensors; Wp % 4 == 0."""
+    dev = _need_dev(*images)
+    B = len(images)
+    if B == 0 or len(out_sizes) != B:
+        raise ValueError("need one output size per image")
+    imgs = []
+    for im in images:
+        if im.dim() != 3 or im.shape[0] != 3 or im.dtype != torch.float32:
+            raise ValueError(f"transform_batch expects f32 [3, h, w] images, got {tuple(im.shape)} {im.dtype}")
+        imgs.append(im if im.is_contiguous() else im.contiguous())
+    if out_dtype not in _DT:
+        raise ValueError(f"unsupported output dtype {out_dtype}")
+    out = torch.empty((B, 3, Hp, Wp), dtype=out_dtype, device=dev,
+                      memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+    ptrs = (C.c_void_p * B)(*[im.data_ptr() for im in imgs])
+    in_hw = (C.c_int32 * (2 * B))(*[int(v) for im in imgs for v in im.shape[1:]])
+    out_hw = (C.c_int32 * (2 * B))(*[int(v) for s in out_sizes for v in s])
+    with torch.cuda.device(dev), _timed("transform_batch", dev):
+        check(lib.rn_transform_batch(ptrs, in_hw, out_hw, B, (C.c_float * 3)(*mean), (C.c_float * 3)(*std), int(Hp), int(Wp),
+                                     _ptr(out), _DT[out_dtype], int(bool(channels_last)), _stream(dev)), "rn_transform_batch")
+    return out
+
+
 def decode_clip(deltas: Tensor, anchors: Tensor, image_hw: Optional[Tensor],
                 reg_w: Sequence[float] = (1.0, 1.0, 1.0, 1.0)) -> Tensor:
     """K4.  deltas [B,A,4] or [A,4]; image_hw i32 [B,2] (device) or None.  -> f32 boxes, same leading shape."""

@@ -8,6 +8,13 @@ long side would exceed ``max_size`` (``align_corners=False``, scale recomputed f
 the integer output size) -> GT boxes scaled by the per-axis size ratio -> images
 zero-padded into one batch whose H, W are rounded up to a multiple of 32.
 ``postprocess`` maps detections back to the original image sizes (eval mode only).
+
+For CUDA fp32 images the normalise / resize / pad / batch sequence is ONE HIP launch
+(``rn_transform_batch``, ``csrc/transform.hip``) that can also write the batch
+directly in the layout and dtype the conv stack consumes (channels-last, autocast dtype), so the
+per-image elementwise kernels, the batch memset + copies, the ``contiguous(channels_last)`` pass
+and autocast's cast of the conv1 input all disappear.  Anything else (CPU tensors, other dtypes)
+takes the PyTorch ops below, which implement the same arithmetic.
 """
 import math
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -94,11 +101,41 @@ class GeneralizedRCNNTransform(nn.Module):
             dst[: im.shape[0], : im.shape[1], : im.shape[2]].copy_(im)
         return out
 
+    # -- fused path ----------------------------------------------------------------------
+    def _fusable(self, images: List[Tensor]) -> bool:
+        return (len(self.image_mean) == 3 and len(self.image_std) == 3 and
+                all(im.is_cuda and im.dim() == 3 and im.shape[0] == 3 and im.dtype == torch.float32 for im in images)
+                and self.size_divisible % 4 == 0)
+
+    def _forward_fused(self, images: List[Tensor], targets, out_dtype: torch.dtype, channels_last: bool):
+        from . import ops                       # the HIP library is only needed once a CUDA image shows up
+        sizes = []
+        for i, im in enumerate(images):
+            h, w = int(im.shape[-2]), int(im.shape[-1])
+            scale = self._scale_for(h, w, self._target_short_side())       # drawn per image, like torchvision
+            new = (int(math.floor(h * scale)), int(math.floor(w * scale)))
+            sizes.append(new)
+            if targets is not None:
+                targets[i]["boxes"] = resize_boxes(targets[i]["boxes"], (h, w), new)
+        d = float(self.size_divisible)
+        hp = int(math.ceil(max(s[0] for s in sizes) / d) * d)
+        wp = int(math.ceil(max(s[1] for s in sizes) / d) * d)
+        batch = ops.transform_batch(images, sizes, self.image_mean, self.image_std, hp, wp, out_dtype, channels_last)
+        return ImageList(batch, sizes), targets
+
     # -- whole transform -----------------------------------------------------------------
-    def forward(self, images: List[Tensor], targets: Optional[List[Dict[str, Tensor]]] = None):
+    def forward(self, images: List[Tensor], targets: Optional[List[Dict[str, Tensor]]] = None,
+                out_dtype: Optional[torch.dtype] = None, channels_last: bool = False):
+        """``out_dtype`` / ``channels_last``: layout hints for the fused CUDA path (defaults: fp32, NCHW --
+        what torchvision's transform returns); ignored by the PyTorch fallback."""
         images = list(images)
         if targets is not None:
             targets = [dict(t) for t in targets]
+        for im in images:
+            if im.dim() != 3:
+                raise ValueError(f"images is expected to be a list of 3d tensors of shape [C, H, W], got {tuple(im.shape)}")
+        if self._fusable(images):
+            return self._forward_fused(images, targets, out_dtype or torch.float32, channels_last)
         for i, im in enumerate(images):
             if im.dim() != 3:
                 raise ValueError(f"images is expected to be a list of 3d tensors of shape [C, H, W], got {tuple(im.shape)}")

@@ -348,9 +348,40 @@ def gen_nms():
     save("nms.npz", **out)
 
 
+def gen_transform():
+    print("[transform]  GeneralizedRCNNTransform as constructed at retinanet/models.py:116 and called at :262, :279")
+    # The class the reference module holds is torchvision's; here it resolves to the stand-in, whose
+    # arithmetic is torch's own ops (sub/div, F.interpolate bilinear on CPU, zero-pad copy).
+    rng = np.random.default_rng(21)
+    imgs = [rng.random((3, 19, 27), dtype=np.float32), rng.random((3, 32, 24), dtype=np.float32),
+            rng.random((3, 20, 30), dtype=np.float32)]
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    out = {"mean": np.float32(mean), "std": np.float32(std)}
+    for i, im in enumerate(imgs):
+        out[f"img{i}"] = im
+    # (min, max): up-scaling limited by max_size; identity for image 0 (19 -> 19); down-scaling
+    for tag, (mn, mx) in {"up": (28, 40), "ident": (19, 100), "down": (12, 16)}.items():
+        t = ref_models.GeneralizedRCNNTransform(mn, mx, mean, std)
+        t.eval()
+        gtb = [torch.tensor([[1.0, 2.0, 10.0, 12.0]]) for _ in imgs]
+        il, tg = t([torch.from_numpy(i) for i in imgs], [{"boxes": b.clone()} for b in gtb])
+        ref = il.tensors.numpy()
+        got, sizes = oracle.transform_batch(imgs, mn, mx, mean, std)
+        assert [tuple(s) for s in il.image_sizes] == sizes, (tag, il.image_sizes, sizes)
+        assert got.shape == ref.shape, (tag, got.shape, ref.shape)
+        err = float(np.abs(got - ref).max())
+        assert err <= 2e-5, (tag, err)
+        print(f"  {tag}: batch {ref.shape}, sizes {sizes}, oracle max abs err {err:.2e}")
+        out[f"{tag}_cfg"] = np.int32([mn, mx])
+        out[f"{tag}_batch"] = ref
+        out[f"{tag}_sizes"] = np.int32(sizes)
+        out[f"{tag}_boxes"] = np.stack([x["boxes"].numpy() for x in tg])
+    save("transform.npz", **out)
+
+
 if __name__ == "__main__":
     oracle.build()
-    which = sys.argv[1:] or ["anchors", "match", "loss", "decode", "detect", "nms"]
+    which = sys.argv[1:] or ["anchors", "match", "loss", "decode", "detect", "nms", "transform"]
     for w in which:
         globals()["gen_" + w]()
     print("done")

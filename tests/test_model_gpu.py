@@ -171,3 +171,22 @@ def test_train_path_uses_level_outputs_and_matches_cat_path():
         np.testing.assert_allclose(float(a[k]), float(b[k]), rtol=1e-5)
     lv = net.retinanet_head.forward_levels(fmaps)["cls_levels"][0]
     assert lv.is_contiguous()          # a view of the channels_last conv output: nothing was copied
+
+
+def test_transform_module_fused_equals_torch_path():
+    """GeneralizedRCNNTransform: CUDA images take the one-launch HIP path; it must agree with the module's
+    own PyTorch-op path (what CPU tensors take) on sizes, rescaled GT boxes and pixels."""
+    from pytorch_retinanet_amd.transform import GeneralizedRCNNTransform
+    torch.manual_seed(3)
+    imgs = [torch.rand(3, 120, 180), torch.rand(3, 200, 150), torch.rand(3, 128, 128)]
+    tgts = [{"boxes": torch.tensor([[10.0, 20.0, 90.0, 100.0]]), "labels": torch.tensor([1])} for _ in imgs]
+    t = GeneralizedRCNNTransform(128, 192, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]).eval()
+    ref, rt = t(imgs, tgts)
+    got, gt = t([i.cuda() for i in imgs], [{k: v.cuda() for k, v in d.items()} for d in tgts])
+    assert got.image_sizes == ref.image_sizes and got.tensors.shape == ref.tensors.shape
+    torch.testing.assert_close(got.tensors.cpu(), ref.tensors, rtol=0, atol=2e-5)
+    for a, b in zip(gt, rt):
+        torch.testing.assert_close(a["boxes"].cpu(), b["boxes"])
+    cl, _ = t([i.cuda() for i in imgs], None, out_dtype=torch.bfloat16, channels_last=True)
+    assert cl.tensors.dtype == torch.bfloat16 and cl.tensors.is_contiguous(memory_format=torch.channels_last)
+    torch.testing.assert_close(cl.tensors.float().cpu(), ref.tensors, rtol=1e-2, atol=1e-2)

@@ -161,3 +161,21 @@ def test_nms_keep_indices(golden, oracle_lib, n):
     for thr in (0.5, 0.3):
         keep = oracle_lib.nms(g[f"n{n}_boxes"], g[f"n{n}_scores"], thr)
         assert np.array_equal(keep, g[f"n{n}_keep_{int(thr * 10)}"])
+
+
+# ------------------------------------------------------------------ T1 transform
+@pytest.mark.parametrize("tag", ["up", "ident", "down"])
+def test_transform_oracle_vs_golden(oracle_lib, golden, tag):
+    """Oracle T1 == the reference's transform (torchvision semantics on torch CPU ops): sizes exact,
+    pixels within 2e-5 abs (values are O(1); torch's CPU bilinear blends in a different order)."""
+    g = golden("transform.npz")
+    imgs = [g[f"img{i}"] for i in range(3)]
+    mn, mx = (int(v) for v in g[f"{tag}_cfg"])
+    got, sizes = oracle_lib.transform_batch(imgs, mn, mx, g["mean"], g["std"])
+    assert sizes == [tuple(int(v) for v in r) for r in g[f"{tag}_sizes"]]
+    assert got.shape == g[f"{tag}_batch"].shape
+    np.testing.assert_allclose(got, g[f"{tag}_batch"], rtol=0, atol=2e-5)
+    if tag == "ident":      # image 0 is not resized: bit-exact normalisation, exact zero padding
+        h, w = sizes[0]
+        assert np.array_equal(got[0, :, :h, :w], (imgs[0] - g["mean"][:, None, None]) / g["std"][:, None, None])
+        assert not got[0, :, h:, :].any() and not got[0, :, :, w:].any()
