@@ -86,9 +86,34 @@ class RetinaNetClassSubnet(nn.Module):
         # prior-probability bias (layers.py:175-178)
         nn.init.constant_(self.class_subnet_output.bias, -math.log((1 - prior) / prior))
 
-    def forward_levels(self, feature_maps: List[Tensor]) -> List[Tensor]:
-        "Per-level logits [N, H*W*A, K]; views of the conv outputs when the activations are channels_last."
-        return [_to_anchor_major(self.class_subnet_output(self.class_subnet(f)), self.num_classes) for f in feature_maps]
+    # MIOpen's fast bf16 NHWC kernels need the output-channel count to be a multiple of 8: the reference's
+    # 9 x 90 = 810 runs at 290 TFLOP/s on MI355X, 9 x 96 = 864 at 800 (tools/head_conv_probe.py: the
+    # final cls conv of the R50 config is 7.7 ms fwd+bwd at 810 and 3.2 ms at 864).  The fast paths
+    # therefore pad the CLASS dimension per anchor up to a multiple of 8 with dead classes: zero
+    # weights and a bias of PAD_LOGIT, for which sigmoid(x + 1)^2 underflows to exactly 0 in fp32, so
+    # they add exactly nothing to the focal loss and its gradients (K3), and never pass the score
+    # threshold (K5).  The parameters keep the reference's shapes ([A*K, C, 3, 3]); the padded copies
+    # are rebuilt from them every forward (2 MB).
+    PAD_LOGIT = -80.0
+
+    @property
+    def padded_classes(self) -> int:
+        return (self.num_classes + 7) // 8 * 8
+
+    def _padded_output_params(self):
+        conv, A, K, Kp = self.class_subnet_output, self.num_anchors, self.num_classes, self.padded_classes
+        w = F.pad(conv.weight.reshape(A, K, *conv.weight.shape[1:]), (0, 0, 0, 0, 0, 0, 0, Kp - K))
+        b = F.pad(conv.bias.reshape(A, K), (0, Kp - K), value=self.PAD_LOGIT)
+        return w.reshape(A * Kp, *conv.weight.shape[1:]), b.reshape(A * Kp)
+
+    def forward_levels(self, feature_maps: List[Tensor], pad_classes: bool = False) -> List[Tensor]:
+        """Per-level logits [N, H*W*A, K]; views of the conv outputs when the activations are channels_last.
+        ``pad_classes``: logits come back as [N, H*W*A, padded_classes], columns K.. are dead classes."""
+        if not pad_classes or self.padded_classes == self.num_classes:
+            return [_to_anchor_major(self.class_subnet_output(self.class_subnet(f)), self.num_classes) for f in feature_maps]
+        w, b = self._padded_output_params()
+        return [_to_anchor_major(F.conv2d(self.class_subnet(f), w, b, stride=1, padding=1), self.padded_classes)
+                for f in feature_maps]
 
     def forward(self, feature_maps: List[Tensor]) -> Tensor:
         return torch.cat(self.forward_levels(feature_maps), dim=1)
@@ -127,9 +152,11 @@ class RetinaNetHead(nn.Module):
     def forward(self, xb: List[Tensor]) -> Dict[str, Tensor]:
         return {"cls_preds": self.classification_head(xb), "bbox_preds": self.regression_head(xb)}
 
-    def forward_levels(self, xb: List[Tensor]) -> Dict[str, List[Tensor]]:
-        "Head outputs left per pyramid level (no concatenation); consumed by ``compute_loss_levels``."
-        return {"cls_levels": self.classification_head.forward_levels(xb),
+    def forward_levels(self, xb: List[Tensor], pad_classes: bool = True) -> Dict[str, List[Tensor]]:
+        """Head outputs left per pyramid level (no concatenation); consumed by ``compute_loss_levels`` and
+        ``Retinanet.process_detections_levels``.  With ``pad_classes`` the logits carry dead classes up to a
+        multiple of 8 (see ``RetinaNetClassSubnet``); they change neither losses, gradients nor detections."""
+        return {"cls_levels": self.classification_head.forward_levels(xb, pad_classes),
                 "bbox_levels": self.regression_head.forward_levels(xb)}
 
     def compute_loss_levels(self, targets, outputs: Dict[str, List[Tensor]], anchors) -> Dict[str, Tensor]:

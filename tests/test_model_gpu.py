@@ -190,3 +190,25 @@ def test_transform_module_fused_equals_torch_path():
     cl, _ = t([i.cuda() for i in imgs], None, out_dtype=torch.bfloat16, channels_last=True)
     assert cl.tensors.dtype == torch.bfloat16 and cl.tensors.is_contiguous(memory_format=torch.channels_last)
     torch.testing.assert_close(cl.tensors.float().cpu(), ref.tensors, rtol=1e-2, atol=1e-2)
+
+
+def test_padded_class_head_matches_reference_shaped_head():
+    """forward_levels(pad_classes=True): real columns == the unpadded conv (fp32: 1e-5), dead columns == -80,
+    gradients reach the [A*K, C, 3, 3] parameters with zero contribution from the dead classes."""
+    import pytorch_retinanet_amd as P
+    torch.manual_seed(4)
+    net = P.Retinanet(num_classes=6, backbone_kind="resnet18", pretrained=False, min_size=128, max_size=160).to(DEV)
+    net = net.to(memory_format=torch.channels_last).eval()
+    head = net.retinanet_head.classification_head
+    assert head.padded_classes == 8
+    fm = [torch.randn(2, 256, 16, 20, device=DEV).contiguous(memory_format=torch.channels_last),
+          torch.randn(2, 256, 8, 10, device=DEV).contiguous(memory_format=torch.channels_last)]
+    plain = head.forward_levels(fm)
+    padded = head.forward_levels(fm, pad_classes=True)
+    for p_, q_ in zip(plain, padded):
+        assert q_.shape == (*p_.shape[:2], 8) and q_.is_contiguous()
+        torch.testing.assert_close(q_[..., :6], p_, rtol=1e-5, atol=1e-5)
+        assert torch.equal(q_[..., 6:], torch.full_like(q_[..., 6:], -80.0))
+    g0 = torch.autograd.grad(sum((p_ ** 2).sum() for p_ in plain), head.class_subnet_output.weight)[0]
+    g1 = torch.autograd.grad(sum((q_[..., :6] ** 2).sum() for q_ in padded), head.class_subnet_output.weight)[0]
+    torch.testing.assert_close(g1, g0, rtol=1e-4, atol=1e-4)
