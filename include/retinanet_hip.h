@@ -155,6 +155,19 @@ int rn_decode_clip(const void *deltas, int dtype, int B, int64_t A,
                    const float *anchors, int64_t anchor_bstride, const int32_t *image_hw,
                    const float reg_w[4], float *out, void *stream);
 
+/* ---- conv epilogue: bias (+ ReLU) (+ position mask), channels-last ------------------------------
+ * y = mask[m % HW] ? act(x + bias[c]) : 0 on [M][C] activations (C % 8 == 0), act = ReLU when relu != 0;
+ * replaces the bias add + nn.ReLU pairs of the reference's head towers (retinanet/layers.py:143-171,
+ * :213-241) and their backward (ReLU mask + bias-gradient reduction, one pass).  mask: u8[HW] shared by
+ * all images, NULL = keep everything (used to zero the gaps of a packed level canvas).  Backward:
+ * dx = dy where y > 0 (relu) and mask, else 0; dbias[c] = sum_m dx[m][c] (f32, deterministic).  dx may be
+ * NULL when relu == 0 and mask == NULL (dx == dy).  workspace: rn_bn_workspace_bytes(C). */
+int rn_bias_act_forward(const void *x, const float *bias, const uint8_t *mask, void *y, int dtype,
+                        int64_t M, int C, int64_t HW, int relu, void *stream);
+int rn_bias_act_backward(const void *dy, const void *y, const uint8_t *mask, void *dx, float *dbias,
+                         int dtype, int64_t M, int C, int64_t HW, int relu,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- T1 transform (normalise + resize + pad + batch) -------------------------------------------
  * Replaces torchvision's GeneralizedRCNNTransform as the reference runs it at
  * retinanet/models.py:116 (construction), :262 and :279 (calls): per image (x - mean) / std, bilinear

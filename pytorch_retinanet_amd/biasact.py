@@ -1,0 +1,167 @@
+"""Conv epilogues for the head: ``bias_act`` (bias + ReLU + optional position mask, one HIP launch each
+way) and the packed level canvas that lets the shared head towers run ONE convolution per layer over
+all five pyramid levels (reference: ``retinanet/layers.py:143-171``, ``:213-241`` -- four 3x3 conv +
+ReLU pairs per tower, applied level by level).
+
+Why a canvas: MIOpen runs the 3x3/256-channel tower conv of the R50 config at 657 TFLOP/s on P3 but at
+170 / 60 / 18 TFLOP/s on P5 / P6 / P7 (tiny grids), and every level costs its own bias-add, ReLU and
+weight-gradient accumulation kernels.  Packing the levels into one ``[N, C, Hc, Wc]`` canvas -- P3 on
+top, P4..P7 side by side below it, one zero row/column between neighbours -- makes it one conv per
+layer (fwd+bwd 1.10 ms instead of 1.58 ms per layer, ``tools/head_conv_probe.py``).  A 3x3 conv with
+padding 1 never mixes levels as long as the gaps hold zeros, which the epilogue's mask re-establishes
+after every layer.
+"""
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+from ._lib import RN_BF16, RN_F16, RN_F32, check, lib
+
+_DT = {torch.float32: RN_F32, torch.bfloat16: RN_BF16, torch.float16: RN_F16}
+_WS: Dict[tuple, Tensor] = {}
+
+
+def _workspace(dev: torch.device, stream: int, channels: int):
+    need = lib.rn_bn_workspace_bytes(channels)
+    key = (dev.index, stream)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _WS[key] = torch.empty((max(need, lib.rn_bn_workspace_bytes(1024)),), dtype=torch.uint8, device=dev)
+    return ws.data_ptr(), ws.numel()
+
+
+def _cl(t: Tensor) -> bool:
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def fusable(x: Tensor, bias: Optional[Tensor]) -> bool:
+    return (x.is_cuda and x.dtype in _DT and _cl(x) and x.shape[1] % 8 == 0 and x.numel() > 0 and bias is not None
+            and bias.dtype == torch.float32)
+
+
+class _BiasAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, mask, relu):
+        N, Cc, H, W = x.shape
+        dev = x.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        y = torch.empty_like(x)
+        check(lib.rn_bias_act_forward(x.data_ptr(), bias.data_ptr(), mask.data_ptr() if mask is not None else 0, y.data_ptr(),
+                                      _DT[x.dtype], N * H * W, Cc, H * W, int(relu), stream), "rn_bias_act_forward")
+        ctx.save_for_backward(y if relu else None, mask)
+        ctx.cfg = (bool(relu), N * H * W, Cc, H * W, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, mask = ctx.saved_tensors
+        relu, M, Cc, HW, dt = ctx.cfg
+        dev = dy.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        if dy.dtype != dt or not _cl(dy):
+            dy = dy.to(dt).contiguous(memory_format=torch.channels_last)
+        need_dx = relu or mask is not None
+        dx = torch.empty_like(dy) if need_dx else dy
+        dbias = torch.empty((Cc,), dtype=torch.float32, device=dev)
+        wp, wn = _workspace(dev, stream, Cc)
+        check(lib.rn_bias_act_backward(dy.data_ptr(), y.data_ptr() if y is not None else 0, mask.data_ptr() if mask is not None else 0,
+                                       dx.data_ptr() if need_dx else 0, dbias.data_ptr(), _DT[dt], M, Cc, HW, int(relu), wp, wn,
+                                       stream), "rn_bias_act_backward")
+        return dx, dbias, None, None
+
+
+def bias_act(x: Tensor, bias: Tensor, mask: Optional[Tensor] = None, relu: bool = True) -> Tensor:
+    """``mask * act(x + bias[None, :, None, None])``; ``mask``: u8 ``[H*W]`` (1 = keep) or None."""
+    if fusable(x, bias):
+        return _BiasAct.apply(x, bias, mask, relu)
+    y = x + bias.to(x.dtype)[None, :, None, None]
+    if relu:
+        y = F.relu(y)
+    if mask is not None:
+        y = y * mask.view(1, 1, x.shape[2], x.shape[3]).to(y.dtype)
+    return y
+
+
+# ---------------------------------------------------------------------------------------------------
+class Canvas:
+    """Placement of L feature maps in one canvas: level 0 on top, the others side by side below it,
+    one empty row / column between neighbours."""
+
+    def __init__(self, shapes: Sequence[Tuple[int, int]], device: torch.device):
+        self.shapes = [(int(h), int(w)) for h, w in shapes]
+        h0, w0 = self.shapes[0]
+        self.origin: List[Tuple[int, int]] = [(0, 0)]
+        col, below = 0, 0
+        for h, w in self.shapes[1:]:
+            self.origin.append((h0 + 1, col))
+            col += w + 1
+            below = max(below, h)
+        self.H = h0 + (1 + below if len(self.shapes) > 1 else 0)
+        self.W = max(w0, col - 1)
+        m = torch.zeros((self.H, self.W), dtype=torch.uint8)
+        for (r, c), (h, w) in zip(self.origin, self.shapes):
+            m[r:r + h, c:c + w] = 1
+        self.mask = m.reshape(-1).to(device)
+        self.fill = sum(h * w for h, w in self.shapes) / float(self.H * self.W)
+
+    _cache: Dict[tuple, "Canvas"] = {}
+
+    @classmethod
+    def of(cls, feature_maps: Sequence[Tensor]) -> "Canvas":
+        key = (tuple(tuple(f.shape[-2:]) for f in feature_maps), feature_maps[0].device)
+        c = cls._cache.get(key)
+        if c is None:
+            c = cls._cache[key] = Canvas(key[0], key[1])
+        return c
+
+
+class _Pack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, canvas: Canvas, *feats):
+        f0 = feats[0]
+        out = torch.empty((f0.shape[0], f0.shape[1], canvas.H, canvas.W), dtype=f0.dtype, device=f0.device,
+                          memory_format=torch.channels_last).zero_()
+        for f, (r, c), (h, w) in zip(feats, canvas.origin, canvas.shapes):
+            out[:, :, r:r + h, c:c + w].copy_(f)
+        ctx.canvas = canvas
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        cv = ctx.canvas
+        return (None,) + tuple(g[:, :, r:r + h, c:c + w].contiguous(memory_format=torch.channels_last)
+                               for (r, c), (h, w) in zip(cv.origin, cv.shapes))
+
+
+class _Unpack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, canvas: Canvas, x):
+        ctx.canvas = canvas
+        ctx.meta = (x.shape, x.dtype, x.device)
+        return tuple(x[:, :, r:r + h, c:c + w].contiguous(memory_format=torch.channels_last)
+                     for (r, c), (h, w) in zip(canvas.origin, canvas.shapes))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        cv = ctx.canvas
+        shape, dt, dev = ctx.meta
+        g = torch.empty(shape, dtype=dt, device=dev, memory_format=torch.channels_last).zero_()
+        for gl, (r, c), (h, w) in zip(grads, cv.origin, cv.shapes):
+            if gl is not None:
+                g[:, :, r:r + h, c:c + w].copy_(gl)
+        return None, g
+
+
+def pack_levels(canvas: Canvas, feature_maps: Sequence[Tensor]) -> Tensor:
+    return _Pack.apply(canvas, *feature_maps)
+
+
+def unpack_levels(canvas: Canvas, x: Tensor) -> List[Tensor]:
+    return list(_Unpack.apply(canvas, x))

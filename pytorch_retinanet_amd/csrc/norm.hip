@@ -462,3 +462,183 @@ RN_API int rn_bn_act_backward(const void *dy, const void *y, const void *x, void
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
+
+// ================================================================ bias (+ ReLU) (+ position mask)
+// y = mask[pos] ? act(x + bias[c]) : 0 on channels-last [M = N*H*W][C] activations, and its backward
+// (dx = act'(y) * dy under the mask, dbias[c] = sum dx) -- the conv epilogue of the head towers and of
+// the packed level canvas (layers.py): PyTorch-ROCm runs a biased conv as conv + broadcast add, the
+// ReLU as a third kernel, and their backward as threshold + a separate channel reduction.  The mask
+// (one byte per spatial position, shared by all images) zeroes the gaps between the pyramid levels
+// packed into one canvas so that the next 3x3 conv sees zero padding there.
+namespace {
+
+template <int DT, bool RELU>
+__global__ __launch_bounds__(BN_BLOCK) void bias_act_kernel(const void *__restrict__ x, void *__restrict__ y, const int64_t nvec,
+                                                            const int C8, const int64_t HW, const float *__restrict__ bias,
+                                                            const uint8_t *__restrict__ mask)
+{
+    for (int64_t v = (int64_t)blockIdx.x * BN_BLOCK + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * BN_BLOCK) {
+        const int64_t row = v / C8;
+        const int cg = (int)(v - row * C8);
+        float f[8];
+        vec8<DT>::ld(x, v, f);
+        const rn::f32x4 b0 = ((const rn::f32x4 *)bias)[2 * cg], b1 = ((const rn::f32x4 *)bias)[2 * cg + 1];
+        const float b[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        const bool keep = !mask || mask[row % HW];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float o = f[j] + b[j];
+            if (RELU) o = o > 0.0f ? o : 0.0f;
+            f[j] = keep ? o : 0.0f;
+        }
+        vec8<DT>::st(y, v, f);
+    }
+}
+
+// dx (optional) + per-block partial channel sums of dx; same thread layout as bn_stats_partial_kernel
+template <int DT, bool RELU, bool WRITE_DX>
+__global__ __launch_bounds__(BN_BLOCK) void bias_act_bwd_kernel(const void *__restrict__ dy, const void *__restrict__ y,
+                                                                void *__restrict__ dx, const int64_t M, const int C, const int64_t HW,
+                                                                const uint8_t *__restrict__ mask, float *__restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // [lanes][C]  (only when lanes > 1)
+    const Split sp = split_of(C);
+    const int64_t rows_per_block = (M + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, M);
+    for (int gi = 0; gi < sp.groups_per_thread; ++gi) {
+        const int cg = (sp.lanes > 1) ? (int)(threadIdx.x % sp.C8) : (int)threadIdx.x + gi * BN_BLOCK;
+        const int rl = (sp.lanes > 1) ? (int)(threadIdx.x / sp.C8) : 0;
+        float s[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = 0.0f;
+        if (cg < sp.C8 && rl < sp.lanes) {
+            int64_t r = r0 + rl;
+            for (; r + sp.lanes < r1; r += 2 * sp.lanes) {                // 2 rows x 2 tensors in flight per thread
+                float g[2][8], yy[2][8];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int64_t v = (r + u * sp.lanes) * sp.C8 + cg;
+                    vec8<DT>::ld(dy, v, g[u]);
+                    if (RELU) vec8<DT>::ld(y, v, yy[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int64_t rr = r + u * sp.lanes;
+                    const bool keep = !mask || mask[rr % HW];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float gj = (keep && !(RELU && !(yy[u][j] > 0.0f))) ? g[u][j] : 0.0f;
+                        g[u][j] = gj;
+                        s[j] += gj;
+                    }
+                    if (WRITE_DX) vec8<DT>::st(dx, rr * sp.C8 + cg, g[u]);
+                }
+            }
+            for (; r < r1; r += sp.lanes) {
+                const int64_t v = r * sp.C8 + cg;
+                float g[8], yy[8];
+                vec8<DT>::ld(dy, v, g);
+                if (RELU) vec8<DT>::ld(y, v, yy);
+                const bool keep = !mask || mask[r % HW];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float gj = (keep && !(RELU && !(yy[j] > 0.0f))) ? g[j] : 0.0f;
+                    g[j] = gj;
+                    s[j] += gj;
+                }
+                if (WRITE_DX) vec8<DT>::st(dx, v, g);
+            }
+        }
+        if (sp.lanes > 1) {
+            if (cg < sp.C8 && rl < sp.lanes) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) smem[rl * C + cg * 8 + j] = s[j];
+            }
+            __syncthreads();
+            for (int c = threadIdx.x; c < C; c += BN_BLOCK) {
+                float t = 0.0f;
+                for (int l = 0; l < sp.lanes; ++l) t += smem[l * C + c];
+                partial[(int64_t)blockIdx.x * C + c] = t;
+            }
+            __syncthreads();
+        } else if (cg < sp.C8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) partial[(int64_t)blockIdx.x * C + cg * 8 + j] = s[j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bias_grad_final_kernel(const float *__restrict__ partial, const int nblocks, const int C,
+                                                              float *__restrict__ dbias)
+{
+    __shared__ double sh[FIN_LANES][FIN_CH];
+    const int ch = threadIdx.x % FIN_CH, ln = threadIdx.x / FIN_CH;
+    const int c = blockIdx.x * FIN_CH + ch;
+    double ls = 0.0;
+    if (c < C)
+        for (int b = ln; b < nblocks; b += FIN_LANES) ls += (double)partial[(int64_t)b * C + c];
+    sh[ln][ch] = ls;
+    __syncthreads();
+    if (ln == 0 && c < C) {
+        double s = 0.0;
+        for (int l = 0; l < FIN_LANES; ++l) s += sh[l][ch];
+        dbias[c] = (float)s;
+    }
+}
+
+}  // namespace
+
+RN_API int rn_bias_act_forward(const void *x, const float *bias, const uint8_t *mask, void *y, int dtype, int64_t M, int C,
+                               int64_t HW, int relu, void *stream)
+{
+    if (!x || !bias || !y || M <= 0 || C <= 0 || (mask && HW <= 0)) return RN_EINVAL;
+    if (C % 8) return RN_EUNSUPPORTED;
+    if (dtype != RN_F32 && dtype != RN_BF16 && dtype != RN_F16) return RN_EINVAL;
+    if (!rn::aligned(x, 16) || !rn::aligned(y, 16) || !rn::aligned(bias, 16)) return RN_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nvec = M * (C / 8);
+    const dim3 g(apply_blocks(nvec)), b(BN_BLOCK);
+    const int C8 = C / 8;
+    if (!mask) HW = 1;
+#define RN_BA(DT) if (relu) hipLaunchKernelGGL((bias_act_kernel<DT, true>), g, b, 0, st, x, y, nvec, C8, HW, bias, mask); \
+                  else hipLaunchKernelGGL((bias_act_kernel<DT, false>), g, b, 0, st, x, y, nvec, C8, HW, bias, mask);
+    switch (dtype) {
+        case RN_F32: RN_BA(RN_F32) break;
+        case RN_BF16: RN_BA(RN_BF16) break;
+        default: RN_BA(RN_F16) break;
+    }
+#undef RN_BA
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+RN_API int rn_bias_act_backward(const void *dy, const void *y, const uint8_t *mask, void *dx, float *dbias, int dtype, int64_t M,
+                                int C, int64_t HW, int relu, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!dy || !dbias || M <= 0 || C <= 0 || (mask && HW <= 0)) return RN_EINVAL;
+    if (relu && !y) return RN_EINVAL;
+    if ((relu || mask) && !dx) return RN_EINVAL;               // without them dx == dy and may be omitted
+    if (C % 8) return RN_EUNSUPPORTED;
+    if (dtype != RN_F32 && dtype != RN_BF16 && dtype != RN_F16) return RN_EINVAL;
+    if (!workspace || workspace_bytes < rn_bn_workspace_bytes(C)) return RN_EWORKSPACE;
+    if (!rn::aligned(dy, 16) || (y && !rn::aligned(y, 16)) || (dx && !rn::aligned(dx, 16))) return RN_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = reduce_blocks(M);
+    const size_t lds = reduce_lds(C) / 2;
+    float *partial = (float *)workspace;
+    if (!mask) HW = 1;
+#define RN_BAB(DT)                                                                                                                         \
+    if (relu) hipLaunchKernelGGL((bias_act_bwd_kernel<DT, true, true>), dim3(nb), dim3(BN_BLOCK), lds, st, dy, y, dx, M, C, HW, mask, partial); \
+    else if (dx) hipLaunchKernelGGL((bias_act_bwd_kernel<DT, false, true>), dim3(nb), dim3(BN_BLOCK), lds, st, dy, y, dx, M, C, HW, mask, partial); \
+    else hipLaunchKernelGGL((bias_act_bwd_kernel<DT, false, false>), dim3(nb), dim3(BN_BLOCK), lds, st, dy, y, dx, M, C, HW, mask, partial);
+    switch (dtype) {
+        case RN_F32: RN_BAB(RN_F32) break;
+        case RN_BF16: RN_BAB(RN_BF16) break;
+        default: RN_BAB(RN_F16) break;
+    }
+#undef RN_BAB
+    RN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bias_grad_final_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, st, partial, nb, C, dbias);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}

@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
 
+from . import biasact
 from .losses import RetinaNetLosses
 
 
@@ -56,6 +57,15 @@ def _tower(in_channels: int, out_channels: int) -> nn.Sequential:
         mods += [nn.Conv2d(in_channels if i == 0 else out_channels, out_channels, 3, stride=1, padding=1),
                  nn.ReLU(inplace=True)]
     return nn.Sequential(*mods)
+
+
+def _tower_on_canvas(tower: nn.Sequential, x: Tensor, mask: Tensor) -> Tensor:
+    """The same four conv + ReLU pairs applied to the packed level canvas: conv without bias, then the
+    fused bias + ReLU + gap-mask epilogue (biasact.py)."""
+    for layer in tower:
+        if isinstance(layer, nn.Conv2d):
+            x = biasact.bias_act(F.conv2d(x, layer.weight, None, layer.stride, layer.padding), layer.bias, mask, relu=True)
+    return x
 
 
 def _init_head(*modules: nn.Module) -> None:
@@ -109,11 +119,14 @@ class RetinaNetClassSubnet(nn.Module):
     def forward_levels(self, feature_maps: List[Tensor], pad_classes: bool = False) -> List[Tensor]:
         """Per-level logits [N, H*W*A, K]; views of the conv outputs when the activations are channels_last.
         ``pad_classes``: logits come back as [N, H*W*A, padded_classes], columns K.. are dead classes."""
+        return self.output_levels([self.class_subnet(f) for f in feature_maps], pad_classes)
+
+    def output_levels(self, tower_outputs: List[Tensor], pad_classes: bool = False) -> List[Tensor]:
+        "Final 3x3 conv on every level's tower output -> logits [N, H*W*A, K or padded_classes]."
         if not pad_classes or self.padded_classes == self.num_classes:
-            return [_to_anchor_major(self.class_subnet_output(self.class_subnet(f)), self.num_classes) for f in feature_maps]
+            return [_to_anchor_major(self.class_subnet_output(t), self.num_classes) for t in tower_outputs]
         w, b = self._padded_output_params()
-        return [_to_anchor_major(F.conv2d(self.class_subnet(f), w, b, stride=1, padding=1), self.padded_classes)
-                for f in feature_maps]
+        return [_to_anchor_major(F.conv2d(t, w, b, stride=1, padding=1), self.padded_classes) for t in tower_outputs]
 
     def forward(self, feature_maps: List[Tensor]) -> Tensor:
         return torch.cat(self.forward_levels(feature_maps), dim=1)
@@ -130,7 +143,10 @@ class RetinaNetBoxSubnet(nn.Module):
         _init_head(self.box_subnet, self.box_subnet_output)
 
     def forward_levels(self, feature_maps: List[Tensor]) -> List[Tensor]:
-        return [_to_anchor_major(self.box_subnet_output(self.box_subnet(f)), 4) for f in feature_maps]
+        return self.output_levels([self.box_subnet(f) for f in feature_maps])
+
+    def output_levels(self, tower_outputs: List[Tensor]) -> List[Tensor]:
+        return [_to_anchor_major(self.box_subnet_output(t), 4) for t in tower_outputs]
 
     def forward(self, feature_maps: List[Tensor]) -> Tensor:
         return torch.cat(self.forward_levels(feature_maps), dim=1)
@@ -152,12 +168,21 @@ class RetinaNetHead(nn.Module):
     def forward(self, xb: List[Tensor]) -> Dict[str, Tensor]:
         return {"cls_preds": self.classification_head(xb), "bbox_preds": self.regression_head(xb)}
 
-    def forward_levels(self, xb: List[Tensor], pad_classes: bool = True) -> Dict[str, List[Tensor]]:
+    def forward_levels(self, xb: List[Tensor], pad_classes: bool = True, canvas: bool = True) -> Dict[str, List[Tensor]]:
         """Head outputs left per pyramid level (no concatenation); consumed by ``compute_loss_levels`` and
         ``Retinanet.process_detections_levels``.  With ``pad_classes`` the logits carry dead classes up to a
-        multiple of 8 (see ``RetinaNetClassSubnet``); they change neither losses, gradients nor detections."""
-        return {"cls_levels": self.classification_head.forward_levels(xb, pad_classes),
-                "bbox_levels": self.regression_head.forward_levels(xb)}
+        multiple of 8 (see ``RetinaNetClassSubnet``); they change neither losses, gradients nor detections.
+        With ``canvas`` (CUDA, channels-last) the two towers run on all levels packed into one canvas --
+        one conv per layer instead of five (biasact.py); the final convs run per level on the unpacked
+        tower outputs so the loss / detection kernels keep reading dense per-level tensors."""
+        ch, rh = self.classification_head, self.regression_head
+        if canvas and len(xb) > 1 and all(biasact.fusable(f, ch.class_subnet[0].bias) for f in xb):
+            cv = biasact.Canvas.of(xb)
+            packed = biasact.pack_levels(cv, xb)
+            cls_t = biasact.unpack_levels(cv, _tower_on_canvas(ch.class_subnet, packed, cv.mask))
+            box_t = biasact.unpack_levels(cv, _tower_on_canvas(rh.box_subnet, packed, cv.mask))
+            return {"cls_levels": ch.output_levels(cls_t, pad_classes), "bbox_levels": rh.output_levels(box_t)}
+        return {"cls_levels": ch.forward_levels(xb, pad_classes), "bbox_levels": rh.forward_levels(xb)}
 
     def compute_loss_levels(self, targets, outputs: Dict[str, List[Tensor]], anchors) -> Dict[str, Tensor]:
         return self.losses.forward_levels(targets, outputs["cls_levels"], outputs["bbox_levels"], anchors)

@@ -212,3 +212,67 @@ def test_padded_class_head_matches_reference_shaped_head():
     g0 = torch.autograd.grad(sum((p_ ** 2).sum() for p_ in plain), head.class_subnet_output.weight)[0]
     g1 = torch.autograd.grad(sum((q_[..., :6] ** 2).sum() for q_ in padded), head.class_subnet_output.weight)[0]
     torch.testing.assert_close(g1, g0, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("relu,use_mask", [(True, True), (True, False), (False, False), (False, True)])
+def test_bias_act_kernel_vs_torch(dtype, relu, use_mask):
+    from pytorch_retinanet_amd import biasact
+    torch.manual_seed(0)
+    N, Cc, H, W = 3, 64, 13, 21
+    x = torch.randn(N, Cc, H, W, device=DEV).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bias = torch.randn(Cc, device=DEV, requires_grad=True)
+    mask = (torch.rand(H * W, device=DEV) > 0.3).to(torch.uint8) if use_mask else None
+    assert biasact.fusable(x, bias)
+    y = biasact.bias_act(x, bias, mask, relu)
+    g = torch.randn_like(y)
+    y.backward(g)
+    xr = x.detach().float().requires_grad_(True)
+    br = bias.detach().clone().requires_grad_(True)
+    yr = xr + br[None, :, None, None]
+    if relu:
+        yr = torch.relu(yr)
+    if mask is not None:
+        yr = yr * mask.view(1, 1, H, W).float()
+    yr.backward(g.float())
+    tol = dict(rtol=1e-6, atol=1e-6) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(y.float(), yr, **tol)
+    # the ReLU decision is taken on the rounded y; compare dx only where the reference's y is not within rounding of 0
+    sure = (yr.abs() > 1e-2) | (yr == 0) if dtype != torch.float32 else torch.ones_like(yr, dtype=torch.bool)
+    torch.testing.assert_close(x.grad.float()[sure], xr.grad[sure], **tol)
+    torch.testing.assert_close(bias.grad, br.grad, rtol=2e-2 if dtype != torch.float32 else 1e-5, atol=5e-2 if dtype != torch.float32 else 1e-5)
+
+
+def test_head_on_canvas_equals_per_level_head():
+    """forward_levels(canvas=True) == forward_levels(canvas=False): same logits / deltas (fp32: 1e-4) and the same
+    parameter gradients -- the packed canvas must not leak between levels."""
+    import pytorch_retinanet_amd as P
+    from pytorch_retinanet_amd import biasact
+    torch.manual_seed(5)
+    net = P.Retinanet(num_classes=6, backbone_kind="resnet18", pretrained=False, min_size=128, max_size=160).to(DEV)
+    net = net.to(memory_format=torch.channels_last).eval()
+    head = net.retinanet_head
+    for p in head.parameters():                     # the reference's init (std 0.01) makes everything tiny: use O(1) weights
+        if p.dim() == 4:
+            torch.nn.init.normal_(p, std=0.03)
+    shapes = [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)]
+    fm = [torch.randn(2, 256, h, w, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True) for h, w in shapes]
+    cv = biasact.Canvas.of(fm)
+    assert cv.H == 16 + 1 + 8 and cv.W == 10 + 1 + 5 + 1 + 3 + 1 + 2 and int(cv.mask.sum()) == sum(h * w for h, w in shapes)
+    outs = {}
+    for canvas in (False, True):
+        head.zero_grad()
+        for f in fm:
+            f.grad = None
+        o = head.forward_levels(fm, pad_classes=True, canvas=canvas)
+        loss = sum((c.float() ** 2).sum() for c in o["cls_levels"]) * 1e-4 + sum((b.float() ** 2).sum() for b in o["bbox_levels"])
+        loss.backward()
+        outs[canvas] = (o, [f.grad.clone() for f in fm], {n: p.grad.clone() for n, p in head.named_parameters() if p.grad is not None})
+    for key in ("cls_levels", "bbox_levels"):
+        for a, b in zip(outs[False][0][key], outs[True][0][key]):
+            assert a.shape == b.shape
+            torch.testing.assert_close(b, a, rtol=1e-4, atol=1e-4)
+    for a, b in zip(outs[False][1], outs[True][1]):
+        torch.testing.assert_close(b, a, rtol=1e-3, atol=1e-4)
+    for n, a in outs[False][2].items():
+        torch.testing.assert_close(outs[True][2][n], a, rtol=1e-3, atol=1e-3)
