@@ -11,6 +11,8 @@ from . import _lib  # noqa: F401  (raises ImportError when the HIP library is mi
 from . import ops  # noqa: F401
 from .anchors import AnchorGenerator
 from .box_utils import activ_2_bbox, bbox_2_activ, matcher
+from .coco_eval import CocoEvaluator
+from .datasets import CSVDetectionDataset
 from .losses import RetinaNetLosses
 from .model import RetinaNetModel, SimpleTrainer, SyntheticDetectionDataset
 from .models import Retinanet
@@ -19,4 +21,4 @@ from .utils import collate_fn, load_hparams, load_obj
 
 __all__ = ["Retinanet", "AnchorGenerator", "RetinaNetLosses", "RetinaNetModel", "SimpleTrainer",
            "SyntheticDetectionDataset", "BucketedGradAllReduce", "matcher", "bbox_2_activ", "activ_2_bbox",
-           "collate_fn", "load_obj", "load_hparams", "ops"]
+           "collate_fn", "load_obj", "load_hparams", "ops", "CocoEvaluator", "CSVDetectionDataset"]

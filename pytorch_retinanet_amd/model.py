@@ -7,10 +7,10 @@ local base provides the two things the hooks rely on (``save_hyperparameters`` a
 ``nn.Module``), and ``SimpleTrainer`` below drives the hooks (one process per GPU, gradients
 exchanged by ``parallel.BucketedGradAllReduce`` over RCCL).
 
-Dataset plumbing (COCO / Pascal / CSV readers, albumentations, pycocotools evaluator --
-reference ``utils/``) is outside this framework's scope (out-of-scope rows):
-``prepare_data`` accepts ``dataset.kind: synthetic`` and raises a clear error for the
-reference's disk formats.
+Data: ``dataset.kind: synthetic`` or ``csv`` (the reference's csv format, ``datasets.py``); the COCO-json /
+Pascal-xml readers and albumentations pipelines of the reference's ``utils/`` are outside this framework's
+scope (``prepare_data`` says so).  ``test_step`` / ``test_epoch_end`` feed the pycocotools-free
+``coco_eval.CocoEvaluator`` (reference ``utils/coco/coco_eval.py``).
 """
 import argparse
 import logging
@@ -85,11 +85,17 @@ class RetinaNetModel(_Base):
             self.trn_ds = SyntheticDetectionDataset(**kw)
             self.val_ds = SyntheticDetectionDataset(**{**kw, "seed": kw.get("seed", 0) + 1})
             self.test_ds = SyntheticDetectionDataset(**{**kw, "seed": kw.get("seed", 0) + 2})
-        elif d.kind in ("coco", "pascal", "csv"):
+        elif d.kind == "csv":             # README.md:103-125: trn_paths / val_paths (optional) / test_paths are csv files
+            from .datasets import CSVDetectionDataset
+            self.trn_ds = CSVDetectionDataset(d.trn_paths)
+            self.val_ds = CSVDetectionDataset(d.val_paths) if d.get("val_paths") else None
+            self.test_ds = CSVDetectionDataset(d.test_paths) if d.get("test_paths") else None
+        elif d.kind in ("coco", "pascal"):
             raise NotImplementedError(
-                f"dataset.kind={d.kind!r}: the reference's disk readers (utils/coco, utils/pascal; pycocotools, "
-                "albumentations, cv2) are outside this framework's scope. Assign `trn_ds` / `val_ds` / `test_ds` "
-                "with your own Dataset yielding (image, target, image_idx), or use kind: synthetic.")
+                f"dataset.kind={d.kind!r}: the reference's COCO-json / Pascal-xml readers (utils/coco, utils/pascal; "
+                "pycocotools, albumentations, cv2) are outside this framework's scope. Convert to the csv format "
+                "(kind: csv), assign `trn_ds` / `val_ds` / `test_ds` with your own Dataset yielding "
+                "(image, target, image_idx), or use kind: synthetic.")
         else:
             raise ValueError("DATASET_KIND not supported")
 
@@ -103,7 +109,10 @@ class RetinaNetModel(_Base):
         return None if self.val_ds is None else self._loader(self.val_ds, self.conf.dataloader.valid_bs)
 
     def test_dataloader(self, *args, **kwargs):
-        return self._loader(self.test_ds, self.conf.dataloader.test_bs)
+        from .coco_eval import CocoEvaluator, gt_from_dataset
+        loader = self._loader(self.test_ds, self.conf.dataloader.test_bs)
+        self.test_evaluator = CocoEvaluator(gt_from_dataset(loader.dataset), ["bbox"])       # reference model.py:105-110
+        return loader
 
     # -- optimisation ----------------------------------------------------------------------------
     def configure_optimizers(self, *args, **kwargs):
