@@ -164,6 +164,10 @@ def main():
         K, s = 90, 2
         kms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items() if v}
         nbytes = k3_bytes(args.batch, A, K, args.gt, s)
+        # the fast path pads the class dimension to a multiple of 8 (layers.RetinaNetClassSubnet): the launch streams
+        # K_run = 96 columns; `achieved` stays on the K = 90 algorithmic figure, the streamed figure is beside it
+        K_run = net.retinanet_head.classification_head.padded_classes
+        streamed = k3_bytes(args.batch, A, K_run, args.gt, s)
         k3_ms = kms.get("loss_fwd_bwd")
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_k3_pmc.json")
@@ -176,6 +180,8 @@ def main():
                 "achieved": round(nbytes / (k3_ms * 1e-3) / 1e9, 1) if k3_ms else None, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(nbytes / (k3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k3_ms else None,
                 "traffic": traffic, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": round(k3_ms, 4) if k3_ms else None,
+                "streamed_bytes_per_launch": streamed, "classes_streamed": K_run,
+                "frac_of_streamed_bytes": round(streamed / (k3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k3_ms else None,
                 "other_kernels_ms": {k: round(v, 4) for k, v in kms.items() if k != "loss_fwd_bwd"}}
         line = {
             "metric": "images/sec RetinaNet-R50-FPN train step @800x1333",
