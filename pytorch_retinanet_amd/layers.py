@@ -180,8 +180,11 @@ class RetinaNetHead(nn.Module):
             cv = biasact.Canvas.of(xb)
             packed = biasact.pack_levels(cv, xb)
             cls_t = biasact.unpack_levels(cv, _tower_on_canvas(ch.class_subnet, packed, cv.mask))
-            box_t = biasact.unpack_levels(cv, _tower_on_canvas(rh.box_subnet, packed, cv.mask))
-            return {"cls_levels": ch.output_levels(cls_t, pad_classes), "bbox_levels": rh.output_levels(box_t)}
+            # the 36-channel box conv is tiny per level (2 TFLOP/s on P7): run it on the canvas too and unpack its
+            # small output instead of the 256-channel tower output
+            box_c = rh.box_subnet_output(_tower_on_canvas(rh.box_subnet, packed, cv.mask))
+            box_levels = [_to_anchor_major(t, 4) for t in biasact.unpack_levels(cv, box_c)]
+            return {"cls_levels": ch.output_levels(cls_t, pad_classes), "bbox_levels": box_levels}
         return {"cls_levels": ch.forward_levels(xb, pad_classes), "bbox_levels": rh.forward_levels(xb)}
 
     def compute_loss_levels(self, targets, outputs: Dict[str, List[Tensor]], anchors) -> Dict[str, Tensor]:
