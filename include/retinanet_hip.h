@@ -134,7 +134,9 @@ int rn_scale_inplace(void *data, int dtype, int64_t n, const float *scale, void 
  * statistics, running stats updated with `momentum` (unbiased variance), *num_batches_tracked += 1
  * (nullable); training == 0: running statistics.  save_mean / save_invstd / coef ([2][C] forward,
  * [3][C] backward scratch) are caller-owned; workspace: rn_bn_workspace_bytes(C).
- * Backward returns dx, dresidual (nullable; = gradient after the ReLU mask), dgamma, dbeta. */
+ * Backward returns dx, dresidual (nullable; = gradient after the ReLU mask), dgamma, dbeta.  With relu != 0
+ * and y == NULL the ReLU mask is recomputed from x and fwd_coef (= the coef array the forward call filled),
+ * which saves one activation read per backward kernel; only valid when the forward had no residual. */
 size_t rn_bn_workspace_bytes(int C);
 int rn_bn_act_forward(const void *x, const void *residual, void *y, int dtype, int64_t M, int C,
                       const float *gamma, const float *beta, float *running_mean, float *running_var,
@@ -143,8 +145,8 @@ int rn_bn_act_forward(const void *x, const void *residual, void *y, int dtype, i
                       size_t workspace_bytes, void *stream);
 int rn_bn_act_backward(const void *dy, const void *y, const void *x, void *dx, void *dresidual, int dtype,
                        int64_t M, int C, const float *gamma, const float *save_mean, const float *save_invstd,
-                       int training, int relu, float *dgamma, float *dbeta, float *coef, void *workspace,
-                       size_t workspace_bytes, void *stream);
+                       const float *fwd_coef, int training, int relu, float *dgamma, float *dbeta, float *coef,
+                       void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- K4 decode_clip ---------------------------------------------------------
  * Replaces activ_2_bbox, retinanet/box_utils.py:37-48 (including its use of

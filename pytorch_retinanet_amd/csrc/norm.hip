@@ -200,12 +200,22 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_apply_kernel(const void *__restri
     }
 }
 
+// ReLU mask of the forward output without reading it: y = round_DT(max(fma(x, a, b), 0)) > 0  <=>  fma(x, a, b)
+// is above the largest value that rounds to zero in DT (same fma, same coefficients as bn_apply_kernel).
+// Only for layers without a residual input (the residual is not available in backward).
+template <int DT> __device__ __forceinline__ float relu_alive_threshold();
+template <> __device__ __forceinline__ float relu_alive_threshold<RN_F32>() { return 0.0f; }
+template <> __device__ __forceinline__ float relu_alive_threshold<RN_BF16>() { return __uint_as_float(0x00004000u); }   // 2^-134: half the smallest bf16 subnormal (ties to even -> 0)
+template <> __device__ __forceinline__ float relu_alive_threshold<RN_F16>() { return __uint_as_float(0x33000000u); }    // 2^-25: half the smallest f16 subnormal
+
 // ---------------------------------------------------------------- backward sums
 // g = dy * (y > 0) (RELU) ; partial[block][0][c] = sum g, partial[block][1][c] = sum g * xhat
-template <int DT, bool RELU>
+// RELU: 0 = none, 1 = mask from y, 2 = mask recomputed from x (y is not read)
+template <int DT, int RELU>
 __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_partial_kernel(const void *__restrict__ dy, const void *__restrict__ y,
                                                                   const void *__restrict__ x, const int64_t M, const int C,
                                                                   const float *__restrict__ save_mean, const float *__restrict__ save_invstd,
+                                                                  const float *__restrict__ fwd_a, const float *__restrict__ fwd_b,
                                                                   float *__restrict__ partial)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -219,9 +229,11 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_partial_kernel(const void *__
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
         if (cg < sp.C8 && rl < sp.lanes) {
-            float mu[8], is[8];
+            float mu[8], is[8], fa[8], fb[8];
             vec8<RN_F32>::ld(save_mean, cg, mu);
             vec8<RN_F32>::ld(save_invstd, cg, is);
+            if (RELU == 2) { vec8<RN_F32>::ld(fwd_a, cg, fa); vec8<RN_F32>::ld(fwd_b, cg, fb); }
+            const float alive = relu_alive_threshold<DT>();
             int64_t r = r0 + rl;
             for (; r + sp.lanes < r1; r += 2 * sp.lanes) {              // 2 rows x 3 tensors = 6 loads in flight per thread
                 float g[2][8], yy[2][8], xx[2][8];
@@ -230,13 +242,14 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_partial_kernel(const void *__
                     const int64_t v = (r + u * sp.lanes) * sp.C8 + cg;
                     vec8<DT>::ld(dy, v, g[u]);
                     vec8<DT>::ld(x, v, xx[u]);
-                    if (RELU) vec8<DT>::ld(y, v, yy[u]);
+                    if (RELU == 1) vec8<DT>::ld(y, v, yy[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float gj = (RELU && !(yy[u][j] > 0.0f)) ? 0.0f : g[u][j];
+                        const bool dead = RELU == 1 ? !(yy[u][j] > 0.0f) : (RELU == 2 ? !(fmaf(xx[u][j], fa[j], fb[j]) > alive) : false);
+                        const float gj = dead ? 0.0f : g[u][j];
                         s[j] += gj;
                         q[j] = fmaf(gj, (xx[u][j] - mu[j]) * is[j], q[j]);
                     }
@@ -246,10 +259,11 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_partial_kernel(const void *__
                 float g[8], yy[8], xx[8];
                 vec8<DT>::ld(dy, v, g);
                 vec8<DT>::ld(x, v, xx);
-                if (RELU) vec8<DT>::ld(y, v, yy);
+                if (RELU == 1) vec8<DT>::ld(y, v, yy);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float gj = (RELU && !(yy[j] > 0.0f)) ? 0.0f : g[j];
+                    const bool dead = RELU == 1 ? !(yy[j] > 0.0f) : (RELU == 2 ? !(fmaf(xx[j], fa[j], fb[j]) > alive) : false);
+                    const float gj = dead ? 0.0f : g[j];
                     s[j] += gj;
                     q[j] = fmaf(gj, (xx[j] - mu[j]) * is[j], q[j]);
                 }
@@ -302,31 +316,36 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float *__restri
     }
 }
 
-// dx = a*g + k0 + k1*x ; dres = g
-template <int DT, bool RELU, bool RES>
+// dx = a*g + k0 + k1*x ; dres = g      (RELU as in bn_bwd_partial_kernel)
+template <int DT, int RELU, bool RES>
 __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(const void *__restrict__ dy, const void *__restrict__ y, const void *__restrict__ x,
                                                                 void *__restrict__ dx, void *__restrict__ dres, const int64_t nvec, const int C8,
                                                                 const float *__restrict__ coef_a, const float *__restrict__ coef_k0,
-                                                                const float *__restrict__ coef_k1)
+                                                                const float *__restrict__ coef_k1, const float *__restrict__ fwd_a,
+                                                                const float *__restrict__ fwd_b)
 {
     const bool fixed = (BN_BLOCK % C8) == 0;
-    float a[8], k0[8], k1[8];
+    float a[8], k0[8], k1[8], fa[8], fb[8];
+    const float alive = relu_alive_threshold<DT>();
     if (fixed) {
         const int cg = threadIdx.x % C8;
         vec8<RN_F32>::ld(coef_a, cg, a); vec8<RN_F32>::ld(coef_k0, cg, k0); vec8<RN_F32>::ld(coef_k1, cg, k1);
+        if (RELU == 2) { vec8<RN_F32>::ld(fwd_a, cg, fa); vec8<RN_F32>::ld(fwd_b, cg, fb); }
     }
     for (int64_t v = (int64_t)blockIdx.x * BN_BLOCK + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * BN_BLOCK) {
         float g[8], yy[8], xx[8];
         vec8<DT>::ld(dy, v, g);
         vec8<DT>::ld(x, v, xx);
-        if (RELU) vec8<DT>::ld(y, v, yy);
+        if (RELU == 1) vec8<DT>::ld(y, v, yy);
         if (!fixed) {
             const int cg = (int)(v % C8);
             vec8<RN_F32>::ld(coef_a, cg, a); vec8<RN_F32>::ld(coef_k0, cg, k0); vec8<RN_F32>::ld(coef_k1, cg, k1);
+            if (RELU == 2) { vec8<RN_F32>::ld(fwd_a, cg, fa); vec8<RN_F32>::ld(fwd_b, cg, fb); }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            if (RELU && !(yy[j] > 0.0f)) g[j] = 0.0f;
+            if (RELU == 1 && !(yy[j] > 0.0f)) g[j] = 0.0f;
+            if (RELU == 2 && !(fmaf(xx[j], fa[j], fb[j]) > alive)) g[j] = 0.0f;
             xx[j] = fmaf(a[j], g[j], fmaf(k1[j], xx[j], k0[j]));
         }
         vec8<DT>::st(dx, v, xx);
@@ -414,12 +433,17 @@ RN_API int rn_bn_act_forward(const void *x, const void *residual, void *y, int d
 }
 
 RN_API int rn_bn_act_backward(const void *dy, const void *y, const void *x, void *dx, void *dresidual, int dtype, int64_t M,
-                              int C, const float *gamma, const float *save_mean, const float *save_invstd, int training,
+                              int C, const float *gamma, const float *save_mean, const float *save_invstd,
+                              const float *fwd_coef /*[2][C] of the forward call, nullable*/, int training,
                               int relu, float *dgamma, float *dbeta, float *coef /*[3][C]*/, void *workspace,
                               size_t workspace_bytes, void *stream)
 {
     if (!dy || !x || !dx || !save_mean || !save_invstd || !coef || M <= 0 || C <= 0) return RN_EINVAL;
-    if (relu && !y) return RN_EINVAL;
+    // ReLU mask: from y when given; without y it is recomputed from x and the forward coefficients, which is
+    // only possible when the forward had no residual input
+    const int rmode = !relu ? 0 : (y ? 1 : 2);
+    if (rmode == 2 && (!fwd_coef || dresidual)) return RN_EINVAL;
+    const float *fa = fwd_coef, *fb = fwd_coef ? fwd_coef + C : nullptr;
     if (C % 8) return RN_EUNSUPPORTED;
     if (dtype != RN_F32 && dtype != RN_BF16 && dtype != RN_F16) return RN_EINVAL;
     if (!workspace || workspace_bytes < rn_bn_workspace_bytes(C)) return RN_EWORKSPACE;
@@ -433,8 +457,9 @@ RN_API int rn_bn_act_backward(const void *dy, const void *y, const void *x, void
     float *partial = (float *)workspace;
     float *ca = coef, *k0 = coef + C, *k1 = coef + 2 * C;
 #define RN_BN_BWD_PART(DT)                                                                                                             \
-    if (relu) hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, true>), dim3(nb), dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, partial); \
-    else hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, false>), dim3(nb), dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, partial);
+    if (rmode == 1) hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 1>), dim3(nb), dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial); \
+    else if (rmode == 2) hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 2>), dim3(nb), dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial); \
+    else hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 0>), dim3(nb), dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial);
     switch (dtype) {
         case RN_F32: RN_BN_BWD_PART(RN_F32) break;
         case RN_BF16: RN_BN_BWD_PART(RN_BF16) break;
@@ -449,10 +474,11 @@ RN_API int rn_bn_act_backward(const void *dy, const void *y, const void *x, void
     const dim3 g(apply_blocks(nvec)), b(BN_BLOCK);
     const int C8 = C / 8;
 #define RN_BN_BWD_APPLY(DT)                                                                                                                  \
-    if (relu) { if (dresidual) hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, true, true>), g, b, 0, st, dy, y, x, dx, dresidual, nvec, C8, ca, k0, k1);   \
-                else hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, true, false>), g, b, 0, st, dy, y, x, dx, dresidual, nvec, C8, ca, k0, k1); }         \
-    else      { if (dresidual) hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, false, true>), g, b, 0, st, dy, y, x, dx, dresidual, nvec, C8, ca, k0, k1);  \
-                else hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, false, false>), g, b, 0, st, dy, y, x, dx, dresidual, nvec, C8, ca, k0, k1); }
+    if (rmode == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, 2, false>), g, b, 0, st, dy, y, x, dx, dresidual, nvec, C8, ca, k0, k1, fa, fb);        \
+    else if (rmode == 1) { if (dresidual) hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, 1, true>), g, b, 0, st, dy, y, x, dx, dresidual, nvec, C8, ca, k0, k1, fa, fb);   \
+                else hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, 1, false>), g, b, 0, st, dy, y, x, dx, dresidual, nvec, C8, ca, k0, k1, fa, fb); }         \
+    else      { if (dresidual) hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, 0, true>), g, b, 0, st, dy, y, x, dx, dresidual, nvec, C8, ca, k0, k1, fa, fb);  \
+                else hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, 0, false>), g, b, 0, st, dy, y, x, dx, dresidual, nvec, C8, ca, k0, k1, fa, fb); }
     switch (dtype) {
         case RN_F32: RN_BN_BWD_APPLY(RN_F32) break;
         case RN_BF16: RN_BN_BWD_APPLY(RN_BF16) break;

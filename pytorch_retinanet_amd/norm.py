@@ -60,7 +60,8 @@ class _BNAct(torch.autograd.Function):
                    weight.data_ptr(), bias.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
                    num_batches_tracked.data_ptr() if num_batches_tracked is not None else 0, int(training), momentum, eps,
                    int(relu), sp, sp + 4 * Cc, sp + 8 * Cc, wp, wn, stream), "rn_bn_act_forward")
-        ctx.save_for_backward(x, y if relu else None, weight, stats)
+        # y is only needed for the ReLU mask when a residual was added; otherwise backward recomputes the mask from x
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, weight, stats)
         ctx.cfg = (bool(training), bool(relu), residual is not None, M, Cc)
         return y
 
@@ -81,7 +82,7 @@ class _BNAct(torch.autograd.Function):
         wp, wn = _workspace(dev, stream, Cc)
         check(_bwd(dy.data_ptr(), y.data_ptr() if y is not None else 0, x.data_ptr(), dx.data_ptr(),
                    dres.data_ptr() if dres is not None else 0, _DT[x.dtype], M, Cc, weight.data_ptr(), sp, sp + 4 * Cc,
-                   int(training), int(relu), gp, gp + 4 * Cc, gp + 8 * Cc, wp, wn, stream), "rn_bn_act_backward")
+                   sp + 8 * Cc, int(training), int(relu), gp, gp + 4 * Cc, gp + 8 * Cc, wp, wn, stream), "rn_bn_act_backward")
         return dx, dres, grads[:Cc], grads[Cc:2 * Cc], None, None, None, None, None, None, None
 
 
