@@ -7,8 +7,10 @@ replacement for that implicit path, not a translation of it:
   * gradients live in a few large flat buckets (default 32 MiB: xGMI is 7
     point-to-point links per GPU, so fewer, larger collectives amortise the per-call
     latency and let RCCL stripe a bucket across all links);
-  * ``param.grad`` of every parameter is a VIEW into its bucket, so there is no
-    flatten / unflatten copy on either side of the collective;
+  * after the exchange ``param.grad`` of every parameter is a VIEW into its bucket (no unflatten copy);
+    on the way in, the freshly produced gradients of a whole bucket are gathered with ONE multi-tensor
+    copy when its last gradient arrives (``zero_grad`` drops the gradients instead of zeroing 150 MB,
+    so autograd assigns instead of accumulating -- no per-parameter ``add_`` kernels, no memsets);
   * buckets are filled in reverse-forward order (head -> FPN -> layer4 ... conv1)
     and a bucket's all-reduce is issued from the autograd hook of its last
     gradient, on the process group's communication stream, so it overlaps the
@@ -66,7 +68,10 @@ class BucketedGradAllReduce:
         b = _Bucket(flat, params)
         off = 0
         for p in params:
-            p.grad = flat[off: off + p.numel()].view_as(p)
+            # same strides as the parameter (channels_last conv weights stay channels_last): autograd's gradient
+            # layout contract, and the optimizer's multi-tensor kernels stay on their fast path
+            dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+            p.grad = torch.as_strided(flat, p.size(), p.stride(), off) if dense else flat[off: off + p.numel()].view_as(p)
             off += p.numel()
             self._owner[p] = (b, p.grad)
             p.register_post_accumulate_grad_hook(self._hook)
@@ -74,17 +79,25 @@ class BucketedGradAllReduce:
 
     # -- called by autograd once per parameter per backward --------------------------------
     def _hook(self, p: torch.Tensor) -> None:
-        b, view = self._owner[p]
-        if p.grad is not view:
-            # someone replaced .grad (e.g. zero_grad(set_to_none=True)): fold it back into the bucket
-            if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
-                view.copy_(p.grad)
-            p.grad = view
+        b = self._owner[p][0]
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)
 
     def _launch(self, b: _Bucket) -> None:
+        # gather the bucket: gradients autograd assigned as fresh tensors (zero_grad() / set_to_none) are copied
+        # into their views in one multi-tensor launch; gradients accumulated in place into the views are already there
+        views, grads = [], []
+        for p in b.params:
+            view = self._owner[p][1]
+            if p.grad is None:
+                view.zero_()                   # parameter without a gradient this step
+            elif p.grad.data_ptr() != view.data_ptr():
+                views.append(view)
+                grads.append(p.grad)
+            p.grad = view
+        if views:
+            torch._foreach_copy_(views, grads)
         b.launched = True
         if self.world == 1:
             return
@@ -107,11 +120,11 @@ class BucketedGradAllReduce:
             b.pending, b.launched = len(b.params), False
 
     def zero_grad(self) -> None:
-        "Zero the buckets in place (one memset each); keeps ``param.grad`` pointing into them."
+        """Drop the gradients (no memset): the next backward assigns fresh tensors, which ``_launch`` gathers
+        into the buckets.  ``module.zero_grad(set_to_none=False)`` -- zeroing the views in place -- works too."""
         for b in self.buckets:
-            b.flat.zero_()
             for p in b.params:
-                p.grad = self._owner[p][1]
+                p.grad = None
 
     def sync_parameters(self, src: int = 0) -> None:
         "Broadcast parameters and buffers from `src` so every rank starts from the same model."

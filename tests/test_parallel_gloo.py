@@ -83,5 +83,14 @@ def test_bucket_layout_single_process():
     model(torch.randn(2, 3, 6, 6)).sum().backward()
     ddp.finish()                           # world size 1: no collective, state resets
     assert all(b.pending == len(b.params) for b in ddp.buckets)
-    ddp.zero_grad()
-    assert all(not b.flat.any() for b in ddp.buckets)
+    for p in params:                       # after the exchange the gradients are views into the buckets again
+        assert any(b.flat.data_ptr() <= p.grad.data_ptr() < b.flat.data_ptr() + b.flat.numel() * 4 for b in ddp.buckets)
+    want = [p.grad.clone() for p in params]
+    ddp.zero_grad()                        # drops the gradients (no memset); the next backward assigns fresh ones
+    assert all(p.grad is None for p in params)
+    model(torch.randn(2, 3, 6, 6)).sum().backward()
+    ddp.finish()                           # ... which are gathered into the bucket views, not accumulated onto old values
+    model2_grads = [p.grad.clone() for p in params]
+    assert all(g.shape == w.shape for g, w in zip(model2_grads, want))
+    for p in params:
+        assert any(b.flat.data_ptr() <= p.grad.data_ptr() < b.flat.data_ptr() + b.flat.numel() * 4 for b in ddp.buckets)
