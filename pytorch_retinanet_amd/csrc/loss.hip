@@ -488,7 +488,6 @@ int launch_stream(StreamT stream_k, LossArgs &a, int vec, hipStream_t st, int *n
     int res = 0;
     int rc = resident_blocks(stream_k, &res);
     if (rc != RN_OK) return rc;
-    if (const char *e = getenv("RN_K3_BLOCKS")) { int v = atoi(e); if (v > 0 && v < res) res = v; }
     // even split of the vectors over the resident waves, in whole wave-iterations (64 vectors = 1 KiB)
     (void)vec;
     const int64_t nvec = a.total_vec;
@@ -509,16 +508,9 @@ template <int DT>
 int launch_loss(LossArgs &a, bool gamma2, bool wg, hipStream_t st, int *ns)
 {
     constexpr int VEC = rn::dt<DT>::VEC;
-    int pf = 2, nt = 1;
-    if (const char *e = getenv("RN_K3_PF")) pf = atoi(e);
-    if (const char *e = getenv("RN_K3_NT")) nt = atoi(e);
+    // PF = 2 groups of loads in flight, non-temporal loads: the best of the (2|4|8) x (nt|plain) sweep on MI355X
     if (gamma2) {
-        if (wg) {
-#define RN_K3_CASE(P, N) if (pf == P && nt == N) return launch_stream(loss_stream_kernel<DT, true, true, P, N>, a, VEC, st, ns);
-            RN_K3_CASE(2, 0) RN_K3_CASE(4, 0) RN_K3_CASE(4, 1) RN_K3_CASE(8, 1)
-#undef RN_K3_CASE
-            return launch_stream(loss_stream_kernel<DT, true, true, 2, 1>, a, VEC, st, ns);
-        }
+        if (wg) return launch_stream(loss_stream_kernel<DT, true, true, 2, 1>, a, VEC, st, ns);
         return launch_stream(loss_stream_kernel<DT, true, false, 2, 1>, a, VEC, st, ns);
     }
     if (wg) return launch_stream(loss_stream_kernel<DT, false, true, 2, 1>, a, VEC, st, ns);

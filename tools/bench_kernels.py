@@ -42,8 +42,9 @@ def timeit(fn, reps, warm=5):
 
 
 def anchors_for(h, w):
-    import oracle
-    cells = [torch.from_numpy(oracle.cell_anchors(s, synth.ANCHOR_RATIOS)).to(DEV) for s in synth.ANCHOR_SIZES]
+    from pytorch_retinanet_amd.anchors import AnchorGenerator
+    ag = AnchorGenerator().to(DEV)
+    cells = list(ag.cell_anchors)
     return ops.anchors_emit(synth.levels_for(h, w), cells, 0.0)
 
 
