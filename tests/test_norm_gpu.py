@@ -16,7 +16,8 @@ def _ref(bn, x, relu, res):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
-@pytest.mark.parametrize("shape", [(2, 64, 17, 23), (3, 256, 9, 11), (2, 2048, 4, 5), (1, 8, 3, 3)])
+@pytest.mark.parametrize("shape", [(2, 64, 17, 23), (3, 256, 9, 11), (2, 2048, 4, 5), (1, 8, 3, 3), (2, 4096, 3, 4), (2, 2056, 2, 3),
+                                   (5, 24, 31, 29)])
 @pytest.mark.parametrize("relu,use_res", [(False, False), (True, False), (True, True)])
 @pytest.mark.parametrize("training", [True, False])
 def test_fused_bn_matches_torch(dtype, tol, shape, relu, use_res, training):
