@@ -170,6 +170,18 @@ int rn_bias_act_backward(const void *dy, const void *y, const uint8_t *mask, voi
                          int dtype, int64_t M, int C, int64_t HW, int relu,
                          void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- 3x3 conv of the head towers on the packed level canvas (MFMA implicit GEMM) -------------------
+ * y = mask * act( conv3x3(x, w, stride 1, pad 1) + bias ) for the 3x3 conv + ReLU pairs of the reference's
+ * towers (retinanet/layers.py:143-171, :213-241), on a canvas that carries a one-pixel ZERO border:
+ * x, y: [M = N*Hp*Wp][C] bf16 (channels-last [N, C, Hp, Wp]); w: [Cout][3][3][Cin] bf16 (the channels-last
+ * memory of a [Cout, Cin, 3, 3] weight); bias f32[Cout] or NULL; mask u8[HWp = Hp*Wp] or NULL -- it must be 0 on
+ * the border (border outputs are computed from wrapped neighbours and are only correct as zeros).  Wp = row
+ * pitch in positions.  dtype: RN_BF16 only; Cin % 64 == 0, Cout % 256 == 0 (else RN_EUNSUPPORTED: the caller
+ * keeps its MIOpen path).  The data gradient is the same call with the taps reversed and the channel roles
+ * swapped (w' = w.flip(2, 3).transpose(0, 1)), relu = 0, bias = NULL. */
+int rn_conv3x3_canvas(const void *x, const void *w, const float *bias, const uint8_t *mask, void *y, int dtype,
+                      int64_t M, int64_t HWp, int Wp, int Cin, int Cout, int relu, void *stream);
+
 /* ---- T1 transform (normalise + resize + pad + batch) -------------------------------------------
  * Replaces torchvision's GeneralizedRCNNTransform as the reference runs it at
  * retinanet/models.py:116 (construction), :262 and :279 (calls): per image (x - mean) / std, bilinear

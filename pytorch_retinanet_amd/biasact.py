@@ -77,6 +77,71 @@ class _BiasAct(torch.autograd.Function):
         return dx, dbias, None, None
 
 
+class _TowerConv(torch.autograd.Function):
+    """relu(conv3x3(x, w) + bias) * mask on a zero-bordered canvas: forward and data gradient are the hand-written
+    MFMA implicit GEMM (``rn_conv3x3_canvas``), the weight gradient is MIOpen's."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, mask):
+        N, Cin, Hp, Wp = x.shape
+        Cout = w.shape[0]
+        dev = x.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        if not _cl(w):
+            w = w.contiguous(memory_format=torch.channels_last)
+        y = torch.empty((N, Cout, Hp, Wp), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+        check(lib.rn_conv3x3_canvas(x.data_ptr(), w.data_ptr(), bias.data_ptr(), mask.data_ptr(), y.data_ptr(), _DT[x.dtype],
+                                    N * Hp * Wp, Hp * Wp, Wp, Cin, Cout, 1, stream), "rn_conv3x3_canvas")
+        ctx.save_for_backward(x, w, y, mask)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y, mask = ctx.saved_tensors
+        N, Cin, Hp, Wp = x.shape
+        Cout = w.shape[0]
+        dev = dy.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        if dy.dtype != x.dtype or not _cl(dy):
+            dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        M = N * Hp * Wp
+        g = torch.empty_like(dy)                                   # gradient at the conv output: ReLU + canvas mask
+        dbias = torch.empty((Cout,), dtype=torch.float32, device=dev)
+        wp, wn = _workspace(dev, stream, Cout)
+        check(lib.rn_bias_act_backward(dy.data_ptr(), y.data_ptr(), mask.data_ptr(), g.data_ptr(), dbias.data_ptr(), _DT[x.dtype],
+                                       M, Cout, Hp * Wp, 1, wp, wn, stream), "rn_bias_act_backward")
+        dx = dw = None
+        if ctx.needs_input_grad[0] and Cin % 256 == 0 and Cout % 64 == 0:
+            wt = w.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)     # [Cin, Cout, 3, 3], taps reversed
+            dx = torch.empty_like(x)
+            check(lib.rn_conv3x3_canvas(g.data_ptr(), wt.data_ptr(), 0, mask.data_ptr(), dx.data_ptr(), _DT[x.dtype],
+                                        M, Hp * Wp, Wp, Cout, Cin, 0, stream), "rn_conv3x3_canvas")
+        need = [ctx.needs_input_grad[0] and dx is None, ctx.needs_input_grad[1], False]
+        if need[0] or need[1]:
+            r = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, need)
+            dx = r[0] if need[0] else dx
+            dw = r[1] if need[1] else None
+        return dx, dw, dbias, None
+
+
+def tower_conv_fusable(x: Tensor, conv) -> bool:
+    "The MFMA canvas conv covers bf16, 3x3 / stride 1 / pad 1, Cin % 64 == 0 and Cout % 256 == 0 (head towers: 256 -> 256)."
+    # (its data gradient runs on the same kernel when Cin % 256 == 0 as well, else on MIOpen)
+    return (x.is_cuda and x.dtype == torch.bfloat16 and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and
+            conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is not None and
+            conv.in_channels % 64 == 0 and conv.out_channels % 256 == 0)
+
+
+def tower_conv(x: Tensor, weight: Tensor, bias: Tensor, mask: Tensor) -> Tensor:
+    """``relu(conv3x3(x, weight) + bias) * mask`` on a canvas built with ``Canvas(..., pad=1)``; ``weight`` is cast to
+    the activation dtype here (what autocast would do)."""
+    return _TowerConv.apply(x, weight.to(x.dtype), bias, mask)
+
+
 def bias_act(x: Tensor, bias: Tensor, mask: Optional[Tensor] = None, relu: bool = True) -> Tensor:
     """``mask * act(x + bias[None, :, None, None])``; ``mask``: u8 ``[H*W]`` (1 = keep) or None."""
     if fusable(x, bias):
@@ -92,19 +157,21 @@ def bias_act(x: Tensor, bias: Tensor, mask: Optional[Tensor] = None, relu: bool 
 # ---------------------------------------------------------------------------------------------------
 class Canvas:
     """Placement of L feature maps in one canvas: level 0 on top, the others side by side below it,
-    one empty row / column between neighbours."""
+    one empty row / column between neighbours; ``pad`` extra empty rows / columns all around (the MFMA canvas
+    conv wants a one-pixel zero border instead of bounds checks)."""
 
-    def __init__(self, shapes: Sequence[Tuple[int, int]], device: torch.device):
+    def __init__(self, shapes: Sequence[Tuple[int, int]], device: torch.device, pad: int = 0):
         self.shapes = [(int(h), int(w)) for h, w in shapes]
+        self.pad = pad
         h0, w0 = self.shapes[0]
-        self.origin: List[Tuple[int, int]] = [(0, 0)]
+        self.origin: List[Tuple[int, int]] = [(pad, pad)]
         col, below = 0, 0
         for h, w in self.shapes[1:]:
-            self.origin.append((h0 + 1, col))
+            self.origin.append((pad + h0 + 1, pad + col))
             col += w + 1
             below = max(below, h)
-        self.H = h0 + (1 + below if len(self.shapes) > 1 else 0)
-        self.W = max(w0, col - 1)
+        self.H = h0 + (1 + below if len(self.shapes) > 1 else 0) + 2 * pad
+        self.W = max(w0, col - 1) + 2 * pad
         m = torch.zeros((self.H, self.W), dtype=torch.uint8)
         for (r, c), (h, w) in zip(self.origin, self.shapes):
             m[r:r + h, c:c + w] = 1
@@ -114,11 +181,11 @@ class Canvas:
     _cache: Dict[tuple, "Canvas"] = {}
 
     @classmethod
-    def of(cls, feature_maps: Sequence[Tensor]) -> "Canvas":
-        key = (tuple(tuple(f.shape[-2:]) for f in feature_maps), feature_maps[0].device)
+    def of(cls, feature_maps: Sequence[Tensor], pad: int = 0) -> "Canvas":
+        key = (tuple(tuple(f.shape[-2:]) for f in feature_maps), feature_maps[0].device, pad)
         c = cls._cache.get(key)
         if c is None:
-            c = cls._cache[key] = Canvas(key[0], key[1])
+            c = cls._cache[key] = Canvas(key[0], key[1], pad)
         return c
 
 

@@ -1,0 +1,202 @@
+// 3x3 / stride-1 / pad-1 convolution of the head towers on the packed level canvas as a hand-written MFMA implicit
+// GEMM, with the bias + ReLU + position-mask epilogue fused (reference: the 3x3 conv + ReLU pairs
+// of retinanet/layers.py:143-171 and :213-241).  Forward and data-gradient use this kernel (the data gradient is the
+// same convolution with the taps reversed and the channel roles swapped); the weight gradient stays on MIOpen.
+//
+// Formulation.  The canvas carries a one-pixel zero border, [N][Hp][Wp][C] = [M][C] with M = N*Hp*Wp, so tap (r, s)
+// of output position m is input position m + (r-1)*Wp + (s-1): no bounds logic in the loop.  Positions whose 3x3
+// neighbourhood would leave their image are border / gap positions; their outputs are forced to zero by the mask,
+// which is also what keeps the levels of the canvas from leaking into each other in the next layer.  Addresses are
+// only clamped into the buffer.  GEMM: Y[m][n] = sum_{c, t} X[m + off_t][c] * W[n][t][c]; K = 9*Cin is walked as
+// Cin/64 channel chunks x 9 taps (chunk outer: a tile's input lines stay in L2 across its taps).
+//
+// Kernel (bf16 in, f32 accumulate, bf16 out): one 256(m) x 256(n) output tile per workgroup, 8 waves of 128 x 64
+// (4 x 2 v_mfma_f32_32x32x16_bf16 tiles, 128 accumulator registers); operands staged global -> LDS by 16-byte
+// LDS-DMA (global_load_lds) into 128-byte rows whose 16-byte chunks are XOR-swizzled with (row >> 1) & 7 (source-side
+// swizzle + the same XOR on the ds_read_b128: conflict-free for its 16-lane groups); 3 activation stages + 2 weight
+// stages = 160 KiB of LDS, activations prefetched two K-tiles ahead, weights one.  The two waves of every SIMD run
+// in PING-PONG: waves 0-3 and 4-7 are one barrier interval apart, so while one group issues its 16 MFMAs the other
+// reads the fragments of its next 16 (12 ds_read_b128) and issues 4 LDS-DMA pieces; a K-tile is two (load, MFMA)
+// phase pairs = 4 barriers.  LDS-DMA retirement: counted vmcnt at the end of the second load phase, one barrier
+// before any wave of either group reads the tile; raw s_barrier (a __syncthreads would drain the DMA).
+// Measured on MI355X, random data, [8,153,170,256] -> 256: 313 us = 785 TFLOP/s (939 without the 4th partial wave of
+// tiles); MIOpen: forward 301-315 us + 32 us for the separate bias/ReLU/mask pass, data gradient 415 us.
+#include "rn_common.hpp"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) void *lds_void_ptr;
+
+constexpr int CONV_BM = 256, CONV_BN = 256, CONV_BK = 64, CONV_THREADS = 512;
+constexpr int CONV_LDS_BYTES = 5 * CONV_BM * CONV_BK * 2;        // 160 KiB
+#define SWZ(row) (((row) >> 1) & 7)
+
+struct ConvArgs {
+    const uint16_t *X;      // [M][Cin] bf16
+    const uint16_t *W;      // [Cout][9][Cin] bf16
+    const float *bias;      // [Cout] or null
+    const uint8_t *mask;    // [HWp] or null (1 = keep)
+    uint16_t *Y;            // [M][Cout] bf16
+    int64_t M, HWp;
+    int Cin, Cout, Wp, relu;
+};
+
+__device__ __forceinline__ uint16_t f2bf(const float f) { return (uint16_t)(rn::dt<RN_BF16>::pk(f, 0.0f) & 0xffffu); }
+
+__global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const ConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];                 // [A0 A1 A2 | B0 B1] x 32 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int64_t m0 = (int64_t)blockIdx.x * CONV_BM;
+    const int n0 = blockIdx.y * CONV_BN;
+    const int cpt = a.Cin / CONV_BK, KT = 9 * cpt;
+    constexpr int TILE = CONV_BM * CONV_BK * 2;
+    unsigned char *const Abase = lds, *const Bbase = lds + 3 * TILE;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    uint32_t a_off[4][4], b_off[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int chunk = kk * 2 + (lane >> 5);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) { const int row = wm * 128 + mi * 32 + (lane & 31); a_off[mi][kk] = row * 128 + ((chunk ^ SWZ(row)) << 4); }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) { const int row = wn * 64 + ni * 32 + (lane & 31); b_off[ni][kk] = row * 128 + ((chunk ^ SWZ(row)) << 4); }
+    }
+    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+
+    auto piece_a = [&](const int kt, const int i) {
+        const int c0 = (kt / 9) * CONV_BK, t = kt % 9;
+        const int off = (t / 3 - 1) * a.Wp + (t % 3 - 1);
+        const int q = i * CONV_THREADS + tid, row = q >> 3, cp = q & 7;
+        int64_t m = m0 + row + off;
+        m = m < 0 ? 0 : (m >= a.M ? a.M - 1 : m);
+        const uint16_t *g = a.X + m * a.Cin + c0 + ((cp ^ SWZ(row)) << 3);
+        __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)(Abase + (kt % 3) * TILE + q * 16), 16, 0, 0);
+    };
+    auto piece_b = [&](const int kt, const int i) {
+        const int c0 = (kt / 9) * CONV_BK, t = kt % 9;
+        const int q = i * CONV_THREADS + tid, row = q >> 3, cp = q & 7;
+        const uint16_t *g = a.W + ((int64_t)(n0 + row) * 9 + t) * a.Cin + c0 + ((cp ^ SWZ(row)) << 3);
+        __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)(Bbase + (kt & 1) * TILE + q * 16), 16, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) piece_a(0, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) piece_b(0, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) piece_a(1, i);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();                    // group 1 runs one barrier interval behind group 0
+
+    bf16x8 fa[2][4], fb[2][2];
+#define RN_DS_READ(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
+#define RN_LOAD_FRAGS(KK, SET)                                                     \
+    RN_DS_READ(fb[SET][0], bbase + b_off[0][KK]); RN_DS_READ(fb[SET][1], bbase + b_off[1][KK]);   \
+    RN_DS_READ(fa[SET][0], abase + a_off[0][KK]); RN_DS_READ(fa[SET][1], abase + a_off[1][KK]);   \
+    RN_DS_READ(fa[SET][2], abase + a_off[2][KK]); RN_DS_READ(fa[SET][3], abase + a_off[3][KK]);
+#define RN_MFMA8(SET)                                                              \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                               \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                           \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][mi], fb[SET][ni], acc[mi][ni], 0, 0, 0);
+#define RN_MFMA_PHASE()                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);          \
+    __builtin_amdgcn_s_setprio(1);                                                 \
+    RN_MFMA8(0) RN_MFMA8(1)                                                        \
+    __builtin_amdgcn_s_setprio(0);                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    __builtin_amdgcn_s_barrier();
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const uint32_t abase = lds_base + (uint32_t)((kt % 3) * TILE), bbase = lds_base + (uint32_t)(3 * TILE + (kt & 1) * TILE);
+        // load phase 2kt: fragments of k-steps 0,1; the weight pieces of tile kt+1
+        RN_LOAD_FRAGS(0, 0) RN_LOAD_FRAGS(1, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < KT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) piece_b(kt + 1, i);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        RN_MFMA_PHASE()
+        // load phase 2kt+1: fragments of k-steps 2,3; the activation pieces of tile kt+2; retire tile kt+1
+        RN_LOAD_FRAGS(2, 0) RN_LOAD_FRAGS(3, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < KT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) piece_a(kt + 2, i);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        RN_MFMA_PHASE()
+    }
+#undef RN_DS_READ
+#undef RN_LOAD_FRAGS
+#undef RN_MFMA8
+#undef RN_MFMA_PHASE
+    if (wm == 0) __builtin_amdgcn_s_barrier();                    // group 0 catches up with group 1's extra barrier
+
+    __syncthreads();
+    uint16_t *Ys = (uint16_t *)lds;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = wn * 64 + ni * 32 + (lane & 31);
+            const float b = a.bias ? a.bias[n0 + col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float v = acc[mi][ni][r] + b;
+                if (a.relu & 1) v = v > 0.0f ? v : 0.0f;
+                Ys[row * CONV_BN + col] = f2bf(v);
+            }
+        }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int q = i * CONV_THREADS + tid, row = q >> 5, piece = q & 31;
+        const int64_t m = m0 + row;
+        if (m < a.M) {
+            uint4 v = *(const uint4 *)(Ys + row * CONV_BN + piece * 8);
+            if (a.mask && !a.mask[m % a.HWp]) v = make_uint4(0, 0, 0, 0);
+            *(uint4 *)(a.Y + m * a.Cout + n0 + piece * 8) = v;
+        }
+    }
+}
+
+}  // namespace
+
+RN_API int rn_conv3x3_canvas(const void *x, const void *w, const float *bias, const uint8_t *mask, void *y, int dtype,
+                             int64_t M, int64_t HWp, int Wp, int Cin, int Cout, int relu, void *stream)
+{
+    if (!x || !w || !y || M <= 0 || HWp <= 0 || Wp <= 0 || Cin <= 0 || Cout <= 0) return RN_EINVAL;
+    if (dtype != RN_BF16 || Cin % CONV_BK || Cout % CONV_BN) return RN_EUNSUPPORTED;
+    if (!rn::aligned(x, 16) || !rn::aligned(w, 16) || !rn::aligned(y, 16)) return RN_EALIGN;
+    static bool attr_set = false;             // idempotent; a race only repeats the call
+    if (!attr_set) {
+        RN_HIP(hipFuncSetAttribute((const void *)conv3x3_canvas_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES));
+        attr_set = true;
+    }
+    ConvArgs a;
+    a.X = (const uint16_t *)x; a.W = (const uint16_t *)w; a.bias = bias; a.mask = mask; a.Y = (uint16_t *)y;
+    a.M = M; a.HWp = HWp; a.Cin = Cin; a.Cout = Cout; a.Wp = Wp; a.relu = relu ? 1 : 0;
+    const dim3 grid((unsigned)((M + CONV_BM - 1) / CONV_BM), (unsigned)(Cout / CONV_BN));
+    hipLaunchKernelGGL(conv3x3_canvas_kernel, grid, dim3(CONV_THREADS), CONV_LDS_BYTES, (hipStream_t)stream, a);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}

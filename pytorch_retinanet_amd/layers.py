@@ -59,12 +59,16 @@ def _tower(in_channels: int, out_channels: int) -> nn.Sequential:
     return nn.Sequential(*mods)
 
 
-def _tower_on_canvas(tower: nn.Sequential, x: Tensor, mask: Tensor) -> Tensor:
-    """The same four conv + ReLU pairs applied to the packed level canvas: conv without bias, then the
-    fused bias + ReLU + gap-mask epilogue (biasact.py)."""
+def _tower_on_canvas(tower: nn.Sequential, x: Tensor, mask: Tensor, mfma: bool = False) -> Tensor:
+    """The same four conv + ReLU pairs applied to the packed level canvas.  ``mfma`` (bf16, zero-bordered canvas):
+    the hand-written MFMA implicit GEMM with the bias + ReLU + gap-mask epilogue fused (csrc/conv.hip);
+    otherwise MIOpen's conv without bias followed by the fused epilogue kernel (biasact.py)."""
     for layer in tower:
         if isinstance(layer, nn.Conv2d):
-            x = biasact.bias_act(F.conv2d(x, layer.weight, None, layer.stride, layer.padding), layer.bias, mask, relu=True)
+            if mfma:
+                x = biasact.tower_conv(x, layer.weight, layer.bias, mask)
+            else:
+                x = biasact.bias_act(F.conv2d(x, layer.weight, None, layer.stride, layer.padding), layer.bias, mask, relu=True)
     return x
 
 
@@ -160,6 +164,7 @@ class RetinaNetHead(nn.Module):
         self.classification_head = RetinaNetClassSubnet(in_channels, out_channels, num_anchors, num_classes, prior)
         self.regression_head = RetinaNetBoxSubnet(in_channels, out_channels, num_anchors)
         self.losses = RetinaNetLosses(num_classes)
+        self.mfma_towers = True            # bf16 canvas towers on the hand-written MFMA conv (False: MIOpen + fused epilogue)
 
     def compute_loss(self, targets: List[Dict[str, Tensor]], outputs: Dict[str, Tensor],
                      anchors: List[Tensor]) -> Dict[str, Tensor]:
@@ -177,12 +182,14 @@ class RetinaNetHead(nn.Module):
         tower outputs so the loss / detection kernels keep reading dense per-level tensors."""
         ch, rh = self.classification_head, self.regression_head
         if canvas and len(xb) > 1 and all(biasact.fusable(f, ch.class_subnet[0].bias) for f in xb):
-            cv = biasact.Canvas.of(xb)
+            convs = [m for m in list(ch.class_subnet) + list(rh.box_subnet) if isinstance(m, nn.Conv2d)]
+            mfma = self.mfma_towers and all(biasact.tower_conv_fusable(xb[0], m) for m in convs)
+            cv = biasact.Canvas.of(xb, pad=1 if mfma else 0)
             packed = biasact.pack_levels(cv, xb)
-            cls_t = biasact.unpack_levels(cv, _tower_on_canvas(ch.class_subnet, packed, cv.mask))
+            cls_t = biasact.unpack_levels(cv, _tower_on_canvas(ch.class_subnet, packed, cv.mask, mfma))
             # the 36-channel box conv is tiny per level (2 TFLOP/s on P7): run it on the canvas too and unpack its
             # small output instead of the 256-channel tower output
-            box_c = rh.box_subnet_output(_tower_on_canvas(rh.box_subnet, packed, cv.mask))
+            box_c = rh.box_subnet_output(_tower_on_canvas(rh.box_subnet, packed, cv.mask, mfma))
             box_levels = [_to_anchor_major(t, 4) for t in biasact.unpack_levels(cv, box_c)]
             return {"cls_levels": ch.output_levels(cls_t, pad_classes), "bbox_levels": box_levels}
         return {"cls_levels": ch.forward_levels(xb, pad_classes), "bbox_levels": rh.forward_levels(xb)}

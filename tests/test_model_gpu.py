@@ -276,3 +276,77 @@ def test_head_on_canvas_equals_per_level_head():
         torch.testing.assert_close(b, a, rtol=1e-3, atol=1e-4)
     for n, a in outs[False][2].items():
         torch.testing.assert_close(outs[True][2][n], a, rtol=1e-3, atol=1e-3)
+
+
+def _canvas_conv_reference(x, w, b, mask2d):
+    y = torch.relu(torch.nn.functional.conv2d(x.float(), w.float(), b, padding=1))
+    return y * mask2d[None, None].float()
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 256, 9, 11), (1, 256, 256, 14, 37), (3, 512, 256, 6, 8), (2, 256, 512, 5, 7)])
+def test_mfma_canvas_conv_forward_backward_vs_torch(shape):
+    """rn_conv3x3_canvas (forward + data gradient) and the MIOpen weight gradient, against torch's conv2d in fp32 on
+    the same bf16 values; zero-bordered canvas with a random interior mask (gaps)."""
+    from pytorch_retinanet_amd import biasact
+    torch.manual_seed(0)
+    N, Cin, Cout, Hp, Wp = shape
+    mask2d = torch.zeros(Hp, Wp, dtype=torch.uint8, device=DEV)
+    mask2d[1:-1, 1:-1] = (torch.rand(Hp - 2, Wp - 2, device=DEV) > 0.2).to(torch.uint8)
+    x = (torch.randn(N, Cin, Hp, Wp, device=DEV) * mask2d[None, None]).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    w = (torch.randn(Cout, Cin, 3, 3, device=DEV) * 0.05).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    b = (torch.randn(Cout, device=DEV) * 0.1).requires_grad_(True)
+    y = biasact.tower_conv(x, w, b, mask2d.reshape(-1))
+    assert y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    g = (torch.randn_like(y) * mask2d[None, None]).to(torch.bfloat16)
+    y.backward(g)
+    xr = x.detach().float().requires_grad_(True)
+    wr = w.detach().to(torch.bfloat16).float().requires_grad_(True)       # the kernel sees the bf16-rounded weights
+    br = b.detach().clone().requires_grad_(True)
+    yr = _canvas_conv_reference(xr, wr, br, mask2d)
+    yr.backward(g.float())
+    scale = float(yr.detach().abs().max())
+    torch.testing.assert_close(y.float(), yr, rtol=2e-2, atol=1e-2 * scale)
+    assert not y.float()[:, :, mask2d == 0].any()                         # border and gaps are exact zeros
+    # gradients: the ReLU decision is taken on the rounded y; skip the elements whose pre-activation is within rounding of 0
+    gs = float(xr.grad.abs().max())
+    interior = mask2d[None, None].bool().expand_as(xr.grad)
+    torch.testing.assert_close(x.grad.float()[interior], xr.grad[interior], rtol=5e-2, atol=3e-2 * gs)
+    torch.testing.assert_close(w.grad.float(), wr.grad, rtol=5e-2, atol=3e-2 * float(wr.grad.abs().max()))
+    torch.testing.assert_close(b.grad, br.grad, rtol=5e-2, atol=3e-2 * float(br.grad.abs().max()))
+
+
+def test_head_mfma_towers_equal_miopen_towers_bf16():
+    """Under bf16 autocast the canvas towers run on the MFMA conv; same logits / deltas / parameter gradients as the
+    MIOpen + fused-epilogue towers (bf16 tolerance)."""
+    import pytorch_retinanet_amd as P
+    torch.manual_seed(7)
+    net = P.Retinanet(num_classes=6, backbone_kind="resnet18", pretrained=False, min_size=128, max_size=160).to(DEV)
+    net = net.to(memory_format=torch.channels_last).eval()
+    head = net.retinanet_head
+    for p in head.parameters():
+        if p.dim() == 4:
+            torch.nn.init.normal_(p, std=0.03)
+    shapes = [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)]
+    fm = [torch.randn(2, 256, h, w, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+          for h, w in shapes]
+    outs = {}
+    for mfma in (False, True):
+        head.mfma_towers = mfma
+        head.zero_grad()
+        for f in fm:
+            f.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            o = head.forward_levels(fm, pad_classes=True, canvas=True)
+        loss = sum((c.float() ** 2).sum() for c in o["cls_levels"]) * 1e-4 + sum((b.float() ** 2).sum() for b in o["bbox_levels"])
+        loss.backward()
+        outs[mfma] = (o, [f.grad.clone() for f in fm], {n: p.grad.clone() for n, p in head.named_parameters() if p.grad is not None})
+    head.mfma_towers = True
+    for key in ("cls_levels", "bbox_levels"):
+        for a, b in zip(outs[False][0][key], outs[True][0][key]):
+            assert a.shape == b.shape
+            torch.testing.assert_close(b.float(), a.float(), rtol=5e-2, atol=5e-2 * float(a.float().abs().max()))
+    for a, b in zip(outs[False][1], outs[True][1]):
+        torch.testing.assert_close(b.float(), a.float(), rtol=1e-1, atol=5e-2 * float(a.float().abs().max()))
+    for n, a in outs[False][2].items():
+        torch.testing.assert_close(outs[True][2][n].float(), a.float(), rtol=1e-1, atol=5e-2 * float(a.float().abs().max()))
