@@ -128,6 +128,67 @@ class _TowerConv(torch.autograd.Function):
         return dx, dw, dbias, None
 
 
+def _ptr_array(ts):
+    return (C.c_void_p * len(ts))(*[t.data_ptr() if t is not None else 0 for t in ts])
+
+
+class _TowerConvPair(torch.autograd.Function):
+    """``_TowerConv`` for two towers of identical geometry (cls and box) in one batched launch each way: their tiles
+    together fill the chip's workgroup waves (2 x 813 tiles: 7 waves of 256 instead of 2 x 4)."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, w0, w1, b0, b1, mask):
+        N, Cin, Hp, Wp = x0.shape
+        Cout = w0.shape[0]
+        dev = x0.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        w0 = w0 if _cl(w0) else w0.contiguous(memory_format=torch.channels_last)
+        w1 = w1 if _cl(w1) else w1.contiguous(memory_format=torch.channels_last)
+        ys = [torch.empty((N, Cout, Hp, Wp), dtype=x0.dtype, device=dev, memory_format=torch.channels_last) for _ in range(2)]
+        check(lib.rn_conv3x3_canvas_batched(_ptr_array([x0, x1]), _ptr_array([w0, w1]), _ptr_array([b0, b1]), mask.data_ptr(),
+                                            _ptr_array(ys), 2, _DT[x0.dtype], N * Hp * Wp, Hp * Wp, Wp, Cin, Cout, 1, stream),
+              "rn_conv3x3_canvas_batched")
+        ctx.save_for_backward(x0, x1, w0, w1, ys[0], ys[1], mask)
+        return ys[0], ys[1]
+
+    @staticmethod
+    def backward(ctx, dy0, dy1):
+        x0, x1, w0, w1, y0, y1, mask = ctx.saved_tensors
+        N, Cin, Hp, Wp = x0.shape
+        Cout = w0.shape[0]
+        dev = x0.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        M = N * Hp * Wp
+        gs, dbs = [], []
+        wp, wn = _workspace(dev, stream, Cout)
+        for dy, y in ((dy0, y0), (dy1, y1)):
+            if dy.dtype != x0.dtype or not _cl(dy):
+                dy = dy.to(x0.dtype).contiguous(memory_format=torch.channels_last)
+            g = torch.empty_like(dy)
+            db = torch.empty((Cout,), dtype=torch.float32, device=dev)
+            check(lib.rn_bias_act_backward(dy.data_ptr(), y.data_ptr(), mask.data_ptr(), g.data_ptr(), db.data_ptr(), _DT[x0.dtype],
+                                           M, Cout, Hp * Wp, 1, wp, wn, stream), "rn_bias_act_backward")
+            gs.append(g); dbs.append(db)
+        dxs = [None, None]
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            wts = [w.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last) for w in (w0, w1)]
+            dxs = [torch.empty_like(x0), torch.empty_like(x1)]
+            check(lib.rn_conv3x3_canvas_batched(_ptr_array(gs), _ptr_array(wts), None, mask.data_ptr(), _ptr_array(dxs), 2,
+                                                _DT[x0.dtype], M, Hp * Wp, Wp, Cout, Cin, 0, stream), "rn_conv3x3_canvas_batched")
+        dws = [torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+               for g, x, w in ((gs[0], x0, w0), (gs[1], x1, w1))]
+        return dxs[0], dxs[1], dws[0], dws[1], dbs[0], dbs[1], None
+
+
+def tower_conv_pair(x0: Tensor, x1: Tensor, w0: Tensor, w1: Tensor, b0: Tensor, b1: Tensor, mask: Tensor):
+    "Two ``tower_conv`` of identical geometry (Cin == Cout % 256 == 0) in one launch each way."
+    return _TowerConvPair.apply(x0, x1, w0.to(x0.dtype), w1.to(x0.dtype), b0, b1, mask)
+
+
 def tower_conv_fusable(x: Tensor, conv) -> bool:
     "The MFMA canvas conv covers bf16, 3x3 / stride 1 / pad 1, Cin % 64 == 0 and Cout % 256 == 0 (head towers: 256 -> 256)."
     # (its data gradient runs on the same kernel when Cin % 256 == 0 as well, else on MIOpen)

@@ -33,20 +33,27 @@ constexpr int CONV_BM = 256, CONV_BN = 256, CONV_BK = 64, CONV_THREADS = 512;
 constexpr int CONV_LDS_BYTES = 5 * CONV_BM * CONV_BK * 2;        // 160 KiB
 #define SWZ(row) (((row) >> 1) & 7)
 
+constexpr int CONV_MAX_PROBLEMS = 4;
+// Up to 4 convolutions of identical geometry in one launch (blockIdx.z = problem): the cls and the box tower run the
+// same shapes side by side, and 2 x 813 tiles fill 7 waves of 256 workgroups where two launches take 2 x 4.
 struct ConvArgs {
-    const uint16_t *X;      // [M][Cin] bf16
-    const uint16_t *W;      // [Cout][9][Cin] bf16
-    const float *bias;      // [Cout] or null
+    const uint16_t *Xs[CONV_MAX_PROBLEMS];      // [M][Cin] bf16
+    const uint16_t *Ws[CONV_MAX_PROBLEMS];      // [Cout][9][Cin] bf16
+    const float *biases[CONV_MAX_PROBLEMS];     // [Cout] or null
+    uint16_t *Ys[CONV_MAX_PROBLEMS];            // [M][Cout] bf16
     const uint8_t *mask;    // [HWp] or null (1 = keep)
-    uint16_t *Y;            // [M][Cout] bf16
     int64_t M, HWp;
     int Cin, Cout, Wp, relu;
 };
+struct ConvProblem { const uint16_t *X, *W; const float *bias; uint16_t *Y; const uint8_t *mask; int64_t M, HWp; int Cin, Cout, Wp, relu; };
 
 __device__ __forceinline__ uint16_t f2bf(const float f) { return (uint16_t)(rn::dt<RN_BF16>::pk(f, 0.0f) & 0xffffu); }
 
-__global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const ConvArgs a)
+__global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const ConvArgs args)
 {
+    ConvProblem a;
+    a.X = args.Xs[blockIdx.z]; a.W = args.Ws[blockIdx.z]; a.bias = args.biases[blockIdx.z]; a.Y = args.Ys[blockIdx.z];
+    a.mask = args.mask; a.M = args.M; a.HWp = args.HWp; a.Cin = args.Cin; a.Cout = args.Cout; a.Wp = args.Wp; a.relu = args.relu;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];                 // [A0 A1 A2 | B0 B1] x 32 KiB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -181,22 +188,38 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
 
 }  // namespace
 
-RN_API int rn_conv3x3_canvas(const void *x, const void *w, const float *bias, const uint8_t *mask, void *y, int dtype,
-                             int64_t M, int64_t HWp, int Wp, int Cin, int Cout, int relu, void *stream)
+RN_API int rn_conv3x3_canvas_batched(const void *const *xs, const void *const *ws, const float *const *biases,
+                                     const uint8_t *mask, void *const *ys, int P, int dtype, int64_t M, int64_t HWp, int Wp,
+                                     int Cin, int Cout, int relu, void *stream)
 {
-    if (!x || !w || !y || M <= 0 || HWp <= 0 || Wp <= 0 || Cin <= 0 || Cout <= 0) return RN_EINVAL;
+    if (!xs || !ws || !ys || P <= 0 || P > CONV_MAX_PROBLEMS || M <= 0 || HWp <= 0 || Wp <= 0 || Cin <= 0 || Cout <= 0) return RN_EINVAL;
     if (dtype != RN_BF16 || Cin % CONV_BK || Cout % CONV_BN) return RN_EUNSUPPORTED;
-    if (!rn::aligned(x, 16) || !rn::aligned(w, 16) || !rn::aligned(y, 16)) return RN_EALIGN;
+    ConvArgs a;
+    for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) {
+        const int q = p < P ? p : 0;
+        if (!xs[q] || !ws[q] || !ys[q]) return RN_EINVAL;
+        if (!rn::aligned(xs[q], 16) || !rn::aligned(ws[q], 16) || !rn::aligned(ys[q], 16)) return RN_EALIGN;
+        a.Xs[p] = (const uint16_t *)xs[q]; a.Ws[p] = (const uint16_t *)ws[q]; a.Ys[p] = (uint16_t *)ys[q];
+        a.biases[p] = biases ? biases[q] : nullptr;
+    }
     static bool attr_set = false;             // idempotent; a race only repeats the call
     if (!attr_set) {
         RN_HIP(hipFuncSetAttribute((const void *)conv3x3_canvas_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES));
         attr_set = true;
     }
-    ConvArgs a;
-    a.X = (const uint16_t *)x; a.W = (const uint16_t *)w; a.bias = bias; a.mask = mask; a.Y = (uint16_t *)y;
-    a.M = M; a.HWp = HWp; a.Cin = Cin; a.Cout = Cout; a.Wp = Wp; a.relu = relu ? 1 : 0;
-    const dim3 grid((unsigned)((M + CONV_BM - 1) / CONV_BM), (unsigned)(Cout / CONV_BN));
+    a.mask = mask; a.M = M; a.HWp = HWp; a.Cin = Cin; a.Cout = Cout; a.Wp = Wp; a.relu = relu ? 1 : 0;
+    const dim3 grid((unsigned)((M + CONV_BM - 1) / CONV_BM), (unsigned)(Cout / CONV_BN), (unsigned)P);
     hipLaunchKernelGGL(conv3x3_canvas_kernel, grid, dim3(CONV_THREADS), CONV_LDS_BYTES, (hipStream_t)stream, a);
     RN_LAUNCH_CHECK();
     return RN_OK;
+}
+
+RN_API int rn_conv3x3_canvas(const void *x, const void *w, const float *bias, const uint8_t *mask, void *y, int dtype,
+                             int64_t M, int64_t HWp, int Wp, int Cin, int Cout, int relu, void *stream)
+{
+    if (!x || !w || !y) return RN_EINVAL;
+    const void *xs[1] = {x}, *ws[1] = {w};
+    const float *bs[1] = {bias};
+    void *ys[1] = {y};
+    return rn_conv3x3_canvas_batched(xs, ws, bs, mask, ys, 1, dtype, M, HWp, Wp, Cin, Cout, relu, stream);
 }

@@ -10,6 +10,7 @@ reference's ``view -> permute -> contiguous`` (layers.py:189-191, :253-255) is a
 zero-copy reshape and the loss / detection kernels stream it directly.
 """
 import math
+import os
 from typing import Dict, List
 
 import torch
@@ -164,7 +165,11 @@ class RetinaNetHead(nn.Module):
         self.classification_head = RetinaNetClassSubnet(in_channels, out_channels, num_anchors, num_classes, prior)
         self.regression_head = RetinaNetBoxSubnet(in_channels, out_channels, num_anchors)
         self.losses = RetinaNetLosses(num_classes)
-        self.mfma_towers = True            # bf16 canvas towers on the hand-written MFMA conv (False: MIOpen + fused epilogue)
+        # bf16 canvas towers: "pair" = hand-written MFMA conv, cls + box tower batched per layer; "single" = the same kernel,
+        # one launch per conv; "miopen" = MIOpen conv + fused epilogue kernel.  RN_TOWERS overrides (A/B measurements).
+        mode = os.environ.get("RN_TOWERS", "pair")
+        self.mfma_towers = mode != "miopen"
+        self.pair_towers = mode == "pair"
 
     def compute_loss(self, targets: List[Dict[str, Tensor]], outputs: Dict[str, Tensor],
                      anchors: List[Tensor]) -> Dict[str, Tensor]:
@@ -186,10 +191,21 @@ class RetinaNetHead(nn.Module):
             mfma = self.mfma_towers and all(biasact.tower_conv_fusable(xb[0], m) for m in convs)
             cv = biasact.Canvas.of(xb, pad=1 if mfma else 0)
             packed = biasact.pack_levels(cv, xb)
-            cls_t = biasact.unpack_levels(cv, _tower_on_canvas(ch.class_subnet, packed, cv.mask, mfma))
+            cc = [m for m in ch.class_subnet if isinstance(m, nn.Conv2d)]
+            bc = [m for m in rh.box_subnet if isinstance(m, nn.Conv2d)]
+            if mfma and self.pair_towers and len(cc) == len(bc) and all(c.weight.shape == b.weight.shape and c.in_channels % 256 == 0
+                                                    for c, b in zip(cc, bc)):
+                xc = xb_ = packed                  # both towers layer by layer, one batched launch per layer and direction
+                for c, b in zip(cc, bc):
+                    xc, xb_ = biasact.tower_conv_pair(xc, xb_, c.weight, b.weight, c.bias, b.bias, cv.mask)
+                cls_c, box_t = xc, xb_
+            else:
+                cls_c = _tower_on_canvas(ch.class_subnet, packed, cv.mask, mfma)
+                box_t = _tower_on_canvas(rh.box_subnet, packed, cv.mask, mfma)
+            cls_t = biasact.unpack_levels(cv, cls_c)
             # the 36-channel box conv is tiny per level (2 TFLOP/s on P7): run it on the canvas too and unpack its
             # small output instead of the 256-channel tower output
-            box_c = rh.box_subnet_output(_tower_on_canvas(rh.box_subnet, packed, cv.mask, mfma))
+            box_c = rh.box_subnet_output(box_t)
             box_levels = [_to_anchor_major(t, 4) for t in biasact.unpack_levels(cv, box_c)]
             return {"cls_levels": ch.output_levels(cls_t, pad_classes), "bbox_levels": box_levels}
         return {"cls_levels": ch.forward_levels(xb, pad_classes), "bbox_levels": rh.forward_levels(xb)}
