@@ -480,7 +480,7 @@ __global__ __launch_bounds__(THREADS2) void conv3x3_mfma_v4_kernel(const ConvArg
         // load phase 2kt: fragments of k-steps 0,1; the weight pieces of tile kt+1
         RN_LOAD_FRAGS(0, 0) RN_LOAD_FRAGS(1, 1)
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < KT) {
+        if (kt + 1 < KT && !(a.relu & 512)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) piece_b(kt + 1, i);
         }
@@ -491,8 +491,10 @@ __global__ __launch_bounds__(THREADS2) void conv3x3_mfma_v4_kernel(const ConvArg
         RN_LOAD_FRAGS(2, 0) RN_LOAD_FRAGS(3, 1)
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 2 < KT) {
+            if (!(a.relu & 256)) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) piece_a(kt + 2, i);
+                for (int i = 0; i < 4; ++i) piece_a(kt + 2, i);
+            }
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
