@@ -202,10 +202,14 @@ RN_API int rn_conv3x3_canvas_batched(const void *const *xs, const void *const *w
         a.Xs[p] = (const uint16_t *)xs[q]; a.Ws[p] = (const uint16_t *)ws[q]; a.Ys[p] = (uint16_t *)ys[q];
         a.biases[p] = biases ? biases[q] : nullptr;
     }
-    static bool attr_set = false;             // idempotent; a race only repeats the call
-    if (!attr_set) {
-        RN_HIP(hipFuncSetAttribute((const void *)conv3x3_canvas_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES));
-        attr_set = true;
+    {   // 160 KiB of dynamic LDS needs the opt-in once per device (the attribute lives with the device's code object)
+        static bool attr_set[64] = {};
+        int dev = 0;
+        RN_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            RN_HIP(hipFuncSetAttribute((const void *)conv3x3_canvas_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES));
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
     }
     a.mask = mask; a.M = M; a.HWp = HWp; a.Cin = Cin; a.Cout = Cout; a.Wp = Wp; a.relu = relu ? 1 : 0;
     const dim3 grid((unsigned)((M + CONV_BM - 1) / CONV_BM), (unsigned)(Cout / CONV_BN), (unsigned)P);
