@@ -188,6 +188,15 @@ int rn_conv3x3_canvas_batched(const void *const *xs, const void *const *ws, cons
                               const uint8_t *mask, void *const *ys, int P, int dtype, int64_t M, int64_t HWp,
                               int Wp, int Cin, int Cout, int relu, void *stream);
 
+/* ---- stem max pooling, channels-last, no index tensor -------------------------------------------------
+ * nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the reference's stem (retinanet/backbone.py:251) on
+ * [N][H][W][C] activations (C % 8 == 0), y: [N][(H-1)/2+1][(W-1)/2+1][C].  argmax (u8, shape of y, nullable for
+ * inference): position 0..8 of the maximum inside its window with PyTorch's scan rule (first maximum; the last
+ * NaN wins) -- one byte per element instead of PyTorch's int64 index; the backward gathers from it. */
+int rn_maxpool3x3s2_forward(const void *x, void *y, uint8_t *argmax, int dtype, int N, int H, int W, int C, void *stream);
+int rn_maxpool3x3s2_backward(const uint8_t *argmax, const void *dy, void *dx, int dtype,
+                             int N, int H, int W, int C, void *stream);
+
 /* ---- T1 transform (normalise + resize + pad + batch) -------------------------------------------
  * Replaces torchvision's GeneralizedRCNNTransform as the reference runs it at
  * retinanet/models.py:116 (construction), :262 and :279 (calls): per image (x - mean) / std, bilinear

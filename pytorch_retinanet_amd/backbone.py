@@ -13,6 +13,7 @@ import torch
 from torch import Tensor, nn
 
 from .norm import FusedBatchNorm2d
+from .pool import FusedMaxPool2d
 
 __all__ = ["resnet18", "resnet34", "resnet50", "resnet101", "resnet152"]
 
@@ -83,7 +84,7 @@ class ResNetBackbone(nn.Module):
         self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
         self.bn1 = FusedBatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
-        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.maxpool = FusedMaxPool2d(kernel_size=3, stride=2, padding=1)
         self.layer1 = self._make_layer(block, 64, layers[0])
         self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
         self.layer3 = self._make_layer(block, 256, layers[2], stride=2)

@@ -1,0 +1,160 @@
+// 3x3 / stride-2 / pad-1 max pooling of the ResNet stem (reference: retinanet/backbone.py:251, nn.MaxPool2d(3, 2, 1))
+// for channels-last activations, forward and backward, with a one-byte arg-max code instead of an int64 index tensor.
+//
+// PyTorch's NHWC kernels write an int64 index per output element in the forward (4x the bytes of the bf16 output)
+// and read it back in the backward; on the R50 stem ([8, 64, 400, 672] -> [8, 64, 200, 336]) they take 176 + 463 us.
+// Here the forward stores the arg-max as ONE BYTE per output element (position 0..8 inside its window, PyTorch's
+// scan rule `val > maxval || isnan(val)`: first maximum, last NaN) and the backward gathers: an input element sums
+// dy over the <= 4 windows whose code names it.  Each thread owns 8 channels (one 16-byte vector) of one position.
+// (Recomputing the arg-max in the backward from x and y was 3x SLOWER than PyTorch: every window maximum needs the
+// scan for an earlier equal element, i.e. 8 more vector loads for most (element, window) pairs.)
+//   forward : reads x (each line is touched by <= 4 windows, served by L1/L2), writes y and the codes
+//   backward: reads the codes and dy of the <= 4 windows covering the position (cached), writes dx
+#include "rn_common.hpp"
+
+namespace {
+
+template <int DT> struct v8 {
+    static __device__ __forceinline__ void ld(const void *p, int64_t v, float (&f)[8]) { rn::dt<DT>::unpack(((const rn::u32x4 *)p)[v], f); }
+    static __device__ __forceinline__ void st(void *p, int64_t v, const float (&f)[8]) { ((rn::u32x4 *)p)[v] = rn::dt<DT>::pack(f); }
+};
+template <> struct v8<RN_F32> {
+    static __device__ __forceinline__ void ld(const void *p, int64_t v, float (&f)[8]) {
+        const rn::f32x4 a = ((const rn::f32x4 *)p)[2 * v], b = ((const rn::f32x4 *)p)[2 * v + 1];
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    }
+    static __device__ __forceinline__ void st(void *p, int64_t v, const float (&f)[8]) {
+        rn::f32x4 a, b;
+        a.x = f[0]; a.y = f[1]; a.z = f[2]; a.w = f[3]; b.x = f[4]; b.y = f[5]; b.z = f[6]; b.w = f[7];
+        ((rn::f32x4 *)p)[2 * v] = a; ((rn::f32x4 *)p)[2 * v + 1] = b;
+    }
+};
+
+struct PoolShape { int N, H, W, C8, OH, OW; };
+
+template <int DT>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const void *__restrict__ x, void *__restrict__ y, uint8_t *__restrict__ idx,
+                                                          const PoolShape s)
+{
+    const int64_t total = (int64_t)s.N * s.OH * s.OW * s.C8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cg = (int)(i % s.C8);
+        int64_t p = i / s.C8;
+        const int ox = (int)(p % s.OW); p /= s.OW;
+        const int oy = (int)(p % s.OH);
+        const int n = (int)(p / s.OH);
+        float m[8];
+        int k[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; k[j] = -1; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int iy = 2 * oy - 1 + r;
+            if (iy < 0 || iy >= s.H) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int ix = 2 * ox - 1 + q;
+                if (ix < 0 || ix >= s.W) continue;
+                float f[8];
+                v8<DT>::ld(x, (((int64_t)n * s.H + iy) * s.W + ix) * s.C8 + cg, f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (k[j] < 0 || f[j] > m[j] || f[j] != f[j]) { m[j] = f[j]; k[j] = r * 3 + q; }   // PyTorch's scan: first maximum, last NaN
+            }
+        }
+        v8<DT>::st(y, i, m);
+        if (idx) {
+            rn::u32x2 pk;
+            pk.x = (uint32_t)k[0] | ((uint32_t)k[1] << 8) | ((uint32_t)k[2] << 16) | ((uint32_t)k[3] << 24);
+            pk.y = (uint32_t)k[4] | ((uint32_t)k[5] << 8) | ((uint32_t)k[6] << 16) | ((uint32_t)k[7] << 24);
+            ((rn::u32x2 *)idx)[i] = pk;
+        }
+    }
+}
+
+// dx of an input element = sum of dy over the (<= 4) windows whose arg-max code names it
+template <int DT>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t *__restrict__ idx, const void *__restrict__ dy,
+                                                          void *__restrict__ dx, const PoolShape s)
+{
+    const int64_t total = (int64_t)s.N * s.H * s.W * s.C8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cg = (int)(i % s.C8);
+        int64_t p = i / s.C8;
+        const int ix = (int)(p % s.W); p /= s.W;
+        const int iy = (int)(p % s.H);
+        const int n = (int)(p / s.H);
+        float g[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = 0.0f;
+        // windows (oy, ox) that contain (iy, ix): 2*o - 1 <= i <= 2*o + 1
+        const int oy0 = iy >> 1, oy1 = (iy + 1) >> 1, ox0 = ix >> 1, ox1 = (ix + 1) >> 1;
+        for (int oy = oy0; oy <= oy1; ++oy) {
+            if (oy >= s.OH) continue;
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                if (ox >= s.OW) continue;
+                const int64_t w = (((int64_t)n * s.OH + oy) * s.OW + ox) * s.C8 + cg;
+                const uint32_t me = (uint32_t)((iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1)));
+                const rn::u32x2 pk = ((const rn::u32x2 *)idx)[w];
+                const uint32_t rep = me * 0x01010101u;
+                // byte-wise compare: zero bytes of (pk ^ rep) are the channels whose arg-max is this element
+                const uint32_t d0 = pk.x ^ rep, d1 = pk.y ^ rep;
+                if (!(((d0 - 0x01010101u) & ~d0 & 0x80808080u) | ((d1 - 0x01010101u) & ~d1 & 0x80808080u))) continue;
+                float gv[8];
+                v8<DT>::ld(dy, w, gv);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    g[j] += (((d0 >> (8 * j)) & 0xffu) == 0u) ? gv[j] : 0.0f;
+                    g[j + 4] += (((d1 >> (8 * j)) & 0xffu) == 0u) ? gv[j + 4] : 0.0f;
+                }
+            }
+        }
+        v8<DT>::st(dx, i, g);
+    }
+}
+
+int pool_blocks(const int64_t n)
+{
+    int64_t b = (n + 255) / 256;
+    if (b > 16384) b = 16384;
+    return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+RN_API int rn_maxpool3x3s2_forward(const void *x, void *y, uint8_t *argmax, int dtype, int N, int H, int W, int C, void *stream)
+{
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return RN_EINVAL;
+    if (C % 8) return RN_EUNSUPPORTED;
+    if (dtype != RN_F32 && dtype != RN_BF16 && dtype != RN_F16) return RN_EINVAL;
+    if (!rn::aligned(x, 16) || !rn::aligned(y, 16) || (argmax && !rn::aligned(argmax, 8))) return RN_EALIGN;
+    const PoolShape s{N, H, W, C / 8, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
+    const dim3 g(pool_blocks((int64_t)N * s.OH * s.OW * s.C8)), b(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case RN_F32: hipLaunchKernelGGL((maxpool_fwd_kernel<RN_F32>), g, b, 0, st, x, y, argmax, s); break;
+        case RN_BF16: hipLaunchKernelGGL((maxpool_fwd_kernel<RN_BF16>), g, b, 0, st, x, y, argmax, s); break;
+        default: hipLaunchKernelGGL((maxpool_fwd_kernel<RN_F16>), g, b, 0, st, x, y, argmax, s); break;
+    }
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+RN_API int rn_maxpool3x3s2_backward(const uint8_t *argmax, const void *dy, void *dx, int dtype, int N, int H, int W, int C,
+                                    void *stream)
+{
+    if (!argmax || !dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0) return RN_EINVAL;
+    if (C % 8) return RN_EUNSUPPORTED;
+    if (dtype != RN_F32 && dtype != RN_BF16 && dtype != RN_F16) return RN_EINVAL;
+    if (!rn::aligned(argmax, 8) || !rn::aligned(dy, 16) || !rn::aligned(dx, 16)) return RN_EALIGN;
+    const PoolShape s{N, H, W, C / 8, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
+    const dim3 g(pool_blocks((int64_t)N * H * W * s.C8)), b(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case RN_F32: hipLaunchKernelGGL((maxpool_bwd_kernel<RN_F32>), g, b, 0, st, argmax, dy, dx, s); break;
+        case RN_BF16: hipLaunchKernelGGL((maxpool_bwd_kernel<RN_BF16>), g, b, 0, st, argmax, dy, dx, s); break;
+        default: hipLaunchKernelGGL((maxpool_bwd_kernel<RN_F16>), g, b, 0, st, argmax, dy, dx, s); break;
+    }
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}

@@ -66,3 +66,38 @@ def test_unfusable_inputs_take_the_torch_path():
     bn = bn.to(DEV)
     y = bn(x.to(DEV))                               # NCHW on the device: torch path too
     assert y.shape == x.shape
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 64, 17, 23), (1, 8, 1, 1), (3, 16, 8, 8), (2, 24, 5, 2)])
+@pytest.mark.parametrize("ties", [False, True])
+def test_fused_maxpool_matches_torch_bitwise(dtype, shape, ties):
+    """rn_maxpool3x3s2_* == F.max_pool2d forward and backward, bit for bit, incl. massive ties (small-integer data:
+    the first maximum of a window takes the gradient) and windows clipped by the border."""
+    from pytorch_retinanet_amd.pool import FusedMaxPool2d
+    torch.manual_seed(1)
+    N, C, H, W = shape
+    src = torch.randint(0, 3, (N, C, H, W), device=DEV).float() if ties else torch.randn(N, C, H, W, device=DEV)
+    x = src.to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    pool = FusedMaxPool2d(3, 2, 1)
+    y = pool(x)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    assert y.shape == yr.shape and torch.equal(y, yr)
+    g = torch.randn_like(yr)
+    y.backward(g)
+    yr.backward(g)
+    assert torch.equal(x.grad, xr.grad)
+
+
+def test_fused_maxpool_nan_follows_torch():
+    from pytorch_retinanet_amd.pool import FusedMaxPool2d
+    x = torch.randn(1, 8, 6, 6, device=DEV)
+    x[0, :, 2, 2] = float("nan"); x[0, 0, 3, 3] = float("nan")
+    x = x.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    y = FusedMaxPool2d(3, 2, 1)(x); yr = F.max_pool2d(xr, 3, 2, 1)
+    assert torch.equal(torch.isnan(y), torch.isnan(yr)) and torch.equal(torch.nan_to_num(y), torch.nan_to_num(yr))
+    g = torch.ones_like(yr)
+    y.backward(g); yr.backward(g)
+    assert torch.equal(x.grad, xr.grad)
