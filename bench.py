@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--gt", type=int, default=8, help="GT boxes per image")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-ddp", action="store_true", help="use the bucketed all-reduce path even at world size 1 (validation)")
+    ap.add_argument("--torch-sgd", action="store_true", help="fp32 parameters + torch.optim.SGD instead of fp32 masters + bf16 conv weights (optim.MasterSGD); same arithmetic")
     ap.add_argument("--cpu-baseline-reps", type=int, default=3)
     return ap.parse_args()
 
@@ -117,7 +118,12 @@ def main():
     torch.manual_seed(0)
     net = P.Retinanet(num_classes=90, backbone_kind=args.backbone, pretrained=False, min_size=800, max_size=1333)
     net = net.to(device).to(memory_format=torch.channels_last).train()
-    optimizer = torch.optim.SGD(net.parameters(), lr=1e-3, weight_decay=1e-3, momentum=0.9)   # hparams.yaml:63-68
+    if args.torch_sgd:
+        optimizer = torch.optim.SGD(net.parameters(), lr=1e-3, weight_decay=1e-3, momentum=0.9)   # hparams.yaml:63-68
+    else:   # the same SGD on fp32 masters; conv weights live in bf16 (what autocast would feed the convs anyway)
+        from pytorch_retinanet_amd.optim import MasterSGD, use_bf16_conv_weights
+        use_bf16_conv_weights(net)
+        optimizer = MasterSGD(net.parameters(), lr=1e-3, weight_decay=1e-3, momentum=0.9)
     ddp = P.BucketedGradAllReduce(net) if (world > 1 or args.force_ddp) else None
     images, targets = synth_batch(args.batch, args.gt, seed=rank, device=device)
 
@@ -132,7 +138,12 @@ def main():
         loss.backward()
         if ddp:
             ddp.finish()
-        optimizer.step()
+            if args.torch_sgd:
+                optimizer.step()
+            else:
+                optimizer.step(grads=ddp.grad_views())
+        else:
+            optimizer.step()
         return loss
 
     for _ in range(args.warmup):

@@ -197,6 +197,18 @@ int rn_maxpool3x3s2_forward(const void *x, void *y, uint8_t *argmax, int dtype, 
 int rn_maxpool3x3s2_backward(const uint8_t *argmax, const void *dy, void *dx, int dtype,
                              int N, int H, int W, int C, void *stream);
 
+/* ---- optimizer step: SGD on fp32 masters with a bf16 working copy, multi-tensor ------------------------------
+ * The update torch.optim.SGD performs (the reference's optimizer, hparams.yaml:63-68), in its order, in fp32:
+ *   g = grad + weight_decay * w;  buf = first_step ? g : momentum * buf + (1 - dampening) * g;
+ *   g = nesterov ? g + momentum * buf : buf;  w -= lr * g
+ * for n_tensors tensors in one launch per 48 (HOST arrays of device pointers / element counts).  params16[i]
+ * (nullable): bf16 copy of tensor i, rewritten as bf16(w) -- the conv weights the bf16 forward consumes, so that
+ * neither autocast's per-step weight casts nor the bf16 -> fp32 gradient casts are needed; when grads16 != 0 the
+ * gradient of a tensor WITH a 16-bit copy is bf16, every other gradient is f32. */
+int rn_sgd_master_step(float *const *masters, float *const *momenta, const void *const *grads, void *const *params16,
+                       const int64_t *numels, int n_tensors, int grads16, float lr, float momentum, float dampening,
+                       float weight_decay, int nesterov, int first_step, void *stream);
+
 /* ---- T1 transform (normalise + resize + pad + batch) -------------------------------------------
  * Replaces torchvision's GeneralizedRCNNTransform as the reference runs it at
  * retinanet/models.py:116 (construction), :262 and :279 (calls): per image (x - mean) / std, bilinear

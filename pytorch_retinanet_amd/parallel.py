@@ -51,8 +51,8 @@ class BucketedGradAllReduce:
         cap = int(bucket_mb * (1 << 20))
         group, size = [], 0
         for p in params:
-            nbytes = p.numel() * p.element_size()
-            if group and (size + nbytes > cap or p.dtype != group[0].dtype or p.device != group[0].device):
+            nbytes = p.numel() * self._grad_dtype(p).itemsize
+            if group and (size + nbytes > cap or self._grad_dtype(p) != self._grad_dtype(group[0]) or p.device != group[0].device):
                 self._make_bucket(group)
                 group, size = [], 0
             group.append(p)
@@ -62,18 +62,25 @@ class BucketedGradAllReduce:
         if sync_params and self.world > 1:
             self.sync_parameters()
 
+    @staticmethod
+    def _grad_dtype(p: torch.Tensor) -> torch.dtype:
+        # bf16 working copies of fp32 master weights (optim.use_bf16_conv_weights) exchange their gradients in fp32
+        return torch.float32 if hasattr(p, "master") else p.dtype
+
     def _make_bucket(self, params) -> None:
         total = sum(p.numel() for p in params)
-        flat = torch.zeros(total, dtype=params[0].dtype, device=params[0].device)
+        flat = torch.zeros(total, dtype=self._grad_dtype(params[0]), device=params[0].device)
         b = _Bucket(flat, params)
         off = 0
         for p in params:
             # same strides as the parameter (channels_last conv weights stay channels_last): autograd's gradient
             # layout contract, and the optimizer's multi-tensor kernels stay on their fast path
             dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
-            p.grad = torch.as_strided(flat, p.size(), p.stride(), off) if dense else flat[off: off + p.numel()].view_as(p)
+            view = torch.as_strided(flat, p.size(), p.stride(), off) if dense else flat[off: off + p.numel()].view_as(p)
+            if view.dtype == p.dtype:
+                p.grad = view
             off += p.numel()
-            self._owner[p] = (b, p.grad)
+            self._owner[p] = (b, view)
             p.register_post_accumulate_grad_hook(self._hook)
         self.buckets.append(b)
 
@@ -95,9 +102,10 @@ class BucketedGradAllReduce:
             elif p.grad.data_ptr() != view.data_ptr():
                 views.append(view)
                 grads.append(p.grad)
-            p.grad = view
+            if view.dtype == p.dtype:
+                p.grad = view              # (a bf16 working copy keeps its bf16 .grad; its exchanged gradient is grad_views()[p])
         if views:
-            torch._foreach_copy_(views, grads)
+            torch._foreach_copy_(views, grads)     # also promotes bf16 gradients into fp32 buckets
         b.launched = True
         if self.world == 1:
             return
@@ -126,11 +134,19 @@ class BucketedGradAllReduce:
             for p in b.params:
                 p.grad = None
 
+    def grad_views(self):
+        "``{parameter: its (averaged) gradient in the bucket}`` -- what ``optim.MasterSGD.step(grads=...)`` consumes."
+        return {p: view for p, (_, view) in self._owner.items()}
+
     def sync_parameters(self, src: int = 0) -> None:
         "Broadcast parameters and buffers from `src` so every rank starts from the same model."
         with torch.no_grad():
             for t in list(self.module.parameters()) + list(self.module.buffers()):
-                dist.broadcast(t.data, src=src, group=self.group)
+                if hasattr(t, "master"):
+                    dist.broadcast(t.master, src=src, group=self.group)
+                    t.data.copy_(t.master)
+                else:
+                    dist.broadcast(t.data, src=src, group=self.group)
 
     @property
     def num_buckets(self) -> int:

@@ -350,3 +350,35 @@ def test_head_mfma_towers_equal_miopen_towers_bf16():
         torch.testing.assert_close(b.float(), a.float(), rtol=1e-1, atol=5e-2 * float(a.float().abs().max()))
     for n, a in outs[False][2].items():
         torch.testing.assert_close(outs[True][2][n].float(), a.float(), rtol=1e-1, atol=5e-2 * float(a.float().abs().max()))
+
+
+@pytest.mark.parametrize("nesterov,dampening", [(False, 0.0), (True, 0.0), (False, 0.1)])
+def test_master_sgd_follows_torch_sgd_under_autocast(nesterov, dampening):
+    """fp32 masters + bf16 conv weights + MasterSGD == fp32 parameters + autocast + torch.optim.SGD: after several steps the
+    masters equal torch's fp32 weights (1e-6: torch's foreach kernels may contract mul+add), BN/bias parameters too."""
+    from pytorch_retinanet_amd.optim import MasterSGD, master_state_dict, use_bf16_conv_weights
+    from pytorch_retinanet_amd.norm import FusedBatchNorm2d
+
+    def make():
+        torch.manual_seed(11)
+        m = torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3, padding=1), FusedBatchNorm2d(16), torch.nn.ReLU(),
+                                torch.nn.Conv2d(16, 8, 1, bias=False)).to(DEV).to(memory_format=torch.channels_last)
+        return m.train()
+    a, b = make(), make()
+    kw = dict(lr=0.05, momentum=0.9, weight_decay=1e-2, nesterov=nesterov, dampening=dampening)
+    oa = torch.optim.SGD(a.parameters(), **kw)
+    assert use_bf16_conv_weights(b) == 2
+    ob = MasterSGD(b.parameters(), **kw)
+    x = torch.randn(4, 8, 12, 10, device=DEV).contiguous(memory_format=torch.channels_last)
+    for _ in range(4):
+        for m, o in ((a, oa), (b, ob)):
+            o.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = (m(x).float() ** 2).mean()
+            loss.backward()
+            o.step()
+    sa, sb = a.state_dict(), master_state_dict(b)
+    assert b[0].weight.dtype == torch.bfloat16 and sb["0.weight"].dtype == torch.float32
+    for k in sa:
+        torch.testing.assert_close(sb[k].float(), sa[k].float(), rtol=2e-5, atol=1e-6, msg=k)
+    assert torch.equal(b[0].weight.float(), sb["0.weight"].to(torch.bfloat16).float())      # working copy == bf16(master)
