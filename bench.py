@@ -202,7 +202,7 @@ def main():
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"RetinaNet-{args.backbone.replace('resnet', 'R')}-FPN bf16 train step, per-GPU batch "
                                    f"{args.batch} x 3x800x1333 (padded 800x1344), A=201600 anchors, K=90, T={args.gt} GT/img, "
-                                   f"SGD(momentum); random-init weights",
+                                   f"SGD(momentum{'' if args.torch_sgd else ', fp32 masters + bf16 conv weights'}); random-init weights",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
             "roofline": roof,
         }

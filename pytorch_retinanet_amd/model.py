@@ -116,7 +116,12 @@ class RetinaNetModel(_Base):
 
     # -- optimisation ----------------------------------------------------------------------------
     def configure_optimizers(self, *args, **kwargs):
-        self.optimizer = load_obj(self.conf.optimizer.class_name)(self.net.parameters(), **dict(self.conf.optimizer.params))
+        opt_cls = load_obj(self.conf.optimizer.class_name)
+        if getattr(opt_cls, "__name__", "") == "MasterSGD" and next(self.net.parameters()).is_cuda:
+            # optimizer.class_name: pytorch_retinanet_amd.optim.MasterSGD -- SGD on fp32 masters, conv weights held in bf16
+            from .optim import use_bf16_conv_weights
+            use_bf16_conv_weights(self.net)
+        self.optimizer = opt_cls(self.net.parameters(), **dict(self.conf.optimizer.params))
         sched = self.conf.scheduler
         if sched.class_name is None:
             return [self.optimizer]
@@ -212,7 +217,10 @@ class SimpleTrainer:
                 out["loss"].backward()
                 if ddp:
                     ddp.finish()
-                optimizer.step()
+                if ddp and type(optimizer).__name__ == "MasterSGD":
+                    optimizer.step(grads=ddp.grad_views())       # fp32 bucket views of the bf16 working copies
+                else:
+                    optimizer.step()
                 step += 1
                 if step % self.log_every == 0:
                     self.log.info("epoch %d step %d loss %.4f", epoch, step, float(out["loss"]))

@@ -94,3 +94,29 @@ def test_bucket_layout_single_process():
     assert all(g.shape == w.shape for g, w in zip(model2_grads, want))
     for p in params:
         assert any(b.flat.data_ptr() <= p.grad.data_ptr() < b.flat.data_ptr() + b.flat.numel() * 4 for b in ddp.buckets)
+
+
+def test_buckets_exchange_bf16_working_copies_in_fp32():
+    """A bf16 parameter that carries an fp32 master (optim.use_bf16_conv_weights) gets an fp32 bucket: its bf16 gradient is
+    promoted on the way in, and the optimizer reads it through grad_views()."""
+    from pytorch_retinanet_amd.parallel import BucketedGradAllReduce
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3, padding=1), torch.nn.Conv2d(4, 2, 1))
+    w = model[0].weight
+    master = w.data.clone()
+    w.data = master.to(torch.bfloat16)
+    w.master = master
+    ddp = BucketedGradAllReduce(model, bucket_mb=1.0)
+    assert all(b.flat.dtype == torch.float32 for b in ddp.buckets) and w.grad is None
+    x = torch.randn(2, 3, 5, 5)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        y = model(x)
+    y.float().sum().backward()
+    g16 = w.grad.clone()
+    assert g16.dtype == torch.bfloat16
+    ddp.finish()
+    views = ddp.grad_views()
+    assert views[w].dtype == torch.float32 and torch.equal(views[w], g16.float())
+    assert model[1].weight.grad.data_ptr() == views[model[1].weight].data_ptr()       # fp32 parameters: .grad IS the view
+    ddp.zero_grad()
+    assert w.grad is None
