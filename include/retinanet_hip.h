@@ -188,6 +188,13 @@ int rn_conv3x3_canvas_batched(const void *const *xs, const void *const *ws, cons
                               const uint8_t *mask, void *const *ys, int P, int dtype, int64_t M, int64_t HWp,
                               int Wp, int Cin, int Cout, int relu, void *stream);
 
+/* The same kernel on an ordinary dense channels-last tensor [N][H][W][C] (no border, no mask): out-of-image taps
+ * read `zeros` (>= 256 bytes of zeros, 16-byte aligned, caller-owned).  Used for the stride-1 3x3 convs of the
+ * backbone (retinanet/backbone.py:112-114, conv2 of layer3) and the FPN smoothing convs (retinanet/layers.py:23-28)
+ * where it beats MIOpen (M = N*H*W >= ~30 000 positions, Cin % 64 == 0, Cout % 256 == 0, bf16). */
+int rn_conv3x3_nhwc(const void *x, const void *w, const float *bias, void *y, int dtype, int N, int H, int W,
+                    int Cin, int Cout, int relu, const void *zeros, void *stream);
+
 /* ---- stem max pooling, channels-last, no index tensor -------------------------------------------------
  * nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the reference's stem (retinanet/backbone.py:251) on
  * [N][H][W][C] activations (C % 8 == 0), y: [N][(H-1)/2+1][(W-1)/2+1][C].  argmax (u8, shape of y, nullable for

@@ -12,6 +12,7 @@ padding 1 never mixes levels as long as the gaps hold zeros, which the epilogue'
 after every layer.
 """
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -293,3 +294,80 @@ def pack_levels(canvas: Canvas, feature_maps: Sequence[Tensor]) -> Tensor:
 
 def unpack_levels(canvas: Canvas, x: Tensor) -> List[Tensor]:
     return list(_Unpack.apply(canvas, x))
+
+
+# ---------------------------------------------------------------------------------------------------
+# The MFMA conv on ordinary dense tensors (stride-1 3x3 convs of layer3 and the FPN smoothing convs)
+_ZEROS: Dict[int, Tensor] = {}
+
+
+def _zero_page(dev: torch.device) -> Tensor:
+    z = _ZEROS.get(dev.index)
+    if z is None:
+        z = _ZEROS[dev.index] = torch.zeros((256,), dtype=torch.uint8, device=dev)
+    return z
+
+
+class _Conv3x3Dense(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        N, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        dev = x.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        if not _cl(w):
+            w = w.contiguous(memory_format=torch.channels_last)
+        y = torch.empty((N, Cout, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+        check(lib.rn_conv3x3_nhwc(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else 0, y.data_ptr(), _DT[x.dtype],
+                                  N, H, W, Cin, Cout, 0, _zero_page(dev).data_ptr(), stream), "rn_conv3x3_nhwc")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        N, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        dev = x.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        if dy.dtype != x.dtype or not _cl(dy):
+            dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0] and Cin % 256 == 0:
+            wt = w.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+            dx = torch.empty_like(x)
+            check(lib.rn_conv3x3_nhwc(dy.data_ptr(), wt.data_ptr(), 0, dx.data_ptr(), _DT[x.dtype], N, H, W, Cout, Cin, 0,
+                                      _zero_page(dev).data_ptr(), stream), "rn_conv3x3_nhwc")
+        need = [ctx.needs_input_grad[0] and dx is None, ctx.needs_input_grad[1], False]
+        if need[0] or need[1]:
+            r = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, need)
+            dx = r[0] if need[0] else dx
+            dw = r[1] if need[1] else None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty((Cout,), dtype=torch.float32, device=dev)
+            wp, wn = _workspace(dev, stream, Cout)
+            check(lib.rn_bias_act_backward(dy.data_ptr(), 0, 0, 0, db.data_ptr(), _DT[x.dtype], N * H * W, Cout, 1, 0, wp, wn, stream),
+                  "rn_bias_act_backward")
+        return dx, dw, db
+
+
+MFMA_CONV_MIN_POSITIONS = 30000       # below this the kernel's 256-row tiles leave most CUs idle and MIOpen is as fast
+# Off by default: in isolation the kernel beats MIOpen on these shapes (layer3 conv2 78 vs 122 us, FPN P3 232 vs 272 us),
+# but inside the train step the A/B is a tie (211.3 vs 211.4 images/s on one box), so the stock path stays.  RN_MFMA_CONV=1.
+MFMA_DENSE_CONV = os.environ.get("RN_MFMA_CONV", "0") == "1"
+
+
+def conv3x3(conv, x: Tensor) -> Tensor:
+    """``conv(x)`` for a 3x3 / stride-1 / pad-1 ``nn.Conv2d``: on the MFMA kernel when it is the faster one (bf16 CUDA
+    channels-last input, Cin % 64 == 0, Cout % 256 == 0, >= 30 000 output positions), else the module itself."""
+    if (x.is_cuda and x.dtype == torch.bfloat16 and _cl(x) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels % 64 == 0
+            and conv.out_channels % 256 == 0 and x.shape[0] * x.shape[2] * x.shape[3] >= MFMA_CONV_MIN_POSITIONS
+            and (conv.bias is None or conv.bias.dtype == torch.float32) and MFMA_DENSE_CONV):
+        return _Conv3x3Dense.apply(x, conv.weight.to(x.dtype), conv.bias)
+    return conv(x)

@@ -42,10 +42,12 @@ struct ConvArgs {
     const float *biases[CONV_MAX_PROBLEMS];     // [Cout] or null
     uint16_t *Ys[CONV_MAX_PROBLEMS];            // [M][Cout] bf16
     const uint8_t *mask;    // [HWp] or null (1 = keep)
+    const uint16_t *zeros;  // dense mode: >= 256 B of zeros, the source of out-of-image taps
     int64_t M, HWp;
     int Cin, Cout, Wp, relu;
+    int H;                  // 0: zero-bordered canvas (no bounds logic); > 0: dense [N][H][Wp] image, taps checked
 };
-struct ConvProblem { const uint16_t *X, *W; const float *bias; uint16_t *Y; const uint8_t *mask; int64_t M, HWp; int Cin, Cout, Wp, relu; };
+struct ConvProblem { const uint16_t *X, *W; const float *bias; uint16_t *Y; const uint8_t *mask; const uint16_t *zeros; int64_t M, HWp; int Cin, Cout, Wp, relu, H; };
 
 __device__ __forceinline__ uint16_t f2bf(const float f) { return (uint16_t)(rn::dt<RN_BF16>::pk(f, 0.0f) & 0xffffu); }
 
@@ -54,6 +56,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     ConvProblem a;
     a.X = args.Xs[blockIdx.z]; a.W = args.Ws[blockIdx.z]; a.bias = args.biases[blockIdx.z]; a.Y = args.Ys[blockIdx.z];
     a.mask = args.mask; a.M = args.M; a.HWp = args.HWp; a.Cin = args.Cin; a.Cout = args.Cout; a.Wp = args.Wp; a.relu = args.relu;
+    a.zeros = args.zeros; a.H = args.H;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];                 // [A0 A1 A2 | B0 B1] x 32 KiB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -82,6 +85,24 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
 
+    // dense mode: which of the 9 taps of this thread's 4 staging rows fall inside the image (bit t of tapmask[i])
+    uint32_t tapmask[4] = {0x1ffu, 0x1ffu, 0x1ffu, 0x1ffu};
+    if (a.H > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t m = m0 + ((i * CONV_THREADS + tid) >> 3);
+            uint32_t bits = 0;
+            if (m < a.M) {
+                const int pos = (int)(m % a.HWp), y = pos / a.Wp, x = pos - y * a.Wp;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                    bits |= (yy >= 0 && yy < a.H && xx >= 0 && xx < a.Wp) ? (1u << t) : 0u;
+                }
+            }
+            tapmask[i] = bits;
+        }
+    }
     auto piece_a = [&](const int kt, const int i) {
         const int c0 = (kt / 9) * CONV_BK, t = kt % 9;
         const int off = (t / 3 - 1) * a.Wp + (t % 3 - 1);
@@ -89,6 +110,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
         int64_t m = m0 + row + off;
         m = m < 0 ? 0 : (m >= a.M ? a.M - 1 : m);
         const uint16_t *g = a.X + m * a.Cin + c0 + ((cp ^ SWZ(row)) << 3);
+        if (a.H > 0 && !((tapmask[i] >> t) & 1u)) g = a.zeros + ((cp ^ SWZ(row)) << 3);       // zero padding
         __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)(Abase + (kt % 3) * TILE + q * 16), 16, 0, 0);
     };
     auto piece_b = [&](const int kt, const int i) {
@@ -188,12 +210,13 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
 
 }  // namespace
 
-RN_API int rn_conv3x3_canvas_batched(const void *const *xs, const void *const *ws, const float *const *biases,
-                                     const uint8_t *mask, void *const *ys, int P, int dtype, int64_t M, int64_t HWp, int Wp,
-                                     int Cin, int Cout, int relu, void *stream)
+static int conv_launch(const void *const *xs, const void *const *ws, const float *const *biases, const uint8_t *mask,
+                       void *const *ys, int P, int dtype, int64_t M, int64_t HWp, int Wp, int Cin, int Cout, int relu, int H,
+                       const void *zeros, void *stream)
 {
     if (!xs || !ws || !ys || P <= 0 || P > CONV_MAX_PROBLEMS || M <= 0 || HWp <= 0 || Wp <= 0 || Cin <= 0 || Cout <= 0) return RN_EINVAL;
     if (dtype != RN_BF16 || Cin % CONV_BK || Cout % CONV_BN) return RN_EUNSUPPORTED;
+    if (H > 0 && (!zeros || !rn::aligned(zeros, 16))) return RN_EINVAL;
     ConvArgs a;
     for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) {
         const int q = p < P ? p : 0;
@@ -212,10 +235,28 @@ RN_API int rn_conv3x3_canvas_batched(const void *const *xs, const void *const *w
         }
     }
     a.mask = mask; a.M = M; a.HWp = HWp; a.Cin = Cin; a.Cout = Cout; a.Wp = Wp; a.relu = relu ? 1 : 0;
+    a.H = H; a.zeros = (const uint16_t *)zeros;
     const dim3 grid((unsigned)((M + CONV_BM - 1) / CONV_BM), (unsigned)(Cout / CONV_BN), (unsigned)P);
     hipLaunchKernelGGL(conv3x3_canvas_kernel, grid, dim3(CONV_THREADS), CONV_LDS_BYTES, (hipStream_t)stream, a);
     RN_LAUNCH_CHECK();
     return RN_OK;
+}
+
+RN_API int rn_conv3x3_canvas_batched(const void *const *xs, const void *const *ws, const float *const *biases,
+                                     const uint8_t *mask, void *const *ys, int P, int dtype, int64_t M, int64_t HWp, int Wp,
+                                     int Cin, int Cout, int relu, void *stream)
+{
+    return conv_launch(xs, ws, biases, mask, ys, P, dtype, M, HWp, Wp, Cin, Cout, relu, 0, nullptr, stream);
+}
+
+RN_API int rn_conv3x3_nhwc(const void *x, const void *w, const float *bias, void *y, int dtype, int N, int H, int W, int Cin,
+                           int Cout, int relu, const void *zeros, void *stream)
+{
+    if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0) return RN_EINVAL;
+    const void *xs[1] = {x}, *ws[1] = {w};
+    const float *bs[1] = {bias};
+    void *ys[1] = {y};
+    return conv_launch(xs, ws, bs, nullptr, ys, 1, dtype, (int64_t)N * H * W, (int64_t)H * W, W, Cin, Cout, relu, H, zeros, stream);
 }
 
 RN_API int rn_conv3x3_canvas(const void *x, const void *w, const float *bias, const uint8_t *mask, void *y, int dtype,

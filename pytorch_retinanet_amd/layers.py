@@ -48,7 +48,8 @@ class FeaturePyramid(nn.Module):
         p3 = self.conv_c3_1x1(c3) + self.upsample_2x(p4)
         p6 = self.conv_c6_3x3(c5)
         p7 = self.conv_c7_3x3(F.relu(p6))
-        return [self.conv_c3_3x3(p3), self.conv_c4_3x3(p4), self.conv_c5_3x3(p5), p6, p7]
+        c3 = biasact.conv3x3                # MFMA kernel where it beats MIOpen (P3, P4 of the R50 config), else the module
+        return [c3(self.conv_c3_3x3, p3), c3(self.conv_c4_3x3, p4), c3(self.conv_c5_3x3, p5), p6, p7]
 
 
 def _tower(in_channels: int, out_channels: int) -> nn.Sequential:

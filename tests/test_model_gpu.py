@@ -382,3 +382,32 @@ def test_master_sgd_follows_torch_sgd_under_autocast(nesterov, dampening):
     for k in sa:
         torch.testing.assert_close(sb[k].float(), sa[k].float(), rtol=2e-5, atol=1e-6, msg=k)
     assert torch.equal(b[0].weight.float(), sb["0.weight"].to(torch.bfloat16).float())      # working copy == bf16(master)
+
+
+@pytest.mark.parametrize("shape,bias", [((2, 256, 256, 11, 13), True), ((1, 64, 256, 9, 40), False), ((3, 256, 512, 5, 6), True)])
+def test_mfma_dense_conv_vs_torch(shape, bias):
+    "rn_conv3x3_nhwc (zero padding by bounds-checked taps) forward + gradients vs torch conv2d on the same bf16 values."
+    from pytorch_retinanet_amd import biasact
+    torch.manual_seed(2)
+    N, Cin, Cout, H, W = shape
+    conv = torch.nn.Conv2d(Cin, Cout, 3, padding=1, bias=bias).to(DEV).to(memory_format=torch.channels_last)
+    x = torch.randn(N, Cin, H, W, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    old, old_on = biasact.MFMA_CONV_MIN_POSITIONS, biasact.MFMA_DENSE_CONV
+    biasact.MFMA_CONV_MIN_POSITIONS, biasact.MFMA_DENSE_CONV = 0, True
+    try:
+        y = biasact.conv3x3(conv, x)
+        assert y.grad_fn is not None and "Conv3x3Dense" in type(y.grad_fn).__name__
+        g = torch.randn_like(y)
+        y.backward(g)
+    finally:
+        biasact.MFMA_CONV_MIN_POSITIONS, biasact.MFMA_DENSE_CONV = old, old_on
+    xr = x.detach().float().requires_grad_(True)
+    wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    br = conv.bias.detach().clone().requires_grad_(True) if bias else None
+    yr = torch.nn.functional.conv2d(xr, wr, br, padding=1)
+    yr.backward(g.float())
+    torch.testing.assert_close(y.float(), yr, rtol=2e-2, atol=1e-2 * float(yr.detach().abs().max()))
+    torch.testing.assert_close(x.grad.float(), xr.grad, rtol=5e-2, atol=2e-2 * float(xr.grad.abs().max()))
+    torch.testing.assert_close(conv.weight.grad.float(), wr.grad, rtol=5e-2, atol=2e-2 * float(wr.grad.abs().max()))
+    if bias:
+        torch.testing.assert_close(conv.bias.grad, br.grad, rtol=2e-2, atol=2e-2 * float(br.grad.abs().max()))
