@@ -195,6 +195,12 @@ int rn_conv3x3_canvas_batched(const void *const *xs, const void *const *ws, cons
 int rn_conv3x3_nhwc(const void *x, const void *w, const float *bias, void *y, int dtype, int N, int H, int W,
                     int Cin, int Cout, int relu, const void *zeros, void *stream);
 
+/* 1x1 / stride-1 convolution = the GEMM Y[M][Cout] = X[M][Cin] * W[Cout][Cin]^T (+ bias) on the same MFMA pipeline
+ * (bf16, Cin % 64 == 0 and >= 128, Cout % 256 == 0).  Opt-in experiment for the bottleneck 1x1 convs
+ * (retinanet/backbone.py:111-116). */
+int rn_conv1x1_nhwc(const void *x, const void *w, const float *bias, void *y, int dtype, int64_t M, int Cin, int Cout,
+                    void *stream);
+
 /* ---- stem max pooling, channels-last, no index tensor -------------------------------------------------
  * nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the reference's stem (retinanet/backbone.py:251) on
  * [N][H][W][C] activations (C % 8 == 0), y: [N][(H-1)/2+1][(W-1)/2+1][C].  argmax (u8, shape of y, nullable for

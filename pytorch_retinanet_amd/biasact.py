@@ -371,3 +371,54 @@ def conv3x3(conv, x: Tensor) -> Tensor:
             and (conv.bias is None or conv.bias.dtype == torch.float32) and MFMA_DENSE_CONV):
         return _Conv3x3Dense.apply(x, conv.weight.to(x.dtype), conv.bias)
     return conv(x)
+
+
+class _Conv1x1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        N, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        dev = x.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        y = torch.empty((N, Cout, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+        check(lib.rn_conv1x1_nhwc(x.data_ptr(), w.data_ptr(), 0, y.data_ptr(), _DT[x.dtype], N * H * W, Cin, Cout,
+                                  torch.cuda.current_stream().cuda_stream), "rn_conv1x1_nhwc")
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        N, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        dev = x.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        if dy.dtype != x.dtype or not _cl(dy):
+            dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        dx = dw = None
+        if ctx.needs_input_grad[0] and Cin % 256 == 0 and Cout >= 128:
+            wt = w.reshape(Cout, Cin).t().contiguous()                      # [Cin][Cout]
+            dx = torch.empty_like(x)
+            check(lib.rn_conv1x1_nhwc(dy.data_ptr(), wt.data_ptr(), 0, dx.data_ptr(), _DT[x.dtype], N * H * W, Cout, Cin,
+                                      torch.cuda.current_stream().cuda_stream), "rn_conv1x1_nhwc")
+        need = [ctx.needs_input_grad[0] and dx is None, ctx.needs_input_grad[1], False]
+        if need[0] or need[1]:
+            r = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, need)
+            dx = r[0] if need[0] else dx
+            dw = r[1] if need[1] else None
+        return dx, dw
+
+
+MFMA_CONV1X1 = os.environ.get("RN_MFMA_1X1", "0") == "1"
+
+
+def conv1x1(conv, x: Tensor) -> Tensor:
+    "``conv(x)`` for a bias-free 1x1 / stride-1 ``nn.Conv2d``; opt-in (RN_MFMA_1X1=1) MFMA GEMM path for A/B measurements."
+    if (MFMA_CONV1X1 and x.is_cuda and x.dtype == torch.bfloat16 and _cl(x) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+            and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and conv.in_channels % 64 == 0
+            and conv.in_channels >= 128 and conv.out_channels % 256 == 0):
+        w = conv.weight.to(x.dtype)
+        return _Conv1x1.apply(x, w if w.is_contiguous() or _cl(w) else w.contiguous())
+    return conv(x)

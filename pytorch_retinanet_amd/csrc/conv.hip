@@ -46,8 +46,9 @@ struct ConvArgs {
     int64_t M, HWp;
     int Cin, Cout, Wp, relu;
     int H;                  // 0: zero-bordered canvas (no bounds logic); > 0: dense [N][H][Wp] image, taps checked
+    int taps;               // 9: 3x3 conv; 1: 1x1 conv = plain GEMM Y[M][Cout] = X[M][Cin] * W[Cout][Cin]^T
 };
-struct ConvProblem { const uint16_t *X, *W; const float *bias; uint16_t *Y; const uint8_t *mask; const uint16_t *zeros; int64_t M, HWp; int Cin, Cout, Wp, relu, H; };
+struct ConvProblem { const uint16_t *X, *W; const float *bias; uint16_t *Y; const uint8_t *mask; const uint16_t *zeros; int64_t M, HWp; int Cin, Cout, Wp, relu, H, taps; };
 
 __device__ __forceinline__ uint16_t f2bf(const float f) { return (uint16_t)(rn::dt<RN_BF16>::pk(f, 0.0f) & 0xffffu); }
 
@@ -56,13 +57,13 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     ConvProblem a;
     a.X = args.Xs[blockIdx.z]; a.W = args.Ws[blockIdx.z]; a.bias = args.biases[blockIdx.z]; a.Y = args.Ys[blockIdx.z];
     a.mask = args.mask; a.M = args.M; a.HWp = args.HWp; a.Cin = args.Cin; a.Cout = args.Cout; a.Wp = args.Wp; a.relu = args.relu;
-    a.zeros = args.zeros; a.H = args.H;
+    a.zeros = args.zeros; a.H = args.H; a.taps = args.taps;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];                 // [A0 A1 A2 | B0 B1] x 32 KiB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const int64_t m0 = (int64_t)blockIdx.x * CONV_BM;
     const int n0 = blockIdx.y * CONV_BN;
-    const int cpt = a.Cin / CONV_BK, KT = 9 * cpt;
+    const int cpt = a.Cin / CONV_BK, KT = a.taps * cpt;
     constexpr int TILE = CONV_BM * CONV_BK * 2;
     unsigned char *const Abase = lds, *const Bbase = lds + 3 * TILE;
 
@@ -104,8 +105,8 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
         }
     }
     auto piece_a = [&](const int kt, const int i) {
-        const int c0 = (kt / 9) * CONV_BK, t = kt % 9;
-        const int off = (t / 3 - 1) * a.Wp + (t % 3 - 1);
+        const int c0 = (kt / a.taps) * CONV_BK, t = kt % a.taps;
+        const int off = a.taps == 1 ? 0 : (t / 3 - 1) * a.Wp + (t % 3 - 1);
         const int q = i * CONV_THREADS + tid, row = q >> 3, cp = q & 7;
         int64_t m = m0 + row + off;
         m = m < 0 ? 0 : (m >= a.M ? a.M - 1 : m);
@@ -114,9 +115,9 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
         __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)(Abase + (kt % 3) * TILE + q * 16), 16, 0, 0);
     };
     auto piece_b = [&](const int kt, const int i) {
-        const int c0 = (kt / 9) * CONV_BK, t = kt % 9;
+        const int c0 = (kt / a.taps) * CONV_BK, t = kt % a.taps;
         const int q = i * CONV_THREADS + tid, row = q >> 3, cp = q & 7;
-        const uint16_t *g = a.W + ((int64_t)(n0 + row) * 9 + t) * a.Cin + c0 + ((cp ^ SWZ(row)) << 3);
+        const uint16_t *g = a.W + ((int64_t)(n0 + row) * a.taps + t) * a.Cin + c0 + ((cp ^ SWZ(row)) << 3);
         __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)(Bbase + (kt & 1) * TILE + q * 16), 16, 0, 0);
     };
 #pragma unroll
@@ -212,8 +213,9 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
 
 static int conv_launch(const void *const *xs, const void *const *ws, const float *const *biases, const uint8_t *mask,
                        void *const *ys, int P, int dtype, int64_t M, int64_t HWp, int Wp, int Cin, int Cout, int relu, int H,
-                       const void *zeros, void *stream)
+                       const void *zeros, void *stream, int taps = 9)
 {
+    if (taps * (Cin / CONV_BK) < 2) return RN_EUNSUPPORTED;         // the pipeline keeps two K-tiles in flight
     if (!xs || !ws || !ys || P <= 0 || P > CONV_MAX_PROBLEMS || M <= 0 || HWp <= 0 || Wp <= 0 || Cin <= 0 || Cout <= 0) return RN_EINVAL;
     if (dtype != RN_BF16 || Cin % CONV_BK || Cout % CONV_BN) return RN_EUNSUPPORTED;
     if (H > 0 && (!zeros || !rn::aligned(zeros, 16))) return RN_EINVAL;
@@ -235,7 +237,7 @@ static int conv_launch(const void *const *xs, const void *const *ws, const float
         }
     }
     a.mask = mask; a.M = M; a.HWp = HWp; a.Cin = Cin; a.Cout = Cout; a.Wp = Wp; a.relu = relu ? 1 : 0;
-    a.H = H; a.zeros = (const uint16_t *)zeros;
+    a.H = H; a.zeros = (const uint16_t *)zeros; a.taps = taps;
     const dim3 grid((unsigned)((M + CONV_BM - 1) / CONV_BM), (unsigned)(Cout / CONV_BN), (unsigned)P);
     hipLaunchKernelGGL(conv3x3_canvas_kernel, grid, dim3(CONV_THREADS), CONV_LDS_BYTES, (hipStream_t)stream, a);
     RN_LAUNCH_CHECK();
@@ -267,4 +269,14 @@ RN_API int rn_conv3x3_canvas(const void *x, const void *w, const float *bias, co
     const float *bs[1] = {bias};
     void *ys[1] = {y};
     return rn_conv3x3_canvas_batched(xs, ws, bs, mask, ys, 1, dtype, M, HWp, Wp, Cin, Cout, relu, stream);
+}
+
+RN_API int rn_conv1x1_nhwc(const void *x, const void *w, const float *bias, void *y, int dtype, int64_t M, int Cin, int Cout,
+                           void *stream)
+{
+    if (!x || !w || !y || M <= 0) return RN_EINVAL;
+    const void *xs[1] = {x}, *ws[1] = {w};
+    const float *bs[1] = {bias};
+    void *ys[1] = {y};
+    return conv_launch(xs, ws, bs, nullptr, ys, 1, dtype, M, M, 1, Cin, Cout, 0, 0, nullptr, stream, 1);
 }

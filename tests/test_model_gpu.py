@@ -411,3 +411,29 @@ def test_mfma_dense_conv_vs_torch(shape, bias):
     torch.testing.assert_close(conv.weight.grad.float(), wr.grad, rtol=5e-2, atol=2e-2 * float(wr.grad.abs().max()))
     if bias:
         torch.testing.assert_close(conv.bias.grad, br.grad, rtol=2e-2, atol=2e-2 * float(br.grad.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 1024, 9, 13), (1, 1024, 256, 7, 40), (3, 128, 512, 5, 6)])
+def test_mfma_conv1x1_vs_torch(shape):
+    "rn_conv1x1_nhwc (the MFMA pipeline as a plain GEMM) forward + gradients vs torch."
+    from pytorch_retinanet_amd import biasact
+    torch.manual_seed(3)
+    N, Cin, Cout, H, W = shape
+    conv = torch.nn.Conv2d(Cin, Cout, 1, bias=False).to(DEV).to(memory_format=torch.channels_last)
+    x = torch.randn(N, Cin, H, W, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    old = biasact.MFMA_CONV1X1
+    biasact.MFMA_CONV1X1 = True
+    try:
+        y = biasact.conv1x1(conv, x)
+        assert "Conv1x1" in type(y.grad_fn).__name__
+        g = torch.randn_like(y)
+        y.backward(g)
+    finally:
+        biasact.MFMA_CONV1X1 = old
+    xr = x.detach().float().requires_grad_(True)
+    wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr)
+    yr.backward(g.float())
+    torch.testing.assert_close(y.float(), yr, rtol=2e-2, atol=1e-2 * float(yr.detach().abs().max()))
+    torch.testing.assert_close(x.grad.float(), xr.grad, rtol=5e-2, atol=2e-2 * float(xr.grad.abs().max()))
+    torch.testing.assert_close(conv.weight.grad.float(), wr.grad, rtol=5e-2, atol=2e-2 * float(wr.grad.abs().max()))
