@@ -188,6 +188,17 @@ int rn_conv3x3_canvas_batched(const void *const *xs, const void *const *ws, cons
                               const uint8_t *mask, void *const *ys, int P, int dtype, int64_t M, int64_t HWp,
                               int Wp, int Cin, int Cout, int relu, void *stream);
 
+/* Weight gradient of the canvas convolution for P <= 4 problems (256 -> 256 channels, bf16):
+ *   dw[p][n][3][3][c] = sum_m g[p][m][n] * x[p][m + tap offset][c]
+ * g: gradient at the conv OUTPUT (already masked: zero on border / gap positions), x: the conv input canvas; both
+ * [M][256] bf16; dw: [256][3][3][256] bf16 (channels-last memory of a [Cout, Cin, 3, 3] weight gradient).  A position-
+ * contraction MFMA GEMM (transposed LDS fragment reads) split over the positions, plus a reduction of the splits;
+ * workspace: rn_conv3x3_wgrad_workspace_bytes(P, M); zeros: >= 256 bytes of zeros. */
+size_t rn_conv3x3_wgrad_workspace_bytes(int P, int64_t M);
+int rn_conv3x3_canvas_wgrad_batched(const void *const *gs, const void *const *xs, void *const *dws, int P, int dtype,
+                                    int64_t M, int Wp, int Cin, int Cout, const void *zeros, void *workspace,
+                                    size_t workspace_bytes, void *stream);
+
 /* The same kernel on an ordinary dense channels-last tensor [N][H][W][C] (no border, no mask): out-of-image taps
  * read `zeros` (>= 256 bytes of zeros, 16-byte aligned, caller-owned).  Used for the stride-1 3x3 convs of the
  * backbone (retinanet/backbone.py:112-114, conv2 of layer3) and the FPN smoothing convs (retinanet/layers.py:23-28)

@@ -78,6 +78,32 @@ class _BiasAct(torch.autograd.Function):
         return dx, dbias, None, None
 
 
+_WG_WS: Dict[tuple, Tensor] = {}
+MFMA_WGRAD = os.environ.get("RN_MFMA_WGRAD", "1") != "0"      # weight gradient of the canvas convs on the MFMA kernel (0: MIOpen)
+
+
+def _canvas_wgrad(gs, xs, ws, Wp: int, stream: int):
+    """Weight gradients of P canvas convs (256 -> 256, bf16) by ``rn_conv3x3_canvas_wgrad_batched``; None when the
+    shapes are outside the kernel's range (the caller then asks MIOpen)."""
+    x0, w0 = xs[0], ws[0]
+    if not (MFMA_WGRAD and x0.dtype == torch.bfloat16 and tuple(w0.shape) == (256, 256, 3, 3)):
+        return None
+    dev = x0.device
+    N, _, Hp, _ = x0.shape
+    M = N * Hp * Wp
+    P = len(gs)
+    need = lib.rn_conv3x3_wgrad_workspace_bytes(P, M)
+    key = (dev.index, stream)
+    wsb = _WG_WS.get(key)
+    if wsb is None or wsb.numel() < need:
+        wsb = _WG_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
+    dws = [torch.empty((256, 256, 3, 3), dtype=x0.dtype, device=dev, memory_format=torch.channels_last) for _ in range(P)]
+    check(lib.rn_conv3x3_canvas_wgrad_batched(_ptr_array(gs), _ptr_array(xs), _ptr_array(dws), P, _DT[x0.dtype], M, Wp, 256, 256,
+                                              _zero_page(dev).data_ptr(), wsb.data_ptr(), wsb.numel(), stream),
+          "rn_conv3x3_canvas_wgrad_batched")
+    return dws
+
+
 class _TowerConv(torch.autograd.Function):
     """relu(conv3x3(x, w) + bias) * mask on a zero-bordered canvas: forward and data gradient are the hand-written
     MFMA implicit GEMM (``rn_conv3x3_canvas``), the weight gradient is MIOpen's."""
@@ -121,11 +147,14 @@ class _TowerConv(torch.autograd.Function):
             dx = torch.empty_like(x)
             check(lib.rn_conv3x3_canvas(g.data_ptr(), wt.data_ptr(), 0, mask.data_ptr(), dx.data_ptr(), _DT[x.dtype],
                                         M, Hp * Wp, Wp, Cout, Cin, 0, stream), "rn_conv3x3_canvas")
-        need = [ctx.needs_input_grad[0] and dx is None, ctx.needs_input_grad[1], False]
+        if ctx.needs_input_grad[1]:
+            r = _canvas_wgrad([g], [x], [w], Wp, stream)
+            dw = r[0] if r is not None else None
+        need = [ctx.needs_input_grad[0] and dx is None, ctx.needs_input_grad[1] and dw is None, False]
         if need[0] or need[1]:
             r = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, need)
             dx = r[0] if need[0] else dx
-            dw = r[1] if need[1] else None
+            dw = r[1] if need[1] else dw
         return dx, dw, dbias, None
 
 
@@ -180,8 +209,10 @@ class _TowerConvPair(torch.autograd.Function):
             dxs = [torch.empty_like(x0), torch.empty_like(x1)]
             check(lib.rn_conv3x3_canvas_batched(_ptr_array(gs), _ptr_array(wts), None, mask.data_ptr(), _ptr_array(dxs), 2,
                                                 _DT[x0.dtype], M, Hp * Wp, Wp, Cout, Cin, 0, stream), "rn_conv3x3_canvas_batched")
-        dws = [torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
-               for g, x, w in ((gs[0], x0, w0), (gs[1], x1, w1))]
+        dws = _canvas_wgrad(gs, [x0, x1], [w0, w1], Wp, stream)
+        if dws is None:
+            dws = [torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+                   for g, x, w in ((gs[0], x0, w0), (gs[1], x1, w1))]
         return dxs[0], dxs[1], dws[0], dws[1], dbs[0], dbs[1], None
 
 

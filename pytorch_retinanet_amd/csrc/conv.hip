@@ -209,6 +209,182 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     }
 }
 
+
+// ================================================================================================================
+// Weight gradient of the same convolution: dW[n][t][c] = sum_m G[m][n] * X[m + off_t][c]   (G = gradient at the conv
+// output, zero on border / gap positions).  A GEMM whose contraction index is the POSITION m, so both operands are
+// k-strided in memory ([m][channel] rows): the tiles are staged exactly as they lie in memory (64 positions x 256
+// channels, 512-byte rows, LDS-DMA) and the MFMA fragments are read with the transposing ds_read_b64_tr_b16 (a 16-lane
+// group reads a 4-position x 16-channel block and every lane receives one channel's 4 positions; two reads make the
+// 8-deep k fragment).  16-byte chunks of a row are XOR-swizzled with (row & 3) << 2 (source side + read side), which
+// spreads the 4 rows of a block over the banks: conflict-free per 32-lane half.
+// Work split: one workgroup per (split of the positions, tap, problem); 256(n) x 256(c) fp32 partial tile per
+// workgroup, 8 waves of 128 x 64 as in the forward kernel, same staging pipeline (3 G stages + 2 X stages, ping-pong
+// wave groups, counted vmcnt).  Partials go to a workspace and a second kernel sums the splits into bf16.
+constexpr int WG_POS = 64;                                       // positions per K-tile
+
+struct WgradArgs {
+    const uint16_t *Gs[CONV_MAX_PROBLEMS];      // [M][256] bf16
+    const uint16_t *Xs[CONV_MAX_PROBLEMS];      // [M][256] bf16
+    const uint16_t *zeros;
+    float *partial;                             // [P][S][9][256][256] f32
+    int64_t M;
+    int Wp, S, tiles_per_split;                 // K-tiles (64 positions) per split
+};
+
+__global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const WgradArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];                 // [G0 G1 G2 | X0 X1] x 32 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int split = blockIdx.x, tap = blockIdx.y, prob = blockIdx.z;
+    const uint16_t *__restrict__ G = a.Gs[prob], *__restrict__ X = a.Xs[prob];
+    const int KT = a.tiles_per_split;
+    const int64_t m_begin = (int64_t)split * KT * WG_POS;
+    const int off = (tap / 3 - 1) * a.Wp + (tap % 3 - 1);
+    constexpr int TILE = WG_POS * 512;                            // 32 KiB
+    unsigned char *const Abase = lds, *const Bbase = lds + 3 * TILE;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // transposed-read addresses: lane = 16*grp + 4*q + p;  grp & 1 selects the 16-channel half of a 32-channel
+    // fragment, grp >> 1 the k half (positions +8); the lane supplies row q, channels 4p .. 4p+3 of its block.
+    const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    uint32_t a_off[4], b_off[2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+        const int ch = wm * 16 + mi * 4 + 2 * (grp & 1) + (p >> 1);                  // 16-byte chunk of the channel row
+        a_off[mi] = (uint32_t)((8 * (grp >> 1) + q) * 512 + ((ch ^ (q << 2)) << 4) + (p & 1) * 8);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int ch = wn * 8 + ni * 4 + 2 * (grp & 1) + (p >> 1);
+        b_off[ni] = (uint32_t)((8 * (grp >> 1) + q) * 512 + ((ch ^ (q << 2)) << 4) + (p & 1) * 8);
+    }
+    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+
+    // staging: tile row = position, 32 chunks of 16 B; LDS position (row, cp) holds global chunk cp ^ ((row & 3) << 2)
+    auto piece = [&](const uint16_t *__restrict__ src, const int64_t shift, unsigned char *dst, const int kt, const int i) {
+        const int qi = i * CONV_THREADS + tid, row = qi >> 5, cp = qi & 31;
+        const int64_t m = m_begin + (int64_t)kt * WG_POS + row;
+        int64_t ms = m + shift;
+        ms = ms < 0 ? 0 : (ms >= a.M ? a.M - 1 : ms);
+        const uint16_t *g = src + ms * 256 + ((cp ^ ((row & 3) << 2)) << 3);
+        if (m >= a.M) g = a.zeros + ((cp & 15) << 3);            // positions past the end contribute nothing
+        __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)(dst + qi * 16), 16, 0, 0);
+    };
+    auto piece_a = [&](const int kt, const int i) { piece(G, 0, Abase + (kt % 3) * TILE, kt, i); };
+    auto piece_b = [&](const int kt, const int i) { piece(X, off, Bbase + (kt & 1) * TILE, kt, i); };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) piece_a(0, i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) piece_b(0, i);
+    if (KT > 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) piece_a(1, i);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();                    // ping-pong, as in the forward kernel
+
+    unsigned long long fa[2][4][2], fb[2][2][2];                  // [k-step set][fragment][k half]
+#define RN_TR_READ(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+#define RN_LOAD_FRAGS(KOFF0, KOFF1, SET)                                             \
+    RN_TR_READ(fb[SET][0][0], bbase + b_off[0], KOFF0); RN_TR_READ(fb[SET][0][1], bbase + b_off[0], KOFF1);   \
+    RN_TR_READ(fb[SET][1][0], bbase + b_off[1], KOFF0); RN_TR_READ(fb[SET][1][1], bbase + b_off[1], KOFF1);   \
+    RN_TR_READ(fa[SET][0][0], abase + a_off[0], KOFF0); RN_TR_READ(fa[SET][0][1], abase + a_off[0], KOFF1);   \
+    RN_TR_READ(fa[SET][1][0], abase + a_off[1], KOFF0); RN_TR_READ(fa[SET][1][1], abase + a_off[1], KOFF1);   \
+    RN_TR_READ(fa[SET][2][0], abase + a_off[2], KOFF0); RN_TR_READ(fa[SET][2][1], abase + a_off[2], KOFF1);   \
+    RN_TR_READ(fa[SET][3][0], abase + a_off[3], KOFF0); RN_TR_READ(fa[SET][3][1], abase + a_off[3], KOFF1);
+    struct U2 { unsigned long long lo, hi; };
+#define RN_FRAG(v) __builtin_bit_cast(bf16x8, U2{v[0], v[1]})
+#define RN_MFMA8(SET)                                                              \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                               \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                           \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(RN_FRAG(fa[SET][mi]), RN_FRAG(fb[SET][ni]), acc[mi][ni], 0, 0, 0);
+#define RN_MFMA_PHASE()                                                            \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);          \
+    __builtin_amdgcn_s_setprio(1);                                                 \
+    RN_MFMA8(0) RN_MFMA8(1)                                                        \
+    __builtin_amdgcn_s_setprio(0);                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                             \
+    __builtin_amdgcn_s_barrier();
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const uint32_t abase = lds_base + (uint32_t)((kt % 3) * TILE), bbase = lds_base + (uint32_t)(3 * TILE + (kt & 1) * TILE);
+        // k-step kk covers positions 16kk .. 16kk+15 of the tile: byte offsets 16*kk*512 (+ 4*512 for the second k half)
+        RN_LOAD_FRAGS(0, 2048, 0) RN_LOAD_FRAGS(8192, 10240, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < KT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) piece_b(kt + 1, i);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        RN_MFMA_PHASE()
+        RN_LOAD_FRAGS(16384, 18432, 0) RN_LOAD_FRAGS(24576, 26624, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < KT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) piece_a(kt + 2, i);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        RN_MFMA_PHASE()
+    }
+#undef RN_TR_READ
+#undef RN_LOAD_FRAGS
+#undef RN_FRAG
+#undef RN_MFMA8
+#undef RN_MFMA_PHASE
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+
+    // partial tile [n][c] f32 of this (problem, split, tap)
+    float *__restrict__ out = a.partial + (((int64_t)prob * a.S + split) * 9 + tap) * 65536;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = wn * 64 + ni * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                out[row * 256 + col] = acc[mi][ni][r];
+            }
+        }
+}
+
+// dW[p][n][t][c] (bf16) = sum over the splits of partial[p][s][t][n][c]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, const int S, uint16_t *dw0, uint16_t *dw1,
+                                                           uint16_t *dw2, uint16_t *dw3)
+{
+    const int prob = blockIdx.y;
+    uint16_t *dw = prob == 0 ? dw0 : (prob == 1 ? dw1 : (prob == 2 ? dw2 : dw3));
+    const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;          // over 9 * 256 * 256 / 4 float4 groups of [t][n][c]
+    if (i4 >= 9 * 65536 / 4) return;
+    rn::f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < S; ++sp) {
+        const rn::f32x4 v = ((const rn::f32x4 *)(partial + ((int64_t)prob * S + sp) * 9 * 65536))[i4];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const int64_t e = i4 * 4;
+    const int t = (int)(e / 65536), n = (int)((e % 65536) / 256), c = (int)(e % 256);
+    rn::u32x2 o;
+    o.x = rn::dt<RN_BF16>::pk(s.x, s.y); o.y = rn::dt<RN_BF16>::pk(s.z, s.w);
+    *(rn::u32x2 *)(dw + ((int64_t)n * 9 + t) * 256 + c) = o;
+}
+
 }  // namespace
 
 static int conv_launch(const void *const *xs, const void *const *ws, const float *const *biases, const uint8_t *mask,
@@ -279,4 +455,52 @@ RN_API int rn_conv1x1_nhwc(const void *x, const void *w, const float *bias, void
     const float *bs[1] = {bias};
     void *ys[1] = {y};
     return conv_launch(xs, ws, bs, nullptr, ys, 1, dtype, M, M, 1, Cin, Cout, 0, 0, nullptr, stream, 1);
+}
+
+RN_API size_t rn_conv3x3_wgrad_workspace_bytes(int P, int64_t M)
+{
+    if (P <= 0 || P > CONV_MAX_PROBLEMS || M <= 0) return 0;
+    return (size_t)P * 64 * 9 * 65536 * sizeof(float);          // up to 64 splits of the positions
+}
+
+RN_API int rn_conv3x3_canvas_wgrad_batched(const void *const *gs, const void *const *xs, void *const *dws, int P, int dtype,
+                                           int64_t M, int Wp, int Cin, int Cout, const void *zeros, void *workspace,
+                                           size_t workspace_bytes, void *stream)
+{
+    if (!gs || !xs || !dws || !zeros || !workspace || P <= 0 || P > CONV_MAX_PROBLEMS || M <= 0 || Wp <= 0) return RN_EINVAL;
+    if (dtype != RN_BF16 || Cin != 256 || Cout != 256) return RN_EUNSUPPORTED;
+    if (workspace_bytes < rn_conv3x3_wgrad_workspace_bytes(P, M)) return RN_EWORKSPACE;
+    WgradArgs a;
+    uint16_t *dw[CONV_MAX_PROBLEMS] = {nullptr, nullptr, nullptr, nullptr};
+    for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) {
+        const int q = p < P ? p : 0;
+        if (!gs[q] || !xs[q] || !dws[q]) return RN_EINVAL;
+        if (!rn::aligned(gs[q], 16) || !rn::aligned(xs[q], 16) || !rn::aligned(dws[q], 16)) return RN_EALIGN;
+        a.Gs[p] = (const uint16_t *)gs[q]; a.Xs[p] = (const uint16_t *)xs[q];
+        dw[p] = (uint16_t *)dws[q];
+    }
+    int dev = 0, cus = 0;
+    RN_HIP(hipGetDevice(&dev));
+    RN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    {
+        static bool attr_set[64] = {};
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            RN_HIP(hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES));
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
+    }
+    // one workgroup per (split, tap, problem): choose the split count so that the grid is about one wave of the chip
+    int S = cus / (9 * P);
+    if (S < 1) S = 1;
+    if (S > 64) S = 64;
+    const int64_t ktiles = (M + WG_POS - 1) / WG_POS;
+    a.tiles_per_split = (int)((ktiles + S - 1) / S);
+    S = (int)((ktiles + a.tiles_per_split - 1) / a.tiles_per_split);
+    a.S = S; a.M = M; a.Wp = Wp; a.zeros = (const uint16_t *)zeros; a.partial = (float *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)S, 9, (unsigned)P), dim3(CONV_THREADS), CONV_LDS_BYTES, st, a);
+    RN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(9 * 65536 / 4 / 256, (unsigned)P), dim3(256), 0, st, (const float *)workspace, S, dw[0], dw[1], dw[2], dw[3]);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
 }

@@ -437,3 +437,24 @@ def test_mfma_conv1x1_vs_torch(shape):
     torch.testing.assert_close(y.float(), yr, rtol=2e-2, atol=1e-2 * float(yr.detach().abs().max()))
     torch.testing.assert_close(x.grad.float(), xr.grad, rtol=5e-2, atol=2e-2 * float(xr.grad.abs().max()))
     torch.testing.assert_close(conv.weight.grad.float(), wr.grad, rtol=5e-2, atol=2e-2 * float(wr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(2, 9, 11), (1, 14, 37), (3, 23, 31)])
+def test_mfma_canvas_wgrad_vs_miopen(shape):
+    """rn_conv3x3_canvas_wgrad_batched (position-contraction MFMA GEMM with transposed LDS reads + split reduction) vs the
+    fp32 weight gradient of torch's conv2d, two problems in one launch, zero-bordered canvas with gaps."""
+    from pytorch_retinanet_amd import biasact
+    torch.manual_seed(5)
+    N, Hp, Wp = shape
+    mask2d = torch.zeros(Hp, Wp, dtype=torch.uint8, device=DEV)
+    mask2d[1:-1, 1:-1] = (torch.rand(Hp - 2, Wp - 2, device=DEV) > 0.2).to(torch.uint8)
+    mk = lambda: (torch.randn(N, 256, Hp, Wp, device=DEV) * mask2d[None, None]).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    xs, gs = [mk(), mk()], [mk(), mk()]
+    w = torch.zeros(256, 256, 3, 3, device=DEV, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    got = biasact._canvas_wgrad(gs, xs, [w, w], Wp, torch.cuda.current_stream().cuda_stream)
+    assert got is not None
+    for g, x, dw in zip(gs, xs, got):
+        ref = torch.ops.aten.convolution_backward(g.float(), x.float(), w.float(), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                  [False, True, False])[1]
+        assert dw.shape == ref.shape and dw.is_contiguous(memory_format=torch.channels_last)
+        torch.testing.assert_close(dw.float(), ref, rtol=2e-2, atol=1e-2 * float(ref.abs().max()))
