@@ -106,7 +106,8 @@ def _canvas_wgrad(gs, xs, ws, Wp: int, stream: int):
 
 class _TowerConv(torch.autograd.Function):
     """relu(conv3x3(x, w) + bias) * mask on a zero-bordered canvas: forward and data gradient are the hand-written
-    MFMA implicit GEMM (``rn_conv3x3_canvas``), the weight gradient is MIOpen's."""
+    MFMA implicit GEMM (``rn_conv3x3_canvas``), the weight gradient the MFMA position-contraction GEMM
+    (``rn_conv3x3_canvas_wgrad_batched``; MIOpen for shapes outside its range)."""
 
     @staticmethod
     def forward(ctx, x, w, bias, mask):

@@ -1,7 +1,8 @@
 // 3x3 / stride-1 / pad-1 convolution of the head towers on the packed level canvas as a hand-written MFMA implicit
 // GEMM, with the bias + ReLU + position-mask epilogue fused (reference: the 3x3 conv + ReLU pairs
 // of retinanet/layers.py:143-171 and :213-241).  Forward and data-gradient use this kernel (the data gradient is the
-// same convolution with the taps reversed and the channel roles swapped); the weight gradient stays on MIOpen.
+// same convolution with the taps reversed and the channel roles swapped); the weight gradient is the second kernel of
+// this file (conv3x3_wgrad_kernel).
 //
 // Formulation.  The canvas carries a one-pixel zero border, [N][Hp][Wp][C] = [M][C] with M = N*Hp*Wp, so tap (r, s)
 // of output position m is input position m + (r-1)*Wp + (s-1): no bounds logic in the loop.  Positions whose 3x3
