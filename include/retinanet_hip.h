@@ -199,6 +199,10 @@ int rn_conv3x3_canvas_wgrad_batched(const void *const *gs, const void *const *xs
                                     int64_t M, int Wp, int Cin, int Cout, const void *zeros, void *workspace,
                                     size_t workspace_bytes, void *stream);
 
+/* The same weight gradient for one ordinary dense channels-last conv (no border: out-of-image taps contribute zero). */
+int rn_conv3x3_nhwc_wgrad(const void *g, const void *x, void *dw, int dtype, int N, int H, int W, int Cin, int Cout,
+                          const void *zeros, void *workspace, size_t workspace_bytes, void *stream);
+
 /* The same kernel on an ordinary dense channels-last tensor [N][H][W][C] (no border, no mask): out-of-image taps
  * read `zeros` (>= 256 bytes of zeros, 16-byte aligned, caller-owned).  Used for the stride-1 3x3 convs of the
  * backbone (retinanet/backbone.py:112-114, conv2 of layer3) and the FPN smoothing convs (retinanet/layers.py:23-28)

@@ -388,6 +388,50 @@ class _Conv3x3Dense(torch.autograd.Function):
         return dx, dw, db
 
 
+class _Conv3x3MfmaWgrad(torch.autograd.Function):
+    """A 3x3 / stride-1 / pad-1, 256 -> 256 bf16 conv whose forward and data gradient stay on MIOpen and whose WEIGHT
+    gradient runs on the MFMA position-contraction GEMM (``rn_conv3x3_nhwc_wgrad``) -- the one piece where the
+    hand-written kernel is clearly ahead on these shapes (MIOpen's split-K wrw + zero / cast kernels)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        y = F.conv2d(x, w, None if bias is None else bias.to(x.dtype), padding=1)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        N, Cin, H, W = x.shape
+        dev = x.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        if dy.dtype != x.dtype or not _cl(dy):
+            dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            need = lib.rn_conv3x3_wgrad_workspace_bytes(1, N * H * W)
+            key = (dev.index, stream)
+            wsb = _WG_WS.get(key)
+            if wsb is None or wsb.numel() < need:
+                wsb = _WG_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
+            dw = torch.empty((256, 256, 3, 3), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+            check(lib.rn_conv3x3_nhwc_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), _DT[x.dtype], N, H, W, 256, 256,
+                                            _zero_page(dev).data_ptr(), wsb.data_ptr(), wsb.numel(), stream), "rn_conv3x3_nhwc_wgrad")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty((256,), dtype=torch.float32, device=dev)
+            wp, wn = _workspace(dev, stream, 256)
+            check(lib.rn_bias_act_backward(dy.data_ptr(), 0, 0, 0, db.data_ptr(), _DT[x.dtype], N * H * W, 256, 1, 0, wp, wn, stream),
+                  "rn_bias_act_backward")
+        return dx, dw, db
+
+
+# off by default: a tie with MIOpen inside the step on the layer3 / FPN shapes (216.2 / 217.3 vs 215.8 / 217.3 images/s)
+MFMA_DENSE_WGRAD = os.environ.get("RN_MFMA_DENSE_WGRAD", "0") == "1"
 MFMA_CONV_MIN_POSITIONS = 30000       # below this the kernel's 256-row tiles leave most CUs idle and MIOpen is as fast
 # Off by default: in isolation the kernel beats MIOpen on these shapes (layer3 conv2 78 vs 122 us, FPN P3 232 vs 272 us),
 # but inside the train step the A/B is a tie (211.3 vs 211.4 images/s on one box), so the stock path stays.  RN_MFMA_CONV=1.
@@ -402,6 +446,12 @@ def conv3x3(conv, x: Tensor) -> Tensor:
             and conv.out_channels % 256 == 0 and x.shape[0] * x.shape[2] * x.shape[3] >= MFMA_CONV_MIN_POSITIONS
             and (conv.bias is None or conv.bias.dtype == torch.float32) and MFMA_DENSE_CONV):
         return _Conv3x3Dense.apply(x, conv.weight.to(x.dtype), conv.bias)
+    if (MFMA_DENSE_WGRAD and x.is_cuda and x.dtype == torch.bfloat16 and _cl(x) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels == 256
+            and conv.out_channels == 256 and x.shape[0] * x.shape[2] * x.shape[3] >= MFMA_CONV_MIN_POSITIONS
+            and (conv.bias is None or conv.bias.dtype == torch.float32) and torch.is_grad_enabled() and conv.weight.requires_grad):
+        w = conv.weight.to(x.dtype)
+        return _Conv3x3MfmaWgrad.apply(x, w if _cl(w) else w.contiguous(memory_format=torch.channels_last), conv.bias)
     return conv(x)
 
 

@@ -231,6 +231,7 @@ struct WgradArgs {
     float *partial;                             // [P][S][9][256][256] f32
     int64_t M;
     int Wp, S, tiles_per_split;                 // K-tiles (64 positions) per split
+    int H;                                      // 0: zero-bordered canvas; > 0: dense [N][H][Wp] images, out-of-image taps read zeros
 };
 
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const WgradArgs a)
@@ -271,13 +272,20 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
     const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
 
     // staging: tile row = position, 32 chunks of 16 B; LDS position (row, cp) holds global chunk cp ^ ((row & 3) << 2)
+    const int dy_tap = tap / 3 - 1, dx_tap = tap % 3 - 1;
+    const int64_t HW = (int64_t)a.H * a.Wp;
     auto piece = [&](const uint16_t *__restrict__ src, const int64_t shift, unsigned char *dst, const int kt, const int i) {
         const int qi = i * CONV_THREADS + tid, row = qi >> 5, cp = qi & 31;
         const int64_t m = m_begin + (int64_t)kt * WG_POS + row;
         int64_t ms = m + shift;
         ms = ms < 0 ? 0 : (ms >= a.M ? a.M - 1 : ms);
         const uint16_t *g = src + ms * 256 + ((cp ^ ((row & 3) << 2)) << 3);
-        if (m >= a.M) g = a.zeros + ((cp & 15) << 3);            // positions past the end contribute nothing
+        bool dead = m >= a.M;                                     // positions past the end contribute nothing
+        if (a.H > 0 && shift != 0 && !dead) {                     // dense images: is the tap of this position inside its image?
+            const int pos = (int)(m % HW), y = pos / a.Wp, x = pos - y * a.Wp;
+            dead = (unsigned)(y + dy_tap) >= (unsigned)a.H || (unsigned)(x + dx_tap) >= (unsigned)a.Wp;
+        }
+        if (dead) g = a.zeros + ((cp & 15) << 3);
         __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)(dst + qi * 16), 16, 0, 0);
     };
     auto piece_a = [&](const int kt, const int i) { piece(G, 0, Abase + (kt % 3) * TILE, kt, i); };
@@ -464,9 +472,27 @@ RN_API size_t rn_conv3x3_wgrad_workspace_bytes(int P, int64_t M)
     return (size_t)P * 64 * 9 * 65536 * sizeof(float);          // up to 64 splits of the positions
 }
 
+static int wgrad_launch(const void *const *gs, const void *const *xs, void *const *dws, int P, int dtype, int64_t M, int Wp, int H,
+                        int Cin, int Cout, const void *zeros, void *workspace, size_t workspace_bytes, void *stream);
+
 RN_API int rn_conv3x3_canvas_wgrad_batched(const void *const *gs, const void *const *xs, void *const *dws, int P, int dtype,
                                            int64_t M, int Wp, int Cin, int Cout, const void *zeros, void *workspace,
                                            size_t workspace_bytes, void *stream)
+{
+    return wgrad_launch(gs, xs, dws, P, dtype, M, Wp, 0, Cin, Cout, zeros, workspace, workspace_bytes, stream);
+}
+
+RN_API int rn_conv3x3_nhwc_wgrad(const void *g, const void *x, void *dw, int dtype, int N, int H, int W, int Cin, int Cout,
+                                 const void *zeros, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (N <= 0 || H <= 0 || W <= 0) return RN_EINVAL;
+    const void *gs[1] = {g}, *xs[1] = {x};
+    void *dws[1] = {dw};
+    return wgrad_launch(gs, xs, dws, 1, dtype, (int64_t)N * H * W, W, H, Cin, Cout, zeros, workspace, workspace_bytes, stream);
+}
+
+static int wgrad_launch(const void *const *gs, const void *const *xs, void *const *dws, int P, int dtype, int64_t M, int Wp, int H,
+                        int Cin, int Cout, const void *zeros, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!gs || !xs || !dws || !zeros || !workspace || P <= 0 || P > CONV_MAX_PROBLEMS || M <= 0 || Wp <= 0) return RN_EINVAL;
     if (dtype != RN_BF16 || Cin != 256 || Cout != 256) return RN_EUNSUPPORTED;
@@ -497,7 +523,7 @@ RN_API int rn_conv3x3_canvas_wgrad_batched(const void *const *gs, const void *co
     const int64_t ktiles = (M + WG_POS - 1) / WG_POS;
     a.tiles_per_split = (int)((ktiles + S - 1) / S);
     S = (int)((ktiles + a.tiles_per_split - 1) / a.tiles_per_split);
-    a.S = S; a.M = M; a.Wp = Wp; a.zeros = (const uint16_t *)zeros; a.partial = (float *)workspace;
+    a.S = S; a.M = M; a.Wp = Wp; a.H = H; a.zeros = (const uint16_t *)zeros; a.partial = (float *)workspace;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)S, 9, (unsigned)P), dim3(CONV_THREADS), CONV_LDS_BYTES, st, a);
     RN_LAUNCH_CHECK();

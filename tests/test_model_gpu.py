@@ -458,3 +458,33 @@ def test_mfma_canvas_wgrad_vs_miopen(shape):
                                                   [False, True, False])[1]
         assert dw.shape == ref.shape and dw.is_contiguous(memory_format=torch.channels_last)
         torch.testing.assert_close(dw.float(), ref, rtol=2e-2, atol=1e-2 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("shape,bias", [((2, 11, 13), True), ((1, 9, 40), False), ((3, 17, 6), True)])
+def test_mfma_dense_wgrad_vs_torch(shape, bias):
+    "MIOpen forward / data gradient + rn_conv3x3_nhwc_wgrad (dense images, out-of-image taps = zero) vs torch in fp32."
+    from pytorch_retinanet_amd import biasact
+    torch.manual_seed(6)
+    N, H, W = shape
+    conv = torch.nn.Conv2d(256, 256, 3, padding=1, bias=bias).to(DEV).to(memory_format=torch.channels_last)
+    x = torch.randn(N, 256, H, W, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    old, old_on = biasact.MFMA_CONV_MIN_POSITIONS, biasact.MFMA_DENSE_WGRAD
+    biasact.MFMA_CONV_MIN_POSITIONS, biasact.MFMA_DENSE_WGRAD = 0, True
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = biasact.conv3x3(conv, x)
+        assert "Conv3x3MfmaWgrad" in type(y.grad_fn).__name__
+        g = torch.randn_like(y)
+        y.backward(g)
+    finally:
+        biasact.MFMA_CONV_MIN_POSITIONS, biasact.MFMA_DENSE_WGRAD = old, old_on
+    xr = x.detach().float().requires_grad_(True)
+    wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    br = conv.bias.detach().clone().requires_grad_(True) if bias else None
+    yr = torch.nn.functional.conv2d(xr, wr, br, padding=1)
+    yr.backward(g.float())
+    torch.testing.assert_close(y.float(), yr, rtol=2e-2, atol=1e-2 * float(yr.detach().abs().max()))
+    torch.testing.assert_close(x.grad.float(), xr.grad, rtol=5e-2, atol=2e-2 * float(xr.grad.abs().max()))
+    torch.testing.assert_close(conv.weight.grad.float(), wr.grad, rtol=5e-2, atol=2e-2 * float(wr.grad.abs().max()))
+    if bias:
+        torch.testing.assert_close(conv.bias.grad, br.grad, rtol=2e-2, atol=2e-2 * float(br.grad.abs().max()))
