@@ -136,12 +136,14 @@ int rn_scale_inplace(void *data, int dtype, int64_t n, const float *scale, void 
  * [3][C] backward scratch) are caller-owned; workspace: rn_bn_workspace_bytes(C).
  * Backward returns dx, dresidual (nullable; = gradient after the ReLU mask), dgamma, dbeta.  With relu != 0
  * and y == NULL the ReLU mask is recomputed from x and fwd_coef (= the coef array the forward call filled),
- * which saves one activation read per backward kernel; only valid when the forward had no residual. */
+ * which saves one activation read per backward kernel; only valid when the forward had no residual.
+ * relu_mask (forward, nullable; u8[M*C/8]): one bit per element, set where y > 0.  Backward with relu == 2 takes that
+ * mask through the `y` argument instead of the activation (1/16 of its bytes) -- the residual layers' variant. */
 size_t rn_bn_workspace_bytes(int C);
 int rn_bn_act_forward(const void *x, const void *residual, void *y, int dtype, int64_t M, int C,
                       const float *gamma, const float *beta, float *running_mean, float *running_var,
                       int64_t *num_batches_tracked, int training, float momentum, float eps, int relu,
-                      float *save_mean, float *save_invstd, float *coef, void *workspace,
+                      float *save_mean, float *save_invstd, float *coef, uint8_t *relu_mask, void *workspace,
                       size_t workspace_bytes, void *stream);
 int rn_bn_act_backward(const void *dy, const void *y, const void *x, void *dx, void *dresidual, int dtype,
                        int64_t M, int C, const float *gamma, const float *save_mean, const float *save_invstd,

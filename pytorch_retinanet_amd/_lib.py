@@ -46,7 +46,7 @@ SIGNATURES = {
     "rn_scale_inplace": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp]),
     "rn_bn_workspace_bytes": (_sz, [C.c_int]),
     "rn_bn_act_forward": (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, _f32, _f32, C.c_int,
-                                    _vp, _vp, _vp, _vp, _sz, _vp]),
+                                    _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rn_bn_act_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
                                      _vp, _vp, _vp, _vp, _sz, _vp]),
     "rn_decode_clip": (C.c_int, [_vp, C.c_int, C.c_int, _i64, _vp, _i64, _vp, C.POINTER(_f32), _vp, _vp]),

@@ -174,12 +174,21 @@ __global__ __launch_bounds__(256) void bn_eval_coef_kernel(const int C, const fl
     coef_b[c] = (beta ? beta[c] : 0.0f) - running_mean[c] * a;
 }
 
+// ReLU mask of the forward output without reading it: y = round_DT(max(fma(x, a, b), 0)) > 0  <=>  fma(x, a, b)
+// is above the largest value that rounds to zero in DT (same fma, same coefficients as bn_apply_kernel).
+// Only for layers without a residual input (the residual is not available in backward).
+template <int DT> __device__ __forceinline__ float relu_alive_threshold();
+template <> __device__ __forceinline__ float relu_alive_threshold<RN_F32>() { return 0.0f; }
+template <> __device__ __forceinline__ float relu_alive_threshold<RN_BF16>() { return __uint_as_float(0x00004000u); }   // 2^-134: half the smallest bf16 subnormal (ties to even -> 0)
+template <> __device__ __forceinline__ float relu_alive_threshold<RN_F16>() { return __uint_as_float(0x33000000u); }    // 2^-25: half the smallest f16 subnormal
+
 // ---------------------------------------------------------------- forward apply: y = act(x*a + b (+ res))
 template <int DT, bool RELU, bool RES>
 __global__ __launch_bounds__(BN_BLOCK) void bn_apply_kernel(const void *__restrict__ x, const void *__restrict__ res, void *__restrict__ y,
                                                             const int64_t nvec, const int C8, const float *__restrict__ coef_a,
-                                                            const float *__restrict__ coef_b)
+                                                            const float *__restrict__ coef_b, uint8_t *__restrict__ relu_mask)
 {
+    const float alive = relu_alive_threshold<DT>();
     // C8 | 256 (every ResNet width): a thread always lands on the same channel group -> coefficients in registers
     const bool fixed = (BN_BLOCK % C8) == 0;
     float a[8], b[8];
@@ -189,24 +198,18 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_apply_kernel(const void *__restri
         vec8<DT>::ld(x, v, f);
         if (RES) vec8<DT>::ld(res, v, r);
         if (!fixed) { const int cg = (int)(v % C8); vec8<RN_F32>::ld(coef_a, cg, a); vec8<RN_F32>::ld(coef_b, cg, b); }
+        unsigned bits = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float t = fmaf(f[j], a[j], b[j]);
             if (RES) t += r[j];
-            if (RELU) t = t > 0.0f ? t : 0.0f;
+            if (RELU) { bits |= (t > alive) ? (1u << j) : 0u; t = t > 0.0f ? t : 0.0f; }
             f[j] = t;
         }
         vec8<DT>::st(y, v, f);
+        if (RELU && relu_mask) relu_mask[v] = (uint8_t)bits;      // one byte per 8 channels: what backward reads instead of y
     }
 }
-
-// ReLU mask of the forward output without reading it: y = round_DT(max(fma(x, a, b), 0)) > 0  <=>  fma(x, a, b)
-// is above the largest value that rounds to zero in DT (same fma, same coefficients as bn_apply_kernel).
-// Only for layers without a residual input (the residual is not available in backward).
-template <int DT> __device__ __forceinline__ float relu_alive_threshold();
-template <> __device__ __forceinline__ float relu_alive_threshold<RN_F32>() { return 0.0f; }
-template <> __device__ __forceinline__ float relu_alive_threshold<RN_BF16>() { return __uint_as_float(0x00004000u); }   // 2^-134: half the smallest bf16 subnormal (ties to even -> 0)
-template <> __device__ __forceinline__ float relu_alive_threshold<RN_F16>() { return __uint_as_float(0x33000000u); }    // 2^-25: half the smallest f16 subnormal
 
 // ---------------------------------------------------------------- backward sums
 // g = dy * (y > 0) (RELU) ; partial[block][0][c] = sum g, partial[block][1][c] = sum g * xhat
@@ -237,18 +240,21 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_partial_kernel(const void *__
             int64_t r = r0 + rl;
             for (; r + sp.lanes < r1; r += 2 * sp.lanes) {              // 2 rows x 3 tensors = 6 loads in flight per thread
                 float g[2][8], yy[2][8], xx[2][8];
+                unsigned mb[2] = {0xffu, 0xffu};
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int64_t v = (r + u * sp.lanes) * sp.C8 + cg;
                     vec8<DT>::ld(dy, v, g[u]);
                     vec8<DT>::ld(x, v, xx[u]);
                     if (RELU == 1) vec8<DT>::ld(y, v, yy[u]);
+                    if (RELU == 3) mb[u] = ((const uint8_t *)y)[v];
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const bool dead = RELU == 1 ? !(yy[u][j] > 0.0f) : (RELU == 2 ? !(fmaf(xx[u][j], fa[j], fb[j]) > alive) : false);
+                        const bool dead = RELU == 1 ? !(yy[u][j] > 0.0f) : (RELU == 2 ? !(fmaf(xx[u][j], fa[j], fb[j]) > alive)
+                                                                  : (RELU == 3 ? !((mb[u] >> j) & 1u) : false));
                         const float gj = dead ? 0.0f : g[u][j];
                         s[j] += gj;
                         q[j] = fmaf(gj, (xx[u][j] - mu[j]) * is[j], q[j]);
@@ -260,9 +266,11 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_partial_kernel(const void *__
                 vec8<DT>::ld(dy, v, g);
                 vec8<DT>::ld(x, v, xx);
                 if (RELU == 1) vec8<DT>::ld(y, v, yy);
+                const unsigned mb1 = RELU == 3 ? ((const uint8_t *)y)[v] : 0xffu;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const bool dead = RELU == 1 ? !(yy[j] > 0.0f) : (RELU == 2 ? !(fmaf(xx[j], fa[j], fb[j]) > alive) : false);
+                    const bool dead = RELU == 1 ? !(yy[j] > 0.0f) : (RELU == 2 ? !(fmaf(xx[j], fa[j], fb[j]) > alive)
+                                                              : (RELU == 3 ? !((mb1 >> j) & 1u) : false));
                     const float gj = dead ? 0.0f : g[j];
                     s[j] += gj;
                     q[j] = fmaf(gj, (xx[j] - mu[j]) * is[j], q[j]);
@@ -337,6 +345,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(const void *__re
         vec8<DT>::ld(dy, v, g);
         vec8<DT>::ld(x, v, xx);
         if (RELU == 1) vec8<DT>::ld(y, v, yy);
+        const unsigned mb = RELU == 3 ? ((const uint8_t *)y)[v] : 0xffu;
         if (!fixed) {
             const int cg = (int)(v % C8);
             vec8<RN_F32>::ld(coef_a, cg, a); vec8<RN_F32>::ld(coef_k0, cg, k0); vec8<RN_F32>::ld(coef_k1, cg, k1);
@@ -346,6 +355,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_apply_kernel(const void *__re
         for (int j = 0; j < 8; ++j) {
             if (RELU == 1 && !(yy[j] > 0.0f)) g[j] = 0.0f;
             if (RELU == 2 && !(fmaf(xx[j], fa[j], fb[j]) > alive)) g[j] = 0.0f;
+            if (RELU == 3 && !((mb >> j) & 1u)) g[j] = 0.0f;
             xx[j] = fmaf(a[j], g[j], fmaf(k1[j], xx[j], k0[j]));
         }
         vec8<DT>::st(dx, v, xx);
@@ -383,7 +393,7 @@ RN_API size_t rn_bn_workspace_bytes(int C) { return C > 0 ? sizeof(float) * (siz
 RN_API int rn_bn_act_forward(const void *x, const void *residual, void *y, int dtype, int64_t M, int C,
                              const float *gamma, const float *beta, float *running_mean, float *running_var,
                              int64_t *num_batches_tracked, int training, float momentum, float eps, int relu,
-                             float *save_mean, float *save_invstd, float *coef /*[2][C]*/, void *workspace,
+                             float *save_mean, float *save_invstd, float *coef /*[2][C]*/, uint8_t *relu_mask, void *workspace,
                              size_t workspace_bytes, void *stream)
 {
     if (!x || !y || !save_mean || !save_invstd || !coef || M <= 0 || C <= 0) return RN_EINVAL;
@@ -418,10 +428,10 @@ RN_API int rn_bn_act_forward(const void *x, const void *residual, void *y, int d
     const dim3 g(apply_blocks(nvec)), b(BN_BLOCK);
     const int C8 = C / 8;
 #define RN_BN_APPLY(DT)                                                                                                          \
-    if (relu) { if (residual) hipLaunchKernelGGL((bn_apply_kernel<DT, true, true>), g, b, 0, st, x, residual, y, nvec, C8, ca, cb);    \
-                else hipLaunchKernelGGL((bn_apply_kernel<DT, true, false>), g, b, 0, st, x, residual, y, nvec, C8, ca, cb); }           \
-    else      { if (residual) hipLaunchKernelGGL((bn_apply_kernel<DT, false, true>), g, b, 0, st, x, residual, y, nvec, C8, ca, cb);   \
-                else hipLaunchKernelGGL((bn_apply_kernel<DT, false, false>), g, b, 0, st, x, residual, y, nvec, C8, ca, cb); }
+    if (relu) { if (residual) hipLaunchKernelGGL((bn_apply_kernel<DT, true, true>), g, b, 0, st, x, residual, y, nvec, C8, ca, cb, relu_mask);    \
+                else hipLaunchKernelGGL((bn_apply_kernel<DT, true, false>), g, b, 0, st, x, residual, y, nvec, C8, ca, cb, relu_mask); }           \
+    else      { if (residual) hipLaunchKernelGGL((bn_apply_kernel<DT, false, true>), g, b, 0, st, x, residual, y, nvec, C8, ca, cb, relu_mask);   \
+                else hipLaunchKernelGGL((bn_apply_kernel<DT, false, false>), g, b, 0, st, x, residual, y, nvec, C8, ca, cb, relu_mask); }
     switch (dtype) {
         case RN_F32: RN_BN_APPLY(RN_F32) break;
         case RN_BF16: RN_BN_APPLY(RN_BF16) break;
@@ -441,13 +451,16 @@ RN_API int rn_bn_act_backward(const void *dy, const void *y, const void *x, void
     if (!dy || !x || !dx || !save_mean || !save_invstd || !coef || M <= 0 || C <= 0) return RN_EINVAL;
     // ReLU mask: from y when given; without y it is recomputed from x and the forward coefficients, which is
     // only possible when the forward had no residual input
-    const int rmode = !relu ? 0 : (y ? 1 : 2);
+    // relu: 0 none; 1: mask from y (the activation) when given, else recomputed from x and fwd_coef (no residual only);
+    //       2: y points to the byte mask the forward call wrote (relu_mask), one bit per element
+    const int rmode = !relu ? 0 : (relu == 2 ? 3 : (y ? 1 : 2));
     if (rmode == 2 && (!fwd_coef || dresidual)) return RN_EINVAL;
+    if (rmode == 3 && !y) return RN_EINVAL;
     const float *fa = fwd_coef, *fb = fwd_coef ? fwd_coef + C : nullptr;
     if (C % 8) return RN_EUNSUPPORTED;
     if (dtype != RN_F32 && dtype != RN_BF16 && dtype != RN_F16) return RN_EINVAL;
     if (!workspace || workspace_bytes < rn_bn_workspace_bytes(C)) return RN_EWORKSPACE;
-    if (!rn::aligned(dy, 16) || !rn::aligned(x, 16) || !rn::aligned(dx, 16) || (y && !rn::aligned(y, 16)) ||
+    if (!rn::aligned(dy, 16) || !rn::aligned(x, 16) || !rn::aligned(dx, 16) || (y && rmode != 3 && !rn::aligned(y, 16)) ||
         (dresidual && !rn::aligned(dresidual, 16)) || !rn::aligned(coef, 16) || !rn::aligned(save_mean, 16) ||
         !rn::aligned(save_invstd, 16))
         return RN_EALIGN;
@@ -459,6 +472,7 @@ RN_API int rn_bn_act_backward(const void *dy, const void *y, const void *x, void
 #define RN_BN_BWD_PART(DT)                                                                                                             \
     if (rmode == 1) hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 1>), dim3(nb), dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial); \
     else if (rmode == 2) hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 2>), dim3(nb), dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial); \
+    else if (rmode == 3) hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 3>), dim3(nb), dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial); \
     else hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 0>), dim3(nb), dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial);
     switch (dtype) {
         case RN_F32: RN_BN_BWD_PART(RN_F32) break;
@@ -475,6 +489,8 @@ RN_API int rn_bn_act_backward(const void *dy, const void *y, const void *x, void
     const int C8 = C / 8;
 #define RN_BN_BWD_APPLY(DT)                                                                                                                  \
     if (rmode == 2) hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, 2, false>), g, b, 0, st, dy, y, x, dx, dresidual, nvec, C8, ca, k0, k1, fa, fb);        \
+    else if (rmode == 3) { if (dresidual) hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, 3, true>), g, b, 0, st, dy, y, x, dx, dresidual, nvec, C8, ca, k0, k1, fa, fb);   \
+                else hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, 3, false>), g, b, 0, st, dy, y, x, dx, dresidual, nvec, C8, ca, k0, k1, fa, fb); }         \
     else if (rmode == 1) { if (dresidual) hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, 1, true>), g, b, 0, st, dy, y, x, dx, dresidual, nvec, C8, ca, k0, k1, fa, fb);   \
                 else hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, 1, false>), g, b, 0, st, dy, y, x, dx, dresidual, nvec, C8, ca, k0, k1, fa, fb); }         \
     else      { if (dresidual) hipLaunchKernelGGL((bn_bwd_apply_kernel<DT, 0, true>), g, b, 0, st, dy, y, x, dx, dresidual, nvec, C8, ca, k0, k1, fa, fb);  \

@@ -56,18 +56,21 @@ class _BNAct(torch.autograd.Function):
         stats = torch.empty((4 * Cc,), dtype=torch.float32, device=dev)   # save_mean | save_invstd | coef a | coef b
         sp = stats.data_ptr()
         wp, wn = _workspace(dev, stream, Cc) if training else (0, 0)
+        # ReLU mask for backward: recomputed from x when there is no residual; with a residual the forward writes one bit
+        # per element (1/16 of the bytes of y) and backward reads that instead of y
+        bits = torch.empty((M * Cc // 8,), dtype=torch.uint8, device=dev) if (relu and residual is not None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[2])) else None
         check(_fwd(x.data_ptr(), residual.data_ptr() if residual is not None else 0, y.data_ptr(), _DT[x.dtype], M, Cc,
                    weight.data_ptr(), bias.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
                    num_batches_tracked.data_ptr() if num_batches_tracked is not None else 0, int(training), momentum, eps,
-                   int(relu), sp, sp + 4 * Cc, sp + 8 * Cc, wp, wn, stream), "rn_bn_act_forward")
-        # y is only needed for the ReLU mask when a residual was added; otherwise backward recomputes the mask from x
-        ctx.save_for_backward(x, y if (relu and residual is not None) else None, weight, stats)
+                   int(relu), sp, sp + 4 * Cc, sp + 8 * Cc, bits.data_ptr() if bits is not None else 0, wp, wn, stream),
+              "rn_bn_act_forward")
+        ctx.save_for_backward(x, bits, weight, stats)
         ctx.cfg = (bool(training), bool(relu), residual is not None, M, Cc)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, weight, stats = ctx.saved_tensors
+        x, bits, weight, stats = ctx.saved_tensors
         training, relu, has_res, M, Cc = ctx.cfg
         dev = x.device
         if dev.index != torch.cuda.current_device():
@@ -80,9 +83,10 @@ class _BNAct(torch.autograd.Function):
         grads = torch.empty((5 * Cc,), dtype=torch.float32, device=dev)     # dgamma | dbeta | coef a | k0 | k1
         gp, sp = grads.data_ptr(), stats.data_ptr()
         wp, wn = _workspace(dev, stream, Cc)
-        check(_bwd(dy.data_ptr(), y.data_ptr() if y is not None else 0, x.data_ptr(), dx.data_ptr(),
+        check(_bwd(dy.data_ptr(), bits.data_ptr() if bits is not None else 0, x.data_ptr(), dx.data_ptr(),
                    dres.data_ptr() if dres is not None else 0, _DT[x.dtype], M, Cc, weight.data_ptr(), sp, sp + 4 * Cc,
-                   sp + 8 * Cc, int(training), int(relu), gp, gp + 4 * Cc, gp + 8 * Cc, wp, wn, stream), "rn_bn_act_backward")
+                   sp + 8 * Cc, int(training), (2 if bits is not None else 1) if relu else 0, gp, gp + 4 * Cc, gp + 8 * Cc, wp, wn,
+                   stream), "rn_bn_act_backward")
         return dx, dres, grads[:Cc], grads[Cc:2 * Cc], None, None, None, None, None, None, None
 
 
