@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-ddp", action="store_true", help="use the bucketed all-reduce path even at world size 1 (validation)")
     ap.add_argument("--torch-sgd", action="store_true", help="fp32 parameters + torch.optim.SGD instead of fp32 masters + bf16 conv weights (optim.MasterSGD); same arithmetic")
-    ap.add_argument("--cpu-baseline-reps", type=int, default=3)
+    ap.add_argument("--cpu-baseline-reps", type=int, default=30, help="batches of the dense-head workload timed on the host (about 10 s of CPU work)")
     return ap.parse_args()
 
 
