@@ -179,7 +179,9 @@ __global__ __launch_bounds__(MASK_CAP) void nms_mask_kernel(const rn::NmsLaunch 
     for (int i = wave; i < n; i += MASK_CAP / RN_WAVE) {
         const f32x4 bi = s_box[i];
         const float ai = s_area[i];
-        for (int w = 0; w < nw; ++w) {
+        const int w0 = (i + 1) >> 6;                         // words entirely at or below the diagonal hold no j > i
+        if (lane < w0) s_mask[i][lane] = 0ull;
+        for (int w = w0; w < nw; ++w) {
             const int j = w * 64 + lane;
             bool sup = false;
             if (j > i && j < n) sup = overlaps(bi, ai, s_box[j], s_area[j], a.iou_thr);
