@@ -41,11 +41,19 @@ class FeaturePyramid(nn.Module):
                 nn.init.kaiming_uniform_(m.weight, a=1)
                 nn.init.constant_(m.bias, 0)
 
+    def _up(self, x: Tensor) -> Tensor:
+        # autocast runs nearest upsampling in fp32 and thereby promotes the whole top-down pathway (adds, their
+        # backward, the casts in front of the 3x3 convs) to fp32; a 2x nearest upsampling is a copy, so keep the dtype
+        if x.is_cuda and torch.is_autocast_enabled("cuda") and os.environ.get("RN_FPN_FP32_UPSAMPLE", "0") != "1":
+            with torch.autocast("cuda", enabled=False):
+                return self.upsample_2x(x)
+        return self.upsample_2x(x)
+
     def forward(self, inps: List[Tensor]) -> List[Tensor]:
         c3, c4, c5 = inps
         p5 = self.conv_c5_1x1(c5)
-        p4 = self.conv_c4_1x1(c4) + self.upsample_2x(p5)
-        p3 = self.conv_c3_1x1(c3) + self.upsample_2x(p4)
+        p4 = self.conv_c4_1x1(c4) + self._up(p5)
+        p3 = self.conv_c3_1x1(c3) + self._up(p4)
         p6 = self.conv_c6_3x3(c5)
         p7 = self.conv_c7_3x3(F.relu(p6))
         c3 = biasact.conv3x3                # MFMA kernel where it beats MIOpen (P3, P4 of the R50 config), else the module
