@@ -204,3 +204,37 @@ def test_conv_stack_equals_reference_with_same_weights():
     # R50 key parity too (bottleneck blocks)
     assert list(R.Retinanet(backbone_kind="resnet50", pretrained=False).state_dict()) == \
         list(P.Retinanet(backbone_kind="resnet50", pretrained=False).state_dict())
+
+
+def test_canvas_layout_and_pack_unpack_roundtrip_cpu():
+    """biasact.Canvas (pure host logic): level placement with and without the zero border, the mask, and that
+    unpack(pack(levels)) is the identity with zeros everywhere else (the torch fallbacks run on CPU)."""
+    import torch
+    from pytorch_retinanet_amd import biasact
+    shapes = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    for pad, (H, W) in ((0, (151, 168)), (1, (153, 170))):
+        cv = biasact.Canvas(shapes, torch.device("cpu"), pad=pad)
+        assert (cv.H, cv.W) == (H, W) and int(cv.mask.sum()) == sum(h * w for h, w in shapes)
+        m = cv.mask.view(cv.H, cv.W)
+        for (r, c), (h, w) in zip(cv.origin, cv.shapes):
+            assert m[r:r + h, c:c + w].all()
+            ring = m[max(r - 1, 0):r + h + 1, max(c - 1, 0):c + w + 1].sum()
+            assert int(ring) == h * w                      # a zero ring (or the canvas edge) around every level
+        if pad:
+            assert not m[0].any() and not m[-1].any() and not m[:, 0].any() and not m[:, -1].any()
+    small = [(6, 8), (3, 4), (2, 2)]
+    cv = biasact.Canvas(small, torch.device("cpu"), pad=1)
+    feats = [torch.randn(2, 8, h, w).contiguous(memory_format=torch.channels_last).requires_grad_(True) for h, w in small]
+    packed = biasact.pack_levels(cv, feats)
+    assert packed.shape == (2, 8, cv.H, cv.W) and not packed[:, :, cv.mask.view(cv.H, cv.W) == 0].any()
+    back = biasact.unpack_levels(cv, packed)
+    for a, b in zip(back, feats):
+        assert torch.equal(a, b)
+    sum((b * (i + 1)).sum() for i, b in enumerate(back)).backward()
+    for i, f in enumerate(feats):
+        assert torch.equal(f.grad, torch.full_like(f, float(i + 1)))
+    # bias_act's PyTorch path (what CPU tensors take)
+    x = torch.randn(2, 8, cv.H, cv.W)
+    y = biasact.bias_act(x, torch.arange(8.0), cv.mask, relu=True)
+    ref = torch.relu(x + torch.arange(8.0)[None, :, None, None]) * cv.mask.view(1, 1, cv.H, cv.W)
+    assert torch.equal(y, ref)
