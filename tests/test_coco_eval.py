@@ -120,3 +120,52 @@ def test_csv_dataset_reader(tmp_path):
     with pytest.raises(ValueError):
         (tmp_path / "bad.csv").write_text("filename,xmin\nx,1\n")
         CSVDetectionDataset(str(tmp_path / "bad.csv"))
+
+
+# ------------------------------------------------------------------ properties (hypothesis)
+from hypothesis import given, settings, strategies as st
+
+
+@st.composite
+def _scene(draw):
+    n_img = draw(st.integers(1, 3))
+    gts, dts = [], []
+    for img in range(n_img):
+        for _ in range(draw(st.integers(0, 4))):
+            x, y = draw(st.integers(0, 200)), draw(st.integers(0, 200))
+            w, h = draw(st.integers(5, 120)), draw(st.integers(5, 120))
+            gts.append(_gt(img, draw(st.integers(1, 2)), (x, y, w, h)))
+        for _ in range(draw(st.integers(0, 6))):
+            x, y = draw(st.integers(0, 200)), draw(st.integers(0, 200))
+            w, h = draw(st.integers(5, 120)), draw(st.integers(5, 120))
+            dts.append(_dt(img, draw(st.integers(1, 2)), (x, y, w, h), draw(st.integers(1, 1000)) / 1000.0))
+    return gts, dts
+
+
+@settings(max_examples=40, deadline=None)
+@given(_scene())
+def test_property_stats_are_bounded_and_order_independent(scene):
+    gts, dts = scene
+    s1 = BBoxEval([dict(g) for g in gts], [dict(d) for d in dts]).evaluate().summarize(verbose=False)
+    assert all(v == -1.0 or -1e-9 <= v <= 1.0 + 1e-9 for v in s1)
+    # the order of detections only matters for exact score ties, the order of ground truth only for boxes of one
+    # (image, category) that tie on IoU with a detection
+    scores = [d["score"] for d in dts]
+    if len(set(scores)) == len(scores):
+        s3 = BBoxEval([dict(g) for g in gts], [dict(d) for d in reversed(dts)]).evaluate().summarize(verbose=False)
+        assert np.allclose(s1, s3)
+    if len({(g["image_id"], g["category_id"]) for g in gts}) == len(gts):
+        s2 = BBoxEval([dict(g) for g in reversed(gts)], [dict(d) for d in dts]).evaluate().summarize(verbose=False)
+        assert np.allclose(s1, s2)
+
+
+@settings(max_examples=25, deadline=None)
+@given(_scene())
+def test_property_detecting_every_ground_truth_exactly_gives_ap_one(scene):
+    gts, _ = scene
+    if not gts:
+        return
+    dts = [_dt(g["image_id"], g["category_id"], g["bbox"], 0.5 + 0.001 * i) for i, g in enumerate(gts)]
+    # identical boxes of one (image, category) would steal each other's matches only at equal IoU: still all TP
+    s = BBoxEval([dict(g) for g in gts], dts).evaluate().summarize(verbose=False)
+    assert s[0] == pytest.approx(1.0) and s[8] == pytest.approx(1.0)
