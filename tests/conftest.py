@@ -14,6 +14,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
+    # the package refuses to import without its HIP library (no CPU fallback): build it if a fresh checkout has none
+    lib = os.path.join(ROOT, "pytorch_retinanet_amd", "libretinanet_hip.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "pytorch_retinanet_amd", "csrc")])
 
 
 def pytest_collection_modifyitems(config, items):
