@@ -94,8 +94,25 @@ def cpu_baseline(args, A, K):
             "ms_per_batch": round(t * 1e3, 2)}
 
 
+def self_launch(args) -> int:
+    """``python bench.py --gpus N`` without a launcher: start N ranks with torch.distributed.run from THIS process,
+    which has not touched the GPU yet (a process that has initialised HIP must not exec / fork GPU children on this
+    pool), relay rank 0's JSON line and return the launcher's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -107,8 +124,8 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
-    if args.gpus != world and rank == 0:
-        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
+    if args.gpus != world or (dist.is_initialized() and dist.get_world_size() != args.gpus):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
     import pytorch_retinanet_amd as P
     from pytorch_retinanet_amd import ops, tuning
@@ -163,7 +180,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ev = ops.timing_events() or {}
     ops.enable_timing(False)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:

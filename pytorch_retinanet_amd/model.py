@@ -100,7 +100,15 @@ class RetinaNetModel(_Base):
             raise ValueError("DATASET_KIND not supported")
 
     def _loader(self, ds, bs, shuffle=False):
-        return DataLoader(ds, bs, shuffle=shuffle, collate_fn=collate_fn, **dict(self.conf.dataloader.args))
+        """Under ``torch.distributed`` every rank reads its own shard (``DistributedSampler``, what Lightning injects
+        for the reference); ``SimpleTrainer`` calls ``sampler.set_epoch`` so the shards reshuffle per epoch."""
+        import torch.distributed as dist
+        sampler = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from torch.utils.data.distributed import DistributedSampler
+            sampler = DistributedSampler(ds, shuffle=shuffle)
+            shuffle = False
+        return DataLoader(ds, bs, shuffle=shuffle, sampler=sampler, collate_fn=collate_fn, **dict(self.conf.dataloader.args))
 
     def train_dataloader(self, *args, **kwargs):
         return self._loader(self.trn_ds, self.conf.dataloader.train_bs, shuffle=True)
@@ -181,8 +189,9 @@ def _to_device(batch, device):
 class SimpleTrainer:
     """Minimal stand-in for ``pl.Trainer`` driving the hooks above on ONE device per process:
     ``fit`` (train + optional validation, scheduler stepping per the hparams contract) and ``test``.
-    Under ``torch.distributed`` every rank runs this loop on its own shard of the batch stream and
-    gradients are averaged by ``BucketedGradAllReduce``."""
+    Under ``torch.distributed`` every rank runs this loop on its own shard of the dataset (``DistributedSampler``),
+    gradients are averaged by ``BucketedGradAllReduce`` and the validation loss is averaged over ranks before it
+    reaches a monitoring scheduler.  Validation runs in ``eval()`` mode like Lightning's (BN buffers untouched)."""
 
     def __init__(self, max_epochs: int = 1, device: Optional[str] = None, precision: str = "bf16",
                  channels_last: bool = True, max_steps: Optional[int] = None, log_every: int = 10):
@@ -209,7 +218,10 @@ class SimpleTrainer:
         step = 0
         for epoch in range(self.max_epochs):
             model.train()
-            for i, batch in enumerate(model.train_dataloader()):
+            loader = model.train_dataloader()
+            if hasattr(getattr(loader, "sampler", None), "set_epoch"):
+                loader.sampler.set_epoch(epoch)
+            for i, batch in enumerate(loader):
                 batch = _to_device(batch, self.device)
                 with self._autocast():
                     out = model.training_step(batch, i)
@@ -239,12 +251,22 @@ class SimpleTrainer:
         loader = model.val_dataloader()
         if loader is None:
             return None
+        import torch.distributed as dist
         tot, n = 0.0, 0
-        with torch.no_grad():
-            for i, batch in enumerate(loader):
-                with self._autocast():
-                    out = model.validation_step(_to_device(batch, self.device), i)
-                tot, n = tot + float(out["val_loss"]), n + 1
+        was_training = model.training
+        model.eval()                      # Lightning validates in eval mode: BN uses (and does not update) running statistics
+        try:
+            with torch.no_grad():
+                for i, batch in enumerate(loader):
+                    with self._autocast():
+                        out = model.validation_step(_to_device(batch, self.device), i)
+                    tot, n = tot + float(out["val_loss"]), n + 1
+        finally:
+            model.train(was_training)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            t = torch.tensor([tot, float(n)], dtype=torch.float64, device=self.device)
+            dist.all_reduce(t)            # every rank steps its ReduceLROnPlateau with the same number
+            tot, n = float(t[0]), int(t[1])
         return tot / max(n, 1)
 
     def test(self, model: RetinaNetModel):

@@ -58,7 +58,7 @@ class _BNAct(torch.autograd.Function):
         wp, wn = _workspace(dev, stream, Cc) if training else (0, 0)
         # ReLU mask for backward: recomputed from x when there is no residual; with a residual the forward writes one bit
         # per element (1/16 of the bytes of y) and backward reads that instead of y
-        bits = torch.empty((M * Cc // 8,), dtype=torch.uint8, device=dev) if (relu and residual is not None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[2])) else None
+        bits = torch.empty((M * Cc // 8,), dtype=torch.uint8, device=dev) if (relu and residual is not None and any(ctx.needs_input_grad[0:3])) else None
         check(_fwd(x.data_ptr(), residual.data_ptr() if residual is not None else 0, y.data_ptr(), _DT[x.dtype], M, Cc,
                    weight.data_ptr(), bias.data_ptr(), running_mean.data_ptr(), running_var.data_ptr(),
                    num_batches_tracked.data_ptr() if num_batches_tracked is not None else 0, int(training), momentum, eps,

@@ -51,7 +51,7 @@ class BucketedGradAllReduce:
         cap = int(bucket_mb * (1 << 20))
         group, size = [], 0
         for p in params:
-            nbytes = p.numel() * self._grad_dtype(p).itemsize
+            nbytes = self._padded(p.numel()) * self._grad_dtype(p).itemsize
             if group and (size + nbytes > cap or self._grad_dtype(p) != self._grad_dtype(group[0]) or p.device != group[0].device):
                 self._make_bucket(group)
                 group, size = [], 0
@@ -67,8 +67,15 @@ class BucketedGradAllReduce:
         # bf16 working copies of fp32 master weights (optim.use_bf16_conv_weights) exchange their gradients in fp32
         return torch.float32 if hasattr(p, "master") else p.dtype
 
+    ALIGN = 64          # elements: every view starts on a 256-byte (fp32) boundary -- rn_sgd_master_step and the
+                        # multi-tensor copies want 16-byte-aligned tensors, and 9*K-element biases are not multiples of 4
+
+    @classmethod
+    def _padded(cls, n: int) -> int:
+        return (n + cls.ALIGN - 1) // cls.ALIGN * cls.ALIGN
+
     def _make_bucket(self, params) -> None:
-        total = sum(p.numel() for p in params)
+        total = sum(self._padded(p.numel()) for p in params)
         flat = torch.zeros(total, dtype=self._grad_dtype(params[0]), device=params[0].device)
         b = _Bucket(flat, params)
         off = 0
@@ -79,7 +86,7 @@ class BucketedGradAllReduce:
             view = torch.as_strided(flat, p.size(), p.stride(), off) if dense else flat[off: off + p.numel()].view_as(p)
             if view.dtype == p.dtype:
                 p.grad = view
-            off += p.numel()
+            off += self._padded(p.numel())
             self._owner[p] = (b, view)
             p.register_post_accumulate_grad_hook(self._hook)
         self.buckets.append(b)
@@ -107,7 +114,7 @@ class BucketedGradAllReduce:
         if views:
             torch._foreach_copy_(views, grads)     # also promotes bf16 gradients into fp32 buckets
         b.launched = True
-        if self.world == 1:
+        if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
             return
         if self.average and self.backend == "nccl":
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)

@@ -12,8 +12,10 @@ so the framework runs channels_last + ``cudnn.benchmark`` and ships the find res
 headline shapes (``miopen_db/*.ufdb.txt``, gfx950 / 256 CUs) so a cold box skips the search.
 ``use_shipped_miopen_db()`` must run before the first convolution of the process.
 """
+import hashlib
 import os
 import shutil
+import stat
 import tempfile
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -24,10 +26,19 @@ def use_shipped_miopen_db(rank: int = 0) -> str:
     MIOpen rewrites the file).  Returns the directory.  No-op if the user already set the path."""
     if os.environ.get("MIOPEN_USER_DB_PATH"):
         return os.environ["MIOPEN_USER_DB_PATH"]
-    dst = os.path.join(tempfile.gettempdir(), f"retinanet_miopen_db_{os.getuid()}_{rank}")
-    os.makedirs(dst, exist_ok=True)
     src = os.path.join(_HERE, "miopen_db")
-    for name in os.listdir(src):
+    names = sorted(os.listdir(src))
+    # keyed by the shipped files' content: a refreshed db gets a fresh directory instead of a stale copy
+    h = hashlib.sha256()
+    for name in names:
+        with open(os.path.join(src, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    dst = os.path.join(tempfile.gettempdir(), f"retinanet_miopen_db_{os.getuid()}_{h.hexdigest()[:12]}_{rank}")
+    os.makedirs(dst, mode=0o700, exist_ok=True)
+    st = os.lstat(dst)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid():     # somebody else's directory (or a symlink): do not use it
+        dst = tempfile.mkdtemp(prefix="retinanet_miopen_db_")
+    for name in names:
         target = os.path.join(dst, name)
         if not os.path.exists(target):
             shutil.copy(os.path.join(src, name), target)

@@ -379,9 +379,85 @@ def gen_transform():
     save("transform.npz", **out)
 
 
+def gen_e2e():
+    """Retinanet.forward (models.py:274-288) and Retinanet.predict (models.py:245-272) of the REFERENCE model itself, for a
+    seed-reproducible state dict: the fixture the assembled GPU model is held to."""
+    print("[e2e]  retinanet/models.py:245-288 (forward in train-mode BN, predict in eval mode)")
+    E2E = dict(num_classes=5, backbone_kind="resnet18", pretrained=False, min_size=128, max_size=160)
+    torch.manual_seed(0)
+    ref = R.Retinanet(**E2E)
+    spec = [(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in ref.state_dict().items()]
+    vals = synth.state_dict_values(spec, seed=4242)
+    sd = ref.state_dict()
+    for k, v in vals.items():
+        sd[k] = torch.from_numpy(v)
+    ref.load_state_dict(sd)
+    images, targets = synth.e2e_inputs()
+    timgs = [torch.from_numpy(i) for i in images]
+    ttgts = [{"boxes": torch.from_numpy(b), "labels": torch.from_numpy(l)} for b, l in targets]
+    out = {"spec_keys": np.array([k for k, _, _ in spec]), "spec_shapes": np.array([",".join(map(str, s)) for _, s, _ in spec]),
+           "spec_dtypes": np.array([d for _, _, d in spec]),
+           "weights_sha": np.array(synth.sha(np.concatenate([vals[k].astype(np.float64).reshape(-1) for k in sorted(vals)]))),
+           "inputs_sha": np.array(synth.sha(np.concatenate([i.reshape(-1) for i in images])))}
+    # (1) training forward: the whole module in train() -- BatchNorm uses batch statistics (Q18: train() un-freezes BN)
+    ref.train()
+    losses = ref(timgs, [{k: v.clone() for k, v in t.items()} for t in ttgts])
+    total = losses["classification_loss"] + losses["regression_loss"]
+    total.backward()
+    out["train_losses"] = np.array([float(losses["classification_loss"].detach()), float(losses["regression_loss"].detach())], np.float64)
+    # gradient fingerprints: L2 norms of a few parameter gradients spread over the stack (bwd parity of the assembled model)
+    probes = ["backbone.backbone.conv1.weight", "backbone.backbone.layer2.0.conv1.weight", "backbone.backbone.layer4.1.bn2.weight",
+              "fpn.conv_c3_3x3.weight", "fpn.conv_c7_3x3.bias", "retinanet_head.classification_head.class_subnet.0.weight",
+              "retinanet_head.classification_head.class_subnet_output.weight", "retinanet_head.classification_head.class_subnet_output.bias",
+              "retinanet_head.regression_head.box_subnet.6.weight", "retinanet_head.regression_head.box_subnet_output.weight"]
+    named = dict(ref.named_parameters())
+    out["grad_probe_keys"] = np.array(probes)
+    out["grad_probe_norms"] = np.array([float(named[k].grad.double().norm()) for k in probes])
+    out["grad_probe_head"] = np.stack([named[k].grad.reshape(-1)[:8].numpy().astype(np.float64) for k in probes])
+    # running statistics after that ONE training forward (momentum update of every BN layer)
+    out["bn1_running_mean_after"] = ref.backbone.backbone.bn1.running_mean.numpy().copy()
+    print(f"  train: cls={out['train_losses'][0]:.6f} reg={out['train_losses'][1]:.6f}")
+    # (2) same weights, frozen BN as constructed (freeze_bn=True leaves BN in eval inside a train()-less module): eval forward
+    ref.load_state_dict(sd)
+    ref.zero_grad()
+    ref.eval()
+    with torch.no_grad():
+        losses_eval = ref(timgs, [{k: v.clone() for k, v in t.items()} for t in ttgts])
+    out["eval_losses"] = np.array([float(losses_eval["classification_loss"]), float(losses_eval["regression_loss"])], np.float64)
+    print(f"  eval-BN forward: cls={out['eval_losses'][0]:.6f} reg={out['eval_losses'][1]:.6f}")
+    # (3) predict in eval mode: detections rescaled to the original image sizes (postprocess)
+    with torch.no_grad():
+        dets = ref.predict(timgs)
+        # head outputs of the same pass, for the oracle cross-check and a tighter intermediate comparison
+        il, _ = ref.transform(timgs, None)
+        fm = ref.fpn(ref.backbone(il.tensors))
+        ho = ref.retinanet_head(fm)
+        anchors = ref.anchor_generator(il, fm)
+    out["batch_shape"] = np.array(il.tensors.shape)
+    out["image_sizes"] = np.array(il.image_sizes)
+    out["cls_preds_sample_idx"] = synth.sample_idx(ho["cls_preds"].numel(), 4096, seed=77)
+    out["cls_preds_sample"] = ho["cls_preds"].reshape(-1)[out["cls_preds_sample_idx"]].numpy()
+    out["box_preds_sample_idx"] = synth.sample_idx(ho["bbox_preds"].numel(), 4096, seed=78)
+    out["box_preds_sample"] = ho["bbox_preds"].reshape(-1)[out["box_preds_sample_idx"]].numpy()
+    ncand = int((torch.sigmoid(ho["cls_preds"]) > 0.05).sum())
+    print(f"  logits: mean {float(ho['cls_preds'].mean()):.3f} std {float(ho['cls_preds'].std()):.3f} max {float(ho['cls_preds'].max()):.3f};"
+          f" box deltas std {float(ho['bbox_preds'].std()):.3f}")
+    for b, d in enumerate(dets):
+        out[f"det_boxes{b}"], out[f"det_scores{b}"], out[f"det_labels{b}"] = d["boxes"].numpy(), d["scores"].numpy(), d["labels"].numpy()
+    print(f"  predict: A={anchors[0].shape[0]} candidates={ncand} dets/img={[len(d['scores']) for d in dets]}"
+          f" top score={[float(d['scores'][0]) if len(d['scores']) else None for d in dets]}")
+    # the oracle on the reference's own head outputs must reproduce process_detections (pins the chain on live logits)
+    hw = [tuple(int(x) for x in s) for s in il.image_sizes]
+    got = oracle.detect(ho["cls_preds"].numpy(), ho["bbox_preds"].numpy(), anchors[0].numpy(), hw)
+    pre = ref.process_detections({"cls_preds": ho["cls_preds"].clone(), "bbox_preds": ho["bbox_preds"].clone()}, anchors, il.image_sizes)
+    compare_dets("e2e", got, [{k: v.numpy() for k, v in d.items()} for d in pre])
+    print("  oracle.detect == reference process_detections on the live head outputs")
+    save("e2e.npz", **out)
+
+
 if __name__ == "__main__":
     oracle.build()
-    which = sys.argv[1:] or ["anchors", "match", "loss", "decode", "detect", "nms", "transform"]
+    which = sys.argv[1:] or ["anchors", "match", "loss", "decode", "detect", "nms", "transform", "e2e"]
     for w in which:
         globals()["gen_" + w]()
     print("done")

@@ -79,3 +79,59 @@ def round_f16(a: np.ndarray) -> np.ndarray:
 
 def sample_idx(n: int, k: int, seed: int = 123) -> np.ndarray:
     return np.sort(np.random.default_rng(seed).choice(n, size=min(k, n), replace=False)).astype(np.int64)
+
+
+def state_dict_values(spec: Sequence[Tuple[str, Tuple[int, ...], str]], seed: int, prior: float = 0.01):
+    """Seed-reproducible model weights for the end-to-end fixture (tests/golden/e2e.npz): one array per
+    ``(key, shape, dtype name)`` of a RetinaNet ``state_dict()``, drawn in key order from PCG64(seed).
+
+    Scales keep activations O(1) through the stack in train-mode AND eval-mode BatchNorm and give the detector
+    something to do: conv weights N(0, g / fan_in) with g = 1 in the backbone (residual sums would otherwise double the
+    variance per block when BN runs on its running statistics) and g = 2 (He) in FPN and head towers, BatchNorm
+    gamma / running_var ~ U(0.5, 1.5), beta / running_mean ~ N(0, 0.1), cls-output weights N(0, 0.0016) around the
+    prior bias (so a few hundred anchors per image pass the 0.05 score threshold, none saturates), box-output
+    weights N(0, 0.0008).
+    ``anchor_generator.cell_anchors.*`` keys are skipped (buffers computed by the model itself).
+    """
+    rng = np.random.default_rng(seed)
+    out = {}
+    for key, shape, dtype in spec:
+        if key.startswith("anchor_generator."):
+            continue
+        leaf = key.rsplit(".", 1)[-1]
+        is_bn = ".bn" in key or ".downsample.1." in key
+        if leaf == "num_batches_tracked":
+            v = np.zeros(shape, dtype=np.int64)
+        elif leaf == "running_var" or (is_bn and leaf == "weight"):
+            v = rng.uniform(0.5, 1.5, size=shape).astype(np.float32)
+        elif leaf == "running_mean" or (is_bn and leaf == "bias"):
+            v = (rng.standard_normal(shape) * 0.1).astype(np.float32)
+        elif leaf == "weight" and len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            std = math.sqrt((1.0 if key.startswith("backbone.") else 2.0) / fan_in)
+            if "class_subnet_output" in key:
+                std = 0.0016
+            elif "box_subnet_output" in key:
+                std = 0.0008
+            v = (rng.standard_normal(shape) * std).astype(np.float32)
+        elif leaf == "bias":
+            v = (rng.standard_normal(shape) * 0.05).astype(np.float32)
+            if "class_subnet_output" in key:
+                v = (v * 6 - math.log((1 - prior) / prior)).astype(np.float32)
+        else:
+            raise KeyError(f"no rule for state-dict entry {key} {shape}")
+        out[key] = v
+    return out
+
+
+def e2e_inputs(seed: int = 31):
+    """Images and targets of the end-to-end fixture: two images of different sizes (resized by the transform to
+    min_size 128 / max_size 160), 3 and 2 GT boxes, labels in 1..5."""
+    rng = np.random.default_rng(seed)
+    sizes = [(120, 150), (140, 128)]
+    images = [rng.random((3, h, w), dtype=np.float32) for h, w in sizes]
+    targets = []
+    for (h, w), T in zip(sizes, (3, 2)):
+        b, l = gt_boxes(rng, T, h, w, num_classes=5, wh_lo=20.0, wh_hi=90.0)
+        targets.append((b, l))
+    return images, targets

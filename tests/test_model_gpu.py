@@ -71,9 +71,23 @@ def test_anchor_generator_module_on_device(golden):
     assert [p.shape[0] for p in per_level] == [36864, 9216, 2304, 576, 144]
 
 
-def test_retinanet_train_step_and_predict_r18():
-    """BASELINE configs[0] (R18-FPN, 2 x 3x512x512): forward + loss + backward, then predict, on the device."""
+def _head_outputs_as_the_kernels_see_them(net, images, targets=None):
+    """(cls [B,A,K] f32, box [B,A,4] f32, anchors, transformed targets, image_sizes) from the per-level path the loss / detect
+    kernels read (packed canvas, MFMA towers under bf16, dead classes stripped)."""
+    K = net.num_classes
+    il, tg = net.transform(images, targets, **net._batch_layout())
+    fmaps = net.fpn(net.backbone(il.tensors))
+    lv = net.retinanet_head.forward_levels(fmaps)
+    cls = torch.cat([c[..., :K] for c in lv["cls_levels"]], 1).float()
+    box = torch.cat(list(lv["bbox_levels"]), 1).float()
+    return cls, box, net.anchor_generator(il, fmaps)[0], tg, il.image_sizes
+
+
+def test_retinanet_train_step_and_predict_r18(oracle_lib):
+    """BASELINE configs[0] (R18-FPN, 2 x 3x512x512): forward + loss + backward, then predict, on the device -- the loss
+    dict and the detections are held to the CPU oracle evaluated on the model's own head outputs."""
     import pytorch_retinanet_amd as P
+    from test_e2e_gpu import box_set_agreement
     torch.manual_seed(0)
     net = P.Retinanet(backbone_kind="resnet18", pretrained=False, min_size=512, max_size=512).to(DEV)
     net = net.to(memory_format=torch.channels_last).train()
@@ -91,14 +105,38 @@ def test_retinanet_train_step_and_predict_r18():
     g = net.retinanet_head.classification_head.class_subnet_output.weight.grad
     assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0
     assert net.backbone.backbone.conv1.weight.grad.abs().sum() > 0
+    # the same forward again (train-mode BN uses batch statistics, so the head outputs repeat): oracle losses on them
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        cls, box, anchors, tg, _ = _head_outputs_as_the_kernels_see_them(net, images, targets)
+    a_np = anchors.cpu().numpy()
+    gtb = [t["boxes"].cpu().numpy() for t in tg]
+    gtl = [t["labels"].cpu().numpy() for t in tg]
+    m, nfg = oracle_lib.iou_match(a_np, gtb)
+    ref = oracle_lib.loss_fwd_bwd(cls.cpu().numpy(), box.cpu().numpy(), a_np, gtb, gtl, m)
+    assert nfg.sum() > 0
+    np.testing.assert_allclose([float(out["classification_loss"].detach()), float(out["regression_loss"].detach())], ref["loss"], rtol=1e-4)
+    # prior-initialised head: the classification loss of an untrained RetinaNet is O(1) per the paper's prior trick
+    assert 0.5 < float(out["classification_loss"].detach()) < 5.0
     net.eval()
+    with torch.no_grad():
+        # an untrained head scores every anchor at the 0.01 prior: spread the logits, then put the score threshold where
+        # about 3000 anchors per image pass it, so the scan, NMS and top-k all have work
+        net.retinanet_head.classification_head.class_subnet_output.weight.normal_(0.0, 1.0)
+        cls, box, anchors, _, hw = _head_outputs_as_the_kernels_see_them(net, images)
+        top = torch.topk(torch.sigmoid(cls).reshape(-1), 6001).values
+        thr = float((top[5999].double() + top[6000].double()) / 2) if top[5999] > top[6000] else float(top[6000])
+    net.score_thres = thr
     dets = net.predict(images)
     assert len(dets) == 2
-    for d in dets:
+    ref_d = oracle_lib.detect(cls.cpu().numpy(), box.cpu().numpy(), anchors.cpu().numpy(), [tuple(int(x) for x in s) for s in hw],
+                              oracle_lib.default_detect_params(thr, 1e-2, net.nms_thres, net.detections_per_img))
+    for d, r in zip(dets, ref_d):
         assert d["boxes"].shape[1] == 4 and d["labels"].dtype == torch.int64 and len(d["scores"]) <= 100
         assert (d["scores"][:-1] >= d["scores"][1:]).all()
         if len(d["labels"]):
             assert d["labels"].min() >= 1 and d["labels"].max() <= 90
+        got = {k: v.cpu().numpy() for k, v in d.items()}
+        assert len(r["labels"]) > 0 and box_set_agreement(got, r, 0.99) >= 0.95       # original size == resized size: no rescale
     assert net(images) is not None                                     # targets=None -> predict (Q19)
 
 

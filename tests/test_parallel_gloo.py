@@ -77,7 +77,10 @@ def test_bucket_layout_single_process():
     params = [p for p in model.parameters()]
     # reverse registration order (~ reverse forward): the last layer's parameters land in the first bucket
     assert ddp.buckets[0].params[0] is params[-1]
-    assert sum(ddp.bucket_bytes()) == sum(p.numel() * 4 for p in params)
+    assert sum(ddp.bucket_bytes()) == sum(BucketedGradAllReduce._padded(p.numel()) * 4 for p in params)
+    for v in ddp.grad_views().values():    # every view starts 256-byte aligned relative to its bucket (RN_EALIGN)
+        b = next(b for b in ddp.buckets if b.flat.data_ptr() <= v.data_ptr() < b.flat.data_ptr() + b.flat.numel() * 4)
+        assert (v.data_ptr() - b.flat.data_ptr()) % 256 == 0
     for p in params:                       # grads are views into the buckets
         assert p.grad is not None and p.grad.data_ptr() >= min(b.flat.data_ptr() for b in ddp.buckets)
     model(torch.randn(2, 3, 6, 6)).sum().backward()
@@ -120,3 +123,19 @@ def test_buckets_exchange_bf16_working_copies_in_fp32():
     assert model[1].weight.grad.data_ptr() == views[model[1].weight].data_ptr()       # fp32 parameters: .grad IS the view
     ddp.zero_grad()
     assert w.grad is None
+
+
+def test_bucket_views_stay_aligned_after_odd_sized_parameters():
+    """9*K-element head biases (K = 90: 810, K = 5: 45) are not multiples of 4 elements: the views packed after them
+    must still start on 16-byte boundaries (rn_sgd_master_step rejects anything else with RN_EALIGN)."""
+    from pytorch_retinanet_amd.parallel import BucketedGradAllReduce
+    model = nn.Sequential(nn.Conv2d(4, 45, 3, padding=1), nn.Conv2d(45, 810, 3, padding=1), nn.Conv2d(810, 3, 1))
+    ddp = BucketedGradAllReduce(model, bucket_mb=32.0)
+    assert ddp.num_buckets == 1
+    base = ddp.buckets[0].flat.data_ptr()
+    for p, v in ddp.grad_views().items():
+        assert (v.data_ptr() - base) % 256 == 0 and v.shape == p.shape and v.stride() == p.stride()
+    model(torch.randn(1, 4, 5, 5)).sum().backward()
+    ddp.finish()
+    for p, v in ddp.grad_views().items():
+        assert p.grad.data_ptr() == v.data_ptr() and torch.isfinite(v).all()
