@@ -526,3 +526,43 @@ def test_mfma_dense_wgrad_vs_torch(shape, bias):
     torch.testing.assert_close(conv.weight.grad.float(), wr.grad, rtol=5e-2, atol=2e-2 * float(wr.grad.abs().max()))
     if bias:
         torch.testing.assert_close(conv.bias.grad, br.grad, rtol=2e-2, atol=2e-2 * float(br.grad.abs().max()))
+
+
+@pytest.mark.parametrize("K", [5, 90])
+def test_bucketed_ddp_world1_with_master_sgd_equals_plain_step(K):
+    """9*K-element head biases used to leave the following fp32 bucket views 8-byte aligned and
+    rn_sgd_master_step refused them (RN_EALIGN).  R18 with K = 5 / 90 under BucketedGradAllReduce at world size 1 +
+    MasterSGD.step(grads=grad_views()) must run and give the same parameters as the plain MasterSGD step."""
+    import pytorch_retinanet_amd as P
+    from pytorch_retinanet_amd.optim import MasterSGD, use_bf16_conv_weights
+
+    def run(use_ddp):
+        torch.manual_seed(5)
+        net = P.Retinanet(num_classes=K, backbone_kind="resnet18", pretrained=False, min_size=128, max_size=160).to(DEV)
+        net = net.to(memory_format=torch.channels_last).train()
+        use_bf16_conv_weights(net)
+        opt = MasterSGD(net.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-3)
+        ddp = P.BucketedGradAllReduce(net, bucket_mb=8.0) if use_ddp else None
+        rng = np.random.default_rng(3)
+        for _ in range(2):
+            images = [torch.from_numpy(rng.random((3, 128, 160), dtype=np.float32)).to(DEV) for _ in range(2)]
+            targets = []
+            for _ in range(2):
+                b, l = synth.gt_boxes(rng, 3, 128, 160, num_classes=K, wh_lo=20.0, wh_hi=90.0)
+                targets.append({"boxes": torch.from_numpy(b).to(DEV), "labels": torch.from_numpy(l).to(DEV)})
+            ddp.zero_grad() if ddp else opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = net(images, targets)
+            (out["classification_loss"] + out["regression_loss"]).backward()
+            if ddp:
+                ddp.finish()
+                for v in ddp.grad_views().values():
+                    assert v.data_ptr() % 16 == 0
+                opt.step(grads=ddp.grad_views())
+            else:
+                opt.step()
+        return {n: (p.master if hasattr(p, "master") else p.data).detach().float().cpu() for n, p in net.named_parameters()}
+
+    a, b = run(True), run(False)
+    for k in a:
+        torch.testing.assert_close(a[k], b[k], rtol=0, atol=1e-6, msg=k)

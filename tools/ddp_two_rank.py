@@ -1,0 +1,97 @@
+#!/usr/bin/env python3
+"""Real-model data-parallel check on ONE GPU: W ranks share ``cuda:0`` and exchange gradients over gloo
+(RCCL refuses two ranks on one device; the bucket / hook / optimizer code is the same for both backends).
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P \
+        tools/ddp_two_rank.py --out DIR [--precision 32|bf16]
+    python tools/ddp_two_rank.py --single --out DIR [--precision 32|bf16]      # same global batch, one process
+
+Model: RetinaNet-R18-FPN, K = 5, 128x160 inputs, BatchNorm frozen on its running statistics (per-GPU batch statistics
+-- the reference's behaviour, Q18 -- would make a 2 x 2 split differ from a batch of 4 by construction).  Global batch
+4; rank r takes images [2r, 2r+1].  Three steps of ``BucketedGradAllReduce`` + ``MasterSGD.step(grads=grad_views())``.
+Every rank saves its fp32 parameters (masters) to DIR/rank{r}.pt, the single-process run to DIR/single.pt;
+``tests/test_ddp_two_rank_gpu.py`` compares them.
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("MIOPEN_LOG_LEVEL", "1")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--single", action="store_true")
+    ap.add_argument("--precision", default="32", choices=["32", "bf16"])
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--global-batch", type=int, default=4)
+    args = ap.parse_args()
+    world = 1 if args.single else int(os.environ["WORLD_SIZE"])
+    rank = 0 if args.single else int(os.environ["RANK"])
+    if not args.single:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+
+    import synth
+    import pytorch_retinanet_amd as P
+    from pytorch_retinanet_amd.optim import MasterSGD, use_bf16_conv_weights
+
+    torch.manual_seed(1234)
+    net = P.Retinanet(num_classes=5, backbone_kind="resnet18", pretrained=False, min_size=128, max_size=160)
+    if rank == 1:                                  # sync_parameters must repair a rank that starts elsewhere
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(0.01)
+    net = net.to(dev).to(memory_format=torch.channels_last).train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()
+    bf16 = args.precision == "bf16"
+    if bf16:
+        use_bf16_conv_weights(net)
+    opt = MasterSGD(net.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    ddp = P.BucketedGradAllReduce(net, bucket_mb=8.0)           # several buckets for a 20 M-parameter model
+    assert ddp.num_buckets >= 3
+
+    rng = np.random.default_rng(99)
+    G = args.global_batch
+    per = G // world
+    losses = []
+    for step in range(args.steps):
+        images = [torch.from_numpy(rng.random((3, 128, 160), dtype=np.float32)) for _ in range(G)]
+        targets = []
+        for _ in range(G):
+            b, l = synth.gt_boxes(rng, 3, 128, 160, num_classes=5, wh_lo=20.0, wh_hi=90.0)
+            targets.append({"boxes": torch.from_numpy(b), "labels": torch.from_numpy(l)})
+        mine = slice(rank * per, (rank + 1) * per)
+        imgs = [i.to(dev) for i in images[mine]]
+        tgts = [{k: v.to(dev) for k, v in t.items()} for t in targets[mine]]
+        ddp.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+            out = net(imgs, tgts)
+            loss = out["classification_loss"] + out["regression_loss"]
+        loss.backward()
+        ddp.finish()
+        opt.step(grads=ddp.grad_views())
+        losses.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    state = {n: (p.master if hasattr(p, "master") else p.data).detach().float().cpu() for n, p in net.named_parameters()}
+    os.makedirs(args.out, exist_ok=True)
+    torch.save({"params": state, "losses": losses, "buckets": ddp.bucket_bytes()},
+               os.path.join(args.out, "single.pt" if args.single else f"rank{rank}.pt"))
+    if not args.single:
+        dist.barrier()
+        dist.destroy_process_group()
+    print(f"rank {rank}/{world}: losses {['%.5f' % x for x in losses]} buckets {ddp.num_buckets}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
