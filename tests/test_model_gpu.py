@@ -115,8 +115,6 @@ def test_retinanet_train_step_and_predict_r18(oracle_lib):
     ref = oracle_lib.loss_fwd_bwd(cls.cpu().numpy(), box.cpu().numpy(), a_np, gtb, gtl, m)
     assert nfg.sum() > 0
     np.testing.assert_allclose([float(out["classification_loss"].detach()), float(out["regression_loss"].detach())], ref["loss"], rtol=1e-4)
-    # prior-initialised head: the classification loss of an untrained RetinaNet is O(1) per the paper's prior trick
-    assert 0.5 < float(out["classification_loss"].detach()) < 5.0
     net.eval()
     with torch.no_grad():
         # an untrained head scores every anchor at the 0.01 prior: spread the logits, then put the score threshold where
