@@ -88,6 +88,14 @@ int rn_anchors_emit(const rn_level *levels, int L, const float *const *cell_anch
 int rn_iou_match(const float *anchors, int64_t anchor_bstride,
                  const float *gt_boxes, const int32_t *gt_off, int B, int64_t A,
                  float fg_thr, float bg_thr, int64_t *matches, int32_t *num_fg, void *stream);
+/* Same, with a host-side hint: total_gt = gt_off[B] - gt_off[0] when the caller knows it (tensor shapes), -1
+ * otherwise.  gt_off lives on the device and the call never syncs, so only the hint can select the batch-shaped
+ * kernel (shared anchors, <= 1024 GT boxes in the batch, <= 32 per image on average: one thread = one anchor x
+ * all images).  A wrong hint never corrupts memory, but the matches of GT rows beyond it are undefined. */
+int rn_iou_match_ex(const float *anchors, int64_t anchor_bstride,
+                    const float *gt_boxes, const int32_t *gt_off, int B, int64_t A,
+                    float fg_thr, float bg_thr, int64_t *matches, int32_t *num_fg,
+                    int64_t total_gt, void *stream);
 
 /* ---- K3 loss_fwd_bwd --------------------------------------------------------
  * Replaces RetinaNetLosses.forward / calc_loss / focal_loss / smooth_l1_loss,

@@ -145,8 +145,9 @@ def iou_match(anchors: Tensor, gt_boxes: Tensor, gt_off: Tensor, B: int, fg_thr:
     matches = torch.empty((B, A), dtype=torch.int64, device=dev)
     num_fg = torch.empty((B,), dtype=torch.int32, device=dev) if want_num_fg else None
     with torch.cuda.device(dev), _timed("iou_match", dev):
-        check(lib.rn_iou_match(_ptr(anchors), bstride, _ptr(gt_boxes), _ptr(gt_off), B, A, fg_thr, bg_thr,
-                               _ptr(matches), _ptr(num_fg), _stream(dev)), "rn_iou_match")
+        # gt_off[B] - gt_off[0] == the row count of gt_boxes (host-known): lets the library pick the batch-shaped kernel
+        check(lib.rn_iou_match_ex(_ptr(anchors), bstride, _ptr(gt_boxes), _ptr(gt_off), B, A, fg_thr, bg_thr,
+                                  _ptr(matches), _ptr(num_fg), int(gt_boxes.shape[0]), _stream(dev)), "rn_iou_match_ex")
     return matches, num_fg
 
 

@@ -562,5 +562,7 @@ def test_bucketed_ddp_world1_with_master_sgd_equals_plain_step(K):
         return {n: (p.master if hasattr(p, "master") else p.data).detach().float().cpu() for n, p in net.named_parameters()}
 
     a, b = run(True), run(False)
+    # not bit-equal: MIOpen's weight-gradient kernels accumulate with atomics, so even two identical runs differ in the
+    # last bf16 bits of the gradients (lr 1e-2, 2 steps)
     for k in a:
-        torch.testing.assert_close(a[k], b[k], rtol=0, atol=1e-6, msg=k)
+        torch.testing.assert_close(a[k], b[k], rtol=0, atol=5e-4, msg=k)

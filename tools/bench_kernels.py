@@ -72,8 +72,11 @@ def bench_k2(reps, T):
     anc = anchors_for(800, 1344)
     gt, gl, off = gts(rng, B, T, 800, 1333)
     ms = timeit(lambda: ops.iou_match(anc, gt, off, B, 0.5, 0.4), reps)
-    nbytes = B * (A * 16 + T * 16 + A * 8)
-    report(f"K2 iou_match B={B} A={A} T={T}", ms, nbytes, {"Gpairs_per_s": round(B * A * T / (ms[0] * 1e-3) / 1e9, 2)})
+    nbytes = B * (A * 16 + T * 16 + A * 8)                  # per image, anchors counted for every image
+    unique = A * 16 + B * (T * 16 + A * 8)                  # one anchor set shared by the batch: read once
+    report(f"K2 iou_match B={B} A={A} T={T}", ms, nbytes, {"Gpairs_per_s": round(B * A * T / (ms[0] * 1e-3) / 1e9, 2),
+                                                           "unique_MB": round(unique / 1e6, 2),
+                                                           "unique_GBps": round(unique / (ms[0] * 1e-3) / 1e9, 1)})
 
 
 def bench_k3(reps, dtype, B=8, want_grad=True):

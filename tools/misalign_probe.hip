@@ -40,7 +40,7 @@ __global__ void k_store(unsigned char *dst, int mis_bytes, int rowstride)
 int main()
 {
     const int blocks = 4096, rowstride = 1620;
-    const size_t bytes = (size_t)blocks * 32 * rowstride + 4096;
+    const size_t bytes = (size_t)blocks * 32 * 1664 + 4096;
     std::vector<unsigned char> h(bytes);
     for (size_t i = 0; i < bytes; ++i) h[i] = (unsigned char)((i * 2654435761u) >> 13);
     unsigned char *d; uint32_t *o;
@@ -69,6 +69,7 @@ int main()
                     }
                 printf("%s mis=%2d rowstride=%d: %s (%zu bad of %d) err=%d  %.1f us/launch\n", kind == 0 ? "lds_dma " : "reg_load", mis, rs,
                        bad ? "MISMATCH" : "OK", bad, blocks * 256, (int)err, ms * 1000 / 20);
+                fflush(stdout);
             }
         }
     for (int mis : {0, 4, 8, 12}) {
