@@ -5,18 +5,20 @@
 //
 // Two kernels:
 //   * iou_match_batch_kernel -- the train-step shape (one anchor set shared by the batch, a few GT per
-//     image): a thread owns ONE anchor for ALL images, so the anchor is loaded once per batch, the GT of the
-//     whole batch sit in LDS, and a launch is A/256 workgroups (788 at A = 201 600) instead of B*A/256.
-//     HBM traffic per batch: A*16 B anchors + sum(T)*16 B GT + B*A*8 B int64 matches.
+//     image): a thread owns ONE anchor for a group of images (the whole batch when A alone fills the chip),
+//     the group's GT sit in LDS.  HBM traffic per batch: A*16 B anchors (L2 hits for the second group) +
+//     sum(T)*16 B GT + B*A*8 B int64 matches.
 //   * iou_match_tile_kernel<R> -- everything else (T up to thousands, per-image anchors): a thread owns R
 //     anchors (strided by the workgroup size: coalesced 16-byte loads, 8-byte stores); GT tiles of 256 are
 //     staged in LDS once per workgroup and every LDS read of a GT box is used for R pairs.
 //
-// Per pair the common case costs 12 VALU instructions: when every GT box of the tile and every anchor of the
-// wave is a proper finite box (x2 > x1, y2 > y1; anchors may be degenerate) the union is positive, so the
-// quotient of a pair WITHOUT overlap is +0 and cannot change (max, first arg-max) -- the IEEE divide (~12
-// instructions) and the update sit behind a wave-uniform branch taken only when some lane overlaps.  Anything
-// else (NaN / Inf / inverted boxes) takes the careful loop, which evaluates torch's semantics pair by pair.
+// Fast loop: when every GT box of the tile and every anchor of the wave is a proper finite box (x2 > x1, y2 > y1;
+// anchors may be degenerate) the union is positive, so the quotient of a pair WITHOUT overlap is +0 and cannot
+// change (max, first arg-max).  Two wave-uniform culls follow from that: (1) a GT box that misses the bounding box
+// of the wave's anchors (a wave owns consecutive anchors = one strip of the feature map) is skipped for the whole
+// wave after 4 compares -- ~90 % of the GT boxes at the headline shapes; (2) otherwise the intersection costs 9
+// instructions per pair and the IEEE divide (~12) + update run only when some lane of the wave overlaps.
+// Anything else (NaN / Inf / inverted boxes) takes the careful loop: torch's semantics pair by pair.
 //
 // Bit-exactness with the CPU path: fp32 throughout, association
 // (area_t + area_a) - inter, IEEE divide, no FMA contraction (this file is
@@ -62,14 +64,54 @@ __device__ __forceinline__ void careful_update(Best &b, const float v, const int
 }
 
 // ---- fast pair: proper finite boxes only ------------------------------------------------------------------
-__device__ __forceinline__ float vmaxf(const float a, const float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-__device__ __forceinline__ float vminf(const float a, const float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-
-__device__ __forceinline__ float inter_fast(const rn::f32x4 t, const rn::f32x4 a)
+// inter = max(min(t.z, a.z) - max(t.x, a.x), 0) * max(min(t.w, a.w) - max(t.y, a.y), 0) in exactly 9 instructions.
+// v_max_f32 / v_min_f32 give, for finite inputs, the same values as torch's max / min / clamp up to the sign of a zero.
+// One asm block because fmaxf / fminf make the compiler re-canonicalise (v_max x, x, x) every loop-invariant operand
+// inside the pair loop.  The GT box is wave-uniform and sits in SGPRs (one scalar operand per VALU instruction).
+struct GtBox { float x, y, z, w, area; };           // wave-uniform
+__device__ __forceinline__ float inter_fast(const GtBox t, const rn::f32x4 a)
 {
-    const float w = vmaxf(vminf(t.z, a.z) - vmaxf(t.x, a.x), 0.0f);
-    const float h = vmaxf(vminf(t.w, a.w) - vmaxf(t.y, a.y), 0.0f);
-    return w * h;
+    float inter, t0, t1;
+    asm("v_min_f32 %0, %5, %9\n\t"
+        "v_max_f32 %1, %3, %7\n\t"
+        "v_sub_f32 %0, %0, %1\n\t"
+        "v_min_f32 %1, %6, %10\n\t"
+        "v_max_f32 %2, %4, %8\n\t"
+        "v_sub_f32 %1, %1, %2\n\t"
+        "v_max_f32 %0, 0, %0\n\t"
+        "v_max_f32 %1, 0, %1\n\t"
+        "v_mul_f32 %0, %0, %1"
+        : "=&v"(inter), "=&v"(t0), "=&v"(t1)
+        : "s"(t.x), "s"(t.y), "s"(t.z), "s"(t.w), "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w));
+    return inter;
+}
+
+// GT boxes reach the pair loop through LDS -> one box per LANE (conflict-free ds_read_b128) -> v_readlane into SGPRs.
+// Reading s_box[j] directly from every lane (a same-address ds_read_b128) is serviced at ~1 lane group per cycle on
+// gfx950: measured 1250 cycles per GT box and wave with 24 waves per CU -- 10x the whole pair arithmetic.
+__device__ __forceinline__ float lane_f(const float v, const int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ GtBox gt_of_lane(const rn::f32x4 box, const float area, const int l)
+{
+    return GtBox{lane_f(box.x, l), lane_f(box.y, l), lane_f(box.z, l), lane_f(box.w, l), lane_f(area, l)};
+}
+__device__ __forceinline__ rn::f32x4 vec(const GtBox g) { return rn::f32x4{g.x, g.y, g.z, g.w}; }
+
+// Bounding box of a wave's anchors, wave-uniform (x0 = min x1, y0 = min y1, x1 = max x2, y1 = max y2).  A GT box that does
+// not properly intersect it has w <= 0 or h <= 0 against every anchor of the wave: all its pairs have inter == 0.
+struct WaveBox { float x0, y0, x1, y1; };
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, RN_WAVE));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, RN_WAVE));
+    return v;
+}
+__device__ __forceinline__ bool may_overlap(const WaveBox bb, const GtBox g)
+{
+    return g.z > bb.x0 && bb.x1 > g.x && g.w > bb.y0 && bb.y1 > g.y;
 }
 
 __device__ __forceinline__ bool gt_is_proper(const rn::f32x4 g, const float area)
@@ -92,22 +134,27 @@ __device__ __forceinline__ int64_t classify(const float best, const int bi, cons
 }
 
 // ============================================================================================================
-// Shared anchors, small GT sets: one thread = one anchor x all images of the batch.
+// Shared anchors, small GT sets: one thread = one anchor x `ipb` images of the batch (blockIdx.y selects the image group).
 __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_batch_kernel(
     const rn::f32x4 *__restrict__ anchors, const rn::f32x4 *__restrict__ gt, const int32_t *__restrict__ gt_off,
-    const int B, const int64_t A, const float fg_thr, const float bg_thr, int64_t *__restrict__ matches,
+    const int B, const int ipb, const int64_t A, const float fg_thr, const float bg_thr, int64_t *__restrict__ matches,
     int32_t *__restrict__ num_fg)
 {
-    __shared__ rn::f32x4 s_box[BATCH_GT_MAX];
-    __shared__ float s_area[BATCH_GT_MAX];
-    __shared__ int s_off[65];
+    __shared__ rn::f32x4 s_box[BATCH_GT_MAX + RN_WAVE];   // (a wave reads 64 entries at a time, possibly past the last row)
+    __shared__ float s_area[BATCH_GT_MAX + RN_WAVE];
     __shared__ int s_bad;
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & (RN_WAVE - 1);
+    const int b0 = blockIdx.y * ipb, b1 = min(B, b0 + ipb);
+    // the anchor load goes out first: its latency overlaps the GT staging below
+    const int64_t a_idx = (int64_t)blockIdx.x * MATCH_BLOCK + tid;
+    const bool live = a_idx < A;
+    rn::f32x4 an = {0.f, 0.f, 0.f, 0.f};
+    if (live) an = anchors[a_idx];
+    const int g0 = gt_off[b0];                                          // scalar loads (uniform addresses)
+    const int total = min(gt_off[b1] - g0, BATCH_GT_MAX);               // (the host promised <= BATCH_GT_MAX)
     if (tid == 0) s_bad = 0;
-    if (tid <= B) s_off[tid] = gt_off[tid] - gt_off[0];
     __syncthreads();
-    const int total = min(s_off[B], BATCH_GT_MAX), g0 = gt_off[0];      // (the host promised total <= BATCH_GT_MAX)
     bool ok = true;
     for (int j = tid; j < total; j += MATCH_BLOCK) {
         const rn::f32x4 g = gt[g0 + j];
@@ -119,31 +166,39 @@ __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_batch_kernel(
     if (!ok) s_bad = 1;                                    // benign race: every writer stores 1
     __syncthreads();
 
-    const int64_t a_idx = (int64_t)blockIdx.x * MATCH_BLOCK + tid;
-    const bool live = a_idx < A;
-    rn::f32x4 an = {0.f, 0.f, 0.f, 0.f};
-    if (live) an = anchors[a_idx];
     const float area_a = (an.z - an.x) * (an.w - an.y);
     const bool fast = !s_bad && __all(anchor_is_proper(an, area_a));
+    WaveBox bb = {0.f, 0.f, 0.f, 0.f};
+    if (fast) bb = WaveBox{wave_min(an.x), wave_min(an.y), wave_max(an.z), wave_max(an.w)};
 
-    for (int b = 0; b < B; ++b) {
-        const int j0 = s_off[b], T = s_off[b + 1] - j0;
+    for (int b = b0; b < b1; ++b) {
+        const int j0 = gt_off[b] - g0, T = gt_off[b + 1] - gt_off[b];
         float best = 0.0f;
         int bi = 0;
-        if (fast) {
-            for (int j = 0; j < T; ++j) {
-                const rn::f32x4 g = s_box[j0 + j];
-                const float inter = inter_fast(g, an);
-                if (__any(inter != 0.0f)) {
-                    const float v = inter / ((s_area[j0 + j] + area_a) - inter);
-                    if (v > best) { best = v; bi = j; }
+        Best bb2 = {0.0f, 0, false};
+        for (int c = 0; c < T; c += RN_WAVE) {
+            const rn::f32x4 mine = s_box[j0 + c + lane];    // lane l holds GT row c + l of this image
+            const float mine_a = s_area[j0 + c + lane];
+            const int m = min(RN_WAVE, T - c);
+            if (fast) {
+                for (int l = 0; l < m; ++l) {
+                    const GtBox g = gt_of_lane(mine, mine_a, l);
+                    if (may_overlap(bb, g)) {               // wave-uniform
+                        const float inter = inter_fast(g, an);
+                        if (__any(inter != 0.0f)) {
+                            const float v = inter / ((g.area + area_a) - inter);
+                            if (v > best) { best = v; bi = c + l; }
+                        }
+                    }
+                }
+            } else {
+                for (int l = 0; l < m; ++l) {
+                    const GtBox g = gt_of_lane(mine, mine_a, l);
+                    careful_update(bb2, iou_pair(vec(g), g.area, an, area_a), c + l);
                 }
             }
-        } else {
-            Best bb = {0.0f, 0, false};
-            for (int j = 0; j < T; ++j) careful_update(bb, iou_pair(s_box[j0 + j], s_area[j0 + j], an, area_a), j);
-            best = bb.v; bi = bb.i;
         }
+        if (!fast) { best = bb2.v; bi = bb2.i; }
         const int64_t r = classify(best, bi, T, fg_thr, bg_thr);
         if (live) matches[(int64_t)b * A + a_idx] = r;
         if (num_fg) {
@@ -165,24 +220,33 @@ __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_tile_kernel(
     __shared__ float s_area[GT_TILE];
     __shared__ int s_bad[2];
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & (RN_WAVE - 1);
     const int b = blockIdx.y;
     const int t0 = gt_off[b];
     const int T = gt_off[b + 1] - t0;
-    const int64_t a0 = (int64_t)blockIdx.x * (MATCH_BLOCK * R) + tid;
+    // a wave owns R * 64 CONSECUTIVE anchors (anchor r of a lane = a0 + 64 r): one contiguous strip of the feature map,
+    // so the "does any lane overlap this GT box" branch below is taken as rarely as possible
+    const int64_t a0 = (int64_t)blockIdx.x * (MATCH_BLOCK * R) + (tid >> 6) * (RN_WAVE * R) + (tid & (RN_WAVE - 1));
 
     rn::f32x4 an[R];
     float area_a[R];
     bool a_ok = true;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int64_t a_idx = a0 + (int64_t)r * MATCH_BLOCK;
+        const int64_t a_idx = a0 + (int64_t)r * RN_WAVE;
         an[r] = rn::f32x4{0.f, 0.f, 0.f, 0.f};
         if (a_idx < A) an[r] = anchors[(int64_t)b * anchor_bstride4 + a_idx];
         area_a[r] = (an[r].z - an[r].x) * (an[r].w - an[r].y);
         a_ok = a_ok && anchor_is_proper(an[r], area_a[r]);
     }
     const bool wave_ok = __all(a_ok);
+    WaveBox bb = {0.f, 0.f, 0.f, 0.f};
+    if (wave_ok) {
+        float x0 = an[0].x, y0 = an[0].y, x1 = an[0].z, y1 = an[0].w;
+#pragma unroll
+        for (int r = 1; r < R; ++r) { x0 = fminf(x0, an[r].x); y0 = fminf(y0, an[r].y); x1 = fmaxf(x1, an[r].z); y1 = fmaxf(y1, an[r].w); }
+        bb = WaveBox{wave_min(x0), wave_min(y0), wave_max(x1), wave_max(y1)};
+    }
 
     Best best[R];
 #pragma unroll
@@ -201,7 +265,11 @@ __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_tile_kernel(
             if (!gt_is_proper(g, ar)) s_bad[it & 1] = 1;
         }
         __syncthreads();
+#ifdef RN_K2_FORCE_FAST
+        if (true) {
+#else
         if (wave_ok && !s_bad[it & 1]) {
+#endif
             // once a tile has been processed here, `have` only means "best/bi hold torch's running result so far";
             // with proper boxes every quotient is >= +0, so starting from (0, index 0) and updating on strict > is exact
             // (a negative running maximum can only come from an earlier careful tile: this tile's first pair beats it)
@@ -210,32 +278,35 @@ __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_tile_kernel(
                 if (!best[r].have) best[r] = Best{0.0f, 0, true};
                 else if (best[r].v < 0.0f) best[r] = Best{0.0f, base, true};
             }
-#pragma unroll 2
-            for (int j = 0; j < n; ++j) {
-                const rn::f32x4 g = s_box[j];
-                float inter[R];
-                bool any = false;
+            for (int c = 0; c < n; c += RN_WAVE) {
+                const rn::f32x4 mine = s_box[c + lane];     // lane l holds GT row base + c + l
+                const float mine_a = s_area[c + lane];
+                const int m = min(RN_WAVE, n - c);
+                for (int l = 0; l < m; ++l) {
+                    const GtBox g = gt_of_lane(mine, mine_a, l);
+                    if (may_overlap(bb, g)) {               // wave-uniform: most GT boxes miss the wave's strip of anchors
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    inter[r] = inter_fast(g, an[r]);
-                    any = any || inter[r] != 0.0f;
-                }
-                if (__any(any)) {
-                    const float ga = s_area[j];
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        // a NaN best (from an earlier careful tile) stays: (v > NaN) is false
-                        const float v = inter[r] / ((ga + area_a[r]) - inter[r]);
-                        if (v > best[r].v) { best[r].v = v; best[r].i = base + j; }
+                        for (int r = 0; r < R; ++r) {
+                            const float inter = inter_fast(g, an[r]);
+                            if (__any(inter != 0.0f)) {
+                                // a NaN best (from an earlier careful tile) stays: (v > NaN) is false
+                                const float v = inter / ((g.area + area_a[r]) - inter);
+                                if (v > best[r].v) { best[r].v = v; best[r].i = base + c + l; }
+                            }
+                        }
                     }
                 }
             }
         } else {
-            for (int j = 0; j < n; ++j) {
-                const rn::f32x4 g = s_box[j];
-                const float ga = s_area[j];
+            for (int c = 0; c < n; c += RN_WAVE) {
+                const rn::f32x4 mine = s_box[c + lane];
+                const float mine_a = s_area[c + lane];
+                const int m = min(RN_WAVE, n - c);
+                for (int l = 0; l < m; ++l) {
+                    const GtBox g = gt_of_lane(mine, mine_a, l);
 #pragma unroll
-                for (int r = 0; r < R; ++r) careful_update(best[r], iou_pair(g, ga, an[r], area_a[r]), base + j);
+                    for (int r = 0; r < R; ++r) careful_update(best[r], iou_pair(vec(g), g.area, an[r], area_a[r]), base + c + l);
+                }
             }
         }
     }
@@ -243,7 +314,7 @@ __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_tile_kernel(
     int nfg = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const int64_t a_idx = a0 + (int64_t)r * MATCH_BLOCK;
+        const int64_t a_idx = a0 + (int64_t)r * RN_WAVE;
         const int64_t m = classify(best[r].v, best[r].i, T, fg_thr, bg_thr);
         if (a_idx < A) {
             matches[(int64_t)b * A + a_idx] = m;
@@ -276,9 +347,14 @@ RN_API int rn_iou_match_ex(const float *anchors, int64_t anchor_bstride, const f
     // The batch kernel needs host knowledge of sum(T) (gt_off lives on the device and this call never syncs):
     // callers that know it pass total_gt >= 0; -1 means unknown -> the general kernel.
     if (anchor_bstride == 0 && B <= 64 && total_gt >= 0 && total_gt <= BATCH_GT_MAX && total_gt <= 32 * (int64_t)B) {
-        const dim3 grid((unsigned)((A + MATCH_BLOCK - 1) / MATCH_BLOCK));
+        // images per workgroup: all of them when the anchors alone give >= 1024 workgroups, else split the batch
+        const int64_t bx = (A + MATCH_BLOCK - 1) / MATCH_BLOCK;
+        int by = (int)((1024 + bx - 1) / bx);
+        by = by < 1 ? 1 : (by > B ? B : by);
+        const int ipb = (B + by - 1) / by;
+        const dim3 grid((unsigned)bx, (unsigned)((B + ipb - 1) / ipb));
         hipLaunchKernelGGL(iou_match_batch_kernel, grid, dim3(MATCH_BLOCK), 0, st, (const rn::f32x4 *)anchors,
-                           (const rn::f32x4 *)gt_boxes, gt_off, B, A, fg_thr, bg_thr, matches, num_fg);
+                           (const rn::f32x4 *)gt_boxes, gt_off, B, ipb, A, fg_thr, bg_thr, matches, num_fg);
     } else if (total_gt >= 0 && total_gt <= 32 * (int64_t)B) {
         const dim3 grid((unsigned)((A + MATCH_BLOCK * 2 - 1) / (MATCH_BLOCK * 2)), (unsigned)B);
         hipLaunchKernelGGL(iou_match_tile_kernel<2>, grid, dim3(MATCH_BLOCK), 0, st, (const rn::f32x4 *)anchors, anchor_bstride / 4,
