@@ -209,22 +209,32 @@ int rn_conv3x3_canvas_wgrad_batched(const void *const *gs, const void *const *xs
                                     int64_t M, int Wp, int Cin, int Cout, const void *zeros, void *workspace,
                                     size_t workspace_bytes, void *stream);
 
-/* The same weight gradient for one ordinary dense channels-last conv (no border: out-of-image taps contribute zero). */
-int rn_conv3x3_nhwc_wgrad(const void *g, const void *x, void *dw, int dtype, int N, int H, int W, int Cin, int Cout,
-                          const void *zeros, void *workspace, size_t workspace_bytes, void *stream);
-
-/* The same kernel on an ordinary dense channels-last tensor [N][H][W][C] (no border, no mask): out-of-image taps
- * read `zeros` (>= 256 bytes of zeros, 16-byte aligned, caller-owned).  Used for the stride-1 3x3 convs of the
- * backbone (retinanet/backbone.py:112-114, conv2 of layer3) and the FPN smoothing convs (retinanet/layers.py:23-28)
- * where it beats MIOpen (M = N*H*W >= ~30 000 positions, Cin % 64 == 0, Cout % 256 == 0, bf16). */
-int rn_conv3x3_nhwc(const void *x, const void *w, const float *bias, void *y, int dtype, int N, int H, int W,
-                    int Cin, int Cout, int relu, const void *zeros, void *stream);
-
-/* 1x1 / stride-1 convolution = the GEMM Y[M][Cout] = X[M][Cin] * W[Cout][Cin]^T (+ bias) on the same MFMA pipeline
- * (bf16, Cin % 64 == 0 and >= 128, Cout % 256 == 0).  Opt-in experiment for the bottleneck 1x1 convs
- * (retinanet/backbone.py:111-116). */
-int rn_conv1x1_nhwc(const void *x, const void *w, const float *bias, void *y, int dtype, int64_t M, int Cin, int Cout,
-                    void *stream);
+/* ---- class-output conv on the canvas with DENSE per-level results -----------------------------------------------
+ * The last 3x3 conv of the classification subnet (retinanet/layers.py:163-167: 256 -> 9*K channels) reads the tower
+ * output where it lies -- on the zero-bordered canvas -- and writes, per pyramid level, the dense channels-last
+ * tensor ys[l] = [N][h_l][w_l][Cout] bf16, which IS the [N][h*w*9][K] logits tensor of retinanet/layers.py:189-191
+ * that rn_loss_fwd_bwd_levels / rn_detect_levels stream (no dead classes, no unpack copy).  levels[l] = where level
+ * l sits on the canvas (top-left row / column, height, width).  Cout: any even number (rows of Cout elements start
+ * on 4-byte boundaries); Cin % 64 == 0; w [Cout][3][3][Cin] bf16; bias f32[Cout] or NULL; zeros: >= 256 bytes of
+ * zeros, 16-byte aligned. */
+typedef struct rn_canvas_level { int32_t r0, c0, h, w; } rn_canvas_level;
+int rn_conv3x3_canvas_to_levels(const void *x, const void *w, const float *bias, const rn_canvas_level *levels, int L,
+                                void *const *ys, int dtype, int N, int Hp, int Wp, int Cin, int Cout,
+                                const void *zeros, void *stream);
+/* Its data gradient: y[M = N*Hp*Wp][Cout] (canvas, masked) = conv of the dense per-level gradients gs[l] =
+ * [N][h_l][w_l][row_elems] with w [Cout][3][3][Kpad] bf16 = the forward weight with taps reversed and channel roles
+ * swapped, its contraction axis laid out in Kpad (next multiple of 64) slots: slot k = channel k for k < e =
+ * row_elems - row_elems % 8; when row_elems % 8 != 0 the kernel fetches the LAST 8 channels of a row for slots e .. e+7
+ * (it never reads past a row), so those slots carry channel row_elems - 8 + (k - e) with ZERO weight on the ones that
+ * repeat (< e); every later slot is zero.  row_elems even and >= 8. */
+int rn_conv3x3_levels_to_canvas(const void *const *gs, const rn_canvas_level *levels, int L, int row_elems,
+                                const void *w, const uint8_t *mask, void *y, int dtype, int N, int Hp, int Wp,
+                                int Kpad, int Cout, const void *zeros, void *stream);
+/* Its weight gradient: dw [row_elems][3][3][Cin = 256] bf16 = sum over canvas positions of gs (gathered) x the
+ * tapped canvas input x [M][256].  workspace: rn_conv3x3_wgrad_workspace_bytes((row_elems + 255) / 256, M). */
+int rn_conv3x3_levels_wgrad(const void *const *gs, const rn_canvas_level *levels, int L, int row_elems,
+                            const void *x, void *dw, int dtype, int N, int Hp, int Wp, int Cin,
+                            const void *zeros, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- stem max pooling, channels-last, no index tensor -------------------------------------------------
  * nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the reference's stem (retinanet/backbone.py:251) on

@@ -12,7 +12,6 @@ from typing import Dict, List, Optional, Type, Union
 import torch
 from torch import Tensor, nn
 
-from .biasact import conv1x1, conv3x3
 from .norm import FusedBatchNorm2d
 from .pool import FusedMaxPool2d
 
@@ -71,9 +70,9 @@ class Bottleneck(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         identity = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(conv1x1(self.conv1, x), relu=True)
-        out = self.bn2(conv3x3(self.conv2, out), relu=True)                 # MFMA kernel where it beats MIOpen (biasact.conv3x3)
-        return self.bn3(conv1x1(self.conv3, out), relu=True, residual=identity)      # relu(bn3(.) + identity), one kernel
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        return self.bn3(self.conv3(out), relu=True, residual=identity)      # relu(bn3(.) + identity), one kernel
 
 
 class ResNetBackbone(nn.Module):

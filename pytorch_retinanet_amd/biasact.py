@@ -329,7 +329,7 @@ def unpack_levels(canvas: Canvas, x: Tensor) -> List[Tensor]:
 
 
 # ---------------------------------------------------------------------------------------------------
-# The MFMA conv on ordinary dense tensors (stride-1 3x3 convs of layer3 and the FPN smoothing convs)
+# The class-output conv (retinanet/layers.py:163-167) on the canvas, dense per-level logits out
 _ZEROS: Dict[int, Tensor] = {}
 
 
@@ -340,10 +340,39 @@ def _zero_page(dev: torch.device) -> Tensor:
     return z
 
 
-class _Conv3x3Dense(torch.autograd.Function):
+class RnCanvasLevel(C.Structure):
+    _fields_ = [("r0", C.c_int32), ("c0", C.c_int32), ("h", C.c_int32), ("w", C.c_int32)]
+
+
+def _level_array(cv: "Canvas"):
+    return (RnCanvasLevel * len(cv.shapes))(*[RnCanvasLevel(r, c, h, w) for (r, c), (h, w) in zip(cv.origin, cv.shapes)])
+
+
+def _dgrad_weight(w: Tensor) -> Tensor:
+    """Forward weight [Cout, Cin, 3, 3] -> the data gradient's weight [Cin, Kpad, 3, 3] (channels-last memory
+    [Cin][3][3][Kpad]): taps reversed, channel roles swapped, and the contraction axis laid out as the kernel walks it
+    (``rn_conv3x3_levels_to_canvas``): slot k = channel k below e = Cout - Cout % 8; if Cout % 8 != 0 the slots
+    e .. e+7 carry channels Cout-8 .. Cout-1 with zero weight on the repeated ones; zeros up to Kpad."""
+    Cout, Cin = w.shape[0], w.shape[1]
+    Kpad = (Cout + 63) // 64 * 64
+    wt = w.flip(2, 3).transpose(0, 1)                                   # [Cin, Cout, 3, 3]
+    out = torch.zeros((Cin, Kpad, 3, 3), dtype=w.dtype, device=w.device).contiguous(memory_format=torch.channels_last)
+    e = Cout - Cout % 8
+    out[:, :e] = wt[:, :e]
+    if Cout % 8:
+        s = 8 - Cout % 8                                                # repeated channels at the head of the last piece
+        out[:, e + s: e + 8] = wt[:, e:]
+    return out
+
+
+class _ClsOutputConv(torch.autograd.Function):
+    """``class_subnet_output`` on the zero-bordered canvas: the result is written per pyramid level as the dense
+    ``[N, h*w*A, K]`` logits the loss / detection kernels stream (exactly Cout = A*K channels: no dead classes, no unpack
+    copy); data and weight gradients gather the dense per-level gradients back (``csrc/conv.hip``, level modes)."""
+
     @staticmethod
-    def forward(ctx, x, w, bias):
-        N, Cin, H, W = x.shape
+    def forward(ctx, x, w, bias, canvas, num_classes):
+        N, Cin, Hp, Wp = x.shape
         Cout = w.shape[0]
         dev = x.device
         if dev.index != torch.cuda.current_device():
@@ -351,156 +380,60 @@ class _Conv3x3Dense(torch.autograd.Function):
         stream = torch.cuda.current_stream().cuda_stream
         if not _cl(w):
             w = w.contiguous(memory_format=torch.channels_last)
-        y = torch.empty((N, Cout, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
-        check(lib.rn_conv3x3_nhwc(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else 0, y.data_ptr(), _DT[x.dtype],
-                                  N, H, W, Cin, Cout, 0, _zero_page(dev).data_ptr(), stream), "rn_conv3x3_nhwc")
+        ys = [torch.empty((N, h * wd * (Cout // num_classes), num_classes), dtype=x.dtype, device=dev) for h, wd in canvas.shapes]
+        check(lib.rn_conv3x3_canvas_to_levels(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else 0, _level_array(canvas),
+                                              len(ys), _ptr_array(ys), _DT[x.dtype], N, Hp, Wp, Cin, Cout, _zero_page(dev).data_ptr(),
+                                              stream), "rn_conv3x3_canvas_to_levels")
         ctx.save_for_backward(x, w)
-        ctx.has_bias = bias is not None
-        return y
+        ctx.canvas, ctx.has_bias = canvas, bias is not None
+        return tuple(ys)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, *dys):
         x, w = ctx.saved_tensors
-        N, Cin, H, W = x.shape
+        cv = ctx.canvas
+        N, Cin, Hp, Wp = x.shape
         Cout = w.shape[0]
         dev = x.device
         if dev.index != torch.cuda.current_device():
             torch.cuda.set_device(dev)
         stream = torch.cuda.current_stream().cuda_stream
-        if dy.dtype != x.dtype or not _cl(dy):
-            dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
-        dx = dw = db = None
-        if ctx.needs_input_grad[0] and Cin % 256 == 0:
-            wt = w.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
-            dx = torch.empty_like(x)
-            check(lib.rn_conv3x3_nhwc(dy.data_ptr(), wt.data_ptr(), 0, dx.data_ptr(), _DT[x.dtype], N, H, W, Cout, Cin, 0,
-                                      _zero_page(dev).data_ptr(), stream), "rn_conv3x3_nhwc")
-        need = [ctx.needs_input_grad[0] and dx is None, ctx.needs_input_grad[1], False]
-        if need[0] or need[1]:
-            r = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, need)
-            dx = r[0] if need[0] else dx
-            dw = r[1] if need[1] else None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty((Cout,), dtype=torch.float32, device=dev)
-            wp, wn = _workspace(dev, stream, Cout)
-            check(lib.rn_bias_act_backward(dy.data_ptr(), 0, 0, 0, db.data_ptr(), _DT[x.dtype], N * H * W, Cout, 1, 0, wp, wn, stream),
-                  "rn_bias_act_backward")
-        return dx, dw, db
-
-
-class _Conv3x3MfmaWgrad(torch.autograd.Function):
-    """A 3x3 / stride-1 / pad-1, 256 -> 256 bf16 conv whose forward and data gradient stay on MIOpen and whose WEIGHT
-    gradient runs on the MFMA position-contraction GEMM (``rn_conv3x3_nhwc_wgrad``) -- the one piece where the
-    hand-written kernel is clearly ahead on these shapes (MIOpen's split-K wrw + zero / cast kernels)."""
-
-    @staticmethod
-    def forward(ctx, x, w, bias):
-        y = F.conv2d(x, w, None if bias is None else bias.to(x.dtype), padding=1)
-        ctx.save_for_backward(x, w)
-        ctx.has_bias = bias is not None
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        N, Cin, H, W = x.shape
-        dev = x.device
-        if dev.index != torch.cuda.current_device():
-            torch.cuda.set_device(dev)
-        stream = torch.cuda.current_stream().cuda_stream
-        if dy.dtype != x.dtype or not _cl(dy):
-            dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        gs = []
+        for dy, (h, wd) in zip(dys, cv.shapes):
+            if dy is None:
+                dy = torch.zeros((N, h * wd * Cout), dtype=x.dtype, device=dev)
+            gs.append(dy.to(x.dtype).contiguous())
+        lv = _level_array(cv)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+            dx = torch.empty_like(x)
+            wt = _dgrad_weight(w)
+            check(lib.rn_conv3x3_levels_to_canvas(_ptr_array(gs), lv, len(gs), Cout, wt.data_ptr(), cv.mask.data_ptr(), dx.data_ptr(),
+                                                  _DT[x.dtype], N, Hp, Wp, wt.shape[1], Cin, _zero_page(dev).data_ptr(), stream),
+                  "rn_conv3x3_levels_to_canvas")
         if ctx.needs_input_grad[1]:
-            need = lib.rn_conv3x3_wgrad_workspace_bytes(1, N * H * W)
+            need = lib.rn_conv3x3_wgrad_workspace_bytes((Cout + 255) // 256, N * Hp * Wp)
             key = (dev.index, stream)
             wsb = _WG_WS.get(key)
             if wsb is None or wsb.numel() < need:
                 wsb = _WG_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
-            dw = torch.empty((256, 256, 3, 3), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
-            check(lib.rn_conv3x3_nhwc_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), _DT[x.dtype], N, H, W, 256, 256,
-                                            _zero_page(dev).data_ptr(), wsb.data_ptr(), wsb.numel(), stream), "rn_conv3x3_nhwc_wgrad")
+            dw = torch.empty((Cout, Cin, 3, 3), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+            check(lib.rn_conv3x3_levels_wgrad(_ptr_array(gs), lv, len(gs), Cout, x.data_ptr(), dw.data_ptr(), _DT[x.dtype], N, Hp, Wp, Cin,
+                                              _zero_page(dev).data_ptr(), wsb.data_ptr(), wsb.numel(), stream), "rn_conv3x3_levels_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.empty((256,), dtype=torch.float32, device=dev)
-            wp, wn = _workspace(dev, stream, 256)
-            check(lib.rn_bias_act_backward(dy.data_ptr(), 0, 0, 0, db.data_ptr(), _DT[x.dtype], N * H * W, 256, 1, 0, wp, wn, stream),
-                  "rn_bias_act_backward")
-        return dx, dw, db
+            db = sum(g.reshape(-1, Cout).sum(0, dtype=torch.float32) for g in gs)
+        return dx, dw, db, None, None
 
 
-# off by default: a tie with MIOpen inside the step on the layer3 / FPN shapes (216.2 / 217.3 vs 215.8 / 217.3 images/s)
-MFMA_DENSE_WGRAD = os.environ.get("RN_MFMA_DENSE_WGRAD", "0") == "1"
-MFMA_CONV_MIN_POSITIONS = 30000       # below this the kernel's 256-row tiles leave most CUs idle and MIOpen is as fast
-# Off by default: in isolation the kernel beats MIOpen on these shapes (layer3 conv2 78 vs 122 us, FPN P3 232 vs 272 us),
-# but inside the train step the A/B is a tie (211.3 vs 211.4 images/s on one box), so the stock path stays.  RN_MFMA_CONV=1.
-MFMA_DENSE_CONV = os.environ.get("RN_MFMA_CONV", "0") == "1"
+def cls_output_conv_fusable(x: Tensor, conv, canvas: "Canvas") -> bool:
+    "bf16 canvas with a zero border, 3x3 / stride 1 / pad 1, Cin == 256, an even number of output channels (>= 8), <= 6 levels."
+    return (x.is_cuda and x.dtype == torch.bfloat16 and _cl(x) and canvas.pad == 1 and conv.kernel_size == (3, 3)
+            and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv.in_channels == 256 and conv.out_channels % 2 == 0 and 8 <= conv.out_channels <= 1024
+            and len(canvas.shapes) <= 6 and x.shape[0] * canvas.H * canvas.W < (1 << 22)
+            and (conv.bias is None or conv.bias.dtype == torch.float32))
 
 
-def conv3x3(conv, x: Tensor) -> Tensor:
-    """``conv(x)`` for a 3x3 / stride-1 / pad-1 ``nn.Conv2d``: on the MFMA kernel when it is the faster one (bf16 CUDA
-    channels-last input, Cin % 64 == 0, Cout % 256 == 0, >= 30 000 output positions), else the module itself."""
-    if (x.is_cuda and x.dtype == torch.bfloat16 and _cl(x) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
-            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels % 64 == 0
-            and conv.out_channels % 256 == 0 and x.shape[0] * x.shape[2] * x.shape[3] >= MFMA_CONV_MIN_POSITIONS
-            and (conv.bias is None or conv.bias.dtype == torch.float32) and MFMA_DENSE_CONV):
-        return _Conv3x3Dense.apply(x, conv.weight.to(x.dtype), conv.bias)
-    if (MFMA_DENSE_WGRAD and x.is_cuda and x.dtype == torch.bfloat16 and _cl(x) and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
-            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels == 256
-            and conv.out_channels == 256 and x.shape[0] * x.shape[2] * x.shape[3] >= MFMA_CONV_MIN_POSITIONS
-            and (conv.bias is None or conv.bias.dtype == torch.float32) and torch.is_grad_enabled() and conv.weight.requires_grad):
-        w = conv.weight.to(x.dtype)
-        return _Conv3x3MfmaWgrad.apply(x, w if _cl(w) else w.contiguous(memory_format=torch.channels_last), conv.bias)
-    return conv(x)
-
-
-class _Conv1x1(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, w):
-        N, Cin, H, W = x.shape
-        Cout = w.shape[0]
-        dev = x.device
-        if dev.index != torch.cuda.current_device():
-            torch.cuda.set_device(dev)
-        y = torch.empty((N, Cout, H, W), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
-        check(lib.rn_conv1x1_nhwc(x.data_ptr(), w.data_ptr(), 0, y.data_ptr(), _DT[x.dtype], N * H * W, Cin, Cout,
-                                  torch.cuda.current_stream().cuda_stream), "rn_conv1x1_nhwc")
-        ctx.save_for_backward(x, w)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        N, Cin, H, W = x.shape
-        Cout = w.shape[0]
-        dev = x.device
-        if dev.index != torch.cuda.current_device():
-            torch.cuda.set_device(dev)
-        if dy.dtype != x.dtype or not _cl(dy):
-            dy = dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
-        dx = dw = None
-        if ctx.needs_input_grad[0] and Cin % 256 == 0 and Cout >= 128:
-            wt = w.reshape(Cout, Cin).t().contiguous()                      # [Cin][Cout]
-            dx = torch.empty_like(x)
-            check(lib.rn_conv1x1_nhwc(dy.data_ptr(), wt.data_ptr(), 0, dx.data_ptr(), _DT[x.dtype], N * H * W, Cout, Cin,
-                                      torch.cuda.current_stream().cuda_stream), "rn_conv1x1_nhwc")
-        need = [ctx.needs_input_grad[0] and dx is None, ctx.needs_input_grad[1], False]
-        if need[0] or need[1]:
-            r = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, need)
-            dx = r[0] if need[0] else dx
-            dw = r[1] if need[1] else None
-        return dx, dw
-
-
-MFMA_CONV1X1 = os.environ.get("RN_MFMA_1X1", "0") == "1"
-
-
-def conv1x1(conv, x: Tensor) -> Tensor:
-    "``conv(x)`` for a bias-free 1x1 / stride-1 ``nn.Conv2d``; opt-in (RN_MFMA_1X1=1) MFMA GEMM path for A/B measurements."
-    if (MFMA_CONV1X1 and x.is_cuda and x.dtype == torch.bfloat16 and _cl(x) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
-            and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and conv.in_channels % 64 == 0
-            and conv.in_channels >= 128 and conv.out_channels % 256 == 0):
-        w = conv.weight.to(x.dtype)
-        return _Conv1x1.apply(x, w if w.is_contiguous() or _cl(w) else w.contiguous())
-    return conv(x)
+def cls_output_conv(x: Tensor, conv, canvas: "Canvas", num_classes: int) -> List[Tensor]:
+    "``conv(x)`` for the class-output conv on a canvas -> per-level logits ``[N, h*w*A, num_classes]`` (dense)."
+    return list(_ClsOutputConv.apply(x, conv.weight.to(x.dtype), conv.bias, canvas, num_classes))

@@ -35,38 +35,97 @@ constexpr int CONV_LDS_BYTES = 5 * CONV_BM * CONV_BK * 2;        // 160 KiB
 #define SWZ(row) (((row) >> 1) & 7)
 
 constexpr int CONV_MAX_PROBLEMS = 4;
+
+// The pyramid levels as they sit on the canvas, and their DENSE per-level tensors [N][h][w][row_elems] (the layout the
+// loss / detection kernels stream: [N][h*w*9][K] with row_elems = 9 K).  Used by the class-output conv, whose
+// 9 x 90 = 810 output channels are written densely (no dead classes), and by its gradients.  Packed (16-bit fields) so the
+// whole set stays in a few SGPRs next to the MFMA kernels' other arguments.
+constexpr int CONV_LEVELS = 6;
+struct LevelSet {
+    int32_t L, row_elems;
+    uint32_t origin[CONV_LEVELS];       // r0 | c0 << 16
+    uint32_t extent[CONV_LEVELS];       // h | w << 16
+    uint16_t *ptr[CONV_LEVELS];
+};
+
+// Row of canvas position (image n, canvas row y, canvas column x) in its level's dense tensor, or null for border / gap
+// positions.  Two steps to stay register-lean inside the MFMA kernels: a 32-bit (level, row index) search, then one
+// 64-bit address computation.
+__device__ __forceinline__ uint16_t *level_row(const LevelSet &ls, const int n, const int y, const int x)
+{
+    int idx = -1, lvl = 0;
+#pragma unroll
+    for (int l = 0; l < CONV_LEVELS; ++l) {
+        if (l < ls.L) {
+            const int h = (int)(ls.extent[l] & 0xffffu), w = (int)(ls.extent[l] >> 16);
+            const unsigned uy = (unsigned)(y - (int)(ls.origin[l] & 0xffffu)), ux = (unsigned)(x - (int)(ls.origin[l] >> 16));
+            if (uy < (unsigned)h && ux < (unsigned)w) { idx = (n * h + (int)uy) * w + (int)ux; lvl = l; }
+        }
+    }
+    if (idx < 0) return nullptr;
+    uint16_t *base = ls.ptr[0];
+#pragma unroll
+    for (int l = 1; l < CONV_LEVELS; ++l) base = (l < ls.L && lvl == l) ? ls.ptr[l] : base;
+    return base + (int64_t)idx * ls.row_elems;
+}
+
+__device__ __forceinline__ const uint16_t *shfl_ptr(const uint16_t *p, const int src_lane)
+{
+    const unsigned long long u = (unsigned long long)(uintptr_t)p;
+    const unsigned lo = __shfl((unsigned)u, src_lane, RN_WAVE), hi = __shfl((unsigned)(u >> 32), src_lane, RN_WAVE);
+    return (const uint16_t *)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
+
+// (image, canvas row, canvas column) of canvas position m < 2^22, without integer division: (m + 0.5) * (1 / d) is at least
+// 0.5 / d away from an integer, far more than the rounding error of the two float operations at these magnitudes
+__device__ __forceinline__ void canvas_coords(const int m, const int HWp, const int Wp, int &n, int &y, int &x)
+{
+    n = (int)(((float)m + 0.5f) * (1.0f / (float)HWp));
+    const int pos = m - n * HWp;
+    y = (int)(((float)pos + 0.5f) * (1.0f / (float)Wp));
+    x = pos - y * Wp;
+}
+
+// Kernel modes.  CANVAS: canvas in, canvas out (the head towers, forward and data gradient).  TO_LEVELS: canvas in, dense
+// per-level tensors out, any even Cout (weight rows >= Cout read zeros; the class-output conv forward).  FROM_LEVELS: the
+// activation operand is gathered from dense per-level tensors whose row length need not be a multiple of 64 (the data
+// gradient of the class-output conv: contraction over 9 taps x 810 channels), canvas out.
+enum { MODE_CANVAS = 0, MODE_TO_LEVELS = 1, MODE_FROM_LEVELS = 2 };
+
 // Up to 4 convolutions of identical geometry in one launch (blockIdx.z = problem): the cls and the box tower run the
 // same shapes side by side, and 2 x 813 tiles fill 7 waves of 256 workgroups where two launches take 2 x 4.
 struct ConvArgs {
-    const uint16_t *Xs[CONV_MAX_PROBLEMS];      // [M][Cin] bf16
+    const uint16_t *Xs[CONV_MAX_PROBLEMS];      // [M][Cin] bf16 (unused in FROM_LEVELS mode)
     const uint16_t *Ws[CONV_MAX_PROBLEMS];      // [Cout][9][Cin] bf16
     const float *biases[CONV_MAX_PROBLEMS];     // [Cout] or null
-    uint16_t *Ys[CONV_MAX_PROBLEMS];            // [M][Cout] bf16
+    uint16_t *Ys[CONV_MAX_PROBLEMS];            // [M][Cout] bf16 (unused in TO_LEVELS mode)
     const uint8_t *mask;    // [HWp] or null (1 = keep)
-    const uint16_t *zeros;  // dense mode: >= 256 B of zeros, the source of out-of-image taps
+    const uint16_t *zeros;  // >= 256 B of zeros: weight rows past Cout, gap positions and channel chunks past the row end
     int64_t M, HWp;
-    int Cin, Cout, Wp, relu;
-    int H;                  // 0: zero-bordered canvas (no bounds logic); > 0: dense [N][H][Wp] image, taps checked
-    int taps;               // 9: 3x3 conv; 1: 1x1 conv = plain GEMM Y[M][Cout] = X[M][Cin] * W[Cout][Cin]^T
+    int Cin, Cout, Wp, relu;    // Cin = channels walked per tap (FROM_LEVELS: the padded row length, a multiple of 64)
+    LevelSet lv;
 };
-struct ConvProblem { const uint16_t *X, *W; const float *bias; uint16_t *Y; const uint8_t *mask; const uint16_t *zeros; int64_t M, HWp; int Cin, Cout, Wp, relu, H, taps; };
+struct ConvProblem { const uint16_t *X, *W; const float *bias; uint16_t *Y; };
 
 __device__ __forceinline__ uint16_t f2bf(const float f) { return (uint16_t)(rn::dt<RN_BF16>::pk(f, 0.0f) & 0xffffu); }
 
+template <int MODE>
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const ConvArgs args)
 {
     ConvProblem a;
     a.X = args.Xs[blockIdx.z]; a.W = args.Ws[blockIdx.z]; a.bias = args.biases[blockIdx.z]; a.Y = args.Ys[blockIdx.z];
-    a.mask = args.mask; a.M = args.M; a.HWp = args.HWp; a.Cin = args.Cin; a.Cout = args.Cout; a.Wp = args.Wp; a.relu = args.relu;
-    a.zeros = args.zeros; a.H = args.H; a.taps = args.taps;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];                 // [A0 A1 A2 | B0 B1] x 32 KiB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const int64_t m0 = (int64_t)blockIdx.x * CONV_BM;
     const int n0 = blockIdx.y * CONV_BN;
-    const int cpt = a.Cin / CONV_BK, KT = a.taps * cpt;
+    const int cpt = args.Cin / CONV_BK, KT = 9 * cpt;
     constexpr int TILE = CONV_BM * CONV_BK * 2;
     unsigned char *const Abase = lds, *const Bbase = lds + 3 * TILE;
+    // K walk.  CANVAS / TO_LEVELS: chunk outer, tap inner (a tile's input lines stay in L2 across its taps).
+    // FROM_LEVELS: tap outer, chunk inner -- the gathered row pointers of a tap are computed once per 13 K-tiles.
+    auto tap_of = [&](const int kt) { return MODE == MODE_FROM_LEVELS ? kt / cpt : kt % 9; };
+    auto chunk_of = [&](const int kt) { return MODE == MODE_FROM_LEVELS ? kt % cpt : kt / 9; };
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -76,55 +135,64 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    uint32_t a_off[4][4], b_off[2][4];
+    // fragment addresses: rows 32 apart share their swizzle ((row >> 1) & 7), so fragment mi / ni of a k-step is the
+    // first one plus mi * 4096 bytes -- an immediate offset of the ds_read, not a register
+    uint32_t a_off[4], b_off[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         const int chunk = kk * 2 + (lane >> 5);
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) { const int row = wm * 128 + mi * 32 + (lane & 31); a_off[mi][kk] = row * 128 + ((chunk ^ SWZ(row)) << 4); }
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) { const int row = wn * 64 + ni * 32 + (lane & 31); b_off[ni][kk] = row * 128 + ((chunk ^ SWZ(row)) << 4); }
+        { const int row = wm * 128 + (lane & 31); a_off[kk] = row * 128 + ((chunk ^ SWZ(row)) << 4); }
+        { const int row = wn * 64 + (lane & 31); b_off[kk] = row * 128 + ((chunk ^ SWZ(row)) << 4); }
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
 
-    // dense mode: which of the 9 taps of this thread's 4 staging rows fall inside the image (bit t of tapmask[i])
-    uint32_t tapmask[4] = {0x1ffu, 0x1ffu, 0x1ffu, 0x1ffu};
-    if (a.H > 0) {
+    // FROM_LEVELS: this thread stages 4 rows of the activation tile (row = (i * 512 + tid) >> 3); their canvas coordinates,
+    // and per tap the base pointer of the tapped position's dense row (null: border / gap / outside -> zeros)
+    const uint16_t *grow[4] = {nullptr, nullptr, nullptr, nullptr};
+    // A wave stages rows i * 64 + wave * 8 + (lane >> 3), i = 0..3: 32 distinct rows.  Lane j < 32 looks up row
+    // (j >> 3) * 64 + wave * 8 + (j & 7) once per tap (9 times per tile) and the wave shares the pointers by shuffles.
+    auto gather_tap = [&](const int t) {
+        const int j = lane & 31;
+        int64_t m = m0 + (j >> 3) * 64 + wave * 8 + (j & 7);
+        m = m < args.M ? m : args.M - 1;
+        int n, y, x;
+        canvas_coords((int)m, (int)args.HWp, args.Wp, n, y, x);
+        const uint16_t *mine = level_row(args.lv, n, y + t / 3 - 1, x + t % 3 - 1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t m = m0 + ((i * CONV_THREADS + tid) >> 3);
-            uint32_t bits = 0;
-            if (m < a.M) {
-                const int pos = (int)(m % a.HWp), y = pos / a.Wp, x = pos - y * a.Wp;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
-                    bits |= (yy >= 0 && yy < a.H && xx >= 0 && xx < a.Wp) ? (1u << t) : 0u;
-                }
-            }
-            tapmask[i] = bits;
-        }
-    }
+        for (int i = 0; i < 4; ++i) grow[i] = shfl_ptr(mine, i * 8 + (lane >> 3));
+    };
     auto piece_a = [&](const int kt, const int i) {
-        const int c0 = (kt / a.taps) * CONV_BK, t = kt % a.taps;
-        const int off = a.taps == 1 ? 0 : (t / 3 - 1) * a.Wp + (t % 3 - 1);
+        const int c0 = chunk_of(kt) * CONV_BK, t = tap_of(kt);
         const int q = i * CONV_THREADS + tid, row = q >> 3, cp = q & 7;
-        int64_t m = m0 + row + off;
-        m = m < 0 ? 0 : (m >= a.M ? a.M - 1 : m);
-        const uint16_t *g = a.X + m * a.Cin + c0 + ((cp ^ SWZ(row)) << 3);
-        if (a.H > 0 && !((tapmask[i] >> t) & 1u)) g = a.zeros + ((cp ^ SWZ(row)) << 3);       // zero padding
+        const uint16_t *g;
+        if (MODE == MODE_FROM_LEVELS) {
+            const int e = c0 + ((cp ^ SWZ(row)) << 3);                      // first channel of this 16-byte piece
+            // pieces that start past the row end read zeros; the piece that straddles it (row_elems % 8 != 0) reads the row's
+            // LAST 8 channels instead -- never past the row -- and the caller lays the weight's contraction axis out to
+            // match: slots e .. e+7 = channels row_elems-8 .., zero weights on the repeated ones (rn_conv3x3_levels_to_canvas)
+            const int es = e + 8 > args.lv.row_elems ? args.lv.row_elems - 8 : e;
+            g = (grow[i] && e < args.lv.row_elems) ? grow[i] + es : args.zeros + ((cp ^ SWZ(row)) << 3);
+        } else {
+            const int off = (t / 3 - 1) * args.Wp + (t % 3 - 1);
+            int64_t m = m0 + row + off;
+            m = m < 0 ? 0 : (m >= args.M ? args.M - 1 : m);
+            g = a.X + m * args.Cin + c0 + ((cp ^ SWZ(row)) << 3);
+        }
         __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)(Abase + (kt % 3) * TILE + q * 16), 16, 0, 0);
     };
     auto piece_b = [&](const int kt, const int i) {
-        const int c0 = (kt / a.taps) * CONV_BK, t = kt % a.taps;
+        const int c0 = chunk_of(kt) * CONV_BK, t = tap_of(kt);
         const int q = i * CONV_THREADS + tid, row = q >> 3, cp = q & 7;
-        const uint16_t *g = a.W + ((int64_t)(n0 + row) * a.taps + t) * a.Cin + c0 + ((cp ^ SWZ(row)) << 3);
+        const uint16_t *g = a.W + ((int64_t)(n0 + row) * 9 + t) * args.Cin + c0 + ((cp ^ SWZ(row)) << 3);
+        if (MODE == MODE_TO_LEVELS && n0 + row >= args.Cout) g = args.zeros + ((cp ^ SWZ(row)) << 3);      // output channels past Cout
         __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)(Bbase + (kt & 1) * TILE + q * 16), 16, 0, 0);
     };
+    if (MODE == MODE_FROM_LEVELS) gather_tap(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) piece_a(0, i);
 #pragma unroll
     for (int i = 0; i < 4; ++i) piece_b(0, i);
+    if (MODE == MODE_FROM_LEVELS && cpt == 1) gather_tap(1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) piece_a(1, i);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -132,11 +200,12 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     if (wm == 1) __builtin_amdgcn_s_barrier();                    // group 1 runs one barrier interval behind group 0
 
     bf16x8 fa[2][4], fb[2][2];
-#define RN_DS_READ(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
+#define RN_DS_READ(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
 #define RN_LOAD_FRAGS(KK, SET)                                                     \
-    RN_DS_READ(fb[SET][0], bbase + b_off[0][KK]); RN_DS_READ(fb[SET][1], bbase + b_off[1][KK]);   \
-    RN_DS_READ(fa[SET][0], abase + a_off[0][KK]); RN_DS_READ(fa[SET][1], abase + a_off[1][KK]);   \
-    RN_DS_READ(fa[SET][2], abase + a_off[2][KK]); RN_DS_READ(fa[SET][3], abase + a_off[3][KK]);
+    { const uint32_t ba = bbase + b_off[KK], aa = abase + a_off[KK];               \
+      RN_DS_READ(fb[SET][0], ba, 0); RN_DS_READ(fb[SET][1], ba, 4096);             \
+      RN_DS_READ(fa[SET][0], aa, 0); RN_DS_READ(fa[SET][1], aa, 4096);             \
+      RN_DS_READ(fa[SET][2], aa, 8192); RN_DS_READ(fa[SET][3], aa, 12288); }
 #define RN_MFMA8(SET)                                                              \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                               \
         _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                           \
@@ -165,6 +234,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
         RN_LOAD_FRAGS(2, 0) RN_LOAD_FRAGS(3, 1)
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 2 < KT) {
+            if (MODE == MODE_FROM_LEVELS && (kt + 2) % cpt == 0) gather_tap((kt + 2) / cpt);     // wave-uniform: a new tap starts
 #pragma unroll
             for (int i = 0; i < 4; ++i) piece_a(kt + 2, i);
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -182,30 +252,62 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     if (wm == 0) __builtin_amdgcn_s_barrier();                    // group 0 catches up with group 1's extra barrier
 
     __syncthreads();
-    uint16_t *Ys = (uint16_t *)lds;
+    uint16_t *Ys = (uint16_t *)lds;                               // [256][256] bf16 output tile = 128 KiB
+    uint16_t **Yrow = (uint16_t **)(lds + CONV_BM * CONV_BN * 2);  // TO_LEVELS: destination row of each tile row (2 KiB)
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const int col = wn * 64 + ni * 32 + (lane & 31);
-            const float b = a.bias ? a.bias[n0 + col] : 0.0f;
+            const float b = (a.bias && (MODE != MODE_TO_LEVELS || n0 + col < args.Cout)) ? a.bias[n0 + col] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 float v = acc[mi][ni][r] + b;
-                if (a.relu & 1) v = v > 0.0f ? v : 0.0f;
+                if (args.relu & 1) v = v > 0.0f ? v : 0.0f;
                 Ys[row * CONV_BN + col] = f2bf(v);
             }
         }
+    if (MODE == MODE_TO_LEVELS && tid < CONV_BM) {
+        const int64_t m = m0 + tid;
+        uint16_t *dst = nullptr;
+        if (m < args.M) {
+            int n, y, x;
+            canvas_coords((int)m, (int)args.HWp, args.Wp, n, y, x);
+            dst = level_row(args.lv, n, y, x);
+        }
+        Yrow[tid] = dst;
+    }
     __syncthreads();
+    if (MODE == MODE_TO_LEVELS) {
+        // dense rows of Cout elements start on 4-byte boundaries only (Cout even): 16-byte stores to dword-aligned
+        // addresses are fine on gfx950 (tools/misalign_probe.hip); the tile's last piece may be cut by the row end
+        const int ncols = min(CONV_BN, args.Cout - n0);           // > 0
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int q = i * CONV_THREADS + tid, row = q >> 5, piece = q & 31;
-        const int64_t m = m0 + row;
-        if (m < a.M) {
-            uint4 v = *(const uint4 *)(Ys + row * CONV_BN + piece * 8);
-            if (a.mask && !a.mask[m % a.HWp]) v = make_uint4(0, 0, 0, 0);
-            *(uint4 *)(a.Y + m * a.Cout + n0 + piece * 8) = v;
+        for (int i = 0; i < 16; ++i) {
+            const int q = i * CONV_THREADS + tid, row = q >> 5, piece = q & 31;
+            uint16_t *dst = Yrow[row];
+            if (dst && piece * 8 < ncols) {
+                const uint16_t *src = Ys + row * CONV_BN + piece * 8;
+                dst += n0 + piece * 8;
+                if (piece * 8 + 8 <= ncols) {
+                    const rn::u32x4 v = *(const rn::u32x4 *)src;
+                    asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(v) : "memory");
+                } else {
+                    for (int e = 0; e < ncols - piece * 8; e += 2) *(uint32_t *)(dst + e) = *(const uint32_t *)(src + e);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int q = i * CONV_THREADS + tid, row = q >> 5, piece = q & 31;
+            const int64_t m = m0 + row;
+            if (m < args.M) {
+                uint4 v = *(const uint4 *)(Ys + row * CONV_BN + piece * 8);
+                if (args.mask && !args.mask[m % args.HWp]) v = make_uint4(0, 0, 0, 0);
+                *(uint4 *)(a.Y + m * args.Cout + n0 + piece * 8) = v;
+            }
         }
     }
 }
@@ -225,22 +327,26 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
 constexpr int WG_POS = 64;                                       // positions per K-tile
 
 struct WgradArgs {
-    const uint16_t *Gs[CONV_MAX_PROBLEMS];      // [M][256] bf16
+    const uint16_t *Gs[CONV_MAX_PROBLEMS];      // [M][256] bf16 (GATHER: unused, the gradient rows come from `lv`)
     const uint16_t *Xs[CONV_MAX_PROBLEMS];      // [M][256] bf16
     const uint16_t *zeros;
     float *partial;                             // [P][S][9][256][256] f32
-    int64_t M;
+    int64_t M, HWp;
     int Wp, S, tiles_per_split;                 // K-tiles (64 positions) per split
-    int H;                                      // 0: zero-bordered canvas; > 0: dense [N][H][Wp] images, out-of-image taps read zeros
+    LevelSet lv;                                // GATHER: dense per-level gradient tensors [N][h][w][row_elems]; problem p = output channels 256 p ..
 };
 
+// GATHER = false: G and X are canvases (the head towers).  GATHER = true: the gradient operand is gathered, position by
+// position, from dense per-level tensors with row_elems channels (the class-output conv: 810); blockIdx.z selects the tile
+// of 256 output channels, chunks past the row end read zeros (the straddling chunk pollutes only unused dW rows).
+template <bool GATHER>
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const WgradArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];                 // [G0 G1 G2 | X0 X1] x 32 KiB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const int split = blockIdx.x, tap = blockIdx.y, prob = blockIdx.z;
-    const uint16_t *__restrict__ G = a.Gs[prob], *__restrict__ X = a.Xs[prob];
+    const uint16_t *__restrict__ G = a.Gs[prob], *__restrict__ X = a.Xs[GATHER ? 0 : prob];
     const int KT = a.tiles_per_split;
     const int64_t m_begin = (int64_t)split * KT * WG_POS;
     const int off = (tap / 3 - 1) * a.Wp + (tap % 3 - 1);
@@ -272,29 +378,54 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
     const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
 
     // staging: tile row = position, 32 chunks of 16 B; LDS position (row, cp) holds global chunk cp ^ ((row & 3) << 2)
-    const int dy_tap = tap / 3 - 1, dx_tap = tap % 3 - 1;
-    const int64_t HW = (int64_t)a.H * a.Wp;
-    auto piece = [&](const uint16_t *__restrict__ src, const int64_t shift, unsigned char *dst, const int kt, const int i) {
+    auto piece_b = [&](const int kt, const int i) {
         const int qi = i * CONV_THREADS + tid, row = qi >> 5, cp = qi & 31;
         const int64_t m = m_begin + (int64_t)kt * WG_POS + row;
-        int64_t ms = m + shift;
+        int64_t ms = m + off;
         ms = ms < 0 ? 0 : (ms >= a.M ? a.M - 1 : ms);
-        const uint16_t *g = src + ms * 256 + ((cp ^ ((row & 3) << 2)) << 3);
-        bool dead = m >= a.M;                                     // positions past the end contribute nothing
-        if (a.H > 0 && shift != 0 && !dead) {                     // dense images: is the tap of this position inside its image?
-            const int pos = (int)(m % HW), y = pos / a.Wp, x = pos - y * a.Wp;
-            dead = (unsigned)(y + dy_tap) >= (unsigned)a.H || (unsigned)(x + dx_tap) >= (unsigned)a.Wp;
-        }
-        if (dead) g = a.zeros + ((cp & 15) << 3);
-        __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)(dst + qi * 16), 16, 0, 0);
+        const uint16_t *g = X + ms * 256 + ((cp ^ ((row & 3) << 2)) << 3);
+        if (m >= a.M) g = a.zeros + ((cp & 15) << 3);             // positions past the end contribute nothing
+        __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)(Bbase + (kt & 1) * TILE + qi * 16), 16, 0, 0);
     };
-    auto piece_a = [&](const int kt, const int i) { piece(G, 0, Abase + (kt % 3) * TILE, kt, i); };
-    auto piece_b = [&](const int kt, const int i) { piece(X, off, Bbase + (kt & 1) * TILE, kt, i); };
+    // GATHER: a wave stages rows i * 16 + wave * 2 + (lane >> 5), i = 0..3, of a K-tile: 8 distinct rows.  Lane j < 8 looks up
+    // row (j >> 1) * 16 + wave * 2 + (j & 1) and the wave shares the pointers by shuffles (1 lookup per lane, not 4).
+    const uint16_t *grow[4] = {nullptr, nullptr, nullptr, nullptr};
+    auto gather_rows = [&](const int kt) {
+        const int j = lane & 7;
+        const int64_t m = m_begin + (int64_t)kt * WG_POS + (j >> 1) * 16 + wave * 2 + (j & 1);
+        const uint16_t *mine = nullptr;
+        if (m < a.M) {
+            int n, y, x;
+            canvas_coords((int)m, (int)a.HWp, a.Wp, n, y, x);
+            mine = level_row(a.lv, n, y, x);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) grow[i] = shfl_ptr(mine, i * 2 + (lane >> 5));
+    };
+    auto piece_a = [&](const int kt, const int i) {
+        const int qi = i * CONV_THREADS + tid, row = qi >> 5, cp = qi & 31;
+        const int64_t m = m_begin + (int64_t)kt * WG_POS + row;
+        const uint16_t *g;
+        if (GATHER) {
+            const int e = prob * 256 + ((cp ^ ((row & 3) << 2)) << 3);          // first output channel of this 16-byte piece
+            // the piece that straddles the row end reads the row's last 8 channels instead (never past the row); the
+            // reduction kernel writes its dW rows to the channels they really are
+            const int es = e + 8 > a.lv.row_elems ? a.lv.row_elems - 8 : e;
+            g = (grow[i] && e < a.lv.row_elems) ? grow[i] + es : a.zeros + ((cp & 15) << 3);
+        } else {
+            const int64_t ms = m >= a.M ? a.M - 1 : m;
+            g = G + ms * 256 + ((cp ^ ((row & 3) << 2)) << 3);
+            if (m >= a.M) g = a.zeros + ((cp & 15) << 3);
+        }
+        __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)(Abase + (kt % 3) * TILE + qi * 16), 16, 0, 0);
+    };
+    if (GATHER) gather_rows(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) piece_a(0, i);
 #pragma unroll
     for (int i = 0; i < 4; ++i) piece_b(0, i);
     if (KT > 1) {
+        if (GATHER) gather_rows(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) piece_a(1, i);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -342,6 +473,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
         RN_LOAD_FRAGS(16384, 18432, 0) RN_LOAD_FRAGS(24576, 26624, 1)
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 2 < KT) {
+            if (GATHER) gather_rows(kt + 2);
 #pragma unroll
             for (int i = 0; i < 4; ++i) piece_a(kt + 2, i);
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -375,11 +507,14 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
 }
 
 // dW[p][n][t][c] (bf16) = sum over the splits of partial[p][s][t][n][c]
+// (rows: output channels of problem p that exist -- 256 except for the last channel tile of the class-output conv)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, const int S, uint16_t *dw0, uint16_t *dw1,
-                                                           uint16_t *dw2, uint16_t *dw3)
+                                                           uint16_t *dw2, uint16_t *dw3, const int rows0, const int rows1,
+                                                           const int rows2, const int rows3, const int shift_from, const int shift)
 {
     const int prob = blockIdx.y;
     uint16_t *dw = prob == 0 ? dw0 : (prob == 1 ? dw1 : (prob == 2 ? dw2 : dw3));
+    const int rows = prob == 0 ? rows0 : (prob == 1 ? rows1 : (prob == 2 ? rows2 : rows3));
     const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;          // over 9 * 256 * 256 / 4 float4 groups of [t][n][c]
     if (i4 >= 9 * 65536 / 4) return;
     rn::f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -389,43 +524,53 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     }
     const int64_t e = i4 * 4;
     const int t = (int)(e / 65536), n = (int)((e % 65536) / 256), c = (int)(e % 256);
+    // gathered gradients whose row length is not a multiple of 8: tile rows shift_from .. shift_from+7 of the LAST problem hold
+    // the row's last 8 channels (conv3x3_wgrad_kernel<true>), i.e. tile row r there is channel r - shift; the first
+    // `shift` of them repeat channels already produced
+    int n_out = n;
+    if (shift > 0 && prob == (int)gridDim.y - 1 && n >= shift_from) {
+        if (n < shift_from + shift || n >= shift_from + 8) return;
+        n_out = n - shift;
+    } else if (n >= rows) return;
     rn::u32x2 o;
     o.x = rn::dt<RN_BF16>::pk(s.x, s.y); o.y = rn::dt<RN_BF16>::pk(s.z, s.w);
-    *(rn::u32x2 *)(dw + ((int64_t)n * 9 + t) * 256 + c) = o;
+    *(rn::u32x2 *)(dw + ((int64_t)n_out * 9 + t) * 256 + c) = o;
 }
 
 }  // namespace
 
-static int conv_launch(const void *const *xs, const void *const *ws, const float *const *biases, const uint8_t *mask,
-                       void *const *ys, int P, int dtype, int64_t M, int64_t HWp, int Wp, int Cin, int Cout, int relu, int H,
-                       const void *zeros, void *stream, int taps = 9)
+template <int MODE>
+static int conv_launch_mode(const ConvArgs &a, const dim3 grid, hipStream_t st)
 {
-    if (taps * (Cin / CONV_BK) < 2) return RN_EUNSUPPORTED;         // the pipeline keeps two K-tiles in flight
-    if (!xs || !ws || !ys || P <= 0 || P > CONV_MAX_PROBLEMS || M <= 0 || HWp <= 0 || Wp <= 0 || Cin <= 0 || Cout <= 0) return RN_EINVAL;
-    if (dtype != RN_BF16 || Cin % CONV_BK || Cout % CONV_BN) return RN_EUNSUPPORTED;
-    if (H > 0 && (!zeros || !rn::aligned(zeros, 16))) return RN_EINVAL;
-    ConvArgs a;
-    for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) {
-        const int q = p < P ? p : 0;
-        if (!xs[q] || !ws[q] || !ys[q]) return RN_EINVAL;
-        if (!rn::aligned(xs[q], 16) || !rn::aligned(ws[q], 16) || !rn::aligned(ys[q], 16)) return RN_EALIGN;
-        a.Xs[p] = (const uint16_t *)xs[q]; a.Ws[p] = (const uint16_t *)ws[q]; a.Ys[p] = (uint16_t *)ys[q];
-        a.biases[p] = biases ? biases[q] : nullptr;
-    }
     {   // 160 KiB of dynamic LDS needs the opt-in once per device (the attribute lives with the device's code object)
         static bool attr_set[64] = {};
         int dev = 0;
         RN_HIP(hipGetDevice(&dev));
         if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-            RN_HIP(hipFuncSetAttribute((const void *)conv3x3_canvas_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES));
+            RN_HIP(hipFuncSetAttribute((const void *)conv3x3_canvas_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES));
             if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
     }
-    a.mask = mask; a.M = M; a.HWp = HWp; a.Cin = Cin; a.Cout = Cout; a.Wp = Wp; a.relu = relu ? 1 : 0;
-    a.H = H; a.zeros = (const uint16_t *)zeros; a.taps = taps;
-    const dim3 grid((unsigned)((M + CONV_BM - 1) / CONV_BM), (unsigned)(Cout / CONV_BN), (unsigned)P);
-    hipLaunchKernelGGL(conv3x3_canvas_kernel, grid, dim3(CONV_THREADS), CONV_LDS_BYTES, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(conv3x3_canvas_kernel<MODE>, grid, dim3(CONV_THREADS), CONV_LDS_BYTES, st, a);
     RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+static int fill_levels(LevelSet &ls, const rn_canvas_level *lv, int L, int row_elems, void *const *ptrs, int N, int Hp, int Wp)
+{
+    if (!lv || !ptrs || L <= 0 || row_elems <= 0 || (row_elems & 1)) return RN_EINVAL;
+    if (L > CONV_LEVELS || Hp > 65535 || Wp > 65535) return RN_EUNSUPPORTED;
+    ls.L = L; ls.row_elems = row_elems;
+    for (int l = 0; l < CONV_LEVELS; ++l) {
+        const int q = l < L ? l : 0;
+        if (!ptrs[q] || lv[q].h <= 0 || lv[q].w <= 0 || lv[q].r0 < 0 || lv[q].c0 < 0 || lv[q].r0 + lv[q].h > Hp || lv[q].c0 + lv[q].w > Wp)
+            return RN_EINVAL;
+        if (!rn::aligned(ptrs[q], 16)) return RN_EALIGN;
+        if ((int64_t)N * lv[q].h * lv[q].w >= (1ll << 31)) return RN_EUNSUPPORTED;
+        ls.origin[l] = (uint32_t)lv[q].r0 | ((uint32_t)lv[q].c0 << 16);
+        ls.extent[l] = (uint32_t)lv[q].h | ((uint32_t)lv[q].w << 16);
+        ls.ptr[l] = (uint16_t *)ptrs[q];
+    }
     return RN_OK;
 }
 
@@ -433,17 +578,19 @@ RN_API int rn_conv3x3_canvas_batched(const void *const *xs, const void *const *w
                                      const uint8_t *mask, void *const *ys, int P, int dtype, int64_t M, int64_t HWp, int Wp,
                                      int Cin, int Cout, int relu, void *stream)
 {
-    return conv_launch(xs, ws, biases, mask, ys, P, dtype, M, HWp, Wp, Cin, Cout, relu, 0, nullptr, stream);
-}
-
-RN_API int rn_conv3x3_nhwc(const void *x, const void *w, const float *bias, void *y, int dtype, int N, int H, int W, int Cin,
-                           int Cout, int relu, const void *zeros, void *stream)
-{
-    if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0) return RN_EINVAL;
-    const void *xs[1] = {x}, *ws[1] = {w};
-    const float *bs[1] = {bias};
-    void *ys[1] = {y};
-    return conv_launch(xs, ws, bs, nullptr, ys, 1, dtype, (int64_t)N * H * W, (int64_t)H * W, W, Cin, Cout, relu, H, zeros, stream);
+    if (!xs || !ws || !ys || P <= 0 || P > CONV_MAX_PROBLEMS || M <= 0 || HWp <= 0 || Wp <= 0 || Cin <= 0 || Cout <= 0) return RN_EINVAL;
+    if (dtype != RN_BF16 || Cin % CONV_BK || Cout % CONV_BN) return RN_EUNSUPPORTED;
+    ConvArgs a = {};
+    for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) {
+        const int q = p < P ? p : 0;
+        if (!xs[q] || !ws[q] || !ys[q]) return RN_EINVAL;
+        if (!rn::aligned(xs[q], 16) || !rn::aligned(ws[q], 16) || !rn::aligned(ys[q], 16)) return RN_EALIGN;
+        a.Xs[p] = (const uint16_t *)xs[q]; a.Ws[p] = (const uint16_t *)ws[q]; a.Ys[p] = (uint16_t *)ys[q];
+        a.biases[p] = biases ? biases[q] : nullptr;
+    }
+    a.mask = mask; a.M = M; a.HWp = HWp; a.Cin = Cin; a.Cout = Cout; a.Wp = Wp; a.relu = relu ? 1 : 0; a.zeros = nullptr;
+    const dim3 grid((unsigned)((M + CONV_BM - 1) / CONV_BM), (unsigned)(Cout / CONV_BN), (unsigned)P);
+    return conv_launch_mode<MODE_CANVAS>(a, grid, (hipStream_t)stream);
 }
 
 RN_API int rn_conv3x3_canvas(const void *x, const void *w, const float *bias, const uint8_t *mask, void *y, int dtype,
@@ -456,14 +603,40 @@ RN_API int rn_conv3x3_canvas(const void *x, const void *w, const float *bias, co
     return rn_conv3x3_canvas_batched(xs, ws, bs, mask, ys, 1, dtype, M, HWp, Wp, Cin, Cout, relu, stream);
 }
 
-RN_API int rn_conv1x1_nhwc(const void *x, const void *w, const float *bias, void *y, int dtype, int64_t M, int Cin, int Cout,
-                           void *stream)
+RN_API int rn_conv3x3_canvas_to_levels(const void *x, const void *w, const float *bias, const rn_canvas_level *levels, int L,
+                                       void *const *ys, int dtype, int N, int Hp, int Wp, int Cin, int Cout, const void *zeros,
+                                       void *stream)
 {
-    if (!x || !w || !y || M <= 0) return RN_EINVAL;
-    const void *xs[1] = {x}, *ws[1] = {w};
-    const float *bs[1] = {bias};
-    void *ys[1] = {y};
-    return conv_launch(xs, ws, bs, nullptr, ys, 1, dtype, M, M, 1, Cin, Cout, 0, 0, nullptr, stream, 1);
+    if (!x || !w || !zeros || N <= 0 || Hp <= 2 || Wp <= 2 || Cin <= 0 || Cout <= 0) return RN_EINVAL;
+    if (dtype != RN_BF16 || Cin % CONV_BK || (Cout & 1) || (int64_t)N * Hp * Wp >= (1 << 22)) return RN_EUNSUPPORTED;
+    if (!rn::aligned(x, 16) || !rn::aligned(w, 16) || !rn::aligned(zeros, 16)) return RN_EALIGN;
+    ConvArgs a = {};
+    const int rc = fill_levels(a.lv, levels, L, Cout, ys, N, Hp, Wp);
+    if (rc != RN_OK) return rc;
+    for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) { a.Xs[p] = (const uint16_t *)x; a.Ws[p] = (const uint16_t *)w; a.biases[p] = bias; a.Ys[p] = nullptr; }
+    a.mask = nullptr; a.M = (int64_t)N * Hp * Wp; a.HWp = (int64_t)Hp * Wp; a.Cin = Cin; a.Cout = Cout; a.Wp = Wp; a.relu = 0;
+    a.zeros = (const uint16_t *)zeros;
+    const dim3 grid((unsigned)((a.M + CONV_BM - 1) / CONV_BM), (unsigned)((Cout + CONV_BN - 1) / CONV_BN), 1);
+    return conv_launch_mode<MODE_TO_LEVELS>(a, grid, (hipStream_t)stream);
+}
+
+RN_API int rn_conv3x3_levels_to_canvas(const void *const *gs, const rn_canvas_level *levels, int L, int row_elems, const void *w,
+                                       const uint8_t *mask, void *y, int dtype, int N, int Hp, int Wp, int Kpad, int Cout,
+                                       const void *zeros, void *stream)
+{
+    if (!gs || !w || !y || !zeros || N <= 0 || Hp <= 2 || Wp <= 2 || Kpad <= 0 || Cout <= 0) return RN_EINVAL;
+    if (dtype != RN_BF16 || Kpad % CONV_BK || Cout % CONV_BN || Kpad < row_elems || Kpad - row_elems >= CONV_BK ||
+        (int64_t)N * Hp * Wp >= (1 << 22) || row_elems < 8)
+        return RN_EUNSUPPORTED;
+    if (!rn::aligned(w, 16) || !rn::aligned(y, 16) || !rn::aligned(zeros, 16)) return RN_EALIGN;
+    ConvArgs a = {};
+    const int rc = fill_levels(a.lv, levels, L, row_elems, const_cast<void *const *>(gs), N, Hp, Wp);
+    if (rc != RN_OK) return rc;
+    for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) { a.Xs[p] = nullptr; a.Ws[p] = (const uint16_t *)w; a.biases[p] = nullptr; a.Ys[p] = (uint16_t *)y; }
+    a.mask = mask; a.M = (int64_t)N * Hp * Wp; a.HWp = (int64_t)Hp * Wp; a.Cin = Kpad; a.Cout = Cout; a.Wp = Wp; a.relu = 0;
+    a.zeros = (const uint16_t *)zeros;
+    const dim3 grid((unsigned)((a.M + CONV_BM - 1) / CONV_BM), (unsigned)(Cout / CONV_BN), 1);
+    return conv_launch_mode<MODE_FROM_LEVELS>(a, grid, (hipStream_t)stream);
 }
 
 RN_API size_t rn_conv3x3_wgrad_workspace_bytes(int P, int64_t M)
@@ -472,47 +645,17 @@ RN_API size_t rn_conv3x3_wgrad_workspace_bytes(int P, int64_t M)
     return (size_t)P * 64 * 9 * 65536 * sizeof(float);          // up to 64 splits of the positions
 }
 
-static int wgrad_launch(const void *const *gs, const void *const *xs, void *const *dws, int P, int dtype, int64_t M, int Wp, int H,
-                        int Cin, int Cout, const void *zeros, void *workspace, size_t workspace_bytes, void *stream);
-
-RN_API int rn_conv3x3_canvas_wgrad_batched(const void *const *gs, const void *const *xs, void *const *dws, int P, int dtype,
-                                           int64_t M, int Wp, int Cin, int Cout, const void *zeros, void *workspace,
-                                           size_t workspace_bytes, void *stream)
+template <bool GATHER>
+static int wgrad_launch(WgradArgs &a, uint16_t *const (&dw)[CONV_MAX_PROBLEMS], const int (&rows)[CONV_MAX_PROBLEMS], int P, int64_t M,
+                        void *workspace, hipStream_t st, int shift_from = 0, int shift = 0)
 {
-    return wgrad_launch(gs, xs, dws, P, dtype, M, Wp, 0, Cin, Cout, zeros, workspace, workspace_bytes, stream);
-}
-
-RN_API int rn_conv3x3_nhwc_wgrad(const void *g, const void *x, void *dw, int dtype, int N, int H, int W, int Cin, int Cout,
-                                 const void *zeros, void *workspace, size_t workspace_bytes, void *stream)
-{
-    if (N <= 0 || H <= 0 || W <= 0) return RN_EINVAL;
-    const void *gs[1] = {g}, *xs[1] = {x};
-    void *dws[1] = {dw};
-    return wgrad_launch(gs, xs, dws, 1, dtype, (int64_t)N * H * W, W, H, Cin, Cout, zeros, workspace, workspace_bytes, stream);
-}
-
-static int wgrad_launch(const void *const *gs, const void *const *xs, void *const *dws, int P, int dtype, int64_t M, int Wp, int H,
-                        int Cin, int Cout, const void *zeros, void *workspace, size_t workspace_bytes, void *stream)
-{
-    if (!gs || !xs || !dws || !zeros || !workspace || P <= 0 || P > CONV_MAX_PROBLEMS || M <= 0 || Wp <= 0) return RN_EINVAL;
-    if (dtype != RN_BF16 || Cin != 256 || Cout != 256) return RN_EUNSUPPORTED;
-    if (workspace_bytes < rn_conv3x3_wgrad_workspace_bytes(P, M)) return RN_EWORKSPACE;
-    WgradArgs a;
-    uint16_t *dw[CONV_MAX_PROBLEMS] = {nullptr, nullptr, nullptr, nullptr};
-    for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) {
-        const int q = p < P ? p : 0;
-        if (!gs[q] || !xs[q] || !dws[q]) return RN_EINVAL;
-        if (!rn::aligned(gs[q], 16) || !rn::aligned(xs[q], 16) || !rn::aligned(dws[q], 16)) return RN_EALIGN;
-        a.Gs[p] = (const uint16_t *)gs[q]; a.Xs[p] = (const uint16_t *)xs[q];
-        dw[p] = (uint16_t *)dws[q];
-    }
     int dev = 0, cus = 0;
     RN_HIP(hipGetDevice(&dev));
     RN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     {
         static bool attr_set[64] = {};
         if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-            RN_HIP(hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES));
+            RN_HIP(hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES));
             if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
     }
@@ -523,11 +666,58 @@ static int wgrad_launch(const void *const *gs, const void *const *xs, void *cons
     const int64_t ktiles = (M + WG_POS - 1) / WG_POS;
     a.tiles_per_split = (int)((ktiles + S - 1) / S);
     S = (int)((ktiles + a.tiles_per_split - 1) / a.tiles_per_split);
-    a.S = S; a.M = M; a.Wp = Wp; a.H = H; a.zeros = (const uint16_t *)zeros; a.partial = (float *)workspace;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)S, 9, (unsigned)P), dim3(CONV_THREADS), CONV_LDS_BYTES, st, a);
+    a.S = S; a.M = M; a.partial = (float *)workspace;
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel<GATHER>, dim3((unsigned)S, 9, (unsigned)P), dim3(CONV_THREADS), CONV_LDS_BYTES, st, a);
     RN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(9 * 65536 / 4 / 256, (unsigned)P), dim3(256), 0, st, (const float *)workspace, S, dw[0], dw[1], dw[2], dw[3]);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(9 * 65536 / 4 / 256, (unsigned)P), dim3(256), 0, st, (const float *)workspace, S, dw[0], dw[1],
+                       dw[2], dw[3], rows[0], rows[1], rows[2], rows[3], shift_from, shift);
     RN_LAUNCH_CHECK();
     return RN_OK;
+}
+
+RN_API int rn_conv3x3_canvas_wgrad_batched(const void *const *gs, const void *const *xs, void *const *dws, int P, int dtype,
+                                           int64_t M, int Wp, int Cin, int Cout, const void *zeros, void *workspace,
+                                           size_t workspace_bytes, void *stream)
+{
+    if (!gs || !xs || !dws || !zeros || !workspace || P <= 0 || P > CONV_MAX_PROBLEMS || M <= 0 || Wp <= 0) return RN_EINVAL;
+    if (dtype != RN_BF16 || Cin != 256 || Cout != 256) return RN_EUNSUPPORTED;
+    if (workspace_bytes < rn_conv3x3_wgrad_workspace_bytes(P, M)) return RN_EWORKSPACE;
+    WgradArgs a = {};
+    uint16_t *dw[CONV_MAX_PROBLEMS] = {nullptr, nullptr, nullptr, nullptr};
+    const int rows[CONV_MAX_PROBLEMS] = {256, 256, 256, 256};
+    for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) {
+        const int q = p < P ? p : 0;
+        if (!gs[q] || !xs[q] || !dws[q]) return RN_EINVAL;
+        if (!rn::aligned(gs[q], 16) || !rn::aligned(xs[q], 16) || !rn::aligned(dws[q], 16)) return RN_EALIGN;
+        a.Gs[p] = (const uint16_t *)gs[q]; a.Xs[p] = (const uint16_t *)xs[q];
+        dw[p] = (uint16_t *)dws[q];
+    }
+    a.Wp = Wp; a.HWp = 0; a.zeros = (const uint16_t *)zeros;
+    return wgrad_launch<false>(a, dw, rows, P, M, workspace, (hipStream_t)stream);
+}
+
+RN_API int rn_conv3x3_levels_wgrad(const void *const *gs, const rn_canvas_level *levels, int L, int row_elems, const void *x, void *dw,
+                                   int dtype, int N, int Hp, int Wp, int Cin, const void *zeros, void *workspace,
+                                   size_t workspace_bytes, void *stream)
+{
+    if (!gs || !x || !dw || !zeros || !workspace || N <= 0 || Hp <= 2 || Wp <= 2) return RN_EINVAL;
+    const int P = (row_elems + 255) / 256;
+    const int64_t M = (int64_t)N * Hp * Wp;
+    if (dtype != RN_BF16 || Cin != 256 || P > CONV_MAX_PROBLEMS || M >= (1 << 22) || row_elems < 8) return RN_EUNSUPPORTED;
+    if (workspace_bytes < rn_conv3x3_wgrad_workspace_bytes(P, M)) return RN_EWORKSPACE;
+    if (!rn::aligned(x, 16) || !rn::aligned(dw, 16) || !rn::aligned(zeros, 16)) return RN_EALIGN;
+    WgradArgs a = {};
+    const int rc = fill_levels(a.lv, levels, L, row_elems, const_cast<void *const *>(gs), N, Hp, Wp);
+    if (rc != RN_OK) return rc;
+    uint16_t *dws[CONV_MAX_PROBLEMS];
+    int rows[CONV_MAX_PROBLEMS];
+    for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) {
+        a.Gs[p] = nullptr; a.Xs[p] = (const uint16_t *)x;
+        dws[p] = (uint16_t *)dw + (int64_t)p * 256 * 9 * 256;                      // dW is [row_elems][3][3][256]
+        rows[p] = row_elems - p * 256 < 256 ? (row_elems - p * 256 > 0 ? row_elems - p * 256 : 0) : 256;
+    }
+    a.Wp = Wp; a.HWp = (int64_t)Hp * Wp; a.zeros = (const uint16_t *)zeros;
+    // tile-local position and size of the straddling piece's shift (see the kernel): last problem only
+    const int tail = row_elems % 8, e_last = row_elems - tail - (P - 1) * 256;
+    return wgrad_launch<true>(a, dws, rows, P, M, workspace, (hipStream_t)stream, tail ? e_last : 0, tail ? 8 - tail : 0);
 }

@@ -56,8 +56,7 @@ class FeaturePyramid(nn.Module):
         p3 = self.conv_c3_1x1(c3) + self._up(p4)
         p6 = self.conv_c6_3x3(c5)
         p7 = self.conv_c7_3x3(F.relu(p6))
-        c3 = biasact.conv3x3                # MFMA kernel where it beats MIOpen (P3, P4 of the R50 config), else the module
-        return [c3(self.conv_c3_3x3, p3), c3(self.conv_c4_3x3, p4), c3(self.conv_c5_3x3, p5), p6, p7]
+        return [self.conv_c3_3x3(p3), self.conv_c4_3x3(p4), self.conv_c5_3x3(p5), p6, p7]
 
 
 def _tower(in_channels: int, out_channels: int) -> nn.Sequential:
@@ -179,6 +178,8 @@ class RetinaNetHead(nn.Module):
         mode = os.environ.get("RN_TOWERS", "pair")
         self.mfma_towers = mode != "miopen"
         self.pair_towers = mode == "pair"
+        # class-output conv on the hand-written MFMA kernel with dense 9*K-channel output (0: MIOpen on 9*ceil8(K) channels)
+        self.mfma_cls_output = os.environ.get("RN_CLS_OUTPUT", "mfma") != "miopen"
 
     def compute_loss(self, targets: List[Dict[str, Tensor]], outputs: Dict[str, Tensor],
                      anchors: List[Tensor]) -> Dict[str, Tensor]:
@@ -211,11 +212,16 @@ class RetinaNetHead(nn.Module):
             else:
                 cls_c = _tower_on_canvas(ch.class_subnet, packed, cv.mask, mfma)
                 box_t = _tower_on_canvas(rh.box_subnet, packed, cv.mask, mfma)
-            cls_t = biasact.unpack_levels(cv, cls_c)
             # the 36-channel box conv is tiny per level (2 TFLOP/s on P7): run it on the canvas too and unpack its
             # small output instead of the 256-channel tower output
             box_c = rh.box_subnet_output(box_t)
             box_levels = [_to_anchor_major(t, 4) for t in biasact.unpack_levels(cv, box_c)]
+            if mfma and self.mfma_cls_output and biasact.cls_output_conv_fusable(cls_c, ch.class_subnet_output, cv):
+                # class-output conv straight from the canvas to dense per-level logits [N, h*w*A, K]: exactly A*K channels
+                # (no dead classes for the loss kernel to stream) and no unpack copy of the 256-channel tower output
+                return {"cls_levels": biasact.cls_output_conv(cls_c, ch.class_subnet_output, cv, ch.num_classes),
+                        "bbox_levels": box_levels}
+            cls_t = biasact.unpack_levels(cv, cls_c)
             return {"cls_levels": ch.output_levels(cls_t, pad_classes), "bbox_levels": box_levels}
         return {"cls_levels": ch.forward_levels(xb, pad_classes), "bbox_levels": rh.forward_levels(xb)}
 

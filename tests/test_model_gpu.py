@@ -378,14 +378,59 @@ def test_head_mfma_towers_equal_miopen_towers_bf16():
         loss.backward()
         outs[mfma] = (o, [f.grad.clone() for f in fm], {n: p.grad.clone() for n, p in head.named_parameters() if p.grad is not None})
     head.mfma_towers = True
+    K = head.classification_head.num_classes
+    assert outs[True][0]["cls_levels"][0].shape[-1] == K            # MFMA class-output conv: dense logits, no dead classes
+    assert outs[False][0]["cls_levels"][0].shape[-1] == 8           # MIOpen path: class dimension padded to a multiple of 8
     for key in ("cls_levels", "bbox_levels"):
         for a, b in zip(outs[False][0][key], outs[True][0][key]):
+            a = a[..., :K] if key == "cls_levels" else a
             assert a.shape == b.shape
             torch.testing.assert_close(b.float(), a.float(), rtol=5e-2, atol=5e-2 * float(a.float().abs().max()))
     for a, b in zip(outs[False][1], outs[True][1]):
         torch.testing.assert_close(b.float(), a.float(), rtol=1e-1, atol=5e-2 * float(a.float().abs().max()))
     for n, a in outs[False][2].items():
         torch.testing.assert_close(outs[True][2][n].float(), a.float(), rtol=1e-1, atol=5e-2 * float(a.float().abs().max()))
+
+
+@pytest.mark.parametrize("N,K,shapes", [(2, 6, [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)]),        # Cout = 54: one tile, 54 % 8 = 6
+                                        (1, 90, [(13, 17), (7, 9), (4, 5)]),                      # Cout = 810: 4 tiles, 810 % 8 = 2
+                                        (3, 32, [(9, 11), (5, 6), (3, 3), (2, 2), (1, 1)])])      # Cout = 288: 2 tiles, multiple of 8
+def test_cls_output_conv_on_canvas_vs_torch(N, K, shapes):
+    """rn_conv3x3_canvas_to_levels / rn_conv3x3_levels_to_canvas / rn_conv3x3_levels_wgrad (the class-output conv of
+    retinanet/layers.py:163-167 with dense 9*K-channel logits) vs torch's conv2d per level on the same bf16 values:
+    outputs, input gradient, weight gradient, bias gradient."""
+    from pytorch_retinanet_amd import biasact
+    torch.manual_seed(K)
+    A = 9
+    conv = torch.nn.Conv2d(256, A * K, 3, padding=1).to(DEV).to(memory_format=torch.channels_last)
+    torch.nn.init.normal_(conv.weight, std=0.05)
+    torch.nn.init.normal_(conv.bias, std=0.5)
+    feats = [torch.randn(N, 256, h, w, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+             for h, w in shapes]
+    cv = biasact.Canvas.of(feats, pad=1)
+    packed = biasact.pack_levels(cv, feats)
+    assert biasact.cls_output_conv_fusable(packed, conv, cv)
+    ys = biasact.cls_output_conv(packed, conv, cv, K)
+    gys = [torch.randn_like(y) for y in ys]
+    torch.autograd.backward(ys, gys)
+    got = ([y.detach().float() for y in ys], [f.grad.float() for f in feats], conv.weight.grad.float().clone(), conv.bias.grad.float().clone())
+    conv.zero_grad()
+    refs, ref_dx = [], []
+    w32, b32 = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True), conv.bias.detach().clone().requires_grad_(True)
+    for f, g, (h, w) in zip(feats, gys, shapes):
+        x32 = f.detach().float().requires_grad_(True)
+        y = torch.nn.functional.conv2d(x32, w32, b32, padding=1)                       # [N, A*K, h, w]
+        y3 = y.permute(0, 2, 3, 1).reshape(N, h * w * A, K)                             # layers.py:189-191
+        y3.backward(g.float())
+        refs.append(y3.detach())
+        ref_dx.append(x32.grad)
+    for a, b in zip(got[0], refs):
+        assert a.shape == b.shape
+        torch.testing.assert_close(a, b, rtol=2e-2, atol=2e-2 * float(b.abs().max()))              # one bf16 rounding of the output
+    for a, b in zip(got[1], ref_dx):
+        torch.testing.assert_close(a, b, rtol=2e-2, atol=2e-2 * float(b.abs().max()))
+    torch.testing.assert_close(got[2], w32.grad, rtol=2e-2, atol=2e-2 * float(w32.grad.abs().max()))
+    torch.testing.assert_close(got[3], b32.grad, rtol=2e-2, atol=2e-2 * float(b32.grad.abs().max()))
 
 
 @pytest.mark.parametrize("nesterov,dampening", [(False, 0.0), (True, 0.0), (False, 0.1)])
@@ -420,61 +465,6 @@ def test_master_sgd_follows_torch_sgd_under_autocast(nesterov, dampening):
     assert torch.equal(b[0].weight.float(), sb["0.weight"].to(torch.bfloat16).float())      # working copy == bf16(master)
 
 
-@pytest.mark.parametrize("shape,bias", [((2, 256, 256, 11, 13), True), ((1, 64, 256, 9, 40), False), ((3, 256, 512, 5, 6), True)])
-def test_mfma_dense_conv_vs_torch(shape, bias):
-    "rn_conv3x3_nhwc (zero padding by bounds-checked taps) forward + gradients vs torch conv2d on the same bf16 values."
-    from pytorch_retinanet_amd import biasact
-    torch.manual_seed(2)
-    N, Cin, Cout, H, W = shape
-    conv = torch.nn.Conv2d(Cin, Cout, 3, padding=1, bias=bias).to(DEV).to(memory_format=torch.channels_last)
-    x = torch.randn(N, Cin, H, W, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-    old, old_on = biasact.MFMA_CONV_MIN_POSITIONS, biasact.MFMA_DENSE_CONV
-    biasact.MFMA_CONV_MIN_POSITIONS, biasact.MFMA_DENSE_CONV = 0, True
-    try:
-        y = biasact.conv3x3(conv, x)
-        assert y.grad_fn is not None and "Conv3x3Dense" in type(y.grad_fn).__name__
-        g = torch.randn_like(y)
-        y.backward(g)
-    finally:
-        biasact.MFMA_CONV_MIN_POSITIONS, biasact.MFMA_DENSE_CONV = old, old_on
-    xr = x.detach().float().requires_grad_(True)
-    wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
-    br = conv.bias.detach().clone().requires_grad_(True) if bias else None
-    yr = torch.nn.functional.conv2d(xr, wr, br, padding=1)
-    yr.backward(g.float())
-    torch.testing.assert_close(y.float(), yr, rtol=2e-2, atol=1e-2 * float(yr.detach().abs().max()))
-    torch.testing.assert_close(x.grad.float(), xr.grad, rtol=5e-2, atol=2e-2 * float(xr.grad.abs().max()))
-    torch.testing.assert_close(conv.weight.grad.float(), wr.grad, rtol=5e-2, atol=2e-2 * float(wr.grad.abs().max()))
-    if bias:
-        torch.testing.assert_close(conv.bias.grad, br.grad, rtol=2e-2, atol=2e-2 * float(br.grad.abs().max()))
-
-
-@pytest.mark.parametrize("shape", [(2, 256, 1024, 9, 13), (1, 1024, 256, 7, 40), (3, 128, 512, 5, 6)])
-def test_mfma_conv1x1_vs_torch(shape):
-    "rn_conv1x1_nhwc (the MFMA pipeline as a plain GEMM) forward + gradients vs torch."
-    from pytorch_retinanet_amd import biasact
-    torch.manual_seed(3)
-    N, Cin, Cout, H, W = shape
-    conv = torch.nn.Conv2d(Cin, Cout, 1, bias=False).to(DEV).to(memory_format=torch.channels_last)
-    x = torch.randn(N, Cin, H, W, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-    old = biasact.MFMA_CONV1X1
-    biasact.MFMA_CONV1X1 = True
-    try:
-        y = biasact.conv1x1(conv, x)
-        assert "Conv1x1" in type(y.grad_fn).__name__
-        g = torch.randn_like(y)
-        y.backward(g)
-    finally:
-        biasact.MFMA_CONV1X1 = old
-    xr = x.detach().float().requires_grad_(True)
-    wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
-    yr = torch.nn.functional.conv2d(xr, wr)
-    yr.backward(g.float())
-    torch.testing.assert_close(y.float(), yr, rtol=2e-2, atol=1e-2 * float(yr.detach().abs().max()))
-    torch.testing.assert_close(x.grad.float(), xr.grad, rtol=5e-2, atol=2e-2 * float(xr.grad.abs().max()))
-    torch.testing.assert_close(conv.weight.grad.float(), wr.grad, rtol=5e-2, atol=2e-2 * float(wr.grad.abs().max()))
-
-
 @pytest.mark.parametrize("shape", [(2, 9, 11), (1, 14, 37), (3, 23, 31)])
 def test_mfma_canvas_wgrad_vs_miopen(shape):
     """rn_conv3x3_canvas_wgrad_batched (position-contraction MFMA GEMM with transposed LDS reads + split reduction) vs the
@@ -494,36 +484,6 @@ def test_mfma_canvas_wgrad_vs_miopen(shape):
                                                   [False, True, False])[1]
         assert dw.shape == ref.shape and dw.is_contiguous(memory_format=torch.channels_last)
         torch.testing.assert_close(dw.float(), ref, rtol=2e-2, atol=1e-2 * float(ref.abs().max()))
-
-
-@pytest.mark.parametrize("shape,bias", [((2, 11, 13), True), ((1, 9, 40), False), ((3, 17, 6), True)])
-def test_mfma_dense_wgrad_vs_torch(shape, bias):
-    "MIOpen forward / data gradient + rn_conv3x3_nhwc_wgrad (dense images, out-of-image taps = zero) vs torch in fp32."
-    from pytorch_retinanet_amd import biasact
-    torch.manual_seed(6)
-    N, H, W = shape
-    conv = torch.nn.Conv2d(256, 256, 3, padding=1, bias=bias).to(DEV).to(memory_format=torch.channels_last)
-    x = torch.randn(N, 256, H, W, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-    old, old_on = biasact.MFMA_CONV_MIN_POSITIONS, biasact.MFMA_DENSE_WGRAD
-    biasact.MFMA_CONV_MIN_POSITIONS, biasact.MFMA_DENSE_WGRAD = 0, True
-    try:
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            y = biasact.conv3x3(conv, x)
-        assert "Conv3x3MfmaWgrad" in type(y.grad_fn).__name__
-        g = torch.randn_like(y)
-        y.backward(g)
-    finally:
-        biasact.MFMA_CONV_MIN_POSITIONS, biasact.MFMA_DENSE_WGRAD = old, old_on
-    xr = x.detach().float().requires_grad_(True)
-    wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
-    br = conv.bias.detach().clone().requires_grad_(True) if bias else None
-    yr = torch.nn.functional.conv2d(xr, wr, br, padding=1)
-    yr.backward(g.float())
-    torch.testing.assert_close(y.float(), yr, rtol=2e-2, atol=1e-2 * float(yr.detach().abs().max()))
-    torch.testing.assert_close(x.grad.float(), xr.grad, rtol=5e-2, atol=2e-2 * float(xr.grad.abs().max()))
-    torch.testing.assert_close(conv.weight.grad.float(), wr.grad, rtol=5e-2, atol=2e-2 * float(wr.grad.abs().max()))
-    if bias:
-        torch.testing.assert_close(conv.bias.grad, br.grad, rtol=2e-2, atol=2e-2 * float(br.grad.abs().max()))
 
 
 @pytest.mark.parametrize("K", [5, 90])
