@@ -127,6 +127,16 @@ int rn_loss_fwd_bwd_levels(const void *const *cls_levels, const void *const *box
                            const int64_t *matches, const int32_t *num_fg, const rn_loss_params *params,
                            float *out_loss, void *const *grad_cls_levels, void *const *grad_box_levels,
                            void *workspace, size_t workspace_bytes, void *stream);
+/* Same call; additionally records the caller's HIP events (hipEvent_t, may be NULL) on `stream` immediately before and
+ * after the streaming kernel -- the dominant kernel of the call -- so a benchmark can time that kernel alone (the
+ * one-block finalize that follows is outside the pair). */
+int rn_loss_fwd_bwd_levels_timed(const void *const *cls_levels, const void *const *box_levels,
+                                 const int64_t *level_anchors, int L, int dtype, int B, int K,
+                                 const float *anchors, int64_t anchor_bstride, const float *gt_boxes,
+                                 const int64_t *gt_labels, const int32_t *gt_off, const int64_t *matches,
+                                 const int32_t *num_fg, const rn_loss_params *params, float *out_loss,
+                                 void *const *grad_cls_levels, void *const *grad_box_levels, void *workspace,
+                                 size_t workspace_bytes, void *stream, void *event_start, void *event_stop);
 
 /* In-place data[i] *= *scale (device scalar); returns immediately on the device
  * when *scale == 1.  Used by autograd's backward to apply the upstream gradient to

@@ -482,6 +482,10 @@ int resident_blocks(KernelT kernel, int *out)
     return RN_OK;
 }
 
+// optional profiling: HIP events recorded on the launch stream right around the stream kernel (not the finalize)
+struct ProfileEvents { hipEvent_t start, stop; };
+static thread_local ProfileEvents g_prof = {nullptr, nullptr};     // set only for the duration of one rn_loss_fwd_bwd_levels_timed call
+
 template <typename StreamT>
 int launch_stream(StreamT stream_k, LossArgs &a, int vec, hipStream_t st, int *n_stream)
 {
@@ -498,8 +502,10 @@ int launch_stream(StreamT stream_k, LossArgs &a, int vec, hipStream_t st, int *n
     a.vec_per_wave = vpw;
     int64_t need = ((nvec + vpw - 1) / vpw + LOSS_WAVES - 1) / LOSS_WAVES;
     if (need < 1) need = 1;
+    if (g_prof.start) RN_HIP(hipEventRecord(g_prof.start, st));
     hipLaunchKernelGGL(stream_k, dim3((unsigned)need), dim3(LOSS_BLOCK), 0, st, a);
     RN_LAUNCH_CHECK();
+    if (g_prof.stop) RN_HIP(hipEventRecord(g_prof.stop, st));
     *n_stream = (int)need;
     return RN_OK;
 }
@@ -593,6 +599,22 @@ RN_API int rn_loss_fwd_bwd_levels(const void *const *cls_levels, const void *con
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float2 *)a.part_stream, ns, out_loss);
     RN_LAUNCH_CHECK();
     return RN_OK;
+}
+
+RN_API int rn_loss_fwd_bwd_levels_timed(const void *const *cls_levels, const void *const *box_levels,
+                                        const int64_t *level_anchors, int L, int dtype, int B, int K,
+                                        const float *anchors, int64_t anchor_bstride, const float *gt_boxes,
+                                        const int64_t *gt_labels, const int32_t *gt_off, const int64_t *matches,
+                                        const int32_t *num_fg, const rn_loss_params *params, float *out_loss,
+                                        void *const *grad_cls_levels, void *const *grad_box_levels, void *workspace,
+                                        size_t workspace_bytes, void *stream, void *event_start, void *event_stop)
+{
+    g_prof.start = (hipEvent_t)event_start; g_prof.stop = (hipEvent_t)event_stop;
+    const int rc = rn_loss_fwd_bwd_levels(cls_levels, box_levels, level_anchors, L, dtype, B, K, anchors, anchor_bstride, gt_boxes,
+                                          gt_labels, gt_off, matches, num_fg, params, out_loss, grad_cls_levels, grad_box_levels,
+                                          workspace, workspace_bytes, stream);
+    g_prof.start = g_prof.stop = nullptr;
+    return rc;
 }
 
 RN_API int rn_loss_fwd_bwd(const void *cls, const void *box, int dtype, int B, int64_t A, int K,
