@@ -79,8 +79,8 @@ def bench_k2(reps, T):
                                                            "unique_GBps": round(unique / (ms[0] * 1e-3) / 1e9, 1)})
 
 
-def bench_k3(reps, dtype, B=8, want_grad=True):
-    A, K, T = 201600, 90, 8
+def bench_k3(reps, dtype, B=8, want_grad=True, T=8):
+    A, K = 201600, 90
     rng = np.random.default_rng(0)
     anc = anchors_for(800, 1344)
     gt, gl, off = gts(rng, B, T, 800, 1333)
@@ -92,7 +92,8 @@ def bench_k3(reps, dtype, B=8, want_grad=True):
     ms = timeit(lambda: ops.loss_fwd_bwd(cls, box, anc, gt, gl, off, m, nfg, p, want_grad), reps)
     s = cls.element_size()
     nbytes = B * ((2 if want_grad else 1) * (A * K * s + A * 4 * s) + A * 8 + T * 24)
-    report(f"K3 loss_{'fwd_bwd' if want_grad else 'fwd'} {str(dtype).split('.')[-1]} B={B} A={A} K={K}", ms, nbytes)
+    report(f"K3 loss_{'fwd_bwd' if want_grad else 'fwd'} {str(dtype).split('.')[-1]} B={B} A={A} K={K} T={T}", ms, nbytes,
+           {"num_fg_per_image": int(nfg.float().mean()), "ignored_rows_per_image": int((m == -2).sum() // B)})
 
 
 def bench_detect(reps, mean, std, tag, B=16):
@@ -137,7 +138,7 @@ def main():
     if "--reps" in sys.argv:
         reps = int(sys.argv[sys.argv.index("--reps") + 1])
         args = [a for a in args if a != str(reps)]
-    which = args or ["k2", "k2_500", "k3", "k3f32", "k3fwd", "detect"]
+    which = args or ["k2", "k2_500", "k3", "k3_500", "k3f32", "k3fwd", "detect"]
     for w in which:
         if w == "k2":
             bench_k2(reps, 8)
@@ -147,6 +148,8 @@ def main():
             bench_k3(reps, torch.bfloat16)
         elif w == "k3f16":
             bench_k3(reps, torch.float16)
+        elif w == "k3_500":          # BASELINE configs[4]: fp16, 500 GT boxes per image -> 25x the repair (phase B) work
+            bench_k3(reps, torch.float16, T=500)
         elif w == "k3f32":
             bench_k3(reps, torch.float32)
         elif w == "k3fwd":

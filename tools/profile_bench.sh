@@ -1,15 +1,16 @@
 #!/bin/bash
 # rocprofv3 summaries of the headline bench for profiles/: kernel-trace stats, then separate PMC passes
 # for the K3 kernel (FETCH_SIZE / WRITE_SIZE cannot share a pass; MI355X_MICROARCH.md, HBM section).
-out=$GRAFT_REPO_ROOT/gpurun_out/profile_r01
-mkdir -p $out
+tag=${1:-r02}
+out=$GRAFT_REPO_ROOT/gpurun_out/profile_$tag
+mkdir -p $out; rm -f $out/k3_pmc.txt
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_kernel_trace.log 2>&1
 cp /tmp/pb/*/*kernel_stats.csv $out/bench_kernel_stats.csv
 python tools/steady_stats.py /tmp/pb/*/*kernel_trace.csv $out/bench_kernel_stats_steady.csv 3 | tee $out/steady_summary.txt
 grep "^{\"metric" $out/bench_kernel_trace.log | tail -1 > $out/bench_line_under_rocprof.json
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pc; rocprofv3 --pmc $ctr --output-format csv -d /tmp/pc -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline > /tmp/pc.log 2>&1
+  rm -f $out/k3_pmc.txt.tmp; rm -rf /tmp/pc; rocprofv3 --pmc $ctr --output-format csv -d /tmp/pc -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline > /tmp/pc.log 2>&1
   python - $ctr >> $out/k3_pmc.txt <<PY
 import csv,glob,sys
 vals=[]
@@ -21,3 +22,23 @@ print(sys.argv[1], "per launch (KB) over", len(vals), "launches: mean", sum(vals
 PY
 done
 cat $out/k3_pmc.txt
+python - $out <<PY
+import json, re, sys, csv
+out = sys.argv[1]
+txt = open(out + "/k3_pmc.txt").read()
+f = float(re.search(r"FETCH_SIZE per launch \(KB\) over \d+ launches: mean ([0-9.]+)", txt).group(1))
+w = float(re.search(r"WRITE_SIZE per launch \(KB\) over \d+ launches: mean ([0-9.]+)", txt).group(1))
+avg = None
+for r in csv.DictReader(open(out + "/bench_kernel_stats_steady.csv")):
+    if "loss_stream_kernel" in r["Name"]:
+        avg = float(r["AverageNs"]) / 1e3
+line = json.loads(open(out + "/bench_line_under_rocprof.json").read())
+json.dump({"kernel": "loss_stream_kernel<bf16,gamma2,grad> (per-level rn_loss_fwd_bwd_levels, dense K = 90 logits)",
+           "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
+           "correction": "FETCH_SIZE x2 on gfx950 for 16 B/lane coalesced streams (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
+           "hbm_bytes_per_launch": int(round((2 * f + w) * 1024)),
+           "algorithmic_bytes_per_launch": line["roofline"]["algorithmic_bytes_per_launch"],
+           "kernel_avg_us_rocprof": avg,
+           "source": "tools/profile_bench.sh (rocprofv3 --pmc, separate passes), bench.py --steps 3"}, open(out + "/k3_pmc.json", "w"), indent=1)
+print(open(out + "/k3_pmc.json").read())
+PY
