@@ -319,12 +319,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void score_scan_kernel(const ScanArgs
 }
 
 // ---- candidates -> per-(image, class) segments ----------------------------------------------
-// One workgroup per image, everything between the score scan and NMS in one launch:
-//  pass 1  decode + clip the box of every candidate's anchor (K4's arithmetic, decode_one), apply
-//          remove_small_boxes (models.py:203; boxes are per anchor, so the size test commutes with
-//          the per-class loop), count survivors per class in LDS, mark the rest dead;
-//  scan    class counts -> segment offsets (seg_start / seg_len, what NMS consumes);
-//  pass 2  scatter the survivors into their class segment (LDS counters hand out the slots).
+// Everything between the score scan and NMS, as two launches of SEG_GROUPS (16) workgroups per image -- one workgroup per
+// image (round 1) kept 16 of the 256 CUs busy for 59 us on this latency-bound chain of dependent loads:
+//  pass 1  (seg_count_kernel) each workgroup takes 1/16 of the image's candidate list: decode + clip the box of every
+//          candidate's anchor (K4's arithmetic, decode_one), apply remove_small_boxes (models.py:203; boxes are per
+//          anchor, so the size test commutes with the per-class loop), count survivors per class in LDS, mark the rest
+//          dead, publish the class histogram of its slice;
+//  pass 2  (seg_scatter_kernel) class totals over the 16 histograms -> segment offsets (seg_start / seg_len, what NMS
+//          consumes); fill pointer of (workgroup, class) = segment start + counts of the workgroups before it; scatter
+//          the slice's survivors (LDS counters hand out the slots).
 // Only ~1e-3 of the anchors are ever decoded; candidates of one anchor in several classes write the
 // same box.  No global atomics: the per-class counters of an image live in 3 cache lines, and
 // ~1e4 global atomics on them serialise in L2 (measured 25 us per pass).
@@ -348,28 +351,28 @@ struct SegArgs {
     int64_t *seg_start;          // [B][K]
     int32_t *seg_len;            // [B][K]
     int32_t *out_status;         // [B] 1 = more candidates than C
+    int32_t *hist;               // [B][SEG_GROUPS][K] per-workgroup class counts (pass 1 -> pass 2)
 };
 constexpr uint64_t DEAD_KEY = ~0ull;      // not a valid key: its score field would be the smallest float
-constexpr int SEG_THREADS = 1024;
+constexpr int SEG_THREADS = 256;
+constexpr int SEG_GROUPS = 16;            // workgroups per image: each takes 1/16 of the image's candidate list
 constexpr int SEG_UNROLL = 4;             // candidates per thread in flight (independent load chains)
 constexpr int SEG_MAXK = 4096;
 
-template <int DT>
-__global__ __launch_bounds__(SEG_THREADS) void seg_build_kernel(const SegArgs a)
+// Shared prologue of the two kernels: shard fills -> exclusive prefix (s_shard[0..S]), overflow flag, and this
+// workgroup's slice [lo, hi) of the image's n candidates.
+struct SegSlice { int64_t n, lo, hi; int over; };
+__device__ __forceinline__ SegSlice seg_slice(const SegArgs &a, const int b, const int g, int *s_shard, int *s_over)
 {
-    __shared__ int s_cnt[SEG_MAXK];
-    __shared__ int s_shard[SCAN_SHARDS + 1];                  // exclusive prefix of the shard fills
-    __shared__ int s_over;
-    const int b = blockIdx.x, t = threadIdx.x;
-    for (int k = t; k < a.K; k += SEG_THREADS) s_cnt[k] = 0;
-    if (t == 0) s_over = 0;
+    const int t = threadIdx.x;
+    if (t == 0) *s_over = 0;
     __syncthreads();
     if (t < RN_WAVE) {                                        // wave 0: shard fills -> prefix (S <= 128: two rounds)
         int run = 0;
         for (int s0 = 0; s0 < a.S; s0 += RN_WAVE) {
             const int sh = s0 + t;
             int c = sh < a.S ? a.cand_count[(int64_t)b * a.S + sh] : 0;
-            if ((int64_t)c > a.Cs) { c = (int)a.Cs; s_over = 1; }
+            if ((int64_t)c > a.Cs) { c = (int)a.Cs; *s_over = 1; }
             int incl = c;
 #pragma unroll
             for (int dd = 1; dd < RN_WAVE; dd <<= 1) { const int up = __shfl_up(incl, dd, RN_WAVE); if (t >= dd) incl += up; }
@@ -379,25 +382,44 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_build_kernel(const SegArgs a)
         if (t == 0) s_shard[a.S] = run;
     }
     __syncthreads();
-    const int64_t n = s_shard[a.S];
-    // candidate i of the image -> its slot in the sharded list
-    auto slot_of = [&](const int64_t i) -> int64_t {
-        int lo = 0, hi = a.S;                                  // shard sh with s_shard[sh] <= i < s_shard[sh + 1]
-        while (hi - lo > 1) { const int md = (lo + hi) >> 1; if (s_shard[md] <= i) lo = md; else hi = md; }
-        return (int64_t)lo * a.Cs + (i - s_shard[lo]);
-    };
+    SegSlice r;
+    r.n = s_shard[a.S];
+    r.lo = r.n * g / SEG_GROUPS;
+    r.hi = r.n * (g + 1) / SEG_GROUPS;
+    r.over = *s_over;
+    return r;
+}
+// candidate i of the image -> its slot in the sharded list
+__device__ __forceinline__ int64_t seg_slot_of(const SegArgs &a, const int *s_shard, const int64_t i)
+{
+    int lo = 0, hi = a.S;                                      // shard sh with s_shard[sh] <= i < s_shard[sh + 1]
+    while (hi - lo > 1) { const int md = (lo + hi) >> 1; if (s_shard[md] <= i) lo = md; else hi = md; }
+    return (int64_t)lo * a.Cs + (i - s_shard[lo]);
+}
+
+// Pass 1 (grid: SEG_GROUPS x B): decode + clip + remove_small_boxes of this workgroup's slice of the candidates, boxes of the
+// survivors, DEAD_KEY over the rest, and the slice's per-class survivor counts -> hist[b][g][K].
+template <int DT>
+__global__ __launch_bounds__(SEG_THREADS) void seg_count_kernel(const SegArgs a)
+{
+    __shared__ int s_cnt[SEG_MAXK];
+    __shared__ int s_shard[SCAN_SHARDS + 1];
+    __shared__ int s_over;
+    const int g = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    for (int k = t; k < a.K; k += SEG_THREADS) s_cnt[k] = 0;
+    const SegSlice sl = seg_slice(a, b, g, s_shard, &s_over);
     float hh = 0.0f, ww = 0.0f;
     if (a.image_hw) { hh = (float)a.image_hw[2 * b]; ww = (float)a.image_hw[2 * b + 1]; }
     uint64_t *cand = a.cand + (int64_t)b * a.S * a.Cs;
 
-    for (int64_t i0 = 0; i0 < n; i0 += SEG_UNROLL * SEG_THREADS) {
+    for (int64_t i0 = sl.lo; i0 < sl.hi; i0 += SEG_UNROLL * SEG_THREADS) {
         uint64_t key[SEG_UNROLL];
         uint32_t anchor[SEG_UNROLL], k[SEG_UNROLL];
         float d[SEG_UNROLL][4];
         rn::f32x4 an[SEG_UNROLL];
         int64_t slot[SEG_UNROLL];
 #pragma unroll
-        for (int u = 0; u < SEG_UNROLL; ++u) { slot[u] = slot_of(min(i0 + u * SEG_THREADS + t, n - 1)); key[u] = cand[slot[u]]; }
+        for (int u = 0; u < SEG_UNROLL; ++u) { slot[u] = seg_slot_of(a, s_shard, min(i0 + u * SEG_THREADS + t, sl.hi - 1)); key[u] = cand[slot[u]]; }
 #pragma unroll
         for (int u = 0; u < SEG_UNROLL; ++u) {
             const uint32_t ak = (uint32_t)key[u];
@@ -413,14 +435,14 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_build_kernel(const SegArgs a)
 #pragma unroll
         for (int u = 0; u < SEG_UNROLL; ++u) {
             const int64_t i = i0 + u * SEG_THREADS + t;
-            if (i >= n) continue;
+            if (i >= sl.hi) continue;
             rn::f32x4 o = decode_one(d[u], an[u], a.rw);
             if (a.image_hw) {
                 o.x = clampf(o.x, 0.0f, ww); o.z = clampf(o.z, 0.0f, ww);
                 o.y = clampf(o.y, 0.0f, hh); o.w = clampf(o.w, 0.0f, hh);
             }
             if ((o.z - o.x) >= a.min_box && (o.w - o.y) >= a.min_box) {
-                a.boxes[(int64_t)b * a.A + anchor[u]] = o;
+                a.boxes[(int64_t)b * a.A + anchor[u]] = o;    // (several candidates of one anchor write the same box)
                 atomicAdd(&s_cnt[k[u]], 1);
             } else {
                 cand[slot[u]] = DEAD_KEY;
@@ -428,7 +450,32 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_build_kernel(const SegArgs a)
         }
     }
     __syncthreads();
-    if (t < RN_WAVE) {                                        // wave 0: exclusive scan of the class counts
+    int32_t *hist = a.hist + ((int64_t)b * SEG_GROUPS + g) * a.K;
+    for (int k = t; k < a.K; k += SEG_THREADS) hist[k] = s_cnt[k];
+}
+
+// Pass 2 (same grid, next launch): class totals over the image's workgroups -> segment offsets (seg_start / seg_len, what
+// NMS consumes); this workgroup's fill pointer of class k = segment start + the counts of the workgroups before it;
+// scatter of the slice's survivors (LDS counters hand out the slots).  The order inside a class segment is arbitrary:
+// NMS sorts by (score, anchor).
+template <int DT>
+__global__ __launch_bounds__(SEG_THREADS) void seg_scatter_kernel(const SegArgs a)
+{
+    __shared__ int s_cnt[SEG_MAXK];                           // class totals, then fill pointers
+    __shared__ int s_before[SEG_MAXK];                        // survivors of class k in the workgroups before this one
+    __shared__ int s_shard[SCAN_SHARDS + 1];
+    __shared__ int s_over;
+    const int g = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    const SegSlice sl = seg_slice(a, b, g, s_shard, &s_over);
+    const int32_t *hist = a.hist + (int64_t)b * SEG_GROUPS * a.K;
+    for (int k = t; k < a.K; k += SEG_THREADS) {
+        int tot = 0, before = 0;
+#pragma unroll
+        for (int gg = 0; gg < SEG_GROUPS; ++gg) { const int c = hist[gg * a.K + k]; tot += c; before += gg < g ? c : 0; }
+        s_cnt[k] = tot; s_before[k] = before;
+    }
+    __syncthreads();
+    if (t < RN_WAVE) {                                        // wave 0: exclusive scan of the class totals
         int run = 0;
         for (int k0 = 0; k0 < a.K; k0 += RN_WAVE) {
             const int kk = k0 + t;
@@ -437,23 +484,26 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_build_kernel(const SegArgs a)
 #pragma unroll
             for (int dd = 1; dd < RN_WAVE; dd <<= 1) { const int up = __shfl_up(incl, dd, RN_WAVE); if (t >= dd) incl += up; }
             if (kk < a.K) {
-                a.seg_start[(int64_t)b * a.K + kk] = (int64_t)b * a.C + run + (incl - c);
-                a.seg_len[(int64_t)b * a.K + kk] = c;
-                s_cnt[kk] = run + (incl - c);                 // becomes the fill pointer of pass 2
+                if (g == 0) {
+                    a.seg_start[(int64_t)b * a.K + kk] = (int64_t)b * a.C + run + (incl - c);
+                    a.seg_len[(int64_t)b * a.K + kk] = c;
+                }
+                s_cnt[kk] = run + (incl - c) + s_before[kk];  // this workgroup's fill pointer
             }
             run += __shfl(incl, RN_WAVE - 1, RN_WAVE);
         }
-        if (t == 0) a.out_status[b] = s_over;
+        if (t == 0 && g == 0) a.out_status[b] = sl.over;
     }
     __syncthreads();
+    const uint64_t *cand = a.cand + (int64_t)b * a.S * a.Cs;
     uint64_t *seg = a.seg + (int64_t)b * a.C;
-    for (int64_t i0 = 0; i0 < n; i0 += SEG_UNROLL * SEG_THREADS) {
+    for (int64_t i0 = sl.lo; i0 < sl.hi; i0 += SEG_UNROLL * SEG_THREADS) {
         uint64_t key[SEG_UNROLL];
 #pragma unroll
-        for (int u = 0; u < SEG_UNROLL; ++u) key[u] = cand[slot_of(min(i0 + u * SEG_THREADS + t, n - 1))];   // this thread's own writes
+        for (int u = 0; u < SEG_UNROLL; ++u) key[u] = cand[seg_slot_of(a, s_shard, min(i0 + u * SEG_THREADS + t, sl.hi - 1))];
 #pragma unroll
         for (int u = 0; u < SEG_UNROLL; ++u) {
-            if (i0 + u * SEG_THREADS + t >= n || key[u] == DEAD_KEY) continue;
+            if (i0 + u * SEG_THREADS + t >= sl.hi || key[u] == DEAD_KEY) continue;
             const uint32_t ak = (uint32_t)key[u];
             const uint32_t anchor = ak / (uint32_t)a.K, k = ak - anchor * (uint32_t)a.K;
             const int pos = atomicAdd(&s_cnt[k], 1);
@@ -719,7 +769,7 @@ size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct DetectWs {
     rn::f32x4 *boxes; uint64_t *cand, *seg; rn::f32x4 *sbox; uint8_t *supp;
-    int32_t *cand_count, *kept_count, *seg_len; int64_t *seg_start;
+    int32_t *cand_count, *kept_count, *seg_len, *hist; int64_t *seg_start;
     size_t zero_bytes, total;
 };
 
@@ -742,6 +792,7 @@ DetectWs carve(void *base, int B, int64_t A, int K, int64_t C)
     w.kept_count = (int32_t *)take(BK * 4);
     w.seg_len = (int32_t *)take(BK * 4);
     w.seg_start = (int64_t *)take(BK * 8);
+    w.hist = (int32_t *)take(BK * 16 * 4);                    // SEG_GROUPS = 16 workgroups per image
     w.total = off;
     return w;
 }
@@ -819,7 +870,7 @@ RN_API int rn_detect_levels(const void *const *cls_levels, const void *const *bo
     fa.anchors = (const rn::f32x4 *)anchors; fa.anchor_bstride4 = anchor_bstride / 4; fa.image_hw = image_hw; fa.rw = rw;
     fa.A = A; fa.C = C; fa.K = K; fa.min_box = params->min_box;
     fa.cand = w.cand; fa.cand_count = w.cand_count; fa.boxes = w.boxes;
-    fa.seg = w.seg; fa.seg_start = w.seg_start; fa.seg_len = w.seg_len; fa.out_status = out_status;
+    fa.seg = w.seg; fa.seg_start = w.seg_start; fa.seg_len = w.seg_len; fa.out_status = out_status; fa.hist = w.hist;
     sa.A = A; sa.C = C; sa.K = K; sa.B = B;
     // shards of the per-image candidate list; the worst-case capacity (the caller's retry) is one list so
     // that "A*K always suffices" holds however the candidates are distributed over the waves
@@ -861,11 +912,12 @@ RN_API int rn_detect_levels(const void *const *cls_levels, const void *const *bo
     }
     RN_LAUNCH_CHECK();
     {
-        const dim3 fg((unsigned)B), fb(SEG_THREADS);
+        static_assert(SEG_GROUPS == 16, "carve() sizes the class histograms for 16 workgroups per image");
+        const dim3 fg(SEG_GROUPS, (unsigned)B), fb(SEG_THREADS);
         switch (dtype) {
-            case RN_F32: hipLaunchKernelGGL((seg_build_kernel<RN_F32>), fg, fb, 0, st, fa); break;
-            case RN_BF16: hipLaunchKernelGGL((seg_build_kernel<RN_BF16>), fg, fb, 0, st, fa); break;
-            default: hipLaunchKernelGGL((seg_build_kernel<RN_F16>), fg, fb, 0, st, fa); break;
+            case RN_F32: hipLaunchKernelGGL((seg_count_kernel<RN_F32>), fg, fb, 0, st, fa); hipLaunchKernelGGL((seg_scatter_kernel<RN_F32>), fg, fb, 0, st, fa); break;
+            case RN_BF16: hipLaunchKernelGGL((seg_count_kernel<RN_BF16>), fg, fb, 0, st, fa); hipLaunchKernelGGL((seg_scatter_kernel<RN_BF16>), fg, fb, 0, st, fa); break;
+            default: hipLaunchKernelGGL((seg_count_kernel<RN_F16>), fg, fb, 0, st, fa); hipLaunchKernelGGL((seg_scatter_kernel<RN_F16>), fg, fb, 0, st, fa); break;
         }
         RN_LAUNCH_CHECK();
     }

@@ -1,10 +1,11 @@
 #!/bin/bash
 # rocprofv3 kernel-trace summary of the dense-head microbenchmarks (K2 at T=8 and T=500, K3 bf16/f32, the
 # inference chain at the cfg-4 shape) -> gpurun_out/profile_r01/kernels_*; copy into profiles/.
-out=$GRAFT_REPO_ROOT/gpurun_out/profile_r01
+tag=${1:-r02}; shift
+out=$GRAFT_REPO_ROOT/gpurun_out/profile_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rm -rf /tmp/pk; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -- python tools/bench_kernels.py k2 k2_500 k3 k3f32 detect > $out/kernels_bench.log 2>&1
+rm -rf /tmp/pk; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pk -- python tools/bench_kernels.py ${@:-k2 k2_500 k3 k3_500 k3f32 detect} > $out/kernels_bench.log 2>&1
 python - $out <<'PY'
 import csv, glob, sys
 out = sys.argv[1]
