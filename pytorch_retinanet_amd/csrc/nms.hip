@@ -39,6 +39,33 @@ __device__ __forceinline__ bool overlaps(const f32x4 bi, const float ai, const f
     return ovr > thr;
 }
 
+// The same predicate for a whole wave, without the divide where it cannot matter: with t = thr * union (> 0, finite),
+// |inter - t| > 2^-21 t decides it -- the rounding of t and of the quotient are 2^-24 relative each -- and only a wave in
+// which some lane is closer than that (or has a non-positive / non-finite union) evaluates the exact quotient.
+__device__ __forceinline__ bool overlaps_wave(const f32x4 bi, const float ai, const f32x4 bj, const float aj, const float thr, const bool live)
+{
+    // inter as in `overlaps` (v_max / v_min give std::max / std::min's values for non-NaN boxes; NaN boxes make `clear`
+    // false below through a NaN t, and the exact path then evaluates the reference expression)
+    float inter, t0, t1;
+    asm("v_min_f32 %0, %5, %9\n\t"
+        "v_max_f32 %1, %3, %7\n\t"
+        "v_sub_f32 %0, %0, %1\n\t"
+        "v_min_f32 %1, %6, %10\n\t"
+        "v_max_f32 %2, %4, %8\n\t"
+        "v_sub_f32 %1, %1, %2\n\t"
+        "v_max_f32 %0, 0, %0\n\t"
+        "v_max_f32 %1, 0, %1\n\t"
+        "v_mul_f32 %0, %0, %1"
+        : "=&v"(inter), "=&v"(t0), "=&v"(t1)
+        : "v"(bi.x), "v"(bi.y), "v"(bi.z), "v"(bi.w), "v"(bj.x), "v"(bj.y), "v"(bj.z), "v"(bj.w));
+    const float uni = (ai + aj) - inter;
+    const float t = thr * uni;
+    const float d = inter - t;
+    const bool clear = t > 0.0f && fabsf(d) > t * 4.76837158e-7f;      // (an infinite or NaN t is never clear)
+    if (__any(live && !clear)) return overlaps(bi, ai, bj, aj, thr);
+    return d > 0.0f;
+}
+
 template <int THREADS>
 __device__ __forceinline__ void bitonic_sort_lds(uint64_t *keys, const int n_pad)
 {
@@ -74,9 +101,8 @@ __device__ __forceinline__ int block_excl_scan(int *s_scan, const int mine, int 
 }
 
 template <int THREADS, int CAP>
-__global__ __launch_bounds__(THREADS) void nms_lds_kernel(const rn::NmsLaunch a, const int min_len, const int max_len)
+__device__ __forceinline__ void nms_lds_body(const rn::NmsLaunch &a, unsigned char *smem)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f32x4 *s_box = (f32x4 *)smem;
     uint64_t *s_key = (uint64_t *)(smem + (size_t)CAP * 16);
     float *s_area = (float *)(smem + (size_t)CAP * 24);
@@ -85,11 +111,6 @@ __global__ __launch_bounds__(THREADS) void nms_lds_kernel(const rn::NmsLaunch a,
 
     const int s = blockIdx.x;
     const int n = a.seg_len[s];
-    if (n < min_len || n > max_len) return;
-    if (n == 0) {
-        if (threadIdx.x == 0) a.kept_count[s] = 0;
-        return;
-    }
     const int64_t start = a.seg_start[s];
     const int64_t box_base = a.box_mode ? (int64_t)(s / a.K) * a.A : start;
 
@@ -174,24 +195,43 @@ __global__ __launch_bounds__(MASK_CAP) void nms_mask_kernel(const rn::NmsLaunch 
         s_area[t] = (b.z - b.x) * (b.w - b.y);
     }
     __syncthreads();
-    // suppression matrix: bit j of s_mask[i][w] (j = 64w + bit) <=> j > i and IoU(i, j) > thr
+    // suppression matrix: bit j of s_mask[i][w] (j = 64w + bit) <=> j > i and IoU(i, j) > thr.  A wave takes every 4th row;
+    // its lanes keep column j = 64w + lane of every word w in registers (box + area), the row's box is one LDS broadcast,
+    // and lane w collects word w so a row costs one LDS store.
     const int nw = (n + 63) >> 6;
+    f32x4 bj[MASK_WORDS];
+    float aj[MASK_WORDS];
+#pragma unroll
+    for (int w = 0; w < MASK_WORDS; ++w) {
+        const int j = min(w * 64 + lane, n - 1);
+        bj[w] = s_box[j]; aj[w] = s_area[j];
+    }
     for (int i = wave; i < n; i += MASK_CAP / RN_WAVE) {
         const f32x4 bi = s_box[i];
         const float ai = s_area[i];
         const int w0 = (i + 1) >> 6;                         // words entirely at or below the diagonal hold no j > i
-        if (lane < w0) s_mask[i][lane] = 0ull;
-        for (int w = w0; w < nw; ++w) {
-            const int j = w * 64 + lane;
-            bool sup = false;
-            if (j > i && j < n) sup = overlaps(bi, ai, s_box[j], s_area[j], a.iou_thr);
-            const unsigned long long m = __ballot(sup);
-            if (lane == 0) s_mask[i][w] = m;
+        uint64_t mine = 0ull;
+#pragma unroll
+        for (int w = 0; w < MASK_WORDS; ++w) {
+            if (w >= w0 && w < nw) {                         // wave-uniform
+                const int j = w * 64 + lane;
+                const bool live = j > i && j < n;
+                const bool sup = overlaps_wave(bi, ai, bj[w], aj[w], a.iou_thr, live) && live;
+                const unsigned long long m = __ballot(sup);
+                if (lane == w) mine = m;
+            }
         }
+        if (lane < MASK_WORDS) s_mask[i][lane] = mine;
     }
     __syncthreads();
-    // greedy scan: every lane of wave 0 carries the same 4-word "removed" set (no cross-lane traffic)
+    // greedy scan by wave 0: row i of the matrix sits in the registers of lane i & 63 (register set i >> 6), the "removed"
+    // set is wave-uniform (SGPRs); a kept row is fetched with v_readlane -- no LDS round trip on the serial chain
     if (wave == 0) {
+        uint64_t row[MASK_WORDS][MASK_WORDS];
+#pragma unroll
+        for (int wb = 0; wb < MASK_WORDS; ++wb)
+#pragma unroll
+            for (int ww = 0; ww < MASK_WORDS; ++ww) row[wb][ww] = (wb * 64 + lane < n && ww < nw) ? s_mask[wb * 64 + lane][ww] : 0ull;
         uint64_t rem[MASK_WORDS];
 #pragma unroll
         for (int w = 0; w < MASK_WORDS; ++w) rem[w] = 0;
@@ -201,11 +241,14 @@ __global__ __launch_bounds__(MASK_CAP) void nms_mask_kernel(const rn::NmsLaunch 
             if (i0 < n) {
                 const int cnt = min(64, n - i0);
                 for (int bit = 0; bit < cnt; ++bit) {
-                    const int i = i0 + bit;
                     if (!((rem[w] >> bit) & 1ull)) {
 #pragma unroll
                         for (int ww = 0; ww < MASK_WORDS; ++ww)
-                            if (ww >= w && ww < nw) rem[ww] |= s_mask[i][ww];
+                            if (ww >= w) {
+                                const unsigned lo = __builtin_amdgcn_readlane((unsigned)row[w][ww], bit);
+                                const unsigned hi = __builtin_amdgcn_readlane((unsigned)(row[w][ww] >> 32), bit);
+                                rem[ww] |= ((uint64_t)hi << 32) | lo;
+                            }
                     }
                 }
             }
@@ -237,14 +280,13 @@ __global__ __launch_bounds__(MASK_CAP) void nms_mask_kernel(const rn::NmsLaunch 
 }
 
 // Segments longer than MED_CAP: chunk sort in LDS, merge passes and NMS state in HBM.
-__global__ __launch_bounds__(BIG_THREADS) void nms_big_kernel(const rn::NmsLaunch a)
+__device__ __forceinline__ void nms_big_body(const rn::NmsLaunch &a)
 {
     __shared__ uint64_t s_key[MED_CAP];
     __shared__ int s_scan[BIG_THREADS + 1];
 
     const int s = blockIdx.x;
     const int n = a.seg_len[s];
-    if (n <= MED_CAP) return;
     const int64_t start = a.seg_start[s];
     const int64_t box_base = a.box_mode ? (int64_t)(s / a.K) * a.A : start;
     uint64_t *buf0 = a.keys + start, *buf1 = a.kept + start;
@@ -336,17 +378,35 @@ __global__ __launch_bounds__(256) void nms_prep_kernel(const float *__restrict__
 
 size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// Segments longer than MASK_CAP in ONE launch of 1024-thread workgroups (most exit at once: such segments are rare at the
+// reference's score threshold): up to MED_CAP entries sort and suppress in LDS, longer ones go through HBM.
+__global__ __launch_bounds__(BIG_THREADS) void nms_large_kernel(const rn::NmsLaunch a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = a.seg_len[blockIdx.x];
+    if (n <= MASK_CAP) return;
+    if (n <= MED_CAP) nms_lds_body<BIG_THREADS, MED_CAP>(a, smem);
+    else nms_big_body(a);
+}
+
 }  // namespace
 
 int rn::launch_nms(const rn::NmsLaunch &a, hipStream_t st)
 {
     if (a.S <= 0) return RN_OK;
-    const size_t lds_med = (size_t)MED_CAP * 29 + sizeof(int) * (256 + 1);
+    const size_t lds_med = (size_t)MED_CAP * 29 + sizeof(int) * (BIG_THREADS + 1);
+    {   // > 64 KiB of LDS in one workgroup (static + dynamic) needs the opt-in once per device
+        static bool attr_set[64] = {};
+        int dev = 0;
+        RN_HIP(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            RN_HIP(hipFuncSetAttribute((const void *)nms_large_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_med));
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
+    }
     hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)a.S), dim3(MASK_CAP), 0, st, a);                 // n <= 256
     RN_LAUNCH_CHECK();
-    hipLaunchKernelGGL((nms_lds_kernel<256, MED_CAP>), dim3((unsigned)a.S), dim3(256), lds_med, st, a, MASK_CAP + 1, MED_CAP);
-    RN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(nms_big_kernel, dim3((unsigned)a.S), dim3(BIG_THREADS), 0, st, a);
+    hipLaunchKernelGGL(nms_large_kernel, dim3((unsigned)a.S), dim3(BIG_THREADS), lds_med, st, a);       // everything longer, one launch
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
