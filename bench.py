@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--force-ddp", action="store_true", help="use the bucketed all-reduce path even at world size 1 (validation)")
     ap.add_argument("--torch-sgd", action="store_true", help="fp32 parameters + torch.optim.SGD instead of fp32 masters + bf16 conv weights (optim.MasterSGD); same arithmetic")
     ap.add_argument("--cpu-baseline-reps", type=int, default=30, help="batches of the dense-head workload timed on the host (about 10 s of CPU work)")
+    ap.add_argument("--no-detect", action="store_true", help="skip the inference-chain (decode + NMS + top-k) roofline line (BASELINE configs[3] shape)")
     return ap.parse_args()
 
 
@@ -107,6 +108,59 @@ def self_launch(args) -> int:
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd)
+
+
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense MFMA peak ~2.5 PFLOP/s
+FWD_GFLOP_PER_IMAGE = 510.3  # R50-FPN + heads forward @800x1344; x3 for forward + data + weight gradients
+
+
+def detect_chain_line(device, with_cpu):
+    """BASELINE configs[3] shape: B = 16 images, A = 338 454 anchors (1344 x 1344 padded input), K = 90, fp16 head outputs,
+    sparse regime (logits N(-7, 1.2), about 11 k candidates per image): rn_detect = score scan + decode + per-class NMS +
+    top-100, events around the call.  CPU: the oracle's process_detections on ONE image of the same batch."""
+    import synth
+    from pytorch_retinanet_amd import ops
+    from pytorch_retinanet_amd.anchors import AnchorGenerator
+    B, A, K = 16, 338454, 90
+    ag = AnchorGenerator().to(device)
+    anc = ops.anchors_emit(synth.levels_for(1344, 1344), list(ag.cell_anchors), 0.0)
+    g = torch.Generator(device=device).manual_seed(1)
+    cls = (torch.randn((B, A, K), device=device, generator=g) * 1.2 - 7.0).to(torch.float16)
+    box = (torch.randn((B, A, 4), device=device, generator=g) * 0.1).to(torch.float16)
+    hw = [(1333, 1333)] * B
+    ncand = int((torch.sigmoid(cls.float()) > 0.05).sum())
+    for _ in range(3):
+        ops.detect(cls, box, anc, hw, 0.05, 1e-2, 0.5, 100, max_candidates=1 << 18)
+    torch.cuda.synchronize()
+    ops.enable_timing(True)
+    for _ in range(10):
+        dets = ops.detect(cls, box, anc, hw, 0.05, 1e-2, 0.5, 100, max_candidates=1 << 18)
+    torch.cuda.synchronize()
+    ev = ops.timing_events()["detect"]
+    ops.enable_timing(False)
+    ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+    nbytes = B * (A * K * 2 + A * 4 * 2 + A * 16)              # SURVEY 8d: logits + deltas + anchors per image
+    line = {"bound": "hbm", "kernel": "rn_detect chain (score_scan + seg_count + seg_scatter + nms_mask + nms_large + topk)",
+            "workload": f"B={B} A={A} K={K} fp16, {ncand // B} candidates/image", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_call_ms": round(ms, 4),
+            "algorithmic_bytes_per_call": nbytes}
+    cpu = None
+    if with_cpu:
+        import oracle
+        oracle.build()
+        c1, b1, a1 = cls[:1].float().cpu().numpy(), box[:1].float().cpu().numpy(), anc.cpu().numpy()
+        times = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            ref = oracle.detect(c1, b1, a1, hw[:1])
+            times.append(time.perf_counter() - t0)
+        t = float(np.median(times[1:]))
+        assert np.array_equal(dets[0]["labels"].cpu().numpy(), ref[0]["labels"])       # the checker, checking
+        cpu = {"value": round(1.0 / t, 3), "unit": "images/sec (decode + NMS + top-100 chain only, fp32 oracle)", "cores": oracle.num_threads(),
+               "kind": "port", "sample": f"3 reps of ONE image of the batch (A={A}, K={K}); the GPU line processes 16 per call",
+               "ms_per_image": round(t * 1e3, 2), "gpu_images_per_sec": round(B / (ms * 1e-3), 1)}
+    del cls, box
+    return line, cpu
 
 
 def main():
@@ -212,7 +266,32 @@ def main():
                 "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": round(k3_ms, 4) if k3_ms else None,
                 "streamed_bytes_per_launch": streamed, "classes_streamed": K_run,
                 "call_ms_with_finalize": round(kms["loss_fwd_bwd"], 4) if "loss_fwd_bwd" in kms else None,
-                "other_kernels_ms": {k: round(v, 4) for k, v in kms.items() if k not in ("loss_fwd_bwd", "loss_stream_kernel")}}
+                "other_kernels_ms": {k: round(v, 4) for k, v in kms.items() if k in ("transform_batch", "iou_match")}}
+        # K2 (iou_match): one anchor set shared by the batch -> the anchors are read once per launch, so the bytes that can
+        # reach HBM are A*16 + B*(T*16 + A*8); SURVEY 8d's per-image figure (anchors counted per image) is beside it
+        k2_ms = kms.get("iou_match")
+        k2_unique = A * 16 + args.batch * (args.gt * 16 + A * 8)
+        k2_alg = args.batch * (A * 16 + args.gt * 16 + A * 8)
+        roof_other = {"iou_match": {
+            "bound": "hbm (launch-latency-bound at this size: DESIGN.md section 3, K2)", "kernel": "iou_match_batch_kernel + the num_fg memset (events around rn_iou_match_ex)",
+            "achieved": round(k2_unique / (k2_ms * 1e-3) / 1e9, 1) if k2_ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(k2_unique / (k2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k2_ms else None,
+            "unique_bytes_per_launch": k2_unique, "survey_8d_bytes_per_launch": k2_alg,
+            "frac_on_survey_8d_bytes": round(k2_alg / (k2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k2_ms else None,
+            "avg_call_ms": round(k2_ms, 4) if k2_ms else None, "pairs_per_sec": round(args.batch * A * args.gt / (k2_ms * 1e-3), 0) if k2_ms else None}}
+        # MFMA share: whole step on the model's useful flops, and the hand-written conv kernels alone (events around each launch)
+        from pytorch_retinanet_amd import biasact
+        step_s = elapsed / args.steps
+        own = {k: (kms[k], biasact.MFMA_FLOP[k], len(ev[k]) / args.steps) for k in kms if k.startswith("mfma_") and k in biasact.MFMA_FLOP}
+        own_flop = sum(f * n for _, f, n in own.values())
+        own_ms = sum(ms * n for ms, _, n in own.values())
+        conv_mfma = {"peak_tflops": MFMA_PEAK_TFLOPS,
+                     "whole_step_tflops": round(3 * FWD_GFLOP_PER_IMAGE * args.batch / step_s / 1e3, 1),
+                     "whole_step_frac": round(3 * FWD_GFLOP_PER_IMAGE * args.batch / step_s / 1e3 / MFMA_PEAK_TFLOPS, 4),
+                     "own_kernels_tflops": round(own_flop / (own_ms * 1e-3) / 1e12, 1) if own_ms else None,
+                     "own_kernels_frac": round(own_flop / (own_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4) if own_ms else None,
+                     "own_kernels_ms_per_step": round(own_ms, 3), "own_kernels_share_of_step_flop": round(own_flop / (3 * FWD_GFLOP_PER_IMAGE * 1e9 * args.batch), 3),
+                     "own_kernels": {k: {"ms": round(ms, 4), "calls_per_step": round(n, 2), "tflops": round(f / (ms * 1e-3) / 1e12, 1)} for k, (ms, f, n) in sorted(own.items())}}
         line = {
             "metric": "images/sec RetinaNet-R50-FPN train step @800x1333",
             "value": round(world * args.batch * args.steps / elapsed, 3),
@@ -223,10 +302,18 @@ def main():
                                    f"{args.batch} x 3x800x1333 (padded 800x1344), A=201600 anchors, K=90, T={args.gt} GT/img, "
                                    f"SGD(momentum{'' if args.torch_sgd else ', fp32 masters + bf16 conv weights'}); random-init weights",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
-            "roofline": roof,
+            "roofline": roof, "roofline_other": roof_other, "conv_mfma": conv_mfma,
+            "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 0,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, A, K)
+        if world == 1 and not args.no_detect:
+            del net, optimizer
+            torch.cuda.empty_cache()
+            det_line, det_cpu = detect_chain_line(device, not args.no_cpu_baseline)
+            line["roofline_other"]["detect_chain"] = det_line
+            if det_cpu is not None:
+                line["cpu_baseline"]["detect_chain"] = det_cpu
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.barrier()

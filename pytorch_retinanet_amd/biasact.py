@@ -20,9 +20,18 @@ import torch.nn.functional as F
 from torch import Tensor
 
 from ._lib import RN_BF16, RN_F16, RN_F32, check, lib
+from .ops import _timed          # event pairs around the MFMA conv launches when ops.enable_timing(True) (bench.py)
 
 _DT = {torch.float32: RN_F32, torch.bfloat16: RN_BF16, torch.float16: RN_F16}
 _WS: Dict[tuple, Tensor] = {}
+MFMA_FLOP: Dict[str, float] = {}      # flop per call of every timed MFMA launch (bench.py: achieved TFLOP/s of the own conv kernels)
+
+
+def _mfma_call(tag: str, dev: torch.device, flop: float, status_thunk, what: str) -> None:
+    "Launch one hand-written MFMA conv; with ops.enable_timing(True) the launch is bracketed by events and its flop recorded."
+    MFMA_FLOP[tag] = flop
+    with _timed(tag, dev):
+        check(status_thunk(), what)
 
 
 def _workspace(dev: torch.device, stream: int, channels: int):
@@ -98,9 +107,10 @@ def _canvas_wgrad(gs, xs, ws, Wp: int, stream: int):
     if wsb is None or wsb.numel() < need:
         wsb = _WG_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
     dws = [torch.empty((256, 256, 3, 3), dtype=x0.dtype, device=dev, memory_format=torch.channels_last) for _ in range(P)]
-    check(lib.rn_conv3x3_canvas_wgrad_batched(_ptr_array(gs), _ptr_array(xs), _ptr_array(dws), P, _DT[x0.dtype], M, Wp, 256, 256,
-                                              _zero_page(dev).data_ptr(), wsb.data_ptr(), wsb.numel(), stream),
-          "rn_conv3x3_canvas_wgrad_batched")
+    _mfma_call(f"mfma_tower_wgrad_x{P}", dev, P * 2.0 * M * 256 * 2304,
+               lambda: lib.rn_conv3x3_canvas_wgrad_batched(_ptr_array(gs), _ptr_array(xs), _ptr_array(dws), P, _DT[x0.dtype], M, Wp, 256, 256,
+                                                           _zero_page(dev).data_ptr(), wsb.data_ptr(), wsb.numel(), stream),
+               "rn_conv3x3_canvas_wgrad_batched")
     return dws
 
 
@@ -120,8 +130,9 @@ class _TowerConv(torch.autograd.Function):
         if not _cl(w):
             w = w.contiguous(memory_format=torch.channels_last)
         y = torch.empty((N, Cout, Hp, Wp), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
-        check(lib.rn_conv3x3_canvas(x.data_ptr(), w.data_ptr(), bias.data_ptr(), mask.data_ptr(), y.data_ptr(), _DT[x.dtype],
-                                    N * Hp * Wp, Hp * Wp, Wp, Cin, Cout, 1, stream), "rn_conv3x3_canvas")
+        _mfma_call("mfma_tower_fwd_x1", dev, 2.0 * N * Hp * Wp * Cout * 9 * Cin,
+                   lambda: lib.rn_conv3x3_canvas(x.data_ptr(), w.data_ptr(), bias.data_ptr(), mask.data_ptr(), y.data_ptr(), _DT[x.dtype],
+                                                 N * Hp * Wp, Hp * Wp, Wp, Cin, Cout, 1, stream), "rn_conv3x3_canvas")
         ctx.save_for_backward(x, w, y, mask)
         return y
 
@@ -146,8 +157,9 @@ class _TowerConv(torch.autograd.Function):
         if ctx.needs_input_grad[0] and Cin % 256 == 0 and Cout % 64 == 0:
             wt = w.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)     # [Cin, Cout, 3, 3], taps reversed
             dx = torch.empty_like(x)
-            check(lib.rn_conv3x3_canvas(g.data_ptr(), wt.data_ptr(), 0, mask.data_ptr(), dx.data_ptr(), _DT[x.dtype],
-                                        M, Hp * Wp, Wp, Cout, Cin, 0, stream), "rn_conv3x3_canvas")
+            _mfma_call("mfma_tower_dgrad_x1", dev, 2.0 * M * Cout * 9 * Cin,
+                       lambda: lib.rn_conv3x3_canvas(g.data_ptr(), wt.data_ptr(), 0, mask.data_ptr(), dx.data_ptr(), _DT[x.dtype],
+                                                     M, Hp * Wp, Wp, Cout, Cin, 0, stream), "rn_conv3x3_canvas")
         if ctx.needs_input_grad[1]:
             r = _canvas_wgrad([g], [x], [w], Wp, stream)
             dw = r[0] if r is not None else None
@@ -178,9 +190,10 @@ class _TowerConvPair(torch.autograd.Function):
         w0 = w0 if _cl(w0) else w0.contiguous(memory_format=torch.channels_last)
         w1 = w1 if _cl(w1) else w1.contiguous(memory_format=torch.channels_last)
         ys = [torch.empty((N, Cout, Hp, Wp), dtype=x0.dtype, device=dev, memory_format=torch.channels_last) for _ in range(2)]
-        check(lib.rn_conv3x3_canvas_batched(_ptr_array([x0, x1]), _ptr_array([w0, w1]), _ptr_array([b0, b1]), mask.data_ptr(),
-                                            _ptr_array(ys), 2, _DT[x0.dtype], N * Hp * Wp, Hp * Wp, Wp, Cin, Cout, 1, stream),
-              "rn_conv3x3_canvas_batched")
+        _mfma_call("mfma_tower_fwd_x2", dev, 2 * 2.0 * N * Hp * Wp * Cout * 9 * Cin,
+                   lambda: lib.rn_conv3x3_canvas_batched(_ptr_array([x0, x1]), _ptr_array([w0, w1]), _ptr_array([b0, b1]), mask.data_ptr(),
+                                                         _ptr_array(ys), 2, _DT[x0.dtype], N * Hp * Wp, Hp * Wp, Wp, Cin, Cout, 1, stream),
+                   "rn_conv3x3_canvas_batched")
         ctx.save_for_backward(x0, x1, w0, w1, ys[0], ys[1], mask)
         return ys[0], ys[1]
 
@@ -208,8 +221,9 @@ class _TowerConvPair(torch.autograd.Function):
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             wts = [w.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last) for w in (w0, w1)]
             dxs = [torch.empty_like(x0), torch.empty_like(x1)]
-            check(lib.rn_conv3x3_canvas_batched(_ptr_array(gs), _ptr_array(wts), None, mask.data_ptr(), _ptr_array(dxs), 2,
-                                                _DT[x0.dtype], M, Hp * Wp, Wp, Cout, Cin, 0, stream), "rn_conv3x3_canvas_batched")
+            _mfma_call("mfma_tower_dgrad_x2", dev, 2 * 2.0 * M * Cout * 9 * Cin,
+                       lambda: lib.rn_conv3x3_canvas_batched(_ptr_array(gs), _ptr_array(wts), None, mask.data_ptr(), _ptr_array(dxs), 2,
+                                                             _DT[x0.dtype], M, Hp * Wp, Wp, Cout, Cin, 0, stream), "rn_conv3x3_canvas_batched")
         dws = _canvas_wgrad(gs, [x0, x1], [w0, w1], Wp, stream)
         if dws is None:
             dws = [torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
@@ -381,9 +395,12 @@ class _ClsOutputConv(torch.autograd.Function):
         if not _cl(w):
             w = w.contiguous(memory_format=torch.channels_last)
         ys = [torch.empty((N, h * wd * (Cout // num_classes), num_classes), dtype=x.dtype, device=dev) for h, wd in canvas.shapes]
-        check(lib.rn_conv3x3_canvas_to_levels(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else 0, _level_array(canvas),
-                                              len(ys), _ptr_array(ys), _DT[x.dtype], N, Hp, Wp, Cin, Cout, _zero_page(dev).data_ptr(),
-                                              stream), "rn_conv3x3_canvas_to_levels")
+        # flop counted on the positions and channels that exist (the kernel also walks canvas gaps and pads Cout to 256s)
+        real = N * sum(h * wd for h, wd in canvas.shapes)
+        _mfma_call("mfma_cls_output_fwd", dev, 2.0 * real * Cout * 9 * Cin,
+                   lambda: lib.rn_conv3x3_canvas_to_levels(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else 0,
+                                                           _level_array(canvas), len(ys), _ptr_array(ys), _DT[x.dtype], N, Hp, Wp, Cin, Cout,
+                                                           _zero_page(dev).data_ptr(), stream), "rn_conv3x3_canvas_to_levels")
         ctx.save_for_backward(x, w)
         ctx.canvas, ctx.has_bias = canvas, bias is not None
         return tuple(ys)
@@ -404,13 +421,15 @@ class _ClsOutputConv(torch.autograd.Function):
                 dy = torch.zeros((N, h * wd * Cout), dtype=x.dtype, device=dev)
             gs.append(dy.to(x.dtype).contiguous())
         lv = _level_array(cv)
+        real = N * sum(h * wd for h, wd in cv.shapes)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             wt = _dgrad_weight(w)
-            check(lib.rn_conv3x3_levels_to_canvas(_ptr_array(gs), lv, len(gs), Cout, wt.data_ptr(), cv.mask.data_ptr(), dx.data_ptr(),
-                                                  _DT[x.dtype], N, Hp, Wp, wt.shape[1], Cin, _zero_page(dev).data_ptr(), stream),
-                  "rn_conv3x3_levels_to_canvas")
+            _mfma_call("mfma_cls_output_dgrad", dev, 2.0 * real * Cout * 9 * Cin,
+                       lambda: lib.rn_conv3x3_levels_to_canvas(_ptr_array(gs), lv, len(gs), Cout, wt.data_ptr(), cv.mask.data_ptr(), dx.data_ptr(),
+                                                               _DT[x.dtype], N, Hp, Wp, wt.shape[1], Cin, _zero_page(dev).data_ptr(), stream),
+                       "rn_conv3x3_levels_to_canvas")
         if ctx.needs_input_grad[1]:
             need = lib.rn_conv3x3_wgrad_workspace_bytes((Cout + 255) // 256, N * Hp * Wp)
             key = (dev.index, stream)
@@ -418,8 +437,10 @@ class _ClsOutputConv(torch.autograd.Function):
             if wsb is None or wsb.numel() < need:
                 wsb = _WG_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
             dw = torch.empty((Cout, Cin, 3, 3), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
-            check(lib.rn_conv3x3_levels_wgrad(_ptr_array(gs), lv, len(gs), Cout, x.data_ptr(), dw.data_ptr(), _DT[x.dtype], N, Hp, Wp, Cin,
-                                              _zero_page(dev).data_ptr(), wsb.data_ptr(), wsb.numel(), stream), "rn_conv3x3_levels_wgrad")
+            _mfma_call("mfma_cls_output_wgrad", dev, 2.0 * real * Cout * 9 * Cin,
+                       lambda: lib.rn_conv3x3_levels_wgrad(_ptr_array(gs), lv, len(gs), Cout, x.data_ptr(), dw.data_ptr(), _DT[x.dtype], N, Hp, Wp,
+                                                           Cin, _zero_page(dev).data_ptr(), wsb.data_ptr(), wsb.numel(), stream),
+                       "rn_conv3x3_levels_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = sum(g.reshape(-1, Cout).sum(0, dtype=torch.float32) for g in gs)
         return dx, dw, db, None, None
