@@ -7,12 +7,13 @@ on the 3x3 of a bottleneck).  The convolutions are PyTorch-ROCm / MIOpen; run th
 model in ``channels_last`` + bf16 autocast on MI355X (see ``models.Retinanet``).
 """
 import os
-from typing import Dict, List, Optional, Type, Union
+from typing import Dict, List, Optional, Tuple, Type, Union
 
 import torch
+import torch.nn.functional as F
 from torch import Tensor, nn
 
-from .norm import FusedBatchNorm2d
+from .norm import FusedBatchNorm2d, _BNAct
 from .pool import FusedMaxPool2d
 
 __all__ = ["resnet18", "resnet34", "resnet50", "resnet101", "resnet152"]
@@ -24,6 +25,54 @@ model_urls = {
     "resnet101": "https://download.pytorch.org/models/resnet101-5d3b4d8f.pth",
     "resnet152": "https://download.pytorch.org/models/resnet152-b121ed2d.pth",
 }
+
+
+# ---- frozen-BN folding for inference (reference backbone.py:348-351 freezes BN by eval()) --------------
+# bn(conv(x)) with BN on its running statistics is one convolution with rescaled weights plus a per-channel bias:
+#   w' = w * gamma / sqrt(var + eps),  b' = beta - mean * gamma / sqrt(var + eps).
+# Under no_grad with the BN layer in eval mode the blocks below run conv(x, w') and hand b' (+ residual, + ReLU) to the
+# same fused one-pass epilogue kernel the BN layers use (as an identity normalisation), so an inference step neither
+# reads the BN statistics nor re-casts fp32 weights under autocast.  The folded tensors are cached per (conv, bn, dtype)
+# and rebuilt when any of the five source tensors changes (version counters), e.g. after load_state_dict.
+FOLD_FROZEN_BN = True
+_FOLD_CACHE: Dict[tuple, tuple] = {}
+
+
+def _folded(conv: nn.Conv2d, bn: nn.BatchNorm2d, dtype: torch.dtype) -> Tuple[Tensor, ...]:
+    src = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    key = (id(conv), id(bn), dtype, conv.weight.device)
+    stamp = tuple((t.data_ptr(), t._version) for t in src)
+    hit = _FOLD_CACHE.get(key)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    with torch.no_grad():
+        w32 = getattr(conv.weight, "master", conv.weight).float()          # fp32 master of a bf16 working copy (optim.py)
+        scale = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+        w = (w32 * scale[:, None, None, None]).to(dtype)
+        if conv.weight.is_contiguous(memory_format=torch.channels_last):
+            w = w.contiguous(memory_format=torch.channels_last)
+        b = (bn.bias.float() - bn.running_mean.float() * scale).contiguous()
+        C = b.numel()
+        ones, zeros = torch.ones(C, device=b.device), torch.zeros(C, device=b.device)
+        var1 = torch.full((C,), 1.0 - bn.eps, device=b.device)             # identity normalisation: (x - 0) / sqrt(var1 + eps) * 1 + b'
+    out = (w, b, ones, zeros, var1)
+    _FOLD_CACHE[key] = (stamp, out)
+    return out
+
+
+def conv_bn(conv: nn.Conv2d, bn: FusedBatchNorm2d, x: Tensor, relu: bool = False, residual: Optional[Tensor] = None) -> Tensor:
+    "``[relu](bn(conv(x)) [+ residual])``; folded into the conv weights when BN is frozen and no gradient is recorded."
+    if FOLD_FROZEN_BN and not bn.training and not torch.is_grad_enabled() and x.is_cuda and bn.track_running_stats:
+        dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+        w, b, ones, zeros, var1 = _folded(conv, bn, dt)
+        y = F.conv2d(x.to(dt), w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        if bn._fusable(y, residual):
+            return _BNAct.apply(y, residual, ones, b, zeros, var1, None, False, 0.0, bn.eps, relu)
+        y = y + b.to(y.dtype)[None, :, None, None]
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+    return bn(conv(x), relu=relu, residual=residual)
 
 
 def _conv3x3(cin: int, cout: int, stride: int = 1) -> nn.Conv2d:
@@ -48,9 +97,9 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x: Tensor) -> Tensor:
-        identity = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x), relu=True)
-        return self.bn2(self.conv2(out), relu=True, residual=identity)      # relu(bn2(.) + identity), one kernel
+        identity = x if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], x)
+        out = conv_bn(self.conv1, self.bn1, x, relu=True)
+        return conv_bn(self.conv2, self.bn2, out, relu=True, residual=identity)      # relu(bn2(.) + identity), one kernel
 
 
 class Bottleneck(nn.Module):
@@ -69,10 +118,10 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x: Tensor) -> Tensor:
-        identity = x if self.downsample is None else self.downsample(x)
-        out = self.bn1(self.conv1(x), relu=True)
-        out = self.bn2(self.conv2(out), relu=True)
-        return self.bn3(self.conv3(out), relu=True, residual=identity)      # relu(bn3(.) + identity), one kernel
+        identity = x if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], x)
+        out = conv_bn(self.conv1, self.bn1, x, relu=True)
+        out = conv_bn(self.conv2, self.bn2, out, relu=True)
+        return conv_bn(self.conv3, self.bn3, out, relu=True, residual=identity)      # relu(bn3(.) + identity), one kernel
 
 
 class ResNetBackbone(nn.Module):
@@ -113,7 +162,7 @@ class ResNetBackbone(nn.Module):
         return nn.Sequential(*stack)
 
     def _forward_impl(self, x: Tensor) -> Dict[str, Tensor]:
-        x = self.maxpool(self.bn1(self.conv1(x), relu=True))
+        x = self.maxpool(conv_bn(self.conv1, self.bn1, x, relu=True))
         x = self.layer1(x)
         c3 = self.layer2(x)
         c4 = self.layer3(c3)

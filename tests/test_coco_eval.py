@@ -169,3 +169,16 @@ def test_property_detecting_every_ground_truth_exactly_gives_ap_one(scene):
     # identical boxes of one (image, category) would steal each other's matches only at equal IoU: still all TP
     s = BBoxEval([dict(g) for g in gts], dts).evaluate().summarize(verbose=False)
     assert s[0] == pytest.approx(1.0) and s[8] == pytest.approx(1.0)
+
+
+def test_hand_computed_protocol_fixtures():
+    """tests/golden/coco_protocol_cases.json: multi-class / area-range / maxDets cases whose 12 statistics were derived by
+    hand from the published COCO protocol (each case carries its derivation); reference evaluator call sites:
+    utils/coco/coco_eval.py:15-156, model.py:136-146."""
+    import json
+    import os
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "coco_protocol_cases.json")))
+    for case in cases["cases"]:
+        s = BBoxEval(case["gt"], case["dt"]).evaluate().summarize(verbose=False)
+        assert len(s) == 12
+        np.testing.assert_allclose(s, case["stats"], atol=1e-9, err_msg=case["name"])

@@ -526,3 +526,44 @@ def test_bucketed_ddp_world1_with_master_sgd_equals_plain_step(K):
     # last bf16 bits of the gradients (lr 1e-2, 2 steps)
     for k in a:
         torch.testing.assert_close(a[k], b[k], rtol=0, atol=5e-4, msg=k)
+
+
+@pytest.mark.parametrize("kind", ["resnet18", "resnet50"])
+def test_frozen_bn_folding_equals_the_unfused_eval_path(kind):
+    """Inference with BN frozen (eval mode, no_grad): conv weights carry gamma / sqrt(var + eps) and the epilogue adds the
+    folded bias (backbone.conv_bn; reference backbone.py:348-351) -- same C3/C4/C5 as bn(conv(x)) on the
+    running statistics, fp32 1e-4 and bf16 autocast within bf16 rounding; the fold is rebuilt when the statistics change."""
+    import pytorch_retinanet_amd as P
+    from pytorch_retinanet_amd import backbone
+    torch.manual_seed(3)
+    net = P.Retinanet(num_classes=4, backbone_kind=kind, pretrained=False, min_size=128, max_size=160).to(DEV)
+    net = net.to(memory_format=torch.channels_last).eval()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):                  # non-trivial statistics and affine parameters
+                m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
+    x = torch.randn(2, 3, 128, 160, device=DEV).contiguous(memory_format=torch.channels_last)
+
+    def run(fold, autocast):
+        backbone.FOLD_FROZEN_BN = fold
+        try:
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                return [o.float() for o in net.backbone(x)]
+        finally:
+            backbone.FOLD_FROZEN_BN = True
+    for autocast, tol in ((False, 1e-4), (True, 4e-2)):
+        ref, got = run(False, autocast), run(True, autocast)
+        for a, b in zip(ref, got):
+            torch.testing.assert_close(b, a, rtol=tol, atol=tol * float(a.abs().max()))
+    assert len(backbone._FOLD_CACHE) > 0
+    before = run(True, False)
+    with torch.no_grad():
+        net.backbone.backbone.bn1.running_mean.add_(0.5)             # statistics change -> version counter -> the fold is rebuilt
+    after, ref = run(True, False), run(False, False)
+    assert not torch.allclose(before[0], after[0])
+    for a, b in zip(ref, after):
+        torch.testing.assert_close(b, a, rtol=1e-4, atol=1e-4 * float(a.abs().max()))
+    # with gradients enabled (or BN in train mode) nothing is folded: the training path is untouched
+    net.train()
+    y = net.backbone(x)
+    assert y[0].requires_grad
