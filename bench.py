@@ -110,6 +110,39 @@ def self_launch(args) -> int:
     return subprocess.call(cmd)
 
 
+def cpu_train_step_baseline(args):
+    """The WHOLE train step on the host, one image: transform -> R50-FPN + heads (PyTorch's CPU kernels, fp32 -- what the
+    reference itself runs on a CPU) -> anchors + IoU match + focal / smooth-L1 loss with gradients (the CPU oracle) ->
+    backward through the conv stack -> SGD(momentum) step.  One warm-up step, then the median of 2 timed steps."""
+    import oracle
+    import synth
+    import pytorch_retinanet_amd as P
+    oracle.build()
+    torch.manual_seed(0)
+    net = P.Retinanet(num_classes=90, backbone_kind=args.backbone, pretrained=False, min_size=800, max_size=1333).train()
+    opt = torch.optim.SGD(net.parameters(), lr=1e-3, weight_decay=1e-3, momentum=0.9)
+    rng = np.random.default_rng(0)
+    img = torch.rand(3, 800, 1333)
+    gtb, gtl = synth.gt_boxes(rng, args.gt, 800, 1333)
+    cells = [oracle.cell_anchors(sz, synth.ANCHOR_RATIOS) for sz in synth.ANCHOR_SIZES]
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        il, _ = net.transform([img], None)
+        fmaps, out = net._features(il.tensors)
+        anc = oracle.anchors_emit(synth.levels_for(il.tensors.shape[-2], il.tensors.shape[-1]), cells, 0.0)
+        m, _ = oracle.iou_match(anc, [gtb])
+        o = oracle.loss_fwd_bwd(out["cls_preds"].detach().numpy(), out["bbox_preds"].detach().numpy(), anc, [gtb], [gtl], m)
+        torch.autograd.backward([out["cls_preds"], out["bbox_preds"]], [torch.from_numpy(o["gcls"]), torch.from_numpy(o["gbox"])])
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times[1:]))
+    return {"value": round(1.0 / t, 4), "unit": "images/sec (whole train step, fp32, batch 1)", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "median of 2 steps (after 1 warm-up) of ONE 3x800x1333 image: PyTorch CPU conv stack forward + backward + SGD, "
+                      "dense head on oracle/rn_oracle.c", "s_per_step": round(t, 3)}
+
+
 MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 dense MFMA peak ~2.5 PFLOP/s
 FWD_GFLOP_PER_IMAGE = 510.3  # SURVEY 8d: R50-FPN + heads forward @800x1344; x3 for forward + data + weight gradients
 
@@ -307,6 +340,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, A, K)
+            line["cpu_baseline"]["train_step"] = cpu_train_step_baseline(args)
         if world == 1 and not args.no_detect:
             del net, optimizer
             torch.cuda.empty_cache()
