@@ -64,6 +64,7 @@ struct LossArgs {
     rn_loss_params p;
     float alpha_pos;         // weight of t=1 elements: 1-alpha (Q2)
     float2 *part_stream;     // [blocks] (cls, reg) partial sums
+    int32_t inplace;         // grad_cls aliases cls: the gradient overwrites the logits (training: nothing reads them again)
 };
 
 // ---- background element (t = 0) ------------------------------------------------------
@@ -223,15 +224,60 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
 
         // prefetch this range's slice of `matches` (phase B input) so its latency hides under the stream
         int pm[PREF_CHUNKS];
+        float px[PREF_CHUNKS];                                        // in-place mode: the logit of a matched row's positive element
 #pragma unroll
         for (int c = 0; c < PREF_CHUNKS; ++c) {
             const int64_t r = row_lo + c * RN_WAVE + lane;
             int m = -1;
+            int b = 0;
             if (r <= row_hi) {
-                const int b = (int)((uint32_t)r / (uint32_t)lv.A_l);
+                b = (int)((uint32_t)r / (uint32_t)lv.A_l);
                 m = (int)a.matches[(int64_t)b * a.A + lv.base + (r - (int64_t)b * lv.A_l)];
             }
             pm[c] = m;
+            px[c] = 0.0f;
+        }
+        if (a.inplace) {
+            // The gradient is about to overwrite the logits, and phase B wants two things from them.  (1) The positive
+            // element of every matched row: read it now (one element per lane and chunk).  (2) Ignored rows must end with
+            // zero loss and zero gradient: overwrite their logits with -inf here -- the stream then computes exactly 0 for
+            // both (sigmoid(-80)^2 underflows, as for dead classes) and phase B has nothing left to repair.
+            // (The host only selects this mode when a wave's rows fit the PREF_CHUNKS * 64 prefetched matches.)
+#pragma unroll
+            for (int c = 0; c < PREF_CHUNKS; ++c) {
+                const int64_t r = row_lo + c * RN_WAVE + lane;
+                bool ignored = false;
+                if (r <= row_hi && pm[c] != -1) {
+                    const int b = (int)((uint32_t)r / (uint32_t)lv.A_l);
+                    const int t0 = a.gt_off[b], T = a.gt_off[b + 1] - t0;
+                    if (T > 0) {
+                        if (pm[c] >= 0) {
+                            const int code = (int)a.gt_labels[t0 + pm[c]] - 1;
+                            const int64_t e_pos = r * K + code;
+                            if (code >= 0 && code < K && e_pos >= e_beg && e_pos < e_end) px[c] = D::ld(lv.cls, e_pos);
+                        } else {
+                            ignored = true;
+                        }
+                    }
+                }
+                const unsigned long long imask = __ballot(ignored);
+                if (imask) {                                              // wave-uniform
+                    if (ignored) s_ign_row[wave][__popcll(imask & ((1ull << lane) - 1ull))] = (unsigned char)lane;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const int total = __popcll(imask) * K;
+                    const int64_t c0 = row_lo + c * RN_WAVE;
+                    for (int t = lane; t < total; t += RN_WAVE) {
+                        const int j = t / K, k = t - j * K;
+                        const int64_t e = (c0 + s_ign_row[wave][j]) * K + k;
+                        if (e >= e_beg && e < e_end) D::st(const_cast<void *>(lv.cls), e, -__builtin_inff());
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the -inf stores land before the stream's loads of this wave
         }
 
         if (v_beg < v_end) {
@@ -350,7 +396,13 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                             const int64_t e_pos = r_e0 + code;
                             if (code >= 0 && code < K && e_pos >= e_beg && e_pos < e_end) {
                                 // matched row: only the positive element differs from what phase A did
-                                const float x = D::ld(lv.cls, e_pos);
+                                float x = 0.0f;
+                                if (a.inplace) {
+#pragma unroll
+                                    for (int k = 0; k < PREF_CHUNKS; ++k) if (c == k) x = px[k];
+                                } else {
+                                    x = D::ld(lv.cls, e_pos);
+                                }
                                 float wb, gbg, l, gr;
                                 bg_elem<GAMMA2>(x, a.p, wb, gbg);
                                 focal_elem<GAMMA2>(x, true, a, l, gr);
@@ -365,7 +417,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) gb[j] *= scale;
                             }
-                        } else {
+                        } else if (!a.inplace) {                       // (in-place mode neutralised ignored rows before the stream)
                             ignored = true;
                             ign_gm = gmul;
                         }
@@ -493,13 +545,14 @@ int launch_stream(StreamT stream_k, LossArgs &a, int vec, hipStream_t st, int *n
     int rc = resident_blocks(stream_k, &res);
     if (rc != RN_OK) return rc;
     // even split of the vectors over the resident waves, in whole wave-iterations (64 vectors = 1 KiB)
-    (void)vec;
     const int64_t nvec = a.total_vec;
     const int64_t waves = (int64_t)res * LOSS_WAVES;
     int64_t vpw = (nvec + waves - 1) / waves;
     vpw = ((vpw + RN_WAVE - 1) / RN_WAVE) * RN_WAVE;
     if (vpw < RN_WAVE) vpw = RN_WAVE;
     a.vec_per_wave = vpw;
+    // in-place mode needs every row of a wave's range among the PREF_CHUNKS * 64 rows whose matches are prefetched
+    if (a.inplace && (vpw * vec) / a.K + 3 > PREF_CHUNKS * RN_WAVE) return RN_EUNSUPPORTED;
     int64_t need = ((nvec + vpw - 1) / vpw + LOSS_WAVES - 1) / LOSS_WAVES;
     if (need < 1) need = 1;
     if (g_prof.start) RN_HIP(hipEventRecord(g_prof.start, st));
@@ -586,6 +639,13 @@ RN_API int rn_loss_fwd_bwd_levels(const void *const *cls_levels, const void *con
     a.p = *params;
     a.alpha_pos = (float)(1.0 - (double)params->alpha);
     a.part_stream = (float2 *)workspace;
+    a.inplace = 0;
+    if (grad_cls_levels) {                                       // in-place: the gradient of every level overwrites its logits
+        int same = 0;
+        for (int l = 0; l < L; ++l) same += grad_cls_levels[l] == cls_levels[l] ? 1 : 0;
+        if (same != 0 && same != L) return RN_EINVAL;
+        a.inplace = same == L ? 1 : 0;
+    }
     const bool gamma2 = params->gamma == 2.0f;
     const bool wg = grad_cls_levels != nullptr;
     hipStream_t st = (hipStream_t)stream;

@@ -97,7 +97,8 @@ def test_forward_losses_and_gradients_match_the_reference_fp32(golden):
         gr = named[str(k)].grad
         assert gr is not None, k
         np.testing.assert_allclose(float(gr.double().norm()), norm, rtol=2e-3, err_msg=str(k))
-        np.testing.assert_allclose(gr.reshape(-1)[:8].double().cpu().numpy(), head, rtol=2e-2, atol=1e-3 * norm / np.sqrt(gr.numel()),
+        # (single elements: fp32 convolutions whose algorithm MIOpen picks per run -- compare against the gradient's rms)
+        np.testing.assert_allclose(gr.reshape(-1)[:8].double().cpu().numpy(), head, rtol=5e-2, atol=1e-2 * norm / np.sqrt(gr.numel()),
                                    err_msg=str(k))
     # one training forward moved the BN running statistics exactly like the reference's
     np.testing.assert_allclose(net.backbone.backbone.bn1.running_mean.cpu().numpy(), g["bn1_running_mean_after"], rtol=1e-4, atol=1e-6)
