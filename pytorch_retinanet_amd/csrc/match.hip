@@ -114,6 +114,11 @@ __device__ __forceinline__ bool may_overlap(const WaveBox bb, const GtBox g)
     return g.z > bb.x0 && bb.x1 > g.x && g.w > bb.y0 && bb.y1 > g.y;
 }
 
+__device__ __forceinline__ bool may_overlap(const WaveBox bb, const rn::f32x4 g)
+{
+    return g.z > bb.x0 && bb.x1 > g.x && g.w > bb.y0 && bb.y1 > g.y;
+}
+
 __device__ __forceinline__ bool gt_is_proper(const rn::f32x4 g, const float area)
 {
     return (g.z - g.x) > 0.0f && (g.w - g.y) > 0.0f && area < __builtin_inff();
@@ -265,11 +270,7 @@ __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_tile_kernel(
             if (!gt_is_proper(g, ar)) s_bad[it & 1] = 1;
         }
         __syncthreads();
-#ifdef RN_K2_FORCE_FAST
-        if (true) {
-#else
         if (wave_ok && !s_bad[it & 1]) {
-#endif
             // once a tile has been processed here, `have` only means "best/bi hold torch's running result so far";
             // with proper boxes every quotient is >= +0, so starting from (0, index 0) and updating on strict > is exact
             // (a negative running maximum can only come from an earlier careful tile: this tile's first pair beats it)
@@ -282,17 +283,20 @@ __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_tile_kernel(
                 const rn::f32x4 mine = s_box[c + lane];     // lane l holds GT row base + c + l
                 const float mine_a = s_area[c + lane];
                 const int m = min(RN_WAVE, n - c);
-                for (int l = 0; l < m; ++l) {
+                // 64 GT boxes are culled against the wave's strip at once (each lane tests its own box); only the survivors --
+                // ~10 % at the headline shapes -- are broadcast and paired
+                unsigned long long todo = __ballot(lane < m && may_overlap(bb, mine));
+                while (todo) {
+                    const int l = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
                     const GtBox g = gt_of_lane(mine, mine_a, l);
-                    if (may_overlap(bb, g)) {               // wave-uniform: most GT boxes miss the wave's strip of anchors
 #pragma unroll
-                        for (int r = 0; r < R; ++r) {
-                            const float inter = inter_fast(g, an[r]);
-                            if (__any(inter != 0.0f)) {
-                                // a NaN best (from an earlier careful tile) stays: (v > NaN) is false
-                                const float v = inter / ((g.area + area_a[r]) - inter);
-                                if (v > best[r].v) { best[r].v = v; best[r].i = base + c + l; }
-                            }
+                    for (int r = 0; r < R; ++r) {
+                        const float inter = inter_fast(g, an[r]);
+                        if (__any(inter != 0.0f)) {
+                            // a NaN best (from an earlier careful tile) stays: (v > NaN) is false
+                            const float v = inter / ((g.area + area_a[r]) - inter);
+                            if (v > best[r].v) { best[r].v = v; best[r].i = base + c + l; }
                         }
                     }
                 }
@@ -321,9 +325,202 @@ __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_tile_kernel(
             nfg += m >= 0 ? 1 : 0;
         }
     }
-    if (num_fg) {
+    if (num_fg) {                                          // one global atomic per workgroup (same-address atomics serialise)
         nfg = rn::wave_sum_i(nfg);
-        if ((tid & (RN_WAVE - 1)) == 0 && nfg) atomicAdd(&num_fg[b], nfg);
+        __syncthreads();                                    // every wave is past its last read of s_bad
+        if (tid == 0) s_bad[0] = 0;
+        __syncthreads();
+        if ((tid & (RN_WAVE - 1)) == 0 && nfg) atomicAdd(&s_bad[0], nfg);
+        __syncthreads();
+        if (tid == 0 && s_bad[0]) atomicAdd(&num_fg[b], s_bad[0]);
+    }
+}
+
+// ============================================================================================================
+// Large GT sets (hundreds of boxes per image): the pair work of an anchor strip is proportional to the number of GT boxes
+// it overlaps, so the waves that own the big anchors of P5-P7 (which overlap nearly everything) run 10-50x longer than the
+// waves of P3 -- with one wave per anchor strip the launch lasted as long as the P6/P7 strips alone (200 of 300 us at
+// T = 500).  Here the GT axis is split as well: grid.z workgroups share an anchor strip, each walks every grid.z-th
+// tile of CHUNK_TILE GT boxes, and the per-anchor results meet in `matches` through a 64-bit atomic max on
+//     key = ordered(IoU) << 32 | ~index        (ordered(): order-preserving map of the float, NaN on top, -0 = +0)
+// whose maximum is torch's (max IoU, first index; the first NaN wins).  A finalize kernel turns the keys into match
+// codes.  Workgroups that took the fast loop only (proper boxes: every IoU >= +0) skip the atomic when their maximum is 0;
+// the finalize kernel recomputes the rare anchor for which that shortcut could matter (a negative maximum, i.e. inverted
+// boxes, or a negative foreground threshold) from scratch.  The strips are handed out from the END of the anchor array
+// (the big anchors) so the long-running workgroups start first.
+constexpr int CHUNK_TILE = 128;
+
+__device__ __forceinline__ uint32_t ordered_bits(const float v)
+{
+    if (v != v) return 0xffffffffu;
+    const uint32_t u = __float_as_uint(v == 0.0f ? 0.0f : v);
+    return (u >> 31) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_value(const uint32_t k)
+{
+    if (k == 0xffffffffu) return __builtin_nanf("");
+    return __uint_as_float((k >> 31) ? (k & 0x7fffffffu) : ~k);
+}
+
+template <int R>
+__global__ __launch_bounds__(MATCH_BLOCK) void iou_match_chunk_kernel(
+    const rn::f32x4 *__restrict__ anchors, const int64_t anchor_bstride4,
+    const rn::f32x4 *__restrict__ gt, const int32_t *__restrict__ gt_off, const int64_t A,
+    unsigned long long *__restrict__ keys)
+{
+    __shared__ rn::f32x4 s_box[CHUNK_TILE];
+    __shared__ float s_area[CHUNK_TILE];
+    __shared__ int s_bad[2];
+
+    const int tid = threadIdx.x, lane = tid & (RN_WAVE - 1);
+    const int b = blockIdx.y;
+    const int t0 = gt_off[b];
+    const int T = gt_off[b + 1] - t0;
+    const int64_t strip = (int64_t)(gridDim.x - 1 - blockIdx.x);          // big anchors (end of the array) first
+    const int64_t a0 = strip * (MATCH_BLOCK * R) + (tid >> 6) * (RN_WAVE * R) + lane;
+
+    rn::f32x4 an[R];
+    float area_a[R];
+    bool a_ok = true;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t a_idx = a0 + (int64_t)r * RN_WAVE;
+        an[r] = rn::f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a_idx < A) an[r] = anchors[(int64_t)b * anchor_bstride4 + a_idx];
+        area_a[r] = (an[r].z - an[r].x) * (an[r].w - an[r].y);
+        a_ok = a_ok && anchor_is_proper(an[r], area_a[r]);
+    }
+    const bool wave_ok = __all(a_ok);
+    WaveBox bb = {0.f, 0.f, 0.f, 0.f};
+    if (wave_ok) {
+        float x0 = an[0].x, y0 = an[0].y, x1 = an[0].z, y1 = an[0].w;
+#pragma unroll
+        for (int r = 1; r < R; ++r) { x0 = fminf(x0, an[r].x); y0 = fminf(y0, an[r].y); x1 = fmaxf(x1, an[r].z); y1 = fmaxf(y1, an[r].w); }
+        bb = WaveBox{wave_min(x0), wave_min(y0), wave_max(x1), wave_max(y1)};
+    }
+
+    Best best[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) best[r] = Best{0.0f, 0, false};
+    bool all_fast = true;                                   // wave-uniform: every tile so far went through the fast loop
+
+    if (tid < 2) s_bad[tid] = 0;
+    for (int base = (int)blockIdx.z * CHUNK_TILE, it = 0; base < T; base += (int)gridDim.z * CHUNK_TILE, ++it) {
+        const int n = min(CHUNK_TILE, T - base);
+        __syncthreads();
+        if (tid == 0) s_bad[(it + 1) & 1] = 0;
+        if (tid < n) {
+            const rn::f32x4 g = gt[t0 + base + tid];
+            const float ar = (g.z - g.x) * (g.w - g.y);
+            s_box[tid] = g;
+            s_area[tid] = ar;
+            if (!gt_is_proper(g, ar)) s_bad[it & 1] = 1;
+        }
+        __syncthreads();
+        if (wave_ok && !s_bad[it & 1]) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (!best[r].have) best[r] = Best{0.0f, base, true};
+                else if (best[r].v < 0.0f) best[r] = Best{0.0f, base, true};
+            }
+            for (int c = 0; c < n; c += RN_WAVE) {
+                const rn::f32x4 mine = s_box[min(c + lane, CHUNK_TILE - 1)];
+                const float mine_a = s_area[min(c + lane, CHUNK_TILE - 1)];
+                const int m = min(RN_WAVE, n - c);
+                // 64 GT boxes are culled against the wave's strip at once (each lane tests its own box); only the survivors
+                // are broadcast and paired
+                unsigned long long todo = __ballot(lane < m && may_overlap(bb, mine));
+                while (todo) {
+                    const int l = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const GtBox g = gt_of_lane(mine, mine_a, l);
+                    float inter[R];
+                    bool any = false;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) { inter[r] = inter_fast(g, an[r]); any = any || inter[r] != 0.0f; }
+                    if (__any(any)) {
+                        // all R quotients in one basic block: the R independent divide chains overlap (the strips that come
+                        // here at all are the big anchors, for which most of the R groups overlap the box anyway)
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const float v = inter[r] / ((g.area + area_a[r]) - inter[r]);
+                            if (v > best[r].v) { best[r].v = v; best[r].i = base + c + l; }
+                        }
+                    }
+                }
+            }
+        } else {
+            all_fast = false;
+            for (int c = 0; c < n; c += RN_WAVE) {
+                const rn::f32x4 mine = s_box[min(c + lane, CHUNK_TILE - 1)];
+                const float mine_a = s_area[min(c + lane, CHUNK_TILE - 1)];
+                const int m = min(RN_WAVE, n - c);
+                for (int l = 0; l < m; ++l) {
+                    const GtBox g = gt_of_lane(mine, mine_a, l);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) careful_update(best[r], iou_pair(vec(g), g.area, an[r], area_a[r]), base + c + l);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int64_t a_idx = a0 + (int64_t)r * RN_WAVE;
+        if (a_idx >= A || !best[r].have) continue;
+        if (all_fast && best[r].v == 0.0f) continue;       // (0, first index of the chunk): cannot win against any other contribution
+        const unsigned long long key = ((unsigned long long)ordered_bits(best[r].v) << 32) | (uint32_t)~(uint32_t)best[r].i;
+        atomicMax(&keys[(int64_t)b * A + a_idx], key);
+    }
+}
+
+// keys -> match codes (+ num_fg).  No key: every IoU was +0 -> (0, index 0).
+constexpr int FIN_BLOCK = 1024;
+__global__ __launch_bounds__(FIN_BLOCK) void iou_match_finalize_kernel(
+    const rn::f32x4 *__restrict__ anchors, const int64_t anchor_bstride4, const rn::f32x4 *__restrict__ gt,
+    const int32_t *__restrict__ gt_off, const int64_t A, const float fg_thr, const float bg_thr,
+    int64_t *__restrict__ matches, int32_t *__restrict__ num_fg)
+{
+    const int b = blockIdx.y;
+    const int t0 = gt_off[b], T = gt_off[b + 1] - t0;
+    __shared__ int s_fg;
+    if (threadIdx.x == 0) s_fg = 0;
+    __syncthreads();
+    const int64_t a_idx = (int64_t)blockIdx.x * FIN_BLOCK + threadIdx.x;
+    const bool live = a_idx < A;
+    int64_t r = -2;
+    if (live) {
+        const unsigned long long key = (unsigned long long)matches[(int64_t)b * A + a_idx];
+        float best = 0.0f;
+        int bi = 0;
+        if (key) { best = ordered_value((uint32_t)(key >> 32)); bi = (int)~(uint32_t)key; }
+        if (T > 0 && (best < 0.0f || (best == 0.0f && fg_thr < 0.0f))) {
+            // the zero-skipping of the chunk kernel is not exact here (inverted boxes / a negative threshold): redo this anchor
+            const rn::f32x4 an = anchors[(int64_t)b * anchor_bstride4 + a_idx];
+            const float area_a = (an.z - an.x) * (an.w - an.y);
+            Best bb = {0.0f, 0, false};
+            for (int j = 0; j < T; ++j) {
+                const rn::f32x4 g = gt[t0 + j];
+                const float ga = (g.z - g.x) * (g.w - g.y);
+                // (not the wave-uniform shortcut of iou_pair: lanes are at different j here)
+                const float ltx = g.x > an.x ? g.x : an.x, lty = g.y > an.y ? g.y : an.y;
+                const float rbx = g.z < an.z ? g.z : an.z, rby = g.w < an.w ? g.w : an.w;
+                float w = rbx - ltx; if (!(w > 0.0f)) w = (w != w) ? w : 0.0f;
+                float h = rby - lty; if (!(h > 0.0f)) h = (h != h) ? h : 0.0f;
+                const float inter = w * h;
+                careful_update(bb, inter / ((ga + area_a) - inter), j);
+            }
+            best = bb.v; bi = bb.i;
+        }
+        r = classify(best, bi, T, fg_thr, bg_thr);
+        matches[(int64_t)b * A + a_idx] = r;
+    }
+    if (num_fg) {
+        // thousands of foreground anchors per image here: one global atomic per 1024 anchors (same-address atomics from every
+        // wave serialise at ~50 per microsecond and address: 35 us of a 69 us kernel before)
+        const unsigned long long fg = __ballot(live && r >= 0);
+        if ((threadIdx.x & (RN_WAVE - 1)) == 0 && fg) atomicAdd(&s_fg, __popcll(fg));
+        __syncthreads();
+        if (threadIdx.x == 0 && s_fg) atomicAdd(&num_fg[b], s_fg);
     }
 }
 
@@ -355,6 +552,18 @@ RN_API int rn_iou_match_ex(const float *anchors, int64_t anchor_bstride, const f
         const dim3 grid((unsigned)bx, (unsigned)((B + ipb - 1) / ipb));
         hipLaunchKernelGGL(iou_match_batch_kernel, grid, dim3(MATCH_BLOCK), 0, st, (const rn::f32x4 *)anchors,
                            (const rn::f32x4 *)gt_boxes, gt_off, B, ipb, A, fg_thr, bg_thr, matches, num_fg);
+    } else if (total_gt > 192 * (int64_t)B && A * (int64_t)B < ((int64_t)1 << 40)) {
+        // hundreds of GT boxes per image: split the GT axis too (see iou_match_chunk_kernel); z workgroups per anchor strip
+        int z = (int)((total_gt / B + CHUNK_TILE - 1) / CHUNK_TILE);
+        z = z < 2 ? 2 : (z > 16 ? 16 : z);
+        RN_HIP(hipMemsetAsync(matches, 0, sizeof(int64_t) * (size_t)B * (size_t)A, st));
+        const dim3 grid((unsigned)((A + MATCH_BLOCK * 4 - 1) / (MATCH_BLOCK * 4)), (unsigned)B, (unsigned)z);
+        hipLaunchKernelGGL(iou_match_chunk_kernel<4>, grid, dim3(MATCH_BLOCK), 0, st, (const rn::f32x4 *)anchors, anchor_bstride / 4,
+                           (const rn::f32x4 *)gt_boxes, gt_off, A, (unsigned long long *)matches);
+        RN_LAUNCH_CHECK();
+        const dim3 fgrid((unsigned)((A + FIN_BLOCK - 1) / FIN_BLOCK), (unsigned)B);
+        hipLaunchKernelGGL(iou_match_finalize_kernel, fgrid, dim3(FIN_BLOCK), 0, st, (const rn::f32x4 *)anchors, anchor_bstride / 4,
+                           (const rn::f32x4 *)gt_boxes, gt_off, A, fg_thr, bg_thr, matches, num_fg);
     } else if (total_gt >= 0 && total_gt <= 32 * (int64_t)B) {
         const dim3 grid((unsigned)((A + MATCH_BLOCK * 2 - 1) / (MATCH_BLOCK * 2)), (unsigned)B);
         hipLaunchKernelGGL(iou_match_tile_kernel<2>, grid, dim3(MATCH_BLOCK), 0, st, (const rn::f32x4 *)anchors, anchor_bstride / 4,
