@@ -127,10 +127,7 @@ int rn_loss_fwd_bwd_levels(const void *const *cls_levels, const void *const *box
                            const int64_t *matches, const int32_t *num_fg, const rn_loss_params *params,
                            float *out_loss, void *const *grad_cls_levels, void *const *grad_box_levels,
                            void *workspace, size_t workspace_bytes, void *stream);
-/* In-place mode: grad_cls_levels[l] == cls_levels[l] for EVERY level makes the class gradient overwrite the logits (a
- * training step never reads them again): half the footprint, and the stores hit lines the loads just brought in.
- * Returns RN_EUNSUPPORTED when the launch geometry cannot offer it (more than 256 anchor rows per wave); call again
- * with separate gradient tensors then.  The box tensors are never aliased. */
+/* grad_cls_levels[l] must not alias cls_levels[l] (RN_EINVAL): the repair phase re-reads logits the stream has passed. */
 /* Same call; additionally records the caller's HIP events (hipEvent_t, may be NULL) on `stream` immediately before and
  * after the streaming kernel -- the dominant kernel of the call -- so a benchmark can time that kernel alone (the
  * one-block finalize that follows is outside the pair). */

@@ -12,7 +12,6 @@ LIB_PATH = os.path.join(_HERE, "libretinanet_hip.so")
 
 RN_F32, RN_BF16, RN_F16 = 0, 1, 2
 RN_MAX_LEVELS = 8
-RN_EUNSUPPORTED = -4          # status code (include/retinanet_hip.h)
 
 
 class RnLevel(C.Structure):

@@ -64,7 +64,6 @@ struct LossArgs {
     rn_loss_params p;
     float alpha_pos;         // weight of t=1 elements: 1-alpha (Q2)
     float2 *part_stream;     // [blocks] (cls, reg) partial sums
-    int32_t inplace;         // grad_cls aliases cls: the gradient overwrites the logits (training: nothing reads them again)
 };
 
 // ---- background element (t = 0) ------------------------------------------------------
@@ -180,7 +179,7 @@ __device__ __forceinline__ float image_gmul(const LossArgs &a, const int b)
 // gradient / regression term of the rows whose first element it owns.  Both phases write from one
 // wave, so program order gives the right final value without any cross-wave ordering.
 constexpr int PREF_CHUNKS = 4;      // 64-row chunks of `matches` prefetched before the stream (256 rows)
-constexpr int IGN_U = 8;            // independent element loads per lane per round in the ignored-row repair
+constexpr int IGN_U = 4;            // independent element loads per lane per round in the ignored-row repair
 
 template <int DT, bool GAMMA2, bool WRITE_GRAD, int PF, int NT>
 __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs a)
@@ -188,8 +187,8 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
     typedef rn::dt<DT> D;
     constexpr int VEC = D::VEC;
     __shared__ float s_part[LOSS_WAVES][2];
-    __shared__ unsigned char s_ign_row[LOSS_WAVES][RN_WAVE];   // ignored rows of the current 64-row chunk (lane offsets)
-    __shared__ float s_ign_gm[LOSS_WAVES][RN_WAVE];            // their alpha/(max(nfg,1)*B)
+    __shared__ unsigned short s_ign_row[LOSS_WAVES][PREF_CHUNKS * RN_WAVE];   // ignored rows of the wave's range (offsets from its first row)
+    __shared__ float s_ign_gm[LOSS_WAVES][PREF_CHUNKS * RN_WAVE];            // their alpha/(max(nfg,1)*B)
 
     const int lane = threadIdx.x & (RN_WAVE - 1);
     // readfirstlane: the wave index and everything derived from it (ranges, trip counts, image
@@ -222,63 +221,22 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
         const int64_t row_lo = e_beg / K;                        // rows are local to the level: r = b * A_l + a_local
         const int64_t row_hi = e_end > e_beg ? (e_end - 1) / K : row_lo - 1;     // inclusive
 
-        // prefetch this range's slice of `matches` (phase B input) so its latency hides under the stream
+        // this range's slice of `matches` (phase B input): loaded while the stream runs, right AFTER the first stream loads
+        // are issued (every cycle before those delays the whole wave)
         int pm[PREF_CHUNKS];
-        float px[PREF_CHUNKS];                                        // in-place mode: the logit of a matched row's positive element
-#pragma unroll
-        for (int c = 0; c < PREF_CHUNKS; ++c) {
-            const int64_t r = row_lo + c * RN_WAVE + lane;
-            int m = -1;
-            int b = 0;
-            if (r <= row_hi) {
-                b = (int)((uint32_t)r / (uint32_t)lv.A_l);
-                m = (int)a.matches[(int64_t)b * a.A + lv.base + (r - (int64_t)b * lv.A_l)];
-            }
-            pm[c] = m;
-            px[c] = 0.0f;
-        }
-        if (a.inplace) {
-            // The gradient is about to overwrite the logits, and phase B wants two things from them.  (1) The positive
-            // element of every matched row: read it now (one element per lane and chunk).  (2) Ignored rows must end with
-            // zero loss and zero gradient: overwrite their logits with -inf here -- the stream then computes exactly 0 for
-            // both (sigmoid(-80)^2 underflows, as for dead classes) and phase B has nothing left to repair.
-            // (The host only selects this mode when a wave's rows fit the PREF_CHUNKS * 64 prefetched matches.)
+        auto load_matches = [&]() {
 #pragma unroll
             for (int c = 0; c < PREF_CHUNKS; ++c) {
                 const int64_t r = row_lo + c * RN_WAVE + lane;
-                bool ignored = false;
-                if (r <= row_hi && pm[c] != -1) {
+                int m = -1;
+                if (r <= row_hi) {
                     const int b = (int)((uint32_t)r / (uint32_t)lv.A_l);
-                    const int t0 = a.gt_off[b], T = a.gt_off[b + 1] - t0;
-                    if (T > 0) {
-                        if (pm[c] >= 0) {
-                            const int code = (int)a.gt_labels[t0 + pm[c]] - 1;
-                            const int64_t e_pos = r * K + code;
-                            if (code >= 0 && code < K && e_pos >= e_beg && e_pos < e_end) px[c] = D::ld(lv.cls, e_pos);
-                        } else {
-                            ignored = true;
-                        }
-                    }
+                    m = (int)a.matches[(int64_t)b * a.A + lv.base + (r - (int64_t)b * lv.A_l)];
                 }
-                const unsigned long long imask = __ballot(ignored);
-                if (imask) {                                              // wave-uniform
-                    if (ignored) s_ign_row[wave][__popcll(imask & ((1ull << lane) - 1ull))] = (unsigned char)lane;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const int total = __popcll(imask) * K;
-                    const int64_t c0 = row_lo + c * RN_WAVE;
-                    for (int t = lane; t < total; t += RN_WAVE) {
-                        const int j = t / K, k = t - j * K;
-                        const int64_t e = (c0 + s_ign_row[wave][j]) * K + k;
-                        if (e >= e_beg && e < e_end) D::st(const_cast<void *>(lv.cls), e, -__builtin_inff());
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
+                pm[c] = m;
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the -inf stores land before the stream's loads of this wave
-        }
+        };
+        if (v_beg >= v_end) load_matches();
 
         if (v_beg < v_end) {
             int b = (int)(e_beg / lv.per_image);                      // image of the first element
@@ -290,6 +248,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
             rn::u32x4 q[PF];
 #pragma unroll
             for (int u = 0; u < PF; ++u) q[u] = (NT & 1) ? __builtin_nontemporal_load(&src[min(v_beg + u * RN_WAVE + lane, last)]) : src[min(v_beg + u * RN_WAVE + lane, last)];
+            load_matches();
 
             int64_t v0 = v_beg;
             for (int64_t gi = 0; gi < groups; ++gi, v0 += PF * RN_WAVE) {
@@ -315,19 +274,35 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                     }
                     acc += (double)acc_g * (double)gmul;
                 } else {                                                 // an image seam crosses this group (<= B-1 times per level)
+                    // The waves that meet a seam must not fall behind (the whole chip waits for the last wave): when only ONE
+                    // seam lies in the group -- always, unless an image of this level is shorter than a group -- every element
+                    // is "image b before element e_seam, image b + 1 from it on": two wave-uniform multipliers and a compare.
+                    const int64_t e_seam = (int64_t)(b + 1) * lv.per_image;
+                    const bool one_seam = lv.per_image >= (int64_t)PF * RN_WAVE * VEC && b + 1 < a.B;
+                    const float gmul_next = one_seam ? image_gmul(a, b + 1) : 0.0f;
 #pragma unroll 1
                     for (int u = 0; u < PF; ++u) {
                         const int64_t v = v0 + u * RN_WAVE + lane;
                         float x[VEC], g[VEC];
                         D::unpack(src[v], x);
+                        // elements [0, k) of this vector belong to image b, the rest to image b + 1
+                        const int k = one_seam ? (int)max(min(e_seam - v * VEC, (int64_t)VEC), (int64_t)0) : VEC;
+                        float s_all = 0.0f, s_hi = 0.0f;
 #pragma unroll
                         for (int j = 0; j < VEC; ++j) {
-                            const float gm = image_gmul(a, (int)((v * VEC + j) / lv.per_image));
                             float wb, gg;
                             bg_elem<GAMMA2>(x[j], a.p, wb, gg);
-                            acc += (double)wb * (double)gm;
-                            g[j] = gg * gm;
+                            if (one_seam) {
+                                s_all += wb;
+                                s_hi += j >= k ? wb : 0.0f;
+                                g[j] = gg * (j >= k ? gmul_next : gmul);
+                            } else {
+                                const float gm = image_gmul(a, (int)((v * VEC + j) / lv.per_image));
+                                acc += (double)wb * (double)gm;
+                                g[j] = gg * gm;
+                            }
                         }
+                        if (one_seam) acc += (double)s_all * (double)gmul + (double)s_hi * ((double)gmul_next - (double)gmul);
                         if (WRITE_GRAD) dst[v] = D::pack(g);
                     }
                     b = (int)(((v0 + PF * RN_WAVE) * VEC) / lv.per_image);
@@ -367,20 +342,136 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
         }
 
         // ---- Phase B: repair this range's special elements; box gradients of the rows it owns --------
-        for (int64_t c0 = row_lo, c = 0; c0 <= row_hi; c0 += RN_WAVE, ++c) {
+        // The first PREF_CHUNKS * 64 rows (all of them at the headline shapes) go through a STAGED pass: every level of the
+        // dependent loads (per-image scalars -> label / GT box / anchor / prediction -> positive logit) is issued for all
+        // chunks at once, so the tail of the kernel is 3 memory round trips instead of ~4 per chunk (18 us -> a few us: the
+        // whole chip idles behind the slowest wave here).  Rows past that (small K, few waves) take the chunk loop below.
+        {
+            int t0s[PREF_CHUNKS], Ts[PREF_CHUNKS], nfs[PREF_CHUNKS];
+            bool special[PREF_CHUNKS], own[PREF_CHUNKS];
+            auto row_of = [&](const int c) { return row_lo + c * RN_WAVE + lane; };
+            // stage 1: per-image scalars of the special rows
+#pragma unroll
+            for (int c = 0; c < PREF_CHUNKS; ++c) {
+                const int64_t r = row_of(c);
+                const bool valid = r <= row_hi;
+                own[c] = valid && r * K >= e_beg;
+                special[c] = valid && pm[c] != -1;
+                t0s[c] = 0; Ts[c] = 0; nfs[c] = 1;
+                if (special[c]) {
+                    const int b = (int)((uint32_t)r / (uint32_t)lv.A_l);
+                    t0s[c] = a.gt_off[b]; Ts[c] = a.gt_off[b + 1]; nfs[c] = a.num_fg[b];
+                }
+            }
+            // stage 2: labels of matched rows
+            int code[PREF_CHUNKS];
+            bool matched[PREF_CHUNKS], ign[PREF_CHUNKS];
+            float scale[PREF_CHUNKS];
+#pragma unroll
+            for (int c = 0; c < PREF_CHUNKS; ++c) {
+                const bool live = special[c] && (Ts[c] - t0s[c]) > 0;  // images without GT: phase A already wrote zeros
+                matched[c] = live && pm[c] >= 0;
+                ign[c] = live && pm[c] < 0;
+                scale[c] = (1.0f / (float)(nfs[c] > 1 ? nfs[c] : 1)) * a.inv_B;
+                code[c] = -1;
+                if (matched[c]) code[c] = (int)a.gt_labels[t0s[c] + pm[c]] - 1;
+            }
+            // stage 3: the positive logit
+            float xp[PREF_CHUNKS];
+            bool pos_ok[PREF_CHUNKS];
+#pragma unroll
+            for (int c = 0; c < PREF_CHUNKS; ++c) {
+                const int64_t e_pos = row_of(c) * K + code[c];
+                pos_ok[c] = matched[c] && code[c] >= 0 && code[c] < K && e_pos >= e_beg && e_pos < e_end;
+                xp[c] = 0.0f;
+                if (pos_ok[c]) xp[c] = D::ld(lv.cls, e_pos);
+            }
+            // stage 4: the positive element's loss and gradient
+#pragma unroll
+            for (int c = 0; c < PREF_CHUNKS; ++c) {
+                if (pos_ok[c]) {                                          // matched row: only the positive element differs from what phase A did
+                    float wb, gbg, l, gr;
+                    bg_elem<GAMMA2>(xp[c], a.p, wb, gbg);
+                    focal_elem<GAMMA2>(xp[c], true, a, l, gr);
+                    acc += (double)l * (double)scale[c] - (double)wb * (double)(a.p.alpha * scale[c]);
+                    if (WRITE_GRAD) D::st(lv.gcls, row_of(c) * K + code[c], gr * scale[c]);
+                }
+            }
+            // stage 5: box gradients of the rows this wave owns -- zeros, except for matched rows (chunks with one: rare)
+#pragma unroll
+            for (int c = 0; c < PREF_CHUNKS; ++c) {
+                float gb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                const bool mo = matched[c] && own[c];
+                if (__any(mo)) {                                          // wave-uniform
+                    if (mo) {
+                        const int64_t r = row_of(c);
+                        const int b = (int)((uint32_t)r / (uint32_t)lv.A_l);
+                        float pred[4];
+                        box4<DT>::ld(lv.box, r, pred);
+                        const float l = reg_row(a.gt_boxes[t0s[c] + pm[c]],
+                                                a.anchors[(int64_t)b * a.anchor_bstride4 + lv.base + (r - (int64_t)b * lv.A_l)], pred, a.p, gb);
+                        reg += l * scale[c];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) gb[j] *= scale[c];
+                    }
+                }
+                if (WRITE_GRAD && own[c]) box4<DT>::st(lv.gbox, row_of(c), gb);
+            }
+            // ignored rows: remove their background contribution and zero their gradient.  The rows of all
+            // chunks are compacted into one wave-private LDS list and their elements spread over all lanes, IGN_U independent
+            // loads per lane per round (elements outside this wave's range are masked).
+            int n_ign = 0;
+#pragma unroll
+            for (int c = 0; c < PREF_CHUNKS; ++c) {
+                const unsigned long long imask = __ballot(ign[c]);
+                if (ign[c]) {
+                    const int pos = n_ign + __popcll(imask & ((1ull << lane) - 1ull));
+                    s_ign_row[wave][pos] = (unsigned short)(c * RN_WAVE + lane);
+                    s_ign_gm[wave][pos] = a.p.alpha * scale[c];
+                }
+                n_ign += __popcll(imask);
+            }
+            if (n_ign) {                                                   // wave-uniform
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int total = n_ign * K;
+                for (int t0 = 0; t0 < total; t0 += RN_WAVE * IGN_U) {
+                    float xs[IGN_U], gms[IGN_U];
+                    int64_t es[IGN_U];
+                    bool ok[IGN_U];
+#pragma unroll
+                    for (int u = 0; u < IGN_U; ++u) {
+                        const int t = min(t0 + u * RN_WAVE + lane, total - 1);
+                        const int j = t / K, k = t - j * K;
+                        es[u] = (row_lo + s_ign_row[wave][j]) * K + k;
+                        gms[u] = s_ign_gm[wave][j];
+                        ok[u] = (t0 + u * RN_WAVE + lane < total) && es[u] >= e_beg && es[u] < e_end;
+                        xs[u] = D::ld(lv.cls, es[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < IGN_U; ++u) {
+                        if (ok[u]) {
+                            float wb, gbg;
+                            bg_elem<GAMMA2>(xs[u], a.p, wb, gbg);
+                            acc -= (double)wb * (double)gms[u];
+                            if (WRITE_GRAD) D::st(lv.gcls, es[u], 0.0f);
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        // rows past the staged pass
+        for (int64_t c0 = row_lo + PREF_CHUNKS * RN_WAVE, c = PREF_CHUNKS; c0 <= row_hi; c0 += RN_WAVE, ++c) {
             const int64_t r = c0 + lane;
             bool ignored = false;
             float ign_gm = 0.0f;
             if (r <= row_hi) {
                 const int b = (int)((uint32_t)r / (uint32_t)lv.A_l);
                 const int64_t ag = lv.base + (r - (int64_t)b * lv.A_l);   // anchor index within the image
-                int64_t m = -1;
-                if (c < PREF_CHUNKS) {
-#pragma unroll
-                    for (int k = 0; k < PREF_CHUNKS; ++k) if (c == k) m = pm[k];
-                } else {
-                    m = a.matches[(int64_t)b * a.A + ag];
-                }
+                const int64_t m = a.matches[(int64_t)b * a.A + ag];
                 const int64_t r_e0 = r * K;
                 const bool own_row = r_e0 >= e_beg;                       // the row's first element is ours
                 float gb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -396,13 +487,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                             const int64_t e_pos = r_e0 + code;
                             if (code >= 0 && code < K && e_pos >= e_beg && e_pos < e_end) {
                                 // matched row: only the positive element differs from what phase A did
-                                float x = 0.0f;
-                                if (a.inplace) {
-#pragma unroll
-                                    for (int k = 0; k < PREF_CHUNKS; ++k) if (c == k) x = px[k];
-                                } else {
-                                    x = D::ld(lv.cls, e_pos);
-                                }
+                                const float x = D::ld(lv.cls, e_pos);
                                 float wb, gbg, l, gr;
                                 bg_elem<GAMMA2>(x, a.p, wb, gbg);
                                 focal_elem<GAMMA2>(x, true, a, l, gr);
@@ -417,7 +502,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) gb[j] *= scale;
                             }
-                        } else if (!a.inplace) {                       // (in-place mode neutralised ignored rows before the stream)
+                        } else {
                             ignored = true;
                             ign_gm = gmul;
                         }
@@ -468,7 +553,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
         }
     }
 
-    float accf = (float)rn::wave_sum_d(acc);
+    const float accf = (float)rn::wave_sum_d(acc);
     reg = rn::wave_sum(reg);
     if (lane == 0) { s_part[wave][0] = accf; s_part[wave][1] = reg; }
     __syncthreads();
@@ -480,7 +565,6 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
     }
 }
 
-// One block adds the per-block partial sums in double in a fixed order (deterministic; no float atomics).
 __global__ __launch_bounds__(1024) void loss_finalize_kernel(const float2 *__restrict__ partials, const int n,
                                                              float *__restrict__ out)
 {
@@ -548,11 +632,12 @@ int launch_stream(StreamT stream_k, LossArgs &a, int vec, hipStream_t st, int *n
     const int64_t nvec = a.total_vec;
     const int64_t waves = (int64_t)res * LOSS_WAVES;
     int64_t vpw = (nvec + waves - 1) / waves;
-    vpw = ((vpw + RN_WAVE - 1) / RN_WAVE) * RN_WAVE;
-    if (vpw < RN_WAVE) vpw = RN_WAVE;
+    // whole groups of 2 wave-iterations: the < 1 group leftover of a range goes through a slow per-element path, and one
+    // slow wave-iteration at the end of EVERY wave is a tail the whole chip waits for
+    vpw = ((vpw + 2 * RN_WAVE - 1) / (2 * RN_WAVE)) * (2 * RN_WAVE);
+    if (vpw < 2 * RN_WAVE) vpw = 2 * RN_WAVE;
     a.vec_per_wave = vpw;
-    // in-place mode needs every row of a wave's range among the PREF_CHUNKS * 64 rows whose matches are prefetched
-    if (a.inplace && (vpw * vec) / a.K + 3 > PREF_CHUNKS * RN_WAVE) return RN_EUNSUPPORTED;
+    (void)vec;
     int64_t need = ((nvec + vpw - 1) / vpw + LOSS_WAVES - 1) / LOSS_WAVES;
     if (need < 1) need = 1;
     if (g_prof.start) RN_HIP(hipEventRecord(g_prof.start, st));
@@ -568,12 +653,17 @@ int launch_loss(LossArgs &a, bool gamma2, bool wg, hipStream_t st, int *ns)
 {
     constexpr int VEC = rn::dt<DT>::VEC;
     // PF = 2 groups of loads in flight, non-temporal loads: the best of the (2|4|8) x (nt|plain) sweep on MI355X
+    int n_stream = 0, rc;
     if (gamma2) {
-        if (wg) return launch_stream(loss_stream_kernel<DT, true, true, 2, 1>, a, VEC, st, ns);
-        return launch_stream(loss_stream_kernel<DT, true, false, 2, 1>, a, VEC, st, ns);
+        if (wg) rc = launch_stream(loss_stream_kernel<DT, true, true, 2, 1>, a, VEC, st, &n_stream);
+        else rc = launch_stream(loss_stream_kernel<DT, true, false, 2, 1>, a, VEC, st, &n_stream);
+    } else {
+        if (wg) rc = launch_stream(loss_stream_kernel<DT, false, true, 2, 1>, a, VEC, st, &n_stream);
+        else rc = launch_stream(loss_stream_kernel<DT, false, false, 2, 1>, a, VEC, st, &n_stream);
     }
-    if (wg) return launch_stream(loss_stream_kernel<DT, false, true, 2, 1>, a, VEC, st, ns);
-    return launch_stream(loss_stream_kernel<DT, false, false, 2, 1>, a, VEC, st, ns);
+    if (rc != RN_OK) return rc;
+    *ns = n_stream;
+    return RN_OK;
 }
 
 }  // namespace
@@ -639,13 +729,9 @@ RN_API int rn_loss_fwd_bwd_levels(const void *const *cls_levels, const void *con
     a.p = *params;
     a.alpha_pos = (float)(1.0 - (double)params->alpha);
     a.part_stream = (float2 *)workspace;
-    a.inplace = 0;
-    if (grad_cls_levels) {                                       // in-place: the gradient of every level overwrites its logits
-        int same = 0;
-        for (int l = 0; l < L; ++l) same += grad_cls_levels[l] == cls_levels[l] ? 1 : 0;
-        if (same != 0 && same != L) return RN_EINVAL;
-        a.inplace = same == L ? 1 : 0;
-    }
+    if (grad_cls_levels)
+        for (int l = 0; l < L; ++l)
+            if (grad_cls_levels[l] == cls_levels[l]) return RN_EINVAL;      // the repair phase re-reads logits the stream has passed
     const bool gamma2 = params->gamma == 2.0f;
     const bool wg = grad_cls_levels != nullptr;
     hipStream_t st = (hipStream_t)stream;

@@ -180,8 +180,6 @@ class RetinaNetHead(nn.Module):
         self.pair_towers = mode == "pair"
         # class-output conv on the hand-written MFMA kernel with dense 9*K-channel output (0: MIOpen on 9*ceil8(K) channels)
         self.mfma_cls_output = os.environ.get("RN_CLS_OUTPUT", "mfma") != "miopen"
-        # training forward: the class gradient overwrites the logits inside the loss kernel (RN_INPLACE_LOSS=0: separate tensor)
-        self.inplace_loss = os.environ.get("RN_INPLACE_LOSS", "1") != "0"
 
     def compute_loss(self, targets: List[Dict[str, Tensor]], outputs: Dict[str, Tensor],
                      anchors: List[Tensor]) -> Dict[str, Tensor]:
@@ -220,15 +218,12 @@ class RetinaNetHead(nn.Module):
             box_levels = [_to_anchor_major(t, 4) for t in biasact.unpack_levels(cv, box_c)]
             if mfma and self.mfma_cls_output and biasact.cls_output_conv_fusable(cls_c, ch.class_subnet_output, cv):
                 # class-output conv straight from the canvas to dense per-level logits [N, h*w*A, K]: exactly A*K channels
-                # (no dead classes for the loss kernel to stream) and no unpack copy of the 256-channel tower output.
-                # "owned_logits": fresh tensors nobody else holds, whose producer's backward does not need them -- the loss
-                # kernel may write their gradient over them (compute_loss_levels)
+                # (no dead classes for the loss kernel to stream) and no unpack copy of the 256-channel tower output
                 return {"cls_levels": biasact.cls_output_conv(cls_c, ch.class_subnet_output, cv, ch.num_classes),
-                        "bbox_levels": box_levels, "owned_logits": True}
+                        "bbox_levels": box_levels}
             cls_t = biasact.unpack_levels(cv, cls_c)
             return {"cls_levels": ch.output_levels(cls_t, pad_classes), "bbox_levels": box_levels}
         return {"cls_levels": ch.forward_levels(xb, pad_classes), "bbox_levels": rh.forward_levels(xb)}
 
     def compute_loss_levels(self, targets, outputs: Dict[str, List[Tensor]], anchors) -> Dict[str, Tensor]:
-        consume = bool(outputs.get("owned_logits")) and self.inplace_loss and torch.is_grad_enabled()
-        return self.losses.forward_levels(targets, outputs["cls_levels"], outputs["bbox_levels"], anchors, consume_logits=consume)
+        return self.losses.forward_levels(targets, outputs["cls_levels"], outputs["bbox_levels"], anchors)

@@ -51,15 +51,13 @@ class _FusedDenseHeadLossLevels(torch.autograd.Function):
     """Per-level head outputs (cls_0..cls_{L-1}, box_0..box_{L-1}) -> f32[2]; no concatenation."""
 
     @staticmethod
-    def forward(ctx, anchors, gt_boxes, gt_labels, gt_off, params, fg_thr, bg_thr, L, inplace, *levels):
+    def forward(ctx, anchors, gt_boxes, gt_labels, gt_off, params, fg_thr, bg_thr, L, *levels):
         cls_levels, box_levels = levels[:L], levels[L:]
         B = cls_levels[0].shape[0]
         matches, num_fg = ops.iou_match(anchors, gt_boxes, gt_off, B, fg_thr, bg_thr)
-        want_grad = any(ctx.needs_input_grad[9:])
-        # inplace: the caller owns the logits and never reads them again -- their gradient overwrites them (K3's stores hit the
-        # lines its loads just brought in, and the step keeps one 290 MB tensor instead of two at the headline shape)
+        want_grad = any(ctx.needs_input_grad[8:])
         loss, gcls, gbox = ops.loss_fwd_bwd_levels(cls_levels, box_levels, anchors, gt_boxes, gt_labels, gt_off, matches,
-                                                   num_fg, params, want_grad, inplace=bool(inplace) and want_grad)
+                                                   num_fg, params, want_grad)
         ctx.grads = (gcls, gbox)
         ctx.meta = [(c.shape, c.dtype) for c in cls_levels] + [(b.shape, b.dtype) for b in box_levels]
         return loss
@@ -77,7 +75,7 @@ class _FusedDenseHeadLossLevels(torch.autograd.Function):
         for t in gbox:
             ops.scale_inplace(t, g[1:2])
         outs = [t.view(shape) if t.dtype == dt else t.to(dt).view(shape) for t, (shape, dt) in zip(list(gcls) + list(gbox), ctx.meta)]
-        return (None,) * 9 + tuple(outs)
+        return (None,) * 8 + tuple(outs)
 
 
 def _stack_anchors(anchors) -> Tensor:
@@ -133,11 +131,9 @@ class RetinaNetLosses(nn.Module):
                                          self._params(), IOU_THRESHOLDS_FOREGROUND, IOU_THRESHOLDS_BACKGROUND)
 
     def forward_levels(self, targets: List[Dict[str, Tensor]], cls_levels: Sequence[Tensor], box_levels: Sequence[Tensor],
-                       anchors, consume_logits: bool = False) -> Dict[str, Tensor]:
+                       anchors) -> Dict[str, Tensor]:
         """Same result as ``forward`` on ``torch.cat(levels, dim=1)``, without materialising the cat
-        (the loss kernel reads the per-level conv outputs where they are).
-        ``consume_logits``: the caller hands over ``cls_levels`` -- the loss kernel may overwrite them with their gradient
-        (their values are undefined afterwards); only for callers whose logits have no other reader."""
+        (the loss kernel reads the per-level conv outputs where they are)."""
         dev = cls_levels[0].device
         boxes, labels = [t["boxes"] for t in targets], [t["labels"] for t in targets]
         counts = [int(b.reshape(-1, 4).shape[0]) for b in boxes]
@@ -146,7 +142,7 @@ class RetinaNetLosses(nn.Module):
         gt_off = ops.gt_offsets(counts, dev)
         out = _FusedDenseHeadLossLevels.apply(_stack_anchors(anchors), gt_boxes, gt_labels, gt_off, self._params(),
                                               IOU_THRESHOLDS_FOREGROUND, IOU_THRESHOLDS_BACKGROUND, len(cls_levels),
-                                              bool(consume_logits), *cls_levels, *box_levels)
+                                              *cls_levels, *box_levels)
         return {"classification_loss": out[0], "regression_loss": out[1]}
 
     def calc_loss(self, anchors: Tensor, clas_pred: Tensor, bbox_pred: Tensor, clas_tgt: Tensor,

@@ -185,10 +185,9 @@ def loss_fwd_bwd(cls: Tensor, box: Tensor, anchors: Tensor, gt_boxes: Tensor, gt
 
 def loss_fwd_bwd_levels(cls_levels: Sequence[Tensor], box_levels: Sequence[Tensor], anchors: Tensor, gt_boxes: Tensor,
                         gt_labels: Tensor, gt_off: Tensor, matches: Tensor, num_fg: Tensor, params: RnLossParams,
-                        want_grad: bool = True, inplace: bool = False):
+                        want_grad: bool = True):
     """K3 on per-level head outputs (no concatenation): cls_levels[l] [B,A_l,K], box_levels[l] [B,A_l,4].
-    -> (loss f32[2], [grad_cls_l], [grad_box_l]).  ``inplace``: the class gradients OVERWRITE ``cls_levels`` (the returned
-    gradient tensors alias them) -- for callers that own the logits and never read them again (the training step)."""
+    -> (loss f32[2], [grad_cls_l], [grad_box_l])."""
     L = len(cls_levels)
     if L == 0 or L > _lib.RN_MAX_LEVELS or len(box_levels) != L:
         raise ValueError("need 1..8 levels of (cls, box) outputs")
@@ -206,8 +205,7 @@ def loss_fwd_bwd_levels(cls_levels: Sequence[Tensor], box_levels: Sequence[Tenso
     gt_boxes = _c(gt_boxes.float()).reshape(-1, 4)
     gt_labels = _c(gt_labels.to(torch.int64)).reshape(-1)
     out = torch.empty((2,), dtype=torch.float32, device=dev)
-    inplace = bool(inplace and want_grad)
-    gcls = ([c.detach() for c in cls_levels] if inplace else [torch.empty_like(c) for c in cls_levels]) if want_grad else None
+    gcls = [torch.empty_like(c) for c in cls_levels] if want_grad else None
     gbox = [torch.empty_like(b) for b in box_levels] if want_grad else None
     ws_bytes = lib.rn_loss_workspace_bytes(B, A, K)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
@@ -218,19 +216,13 @@ def loss_fwd_bwd_levels(cls_levels: Sequence[Tensor], box_levels: Sequence[Tenso
     if _TIMERS is not None:
         k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         k0.record(torch.cuda.current_stream(dev)); k1.record(torch.cuda.current_stream(dev))      # creates the handles
-    def call():
-        return lib.rn_loss_fwd_bwd_levels_timed(arr(cls_levels), arr(box_levels), (C.c_int64 * L)(*counts), L, _dtype_code(cls_levels[0]),
+    with torch.cuda.device(dev), _timed("loss_fwd_bwd" if want_grad else "loss_fwd", dev):
+        check(lib.rn_loss_fwd_bwd_levels_timed(arr(cls_levels), arr(box_levels), (C.c_int64 * L)(*counts), L, _dtype_code(cls_levels[0]),
                                                 B, K, _ptr(anchors), bstride, _ptr(gt_boxes), _ptr(gt_labels), _ptr(gt_off),
                                                 _ptr(matches), _ptr(num_fg), C.byref(params), _ptr(out),
                                                 arr(gcls) if want_grad else None, arr(gbox) if want_grad else None,
                                                 _ptr(ws), ws_bytes, _stream(dev), k0.cuda_event if k0 else None,
-                                                k1.cuda_event if k1 else None)
-    with torch.cuda.device(dev), _timed("loss_fwd_bwd" if want_grad else "loss_fwd", dev):
-        status = call()
-        if inplace and status == _lib.RN_EUNSUPPORTED:      # launch geometry cannot do it in place: separate gradient tensors
-            gcls = [torch.empty_like(c) for c in cls_levels]
-            status = call()
-        check(status, "rn_loss_fwd_bwd_levels_timed")
+                                                k1.cuda_event if k1 else None), "rn_loss_fwd_bwd_levels_timed")
     if k0 is not None:
         _TIMERS.setdefault("loss_stream_kernel" if want_grad else "loss_stream_kernel_fwd", []).append((k0, k1))
     return out, gcls, gbox
