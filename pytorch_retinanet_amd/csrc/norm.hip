@@ -16,12 +16,13 @@
 // block's rows, LDS tree over the block's row lanes, one partial per block, combined in double by a
 // per-channel kernel (deterministic; no float atomics).  Requires C % 8 == 0.
 #include "rn_common.hpp"
+#include <cstdlib>
 
 namespace {
 
 constexpr int BN_BLOCK = 256;
 constexpr int BN_MAX_BLOCKS = 512;
-constexpr int FIN_CH = 16;                // channels per block of the per-channel kernels
+constexpr int FIN_CH = 8;                 // channels per block of the per-channel kernels
 constexpr int FIN_LANES = 256 / FIN_CH;    // threads that split the partial sums of one channel
 
 template <int DT> struct vec8;          // 8 consecutive channels <-> float[8]
@@ -57,58 +58,119 @@ __device__ __forceinline__ Split split_of(const int C)
     return s;
 }
 
+// The BN reduction kernels also split the CHANNELS over blockIdx.y (gridDim.y slabs of C8 / gridDim.y channel groups): a
+// layer with few rows and many channels (layer3 / layer4: 8 400 - 33 600 rows of 2 - 4 KiB) gets enough blocks to fill the
+// chip without more per-block partials than the per-channel kernel wants to read.  Thread = (local group lg, row lane rl).
+struct Slab { int C8, Cs8, cg0, lanes, groups_per_thread; };
+__device__ __forceinline__ Slab slab_of(const int C)
+{
+    Slab s;
+    s.C8 = C / 8;
+    s.Cs8 = s.C8 / (int)gridDim.y;
+    s.cg0 = (int)blockIdx.y * s.Cs8;
+    if (s.Cs8 >= BN_BLOCK) { s.lanes = 1; s.groups_per_thread = (s.Cs8 + BN_BLOCK - 1) / BN_BLOCK; }
+    else { s.lanes = BN_BLOCK / s.Cs8; s.groups_per_thread = 1; }
+    return s;
+}
+// block totals of the slab's channels -> partial[blockIdx.x][2][C]   (s, q: this thread's 8-channel sums)
+__device__ __forceinline__ void slab_reduce(const Slab &sp, const int C, const int lg, const int rl, const bool valid, const float (&s)[8],
+                                            const float (&q)[8], float *smem, float *__restrict__ partial)
+{
+    const int Cs = sp.Cs8 * 8;
+    if (sp.lanes > 1) {
+        if (valid) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { smem[(rl * 2 + 0) * Cs + lg * 8 + j] = s[j]; smem[(rl * 2 + 1) * Cs + lg * 8 + j] = q[j]; }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < 2 * Cs; c += BN_BLOCK) {          // c indexes [2][Cs]
+            float t = 0.0f;
+            for (int l = 0; l < sp.lanes; ++l) t += smem[l * 2 * Cs + c];
+            const int which = c >= Cs ? 1 : 0;
+            partial[((int64_t)blockIdx.x * 2 + which) * C + sp.cg0 * 8 + (c - which * Cs)] = t;
+        }
+    } else if (valid) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            partial[(int64_t)blockIdx.x * 2 * C + (sp.cg0 + lg) * 8 + j] = s[j];
+            partial[(int64_t)blockIdx.x * 2 * C + C + (sp.cg0 + lg) * 8 + j] = q[j];
+        }
+    }
+}
+
+
+// Row traversal of the two reduction kernels (the per-thread sequence of rows; every row is visited once whatever the
+// order, and the per-block partials are combined in a fixed order, so each ORDER is deterministic).
+//   0: blocks own contiguous row ranges, walked front to back
+//   1: sweep -- all blocks advance through the tensor together, front to back (the order the apply kernels use)
+//   2: sweep, back to front: the rows the producer wrote last are read first, and the apply kernel that follows finds the
+//      front of the tensor -- read last here -- in the Infinity Cache
+struct RowWalk {
+    int64_t base, step, n;          // row(k) = base + k * step, k = 0 .. n-1
+    __device__ __forceinline__ int64_t row(const int64_t k) const { return base + k * step; }
+};
+__device__ __forceinline__ RowWalk row_walk(const int order, const int64_t M, const int lanes, const int rl)
+{
+    RowWalk w;
+    const int64_t G = gridDim.x, b = blockIdx.x;
+    if (order == 0) {
+        const int64_t rows_per_block = (M + G - 1) / G;
+        const int64_t r0 = b * rows_per_block, r1 = min(r0 + rows_per_block, M);
+        w.base = r0 + rl; w.step = lanes;
+        w.n = r1 > w.base ? (r1 - w.base + lanes - 1) / lanes : 0;
+    } else {
+        const int64_t first = b * lanes + rl, stride = G * lanes;
+        w.n = M > first ? (M - first + stride - 1) / stride : 0;
+        if (order == 1) { w.base = first; w.step = stride; }
+        else { w.base = first + (w.n - 1) * stride; w.step = -stride; }
+    }
+    return w;
+}
+
+// Default 2 (in-step A/B on two boxes, 4 pairs: +0.6 ... +1.3 % images/s over order 0, order 1 in between; choosing by tensor
+// size was no better); RN_BN_ORDER=0/1/2 forces one order.
+inline int bn_order()
+{
+    static const int order = [] { const char *e = getenv("RN_BN_ORDER"); return e ? atoi(e) : 2; }();
+    return order;
+}
+
 // ---------------------------------------------------------------- forward statistics
 // partial[block][0][c] = sum x, partial[block][1][c] = sum x^2 over the block's rows
 template <int DT>
 __global__ __launch_bounds__(BN_BLOCK) void bn_stats_partial_kernel(const void *__restrict__ x, const int64_t M, const int C,
-                                                                    float *__restrict__ partial)
+                                                                    float *__restrict__ partial, const int order)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];      // [lanes][2][C]  (only when lanes > 1)
-    const Split sp = split_of(C);
-    const int64_t rows_per_block = (M + gridDim.x - 1) / gridDim.x;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, M);
+    const Slab sp = slab_of(C);
     for (int gi = 0; gi < sp.groups_per_thread; ++gi) {
-        const int cg = (sp.lanes > 1) ? (int)(threadIdx.x % sp.C8) : (int)threadIdx.x + gi * BN_BLOCK;
-        const int rl = (sp.lanes > 1) ? (int)(threadIdx.x / sp.C8) : 0;
+        const int lg = (sp.lanes > 1) ? (int)(threadIdx.x % sp.Cs8) : (int)threadIdx.x + gi * BN_BLOCK;
+        const int rl = (sp.lanes > 1) ? (int)(threadIdx.x / sp.Cs8) : 0;
+        const int cg = sp.cg0 + lg;
+        const bool valid = lg < sp.Cs8 && rl < sp.lanes;
         float s[8], q[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
-        if (cg < sp.C8 && rl < sp.lanes) {
-            int64_t r = r0 + rl;
-            for (; r + 3 * sp.lanes < r1; r += 4 * sp.lanes) {          // 4 independent 16-byte loads in flight per thread
+        if (valid) {
+            const RowWalk w = row_walk(order, M, sp.lanes, rl);
+            int64_t k = 0;
+            for (; k + 3 < w.n; k += 4) {                                // 4 independent 16-byte loads in flight per thread
                 float f[4][8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) vec8<DT>::ld(x, (r + u * sp.lanes) * sp.C8 + cg, f[u]);
+                for (int u = 0; u < 4; ++u) vec8<DT>::ld(x, w.row(k + u) * sp.C8 + cg, f[u]);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { s[j] += f[u][j]; q[j] = fmaf(f[u][j], f[u][j], q[j]); }
             }
-            for (; r < r1; r += sp.lanes) {
+            for (; k < w.n; ++k) {
                 float f[8];
-                vec8<DT>::ld(x, r * sp.C8 + cg, f);
+                vec8<DT>::ld(x, w.row(k) * sp.C8 + cg, f);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] = fmaf(f[j], f[j], q[j]); }
             }
         }
-        if (sp.lanes > 1) {
-            if (cg < sp.C8 && rl < sp.lanes) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { smem[(rl * 2 + 0) * C + cg * 8 + j] = s[j]; smem[(rl * 2 + 1) * C + cg * 8 + j] = q[j]; }
-            }
-            __syncthreads();
-            for (int c = threadIdx.x; c < 2 * C; c += BN_BLOCK) {      // c indexes [2][C]
-                float t = 0.0f;
-                for (int l = 0; l < sp.lanes; ++l) t += smem[l * 2 * C + c];
-                partial[(int64_t)blockIdx.x * 2 * C + c] = t;
-            }
-        } else if (cg < sp.C8) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                partial[(int64_t)blockIdx.x * 2 * C + cg * 8 + j] = s[j];
-                partial[(int64_t)blockIdx.x * 2 * C + C + cg * 8 + j] = q[j];
-            }
-        }
+        slab_reduce(sp, C, lg, rl, valid, s, q, smem, partial);
     }
 }
 
@@ -118,8 +180,17 @@ __device__ __forceinline__ void channel_totals(const float *__restrict__ partial
                                                const int ln, double (*sh)[FIN_LANES][FIN_CH], double &s, double &q)
 {
     double ls = 0.0, lq = 0.0;
-    if (c < C)
-        for (int b = ln; b < nblocks; b += FIN_LANES) { ls += (double)partial[(int64_t)b * 2 * C + c]; lq += (double)partial[(int64_t)b * 2 * C + C + c]; }
+    if (c < C) {
+        int b = ln;
+        for (; b + 3 * FIN_LANES < nblocks; b += 4 * FIN_LANES) {        // 8 independent loads in flight (the partials come from other XCDs' writes: misses)
+            float ps[4], pq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { ps[u] = partial[(int64_t)(b + u * FIN_LANES) * 2 * C + c]; pq[u] = partial[(int64_t)(b + u * FIN_LANES) * 2 * C + C + c]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { ls += (double)ps[u]; lq += (double)pq[u]; }
+        }
+        for (; b < nblocks; b += FIN_LANES) { ls += (double)partial[(int64_t)b * 2 * C + c]; lq += (double)partial[(int64_t)b * 2 * C + C + c]; }
+    }
     const int ch = threadIdx.x % FIN_CH;
     sh[0][ln][ch] = ls; sh[1][ln][ch] = lq;
     __syncthreads();
@@ -219,31 +290,32 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_partial_kernel(const void *__
                                                                   const void *__restrict__ x, const int64_t M, const int C,
                                                                   const float *__restrict__ save_mean, const float *__restrict__ save_invstd,
                                                                   const float *__restrict__ fwd_a, const float *__restrict__ fwd_b,
-                                                                  float *__restrict__ partial)
+                                                                  float *__restrict__ partial, const int order)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const Split sp = split_of(C);
-    const int64_t rows_per_block = (M + gridDim.x - 1) / gridDim.x;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, M);
+    const Slab sp = slab_of(C);
     for (int gi = 0; gi < sp.groups_per_thread; ++gi) {
-        const int cg = (sp.lanes > 1) ? (int)(threadIdx.x % sp.C8) : (int)threadIdx.x + gi * BN_BLOCK;
-        const int rl = (sp.lanes > 1) ? (int)(threadIdx.x / sp.C8) : 0;
+        const int lg = (sp.lanes > 1) ? (int)(threadIdx.x % sp.Cs8) : (int)threadIdx.x + gi * BN_BLOCK;
+        const int rl = (sp.lanes > 1) ? (int)(threadIdx.x / sp.Cs8) : 0;
+        const int cg = sp.cg0 + lg;
+        const bool valid = lg < sp.Cs8 && rl < sp.lanes;
         float s[8], q[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s[j] = 0.0f; q[j] = 0.0f; }
-        if (cg < sp.C8 && rl < sp.lanes) {
+        if (valid) {
             float mu[8], is[8], fa[8], fb[8];
             vec8<RN_F32>::ld(save_mean, cg, mu);
             vec8<RN_F32>::ld(save_invstd, cg, is);
             if (RELU == 2) { vec8<RN_F32>::ld(fwd_a, cg, fa); vec8<RN_F32>::ld(fwd_b, cg, fb); }
             const float alive = relu_alive_threshold<DT>();
-            int64_t r = r0 + rl;
-            for (; r + sp.lanes < r1; r += 2 * sp.lanes) {              // 2 rows x 3 tensors = 6 loads in flight per thread
+            const RowWalk w = row_walk(order, M, sp.lanes, rl);
+            int64_t k = 0;
+            for (; k + 1 < w.n; k += 2) {                                // 2 rows x 3 tensors = 6 loads in flight per thread
                 float g[2][8], yy[2][8], xx[2][8];
                 unsigned mb[2] = {0xffu, 0xffu};
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int64_t v = (r + u * sp.lanes) * sp.C8 + cg;
+                    const int64_t v = w.row(k + u) * sp.C8 + cg;
                     vec8<DT>::ld(dy, v, g[u]);
                     vec8<DT>::ld(x, v, xx[u]);
                     if (RELU == 1) vec8<DT>::ld(y, v, yy[u]);
@@ -260,8 +332,8 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_partial_kernel(const void *__
                         q[j] = fmaf(gj, (xx[u][j] - mu[j]) * is[j], q[j]);
                     }
             }
-            for (; r < r1; r += sp.lanes) {
-                const int64_t v = r * sp.C8 + cg;
+            for (; k < w.n; ++k) {
+                const int64_t v = w.row(k) * sp.C8 + cg;
                 float g[8], yy[8], xx[8];
                 vec8<DT>::ld(dy, v, g);
                 vec8<DT>::ld(x, v, xx);
@@ -277,24 +349,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_partial_kernel(const void *__
                 }
             }
         }
-        if (sp.lanes > 1) {
-            if (cg < sp.C8 && rl < sp.lanes) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { smem[(rl * 2 + 0) * C + cg * 8 + j] = s[j]; smem[(rl * 2 + 1) * C + cg * 8 + j] = q[j]; }
-            }
-            __syncthreads();
-            for (int c = threadIdx.x; c < 2 * C; c += BN_BLOCK) {
-                float t = 0.0f;
-                for (int l = 0; l < sp.lanes; ++l) t += smem[l * 2 * C + c];
-                partial[(int64_t)blockIdx.x * 2 * C + c] = t;
-            }
-        } else if (cg < sp.C8) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                partial[(int64_t)blockIdx.x * 2 * C + cg * 8 + j] = s[j];
-                partial[(int64_t)blockIdx.x * 2 * C + C + cg * 8 + j] = q[j];
-            }
-        }
+        slab_reduce(sp, C, lg, rl, valid, s, q, smem, partial);
     }
 }
 
@@ -371,6 +426,27 @@ int reduce_blocks(const int64_t M)
     return (int)b;
 }
 
+// Grid of the two BN reduction kernels: x = row splits (each writes one partial per channel: at most 1 MiB of partials for
+// the per-channel kernel to read), y = channel slabs (>= 32 groups = 512-byte row segments) when the rows alone give fewer
+// than ~512 blocks.
+struct ReduceGrid { int row_splits, slabs; size_t lds; };
+ReduceGrid reduce_grid(const int64_t M, const int C)
+{
+    ReduceGrid g;
+    const int C8 = C / 8;
+    int64_t cap = (int64_t)131072 / C;                               // row_splits * 2 * C floats <= 1 MiB
+    cap = cap > BN_MAX_BLOCKS ? BN_MAX_BLOCKS : (cap < 16 ? 16 : cap);
+    int64_t b = (M + 63) / 64;                                       // at least ~64 rows per block
+    b = b > cap ? cap : (b < 1 ? 1 : b);
+    g.row_splits = (int)b;
+    g.slabs = 1;
+    while (g.row_splits * g.slabs * 2 <= 512 && C8 % (g.slabs * 2) == 0 && C8 / (g.slabs * 2) >= 32) g.slabs *= 2;
+    const int Cs8 = C8 / g.slabs;
+    const int lanes = (Cs8 >= BN_BLOCK) ? 1 : BN_BLOCK / Cs8;
+    g.lds = lanes > 1 ? sizeof(float) * (size_t)lanes * 2 * (size_t)Cs8 * 8 : 0;
+    return g;
+}
+
 size_t reduce_lds(const int C)
 {
     const int C8 = C / 8;
@@ -407,13 +483,16 @@ RN_API int rn_bn_act_forward(const void *x, const void *residual, void *y, int d
     float *ca = coef, *cb = coef + C;
     if (training) {
         if (!workspace || workspace_bytes < rn_bn_workspace_bytes(C)) return RN_EWORKSPACE;
-        const int nb = reduce_blocks(M);
-        const size_t lds = reduce_lds(C);
+        const ReduceGrid rg = reduce_grid(M, C);
+        const int nb = rg.row_splits;
+        const dim3 grid(rg.row_splits, rg.slabs);
+        const size_t lds = rg.lds;
+        const int order = bn_order();
         float *partial = (float *)workspace;
         switch (dtype) {
-            case RN_F32: hipLaunchKernelGGL((bn_stats_partial_kernel<RN_F32>), dim3(nb), dim3(BN_BLOCK), lds, st, x, M, C, partial); break;
-            case RN_BF16: hipLaunchKernelGGL((bn_stats_partial_kernel<RN_BF16>), dim3(nb), dim3(BN_BLOCK), lds, st, x, M, C, partial); break;
-            default: hipLaunchKernelGGL((bn_stats_partial_kernel<RN_F16>), dim3(nb), dim3(BN_BLOCK), lds, st, x, M, C, partial); break;
+            case RN_F32: hipLaunchKernelGGL((bn_stats_partial_kernel<RN_F32>), grid, dim3(BN_BLOCK), lds, st, x, M, C, partial, order); break;
+            case RN_BF16: hipLaunchKernelGGL((bn_stats_partial_kernel<RN_BF16>), grid, dim3(BN_BLOCK), lds, st, x, M, C, partial, order); break;
+            default: hipLaunchKernelGGL((bn_stats_partial_kernel<RN_F16>), grid, dim3(BN_BLOCK), lds, st, x, M, C, partial, order); break;
         }
         RN_LAUNCH_CHECK();
         hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, st, partial, nb, M, C, gamma, beta, running_mean,
@@ -465,15 +544,18 @@ RN_API int rn_bn_act_backward(const void *dy, const void *y, const void *x, void
         !rn::aligned(save_invstd, 16))
         return RN_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-    const int nb = reduce_blocks(M);
-    const size_t lds = reduce_lds(C);
+    const ReduceGrid rg = reduce_grid(M, C);
+    const int nb = rg.row_splits;
+    const dim3 grid(rg.row_splits, rg.slabs);
+    const size_t lds = rg.lds;
+    const int order = bn_order();
     float *partial = (float *)workspace;
     float *ca = coef, *k0 = coef + C, *k1 = coef + 2 * C;
 #define RN_BN_BWD_PART(DT)                                                                                                             \
-    if (rmode == 1) hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 1>), dim3(nb), dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial); \
-    else if (rmode == 2) hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 2>), dim3(nb), dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial); \
-    else if (rmode == 3) hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 3>), dim3(nb), dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial); \
-    else hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 0>), dim3(nb), dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial);
+    if (rmode == 1) hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 1>), grid, dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial, order); \
+    else if (rmode == 2) hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 2>), grid, dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial, order); \
+    else if (rmode == 3) hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 3>), grid, dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial, order); \
+    else hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 0>), grid, dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial, order);
     switch (dtype) {
         case RN_F32: RN_BN_BWD_PART(RN_F32) break;
         case RN_BF16: RN_BN_BWD_PART(RN_BF16) break;
