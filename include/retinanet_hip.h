@@ -224,12 +224,17 @@ int rn_conv3x3_canvas_wgrad_batched(const void *const *gs, const void *const *xs
  * The last 3x3 conv of the classification subnet (retinanet/layers.py:163-167: 256 -> 9*K channels) reads the tower
  * output where it lies -- on the zero-bordered canvas -- and writes, per pyramid level, the dense channels-last
  * tensor ys[l] = [N][h_l][w_l][Cout] bf16, which IS the [N][h*w*9][K] logits tensor of retinanet/layers.py:189-191
- * that rn_loss_fwd_bwd_levels / rn_detect_levels stream (no dead classes, no unpack copy).  levels[l] = where level
- * l sits on the canvas (top-left row / column, height, width).  Cout: any even number (rows of Cout elements start
- * on 4-byte boundaries); Cin % 64 == 0; w [Cout][3][3][Cin] bf16; bias f32[Cout] or NULL; zeros: >= 256 bytes of
- * zeros, 16-byte aligned. */
-typedef struct rn_canvas_level { int32_t r0, c0, h, w; } rn_canvas_level;
-int rn_conv3x3_canvas_to_levels(const void *x, const void *w, const float *bias, const rn_canvas_level *levels, int L,
+ * that rn_loss_fwd_bwd_levels / rn_detect_levels stream (no dead classes, no unpack copy).
+ * Canvas layout: the canvas is N sheets of [Hp][Wp] positions; a sheet carries `slots` images (image = sheet * slots +
+ * slot; the last sheet may have unused slots when n_images is not a multiple of slots), each pyramid level of each slot in
+ * its own rectangle with at least one empty row / column around it.  map (int32, DEVICE memory, [Hp * Wp]) says what lies
+ * at every position of a sheet: -1 = border / gap, else (slot << 28) | (tensor << 24) | (y * w + x), i.e. position (y, x)
+ * of that slot's image in per-level tensor `tensor` (T <= 6 tensors, hw[t] = h_t * w_t < 2^24).  Entries that point
+ * outside their tensor are treated as gaps.
+ * Cout: any even number (rows of Cout elements start on 4-byte boundaries); Cin % 64 == 0; w [Cout][3][3][Cin] bf16;
+ * bias f32[Cout] or NULL; zeros: >= 256 bytes of zeros, 16-byte aligned. */
+typedef struct rn_canvas_layout { const int32_t *map; int32_t slots, n_images, T; int32_t hw[6]; } rn_canvas_layout;
+int rn_conv3x3_canvas_to_levels(const void *x, const void *w, const float *bias, const rn_canvas_layout *layout,
                                 void *const *ys, int dtype, int N, int Hp, int Wp, int Cin, int Cout,
                                 const void *zeros, void *stream);
 /* Its data gradient: y[M = N*Hp*Wp][Cout] (canvas, masked) = conv of the dense per-level gradients gs[l] =
@@ -238,12 +243,12 @@ int rn_conv3x3_canvas_to_levels(const void *x, const void *w, const float *bias,
  * row_elems - row_elems % 8; when row_elems % 8 != 0 the kernel fetches the LAST 8 channels of a row for slots e .. e+7
  * (it never reads past a row), so those slots carry channel row_elems - 8 + (k - e) with ZERO weight on the ones that
  * repeat (< e); every later slot is zero.  row_elems even and >= 8. */
-int rn_conv3x3_levels_to_canvas(const void *const *gs, const rn_canvas_level *levels, int L, int row_elems,
+int rn_conv3x3_levels_to_canvas(const void *const *gs, const rn_canvas_layout *layout, int row_elems,
                                 const void *w, const uint8_t *mask, void *y, int dtype, int N, int Hp, int Wp,
                                 int Kpad, int Cout, const void *zeros, void *stream);
 /* Its weight gradient: dw [row_elems][3][3][Cin = 256] bf16 = sum over canvas positions of gs (gathered) x the
  * tapped canvas input x [M][256].  workspace: rn_conv3x3_wgrad_workspace_bytes((row_elems + 255) / 256, M). */
-int rn_conv3x3_levels_wgrad(const void *const *gs, const rn_canvas_level *levels, int L, int row_elems,
+int rn_conv3x3_levels_wgrad(const void *const *gs, const rn_canvas_layout *layout, int row_elems,
                             const void *x, void *dw, int dtype, int N, int Hp, int Wp, int Cin,
                             const void *zeros, void *workspace, size_t workspace_bytes, void *stream);
 

@@ -62,11 +62,11 @@ SIGNATURES = {
     "rn_maxpool3x3s2_forward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "rn_maxpool3x3s2_backward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "rn_sgd_master_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32, _f32, _f32, C.c_int, C.c_int, _vp]),
-    "rn_conv3x3_canvas_to_levels": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+    "rn_conv3x3_canvas_to_levels": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                               _vp, _vp]),
-    "rn_conv3x3_levels_to_canvas": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+    "rn_conv3x3_levels_to_canvas": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_int, _vp, _vp]),
-    "rn_conv3x3_levels_wgrad": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp,
+    "rn_conv3x3_levels_wgrad": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp,
                                           _sz, _vp]),
     "rn_conv3x3_wgrad_workspace_bytes": (_sz, [C.c_int, _i64]),
     "rn_conv3x3_canvas_wgrad_batched": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _sz, _vp]),

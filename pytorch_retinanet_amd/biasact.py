@@ -15,6 +15,7 @@ import ctypes as C
 import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import Tensor
@@ -24,6 +25,7 @@ from .ops import _timed          # event pairs around the MFMA conv launches whe
 
 _DT = {torch.float32: RN_F32, torch.bfloat16: RN_BF16, torch.float16: RN_F16}
 _WS: Dict[tuple, Tensor] = {}
+PAIR_SHEETS = os.environ.get("RN_CANVAS_SLOTS", "2") != "1"     # two images per canvas sheet (Canvas.of); RN_CANVAS_SLOTS=1: one
 MFMA_FLOP: Dict[str, float] = {}      # flop per call of every timed MFMA launch (bench.py: achieved TFLOP/s of the own conv kernels)
 
 
@@ -264,36 +266,78 @@ def bias_act(x: Tensor, bias: Tensor, mask: Optional[Tensor] = None, relu: bool 
 
 # ---------------------------------------------------------------------------------------------------
 class Canvas:
-    """Placement of L feature maps in one canvas: level 0 on top, the others side by side below it,
-    one empty row / column between neighbours; ``pad`` extra empty rows / columns all around (the MFMA canvas
-    conv wants a one-pixel zero border instead of bounds checks)."""
+    """Placement of the L feature maps of ``slots`` images on one canvas SHEET, one empty row / column between neighbours and
+    ``pad`` extra empty rows / columns all around (the MFMA canvas conv wants a one-pixel zero border instead of bounds
+    checks).  The copies of level 0 are stacked; below them the other rectangles -- level 1 of every slot, then level 2 of
+    every slot, ... -- are laid left to right on shelves as wide as the sheet.  With one slot that is "level 0 on top, the
+    others side by side below it"; with two, the second image's P4 fills the space beside the first one's (the standard
+    800 x 1344 pyramid: 23 940 positions per image instead of 26 010, which takes the head's 256 x 256 conv tiles of a
+    batch of 8 from 7 rounds of the chip's 256 CUs to 6).  Image n lies on sheet n // slots in slot n % slots.
 
-    def __init__(self, shapes: Sequence[Tuple[int, int]], device: torch.device, pad: int = 0):
+    ``regions``: (level, slot, row, col, h, w) of every rectangle; ``origin``: the rectangles of slot 0 (one per level);
+    ``mask``: uint8 [H*W], 1 on feature positions; ``map``: int32 [H*W] for the level-mode kernels (``rn_canvas_layout``):
+    -1 on gaps, else slot << 28 | level << 24 | (y * w + x)."""
+
+    def __init__(self, shapes: Sequence[Tuple[int, int]], device: torch.device, pad: int = 0, slots: int = 1):
         self.shapes = [(int(h), int(w)) for h, w in shapes]
-        self.pad = pad
+        self.pad, self.slots = pad, int(slots)
+        S = self.slots
+        assert 1 <= S <= 8 and len(self.shapes) <= 16
         h0, w0 = self.shapes[0]
-        self.origin: List[Tuple[int, int]] = [(pad, pad)]
-        col, below = 0, 0
-        for h, w in self.shapes[1:]:
-            self.origin.append((pad + h0 + 1, pad + col))
+        rest = [(l, s_) for l in range(1, len(self.shapes)) for s_ in range(S)]
+        inner_w = max([w0] + ([S * (self.shapes[1][1] + 1) - 1] if len(self.shapes) > 1 else []))
+        self.regions: List[Tuple[int, int, int, int, int, int]] = []
+        row = pad
+        for s_ in range(S):
+            self.regions.append((0, s_, row, pad, h0, w0))
+            row += h0 + 1
+        col, shelf_h = 0, 0
+        for l, s_ in rest:
+            h, w = self.shapes[l]
+            if col and col + w > inner_w:                       # next shelf
+                row += shelf_h + 1
+                col, shelf_h = 0, 0
+            self.regions.append((l, s_, row, pad + col, h, w))
             col += w + 1
-            below = max(below, h)
-        self.H = h0 + (1 + below if len(self.shapes) > 1 else 0) + 2 * pad
-        self.W = max(w0, col - 1) + 2 * pad
-        m = torch.zeros((self.H, self.W), dtype=torch.uint8)
-        for (r, c), (h, w) in zip(self.origin, self.shapes):
+            shelf_h = max(shelf_h, h)
+        self.H = (row + shelf_h if rest else row - 1) + pad
+        self.W = inner_w + 2 * pad
+        self.origin: List[Tuple[int, int]] = [(r, c) for l, s_, r, c, h, w in sorted(self.regions) if s_ == 0]
+        m = np.zeros((self.H, self.W), dtype=np.uint8)
+        mp = np.full((self.H, self.W), -1, dtype=np.int32)
+        for l, s_, r, c, h, w in self.regions:
+            assert not m[max(r - 1, 0):r + h + 1, max(c - 1, 0):c + w + 1].any(), "canvas rectangles touch"
             m[r:r + h, c:c + w] = 1
-        self.mask = m.reshape(-1).to(device)
-        self.fill = sum(h * w for h, w in self.shapes) / float(self.H * self.W)
+            mp[r:r + h, c:c + w] = (s_ << 28) | (l << 24) | (np.arange(h)[:, None] * w + np.arange(w)[None, :])
+        self.mask = torch.from_numpy(m.reshape(-1)).to(device)
+        self.map = torch.from_numpy(mp.reshape(-1)).to(device)
+        self.fill = S * sum(h * w for h, w in self.shapes) / float(self.H * self.W)
+
+    def sheets(self, n_images: int) -> int:
+        return (n_images + self.slots - 1) // self.slots
 
     _cache: Dict[tuple, "Canvas"] = {}
 
     @classmethod
-    def of(cls, feature_maps: Sequence[Tensor], pad: int = 0) -> "Canvas":
-        key = (tuple(tuple(f.shape[-2:]) for f in feature_maps), feature_maps[0].device, pad)
+    def of(cls, feature_maps: Sequence[Tensor], pad: int = 0, slots: Optional[int] = None) -> "Canvas":
+        """The canvas for these feature maps; ``slots`` None: two images per sheet when that takes fewer positions (zero-
+        bordered canvases of the MFMA kernels only), else one."""
+        shapes = tuple(tuple(int(v) for v in f.shape[-2:]) for f in feature_maps)
+        dev, N = feature_maps[0].device, int(feature_maps[0].shape[0])
+        if slots is None:
+            slots = 1
+            if pad and N > 1 and PAIR_SHEETS:
+                one, two = cls._get(shapes, dev, pad, 1), cls._get(shapes, dev, pad, 2)
+                if two.sheets(N) * two.H * two.W < N * one.H * one.W:
+                    slots = 2
+        return cls._get(shapes, dev, pad, slots)
+
+    @classmethod
+    def _get(cls, shapes, dev, pad, slots) -> "Canvas":
+        key = (shapes, dev, pad, slots)
         c = cls._cache.get(key)
         if c is None:
-            c = cls._cache[key] = Canvas(key[0], key[1], pad)
+            c = cls._cache[key] = Canvas(shapes, dev, pad, slots)
         return c
 
 
@@ -301,45 +345,63 @@ class _Pack(torch.autograd.Function):
     @staticmethod
     def forward(ctx, canvas: Canvas, *feats):
         f0 = feats[0]
-        out = torch.empty((f0.shape[0], f0.shape[1], canvas.H, canvas.W), dtype=f0.dtype, device=f0.device,
+        N, S = f0.shape[0], canvas.slots
+        out = torch.empty((canvas.sheets(N), f0.shape[1], canvas.H, canvas.W), dtype=f0.dtype, device=f0.device,
                           memory_format=torch.channels_last).zero_()
-        for f, (r, c), (h, w) in zip(feats, canvas.origin, canvas.shapes):
-            out[:, :, r:r + h, c:c + w].copy_(f)
-        ctx.canvas = canvas
+        for l, s_, r, c, h, w in canvas.regions:
+            src = feats[l][s_::S]
+            if src.shape[0]:
+                out[:src.shape[0], :, r:r + h, c:c + w].copy_(src)
+        ctx.canvas, ctx.n = canvas, N
         return out
 
     @staticmethod
     def backward(ctx, g):
-        cv = ctx.canvas
-        return (None,) + tuple(g[:, :, r:r + h, c:c + w].contiguous(memory_format=torch.channels_last)
-                               for (r, c), (h, w) in zip(cv.origin, cv.shapes))
+        return (None,) + tuple(_gather_levels(ctx.canvas, g, ctx.n))
+
+
+def _gather_levels(cv: "Canvas", x: Tensor, n_images: int) -> List[Tensor]:
+    "The per-level tensors [n_images, C, h, w] (channels-last) cut out of canvas sheets."
+    S = cv.slots
+    if S == 1:
+        return [x[:, :, r:r + h, c:c + w].contiguous(memory_format=torch.channels_last) for (r, c), (h, w) in zip(cv.origin, cv.shapes)]
+    outs = [torch.empty((n_images, x.shape[1], h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last) for h, w in cv.shapes]
+    for l, s_, r, c, h, w in cv.regions:
+        dst = outs[l][s_::S]
+        if dst.shape[0]:
+            dst.copy_(x[:dst.shape[0], :, r:r + h, c:c + w])
+    return outs
 
 
 class _Unpack(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, canvas: Canvas, x):
+    def forward(ctx, canvas: Canvas, x, n_images):
         ctx.canvas = canvas
         ctx.meta = (x.shape, x.dtype, x.device)
-        return tuple(x[:, :, r:r + h, c:c + w].contiguous(memory_format=torch.channels_last)
-                     for (r, c), (h, w) in zip(canvas.origin, canvas.shapes))
+        return tuple(_gather_levels(canvas, x, n_images))
 
     @staticmethod
     def backward(ctx, *grads):
         cv = ctx.canvas
         shape, dt, dev = ctx.meta
+        S = cv.slots
         g = torch.empty(shape, dtype=dt, device=dev, memory_format=torch.channels_last).zero_()
-        for gl, (r, c), (h, w) in zip(grads, cv.origin, cv.shapes):
+        for l, s_, r, c, h, w in cv.regions:
+            gl = grads[l]
             if gl is not None:
-                g[:, :, r:r + h, c:c + w].copy_(gl)
-        return None, g
+                src = gl[s_::S]
+                if src.shape[0]:
+                    g[:src.shape[0], :, r:r + h, c:c + w].copy_(src)
+        return None, g, None
 
 
 def pack_levels(canvas: Canvas, feature_maps: Sequence[Tensor]) -> Tensor:
     return _Pack.apply(canvas, *feature_maps)
 
 
-def unpack_levels(canvas: Canvas, x: Tensor) -> List[Tensor]:
-    return list(_Unpack.apply(canvas, x))
+def unpack_levels(canvas: Canvas, x: Tensor, n_images: Optional[int] = None) -> List[Tensor]:
+    "``n_images``: the batch size (default: every slot of every sheet holds an image)."
+    return list(_Unpack.apply(canvas, x, x.shape[0] * canvas.slots if n_images is None else int(n_images)))
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -354,12 +416,16 @@ def _zero_page(dev: torch.device) -> Tensor:
     return z
 
 
-class RnCanvasLevel(C.Structure):
-    _fields_ = [("r0", C.c_int32), ("c0", C.c_int32), ("h", C.c_int32), ("w", C.c_int32)]
+class RnCanvasLayout(C.Structure):
+    _fields_ = [("map", C.c_void_p), ("slots", C.c_int32), ("n_images", C.c_int32), ("T", C.c_int32), ("hw", C.c_int32 * 6)]
 
 
-def _level_array(cv: "Canvas"):
-    return (RnCanvasLevel * len(cv.shapes))(*[RnCanvasLevel(r, c, h, w) for (r, c), (h, w) in zip(cv.origin, cv.shapes)])
+def _layout(cv: "Canvas", n_images: int):
+    lay = RnCanvasLayout()
+    lay.map, lay.slots, lay.n_images, lay.T = cv.map.data_ptr(), cv.slots, int(n_images), len(cv.shapes)
+    for i, (h, w) in enumerate(cv.shapes):
+        lay.hw[i] = h * w
+    return C.byref(lay)
 
 
 def _dgrad_weight(w: Tensor) -> Tensor:
@@ -385,8 +451,9 @@ class _ClsOutputConv(torch.autograd.Function):
     copy); data and weight gradients gather the dense per-level gradients back (``csrc/conv.hip``, level modes)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, canvas, num_classes):
-        N, Cin, Hp, Wp = x.shape
+    def forward(ctx, x, w, bias, canvas, num_classes, n_images):
+        sheets, Cin, Hp, Wp = x.shape
+        N = int(n_images)
         Cout = w.shape[0]
         dev = x.device
         if dev.index != torch.cuda.current_device():
@@ -399,17 +466,18 @@ class _ClsOutputConv(torch.autograd.Function):
         real = N * sum(h * wd for h, wd in canvas.shapes)
         _mfma_call("mfma_cls_output_fwd", dev, 2.0 * real * Cout * 9 * Cin,
                    lambda: lib.rn_conv3x3_canvas_to_levels(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else 0,
-                                                           _level_array(canvas), len(ys), _ptr_array(ys), _DT[x.dtype], N, Hp, Wp, Cin, Cout,
+                                                           _layout(canvas, N), _ptr_array(ys), _DT[x.dtype], sheets, Hp, Wp, Cin, Cout,
                                                            _zero_page(dev).data_ptr(), stream), "rn_conv3x3_canvas_to_levels")
         ctx.save_for_backward(x, w)
-        ctx.canvas, ctx.has_bias = canvas, bias is not None
+        ctx.canvas, ctx.has_bias, ctx.n_images = canvas, bias is not None, N
         return tuple(ys)
 
     @staticmethod
     def backward(ctx, *dys):
         x, w = ctx.saved_tensors
         cv = ctx.canvas
-        N, Cin, Hp, Wp = x.shape
+        sheets, Cin, Hp, Wp = x.shape
+        N = ctx.n_images
         Cout = w.shape[0]
         dev = x.device
         if dev.index != torch.cuda.current_device():
@@ -420,30 +488,30 @@ class _ClsOutputConv(torch.autograd.Function):
             if dy is None:
                 dy = torch.zeros((N, h * wd * Cout), dtype=x.dtype, device=dev)
             gs.append(dy.to(x.dtype).contiguous())
-        lv = _level_array(cv)
+        lv = _layout(cv, N)
         real = N * sum(h * wd for h, wd in cv.shapes)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             wt = _dgrad_weight(w)
             _mfma_call("mfma_cls_output_dgrad", dev, 2.0 * real * Cout * 9 * Cin,
-                       lambda: lib.rn_conv3x3_levels_to_canvas(_ptr_array(gs), lv, len(gs), Cout, wt.data_ptr(), cv.mask.data_ptr(), dx.data_ptr(),
-                                                               _DT[x.dtype], N, Hp, Wp, wt.shape[1], Cin, _zero_page(dev).data_ptr(), stream),
+                       lambda: lib.rn_conv3x3_levels_to_canvas(_ptr_array(gs), lv, Cout, wt.data_ptr(), cv.mask.data_ptr(), dx.data_ptr(),
+                                                               _DT[x.dtype], sheets, Hp, Wp, wt.shape[1], Cin, _zero_page(dev).data_ptr(), stream),
                        "rn_conv3x3_levels_to_canvas")
         if ctx.needs_input_grad[1]:
-            need = lib.rn_conv3x3_wgrad_workspace_bytes((Cout + 255) // 256, N * Hp * Wp)
+            need = lib.rn_conv3x3_wgrad_workspace_bytes((Cout + 255) // 256, sheets * Hp * Wp)
             key = (dev.index, stream)
             wsb = _WG_WS.get(key)
             if wsb is None or wsb.numel() < need:
                 wsb = _WG_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
             dw = torch.empty((Cout, Cin, 3, 3), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
             _mfma_call("mfma_cls_output_wgrad", dev, 2.0 * real * Cout * 9 * Cin,
-                       lambda: lib.rn_conv3x3_levels_wgrad(_ptr_array(gs), lv, len(gs), Cout, x.data_ptr(), dw.data_ptr(), _DT[x.dtype], N, Hp, Wp,
+                       lambda: lib.rn_conv3x3_levels_wgrad(_ptr_array(gs), lv, Cout, x.data_ptr(), dw.data_ptr(), _DT[x.dtype], sheets, Hp, Wp,
                                                            Cin, _zero_page(dev).data_ptr(), wsb.data_ptr(), wsb.numel(), stream),
                        "rn_conv3x3_levels_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = sum(g.reshape(-1, Cout).sum(0, dtype=torch.float32) for g in gs)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 def cls_output_conv_fusable(x: Tensor, conv, canvas: "Canvas") -> bool:
@@ -451,10 +519,12 @@ def cls_output_conv_fusable(x: Tensor, conv, canvas: "Canvas") -> bool:
     return (x.is_cuda and x.dtype == torch.bfloat16 and _cl(x) and canvas.pad == 1 and conv.kernel_size == (3, 3)
             and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
             and conv.in_channels == 256 and conv.out_channels % 2 == 0 and 8 <= conv.out_channels <= 1024
-            and len(canvas.shapes) <= 6 and x.shape[0] * canvas.H * canvas.W < (1 << 22)
+            and len(canvas.shapes) <= 6 and canvas.slots <= 8 and x.shape[0] * canvas.H * canvas.W < (1 << 22)
             and (conv.bias is None or conv.bias.dtype == torch.float32))
 
 
-def cls_output_conv(x: Tensor, conv, canvas: "Canvas", num_classes: int) -> List[Tensor]:
-    "``conv(x)`` for the class-output conv on a canvas -> per-level logits ``[N, h*w*A, num_classes]`` (dense)."
-    return list(_ClsOutputConv.apply(x, conv.weight.to(x.dtype), conv.bias, canvas, num_classes))
+def cls_output_conv(x: Tensor, conv, canvas: "Canvas", num_classes: int, n_images: Optional[int] = None) -> List[Tensor]:
+    """``conv(x)`` for the class-output conv on a canvas -> per-level logits ``[n_images, h*w*A, num_classes]`` (dense);
+    ``n_images`` defaults to every slot of every sheet."""
+    n = x.shape[0] * canvas.slots if n_images is None else int(n_images)
+    return list(_ClsOutputConv.apply(x, conv.weight.to(x.dtype), conv.bias, canvas, num_classes, n))

@@ -38,52 +38,90 @@ constexpr int CONV_MAX_PROBLEMS = 4;
 
 // The pyramid levels as they sit on the canvas, and their DENSE per-level tensors [N][h][w][row_elems] (the layout the
 // loss / detection kernels stream: [N][h*w*9][K] with row_elems = 9 K).  Used by the class-output conv, whose
-// 9 x 90 = 810 output channels are written densely (no dead classes), and by its gradients.  Packed (16-bit fields) so the
-// whole set stays in a few SGPRs next to the MFMA kernels' other arguments.
+// 9 x 90 = 810 output channels are written densely (no dead classes), and by its gradients.
+// A canvas SHEET [Hp][Wp] carries `slots` images (the second image's P4 fills the space beside the first one's, ...), so the
+// placement is a table: map[position on the sheet] = -1 for border / gap positions, else
+//     (slot << 28) | (tensor << 24) | (y * w + x)        -- position (y, x) of image sheet * slots + slot in tensor `tensor`.
 constexpr int CONV_LEVELS = 6;
 struct LevelSet {
-    int32_t L, row_elems;
-    uint32_t origin[CONV_LEVELS];       // r0 | c0 << 16
-    uint32_t extent[CONV_LEVELS];       // h | w << 16
+    const int32_t *map;                 // [HWp], device memory
+    int32_t row_elems, slots, n_images, T;
+    int32_t hw[CONV_LEVELS];            // h * w of each tensor
     uint16_t *ptr[CONV_LEVELS];
 };
 
-// Row of canvas position (image n, canvas row y, canvas column x) in its level's dense tensor, or null for border / gap
-// positions.  Two steps to stay register-lean inside the MFMA kernels: a 32-bit (level, row index) search, then one
-// 64-bit address computation.
-__device__ __forceinline__ uint16_t *level_row(const LevelSet &ls, const int n, const int y, const int x)
-{
-    int idx = -1, lvl = 0;
-#pragma unroll
-    for (int l = 0; l < CONV_LEVELS; ++l) {
-        if (l < ls.L) {
-            const int h = (int)(ls.extent[l] & 0xffffu), w = (int)(ls.extent[l] >> 16);
-            const unsigned uy = (unsigned)(y - (int)(ls.origin[l] & 0xffffu)), ux = (unsigned)(x - (int)(ls.origin[l] >> 16));
-            if (uy < (unsigned)h && ux < (unsigned)w) { idx = (n * h + (int)uy) * w + (int)ux; lvl = l; }
-        }
-    }
-    if (idx < 0) return nullptr;
-    uint16_t *base = ls.ptr[0];
-#pragma unroll
-    for (int l = 1; l < CONV_LEVELS; ++l) base = (l < ls.L && lvl == l) ? ls.ptr[l] : base;
-    return base + (int64_t)idx * ls.row_elems;
-}
-
-__device__ __forceinline__ const uint16_t *shfl_ptr(const uint16_t *p, const int src_lane)
-{
-    const unsigned long long u = (unsigned long long)(uintptr_t)p;
-    const unsigned lo = __shfl((unsigned)u, src_lane, RN_WAVE), hi = __shfl((unsigned)(u >> 32), src_lane, RN_WAVE);
-    return (const uint16_t *)(uintptr_t)(((unsigned long long)hi << 32) | lo);
-}
-
-// (image, canvas row, canvas column) of canvas position m < 2^22, without integer division: (m + 0.5) * (1 / d) is at least
-// 0.5 / d away from an integer, far more than the rounding error of the two float operations at these magnitudes
-__device__ __forceinline__ void canvas_coords(const int m, const int HWp, const int Wp, int &n, int &y, int &x)
+// Sheet index and position on the sheet of canvas position m < 2^22, without integer division: (m + 0.5) * (1 / d) is at
+// least 0.5 / d away from an integer, far more than the rounding error of the two float operations at these magnitudes
+__device__ __forceinline__ void sheet_coords(const int m, const int HWp, int &n, int &pos)
 {
     n = (int)(((float)m + 0.5f) * (1.0f / (float)HWp));
-    const int pos = m - n * HWp;
-    y = (int)(((float)pos + 0.5f) * (1.0f / (float)Wp));
-    x = pos - y * Wp;
+    pos = m - n * HWp;
+}
+
+// The tensors' base pointers and sizes pinned in SGPRs (readfirstlane): indexed by a per-lane tensor number straight from the
+// kernel arguments, the compiler turns `ptr[t]` into a vector load from the argument segment, and waits for it with
+// s_waitcnt vmcnt(0) inside the MFMA loops.
+struct LevelRegs { uint32_t lo[CONV_LEVELS], hi[CONV_LEVELS]; int32_t hw[CONV_LEVELS]; };
+__device__ __forceinline__ LevelRegs level_regs(const LevelSet &ls)
+{
+    LevelRegs r;
+#pragma unroll
+    for (int l = 0; l < CONV_LEVELS; ++l) {
+        const unsigned long long u = (unsigned long long)(uintptr_t)ls.ptr[l];
+        r.lo[l] = __builtin_amdgcn_readfirstlane((uint32_t)u);
+        r.hi[l] = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+        r.hw[l] = __builtin_amdgcn_readfirstlane(ls.hw[l]);
+    }
+    return r;
+}
+
+// Row of the dense tensor behind map entry `e` on sheet n; null for gaps, for the unused slots of the last sheet and for
+// entries outside the tensor (a wrong table cannot make the kernels read or write out of bounds).
+__device__ __forceinline__ uint16_t *level_row(const LevelSet &ls, const LevelRegs &lr, const int n, const int32_t e)
+{
+    if (e < 0) return nullptr;
+    const int t = (e >> 24) & 15, img = n * ls.slots + ((e >> 28) & 7), local = e & 0xffffff;
+    uint32_t lo = lr.lo[0], hi = lr.hi[0];
+    int hw = lr.hw[0];
+#pragma unroll
+    for (int l = 1; l < CONV_LEVELS; ++l) {
+        lo = t == l ? lr.lo[l] : lo;
+        hi = t == l ? lr.hi[l] : hi;
+        hw = t == l ? lr.hw[l] : hw;
+    }
+    if (t >= ls.T || img >= ls.n_images || local >= hw) return nullptr;
+    uint16_t *base = (uint16_t *)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+    return base + ((int64_t)img * hw + local) * ls.row_elems;
+}
+
+// Map fetches inside the MFMA loops must not make the compiler wait for the LDS-DMA pieces in flight (its own s_waitcnt for
+// a loop-carried load is vmcnt(0)): the fetch is issued by hand one step ahead (map_fetch: branch-free, the caller clamps the
+// position and keeps the validity), it is older than the 4 pieces issued after it, so the loops' counted
+// `s_waitcnt vmcnt(4)` retires it, and map_landed() right after that wait hands the register back to the compiler.
+__device__ __forceinline__ void map_fetch(int32_t &dst, const int32_t *p) { asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory"); }
+__device__ __forceinline__ void map_landed(int32_t &dst) { asm volatile("" : "+v"(dst) :: "memory"); }
+
+// Cross-lane pointer exchange inside the MFMA loops.  NOT __shfl: that is a ds_bpermute_b32, which the compiler counts as an
+// LDS read that may alias the LDS-DMA pieces in flight and protects with s_waitcnt vmcnt(0) -- a full drain of the staging
+// pipeline per call (the gathering weight-gradient kernel did that once per K-tile in round 2's first version).
+// bperm_ptr: the same instruction behind asm (it does not touch LDS memory); pair_ptr: v_readlane for the two-source case.
+__device__ __forceinline__ const uint16_t *bperm_ptr(const uint16_t *p, const int src_lane)
+{
+    const unsigned long long u = (unsigned long long)(uintptr_t)p;
+    unsigned lo, hi;
+    const unsigned sel = (unsigned)src_lane << 2;
+    asm volatile("ds_bpermute_b32 %0, %2, %3\n\tds_bpermute_b32 %1, %2, %4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(lo), "=&v"(hi) : "v"(sel), "v"((unsigned)u), "v"((unsigned)(u >> 32)) : "memory");
+    return (const uint16_t *)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
+template <int LANE_A, int LANE_B>
+__device__ __forceinline__ const uint16_t *pair_ptr(const uint16_t *p, const bool second)
+{
+    const unsigned long long u = (unsigned long long)(uintptr_t)p;
+    const unsigned lo_a = __builtin_amdgcn_readlane((unsigned)u, LANE_A), hi_a = __builtin_amdgcn_readlane((unsigned)(u >> 32), LANE_A);
+    const unsigned lo_b = __builtin_amdgcn_readlane((unsigned)u, LANE_B), hi_b = __builtin_amdgcn_readlane((unsigned)(u >> 32), LANE_B);
+    const unsigned long long a = ((unsigned long long)hi_a << 32) | lo_a, b = ((unsigned long long)hi_b << 32) | lo_b;
+    return (const uint16_t *)(uintptr_t)(second ? b : a);
 }
 
 // Kernel modes.  CANVAS: canvas in, canvas out (the head towers, forward and data gradient).  TO_LEVELS: canvas in, dense
@@ -151,15 +189,29 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     const uint16_t *grow[4] = {nullptr, nullptr, nullptr, nullptr};
     // A wave stages rows i * 64 + wave * 8 + (lane >> 3), i = 0..3: 32 distinct rows.  Lane j < 32 looks up row
     // (j >> 3) * 64 + wave * 8 + (j & 7) once per tap (9 times per tile) and the wave shares the pointers by shuffles.
-    auto gather_tap = [&](const int t) {
+    // The map entry of the NEXT tap is fetched when a tap's pointers are formed (map_fetch / map_landed above).
+    LevelRegs lregs = {};
+    if (MODE != MODE_CANVAS) lregs = level_regs(args.lv);
+    int g_n = 0, g_pos = 0;
+    int32_t g_entry = -1;
+    bool g_valid = false;
+    auto tap_pos = [&](const int t) { return g_pos + (t / 3 - 1) * args.Wp + (t % 3 - 1); };
+    if (MODE == MODE_FROM_LEVELS) {
         const int j = lane & 31;
         int64_t m = m0 + (j >> 3) * 64 + wave * 8 + (j & 7);
         m = m < args.M ? m : args.M - 1;
-        int n, y, x;
-        canvas_coords((int)m, (int)args.HWp, args.Wp, n, y, x);
-        const uint16_t *mine = level_row(args.lv, n, y + t / 3 - 1, x + t % 3 - 1);
+        sheet_coords((int)m, (int)args.HWp, g_n, g_pos);
+        const int p0 = tap_pos(0);
+        g_valid = p0 >= 0 && p0 < (int)args.HWp;
+        g_entry = args.lv.map[g_valid ? p0 : 0];                  // (prologue: nothing in flight yet)
+    }
+    auto gather_tap = [&](const int t) {
+        const uint16_t *mine = level_row(args.lv, lregs, g_n, g_valid ? g_entry : -1);
+        const int pn = tap_pos(t + 1 < 9 ? t + 1 : t);
+        g_valid = pn >= 0 && pn < (int)args.HWp;
+        map_fetch(g_entry, args.lv.map + (g_valid ? pn : 0));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) grow[i] = shfl_ptr(mine, i * 8 + (lane >> 3));
+        for (int i = 0; i < 4; ++i) grow[i] = bperm_ptr(mine, i * 8 + (lane >> 3));
     };
     auto piece_a = [&](const int kt, const int i) {
         const int c0 = chunk_of(kt) * CONV_BK, t = tap_of(kt);
@@ -192,10 +244,15 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     for (int i = 0; i < 4; ++i) piece_a(0, i);
 #pragma unroll
     for (int i = 0; i < 4; ++i) piece_b(0, i);
-    if (MODE == MODE_FROM_LEVELS && cpt == 1) gather_tap(1);
+    if (MODE == MODE_FROM_LEVELS && cpt == 1) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // the fetch of tap 1 is older than tile 0's 8 pieces
+        map_landed(g_entry);
+        gather_tap(1);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) piece_a(1, i);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (MODE == MODE_FROM_LEVELS) map_landed(g_entry);
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();                    // group 1 runs one barrier interval behind group 0
 
@@ -238,6 +295,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
 #pragma unroll
             for (int i = 0; i < 4; ++i) piece_a(kt + 2, i);
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (MODE == MODE_FROM_LEVELS) map_landed(g_entry);
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -272,9 +330,9 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
         const int64_t m = m0 + tid;
         uint16_t *dst = nullptr;
         if (m < args.M) {
-            int n, y, x;
-            canvas_coords((int)m, (int)args.HWp, args.Wp, n, y, x);
-            dst = level_row(args.lv, n, y, x);
+            int n, pos;
+            sheet_coords((int)m, (int)args.HWp, n, pos);
+            dst = level_row(args.lv, lregs, n, args.lv.map[pos]);
         }
         Yrow[tid] = dst;
     }
@@ -390,17 +448,27 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
     // GATHER: a wave stages rows i * 16 + wave * 2 + (lane >> 5), i = 0..3, of a K-tile: 8 distinct rows.  Lane j < 8 looks up
     // row (j >> 1) * 16 + wave * 2 + (j & 1) and the wave shares the pointers by shuffles (1 lookup per lane, not 4).
     const uint16_t *grow[4] = {nullptr, nullptr, nullptr, nullptr};
-    auto gather_rows = [&](const int kt) {
+    // (the map entries of K-tile kt + 1 are fetched while the pointers of K-tile kt are formed: map_fetch / map_landed)
+    LevelRegs lregs = {};
+    if (GATHER) lregs = level_regs(a.lv);
+    int w_n = 0;
+    int32_t w_entry = -1;
+    bool w_valid = false;
+    auto rows_pos = [&](const int kt) {                            // -> w_n, w_valid; returns the (clamped) sheet position
         const int j = lane & 7;
         const int64_t m = m_begin + (int64_t)kt * WG_POS + (j >> 1) * 16 + wave * 2 + (j & 1);
-        const uint16_t *mine = nullptr;
-        if (m < a.M) {
-            int n, y, x;
-            canvas_coords((int)m, (int)a.HWp, a.Wp, n, y, x);
-            mine = level_row(a.lv, n, y, x);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) grow[i] = shfl_ptr(mine, i * 2 + (lane >> 5));
+        w_valid = m < a.M;
+        int pos;
+        sheet_coords((int)(w_valid ? m : a.M - 1), (int)a.HWp, w_n, pos);
+        return pos;
+    };
+    if (GATHER) w_entry = a.lv.map[rows_pos(0)];                   // (prologue: nothing in flight yet)
+    auto gather_rows = [&](const int kt) {
+        const uint16_t *mine = level_row(a.lv, lregs, w_n, w_valid ? w_entry : -1);
+        map_fetch(w_entry, a.lv.map + rows_pos(kt + 1 < KT ? kt + 1 : kt));
+        const bool second = lane >= 32;
+        grow[0] = pair_ptr<0, 1>(mine, second); grow[1] = pair_ptr<2, 3>(mine, second);
+        grow[2] = pair_ptr<4, 5>(mine, second); grow[3] = pair_ptr<6, 7>(mine, second);
     };
     auto piece_a = [&](const int kt, const int i) {
         const int qi = i * CONV_THREADS + tid, row = qi >> 5, cp = qi & 31;
@@ -425,10 +493,15 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
 #pragma unroll
     for (int i = 0; i < 4; ++i) piece_b(0, i);
     if (KT > 1) {
-        if (GATHER) gather_rows(1);
+        if (GATHER) {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // the fetch for K-tile 1 is older than tile 0's 8 pieces
+            map_landed(w_entry);
+            gather_rows(1);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) piece_a(1, i);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (GATHER) map_landed(w_entry);
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -477,6 +550,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
 #pragma unroll
             for (int i = 0; i < 4; ++i) piece_a(kt + 2, i);
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (GATHER) map_landed(w_entry);
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -556,19 +630,18 @@ static int conv_launch_mode(const ConvArgs &a, const dim3 grid, hipStream_t st)
     return RN_OK;
 }
 
-static int fill_levels(LevelSet &ls, const rn_canvas_level *lv, int L, int row_elems, void *const *ptrs, int N, int Hp, int Wp)
+static int fill_levels(LevelSet &ls, const rn_canvas_layout *lay, int row_elems, void *const *ptrs, int N, int Hp, int Wp)
 {
-    if (!lv || !ptrs || L <= 0 || row_elems <= 0 || (row_elems & 1)) return RN_EINVAL;
-    if (L > CONV_LEVELS || Hp > 65535 || Wp > 65535) return RN_EUNSUPPORTED;
-    ls.L = L; ls.row_elems = row_elems;
+    if (!lay || !lay->map || !ptrs || row_elems <= 0 || (row_elems & 1)) return RN_EINVAL;
+    if (lay->T <= 0 || lay->slots <= 0 || lay->n_images <= 0 || (int64_t)N * lay->slots < lay->n_images) return RN_EINVAL;
+    if (lay->T > CONV_LEVELS || lay->slots > 8) return RN_EUNSUPPORTED;
+    ls.map = lay->map; ls.row_elems = row_elems; ls.slots = lay->slots; ls.n_images = lay->n_images; ls.T = lay->T;
     for (int l = 0; l < CONV_LEVELS; ++l) {
-        const int q = l < L ? l : 0;
-        if (!ptrs[q] || lv[q].h <= 0 || lv[q].w <= 0 || lv[q].r0 < 0 || lv[q].c0 < 0 || lv[q].r0 + lv[q].h > Hp || lv[q].c0 + lv[q].w > Wp)
-            return RN_EINVAL;
+        const int q = l < lay->T ? l : 0;
+        if (!ptrs[q] || lay->hw[q] <= 0 || lay->hw[q] >= (1 << 24) || lay->hw[q] > Hp * Wp) return RN_EINVAL;
         if (!rn::aligned(ptrs[q], 16)) return RN_EALIGN;
-        if ((int64_t)N * lv[q].h * lv[q].w >= (1ll << 31)) return RN_EUNSUPPORTED;
-        ls.origin[l] = (uint32_t)lv[q].r0 | ((uint32_t)lv[q].c0 << 16);
-        ls.extent[l] = (uint32_t)lv[q].h | ((uint32_t)lv[q].w << 16);
+        if ((int64_t)lay->n_images * lay->hw[q] >= (1ll << 31)) return RN_EUNSUPPORTED;
+        ls.hw[l] = lay->hw[q];
         ls.ptr[l] = (uint16_t *)ptrs[q];
     }
     return RN_OK;
@@ -603,7 +676,7 @@ RN_API int rn_conv3x3_canvas(const void *x, const void *w, const float *bias, co
     return rn_conv3x3_canvas_batched(xs, ws, bs, mask, ys, 1, dtype, M, HWp, Wp, Cin, Cout, relu, stream);
 }
 
-RN_API int rn_conv3x3_canvas_to_levels(const void *x, const void *w, const float *bias, const rn_canvas_level *levels, int L,
+RN_API int rn_conv3x3_canvas_to_levels(const void *x, const void *w, const float *bias, const rn_canvas_layout *layout,
                                        void *const *ys, int dtype, int N, int Hp, int Wp, int Cin, int Cout, const void *zeros,
                                        void *stream)
 {
@@ -611,7 +684,7 @@ RN_API int rn_conv3x3_canvas_to_levels(const void *x, const void *w, const float
     if (dtype != RN_BF16 || Cin % CONV_BK || (Cout & 1) || (int64_t)N * Hp * Wp >= (1 << 22)) return RN_EUNSUPPORTED;
     if (!rn::aligned(x, 16) || !rn::aligned(w, 16) || !rn::aligned(zeros, 16)) return RN_EALIGN;
     ConvArgs a = {};
-    const int rc = fill_levels(a.lv, levels, L, Cout, ys, N, Hp, Wp);
+    const int rc = fill_levels(a.lv, layout, Cout, ys, N, Hp, Wp);
     if (rc != RN_OK) return rc;
     for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) { a.Xs[p] = (const uint16_t *)x; a.Ws[p] = (const uint16_t *)w; a.biases[p] = bias; a.Ys[p] = nullptr; }
     a.mask = nullptr; a.M = (int64_t)N * Hp * Wp; a.HWp = (int64_t)Hp * Wp; a.Cin = Cin; a.Cout = Cout; a.Wp = Wp; a.relu = 0;
@@ -620,7 +693,7 @@ RN_API int rn_conv3x3_canvas_to_levels(const void *x, const void *w, const float
     return conv_launch_mode<MODE_TO_LEVELS>(a, grid, (hipStream_t)stream);
 }
 
-RN_API int rn_conv3x3_levels_to_canvas(const void *const *gs, const rn_canvas_level *levels, int L, int row_elems, const void *w,
+RN_API int rn_conv3x3_levels_to_canvas(const void *const *gs, const rn_canvas_layout *layout, int row_elems, const void *w,
                                        const uint8_t *mask, void *y, int dtype, int N, int Hp, int Wp, int Kpad, int Cout,
                                        const void *zeros, void *stream)
 {
@@ -630,7 +703,7 @@ RN_API int rn_conv3x3_levels_to_canvas(const void *const *gs, const rn_canvas_le
         return RN_EUNSUPPORTED;
     if (!rn::aligned(w, 16) || !rn::aligned(y, 16) || !rn::aligned(zeros, 16)) return RN_EALIGN;
     ConvArgs a = {};
-    const int rc = fill_levels(a.lv, levels, L, row_elems, const_cast<void *const *>(gs), N, Hp, Wp);
+    const int rc = fill_levels(a.lv, layout, row_elems, const_cast<void *const *>(gs), N, Hp, Wp);
     if (rc != RN_OK) return rc;
     for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) { a.Xs[p] = nullptr; a.Ws[p] = (const uint16_t *)w; a.biases[p] = nullptr; a.Ys[p] = (uint16_t *)y; }
     a.mask = mask; a.M = (int64_t)N * Hp * Wp; a.HWp = (int64_t)Hp * Wp; a.Cin = Kpad; a.Cout = Cout; a.Wp = Wp; a.relu = 0;
@@ -696,7 +769,7 @@ RN_API int rn_conv3x3_canvas_wgrad_batched(const void *const *gs, const void *co
     return wgrad_launch<false>(a, dw, rows, P, M, workspace, (hipStream_t)stream);
 }
 
-RN_API int rn_conv3x3_levels_wgrad(const void *const *gs, const rn_canvas_level *levels, int L, int row_elems, const void *x, void *dw,
+RN_API int rn_conv3x3_levels_wgrad(const void *const *gs, const rn_canvas_layout *layout, int row_elems, const void *x, void *dw,
                                    int dtype, int N, int Hp, int Wp, int Cin, const void *zeros, void *workspace,
                                    size_t workspace_bytes, void *stream)
 {
@@ -707,7 +780,7 @@ RN_API int rn_conv3x3_levels_wgrad(const void *const *gs, const rn_canvas_level 
     if (workspace_bytes < rn_conv3x3_wgrad_workspace_bytes(P, M)) return RN_EWORKSPACE;
     if (!rn::aligned(x, 16) || !rn::aligned(dw, 16) || !rn::aligned(zeros, 16)) return RN_EALIGN;
     WgradArgs a = {};
-    const int rc = fill_levels(a.lv, levels, L, row_elems, const_cast<void *const *>(gs), N, Hp, Wp);
+    const int rc = fill_levels(a.lv, layout, row_elems, const_cast<void *const *>(gs), N, Hp, Wp);
     if (rc != RN_OK) return rc;
     uint16_t *dws[CONV_MAX_PROBLEMS];
     int rows[CONV_MAX_PROBLEMS];

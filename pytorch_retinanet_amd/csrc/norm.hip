@@ -21,6 +21,7 @@
 namespace {
 
 constexpr int BN_BLOCK = 256;
+constexpr int BN_RBLOCK_MAX = 1024;       // threads per block of the two BN reduction kernels (runtime: reduce_grid)
 constexpr int BN_MAX_BLOCKS = 512;
 constexpr int FIN_CH = 8;                 // channels per block of the per-channel kernels
 constexpr int FIN_LANES = 256 / FIN_CH;    // threads that split the partial sums of one channel
@@ -68,8 +69,9 @@ __device__ __forceinline__ Slab slab_of(const int C)
     s.C8 = C / 8;
     s.Cs8 = s.C8 / (int)gridDim.y;
     s.cg0 = (int)blockIdx.y * s.Cs8;
-    if (s.Cs8 >= BN_BLOCK) { s.lanes = 1; s.groups_per_thread = (s.Cs8 + BN_BLOCK - 1) / BN_BLOCK; }
-    else { s.lanes = BN_BLOCK / s.Cs8; s.groups_per_thread = 1; }
+    const int T = (int)blockDim.x;                                   // 256 .. 1024 threads (reduce_grid)
+    if (s.Cs8 >= T) { s.lanes = 1; s.groups_per_thread = (s.Cs8 + T - 1) / T; }
+    else { s.lanes = T / s.Cs8; s.groups_per_thread = 1; }
     return s;
 }
 // block totals of the slab's channels -> partial[blockIdx.x][2][C]   (s, q: this thread's 8-channel sums)
@@ -83,7 +85,7 @@ __device__ __forceinline__ void slab_reduce(const Slab &sp, const int C, const i
             for (int j = 0; j < 8; ++j) { smem[(rl * 2 + 0) * Cs + lg * 8 + j] = s[j]; smem[(rl * 2 + 1) * Cs + lg * 8 + j] = q[j]; }
         }
         __syncthreads();
-        for (int c = threadIdx.x; c < 2 * Cs; c += BN_BLOCK) {          // c indexes [2][Cs]
+        for (int c = threadIdx.x; c < 2 * Cs; c += (int)blockDim.x) {   // c indexes [2][Cs]
             float t = 0.0f;
             for (int l = 0; l < sp.lanes; ++l) t += smem[l * 2 * Cs + c];
             const int which = c >= Cs ? 1 : 0;
@@ -138,13 +140,13 @@ inline int bn_order()
 // ---------------------------------------------------------------- forward statistics
 // partial[block][0][c] = sum x, partial[block][1][c] = sum x^2 over the block's rows
 template <int DT>
-__global__ __launch_bounds__(BN_BLOCK) void bn_stats_partial_kernel(const void *__restrict__ x, const int64_t M, const int C,
+__global__ __launch_bounds__(BN_RBLOCK_MAX) void bn_stats_partial_kernel(const void *__restrict__ x, const int64_t M, const int C,
                                                                     float *__restrict__ partial, const int order)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];      // [lanes][2][C]  (only when lanes > 1)
     const Slab sp = slab_of(C);
     for (int gi = 0; gi < sp.groups_per_thread; ++gi) {
-        const int lg = (sp.lanes > 1) ? (int)(threadIdx.x % sp.Cs8) : (int)threadIdx.x + gi * BN_BLOCK;
+        const int lg = (sp.lanes > 1) ? (int)(threadIdx.x % sp.Cs8) : (int)threadIdx.x + gi * (int)blockDim.x;
         const int rl = (sp.lanes > 1) ? (int)(threadIdx.x / sp.Cs8) : 0;
         const int cg = sp.cg0 + lg;
         const bool valid = lg < sp.Cs8 && rl < sp.lanes;
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_apply_kernel(const void *__restri
 // g = dy * (y > 0) (RELU) ; partial[block][0][c] = sum g, partial[block][1][c] = sum g * xhat
 // RELU: 0 = none, 1 = mask from y, 2 = mask recomputed from x (y is not read)
 template <int DT, int RELU>
-__global__ __launch_bounds__(BN_BLOCK) void bn_bwd_partial_kernel(const void *__restrict__ dy, const void *__restrict__ y,
+__global__ __launch_bounds__(BN_RBLOCK_MAX) void bn_bwd_partial_kernel(const void *__restrict__ dy, const void *__restrict__ y,
                                                                   const void *__restrict__ x, const int64_t M, const int C,
                                                                   const float *__restrict__ save_mean, const float *__restrict__ save_invstd,
                                                                   const float *__restrict__ fwd_a, const float *__restrict__ fwd_b,
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(BN_BLOCK) void bn_bwd_partial_kernel(const void *__
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Slab sp = slab_of(C);
     for (int gi = 0; gi < sp.groups_per_thread; ++gi) {
-        const int lg = (sp.lanes > 1) ? (int)(threadIdx.x % sp.Cs8) : (int)threadIdx.x + gi * BN_BLOCK;
+        const int lg = (sp.lanes > 1) ? (int)(threadIdx.x % sp.Cs8) : (int)threadIdx.x + gi * (int)blockDim.x;
         const int rl = (sp.lanes > 1) ? (int)(threadIdx.x / sp.Cs8) : 0;
         const int cg = sp.cg0 + lg;
         const bool valid = lg < sp.Cs8 && rl < sp.lanes;
@@ -429,8 +431,8 @@ int reduce_blocks(const int64_t M)
 // Grid of the two BN reduction kernels: x = row splits (each writes one partial per channel: at most 1 MiB of partials for
 // the per-channel kernel to read), y = channel slabs (>= 32 groups = 512-byte row segments) when the rows alone give fewer
 // than ~512 blocks.
-struct ReduceGrid { int row_splits, slabs; size_t lds; };
-ReduceGrid reduce_grid(const int64_t M, const int C)
+struct ReduceGrid { int row_splits, slabs, threads; size_t lds; };
+ReduceGrid reduce_grid(const int64_t M, const int C, const bool wide)
 {
     ReduceGrid g;
     const int C8 = C / 8;
@@ -441,8 +443,13 @@ ReduceGrid reduce_grid(const int64_t M, const int C)
     g.row_splits = (int)b;
     g.slabs = 1;
     while (g.row_splits * g.slabs * 2 <= 512 && C8 % (g.slabs * 2) == 0 && C8 / (g.slabs * 2) >= 32) g.slabs *= 2;
+    // 512-thread blocks for the backward reduction of residual layers (it reads a byte of ReLU mask per 16 bytes of gradient
+    // and wants the extra waves: -28 % at every layer size in the step); 256 everywhere else (512 / 1024: no gain or a loss)
+    static const int forced = [] { const char *e = getenv("RN_BN_RTHREADS"); return e ? atoi(e) : 0; }();
     const int Cs8 = C8 / g.slabs;
-    const int lanes = (Cs8 >= BN_BLOCK) ? 1 : BN_BLOCK / Cs8;
+    g.threads = wide ? 2 * BN_BLOCK : BN_BLOCK;
+    if (forced >= 64 && forced <= BN_RBLOCK_MAX) g.threads = forced;
+    const int lanes = (Cs8 >= g.threads) ? 1 : g.threads / Cs8;
     g.lds = lanes > 1 ? sizeof(float) * (size_t)lanes * 2 * (size_t)Cs8 * 8 : 0;
     return g;
 }
@@ -483,16 +490,16 @@ RN_API int rn_bn_act_forward(const void *x, const void *residual, void *y, int d
     float *ca = coef, *cb = coef + C;
     if (training) {
         if (!workspace || workspace_bytes < rn_bn_workspace_bytes(C)) return RN_EWORKSPACE;
-        const ReduceGrid rg = reduce_grid(M, C);
+        const ReduceGrid rg = reduce_grid(M, C, false);
         const int nb = rg.row_splits;
         const dim3 grid(rg.row_splits, rg.slabs);
         const size_t lds = rg.lds;
         const int order = bn_order();
         float *partial = (float *)workspace;
         switch (dtype) {
-            case RN_F32: hipLaunchKernelGGL((bn_stats_partial_kernel<RN_F32>), grid, dim3(BN_BLOCK), lds, st, x, M, C, partial, order); break;
-            case RN_BF16: hipLaunchKernelGGL((bn_stats_partial_kernel<RN_BF16>), grid, dim3(BN_BLOCK), lds, st, x, M, C, partial, order); break;
-            default: hipLaunchKernelGGL((bn_stats_partial_kernel<RN_F16>), grid, dim3(BN_BLOCK), lds, st, x, M, C, partial, order); break;
+            case RN_F32: hipLaunchKernelGGL((bn_stats_partial_kernel<RN_F32>), grid, dim3(rg.threads), lds, st, x, M, C, partial, order); break;
+            case RN_BF16: hipLaunchKernelGGL((bn_stats_partial_kernel<RN_BF16>), grid, dim3(rg.threads), lds, st, x, M, C, partial, order); break;
+            default: hipLaunchKernelGGL((bn_stats_partial_kernel<RN_F16>), grid, dim3(rg.threads), lds, st, x, M, C, partial, order); break;
         }
         RN_LAUNCH_CHECK();
         hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, st, partial, nb, M, C, gamma, beta, running_mean,
@@ -544,7 +551,7 @@ RN_API int rn_bn_act_backward(const void *dy, const void *y, const void *x, void
         !rn::aligned(save_invstd, 16))
         return RN_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-    const ReduceGrid rg = reduce_grid(M, C);
+    const ReduceGrid rg = reduce_grid(M, C, rmode == 3);
     const int nb = rg.row_splits;
     const dim3 grid(rg.row_splits, rg.slabs);
     const size_t lds = rg.lds;
@@ -552,10 +559,10 @@ RN_API int rn_bn_act_backward(const void *dy, const void *y, const void *x, void
     float *partial = (float *)workspace;
     float *ca = coef, *k0 = coef + C, *k1 = coef + 2 * C;
 #define RN_BN_BWD_PART(DT)                                                                                                             \
-    if (rmode == 1) hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 1>), grid, dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial, order); \
-    else if (rmode == 2) hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 2>), grid, dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial, order); \
-    else if (rmode == 3) hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 3>), grid, dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial, order); \
-    else hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 0>), grid, dim3(BN_BLOCK), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial, order);
+    if (rmode == 1) hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 1>), grid, dim3(rg.threads), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial, order); \
+    else if (rmode == 2) hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 2>), grid, dim3(rg.threads), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial, order); \
+    else if (rmode == 3) hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 3>), grid, dim3(rg.threads), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial, order); \
+    else hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 0>), grid, dim3(rg.threads), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial, order);
     switch (dtype) {
         case RN_F32: RN_BN_BWD_PART(RN_F32) break;
         case RN_BF16: RN_BN_BWD_PART(RN_BF16) break;

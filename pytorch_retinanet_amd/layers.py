@@ -215,13 +215,14 @@ class RetinaNetHead(nn.Module):
             # the 36-channel box conv is tiny per level (2 TFLOP/s on P7): run it on the canvas too and unpack its
             # small output instead of the 256-channel tower output
             box_c = rh.box_subnet_output(box_t)
-            box_levels = [_to_anchor_major(t, 4) for t in biasact.unpack_levels(cv, box_c)]
+            n_img = xb[0].shape[0]
+            box_levels = [_to_anchor_major(t, 4) for t in biasact.unpack_levels(cv, box_c, n_img)]
             if mfma and self.mfma_cls_output and biasact.cls_output_conv_fusable(cls_c, ch.class_subnet_output, cv):
                 # class-output conv straight from the canvas to dense per-level logits [N, h*w*A, K]: exactly A*K channels
                 # (no dead classes for the loss kernel to stream) and no unpack copy of the 256-channel tower output
-                return {"cls_levels": biasact.cls_output_conv(cls_c, ch.class_subnet_output, cv, ch.num_classes),
+                return {"cls_levels": biasact.cls_output_conv(cls_c, ch.class_subnet_output, cv, ch.num_classes, n_img),
                         "bbox_levels": box_levels}
-            cls_t = biasact.unpack_levels(cv, cls_c)
+            cls_t = biasact.unpack_levels(cv, cls_c, n_img)
             return {"cls_levels": ch.output_levels(cls_t, pad_classes), "bbox_levels": box_levels}
         return {"cls_levels": ch.forward_levels(xb, pad_classes), "bbox_levels": rh.forward_levels(xb)}
 

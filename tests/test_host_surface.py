@@ -207,32 +207,49 @@ def test_conv_stack_equals_reference_with_same_weights():
 
 
 def test_canvas_layout_and_pack_unpack_roundtrip_cpu():
-    """biasact.Canvas (pure host logic): level placement with and without the zero border, the mask, and that
-    unpack(pack(levels)) is the identity with zeros everywhere else (the torch fallbacks run on CPU)."""
+    """biasact.Canvas (pure host logic): level placement with and without the zero border, one and two images per sheet,
+    the mask and the position map of the level-mode kernels, and that unpack(pack(levels)) is the identity with zeros
+    everywhere else, also for an odd batch on two-slot sheets (the torch fallbacks run on CPU)."""
+    import numpy as np
     import torch
     from pytorch_retinanet_amd import biasact
     shapes = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
-    for pad, (H, W) in ((0, (151, 168)), (1, (153, 170))):
-        cv = biasact.Canvas(shapes, torch.device("cpu"), pad=pad)
-        assert (cv.H, cv.W) == (H, W) and int(cv.mask.sum()) == sum(h * w for h, w in shapes)
+    for pad, slots, (H, W) in ((0, 1, (151, 168)), (1, 1, (153, 170)), (1, 2, (280, 171)), (0, 2, (278, 169))):
+        cv = biasact.Canvas(shapes, torch.device("cpu"), pad=pad, slots=slots)
+        assert (cv.H, cv.W) == (H, W) and int(cv.mask.sum()) == slots * sum(h * w for h, w in shapes)
+        assert len(cv.regions) == slots * len(shapes) and len(cv.origin) == len(shapes)
         m = cv.mask.view(cv.H, cv.W)
-        for (r, c), (h, w) in zip(cv.origin, cv.shapes):
-            assert m[r:r + h, c:c + w].all()
+        mp = cv.map.view(cv.H, cv.W).numpy()
+        assert ((mp >= 0) == (m.numpy() == 1)).all()
+        for l, s_, r, c, h, w in cv.regions:
+            assert (h, w) == cv.shapes[l] and m[r:r + h, c:c + w].all()
             ring = m[max(r - 1, 0):r + h + 1, max(c - 1, 0):c + w + 1].sum()
-            assert int(ring) == h * w                      # a zero ring (or the canvas edge) around every level
+            assert int(ring) == h * w                      # a zero ring (or the canvas edge) around every rectangle
+            want = (s_ << 28) | (l << 24) | (np.arange(h)[:, None] * w + np.arange(w)[None, :])
+            assert (mp[r:r + h, c:c + w] == want).all()
         if pad:
             assert not m[0].any() and not m[-1].any() and not m[:, 0].any() and not m[:, -1].any()
+    # two images per sheet: 8 % fewer positions per image on the standard pyramid
+    one, two = biasact.Canvas(shapes, torch.device("cpu"), 1, 1), biasact.Canvas(shapes, torch.device("cpu"), 1, 2)
+    assert two.H * two.W / 2 < 0.925 * one.H * one.W and two.sheets(8) == 4 and two.sheets(3) == 2
     small = [(6, 8), (3, 4), (2, 2)]
+    for slots, N in ((1, 2), (2, 2), (2, 3)):
+        cv = biasact.Canvas(small, torch.device("cpu"), pad=1, slots=slots)
+        feats = [torch.randn(N, 8, h, w).contiguous(memory_format=torch.channels_last).requires_grad_(True) for h, w in small]
+        packed = biasact.pack_levels(cv, feats)
+        assert packed.shape == (cv.sheets(N), 8, cv.H, cv.W) and not packed[:, :, cv.mask.view(cv.H, cv.W) == 0].any()
+        if slots == 2 and N == 3:                          # image 2 = sheet 1, slot 0; slot 1 of sheet 1 stays empty
+            l, s_, r, c, h, w = [q for q in cv.regions if q[0] == 0 and q[1] == 1][0]
+            assert not packed[1, :, r:r + h, c:c + w].any()
+            l, s_, r, c, h, w = [q for q in cv.regions if q[0] == 1 and q[1] == 0][0]
+            assert torch.equal(packed[1, :, r:r + h, c:c + w], feats[1][2])
+        back = biasact.unpack_levels(cv, packed, N)
+        for a, b in zip(back, feats):
+            assert torch.equal(a, b)
+        sum((b * (i + 1)).sum() for i, b in enumerate(back)).backward()
+        for i, f in enumerate(feats):
+            assert torch.equal(f.grad, torch.full_like(f, float(i + 1)))
     cv = biasact.Canvas(small, torch.device("cpu"), pad=1)
-    feats = [torch.randn(2, 8, h, w).contiguous(memory_format=torch.channels_last).requires_grad_(True) for h, w in small]
-    packed = biasact.pack_levels(cv, feats)
-    assert packed.shape == (2, 8, cv.H, cv.W) and not packed[:, :, cv.mask.view(cv.H, cv.W) == 0].any()
-    back = biasact.unpack_levels(cv, packed)
-    for a, b in zip(back, feats):
-        assert torch.equal(a, b)
-    sum((b * (i + 1)).sum() for i, b in enumerate(back)).backward()
-    for i, f in enumerate(feats):
-        assert torch.equal(f.grad, torch.full_like(f, float(i + 1)))
     # bias_act's PyTorch path (what CPU tensors take)
     x = torch.randn(2, 8, cv.H, cv.W)
     y = biasact.bias_act(x, torch.arange(8.0), cv.mask, relu=True)

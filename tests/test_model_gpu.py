@@ -294,7 +294,7 @@ def test_head_on_canvas_equals_per_level_head():
     shapes = [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)]
     fm = [torch.randn(2, 256, h, w, device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True) for h, w in shapes]
     cv = biasact.Canvas.of(fm)
-    assert cv.H == 16 + 1 + 8 and cv.W == 10 + 1 + 5 + 1 + 3 + 1 + 2 and int(cv.mask.sum()) == sum(h * w for h, w in shapes)
+    assert cv.W == 20 and cv.slots == 1 and int(cv.mask.sum()) == sum(h * w for h, w in shapes)      # (no border: the MIOpen canvas)
     outs = {}
     for canvas in (False, True):
         head.zero_grad()
@@ -392,10 +392,13 @@ def test_head_mfma_towers_equal_miopen_towers_bf16():
         torch.testing.assert_close(outs[True][2][n].float(), a.float(), rtol=1e-1, atol=5e-2 * float(a.float().abs().max()))
 
 
-@pytest.mark.parametrize("N,K,shapes", [(2, 6, [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)]),        # Cout = 54: one tile, 54 % 8 = 6
-                                        (1, 90, [(13, 17), (7, 9), (4, 5)]),                      # Cout = 810: 4 tiles, 810 % 8 = 2
-                                        (3, 32, [(9, 11), (5, 6), (3, 3), (2, 2), (1, 1)])])      # Cout = 288: 2 tiles, multiple of 8
-def test_cls_output_conv_on_canvas_vs_torch(N, K, shapes):
+@pytest.mark.parametrize("N,K,shapes,slots", [(2, 6, [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)], 1),   # Cout = 54: one tile, 54 % 8 = 6
+                                              (2, 6, [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)], 2),   # the same, both images on one sheet
+                                              (1, 90, [(13, 17), (7, 9), (4, 5)], 1),                 # Cout = 810: 4 tiles, 810 % 8 = 2
+                                              (3, 90, [(13, 17), (7, 9), (4, 5)], 2),                 # odd batch: the last sheet's second slot is empty
+                                              (3, 32, [(9, 11), (5, 6), (3, 3), (2, 2), (1, 1)], 1),  # Cout = 288: 2 tiles, multiple of 8
+                                              (4, 32, [(9, 11), (5, 6), (3, 3), (2, 2), (1, 1)], 2)])
+def test_cls_output_conv_on_canvas_vs_torch(N, K, shapes, slots):
     """rn_conv3x3_canvas_to_levels / rn_conv3x3_levels_to_canvas / rn_conv3x3_levels_wgrad (the class-output conv of
     retinanet/layers.py:163-167 with dense 9*K-channel logits) vs torch's conv2d per level on the same bf16 values:
     outputs, input gradient, weight gradient, bias gradient."""
@@ -407,10 +410,11 @@ def test_cls_output_conv_on_canvas_vs_torch(N, K, shapes):
     torch.nn.init.normal_(conv.bias, std=0.5)
     feats = [torch.randn(N, 256, h, w, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
              for h, w in shapes]
-    cv = biasact.Canvas.of(feats, pad=1)
+    cv = biasact.Canvas.of(feats, pad=1, slots=slots)
     packed = biasact.pack_levels(cv, feats)
+    assert packed.shape[0] == (N + slots - 1) // slots
     assert biasact.cls_output_conv_fusable(packed, conv, cv)
-    ys = biasact.cls_output_conv(packed, conv, cv, K)
+    ys = biasact.cls_output_conv(packed, conv, cv, K, N)
     gys = [torch.randn_like(y) for y in ys]
     torch.autograd.backward(ys, gys)
     got = ([y.detach().float() for y in ys], [f.grad.float() for f in feats], conv.weight.grad.float().clone(), conv.bias.grad.float().clone())
