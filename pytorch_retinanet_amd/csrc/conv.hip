@@ -147,13 +147,16 @@ struct ConvProblem { const uint16_t *X, *W; const float *bias; uint16_t *Y; };
 
 __device__ __forceinline__ uint16_t f2bf(const float f) { return (uint16_t)(rn::dt<RN_BF16>::pk(f, 0.0f) & 0xffffu); }
 
+struct Walk { int tap, chunk; };      // position of the K walk
+
 template <int MODE>
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const ConvArgs args)
 {
     ConvProblem a;
     a.X = args.Xs[blockIdx.z]; a.W = args.Ws[blockIdx.z]; a.bias = args.biases[blockIdx.z]; a.Y = args.Ys[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];                 // [A0 A1 A2 | B0 B1] x 32 KiB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform: LDS-DMA bases and wave roles live in SGPRs
     const int wm = wave >> 2, wn = wave & 3;
     const int64_t m0 = (int64_t)blockIdx.x * CONV_BM;
     const int n0 = blockIdx.y * CONV_BN;
@@ -162,8 +165,11 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     unsigned char *const Abase = lds, *const Bbase = lds + 3 * TILE;
     // K walk.  CANVAS / TO_LEVELS: chunk outer, tap inner (a tile's input lines stay in L2 across its taps).
     // FROM_LEVELS: tap outer, chunk inner -- the gathered row pointers of a tap are computed once per 13 K-tiles.
-    auto tap_of = [&](const int kt) { return MODE == MODE_FROM_LEVELS ? kt / cpt : kt % 9; };
-    auto chunk_of = [&](const int kt) { return MODE == MODE_FROM_LEVELS ? kt % cpt : kt / 9; };
+    // The walk is kept as (tap, chunk, stage) counters -- no division in the loop.
+    auto advance = [&](Walk &w) {
+        if (MODE == MODE_FROM_LEVELS) { if (++w.chunk == cpt) { w.chunk = 0; ++w.tap; } }
+        else { if (++w.tap == 9) { w.tap = 0; ++w.chunk; } }
+    };
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -213,44 +219,78 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
 #pragma unroll
         for (int i = 0; i < 4; ++i) grow[i] = bperm_ptr(mine, i * 8 + (lane >> 3));
     };
-    auto piece_a = [&](const int kt, const int i) {
-        const int c0 = chunk_of(kt) * CONV_BK, t = tap_of(kt);
+    // Staging addresses.  A piece is one LDS-DMA wave instruction: 64 lanes x 16 bytes to consecutive LDS addresses from a
+    // wave-uniform base (M0).  Fast path (every tile whose taps stay inside the buffer; weights: every tile but a ragged last
+    // column tile): the source address is a wave-uniform 64-bit base -- tile origin + tap offset + channel chunk, SALU work
+    // -- plus a per-thread 32-bit offset computed once per kernel; the old per-piece 64-bit multiply / clamp VALU chains
+    // (~15 VALU each, 8 pieces per K-tile) made the load phases longer than the partner group's 16 MFMAs.
+    uint32_t voff_a[4], voff_b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
         const int q = i * CONV_THREADS + tid, row = q >> 3, cp = q & 7;
-        const uint16_t *g;
+        voff_a[i] = (uint32_t)(row * args.Cin + ((cp ^ SWZ(row)) << 3)) * 2u;
+        voff_b[i] = (uint32_t)(row * 9 * args.Cin + ((cp ^ SWZ(row)) << 3)) * 2u;
+    }
+    const bool a_edge = m0 - (args.Wp + 1) < 0 || m0 + CONV_BM + args.Wp + 1 > args.M;             // wave-uniform
+    const bool b_ragged = MODE == MODE_TO_LEVELS && n0 + CONV_BN > args.Cout;
+    auto lds_piece = [&](unsigned char *stage_base, const int i) {                                  // wave-uniform LDS base of piece i
+        return stage_base + i * (CONV_THREADS * 16) + wave * (RN_WAVE * 16);
+    };
+    auto piece_a = [&](const Walk w, const int stage, const int i) {
+        const int c0 = w.chunk * CONV_BK, t = w.tap;
+        const int q = i * CONV_THREADS + tid, row = q >> 3, cp = q & 7;
+        unsigned char *const sb = Abase + stage * TILE;
         if (MODE == MODE_FROM_LEVELS) {
             const int e = c0 + ((cp ^ SWZ(row)) << 3);                      // first channel of this 16-byte piece
             // pieces that start past the row end read zeros; the piece that straddles it (row_elems % 8 != 0) reads the row's
             // LAST 8 channels instead -- never past the row -- and the caller lays the weight's contraction axis out to
             // match: slots e .. e+7 = channels row_elems-8 .., zero weights on the repeated ones (rn_conv3x3_levels_to_canvas)
             const int es = e + 8 > args.lv.row_elems ? args.lv.row_elems - 8 : e;
-            g = (grow[i] && e < args.lv.row_elems) ? grow[i] + es : args.zeros + ((cp ^ SWZ(row)) << 3);
+            const uint16_t *g = (grow[i] && e < args.lv.row_elems) ? grow[i] + es : args.zeros + ((cp ^ SWZ(row)) << 3);
+            __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
         } else {
             const int off = (t / 3 - 1) * args.Wp + (t % 3 - 1);
-            int64_t m = m0 + row + off;
-            m = m < 0 ? 0 : (m >= args.M ? args.M - 1 : m);
-            g = a.X + m * args.Cin + c0 + ((cp ^ SWZ(row)) << 3);
+            if (!a_edge) {
+                const unsigned char *base = (const unsigned char *)a.X + ((m0 + off) * args.Cin + c0) * 2;
+                __builtin_amdgcn_global_load_lds((const void *)(base + voff_a[i]), (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
+            } else {
+                int64_t m = m0 + row + off;
+                m = m < 0 ? 0 : (m >= args.M ? args.M - 1 : m);
+                const uint16_t *g = a.X + m * args.Cin + c0 + ((cp ^ SWZ(row)) << 3);
+                __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
+            }
         }
-        __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)(Abase + (kt % 3) * TILE + q * 16), 16, 0, 0);
     };
-    auto piece_b = [&](const int kt, const int i) {
-        const int c0 = chunk_of(kt) * CONV_BK, t = tap_of(kt);
-        const int q = i * CONV_THREADS + tid, row = q >> 3, cp = q & 7;
-        const uint16_t *g = a.W + ((int64_t)(n0 + row) * 9 + t) * args.Cin + c0 + ((cp ^ SWZ(row)) << 3);
-        if (MODE == MODE_TO_LEVELS && n0 + row >= args.Cout) g = args.zeros + ((cp ^ SWZ(row)) << 3);      // output channels past Cout
-        __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)(Bbase + (kt & 1) * TILE + q * 16), 16, 0, 0);
+    auto piece_b = [&](const Walk w, const int stage, const int i) {
+        const int c0 = w.chunk * CONV_BK, t = w.tap;
+        unsigned char *const sb = Bbase + stage * TILE;
+        if (!b_ragged) {
+            const unsigned char *base = (const unsigned char *)a.W + (((int64_t)n0 * 9 + t) * args.Cin + c0) * 2;
+            __builtin_amdgcn_global_load_lds((const void *)(base + voff_b[i]), (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
+        } else {
+            const int q = i * CONV_THREADS + tid, row = q >> 3, cp = q & 7;
+            const uint16_t *g = a.W + ((int64_t)(n0 + row) * 9 + t) * args.Cin + c0 + ((cp ^ SWZ(row)) << 3);
+            if (n0 + row >= args.Cout) g = args.zeros + ((cp ^ SWZ(row)) << 3);      // output channels past Cout
+            __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
+        }
     };
+    Walk wa = {0, 0}, wb = {0, 0};                                  // K-tile whose A / B pieces are issued next
+    int sa = 0;                                                     // its A stage (mod 3)
     if (MODE == MODE_FROM_LEVELS) gather_tap(0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) piece_a(0, i);
+    for (int i = 0; i < 4; ++i) piece_a(wa, 0, i);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) piece_b(0, i);
+    for (int i = 0; i < 4; ++i) piece_b(wb, 0, i);
+    advance(wa); advance(wb);                                       // -> K-tile 1
     if (MODE == MODE_FROM_LEVELS && cpt == 1) {
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // the fetch of tap 1 is older than tile 0's 8 pieces
         map_landed(g_entry);
         gather_tap(1);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) piece_a(1, i);
+    for (int i = 0; i < 4; ++i) piece_a(wa, 1, i);
+    advance(wa);                                                    // -> K-tile 2
+    sa = 2;
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     if (MODE == MODE_FROM_LEVELS) map_landed(g_entry);
     __builtin_amdgcn_s_barrier();
@@ -275,14 +315,17 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     __builtin_amdgcn_sched_barrier(0);                                             \
     __builtin_amdgcn_s_barrier();
 
+    int scur = 0;                                                   // A stage of K-tile kt (mod 3)
     for (int kt = 0; kt < KT; ++kt) {
-        const uint32_t abase = lds_base + (uint32_t)((kt % 3) * TILE), bbase = lds_base + (uint32_t)(3 * TILE + (kt & 1) * TILE);
+        const uint32_t abase = lds_base + (uint32_t)(scur * TILE), bbase = lds_base + (uint32_t)(3 * TILE + (kt & 1) * TILE);
+        scur = scur == 2 ? 0 : scur + 1;
         // load phase 2kt: fragments of k-steps 0,1; the weight pieces of tile kt+1
         RN_LOAD_FRAGS(0, 0) RN_LOAD_FRAGS(1, 1)
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < KT) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) piece_b(kt + 1, i);
+            for (int i = 0; i < 4; ++i) piece_b(wb, (kt + 1) & 1, i);
+            advance(wb);
         }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -291,9 +334,11 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
         RN_LOAD_FRAGS(2, 0) RN_LOAD_FRAGS(3, 1)
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 2 < KT) {
-            if (MODE == MODE_FROM_LEVELS && (kt + 2) % cpt == 0) gather_tap((kt + 2) / cpt);     // wave-uniform: a new tap starts
+            if (MODE == MODE_FROM_LEVELS && wa.chunk == 0) gather_tap(wa.tap);     // wave-uniform: a new tap starts
 #pragma unroll
-            for (int i = 0; i < 4; ++i) piece_a(kt + 2, i);
+            for (int i = 0; i < 4; ++i) piece_a(wa, sa, i);
+            advance(wa);
+            sa = sa == 2 ? 0 : sa + 1;
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             if (MODE == MODE_FROM_LEVELS) map_landed(g_entry);
         } else {
@@ -401,7 +446,8 @@ template <bool GATHER>
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const WgradArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];                 // [G0 G1 G2 | X0 X1] x 32 KiB
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform (LDS-DMA bases, wave roles)
     const int wm = wave >> 2, wn = wave & 3;
     const int split = blockIdx.x, tap = blockIdx.y, prob = blockIdx.z;
     const uint16_t *__restrict__ G = a.Gs[prob], *__restrict__ X = a.Xs[GATHER ? 0 : prob];
@@ -435,15 +481,33 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
 
-    // staging: tile row = position, 32 chunks of 16 B; LDS position (row, cp) holds global chunk cp ^ ((row & 3) << 2)
-    auto piece_b = [&](const int kt, const int i) {
+    // staging: tile row = position, 32 chunks of 16 B; LDS position (row, cp) holds global chunk cp ^ ((row & 3) << 2).
+    // As in the forward kernel: wave-uniform 64-bit base per K-tile + a per-thread 32-bit offset for every K-tile that lies
+    // inside the buffer; the clamping per-lane path only for the first / last ones.
+    uint32_t voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
         const int qi = i * CONV_THREADS + tid, row = qi >> 5, cp = qi & 31;
-        const int64_t m = m_begin + (int64_t)kt * WG_POS + row;
-        int64_t ms = m + off;
-        ms = ms < 0 ? 0 : (ms >= a.M ? a.M - 1 : ms);
-        const uint16_t *g = X + ms * 256 + ((cp ^ ((row & 3) << 2)) << 3);
-        if (m >= a.M) g = a.zeros + ((cp & 15) << 3);             // positions past the end contribute nothing
-        __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)(Bbase + (kt & 1) * TILE + qi * 16), 16, 0, 0);
+        voff[i] = (uint32_t)(row * 512 + ((cp ^ ((row & 3) << 2)) << 4));
+    }
+    auto lds_piece = [&](unsigned char *stage_base, const int i) {
+        return stage_base + i * (CONV_THREADS * 16) + wave * (RN_WAVE * 16);
+    };
+    auto piece_b = [&](const int kt, const int i) {
+        const int64_t t0 = m_begin + (int64_t)kt * WG_POS;                                   // first position of the K-tile
+        unsigned char *const sb = Bbase + (kt & 1) * TILE;
+        if (t0 + off >= 0 && t0 + off + WG_POS <= a.M) {                                      // wave-uniform
+            const unsigned char *base = (const unsigned char *)X + (t0 + off) * 512;
+            __builtin_amdgcn_global_load_lds((const void *)(base + voff[i]), (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
+        } else {
+            const int qi = i * CONV_THREADS + tid, row = qi >> 5, cp = qi & 31;
+            const int64_t m = t0 + row;
+            int64_t ms = m + off;
+            ms = ms < 0 ? 0 : (ms >= a.M ? a.M - 1 : ms);
+            const uint16_t *g = X + ms * 256 + ((cp ^ ((row & 3) << 2)) << 3);
+            if (m >= a.M) g = a.zeros + ((cp & 15) << 3);             // positions past the end contribute nothing
+            __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
+        }
     };
     // GATHER: a wave stages rows i * 16 + wave * 2 + (lane >> 5), i = 0..3, of a K-tile: 8 distinct rows.  Lane j < 8 looks up
     // row (j >> 1) * 16 + wave * 2 + (j & 1) and the wave shares the pointers by shuffles (1 lookup per lane, not 4).
@@ -470,26 +534,31 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
         grow[0] = pair_ptr<0, 1>(mine, second); grow[1] = pair_ptr<2, 3>(mine, second);
         grow[2] = pair_ptr<4, 5>(mine, second); grow[3] = pair_ptr<6, 7>(mine, second);
     };
-    auto piece_a = [&](const int kt, const int i) {
+    auto piece_a = [&](const int kt, const int stage, const int i) {
         const int qi = i * CONV_THREADS + tid, row = qi >> 5, cp = qi & 31;
-        const int64_t m = m_begin + (int64_t)kt * WG_POS + row;
-        const uint16_t *g;
+        const int64_t t0 = m_begin + (int64_t)kt * WG_POS;
+        unsigned char *const sb = Abase + stage * TILE;
         if (GATHER) {
             const int e = prob * 256 + ((cp ^ ((row & 3) << 2)) << 3);          // first output channel of this 16-byte piece
             // the piece that straddles the row end reads the row's last 8 channels instead (never past the row); the
             // reduction kernel writes its dW rows to the channels they really are
             const int es = e + 8 > a.lv.row_elems ? a.lv.row_elems - 8 : e;
-            g = (grow[i] && e < a.lv.row_elems) ? grow[i] + es : a.zeros + ((cp & 15) << 3);
+            const uint16_t *g = (grow[i] && e < a.lv.row_elems) ? grow[i] + es : a.zeros + ((cp & 15) << 3);
+            __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
+        } else if (t0 + WG_POS <= a.M) {                                          // wave-uniform
+            const unsigned char *base = (const unsigned char *)G + t0 * 512;
+            __builtin_amdgcn_global_load_lds((const void *)(base + voff[i]), (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
         } else {
+            const int64_t m = t0 + row;
             const int64_t ms = m >= a.M ? a.M - 1 : m;
-            g = G + ms * 256 + ((cp ^ ((row & 3) << 2)) << 3);
+            const uint16_t *g = G + ms * 256 + ((cp ^ ((row & 3) << 2)) << 3);
             if (m >= a.M) g = a.zeros + ((cp & 15) << 3);
+            __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
         }
-        __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)(Abase + (kt % 3) * TILE + qi * 16), 16, 0, 0);
     };
     if (GATHER) gather_rows(0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) piece_a(0, i);
+    for (int i = 0; i < 4; ++i) piece_a(0, 0, i);
 #pragma unroll
     for (int i = 0; i < 4; ++i) piece_b(0, i);
     if (KT > 1) {
@@ -499,7 +568,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
             gather_rows(1);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) piece_a(1, i);
+        for (int i = 0; i < 4; ++i) piece_a(1, 1, i);
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         if (GATHER) map_landed(w_entry);
     } else {
@@ -531,8 +600,10 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
     __builtin_amdgcn_sched_barrier(0);                                             \
     __builtin_amdgcn_s_barrier();
 
+    int scur = 0, sa = 2;                                           // A stages (mod 3) of K-tiles kt and kt + 2
     for (int kt = 0; kt < KT; ++kt) {
-        const uint32_t abase = lds_base + (uint32_t)((kt % 3) * TILE), bbase = lds_base + (uint32_t)(3 * TILE + (kt & 1) * TILE);
+        const uint32_t abase = lds_base + (uint32_t)(scur * TILE), bbase = lds_base + (uint32_t)(3 * TILE + (kt & 1) * TILE);
+        scur = scur == 2 ? 0 : scur + 1;
         // k-step kk covers positions 16kk .. 16kk+15 of the tile: byte offsets 16*kk*512 (+ 4*512 for the second k half)
         RN_LOAD_FRAGS(0, 2048, 0) RN_LOAD_FRAGS(8192, 10240, 1)
         __builtin_amdgcn_sched_barrier(0);
@@ -548,7 +619,8 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
         if (kt + 2 < KT) {
             if (GATHER) gather_rows(kt + 2);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) piece_a(kt + 2, i);
+            for (int i = 0; i < 4; ++i) piece_a(kt + 2, sa, i);
+            sa = sa == 2 ? 0 : sa + 1;
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             if (GATHER) map_landed(w_entry);
         } else {
