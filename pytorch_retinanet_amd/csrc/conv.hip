@@ -402,13 +402,20 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
             }
         }
     } else {
+        // position of the tile's first row on its sheet: one scalar 64-bit modulo per tile, then 32-bit steps
+        const int64_t pos0 = m0 % args.HWp;
+        const bool one_wrap = args.HWp >= CONV_BM;                  // the tile crosses at most one sheet boundary
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int q = i * CONV_THREADS + tid, row = q >> 5, piece = q & 31;
             const int64_t m = m0 + row;
             if (m < args.M) {
                 uint4 v = *(const uint4 *)(Ys + row * CONV_BN + piece * 8);
-                if (args.mask && !args.mask[m % args.HWp]) v = make_uint4(0, 0, 0, 0);
+                if (args.mask) {
+                    int64_t pos = pos0 + row;
+                    if (one_wrap) pos = pos >= args.HWp ? pos - args.HWp : pos; else pos %= args.HWp;
+                    if (!args.mask[pos]) v = make_uint4(0, 0, 0, 0);
+                }
                 *(uint4 *)(a.Y + m * args.Cout + n0 + piece * 8) = v;
             }
         }
