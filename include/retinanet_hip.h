@@ -220,6 +220,25 @@ int rn_conv3x3_canvas_wgrad_batched(const void *const *gs, const void *const *xs
                                     int64_t M, int Wp, int Cin, int Cout, const void *zeros, void *workspace,
                                     size_t workspace_bytes, void *stream);
 
+/* rn_conv3x3_canvas_batched that also writes, per problem, the ReLU bits of its outputs: relu_mask_outs[p] = [M][Cout / 8]
+ * bytes, bit j of byte (m, c / 8) = [ys[p][m][c + j] > 0] (relu must be set; 16-byte aligned).
+ * Data gradient of P tower convs whose INPUT was the ReLU output of the layer below (retinanet/layers.py:143-171: conv +
+ * ReLU pairs), with that layer's ReLU backward and bias gradient fused into the epilogue:
+ *   ys[p] = conv3x3(gs[p], ws[p]) * mask * relu_bits[p],   dbiases[p][c] = sum over positions of ys[p][., c]
+ * gs: gradients at the conv outputs [M][Cin]; ws: the forward weights with taps reversed and channel roles swapped,
+ * [Cout][3][3][Cin]; relu_masks[p]: the ReLU bits of the conv's forward INPUT (= the layer below's relu_mask_outs), [M][Cout / 8];
+ * dbiases: f32 [Cout] each.  ys[p] is the gradient at the PRE-activation of the layer below (what rn_bias_act_backward
+ * would produce from the plain data gradient), so that layer needs no pass of its own.  Column sums: one partial row per
+ * 256-position tile in `workspace` (rn_conv3x3_colsum_workspace_bytes), reduced in double in a fixed order. */
+int rn_conv3x3_canvas_batched_ex(const void *const *xs, const void *const *ws, const float *const *biases,
+                                 const uint8_t *mask, void *const *ys, uint8_t *const *relu_mask_outs, int P, int dtype, int64_t M,
+                                 int64_t HWp, int Wp, int Cin, int Cout, int relu, void *stream);
+size_t rn_conv3x3_colsum_workspace_bytes(int P, int64_t M, int Cout);
+int rn_conv3x3_canvas_dgrad_relu_batched(const void *const *gs, const void *const *ws, const uint8_t *const *relu_masks,
+                                         const uint8_t *mask, void *const *ys, float *const *dbiases, int P, int dtype,
+                                         int64_t M, int64_t HWp, int Wp, int Cin, int Cout, void *workspace,
+                                         size_t workspace_bytes, void *stream);
+
 /* ---- class-output conv on the canvas with DENSE per-level results -----------------------------------------------
  * The last 3x3 conv of the classification subnet (retinanet/layers.py:163-167: 256 -> 9*K channels) reads the tower
  * output where it lies -- on the zero-bordered canvas -- and writes, per pyramid level, the dense channels-last

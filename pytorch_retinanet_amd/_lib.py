@@ -68,6 +68,10 @@ SIGNATURES = {
                                               C.c_int, _vp, _vp]),
     "rn_conv3x3_levels_wgrad": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp,
                                           _sz, _vp]),
+    "rn_conv3x3_canvas_batched_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _i64, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "rn_conv3x3_colsum_workspace_bytes": (_sz, [C.c_int, _i64, C.c_int]),
+    "rn_conv3x3_canvas_dgrad_relu_batched": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _i64, _i64, C.c_int, C.c_int, C.c_int,
+                                                       _vp, _sz, _vp]),
     "rn_conv3x3_wgrad_workspace_bytes": (_sz, [C.c_int, _i64]),
     "rn_conv3x3_canvas_wgrad_batched": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _sz, _vp]),
     "rn_transform_batch": (C.c_int, [_vp, _vp, _vp, C.c_int, C.POINTER(_f32), C.POINTER(_f32), C.c_int, C.c_int, _vp,

@@ -177,12 +177,30 @@ def _ptr_array(ts):
     return (C.c_void_p * len(ts))(*[t.data_ptr() if t is not None else 0 for t in ts])
 
 
+class TowerLink:
+    """Hand-over between consecutive ``_TowerConvPair`` layers of one tower pair in backward.  When layer l's inputs are the
+    ReLU outputs of layer l - 1 and feed nothing else (``tower_conv_pair(..., prev=link)``), layer l's data-gradient kernel
+    also applies layer l - 1's ReLU mask and sums the columns (``rn_conv3x3_canvas_dgrad_relu_batched``): what it returns as
+    the input gradients IS layer l - 1's pre-activation gradient, and the bias gradients wait here.  Layer l - 1 uses them
+    only if the gradient tensors autograd hands it are exactly the ones layer l returned -- same storage AND same version
+    counter: when the output has another consumer autograd may add that gradient IN PLACE into the returned buffer -- ;
+    anything else takes the ordinary ``rn_bias_act_backward`` pass (masking a pre-masked gradient again is harmless)."""
+    __slots__ = ("ptrs", "dbias", "relu_masks")
+
+    def __init__(self):
+        self.ptrs, self.dbias, self.relu_masks = None, None, None     # relu_masks: the ReLU bits of the layer's outputs (forward)
+
+
+_CS_WS: Dict[tuple, Tensor] = {}
+FUSE_TOWER_RELU_BWD = os.environ.get("RN_FUSE_TOWER_RELU_BWD", "1") != "0"
+
+
 class _TowerConvPair(torch.autograd.Function):
     """``_TowerConv`` for two towers of identical geometry (cls and box) in one batched launch each way: their tiles
-    together fill the chip's workgroup waves (2 x 813 tiles: 7 waves of 256 instead of 2 x 4)."""
+    together fill the chip's workgroup waves.  ``prev`` / ``link``: see ``TowerLink``."""
 
     @staticmethod
-    def forward(ctx, x0, x1, w0, w1, b0, b1, mask):
+    def forward(ctx, x0, x1, w0, w1, b0, b1, mask, prev, link):
         N, Cin, Hp, Wp = x0.shape
         Cout = w0.shape[0]
         dev = x0.device
@@ -192,11 +210,18 @@ class _TowerConvPair(torch.autograd.Function):
         w0 = w0 if _cl(w0) else w0.contiguous(memory_format=torch.channels_last)
         w1 = w1 if _cl(w1) else w1.contiguous(memory_format=torch.channels_last)
         ys = [torch.empty((N, Cout, Hp, Wp), dtype=x0.dtype, device=dev, memory_format=torch.channels_last) for _ in range(2)]
+        rms = None
+        if link is not None and FUSE_TOWER_RELU_BWD and any(ctx.needs_input_grad[:6]):
+            rms = [torch.empty((N * Hp * Wp * (Cout // 8),), dtype=torch.uint8, device=dev) for _ in range(2)]
         _mfma_call("mfma_tower_fwd_x2", dev, 2 * 2.0 * N * Hp * Wp * Cout * 9 * Cin,
-                   lambda: lib.rn_conv3x3_canvas_batched(_ptr_array([x0, x1]), _ptr_array([w0, w1]), _ptr_array([b0, b1]), mask.data_ptr(),
-                                                         _ptr_array(ys), 2, _DT[x0.dtype], N * Hp * Wp, Hp * Wp, Wp, Cin, Cout, 1, stream),
-                   "rn_conv3x3_canvas_batched")
+                   lambda: lib.rn_conv3x3_canvas_batched_ex(_ptr_array([x0, x1]), _ptr_array([w0, w1]), _ptr_array([b0, b1]), mask.data_ptr(),
+                                                            _ptr_array(ys), _ptr_array(rms) if rms else None, 2, _DT[x0.dtype], N * Hp * Wp,
+                                                            Hp * Wp, Wp, Cin, Cout, 1, stream),
+                   "rn_conv3x3_canvas_batched_ex")
+        if link is not None:
+            link.relu_masks = rms
         ctx.save_for_backward(x0, x1, w0, w1, ys[0], ys[1], mask)
+        ctx.prev, ctx.link = prev, link
         return ys[0], ys[1]
 
     @staticmethod
@@ -209,33 +234,58 @@ class _TowerConvPair(torch.autograd.Function):
             torch.cuda.set_device(dev)
         stream = torch.cuda.current_stream().cuda_stream
         M = N * Hp * Wp
+        link, prev = ctx.link, ctx.prev
         gs, dbs = [], []
-        wp, wn = _workspace(dev, stream, Cout)
-        for dy, y in ((dy0, y0), (dy1, y1)):
-            if dy.dtype != x0.dtype or not _cl(dy):
-                dy = dy.to(x0.dtype).contiguous(memory_format=torch.channels_last)
-            g = torch.empty_like(dy)
-            db = torch.empty((Cout,), dtype=torch.float32, device=dev)
-            check(lib.rn_bias_act_backward(dy.data_ptr(), y.data_ptr(), mask.data_ptr(), g.data_ptr(), db.data_ptr(), _DT[x0.dtype],
-                                           M, Cout, Hp * Wp, 1, wp, wn, stream), "rn_bias_act_backward")
-            gs.append(g); dbs.append(db)
+        if (link is not None and link.ptrs is not None
+                and link.ptrs == (dy0.data_ptr(), dy0._version, dy1.data_ptr(), dy1._version)
+                and dy0.dtype == x0.dtype and _cl(dy0) and _cl(dy1)):
+            gs, dbs = [dy0, dy1], list(link.dbias)            # the layer above already applied this layer's ReLU mask
+        else:
+            wp, wn = _workspace(dev, stream, Cout)
+            for dy, y in ((dy0, y0), (dy1, y1)):
+                if dy.dtype != x0.dtype or not _cl(dy):
+                    dy = dy.to(x0.dtype).contiguous(memory_format=torch.channels_last)
+                g = torch.empty_like(dy)
+                db = torch.empty((Cout,), dtype=torch.float32, device=dev)
+                check(lib.rn_bias_act_backward(dy.data_ptr(), y.data_ptr(), mask.data_ptr(), g.data_ptr(), db.data_ptr(), _DT[x0.dtype],
+                                               M, Cout, Hp * Wp, 1, wp, wn, stream), "rn_bias_act_backward")
+                gs.append(g); dbs.append(db)
+        if link is not None:
+            link.ptrs, link.dbias = None, None
         dxs = [None, None]
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             wts = [w.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last) for w in (w0, w1)]
             dxs = [torch.empty_like(x0), torch.empty_like(x1)]
-            _mfma_call("mfma_tower_dgrad_x2", dev, 2 * 2.0 * M * Cout * 9 * Cin,
-                       lambda: lib.rn_conv3x3_canvas_batched(_ptr_array(gs), _ptr_array(wts), None, mask.data_ptr(), _ptr_array(dxs), 2,
-                                                             _DT[x0.dtype], M, Hp * Wp, Wp, Cout, Cin, 0, stream), "rn_conv3x3_canvas_batched")
+            if prev is not None and prev.relu_masks is not None and Cin == Cout:
+                need = lib.rn_conv3x3_colsum_workspace_bytes(2, M, Cin)
+                key = (dev.index, stream)
+                wsb = _CS_WS.get(key)
+                if wsb is None or wsb.numel() < need:
+                    wsb = _CS_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
+                dbp = [torch.empty((Cin,), dtype=torch.float32, device=dev) for _ in range(2)]
+                _mfma_call("mfma_tower_dgrad_x2", dev, 2 * 2.0 * M * Cout * 9 * Cin,
+                           lambda: lib.rn_conv3x3_canvas_dgrad_relu_batched(_ptr_array(gs), _ptr_array(wts), _ptr_array(prev.relu_masks), mask.data_ptr(),
+                                                                            _ptr_array(dxs), _ptr_array(dbp), 2, _DT[x0.dtype], M, Hp * Wp, Wp,
+                                                                            Cout, Cin, wsb.data_ptr(), wsb.numel(), stream),
+                           "rn_conv3x3_canvas_dgrad_relu_batched")
+                prev.ptrs, prev.dbias = (dxs[0].data_ptr(), dxs[0]._version, dxs[1].data_ptr(), dxs[1]._version), dbp
+            else:
+                _mfma_call("mfma_tower_dgrad_x2", dev, 2 * 2.0 * M * Cout * 9 * Cin,
+                           lambda: lib.rn_conv3x3_canvas_batched(_ptr_array(gs), _ptr_array(wts), None, mask.data_ptr(), _ptr_array(dxs), 2,
+                                                                 _DT[x0.dtype], M, Hp * Wp, Wp, Cout, Cin, 0, stream), "rn_conv3x3_canvas_batched")
         dws = _canvas_wgrad(gs, [x0, x1], [w0, w1], Wp, stream)
         if dws is None:
             dws = [torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
                    for g, x, w in ((gs[0], x0, w0), (gs[1], x1, w1))]
-        return dxs[0], dxs[1], dws[0], dws[1], dbs[0], dbs[1], None
+        return dxs[0], dxs[1], dws[0], dws[1], dbs[0], dbs[1], None, None, None
 
 
-def tower_conv_pair(x0: Tensor, x1: Tensor, w0: Tensor, w1: Tensor, b0: Tensor, b1: Tensor, mask: Tensor):
-    "Two ``tower_conv`` of identical geometry (Cin == Cout % 256 == 0) in one launch each way."
-    return _TowerConvPair.apply(x0, x1, w0.to(x0.dtype), w1.to(x0.dtype), b0, b1, mask)
+def tower_conv_pair(x0: Tensor, x1: Tensor, w0: Tensor, w1: Tensor, b0: Tensor, b1: Tensor, mask: Tensor,
+                    prev: Optional[TowerLink] = None, link: Optional[TowerLink] = None):
+    """Two ``tower_conv`` of identical geometry (Cin == Cout % 256 == 0) in one launch each way.  Chaining: pass the
+    ``link`` given to the layer below as ``prev`` here when (x0, x1) are that layer's outputs and feed NOTHING else; its
+    ReLU backward and bias gradient then ride in this layer's data-gradient kernel (``TowerLink``)."""
+    return _TowerConvPair.apply(x0, x1, w0.to(x0.dtype), w1.to(x0.dtype), b0, b1, mask, prev, link)
 
 
 def tower_conv_fusable(x: Tensor, conv) -> bool:

@@ -139,6 +139,12 @@ struct ConvArgs {
     uint16_t *Ys[CONV_MAX_PROBLEMS];            // [M][Cout] bf16 (unused in TO_LEVELS mode)
     const uint8_t *mask;    // [HWp] or null (1 = keep)
     const uint16_t *zeros;  // >= 256 B of zeros: weight rows past Cout, gap positions and channel chunks past the row end
+    // data-gradient epilogue of a conv whose INPUT was a ReLU output (the head towers): the result is also multiplied by
+    // [relu_src > 0] (as a bit mask the forward conv of the layer below wrote) and its column sums -- the bias gradient of the layer below -- go to
+    // colsum[p] as one partial row per row tile, [tiles_m][Cout] f32; both null otherwise
+    const uint8_t *relu_masks[CONV_MAX_PROBLEMS];  // [M][Cout / 8] bytes: bit j of byte (m, c / 8) = [relu_src[m][c + j] > 0]
+    float *colsums[CONV_MAX_PROBLEMS];
+    uint8_t *relu_mask_outs[CONV_MAX_PROBLEMS];    // forward with ReLU: the same mask of the OUTPUT, written by the epilogue (or null)
     int64_t M, HWp;
     int Cin, Cout, Wp, relu;    // Cin = channels walked per tap (FROM_LEVELS: the padded row length, a multiple of 64)
     LevelSet lv;
@@ -357,6 +363,14 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     __syncthreads();
     uint16_t *Ys = (uint16_t *)lds;                               // [256][256] bf16 output tile = 128 KiB
     uint16_t **Yrow = (uint16_t **)(lds + CONV_BM * CONV_BN * 2);  // TO_LEVELS: destination row of each tile row (2 KiB)
+    float *s_cs = (float *)(lds + CONV_BM * CONV_BN * 2 + 2048);  // fused ReLU backward: column sums [16][256] f32 (16 KiB)
+    uint8_t *s_rmask = lds + CONV_BM * CONV_BN * 2 + 2048 + 16384; //   and the tile's ReLU bits [256][32] bytes (8 KiB)
+    const uint8_t *relu_mask = MODE == MODE_TO_LEVELS ? nullptr : args.relu_masks[blockIdx.z];
+    uint4 rm_pre = make_uint4(0, 0, 0, 0);
+    if (relu_mask) {                                              // fetched now, consumed after the staging below: latency hidden
+        const int row = tid >> 1, half = tid & 1;
+        if (m0 + row < args.M) rm_pre = *(const uint4 *)(relu_mask + (m0 + row) * (args.Cout >> 3) + (n0 >> 3) + half * 16);
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -381,6 +395,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
         }
         Yrow[tid] = dst;
     }
+    if (relu_mask) *(uint4 *)(s_rmask + tid * 16) = rm_pre;
     __syncthreads();
     if (MODE == MODE_TO_LEVELS) {
         // dense rows of Cout elements start on 4-byte boundaries only (Cout even): 16-byte stores to dword-aligned
@@ -404,6 +419,8 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     } else {
         // position of the tile's first row on its sheet: one scalar 64-bit modulo per tile, then 32-bit steps
         const int64_t pos0 = m0 % args.HWp;
+        uint8_t *rmask_out = MODE == MODE_TO_LEVELS ? nullptr : args.relu_mask_outs[blockIdx.z];
+        float cs[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         const bool one_wrap = args.HWp >= CONV_BM;                  // the tile crosses at most one sheet boundary
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -416,7 +433,41 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
                     if (one_wrap) pos = pos >= args.HWp ? pos - args.HWp : pos; else pos %= args.HWp;
                     if (!args.mask[pos]) v = make_uint4(0, 0, 0, 0);
                 }
+                if (relu_mask) {
+                    const uint32_t bits = s_rmask[row * 32 + piece];
+                    uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {                    // two bf16 per word
+                        vw[j] &= ((bits >> (2 * j)) & 1u ? 0x0000ffffu : 0u) | ((bits >> (2 * j + 1)) & 1u ? 0xffff0000u : 0u);
+                        cs[2 * j] += __uint_as_float(vw[j] << 16);
+                        cs[2 * j + 1] += __uint_as_float(vw[j] & 0xffff0000u);
+                    }
+                    v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+                }
+                if (rmask_out) {                                     // forward: the ReLU bits of what is stored (y > 0 as floats: NaN no)
+                    const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+                    uint32_t bits = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bits |= (__uint_as_float(vw[j] << 16) > 0.0f ? 1u : 0u) << (2 * j);
+                        bits |= (__uint_as_float(vw[j] & 0xffff0000u) > 0.0f ? 1u : 0u) << (2 * j + 1);
+                    }
+                    rmask_out[m * (args.Cout >> 3) + (n0 >> 3) + piece] = (uint8_t)bits;
+                }
                 *(uint4 *)(a.Y + m * args.Cout + n0 + piece * 8) = v;
+            }
+        }
+        if (relu_mask) {
+            // a thread owns one 8-column piece over 16 rows; the 16 threads of a piece (tid & 31 equal) meet in LDS behind the
+            // staged tile, then 256 threads write the tile's column sums
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s_cs[(tid >> 5) * CONV_BN + (tid & 31) * 8 + j] = cs[j];
+            __syncthreads();
+            if (tid < CONV_BN) {
+                float t = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += s_cs[r * CONV_BN + tid];
+                args.colsums[blockIdx.z][(int64_t)blockIdx.x * args.Cout + n0 + tid] = t;
             }
         }
     }
@@ -690,6 +741,38 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     *(rn::u32x2 *)(dw + ((int64_t)n_out * 9 + t) * 256 + c) = o;
 }
 
+
+// Column sums of a fused data-gradient epilogue: partial [P][tiles][C] f32 (one row per row tile) -> out[p][C] f32, summed in
+// double in a fixed order (deterministic).  Block = 8 channels x 32 lanes over the tiles.
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restrict__ partial, const int tiles, const int C, float *out0,
+                                                            float *out1, float *out2, float *out3)
+{
+    __shared__ double sh[32][8];
+    const int p = blockIdx.y, ch = threadIdx.x & 7, ln = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + ch;
+    const float *src = partial + (int64_t)p * tiles * C;
+    double s = 0.0;
+    if (c < C) {
+        int b = ln;
+        for (; b + 96 < tiles; b += 128) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = src[(int64_t)(b + 32 * u) * C + c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) s += (double)v[u];
+        }
+        for (; b < tiles; b += 32) s += (double)src[(int64_t)b * C + c];
+    }
+    sh[ln][ch] = s;
+    __syncthreads();
+    if (ln == 0 && c < C) {
+        double t = 0.0;
+        for (int l = 0; l < 32; ++l) t += sh[l][ch];
+        float *out = p == 0 ? out0 : (p == 1 ? out1 : (p == 2 ? out2 : out3));
+        out[c] = (float)t;
+    }
+}
+
 }  // namespace
 
 template <int MODE>
@@ -726,10 +809,22 @@ static int fill_levels(LevelSet &ls, const rn_canvas_layout *lay, int row_elems,
     return RN_OK;
 }
 
+RN_API int rn_conv3x3_canvas_batched_ex(const void *const *xs, const void *const *ws, const float *const *biases,
+                                        const uint8_t *mask, void *const *ys, uint8_t *const *relu_mask_outs, int P, int dtype, int64_t M,
+                                        int64_t HWp, int Wp, int Cin, int Cout, int relu, void *stream);
+
 RN_API int rn_conv3x3_canvas_batched(const void *const *xs, const void *const *ws, const float *const *biases,
                                      const uint8_t *mask, void *const *ys, int P, int dtype, int64_t M, int64_t HWp, int Wp,
                                      int Cin, int Cout, int relu, void *stream)
 {
+    return rn_conv3x3_canvas_batched_ex(xs, ws, biases, mask, ys, nullptr, P, dtype, M, HWp, Wp, Cin, Cout, relu, stream);
+}
+
+RN_API int rn_conv3x3_canvas_batched_ex(const void *const *xs, const void *const *ws, const float *const *biases,
+                                        const uint8_t *mask, void *const *ys, uint8_t *const *relu_mask_outs, int P, int dtype, int64_t M,
+                                        int64_t HWp, int Wp, int Cin, int Cout, int relu, void *stream)
+{
+    if (relu_mask_outs && !relu) return RN_EINVAL;
     if (!xs || !ws || !ys || P <= 0 || P > CONV_MAX_PROBLEMS || M <= 0 || HWp <= 0 || Wp <= 0 || Cin <= 0 || Cout <= 0) return RN_EINVAL;
     if (dtype != RN_BF16 || Cin % CONV_BK || Cout % CONV_BN) return RN_EUNSUPPORTED;
     ConvArgs a = {};
@@ -739,6 +834,8 @@ RN_API int rn_conv3x3_canvas_batched(const void *const *xs, const void *const *w
         if (!rn::aligned(xs[q], 16) || !rn::aligned(ws[q], 16) || !rn::aligned(ys[q], 16)) return RN_EALIGN;
         a.Xs[p] = (const uint16_t *)xs[q]; a.Ws[p] = (const uint16_t *)ws[q]; a.Ys[p] = (uint16_t *)ys[q];
         a.biases[p] = biases ? biases[q] : nullptr;
+        a.relu_mask_outs[p] = relu_mask_outs ? relu_mask_outs[q] : nullptr;
+        if (relu_mask_outs && (!relu_mask_outs[q] || !rn::aligned(relu_mask_outs[q], 16))) return relu_mask_outs[q] ? RN_EALIGN : RN_EINVAL;
     }
     a.mask = mask; a.M = M; a.HWp = HWp; a.Cin = Cin; a.Cout = Cout; a.Wp = Wp; a.relu = relu ? 1 : 0; a.zeros = nullptr;
     const dim3 grid((unsigned)((M + CONV_BM - 1) / CONV_BM), (unsigned)(Cout / CONV_BN), (unsigned)P);
@@ -753,6 +850,45 @@ RN_API int rn_conv3x3_canvas(const void *x, const void *w, const float *bias, co
     const float *bs[1] = {bias};
     void *ys[1] = {y};
     return rn_conv3x3_canvas_batched(xs, ws, bs, mask, ys, 1, dtype, M, HWp, Wp, Cin, Cout, relu, stream);
+}
+
+RN_API size_t rn_conv3x3_colsum_workspace_bytes(int P, int64_t M, int Cout)
+{
+    if (P <= 0 || P > CONV_MAX_PROBLEMS || M <= 0 || Cout <= 0) return 0;
+    return (size_t)P * (size_t)((M + CONV_BM - 1) / CONV_BM) * (size_t)Cout * sizeof(float);
+}
+
+RN_API int rn_conv3x3_canvas_dgrad_relu_batched(const void *const *gs, const void *const *ws, const uint8_t *const *relu_masks,
+                                                const uint8_t *mask, void *const *ys, float *const *dbiases, int P, int dtype,
+                                                int64_t M, int64_t HWp, int Wp, int Cin, int Cout, void *workspace,
+                                                size_t workspace_bytes, void *stream)
+{
+    if (!gs || !ws || !relu_masks || !ys || !dbiases || !workspace || P <= 0 || P > CONV_MAX_PROBLEMS || M <= 0 || HWp <= 0 || Wp <= 0 ||
+        Cin <= 0 || Cout <= 0)
+        return RN_EINVAL;
+    if (dtype != RN_BF16 || Cin % CONV_BK || Cout % CONV_BN) return RN_EUNSUPPORTED;
+    if (workspace_bytes < rn_conv3x3_colsum_workspace_bytes(P, M, Cout)) return RN_EWORKSPACE;
+    ConvArgs a = {};
+    const int64_t tiles = (M + CONV_BM - 1) / CONV_BM;
+    float *outs[CONV_MAX_PROBLEMS] = {nullptr, nullptr, nullptr, nullptr};
+    for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) {
+        const int q = p < P ? p : 0;
+        if (!gs[q] || !ws[q] || !ys[q] || !relu_masks[q] || !dbiases[q]) return RN_EINVAL;
+        if (!rn::aligned(gs[q], 16) || !rn::aligned(ws[q], 16) || !rn::aligned(ys[q], 16) || !rn::aligned(relu_masks[q], 16)) return RN_EALIGN;
+        a.Xs[p] = (const uint16_t *)gs[q]; a.Ws[p] = (const uint16_t *)ws[q]; a.Ys[p] = (uint16_t *)ys[q];
+        a.biases[p] = nullptr;
+        a.relu_masks[p] = relu_masks[q];
+        a.colsums[p] = (float *)workspace + (int64_t)q * tiles * Cout;
+        outs[p] = dbiases[q];
+    }
+    a.mask = mask; a.M = M; a.HWp = HWp; a.Cin = Cin; a.Cout = Cout; a.Wp = Wp; a.relu = 0; a.zeros = nullptr;
+    const dim3 grid((unsigned)tiles, (unsigned)(Cout / CONV_BN), (unsigned)P);
+    const int rc = conv_launch_mode<MODE_CANVAS>(a, grid, (hipStream_t)stream);
+    if (rc != RN_OK) return rc;
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((Cout + 7) / 8), (unsigned)P), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)workspace, (int)tiles, Cout, outs[0], outs[1], outs[2], outs[3]);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
 }
 
 RN_API int rn_conv3x3_canvas_to_levels(const void *x, const void *w, const float *bias, const rn_canvas_layout *layout,

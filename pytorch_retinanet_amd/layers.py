@@ -206,8 +206,11 @@ class RetinaNetHead(nn.Module):
             if mfma and self.pair_towers and len(cc) == len(bc) and all(c.weight.shape == b.weight.shape and c.in_channels % 256 == 0
                                                     for c, b in zip(cc, bc)):
                 xc = xb_ = packed                  # both towers layer by layer, one batched launch per layer and direction
-                for c, b in zip(cc, bc):
-                    xc, xb_ = biasact.tower_conv_pair(xc, xb_, c.weight, b.weight, c.bias, b.bias, cv.mask)
+                prev = None                        # (a layer's outputs feed only the next layer: its ReLU backward rides in
+                for i, (c, b) in enumerate(zip(cc, bc)):       #  that layer's data-gradient kernel, biasact.TowerLink)
+                    link = biasact.TowerLink() if i + 1 < len(cc) else None
+                    xc, xb_ = biasact.tower_conv_pair(xc, xb_, c.weight, b.weight, c.bias, b.bias, cv.mask, prev, link)
+                    prev = link
                 cls_c, box_t = xc, xb_
             else:
                 cls_c = _tower_on_canvas(ch.class_subnet, packed, cv.mask, mfma)

@@ -392,6 +392,51 @@ def test_head_mfma_towers_equal_miopen_towers_bf16():
         torch.testing.assert_close(outs[True][2][n].float(), a.float(), rtol=1e-1, atol=5e-2 * float(a.float().abs().max()))
 
 
+@pytest.mark.parametrize("N", [2, 3])
+def test_tower_relu_backward_fused_into_the_data_gradient_kernel(N):
+    """A chain of tower_conv_pair layers with TowerLink hand-over (the ReLU backward and bias gradient of layer l - 1 ride in
+    layer l's data-gradient kernel: rn_conv3x3_canvas_dgrad_relu_batched) == the same chain with the separate
+    rn_bias_act_backward passes: input gradients bit-equal, weight gradients bit-equal, bias gradients to fp32 summation
+    order; and a layer whose output has a second consumer falls back to the separate pass."""
+    from pytorch_retinanet_amd import biasact
+    torch.manual_seed(3)
+    shapes = [(9, 12), (5, 6), (3, 3)]
+    feats = [torch.randn(N, 256, h, w, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for h, w in shapes]
+    cv = biasact.Canvas.of(feats, pad=1)
+    ws = [[(torch.randn(256, 256, 3, 3, device=DEV) * 0.02).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+           for _ in range(2)] for _ in range(3)]
+    bs = [[(torch.randn(256, device=DEV) * 0.1).requires_grad_(True) for _ in range(2)] for _ in range(3)]
+
+    def run(linked, tap_middle=False):
+        x = biasact.pack_levels(cv, feats).requires_grad_(True)
+        for t in [w for l in ws for w in l] + [b for l in bs for b in l]:
+            t.grad = None
+        a = b = x
+        prev, extra = None, 0.0
+        for i in range(3):
+            link = biasact.TowerLink() if (linked and i < 2) else None
+            a, b = biasact.tower_conv_pair(a, b, ws[i][0], ws[i][1], bs[i][0], bs[i][1], cv.mask, prev if linked else None, link)
+            prev = link
+            if tap_middle and i == 1:
+                extra = (a.float() * 0.5).sum()                  # a second consumer of layer 1's output
+        ((a.float() ** 2).sum() + (b.float() ** 3).sum() + extra).backward()
+        return x.grad.clone(), [[w.grad.clone() for w in l] for l in ws], [[t.grad.clone() for t in l] for l in bs]
+
+    ref = run(False)
+    got = run(True)
+    assert torch.equal(got[0], ref[0])
+    for l in range(3):
+        for k in range(2):
+            assert torch.equal(got[1][l][k], ref[1][l][k]), (l, k)
+            torch.testing.assert_close(got[2][l][k], ref[2][l][k], rtol=1e-4, atol=1e-4 * float(ref[2][l][k].abs().max()))
+    ref2, got2 = run(False, True), run(True, True)                # autograd sums two gradients for layer 1's output: no hand-over there
+    assert torch.equal(got2[0], ref2[0])
+    for l in range(3):
+        for k in range(2):
+            torch.testing.assert_close(got2[2][l][k], ref2[2][l][k], rtol=1e-4, atol=1e-4 * float(ref2[2][l][k].abs().max()))
+            assert torch.equal(got2[1][l][k], ref2[1][l][k]), (l, k)
+
+
 @pytest.mark.parametrize("N,K,shapes,slots", [(2, 6, [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)], 1),   # Cout = 54: one tile, 54 % 8 = 6
                                               (2, 6, [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)], 2),   # the same, both images on one sheet
                                               (1, 90, [(13, 17), (7, 9), (4, 5)], 1),                 # Cout = 810: 4 tiles, 810 % 8 = 2
