@@ -143,6 +143,8 @@ int rn_loss_fwd_bwd_levels_timed(const void *const *cls_levels, const void *cons
  * when *scale == 1.  Used by autograd's backward to apply the upstream gradient to
  * the gradients rn_loss_fwd_bwd already wrote, without a host sync. */
 int rn_scale_inplace(void *data, int dtype, int64_t n, const float *scale, void *stream);
+/* The same for up to 16 tensors of one dtype in one launch: data[k][0..n[k]) *= *scales[k] (device scalars). */
+int rn_scale_inplace_batched(void *const *data, const int64_t *n, const float *const *scales, int count, int dtype, void *stream);
 
 /* ---- fused BatchNorm2d (+ residual) (+ ReLU), channels-last ---------------------------------
  * Conv-stack widening.  Replaces the bn -> (+identity) -> relu sequences of the
@@ -233,6 +235,9 @@ int rn_conv3x3_canvas_wgrad_batched(const void *const *gs, const void *const *xs
 int rn_conv3x3_canvas_batched_ex(const void *const *xs, const void *const *ws, const float *const *biases,
                                  const uint8_t *mask, void *const *ys, uint8_t *const *relu_mask_outs, int P, int dtype, int64_t M,
                                  int64_t HWp, int Wp, int Cin, int Cout, int relu, void *stream);
+/* The data gradient's weights of P convs: outs[p] [Cin][3][3][Cout] = ws[p] [Cout][3][3][Cin] with taps reversed and channel
+ * roles swapped (16-bit elements, Cout % 32 == Cin % 32 == 0); one launch. */
+int rn_conv3x3_dgrad_weight_batched(const void *const *ws, void *const *outs, int P, int Cout, int Cin, void *stream);
 size_t rn_conv3x3_colsum_workspace_bytes(int P, int64_t M, int Cout);
 int rn_conv3x3_canvas_dgrad_relu_batched(const void *const *gs, const void *const *ws, const uint8_t *const *relu_masks,
                                          const uint8_t *mask, void *const *ys, float *const *dbiases, int P, int dtype,

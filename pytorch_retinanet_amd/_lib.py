@@ -48,6 +48,7 @@ SIGNATURES = {
                                                _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.POINTER(RnLossParams), _vp,
                                                C.POINTER(_vp), C.POINTER(_vp), _vp, _sz, _vp, _vp, _vp]),
     "rn_scale_inplace": (C.c_int, [_vp, C.c_int, _i64, _vp, _vp]),
+    "rn_scale_inplace_batched": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "rn_bn_workspace_bytes": (_sz, [C.c_int]),
     "rn_bn_act_forward": (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, _f32, _f32, C.c_int,
                                     _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     "rn_conv3x3_levels_wgrad": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp,
                                           _sz, _vp]),
     "rn_conv3x3_canvas_batched_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _i64, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "rn_conv3x3_dgrad_weight_batched": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "rn_conv3x3_colsum_workspace_bytes": (_sz, [C.c_int, _i64, C.c_int]),
     "rn_conv3x3_canvas_dgrad_relu_batched": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _i64, _i64, C.c_int, C.c_int, C.c_int,
                                                        _vp, _sz, _vp]),

@@ -254,7 +254,9 @@ class _TowerConvPair(torch.autograd.Function):
             link.ptrs, link.dbias = None, None
         dxs = [None, None]
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            wts = [w.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last) for w in (w0, w1)]
+            wts = [torch.empty((Cin, Cout, 3, 3), dtype=w0.dtype, device=dev, memory_format=torch.channels_last) for _ in range(2)]
+            check(lib.rn_conv3x3_dgrad_weight_batched(_ptr_array([w0, w1]), _ptr_array(wts), 2, Cout, Cin, stream),
+                  "rn_conv3x3_dgrad_weight_batched")                   # [Cin, Cout, 3, 3], taps reversed: one launch for both
             dxs = [torch.empty_like(x0), torch.empty_like(x1)]
             if prev is not None and prev.relu_masks is not None and Cin == Cout:
                 need = lib.rn_conv3x3_colsum_workspace_bytes(2, M, Cin)

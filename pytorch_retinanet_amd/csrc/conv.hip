@@ -742,6 +742,31 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
 }
 
 
+// Data-gradient weights of P convs in one launch: out[ci][8 - t][co] = w[co][t][ci] (taps reversed, channel roles swapped),
+// w [Cout][9][Cin], out [Cin][9][Cout], 16-bit elements; 32 x 32 tiles through LDS.  (torch: flip + transpose + contiguous,
+// four small launches per weight, every step.)
+struct WeightPrep { const uint16_t *w[CONV_MAX_PROBLEMS]; uint16_t *out[CONV_MAX_PROBLEMS]; int Cout, Cin; };
+__global__ __launch_bounds__(256) void dgrad_weight_kernel(const WeightPrep a)
+{
+    __shared__ uint16_t tile[32][34];
+    const int t = blockIdx.x % 9, p = blockIdx.x / 9;
+    const int co0 = blockIdx.y * 32, ci0 = blockIdx.z * 32;
+    const uint16_t *__restrict__ w = a.w[p];
+    uint16_t *__restrict__ out = a.out[p];
+    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + 8 * k;                                  // co offset
+        tile[r][c] = w[((int64_t)(co0 + r) * 9 + t) * a.Cin + ci0 + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + 8 * k;                                  // ci offset
+        out[((int64_t)(ci0 + r) * 9 + (8 - t)) * a.Cout + co0 + c] = tile[c][r];
+    }
+}
+
 // Column sums of a fused data-gradient epilogue: partial [P][tiles][C] f32 (one row per row tile) -> out[p][C] f32, summed in
 // double in a fixed order (deterministic).  Block = 8 channels x 32 lanes over the tiles.
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restrict__ partial, const int tiles, const int C, float *out0,
@@ -850,6 +875,23 @@ RN_API int rn_conv3x3_canvas(const void *x, const void *w, const float *bias, co
     const float *bs[1] = {bias};
     void *ys[1] = {y};
     return rn_conv3x3_canvas_batched(xs, ws, bs, mask, ys, 1, dtype, M, HWp, Wp, Cin, Cout, relu, stream);
+}
+
+RN_API int rn_conv3x3_dgrad_weight_batched(const void *const *ws, void *const *outs, int P, int Cout, int Cin, void *stream)
+{
+    if (!ws || !outs || P <= 0 || P > CONV_MAX_PROBLEMS || Cout <= 0 || Cin <= 0) return RN_EINVAL;
+    if (Cout % 32 || Cin % 32) return RN_EUNSUPPORTED;
+    WeightPrep a = {};
+    for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) {
+        const int q = p < P ? p : 0;
+        if (!ws[q] || !outs[q] || ws[q] == outs[q]) return RN_EINVAL;
+        a.w[p] = (const uint16_t *)ws[q]; a.out[p] = (uint16_t *)outs[q];
+    }
+    a.Cout = Cout; a.Cin = Cin;
+    hipLaunchKernelGGL(dgrad_weight_kernel, dim3((unsigned)(9 * P), (unsigned)(Cout / 32), (unsigned)(Cin / 32)), dim3(256), 0,
+                       (hipStream_t)stream, a);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
 }
 
 RN_API size_t rn_conv3x3_colsum_workspace_bytes(int P, int64_t M, int Cout)

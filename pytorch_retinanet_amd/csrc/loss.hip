@@ -602,6 +602,33 @@ __global__ __launch_bounds__(256) void scale_inplace_kernel(void *data, const in
     }
 }
 
+// The same for up to 16 tensors in ONE launch (blockIdx.y = tensor): the gradients of a per-level loss call -- 5 class and
+// 5 box tensors, scaled by the two upstream scalars -- cost ten 5 us launches otherwise, for a multiplication by 1.
+constexpr int SCALE_MAX_TENSORS = 16;
+struct ScaleTable { void *data[SCALE_MAX_TENSORS]; int64_t n[SCALE_MAX_TENSORS]; const float *scale[SCALE_MAX_TENSORS]; };
+template <int DT>
+__global__ __launch_bounds__(256) void scale_inplace_batched_kernel(const ScaleTable t)
+{
+    typedef rn::dt<DT> D;
+    constexpr int VEC = D::VEC;
+    const int k = blockIdx.y;
+    const float s = *t.scale[k];
+    if (s == 1.0f) return;
+    const int64_t n = t.n[k], nvec = n / VEC;
+    rn::u32x4 *p = (rn::u32x4 *)t.data[k];
+    for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+        float f[VEC];
+        D::unpack(p[v], f);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) f[j] *= s;
+        p[v] = D::pack(f);
+    }
+    if (blockIdx.x == 0) {
+        const int64_t i = nvec * VEC + threadIdx.x;
+        if (i < n) D::st(t.data[k], i, D::ld(t.data[k], i) * s);
+    }
+}
+
 // Grid = what is co-resident (CUs x blocks/CU from the occupancy query), never more: a second,
 // partially filled round of blocks would idle most of the chip for a whole block lifetime.
 template <typename KernelT>
@@ -793,6 +820,33 @@ RN_API int rn_scale_inplace(void *data, int dtype, int64_t n, const float *scale
         case RN_BF16: hipLaunchKernelGGL((scale_inplace_kernel<RN_BF16>), dim3((unsigned)blocks), dim3(256), 0, st, data, n, scale); break;
         case RN_F16: hipLaunchKernelGGL((scale_inplace_kernel<RN_F16>), dim3((unsigned)blocks), dim3(256), 0, st, data, n, scale); break;
         default: return RN_EINVAL;
+    }
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+RN_API int rn_scale_inplace_batched(void *const *data, const int64_t *n, const float *const *scales, int count, int dtype, void *stream)
+{
+    if (!data || !n || !scales || count < 0 || count > SCALE_MAX_TENSORS) return RN_EINVAL;
+    if (dtype != RN_F32 && dtype != RN_BF16 && dtype != RN_F16) return RN_EINVAL;
+    if (count == 0) return RN_OK;
+    ScaleTable t = {};
+    int64_t most = 0;
+    for (int k = 0; k < SCALE_MAX_TENSORS; ++k) {
+        const int q = k < count ? k : 0;
+        if (!data[q] || !scales[q] || n[q] < 0) return RN_EINVAL;
+        if (!rn::aligned(data[q], 16)) return RN_EALIGN;
+        t.data[k] = data[q]; t.n[k] = n[q]; t.scale[k] = scales[q];
+        if (k < count && n[q] > most) most = n[q];
+    }
+    int64_t blocks = (most / 4 + 255) / 256;
+    blocks = blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks);
+    const dim3 grid((unsigned)blocks, (unsigned)count);
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case RN_F32: hipLaunchKernelGGL((scale_inplace_batched_kernel<RN_F32>), grid, dim3(256), 0, st, t); break;
+        case RN_BF16: hipLaunchKernelGGL((scale_inplace_batched_kernel<RN_BF16>), grid, dim3(256), 0, st, t); break;
+        default: hipLaunchKernelGGL((scale_inplace_batched_kernel<RN_F16>), grid, dim3(256), 0, st, t); break;
     }
     RN_LAUNCH_CHECK();
     return RN_OK;

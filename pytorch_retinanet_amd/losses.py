@@ -60,20 +60,21 @@ class _FusedDenseHeadLossLevels(torch.autograd.Function):
                                                    num_fg, params, want_grad)
         ctx.grads = (gcls, gbox)
         ctx.meta = [(c.shape, c.dtype) for c in cls_levels] + [(b.shape, b.dtype) for b in box_levels]
-        return loss
+        # two scalar outputs (views of the kernel's f32[2]): backward then receives the two upstream scalars directly, without
+        # autograd's select-backward zeros / copies / add in front of the first gradient kernel
+        return loss[0], loss[1]
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g0, g1):
         if ctx.grads is None or ctx.grads[0] is None:
             raise RuntimeError("fused RetinaNet loss: backward called twice (or without gradients recorded); "
                                "re-run the forward pass instead of retain_graph=True")
         gcls, gbox = ctx.grads
         ctx.grads = None
-        g = g.to(torch.float32)
-        for t in gcls:
-            ops.scale_inplace(t, g[0:1])
-        for t in gbox:
-            ops.scale_inplace(t, g[1:2])
+        dev = gcls[0].device
+        g0 = torch.zeros((1,), device=dev) if g0 is None else g0.reshape(1)
+        g1 = torch.zeros((1,), device=dev) if g1 is None else g1.reshape(1)
+        ops.scale_inplace_batched(list(gcls) + list(gbox), [g0] * len(gcls) + [g1] * len(gbox))      # one launch
         outs = [t.view(shape) if t.dtype == dt else t.to(dt).view(shape) for t, (shape, dt) in zip(list(gcls) + list(gbox), ctx.meta)]
         return (None,) * 8 + tuple(outs)
 

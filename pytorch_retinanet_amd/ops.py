@@ -239,6 +239,29 @@ def scale_inplace(t: Tensor, scale: Tensor) -> Tensor:
     return t
 
 
+def scale_inplace_batched(tensors: Sequence[Tensor], scales: Sequence[Tensor]) -> None:
+    """tensors[k] *= scales[k] (device scalars, f32[1]) for up to 16 contiguous tensors per launch, grouped by dtype; a no-op on
+    the device where a scale is 1."""
+    if not tensors:
+        return
+    dev = _need_dev(*tensors, *scales)
+    scales = [_c(s.detach().to(torch.float32)).reshape(1) for s in scales]
+    by_dtype = {}
+    for t, s in zip(tensors, scales):
+        if not t.is_contiguous():
+            raise ValueError("scale_inplace_batched needs contiguous tensors")
+        if t.numel():
+            by_dtype.setdefault(t.dtype, []).append((t, s))
+    with torch.cuda.device(dev):
+        for dt, items in by_dtype.items():
+            for i in range(0, len(items), 16):
+                part = items[i:i + 16]
+                n = len(part)
+                check(lib.rn_scale_inplace_batched((C.c_void_p * n)(*[_ptr(t) for t, _ in part]), (C.c_int64 * n)(*[t.numel() for t, _ in part]),
+                                                   (C.c_void_p * n)(*[_ptr(s) for _, s in part]), n, _dtype_code(part[0][0]), _stream(dev)),
+                      "rn_scale_inplace_batched")
+
+
 def image_hw_tensor(sizes: Sequence[Tuple[int, int]], device: torch.device) -> Tensor:
     host = torch.tensor([[int(h), int(w)] for h, w in sizes], dtype=torch.int32)
     return host.pin_memory().to(device, non_blocking=True)
