@@ -566,6 +566,65 @@ class _ClsOutputConv(torch.autograd.Function):
         return dx, dw, db, None, None, None
 
 
+class _BoxOutputConv(torch.autograd.Function):
+    """``box_subnet_output`` (256 -> A*4 = 36 channels) on the canvas: MIOpen forward + unpack to the dense per-level
+    ``[N, h*w*A, 4]`` deltas; the DATA gradient gathers the per-level gradients straight from those dense tensors with the
+    MFMA level-mode kernel (``rn_conv3x3_levels_to_canvas``: 9 K-tiles per tile instead of a 36-channel MIOpen igemm, 55 vs
+    165 us); the weight gradient stays with MIOpen on the re-assembled canvas gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, canvas, n_images):
+        y = F.conv2d(x, w, bias, stride=1, padding=1)
+        ctx.save_for_backward(x, w)
+        ctx.canvas, ctx.n_images, ctx.has_bias = canvas, int(n_images), bias is not None
+        outs = _gather_levels(canvas, y, ctx.n_images)
+        return tuple(t.permute(0, 2, 3, 1).reshape(ctx.n_images, -1, 4) for t in outs)        # layers.py:189-191, zero-copy
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x, w = ctx.saved_tensors
+        cv, N = ctx.canvas, ctx.n_images
+        sheets, Cin, Hp, Wp = x.shape
+        Cout = w.shape[0]
+        dev = x.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        gs = []
+        for dy, (h, wd) in zip(dys, cv.shapes):
+            if dy is None:
+                dy = torch.zeros((N, h * wd * Cout), dtype=x.dtype, device=dev)
+            gs.append(dy.to(x.dtype).contiguous())
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            wt = _dgrad_weight(w)
+            _mfma_call("mfma_box_output_dgrad", dev, 2.0 * N * sum(h * wd for h, wd in cv.shapes) * Cout * 9 * Cin,
+                       lambda: lib.rn_conv3x3_levels_to_canvas(_ptr_array(gs), _layout(cv, N), Cout, wt.data_ptr(), cv.mask.data_ptr(), dx.data_ptr(),
+                                                               _DT[x.dtype], sheets, Hp, Wp, wt.shape[1], Cin, _zero_page(dev).data_ptr(), stream),
+                       "rn_conv3x3_levels_to_canvas")
+        if ctx.needs_input_grad[1]:
+            g = torch.empty((sheets, Cout, Hp, Wp), dtype=x.dtype, device=dev, memory_format=torch.channels_last).zero_()
+            S = cv.slots
+            for l, s_, r, c, h, wd in cv.regions:
+                src = gs[l].view(N, h, wd, Cout)[s_::S]
+                if src.shape[0]:
+                    g[:src.shape[0], :, r:r + h, c:c + wd].copy_(src.permute(0, 3, 1, 2))
+            dw = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = sum(g_.reshape(-1, Cout).sum(0, dtype=torch.float32) for g_ in gs)
+        return dx, dw, db, None, None
+
+
+def box_output_conv_fusable(x: Tensor, conv, canvas: "Canvas") -> bool:
+    return cls_output_conv_fusable(x, conv, canvas) and conv.out_channels % 4 == 0
+
+
+def box_output_conv(x: Tensor, conv, canvas: "Canvas", n_images: int) -> List[Tensor]:
+    "``conv(x)`` for the box-output conv on a canvas -> per-level deltas ``[n_images, h*w*A, 4]`` (dense)."
+    return list(_BoxOutputConv.apply(x, conv.weight.to(x.dtype), conv.bias.to(x.dtype) if conv.bias is not None else None, canvas, n_images))
+
+
 def cls_output_conv_fusable(x: Tensor, conv, canvas: "Canvas") -> bool:
     "bf16 canvas with a zero border, 3x3 / stride 1 / pad 1, Cin == 256, an even number of output channels (>= 8), <= 6 levels."
     return (x.is_cuda and x.dtype == torch.bfloat16 and _cl(x) and canvas.pad == 1 and conv.kernel_size == (3, 3)

@@ -180,6 +180,7 @@ class RetinaNetHead(nn.Module):
         self.pair_towers = mode == "pair"
         # class-output conv on the hand-written MFMA kernel with dense 9*K-channel output (0: MIOpen on 9*ceil8(K) channels)
         self.mfma_cls_output = os.environ.get("RN_CLS_OUTPUT", "mfma") != "miopen"
+        self.mfma_box_output = os.environ.get("RN_BOX_OUTPUT", "mfma") != "miopen"      # box-output conv: MFMA data gradient (biasact._BoxOutputConv)
 
     def compute_loss(self, targets: List[Dict[str, Tensor]], outputs: Dict[str, Tensor],
                      anchors: List[Tensor]) -> Dict[str, Tensor]:
@@ -217,9 +218,12 @@ class RetinaNetHead(nn.Module):
                 box_t = _tower_on_canvas(rh.box_subnet, packed, cv.mask, mfma)
             # the 36-channel box conv is tiny per level (2 TFLOP/s on P7): run it on the canvas too and unpack its
             # small output instead of the 256-channel tower output
-            box_c = rh.box_subnet_output(box_t)
             n_img = xb[0].shape[0]
-            box_levels = [_to_anchor_major(t, 4) for t in biasact.unpack_levels(cv, box_c, n_img)]
+            if mfma and self.mfma_box_output and biasact.box_output_conv_fusable(box_t, rh.box_subnet_output, cv):
+                box_levels = biasact.box_output_conv(box_t, rh.box_subnet_output, cv, n_img)      # MFMA data gradient
+            else:
+                box_c = rh.box_subnet_output(box_t)
+                box_levels = [_to_anchor_major(t, 4) for t in biasact.unpack_levels(cv, box_c, n_img)]
             if mfma and self.mfma_cls_output and biasact.cls_output_conv_fusable(cls_c, ch.class_subnet_output, cv):
                 # class-output conv straight from the canvas to dense per-level logits [N, h*w*A, K]: exactly A*K channels
                 # (no dead classes for the loss kernel to stream) and no unpack copy of the 256-channel tower output
