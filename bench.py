@@ -203,6 +203,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank != 0:
+        os.dup2(2, 1)                            # only rank 0 owns stdout (see the end of main)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the dense-head path)")
     torch.cuda.set_device(local_rank)
@@ -350,10 +352,25 @@ def main():
             line["roofline_other"]["detect_chain"] = det_line
             if det_cpu is not None:
                 line["cpu_baseline"]["detect_chain"] = det_cpu
-        print(json.dumps(line), flush=True)
+    else:
+        line = None
+    # The JSON line must be the LAST line of the job's stdout.  RCCL writes a "Librccl path" line to C stdout when it
+    # unloads, and torch.distributed.run merges every rank's stdout: so the process group goes first, ranks != 0 never write to
+    # stdout (fd 1 was pointed at stderr right after argument parsing), and rank 0 flushes C stdio, prints, and leaves without
+    # running any library destructor.
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if line is not None:
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:          # noqa: BLE001
+            pass
+        print(json.dumps(line), flush=True)
+        if world > 1 or args.force_ddp:
+            os._exit(0)
 
 
 if __name__ == "__main__":
