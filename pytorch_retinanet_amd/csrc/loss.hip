@@ -59,6 +59,7 @@ struct LossArgs {
     const int32_t *num_fg;
     int64_t A;               // anchors per image over all levels (row length of `matches`)
     int64_t vec_per_wave;    // stream kernel: 16-byte vectors per wave (multiple of 64)
+    int32_t reverse;         // stream kernel: waves take the ranges back to front (the logits the conv wrote last are read first)
     int32_t K, B;
     float inv_B;
     rn_loss_params p;
@@ -194,7 +195,8 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
     // readfirstlane: the wave index and everything derived from it (ranges, trip counts, image
     // seams) is wave-uniform -> SGPRs and scalar branches.
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t gwave = (int64_t)blockIdx.x * LOSS_WAVES + wave;
+    const int64_t gwave_raw = (int64_t)blockIdx.x * LOSS_WAVES + wave;
+    const int64_t gwave = a.reverse ? (int64_t)gridDim.x * LOSS_WAVES - 1 - gwave_raw : gwave_raw;
     const int64_t gv_beg = gwave * a.vec_per_wave;                // this wave's range in the virtual vector space
     const int64_t gv_end = min(gv_beg + a.vec_per_wave, a.total_vec);  // (levels laid end to end)
     const int K = a.K;
@@ -664,6 +666,13 @@ int launch_stream(StreamT stream_k, LossArgs &a, int vec, hipStream_t st, int *n
     vpw = ((vpw + 2 * RN_WAVE - 1) / (2 * RN_WAVE)) * (2 * RN_WAVE);
     if (vpw < 2 * RN_WAVE) vpw = 2 * RN_WAVE;
     a.vec_per_wave = vpw;
+    {
+        // default 1: in the train step the class-output conv has just written the logits, column pass by column pass; the
+        // Infinity Cache (256 MiB) still holds the last three passes and the tail rows of the first, and a back-to-front walk
+        // reads exactly those first: 131 -> 117 us on one box (RN_K3_ORDER=0/1 A/B, tools/k3_order_ab.sh); no effect on cold data
+        static const int order = [] { const char *e = getenv("RN_K3_ORDER"); return e ? atoi(e) : 1; }();
+        a.reverse = order;
+    }
     (void)vec;
     int64_t need = ((nvec + vpw - 1) / vpw + LOSS_WAVES - 1) / LOSS_WAVES;
     if (need < 1) need = 1;
