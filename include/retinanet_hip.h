@@ -238,6 +238,12 @@ int rn_conv3x3_canvas_batched_ex(const void *const *xs, const void *const *ws, c
 /* The data gradient's weights of P convs: outs[p] [Cin][3][3][Cout] = ws[p] [Cout][3][3][Cin] with taps reversed and channel
  * roles swapped (16-bit elements, Cout % 32 == Cin % 32 == 0); one launch. */
 int rn_conv3x3_dgrad_weight_batched(const void *const *ws, void *const *outs, int P, int Cout, int Cin, void *stream);
+/* out[c] = sum over l and rows of xs[l][row][c] for L <= 6 dense row-major bf16 / f16 tensors [rows[l]][C] (C even, any
+ * multiple of 2: the 810-channel logit gradients): the bias gradient of the class- / box-output conv.  f32 out[C],
+ * deterministic. */
+size_t rn_colsum_rows_workspace_bytes(int L, int C);
+int rn_colsum_rows(const void *const *xs, const int64_t *rows, int L, int C, int dtype, float *out, void *workspace,
+                   size_t workspace_bytes, void *stream);
 size_t rn_conv3x3_colsum_workspace_bytes(int P, int64_t M, int Cout);
 int rn_conv3x3_canvas_dgrad_relu_batched(const void *const *gs, const void *const *ws, const uint8_t *const *relu_masks,
                                          const uint8_t *mask, void *const *ys, float *const *dbiases, int P, int dtype,

@@ -562,8 +562,26 @@ class _ClsOutputConv(torch.autograd.Function):
                                                            Cin, _zero_page(dev).data_ptr(), wsb.data_ptr(), wsb.numel(), stream),
                        "rn_conv3x3_levels_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = sum(g.reshape(-1, Cout).sum(0, dtype=torch.float32) for g in gs)
+            db = _colsum_levels(gs, Cout)
         return dx, dw, db, None, None, None
+
+
+def _colsum_levels(gs: Sequence[Tensor], C_: int) -> Tensor:
+    "f32[C] = column sums over all rows of the dense per-level tensors ``[N, rows * C]`` (bias gradient): one read, two launches."
+    dev = gs[0].device
+    if gs[0].dtype not in (torch.bfloat16, torch.float16) or C_ % 2 or len(gs) > 6:
+        return sum(g.reshape(-1, C_).sum(0, dtype=torch.float32) for g in gs)
+    stream = torch.cuda.current_stream().cuda_stream
+    need = lib.rn_colsum_rows_workspace_bytes(len(gs), C_)
+    key = (dev.index, stream, "rows")
+    wsb = _CS_WS.get(key)
+    if wsb is None or wsb.numel() < need:
+        wsb = _CS_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
+    out = torch.empty((C_,), dtype=torch.float32, device=dev)
+    n = len(gs)
+    check(lib.rn_colsum_rows(_ptr_array(gs), (C.c_int64 * n)(*[g.numel() // C_ for g in gs]), n, C_, _DT[gs[0].dtype], out.data_ptr(),
+                             wsb.data_ptr(), wsb.numel(), stream), "rn_colsum_rows")
+    return out
 
 
 class _BoxOutputConv(torch.autograd.Function):
@@ -612,7 +630,7 @@ class _BoxOutputConv(torch.autograd.Function):
                     g[:src.shape[0], :, r:r + h, c:c + wd].copy_(src.permute(0, 3, 1, 2))
             dw = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = sum(g_.reshape(-1, Cout).sum(0, dtype=torch.float32) for g_ in gs)
+            db = _colsum_levels(gs, Cout)
         return dx, dw, db, None, None
 
 

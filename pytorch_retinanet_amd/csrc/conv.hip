@@ -767,6 +767,55 @@ __global__ __launch_bounds__(256) void dgrad_weight_kernel(const WeightPrep a)
     }
 }
 
+// Column sums of up to 6 dense row-major tensors [rows_l][C] of 16-bit floats whose row length C (even) is NOT a multiple
+// of the 8-element vector: the bias gradient of the class-output conv over the per-level logit gradients (C = 810: torch needs
+// five reductions + fills + adds, 200 us per step, for what is one 290 MB read).  A "super-row" of S = 8 / gcd(8, C) rows is a
+// whole number V = C * S / 8 of 16-byte vectors, so thread slot j of a super-row always sees the same 8 columns and sums them
+// in registers; G super-rows per block iteration; block totals in a fixed order -> partial[block][C]; colsum_reduce_kernel
+// adds the blocks (and thereby the levels).  Rows beyond the last whole super-row: element loop of the level's block 0.
+constexpr int CSR_BLOCKS = 128;             // blocks per tensor
+struct ColsumRowsArgs { const uint16_t *x[CONV_LEVELS]; int64_t rows[CONV_LEVELS]; int C, S, V, G; float *partial; };
+template <int DT>
+__global__ __launch_bounds__(1024) void colsum_rows_kernel(const ColsumRowsArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_acc[];            // [G][V * 8]
+    const int l = blockIdx.y, t = threadIdx.x;
+    const int j = t % a.V, g = t / a.V;
+    const uint16_t *__restrict__ x = a.x[l];
+    const int64_t srows = a.rows[l] / a.S;                                    // whole super-rows
+    float acc[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (g < a.G) {
+        const int64_t step = (int64_t)gridDim.x * a.G;
+        int64_t sr = (int64_t)blockIdx.x * a.G + g;
+        const rn::u32x4 *xv = (const rn::u32x4 *)x;
+        for (; sr + step < srows; sr += 2 * step) {                           // two loads in flight
+            float f0[8], f1[8];
+            rn::dt<DT>::unpack(xv[sr * a.V + j], f0);
+            rn::dt<DT>::unpack(xv[(sr + step) * a.V + j], f1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += f0[e] + f1[e];
+        }
+        for (; sr < srows; sr += step) {
+            float f0[8];
+            rn::dt<DT>::unpack(xv[sr * a.V + j], f0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += f0[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_acc[(g * a.V + j) * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    const int E = a.V * 8;                                                    // elements of a super-row = S * C
+    for (int c = t; c < a.C; c += blockDim.x) {
+        float tot = 0.0f;
+        for (int gg = 0; gg < a.G; ++gg)
+            for (int r = 0; r < a.S; ++r) tot += s_acc[gg * E + r * a.C + c];
+        if (blockIdx.x == 0)                                                  // leftover rows of this tensor
+            for (int64_t row = srows * a.S; row < a.rows[l]; ++row) tot += rn::dt<DT>::ld(x, row * a.C + c);
+        a.partial[((int64_t)l * gridDim.x + blockIdx.x) * a.C + c] = tot;
+    }
+}
+
 // Column sums of a fused data-gradient epilogue: partial [P][tiles][C] f32 (one row per row tile) -> out[p][C] f32, summed in
 // double in a fixed order (deterministic).  Block = 8 channels x 32 lanes over the tiles.
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restrict__ partial, const int tiles, const int C, float *out0,
@@ -890,6 +939,44 @@ RN_API int rn_conv3x3_dgrad_weight_batched(const void *const *ws, void *const *o
     a.Cout = Cout; a.Cin = Cin;
     hipLaunchKernelGGL(dgrad_weight_kernel, dim3((unsigned)(9 * P), (unsigned)(Cout / 32), (unsigned)(Cin / 32)), dim3(256), 0,
                        (hipStream_t)stream, a);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+RN_API size_t rn_colsum_rows_workspace_bytes(int L, int C)
+{
+    if (L <= 0 || L > CONV_LEVELS || C <= 0) return 0;
+    return (size_t)L * CSR_BLOCKS * (size_t)C * sizeof(float);
+}
+
+RN_API int rn_colsum_rows(const void *const *xs, const int64_t *rows, int L, int C, int dtype, float *out, void *workspace,
+                          size_t workspace_bytes, void *stream)
+{
+    if (!xs || !rows || !out || !workspace || L <= 0 || L > CONV_LEVELS || C <= 0) return RN_EINVAL;
+    if ((dtype != RN_BF16 && dtype != RN_F16) || (C & 1)) return RN_EUNSUPPORTED;
+    if (workspace_bytes < rn_colsum_rows_workspace_bytes(L, C)) return RN_EWORKSPACE;
+    ColsumRowsArgs a = {};
+    int g8 = 8;                                                        // gcd(8, C)
+    while (C % g8) g8 >>= 1;
+    a.C = C; a.S = 8 / g8; a.V = C / g8;
+    if (a.V > 1024) return RN_EUNSUPPORTED;
+    a.G = 1024 / a.V;
+    if (a.G > 8) a.G = 8;
+    for (int l = 0; l < CONV_LEVELS; ++l) {
+        const int q = l < L ? l : 0;
+        if (!xs[q] || rows[q] < 0) return RN_EINVAL;
+        if (!rn::aligned(xs[q], 16)) return RN_EALIGN;
+        a.x[l] = (const uint16_t *)xs[q]; a.rows[l] = rows[q];
+    }
+    a.partial = (float *)workspace;
+    const int threads = ((a.V * a.G + 63) / 64) * 64;
+    const size_t lds = (size_t)a.G * a.V * 8 * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == RN_BF16) hipLaunchKernelGGL((colsum_rows_kernel<RN_BF16>), dim3(CSR_BLOCKS, (unsigned)L), dim3((unsigned)threads), lds, st, a);
+    else hipLaunchKernelGGL((colsum_rows_kernel<RN_F16>), dim3(CSR_BLOCKS, (unsigned)L), dim3((unsigned)threads), lds, st, a);
+    RN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((C + 7) / 8), 1), dim3(256), 0, st, (const float *)workspace, L * CSR_BLOCKS, C, out,
+                       out, out, out);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
