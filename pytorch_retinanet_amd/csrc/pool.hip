@@ -37,7 +37,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const void *__restrict
                                                           const PoolShape s)
 {
     const int64_t total = (int64_t)s.N * s.OH * s.OW * s.C8;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    // back to front: the producer (the stem's BN apply, 275 MB) wrote the end of x last, the Infinity Cache still holds it
+    for (int64_t ii = (int64_t)blockIdx.x * 256 + threadIdx.x; ii < total; ii += (int64_t)gridDim.x * 256) {
+        const int64_t i = total - 1 - ii;
         const int cg = (int)(i % s.C8);
         int64_t p = i / s.C8;
         const int ox = (int)(p % s.OW); p /= s.OW;
