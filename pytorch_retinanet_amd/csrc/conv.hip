@@ -23,6 +23,7 @@
 // Measured on MI355X, random data, [8,153,170,256] -> 256: 313 us = 785 TFLOP/s (939 without the 4th partial wave of
 // tiles); MIOpen: forward 301-315 us + 32 us for the separate bias/ReLU/mask pass, data gradient 415 us.
 #include "rn_common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -147,6 +148,7 @@ struct ConvArgs {
     uint8_t *relu_mask_outs[CONV_MAX_PROBLEMS];    // forward with ReLU: the same mask of the OUTPUT, written by the epilogue (or null)
     int64_t M, HWp;
     int Cin, Cout, Wp, relu;    // Cin = channels walked per tap (FROM_LEVELS: the padded row length, a multiple of 64)
+    int n_base;                 // first output channel of blockIdx.y = 0 (the NARROW launch of the last column tile)
     LevelSet lv;
 };
 struct ConvProblem { const uint16_t *X, *W; const float *bias; uint16_t *Y; };
@@ -155,17 +157,22 @@ __device__ __forceinline__ uint16_t f2bf(const float f) { return (uint16_t)(rn::
 
 struct Walk { int tap, chunk; };      // position of the K walk
 
-template <int MODE>
+// NARROW (TO_LEVELS only): a column tile of at most 64 output channels -- the last, ragged tile of the 810-channel
+// class-output conv (42 columns).  All 8 waves split the ROWS (32 each) and compute 32 x 64: a quarter of the MFMAs and a
+// quarter of the weight staging of a full tile whose other 192 columns would be zeros.
+template <int MODE, bool NARROW = false>
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const ConvArgs args)
 {
+    constexpr int MI = NARROW ? 1 : 4;                            // 32-row accumulator tiles per wave
     ConvProblem a;
     a.X = args.Xs[blockIdx.z]; a.W = args.Ws[blockIdx.z]; a.bias = args.biases[blockIdx.z]; a.Y = args.Ys[blockIdx.z];
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];                 // [A0 A1 A2 | B0 B1] x 32 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform: LDS-DMA bases and wave roles live in SGPRs
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = NARROW ? wave : wave >> 2, wn = NARROW ? 0 : wave & 3;
+    const int grp = wave >> 2;                                    // ping-pong group: waves 0-3 / 4-7 (one wave of each per SIMD)
     const int64_t m0 = (int64_t)blockIdx.x * CONV_BM;
-    const int n0 = blockIdx.y * CONV_BN;
+    const int n0 = blockIdx.y * CONV_BN + args.n_base;
     const int cpt = args.Cin / CONV_BK, KT = 9 * cpt;
     constexpr int TILE = CONV_BM * CONV_BK * 2;
     unsigned char *const Abase = lds, *const Bbase = lds + 3 * TILE;
@@ -177,9 +184,9 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
         else { if (++w.tap == 9) { w.tap = 0; ++w.chunk; } }
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         const int chunk = kk * 2 + (lane >> 5);
-        { const int row = wm * 128 + (lane & 31); a_off[kk] = row * 128 + ((chunk ^ SWZ(row)) << 4); }
+        { const int row = wm * (32 * MI) + (lane & 31); a_off[kk] = row * 128 + ((chunk ^ SWZ(row)) << 4); }
         { const int row = wn * 64 + (lane & 31); b_off[kk] = row * 128 + ((chunk ^ SWZ(row)) << 4); }
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
@@ -268,6 +275,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
         }
     };
     auto piece_b = [&](const Walk w, const int stage, const int i) {
+        if (NARROW && i > 0) return;                                 // 64 weight rows = the first piece of every thread
         const int c0 = w.chunk * CONV_BK, t = w.tap;
         unsigned char *const sb = Bbase + stage * TILE;
         if (!b_ragged) {
@@ -300,17 +308,17 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     if (MODE == MODE_FROM_LEVELS) map_landed(g_entry);
     __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();                    // group 1 runs one barrier interval behind group 0
+    if (grp == 1) __builtin_amdgcn_s_barrier();                    // group 1 runs one barrier interval behind group 0
 
-    bf16x8 fa[2][4], fb[2][2];
+    bf16x8 fa[2][MI], fb[2][2];
 #define RN_DS_READ(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
 #define RN_LOAD_FRAGS(KK, SET)                                                     \
     { const uint32_t ba = bbase + b_off[KK], aa = abase + a_off[KK];               \
       RN_DS_READ(fb[SET][0], ba, 0); RN_DS_READ(fb[SET][1], ba, 4096);             \
-      RN_DS_READ(fa[SET][0], aa, 0); RN_DS_READ(fa[SET][1], aa, 4096);             \
-      RN_DS_READ(fa[SET][2], aa, 8192); RN_DS_READ(fa[SET][3], aa, 12288); }
+      RN_DS_READ(fa[SET][0], aa, 0);                                               \
+      if (MI == 4) { RN_DS_READ(fa[SET][MI - 3], aa, 4096); RN_DS_READ(fa[SET][MI - 2], aa, 8192); RN_DS_READ(fa[SET][MI - 1], aa, 12288); } }
 #define RN_MFMA8(SET)                                                              \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                               \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                              \
         _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                           \
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][mi], fb[SET][ni], acc[mi][ni], 0, 0, 0);
 #define RN_MFMA_PHASE()                                                            \
@@ -358,7 +366,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
 #undef RN_LOAD_FRAGS
 #undef RN_MFMA8
 #undef RN_MFMA_PHASE
-    if (wm == 0) __builtin_amdgcn_s_barrier();                    // group 0 catches up with group 1's extra barrier
+    if (grp == 0) __builtin_amdgcn_s_barrier();                    // group 0 catches up with group 1's extra barrier
 
     __syncthreads();
     uint16_t *Ys = (uint16_t *)lds;                               // [256][256] bf16 output tile = 128 KiB
@@ -372,14 +380,14 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
         if (m0 + row < args.M) rm_pre = *(const uint4 *)(relu_mask + (m0 + row) * (args.Cout >> 3) + (n0 >> 3) + half * 16);
     }
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
             const int col = wn * 64 + ni * 32 + (lane & 31);
             const float b = (a.bias && (MODE != MODE_TO_LEVELS || n0 + col < args.Cout)) ? a.bias[n0 + col] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int row = wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 float v = acc[mi][ni][r] + b;
                 if (args.relu & 1) v = v > 0.0f ? v : 0.0f;
                 Ys[row * CONV_BN + col] = f2bf(v);
@@ -402,8 +410,8 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
         // addresses are fine on gfx950 (tools/misalign_probe.hip); the tile's last piece may be cut by the row end
         const int ncols = min(CONV_BN, args.Cout - n0);           // > 0
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int q = i * CONV_THREADS + tid, row = q >> 5, piece = q & 31;
+        for (int i = 0; i < (NARROW ? 4 : 16); ++i) {               // NARROW: 8 pieces (64 columns) per row
+            const int q = i * CONV_THREADS + tid, row = NARROW ? q >> 3 : q >> 5, piece = NARROW ? q & 7 : q & 31;
             uint16_t *dst = Yrow[row];
             if (dst && piece * 8 < ncols) {
                 const uint16_t *src = Ys + row * CONV_BN + piece * 8;
@@ -849,7 +857,7 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restr
 
 }  // namespace
 
-template <int MODE>
+template <int MODE, bool NARROW = false>
 static int conv_launch_mode(const ConvArgs &a, const dim3 grid, hipStream_t st)
 {
     {   // 160 KiB of dynamic LDS needs the opt-in once per device (the attribute lives with the device's code object)
@@ -857,11 +865,11 @@ static int conv_launch_mode(const ConvArgs &a, const dim3 grid, hipStream_t st)
         int dev = 0;
         RN_HIP(hipGetDevice(&dev));
         if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-            RN_HIP(hipFuncSetAttribute((const void *)conv3x3_canvas_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES));
+            RN_HIP(hipFuncSetAttribute((const void *)conv3x3_canvas_kernel<MODE, NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES));
             if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
     }
-    hipLaunchKernelGGL(conv3x3_canvas_kernel<MODE>, grid, dim3(CONV_THREADS), CONV_LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv3x3_canvas_kernel<MODE, NARROW>), grid, dim3(CONV_THREADS), CONV_LDS_BYTES, st, a);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
@@ -1033,7 +1041,17 @@ RN_API int rn_conv3x3_canvas_to_levels(const void *x, const void *w, const float
     for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) { a.Xs[p] = (const uint16_t *)x; a.Ws[p] = (const uint16_t *)w; a.biases[p] = bias; a.Ys[p] = nullptr; }
     a.mask = nullptr; a.M = (int64_t)N * Hp * Wp; a.HWp = (int64_t)Hp * Wp; a.Cin = Cin; a.Cout = Cout; a.Wp = Wp; a.relu = 0;
     a.zeros = (const uint16_t *)zeros;
-    const dim3 grid((unsigned)((a.M + CONV_BM - 1) / CONV_BM), (unsigned)((Cout + CONV_BN - 1) / CONV_BN), 1);
+    const unsigned tiles_m = (unsigned)((a.M + CONV_BM - 1) / CONV_BM);
+    const int full = Cout / CONV_BN, rest = Cout % CONV_BN;
+    static const bool narrow_ok = [] { const char *e = getenv("RN_CONV_NARROW"); return !e || atoi(e) != 0; }();
+    if (narrow_ok && full > 0 && rest > 0 && rest <= 64) {
+        // whole 256-column tiles, then the ragged last one (<= 64 columns) on the NARROW kernel
+        int rc2 = conv_launch_mode<MODE_TO_LEVELS>(a, dim3(tiles_m, (unsigned)full, 1), (hipStream_t)stream);
+        if (rc2 != RN_OK) return rc2;
+        a.n_base = full * CONV_BN;
+        return conv_launch_mode<MODE_TO_LEVELS, true>(a, dim3(tiles_m, 1, 1), (hipStream_t)stream);
+    }
+    const dim3 grid(tiles_m, (unsigned)((Cout + CONV_BN - 1) / CONV_BN), 1);
     return conv_launch_mode<MODE_TO_LEVELS>(a, grid, (hipStream_t)stream);
 }
 
