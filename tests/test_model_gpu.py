@@ -105,7 +105,7 @@ def test_retinanet_train_step_and_predict_r18(oracle_lib):
     g = net.retinanet_head.classification_head.class_subnet_output.weight.grad
     assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0
     assert net.backbone.backbone.conv1.weight.grad.abs().sum() > 0
-    # the same forward again (train-mode BN uses batch statistics, so the head outputs repeat): oracle losses on them
+    # the same forward again (train-mode BN uses batch statistics, so the head outputs repeat up to conv rounding): oracle losses on them
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         cls, box, anchors, tg, _ = _head_outputs_as_the_kernels_see_them(net, images, targets)
     a_np = anchors.cpu().numpy()
@@ -114,7 +114,11 @@ def test_retinanet_train_step_and_predict_r18(oracle_lib):
     m, nfg = oracle_lib.iou_match(a_np, gtb)
     ref = oracle_lib.loss_fwd_bwd(cls.cpu().numpy(), box.cpu().numpy(), a_np, gtb, gtl, m)
     assert nfg.sum() > 0
-    np.testing.assert_allclose([float(out["classification_loss"].detach()), float(out["regression_loss"].detach())], ref["loss"], rtol=1e-4)
+    # (1) the loss kernels on exactly these head outputs == the oracle; (2) Retinanet.forward's own loss dict agrees with it up
+    # to what a repeated forward can differ (MIOpen's convolutions are not bit-reproducible from call to call)
+    got = net.retinanet_head.losses(tg, {"cls_preds": cls, "bbox_preds": box}, [anchors, anchors])
+    np.testing.assert_allclose([float(got["classification_loss"]), float(got["regression_loss"])], ref["loss"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose([float(out["classification_loss"].detach()), float(out["regression_loss"].detach())], ref["loss"], rtol=2e-3)
     net.eval()
     with torch.no_grad():
         # an untrained head scores every anchor at the 0.01 prior: spread the logits, then put the score threshold where
