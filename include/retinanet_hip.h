@@ -264,6 +264,10 @@ int rn_conv3x3_canvas_dgrad_relu_batched(const void *const *gs, const void *cons
  * Cout: any even number (rows of Cout elements start on 4-byte boundaries); Cin % 64 == 0; w [Cout][3][3][Cin] bf16;
  * bias f32[Cout] or NULL; zeros: >= 256 bytes of zeros, 16-byte aligned. */
 typedef struct rn_canvas_layout { const int32_t *map; int32_t slots, n_images, T; int32_t hw[6]; } rn_canvas_layout;
+/* Pack (to_canvas != 0) the per-level tensors levels[t] = [n_images][h_t][w_t][C] onto the canvas [N sheets][Hp][Wp][C] with
+ * zeros in the gaps, or unpack the canvas into them (to_canvas == 0), as `layout` places them; bf16 / f16, C even; one launch. */
+int rn_canvas_pack(void *const *levels, const rn_canvas_layout *layout, void *canvas, int dtype, int N, int Hp, int Wp, int C,
+                   int to_canvas, void *stream);
 int rn_conv3x3_canvas_to_levels(const void *x, const void *w, const float *bias, const rn_canvas_layout *layout,
                                 void *const *ys, int dtype, int N, int Hp, int Wp, int Cin, int Cout,
                                 const void *zeros, void *stream);

@@ -393,17 +393,37 @@ class Canvas:
         return c
 
 
+def _pack_native(cv: "Canvas", levels: Sequence[Tensor], canvas_t: Tensor, n_images: int, to_canvas: bool) -> bool:
+    """``rn_canvas_pack``: all levels <-> the canvas sheets in one launch (False: shapes / dtypes the kernel does not take)."""
+    x = canvas_t
+    if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 4 and _cl(x) and x.shape[1] % 2 == 0
+            and len(levels) <= 6 and x.shape[0] * cv.H * cv.W < (1 << 22)):
+        return False
+    for t in levels:
+        if not (t.is_cuda and t.dtype == x.dtype and t.dim() == 4 and t.shape[1] == x.shape[1] and (_cl(t) or t.shape[1] == 1)
+                and t.data_ptr() % 16 == 0):
+            return False
+    dev = x.device
+    if dev.index != torch.cuda.current_device():
+        torch.cuda.set_device(dev)
+    check(lib.rn_canvas_pack(_ptr_array(levels), _layout(cv, n_images), x.data_ptr(), _DT[x.dtype], x.shape[0], cv.H, cv.W, x.shape[1],
+                             1 if to_canvas else 0, torch.cuda.current_stream().cuda_stream), "rn_canvas_pack")
+    return True
+
+
 class _Pack(torch.autograd.Function):
     @staticmethod
     def forward(ctx, canvas: Canvas, *feats):
         f0 = feats[0]
         N, S = f0.shape[0], canvas.slots
         out = torch.empty((canvas.sheets(N), f0.shape[1], canvas.H, canvas.W), dtype=f0.dtype, device=f0.device,
-                          memory_format=torch.channels_last).zero_()
-        for l, s_, r, c, h, w in canvas.regions:
-            src = feats[l][s_::S]
-            if src.shape[0]:
-                out[:src.shape[0], :, r:r + h, c:c + w].copy_(src)
+                          memory_format=torch.channels_last)
+        if not _pack_native(canvas, feats, out, N, True):
+            out.zero_()
+            for l, s_, r, c, h, w in canvas.regions:
+                src = feats[l][s_::S]
+                if src.shape[0]:
+                    out[:src.shape[0], :, r:r + h, c:c + w].copy_(src)
         ctx.canvas, ctx.n = canvas, N
         return out
 
@@ -415,9 +435,11 @@ class _Pack(torch.autograd.Function):
 def _gather_levels(cv: "Canvas", x: Tensor, n_images: int) -> List[Tensor]:
     "The per-level tensors [n_images, C, h, w] (channels-last) cut out of canvas sheets."
     S = cv.slots
+    outs = [torch.empty((n_images, x.shape[1], h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last) for h, w in cv.shapes]
+    if _pack_native(cv, outs, x if _cl(x) else x.contiguous(memory_format=torch.channels_last), n_images, False):
+        return outs
     if S == 1:
         return [x[:, :, r:r + h, c:c + w].contiguous(memory_format=torch.channels_last) for (r, c), (h, w) in zip(cv.origin, cv.shapes)]
-    outs = [torch.empty((n_images, x.shape[1], h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last) for h, w in cv.shapes]
     for l, s_, r, c, h, w in cv.regions:
         dst = outs[l][s_::S]
         if dst.shape[0]:
@@ -430,21 +452,32 @@ class _Unpack(torch.autograd.Function):
     def forward(ctx, canvas: Canvas, x, n_images):
         ctx.canvas = canvas
         ctx.meta = (x.shape, x.dtype, x.device)
+        ctx.n = int(n_images)
         return tuple(_gather_levels(canvas, x, n_images))
 
     @staticmethod
     def backward(ctx, *grads):
         cv = ctx.canvas
         shape, dt, dev = ctx.meta
-        S = cv.slots
-        g = torch.empty(shape, dtype=dt, device=dev, memory_format=torch.channels_last).zero_()
-        for l, s_, r, c, h, w in cv.regions:
-            gl = grads[l]
-            if gl is not None:
-                src = gl[s_::S]
-                if src.shape[0]:
-                    g[:src.shape[0], :, r:r + h, c:c + w].copy_(src)
-        return None, g, None
+        return None, _scatter_levels(cv, grads, shape, dt, dev, ctx.n), None
+
+
+def _scatter_levels(cv: "Canvas", grads, shape, dt, dev, n_images: int) -> Tensor:
+    "The canvas sheets holding the per-level tensors ``grads`` (None = zeros), zeros in the gaps."
+    S = cv.slots
+    g = torch.empty(shape, dtype=dt, device=dev, memory_format=torch.channels_last)
+    if all(gl is not None for gl in grads):
+        lv = [gl if (gl.dtype == dt and _cl(gl)) else gl.to(dt).contiguous(memory_format=torch.channels_last) for gl in grads]
+        if _pack_native(cv, lv, g, n_images, True):
+            return g
+    g.zero_()
+    for l, s_, r, c, h, w in cv.regions:
+        gl = grads[l]
+        if gl is not None:
+            src = gl[s_::S]
+            if src.shape[0]:
+                g[:src.shape[0], :, r:r + h, c:c + w].copy_(src)
+    return g
 
 
 def pack_levels(canvas: Canvas, feature_maps: Sequence[Tensor]) -> Tensor:
@@ -622,12 +655,8 @@ class _BoxOutputConv(torch.autograd.Function):
                                                                _DT[x.dtype], sheets, Hp, Wp, wt.shape[1], Cin, _zero_page(dev).data_ptr(), stream),
                        "rn_conv3x3_levels_to_canvas")
         if ctx.needs_input_grad[1]:
-            g = torch.empty((sheets, Cout, Hp, Wp), dtype=x.dtype, device=dev, memory_format=torch.channels_last).zero_()
-            S = cv.slots
-            for l, s_, r, c, h, wd in cv.regions:
-                src = gs[l].view(N, h, wd, Cout)[s_::S]
-                if src.shape[0]:
-                    g[:src.shape[0], :, r:r + h, c:c + wd].copy_(src.permute(0, 3, 1, 2))
+            g = _scatter_levels(cv, [gl.view(N, h, wd, Cout).permute(0, 3, 1, 2) for gl, (h, wd) in zip(gs, cv.shapes)],
+                                (sheets, Cout, Hp, Wp), x.dtype, dev, N)
             dw = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum_levels(gs, Cout)

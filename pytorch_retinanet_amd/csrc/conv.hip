@@ -23,6 +23,7 @@
 // Measured on MI355X, random data, [8,153,170,256] -> 256: 313 us = 785 TFLOP/s (939 without the 4th partial wave of
 // tiles); MIOpen: forward 301-315 us + 32 us for the separate bias/ReLU/mask pass, data gradient 415 us.
 #include "rn_common.hpp"
+#include <type_traits>
 #include <cstdlib>
 
 namespace {
@@ -775,6 +776,33 @@ __global__ __launch_bounds__(256) void dgrad_weight_kernel(const WeightPrep a)
     }
 }
 
+// Pack the per-level tensors [n_images][h][w][C] onto the canvas sheets [N][Hp][Wp][C] (gaps zeroed) or unpack them, through
+// the position map: one launch instead of a zero fill plus one strided copy per (level, slot) -- 11 launches for five levels on
+// two-image sheets, four times per step.  UNIT = bytes per thread item (16, 8 or 4: C * 2 must be a multiple).
+template <int UNIT, bool TO_CANVAS>
+__global__ __launch_bounds__(256) void canvas_pack_kernel(const LevelSet ls, uint16_t *__restrict__ canvas, const int64_t M, const int HWp,
+                                                          const int units_per_row)
+{
+    typedef typename std::conditional<UNIT == 16, uint4, typename std::conditional<UNIT == 8, uint2, uint32_t>::type>::type V;
+    const LevelRegs lr = level_regs(ls);
+    const int64_t total = M * units_per_row;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / units_per_row;
+        const int u = (int)(i - m * units_per_row);
+        int n, pos;
+        sheet_coords((int)m, HWp, n, pos);
+        uint16_t *row = level_row(ls, lr, n, ls.map[pos]);
+        V *c = (V *)(canvas + m * ls.row_elems) + u;
+        if (TO_CANVAS) {
+            V v = {};
+            if (row) v = ((const V *)row)[u];
+            *c = v;
+        } else if (row) {
+            ((V *)row)[u] = *c;
+        }
+    }
+}
+
 // Column sums of up to 6 dense row-major tensors [rows_l][C] of 16-bit floats whose row length C (even) is NOT a multiple
 // of the 8-element vector: the bias gradient of the class-output conv over the per-level logit gradients (C = 810: torch needs
 // five reductions + fills + adds, 200 us per step, for what is one 290 MB read).  A "super-row" of S = 8 / gcd(8, C) rows is a
@@ -947,6 +975,30 @@ RN_API int rn_conv3x3_dgrad_weight_batched(const void *const *ws, void *const *o
     a.Cout = Cout; a.Cin = Cin;
     hipLaunchKernelGGL(dgrad_weight_kernel, dim3((unsigned)(9 * P), (unsigned)(Cout / 32), (unsigned)(Cin / 32)), dim3(256), 0,
                        (hipStream_t)stream, a);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+RN_API int rn_canvas_pack(void *const *levels, const rn_canvas_layout *layout, void *canvas, int dtype, int N, int Hp, int Wp, int C,
+                          int to_canvas, void *stream)
+{
+    if (!levels || !canvas || N <= 0 || Hp <= 0 || Wp <= 0 || C <= 0) return RN_EINVAL;
+    if ((dtype != RN_BF16 && dtype != RN_F16) || (C & 1) || (int64_t)N * Hp * Wp >= (1 << 22)) return RN_EUNSUPPORTED;
+    if (!rn::aligned(canvas, 16)) return RN_EALIGN;
+    LevelSet ls = {};
+    const int rc = fill_levels(ls, layout, C, levels, N, Hp, Wp);
+    if (rc != RN_OK) return rc;
+    const int64_t M = (int64_t)N * Hp * Wp;
+    const int unit = (C % 8 == 0) ? 16 : ((C % 4 == 0) ? 8 : 4);
+    const int upr = C * 2 / unit;
+    int64_t blocks = (M * upr + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t st = (hipStream_t)stream;
+#define RN_PACK(U)                                                                                                              \
+    if (to_canvas) hipLaunchKernelGGL((canvas_pack_kernel<U, true>), dim3((unsigned)blocks), dim3(256), 0, st, ls, (uint16_t *)canvas, M, Hp * Wp, upr); \
+    else hipLaunchKernelGGL((canvas_pack_kernel<U, false>), dim3((unsigned)blocks), dim3(256), 0, st, ls, (uint16_t *)canvas, M, Hp * Wp, upr);
+    if (unit == 16) { RN_PACK(16) } else if (unit == 8) { RN_PACK(8) } else { RN_PACK(4) }
+#undef RN_PACK
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
