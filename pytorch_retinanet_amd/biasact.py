@@ -193,6 +193,7 @@ class TowerLink:
 
 _CS_WS: Dict[tuple, Tensor] = {}
 FUSE_TOWER_RELU_BWD = os.environ.get("RN_FUSE_TOWER_RELU_BWD", "1") != "0"
+BOX_OUTPUT_FWD_MFMA = os.environ.get("RN_BOX_OUTPUT_FWD", "mfma") != "miopen"     # box-output conv forward on the narrow MFMA level-mode kernel
 
 
 class _TowerConvPair(torch.autograd.Function):
@@ -625,11 +626,27 @@ class _BoxOutputConv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, canvas, n_images):
-        y = F.conv2d(x, w, bias, stride=1, padding=1)
         ctx.save_for_backward(x, w)
         ctx.canvas, ctx.n_images, ctx.has_bias = canvas, int(n_images), bias is not None
-        outs = _gather_levels(canvas, y, ctx.n_images)
-        return tuple(t.permute(0, 2, 3, 1).reshape(ctx.n_images, -1, 4) for t in outs)        # layers.py:189-191, zero-copy
+        N = ctx.n_images
+        sheets, Cin, Hp, Wp = x.shape
+        Cout = w.shape[0]
+        if BOX_OUTPUT_FWD_MFMA and (bias is None or bias.dtype == torch.float32):
+            # the narrow (<= 64 columns) variant of the MFMA level-mode kernel writes the dense per-level deltas directly
+            dev = x.device
+            if dev.index != torch.cuda.current_device():
+                torch.cuda.set_device(dev)
+            stream = torch.cuda.current_stream().cuda_stream
+            wc = w if _cl(w) else w.contiguous(memory_format=torch.channels_last)
+            ys = [torch.empty((N, h * wd * (Cout // 4), 4), dtype=x.dtype, device=dev) for h, wd in canvas.shapes]
+            _mfma_call("mfma_box_output_fwd", dev, 2.0 * N * sum(h * wd for h, wd in canvas.shapes) * Cout * 9 * Cin,
+                       lambda: lib.rn_conv3x3_canvas_to_levels(x.data_ptr(), wc.data_ptr(), bias.data_ptr() if bias is not None else 0,
+                                                               _layout(canvas, N), _ptr_array(ys), _DT[x.dtype], sheets, Hp, Wp, Cin, Cout,
+                                                               _zero_page(dev).data_ptr(), stream), "rn_conv3x3_canvas_to_levels")
+            return tuple(ys)
+        y = F.conv2d(x, w, bias.to(x.dtype) if bias is not None else None, stride=1, padding=1)
+        outs = _gather_levels(canvas, y, N)
+        return tuple(t.permute(0, 2, 3, 1).reshape(N, -1, 4) for t in outs)        # layers.py:189-191, zero-copy
 
     @staticmethod
     def backward(ctx, *dys):
@@ -669,7 +686,7 @@ def box_output_conv_fusable(x: Tensor, conv, canvas: "Canvas") -> bool:
 
 def box_output_conv(x: Tensor, conv, canvas: "Canvas", n_images: int) -> List[Tensor]:
     "``conv(x)`` for the box-output conv on a canvas -> per-level deltas ``[n_images, h*w*A, 4]`` (dense)."
-    return list(_BoxOutputConv.apply(x, conv.weight.to(x.dtype), conv.bias.to(x.dtype) if conv.bias is not None else None, canvas, n_images))
+    return list(_BoxOutputConv.apply(x, conv.weight.to(x.dtype), conv.bias, canvas, n_images))
 
 
 def cls_output_conv_fusable(x: Tensor, conv, canvas: "Canvas") -> bool:

@@ -1096,10 +1096,13 @@ RN_API int rn_conv3x3_canvas_to_levels(const void *x, const void *w, const float
     const unsigned tiles_m = (unsigned)((a.M + CONV_BM - 1) / CONV_BM);
     const int full = Cout / CONV_BN, rest = Cout % CONV_BN;
     static const bool narrow_ok = [] { const char *e = getenv("RN_CONV_NARROW"); return !e || atoi(e) != 0; }();
-    if (narrow_ok && full > 0 && rest > 0 && rest <= 64) {
-        // whole 256-column tiles, then the ragged last one (<= 64 columns) on the NARROW kernel
-        int rc2 = conv_launch_mode<MODE_TO_LEVELS>(a, dim3(tiles_m, (unsigned)full, 1), (hipStream_t)stream);
-        if (rc2 != RN_OK) return rc2;
+    if (narrow_ok && rest > 0 && rest <= 64) {
+        // whole 256-column tiles, then the ragged last one (<= 64 columns; the only one of the 36-channel box-output conv) on
+        // the NARROW kernel
+        if (full > 0) {
+            const int rc2 = conv_launch_mode<MODE_TO_LEVELS>(a, dim3(tiles_m, (unsigned)full, 1), (hipStream_t)stream);
+            if (rc2 != RN_OK) return rc2;
+        }
         a.n_base = full * CONV_BN;
         return conv_launch_mode<MODE_TO_LEVELS, true>(a, dim3(tiles_m, 1, 1), (hipStream_t)stream);
     }
