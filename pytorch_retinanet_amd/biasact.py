@@ -193,6 +193,7 @@ class TowerLink:
 
 _CS_WS: Dict[tuple, Tensor] = {}
 FUSE_TOWER_RELU_BWD = os.environ.get("RN_FUSE_TOWER_RELU_BWD", "1") != "0"
+BOX_OUTPUT_WGRAD_MFMA = os.environ.get("RN_BOX_OUTPUT_WGRAD", "mfma") != "miopen"   # ... and its weight gradient on the narrow gathering kernel
 BOX_OUTPUT_FWD_MFMA = os.environ.get("RN_BOX_OUTPUT_FWD", "mfma") != "miopen"     # box-output conv forward on the narrow MFMA level-mode kernel
 
 
@@ -671,7 +672,19 @@ class _BoxOutputConv(torch.autograd.Function):
                        lambda: lib.rn_conv3x3_levels_to_canvas(_ptr_array(gs), _layout(cv, N), Cout, wt.data_ptr(), cv.mask.data_ptr(), dx.data_ptr(),
                                                                _DT[x.dtype], sheets, Hp, Wp, wt.shape[1], Cin, _zero_page(dev).data_ptr(), stream),
                        "rn_conv3x3_levels_to_canvas")
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and BOX_OUTPUT_WGRAD_MFMA and Cin == 256:
+            # the narrow (<= 64 rows) variant of the gathering MFMA weight-gradient kernel
+            need = lib.rn_conv3x3_wgrad_workspace_bytes(1, sheets * Hp * Wp)
+            key = (dev.index, stream)
+            wsb = _WG_WS.get(key)
+            if wsb is None or wsb.numel() < need:
+                wsb = _WG_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
+            dw = torch.empty((Cout, Cin, 3, 3), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+            _mfma_call("mfma_box_output_wgrad", dev, 2.0 * N * sum(h * wd for h, wd in cv.shapes) * Cout * 9 * Cin,
+                       lambda: lib.rn_conv3x3_levels_wgrad(_ptr_array(gs), _layout(cv, N), Cout, x.data_ptr(), dw.data_ptr(), _DT[x.dtype], sheets, Hp, Wp,
+                                                           Cin, _zero_page(dev).data_ptr(), wsb.data_ptr(), wsb.numel(), stream),
+                       "rn_conv3x3_levels_wgrad")
+        elif ctx.needs_input_grad[1]:
             g = _scatter_levels(cv, [gl.view(N, h, wd, Cout).permute(0, 3, 1, 2) for gl, (h, wd) in zip(gs, cv.shapes)],
                                 (sheets, Cout, Hp, Wp), x.dtype, dev, N)
             dw = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]

@@ -503,19 +503,25 @@ struct WgradArgs {
     float *partial;                             // [P][S][9][256][256] f32
     int64_t M, HWp;
     int Wp, S, tiles_per_split;                 // K-tiles (64 positions) per split
+    int ch_base;                                // GATHER: first output channel of problem 0 (the NARROW launch of the last row tile)
     LevelSet lv;                                // GATHER: dense per-level gradient tensors [N][h][w][row_elems]; problem p = output channels 256 p ..
 };
 
 // GATHER = false: G and X are canvases (the head towers).  GATHER = true: the gradient operand is gathered, position by
 // position, from dense per-level tensors with row_elems channels (the class-output conv: 810); blockIdx.z selects the tile
 // of 256 output channels, chunks past the row end read zeros (the straddling chunk pollutes only unused dW rows).
-template <bool GATHER>
+// NARROW (GATHER only): a row tile of at most 64 output channels -- the ragged last tile of the 810-channel class-output conv
+// (42 rows) and the whole 36-channel box-output conv.  All 8 waves split the 256 input channels (32 each) and compute
+// 64 x 32: a quarter of the MFMAs and half of the fragment reads of a full tile whose other 192 rows would be zeros.
+template <bool GATHER, bool NARROW = false>
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const WgradArgs a)
 {
+    constexpr int MI = NARROW ? 2 : 4, NI = NARROW ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];                 // [G0 G1 G2 | X0 X1] x 32 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform (LDS-DMA bases, wave roles)
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = NARROW ? 0 : wave >> 2, wn = NARROW ? wave : wave & 3;       // NARROW: wn counts 32-channel columns
+    const int pp = wave >> 2;                                     // ping-pong group: waves 0-3 / 4-7
     const int split = blockIdx.x, tap = blockIdx.y, prob = blockIdx.z;
     const uint16_t *__restrict__ G = a.Gs[prob], *__restrict__ X = a.Xs[GATHER ? 0 : prob];
     const int KT = a.tiles_per_split;
@@ -524,26 +530,26 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
     constexpr int TILE = WG_POS * 512;                            // 32 KiB
     unsigned char *const Abase = lds, *const Bbase = lds + 3 * TILE;
 
-    f32x16 acc[4][2];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     // transposed-read addresses: lane = 16*grp + 4*q + p;  grp & 1 selects the 16-channel half of a 32-channel
     // fragment, grp >> 1 the k half (positions +8); the lane supplies row q, channels 4p .. 4p+3 of its block.
     const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-    uint32_t a_off[4], b_off[2];
+    uint32_t a_off[MI], b_off[NI];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
         const int ch = wm * 16 + mi * 4 + 2 * (grp & 1) + (p >> 1);                  // 16-byte chunk of the channel row
         a_off[mi] = (uint32_t)((8 * (grp >> 1) + q) * 512 + ((ch ^ (q << 2)) << 4) + (p & 1) * 8);
     }
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int ch = wn * 8 + ni * 4 + 2 * (grp & 1) + (p >> 1);
+    for (int ni = 0; ni < NI; ++ni) {
+        const int ch = wn * (4 * NI) + ni * 4 + 2 * (grp & 1) + (p >> 1);
         b_off[ni] = (uint32_t)((8 * (grp >> 1) + q) * 512 + ((ch ^ (q << 2)) << 4) + (p & 1) * 8);
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
@@ -606,7 +612,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
         const int64_t t0 = m_begin + (int64_t)kt * WG_POS;
         unsigned char *const sb = Abase + stage * TILE;
         if (GATHER) {
-            const int e = prob * 256 + ((cp ^ ((row & 3) << 2)) << 3);          // first output channel of this 16-byte piece
+            const int e = a.ch_base + prob * 256 + ((cp ^ ((row & 3) << 2)) << 3);          // first output channel of this 16-byte piece
             // the piece that straddles the row end reads the row's last 8 channels instead (never past the row); the
             // reduction kernel writes its dW rows to the channels they really are
             const int es = e + 8 > a.lv.row_elems ? a.lv.row_elems - 8 : e;
@@ -642,22 +648,23 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    if (wm == 1) __builtin_amdgcn_s_barrier();                    // ping-pong, as in the forward kernel
+    if (pp == 1) __builtin_amdgcn_s_barrier();                    // ping-pong, as in the forward kernel
 
-    unsigned long long fa[2][4][2], fb[2][2][2];                  // [k-step set][fragment][k half]
+    unsigned long long fa[2][MI][2], fb[2][NI][2];                // [k-step set][fragment][k half]
 #define RN_TR_READ(dst, addr, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
 #define RN_LOAD_FRAGS(KOFF0, KOFF1, SET)                                             \
     RN_TR_READ(fb[SET][0][0], bbase + b_off[0], KOFF0); RN_TR_READ(fb[SET][0][1], bbase + b_off[0], KOFF1);   \
-    RN_TR_READ(fb[SET][1][0], bbase + b_off[1], KOFF0); RN_TR_READ(fb[SET][1][1], bbase + b_off[1], KOFF1);   \
+    if (NI == 2) { RN_TR_READ(fb[SET][NI - 1][0], bbase + b_off[NI - 1], KOFF0); RN_TR_READ(fb[SET][NI - 1][1], bbase + b_off[NI - 1], KOFF1); } \
     RN_TR_READ(fa[SET][0][0], abase + a_off[0], KOFF0); RN_TR_READ(fa[SET][0][1], abase + a_off[0], KOFF1);   \
     RN_TR_READ(fa[SET][1][0], abase + a_off[1], KOFF0); RN_TR_READ(fa[SET][1][1], abase + a_off[1], KOFF1);   \
-    RN_TR_READ(fa[SET][2][0], abase + a_off[2], KOFF0); RN_TR_READ(fa[SET][2][1], abase + a_off[2], KOFF1);   \
-    RN_TR_READ(fa[SET][3][0], abase + a_off[3], KOFF0); RN_TR_READ(fa[SET][3][1], abase + a_off[3], KOFF1);
+    if (MI == 4) {                                                                                            \
+        RN_TR_READ(fa[SET][MI - 2][0], abase + a_off[MI - 2], KOFF0); RN_TR_READ(fa[SET][MI - 2][1], abase + a_off[MI - 2], KOFF1);   \
+        RN_TR_READ(fa[SET][MI - 1][0], abase + a_off[MI - 1], KOFF0); RN_TR_READ(fa[SET][MI - 1][1], abase + a_off[MI - 1], KOFF1); }
     struct U2 { unsigned long long lo, hi; };
 #define RN_FRAG(v) __builtin_bit_cast(bf16x8, U2{v[0], v[1]})
 #define RN_MFMA8(SET)                                                              \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                               \
-        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                           \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                              \
+        _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                          \
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(RN_FRAG(fa[SET][mi]), RN_FRAG(fb[SET][ni]), acc[mi][ni], 0, 0, 0);
 #define RN_MFMA_PHASE()                                                            \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);          \
@@ -702,15 +709,15 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
 #undef RN_FRAG
 #undef RN_MFMA8
 #undef RN_MFMA_PHASE
-    if (wm == 0) __builtin_amdgcn_s_barrier();
+    if (pp == 0) __builtin_amdgcn_s_barrier();
 
     // partial tile [n][c] f32 of this (problem, split, tap)
     float *__restrict__ out = a.partial + (((int64_t)prob * a.S + split) * 9 + tap) * 65536;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int col = wn * 64 + ni * 32 + (lane & 31);
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = wn * (32 * NI) + ni * 32 + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -730,13 +737,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     const int rows = prob == 0 ? rows0 : (prob == 1 ? rows1 : (prob == 2 ? rows2 : rows3));
     const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;          // over 9 * 256 * 256 / 4 float4 groups of [t][n][c]
     if (i4 >= 9 * 65536 / 4) return;
+    const int64_t e = i4 * 4;
+    const int t = (int)(e / 65536), n = (int)((e % 65536) / 256), c = (int)(e % 256);
+    if (n >= rows && !(shift > 0 && prob == (int)gridDim.y - 1 && n >= shift_from && n < shift_from + 8)) return;   // rows nobody wrote or wants
     rn::f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (int sp = 0; sp < S; ++sp) {
         const rn::f32x4 v = ((const rn::f32x4 *)(partial + ((int64_t)prob * S + sp) * 9 * 65536))[i4];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    const int64_t e = i4 * 4;
-    const int t = (int)(e / 65536), n = (int)((e % 65536) / 256), c = (int)(e % 256);
     // gathered gradients whose row length is not a multiple of 8: tile rows shift_from .. shift_from+7 of the LAST problem hold
     // the row's last 8 channels (conv3x3_wgrad_kernel<true>), i.e. tile row r there is channel r - shift; the first
     // `shift` of them repeat channels already produced
@@ -1135,9 +1143,9 @@ RN_API size_t rn_conv3x3_wgrad_workspace_bytes(int P, int64_t M)
     return (size_t)P * 64 * 9 * 65536 * sizeof(float);          // up to 64 splits of the positions
 }
 
-template <bool GATHER>
+template <bool GATHER, bool NARROW = false>
 static int wgrad_launch(WgradArgs &a, uint16_t *const (&dw)[CONV_MAX_PROBLEMS], const int (&rows)[CONV_MAX_PROBLEMS], int P, int64_t M,
-                        void *workspace, hipStream_t st, int shift_from = 0, int shift = 0)
+                        void *workspace, hipStream_t st, int shift_from = 0, int shift = 0, size_t *used_floats = nullptr)
 {
     int dev = 0, cus = 0;
     RN_HIP(hipGetDevice(&dev));
@@ -1145,7 +1153,7 @@ static int wgrad_launch(WgradArgs &a, uint16_t *const (&dw)[CONV_MAX_PROBLEMS], 
     {
         static bool attr_set[64] = {};
         if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-            RN_HIP(hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES));
+            RN_HIP(hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<GATHER, NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES));
             if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
     }
@@ -1157,7 +1165,8 @@ static int wgrad_launch(WgradArgs &a, uint16_t *const (&dw)[CONV_MAX_PROBLEMS], 
     a.tiles_per_split = (int)((ktiles + S - 1) / S);
     S = (int)((ktiles + a.tiles_per_split - 1) / a.tiles_per_split);
     a.S = S; a.M = M; a.partial = (float *)workspace;
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel<GATHER>, dim3((unsigned)S, 9, (unsigned)P), dim3(CONV_THREADS), CONV_LDS_BYTES, st, a);
+    if (used_floats) *used_floats = (size_t)P * S * 9 * 65536;
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<GATHER, NARROW>), dim3((unsigned)S, 9, (unsigned)P), dim3(CONV_THREADS), CONV_LDS_BYTES, st, a);
     RN_LAUNCH_CHECK();
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(9 * 65536 / 4 / 256, (unsigned)P), dim3(256), 0, st, (const float *)workspace, S, dw[0], dw[1],
                        dw[2], dw[3], rows[0], rows[1], rows[2], rows[3], shift_from, shift);
@@ -1209,5 +1218,20 @@ RN_API int rn_conv3x3_levels_wgrad(const void *const *gs, const rn_canvas_layout
     a.Wp = Wp; a.HWp = (int64_t)Hp * Wp; a.zeros = (const uint16_t *)zeros;
     // tile-local position and size of the straddling piece's shift (see the kernel): last problem only
     const int tail = row_elems % 8, e_last = row_elems - tail - (P - 1) * 256;
+    static const bool narrow_ok = [] { const char *e = getenv("RN_CONV_NARROW"); return !e || atoi(e) != 0; }();
+    if (narrow_ok && P == 1 && rows[0] <= 64 && (!tail || e_last + 8 <= 64)) {
+        // a conv with at most 64 output channels (the 36-channel box-output conv) on the NARROW kernel.  (Splitting the ragged last
+        // row tile of the 810-channel conv off the same way was measured and is slower -- 0.94 vs 0.91 ms: a K-tile of the
+        // gathering kernel costs the same 1.9 us with a quarter of the MFMAs, it is bound by staging, not by the matrix pipe.)
+        size_t used = 0;
+        if (P > 1) {
+            const int rc2 = wgrad_launch<true>(a, dws, rows, P - 1, M, workspace, (hipStream_t)stream, 0, 0, &used);
+            if (rc2 != RN_OK) return rc2;
+        }
+        uint16_t *dw1[CONV_MAX_PROBLEMS] = {dws[P - 1], dws[P - 1], dws[P - 1], dws[P - 1]};
+        const int rows1[CONV_MAX_PROBLEMS] = {rows[P - 1], 0, 0, 0};
+        a.ch_base = (P - 1) * 256;
+        return wgrad_launch<true, true>(a, dw1, rows1, 1, M, (float *)workspace + used, (hipStream_t)stream, tail ? e_last : 0, tail ? 8 - tail : 0);
+    }
     return wgrad_launch<true>(a, dws, rows, P, M, workspace, (hipStream_t)stream, tail ? e_last : 0, tail ? 8 - tail : 0);
 }
