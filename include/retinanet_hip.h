@@ -206,7 +206,7 @@ int rn_conv3x3_canvas(const void *x, const void *w, const float *bias, const uin
                       int64_t M, int64_t HWp, int Wp, int Cin, int Cout, int relu, void *stream);
 /* P <= 4 convolutions of identical geometry in ONE launch (HOST arrays of device pointers; biases nullable as a
  * whole): the cls and box towers run the same shapes side by side, and their tiles together fill the chip's
- * workgroup waves better than two launches (2 x 813 tiles: 7 waves of 256 instead of 2 x 4). */
+ * workgroup waves better than two launches (2 x 749 tiles of two-image sheets at B = 8: 6 rounds of 256 CUs). */
 int rn_conv3x3_canvas_batched(const void *const *xs, const void *const *ws, const float *const *biases,
                               const uint8_t *mask, void *const *ys, int P, int dtype, int64_t M, int64_t HWp,
                               int Wp, int Cin, int Cout, int relu, void *stream);
@@ -223,38 +223,41 @@ int rn_conv3x3_canvas_wgrad_batched(const void *const *gs, const void *const *xs
                                     size_t workspace_bytes, void *stream);
 
 /* rn_conv3x3_canvas_batched that also writes, per problem, the ReLU bits of its outputs: relu_mask_outs[p] = [M][Cout / 8]
- * bytes, bit j of byte (m, c / 8) = [ys[p][m][c + j] > 0] (relu must be set; 16-byte aligned).
- * Data gradient of P tower convs whose INPUT was the ReLU output of the layer below (retinanet/layers.py:143-171: conv +
- * ReLU pairs), with that layer's ReLU backward and bias gradient fused into the epilogue:
- *   ys[p] = conv3x3(gs[p], ws[p]) * mask * relu_bits[p],   dbiases[p][c] = sum over positions of ys[p][., c]
- * gs: gradients at the conv outputs [M][Cin]; ws: the forward weights with taps reversed and channel roles swapped,
- * [Cout][3][3][Cin]; relu_masks[p]: the ReLU bits of the conv's forward INPUT (= the layer below's relu_mask_outs), [M][Cout / 8];
- * dbiases: f32 [Cout] each.  ys[p] is the gradient at the PRE-activation of the layer below (what rn_bias_act_backward
- * would produce from the plain data gradient), so that layer needs no pass of its own.  Column sums: one partial row per
- * 256-position tile in `workspace` (rn_conv3x3_colsum_workspace_bytes), reduced in double in a fixed order. */
+ * bytes, bit j of byte (m, c / 8) = [ys[p][m][c + j] > 0] (relu must be set; 16-byte aligned; NULL = plain
+ * rn_conv3x3_canvas_batched). */
 int rn_conv3x3_canvas_batched_ex(const void *const *xs, const void *const *ws, const float *const *biases,
                                  const uint8_t *mask, void *const *ys, uint8_t *const *relu_mask_outs, int P, int dtype, int64_t M,
                                  int64_t HWp, int Wp, int Cin, int Cout, int relu, void *stream);
-/* The data gradient's weights of P convs: outs[p] [Cin][3][3][Cout] = ws[p] [Cout][3][3][Cin] with taps reversed and channel
- * roles swapped (16-bit elements, Cout % 32 == Cin % 32 == 0); one launch. */
-int rn_conv3x3_dgrad_weight_batched(const void *const *ws, void *const *outs, int P, int Cout, int Cin, void *stream);
-/* out[c] = sum over l and rows of xs[l][row][c] for L <= 6 dense row-major bf16 / f16 tensors [rows[l]][C] (C even, any
- * multiple of 2: the 810-channel logit gradients): the bias gradient of the class- / box-output conv.  f32 out[C],
- * deterministic. */
-size_t rn_colsum_rows_workspace_bytes(int L, int C);
-int rn_colsum_rows(const void *const *xs, const int64_t *rows, int L, int C, int dtype, float *out, void *workspace,
-                   size_t workspace_bytes, void *stream);
+/* Data gradient of P tower convs whose INPUT was the ReLU output of the layer below (retinanet/layers.py:143-171: conv +
+ * ReLU pairs), with that layer's ReLU backward and bias gradient fused into the epilogue:
+ *   ys[p] = conv3x3(gs[p], ws[p]) * mask * relu_bits[p],   dbiases[p][c] = sum over positions of ys[p][., c]
+ * gs: gradients at the conv outputs [M][Cin]; ws: the forward weights with taps reversed and channel roles swapped,
+ * [Cout][3][3][Cin]; relu_masks[p]: the ReLU bits of the conv's forward INPUT (= the layer below's relu_mask_outs),
+ * [M][Cout / 8]; dbiases: f32 [Cout] each.  ys[p] is the gradient at the PRE-activation of the layer below (what
+ * rn_bias_act_backward would produce from the plain data gradient), so that layer needs no pass of its own.  Column sums:
+ * one partial row per 256-position tile in `workspace` (rn_conv3x3_colsum_workspace_bytes), reduced in double in a fixed
+ * order. */
 size_t rn_conv3x3_colsum_workspace_bytes(int P, int64_t M, int Cout);
 int rn_conv3x3_canvas_dgrad_relu_batched(const void *const *gs, const void *const *ws, const uint8_t *const *relu_masks,
                                          const uint8_t *mask, void *const *ys, float *const *dbiases, int P, int dtype,
                                          int64_t M, int64_t HWp, int Wp, int Cin, int Cout, void *workspace,
                                          size_t workspace_bytes, void *stream);
+/* The data gradient's weights of P convs: outs[p] [Cin][3][3][Cout] = ws[p] [Cout][3][3][Cin] with taps reversed and channel
+ * roles swapped (16-bit elements, Cout % 32 == Cin % 32 == 0); one launch. */
+int rn_conv3x3_dgrad_weight_batched(const void *const *ws, void *const *outs, int P, int Cout, int Cin, void *stream);
+/* out[c] = sum over l and rows of xs[l][row][c] for L <= 6 dense row-major bf16 / f16 tensors [rows[l]][C] (C even: the
+ * 810-channel logit gradients, the 36-channel box-delta gradients): the bias gradient of the class- / box-output conv.
+ * f32 out[C], deterministic. */
+size_t rn_colsum_rows_workspace_bytes(int L, int C);
+int rn_colsum_rows(const void *const *xs, const int64_t *rows, int L, int C, int dtype, float *out, void *workspace,
+                   size_t workspace_bytes, void *stream);
 
 /* ---- class-output conv on the canvas with DENSE per-level results -----------------------------------------------
  * The last 3x3 conv of the classification subnet (retinanet/layers.py:163-167: 256 -> 9*K channels) reads the tower
  * output where it lies -- on the zero-bordered canvas -- and writes, per pyramid level, the dense channels-last
- * tensor ys[l] = [N][h_l][w_l][Cout] bf16, which IS the [N][h*w*9][K] logits tensor of retinanet/layers.py:189-191
- * that rn_loss_fwd_bwd_levels / rn_detect_levels stream (no dead classes, no unpack copy).
+ * tensor ys[l] = [n_images][h_l][w_l][Cout] bf16, which IS the [N][h*w*9][K] logits tensor of retinanet/layers.py:189-191
+ * that rn_loss_fwd_bwd_levels / rn_detect_levels stream (no dead classes, no unpack copy).  Also used for the 36-channel
+ * box-output conv (layers.py:235-251); a ragged last tile of <= 64 output channels runs on a narrow kernel variant.
  * Canvas layout: the canvas is N sheets of [Hp][Wp] positions; a sheet carries `slots` images (image = sheet * slots +
  * slot; the last sheet may have unused slots when n_images is not a multiple of slots), each pyramid level of each slot in
  * its own rectangle with at least one empty row / column around it.  map (int32, DEVICE memory, [Hp * Wp]) says what lies
