@@ -102,6 +102,55 @@ class BasicBlock(nn.Module):
         return conv_bn(self.conv2, self.bn2, out, relu=True, residual=identity)      # relu(bn2(.) + identity), one kernel
 
 
+class _SkipLink:
+    "Carries the identity branch's gradient from bn3's backward to conv1's (``_Conv1x1Skip``)."
+    __slots__ = ("dres",)
+
+    def __init__(self):
+        self.dres = None
+
+
+class _Conv1x1Skip(torch.autograd.Function):
+    """conv1 (1x1, stride 1) of an identity bottleneck.  Its data gradient is a plain GEMM [M, Cmid] x [Cmid, Cin] on the
+    channels-last activations, and the block input's other gradient -- the identity branch's, which autograd would add with
+    a separate elementwise kernel (3 passes over the block's largest tensor; 12 blocks, 0.6 ms per step) -- goes in as the
+    GEMM's accumulator input: ``addmm(dres, g, w)``, one library GEMM (hipBLASLt) instead of MIOpen's data gradient + add."""
+
+    @staticmethod
+    def forward(ctx, x, w, link):
+        ctx.save_for_backward(x, w)
+        ctx.link = link
+        return F.conv2d(x, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        link = ctx.link
+        dres, link.dres = link.dres, None
+        N, Cmid, H, W = g.shape
+        Cin = w.shape[1]
+        if not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.contiguous(memory_format=torch.channels_last)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            g2 = g.permute(0, 2, 3, 1).reshape(-1, Cmid)
+            w2 = w.reshape(Cmid, Cin)
+            if dres is not None:
+                dx2 = torch.addmm(dres.permute(0, 2, 3, 1).reshape(-1, Cin), g2, w2)
+            else:
+                dx2 = g2 @ w2
+            dx = dx2.view(N, H, W, Cin).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            dw = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        return dx, dw, None
+
+
+FUSE_SKIP_ADD = os.environ.get("RN_FUSE_SKIP_ADD", "1") != "0"
+# layer1 / layer2 only (64 / 128 mid channels): there the GEMM is memory-bound and hipBLASLt streams it (52 us avg); for
+# layer3 / layer4 its pick for the skinny shape (33 600 x 1024 x 256) takes 97 us against 55 us for MIOpen's data gradient + the add
+SKIP_ADD_MAX_MID = int(os.environ.get("RN_SKIP_ADD_MAX_MID", "128"))
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -118,6 +167,17 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x: Tensor) -> Tensor:
+        if (FUSE_SKIP_ADD and self.downsample is None and torch.is_grad_enabled() and x.requires_grad and x.is_cuda
+                and x.dtype in (torch.bfloat16, torch.float16) and x.is_contiguous(memory_format=torch.channels_last)
+                and self.conv1.stride == (1, 1) and self.conv1.groups == 1 and self.conv1.out_channels <= SKIP_ADD_MAX_MID):
+            # identity block, training: the identity branch's gradient rides in conv1's data-gradient GEMM (_Conv1x1Skip)
+            link = _SkipLink()
+            out = self.bn1(_Conv1x1Skip.apply(x, self.conv1.weight.to(x.dtype), link), relu=True)
+            out = conv_bn(self.conv2, self.bn2, out, relu=True)
+            out3 = self.conv3(out)
+            if self.bn3._fusable(out3, x):
+                return self.bn3(out3, relu=True, residual=x, link=link)
+            return self.bn3(out3, relu=True, residual=x)
         identity = x if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], x)
         out = conv_bn(self.conv1, self.bn1, x, relu=True)
         out = conv_bn(self.conv2, self.bn2, out, relu=True)

@@ -45,7 +45,7 @@ def _cl(t: Tensor) -> bool:
 
 class _BNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps, relu):
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, num_batches_tracked, training, momentum, eps, relu, link=None):
         N, Cc, H, W = x.shape
         M = N * H * W
         dev = x.device
@@ -66,6 +66,7 @@ class _BNAct(torch.autograd.Function):
               "rn_bn_act_forward")
         ctx.save_for_backward(x, bits, weight, stats)
         ctx.cfg = (bool(training), bool(relu), residual is not None, M, Cc)
+        ctx.link = link
         return y
 
     @staticmethod
@@ -87,7 +88,12 @@ class _BNAct(torch.autograd.Function):
                    dres.data_ptr() if dres is not None else 0, _DT[x.dtype], M, Cc, weight.data_ptr(), sp, sp + 4 * Cc,
                    sp + 8 * Cc, int(training), (2 if bits is not None else 1) if relu else 0, gp, gp + 4 * Cc, gp + 8 * Cc, wp, wn,
                    stream), "rn_bn_act_backward")
-        return dx, dres, grads[:Cc], grads[Cc:2 * Cc], None, None, None, None, None, None, None
+        if ctx.link is not None and dres is not None:
+            # the residual branch's gradient is handed to the consumer that adds it inside its own kernel (backbone.Bottleneck:
+            # conv1's data gradient is one GEMM with this tensor as its accumulator input) instead of to autograd's add
+            ctx.link.dres = dres
+            dres = None
+        return dx, dres, grads[:Cc], grads[Cc:2 * Cc], None, None, None, None, None, None, None, None
 
 
 class FusedBatchNorm2d(nn.BatchNorm2d):
@@ -100,11 +106,14 @@ class FusedBatchNorm2d(nn.BatchNorm2d):
             return False
         return True
 
-    def forward(self, x: Tensor, relu: bool = False, residual: Optional[Tensor] = None) -> Tensor:
+    def forward(self, x: Tensor, relu: bool = False, residual: Optional[Tensor] = None, link=None) -> Tensor:
+        """``link`` (an object with a ``dres`` attribute, fused path only): backward leaves the residual branch's gradient there
+        instead of returning it -- for a caller that adds it elsewhere (``backbone.Bottleneck``)."""
         if self._fusable(x, residual):
             return _BNAct.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var,
                                 self.num_batches_tracked if self.training else None, self.training, self.momentum,
-                                self.eps, relu)
+                                self.eps, relu, link)
+        assert link is None, "the residual-gradient hand-over needs the fused BN path"
         y = super().forward(x)
         if residual is not None:
             y = y + residual
