@@ -298,6 +298,13 @@ int rn_maxpool3x3s2_forward(const void *x, void *y, uint8_t *argmax, int dtype, 
 int rn_maxpool3x3s2_backward(const uint8_t *argmax, const void *dy, void *dx, int dtype,
                              int N, int H, int W, int C, void *stream);
 
+/* ---- FPN top-down step, channels-last ----------------------------------------------------------------------
+ * out = lat + nearest_upsample_2x(top)   (retinanet/layers.py:36,52-53: lateral 1x1 conv + nn.Upsample(scale_factor=2) of the
+ * level above): lat, out [N][H][W][C], top [N][H/2][W/2][C] (H, W even, C % 8 == 0), one pass.  Backward for `top`:
+ * dtop = the 2 x 2 block sums of g (f32 accumulation); the lateral's gradient is g itself. */
+int rn_fpn_add_upsample2x(const void *lat, const void *top, void *out, int dtype, int N, int H, int W, int C, void *stream);
+int rn_fpn_upsample2x_backward(const void *g, void *dtop, int dtype, int N, int Ht, int Wt, int C, void *stream);
+
 /* ---- optimizer step: SGD on fp32 masters with a bf16 working copy, multi-tensor ------------------------------
  * The update torch.optim.SGD performs (the reference's optimizer, hparams.yaml:63-68), in its order, in fp32:
  *   g = grad + weight_decay * w;  buf = first_step ? g : momentum * buf + (1 - dampening) * g;

@@ -115,6 +115,56 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t *__restr
     }
 }
 
+// FPN top-down step (retinanet/layers.py:36,52-53: lateral + 2x nearest upsampling of the level above), channels-last:
+//   out[n][y][x][c] = lat[n][y][x][c] + top[n][y / 2][x / 2][c]            (H = 2 Ht, W = 2 Wt)
+// and its backward for `top`: dtop[n][yt][xt][c] = sum of the 2 x 2 block of g (summed in f32, rounded once); the lateral's
+// gradient is g itself.  One pass each instead of an upsampling kernel + an add (forward) / an upsampling-backward kernel.
+template <int DT>
+__global__ __launch_bounds__(256) void add_up2x_kernel(const void *__restrict__ lat, const void *__restrict__ top, void *__restrict__ out,
+                                                       const int N, const int H, const int W, const int C8)
+{
+    const int64_t total = (int64_t)N * H * W * C8;
+    const int Wt = W >> 1, Ht = H >> 1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cg = (int)(i % C8);
+        int64_t p = i / C8;
+        const int x = (int)(p % W); p /= W;
+        const int y = (int)(p % H);
+        const int n = (int)(p / H);
+        float a[8], b[8];
+        v8<DT>::ld(lat, i, a);
+        v8<DT>::ld(top, (((int64_t)n * Ht + (y >> 1)) * Wt + (x >> 1)) * C8 + cg, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += b[j];
+        v8<DT>::st(out, i, a);
+    }
+}
+template <int DT>
+__global__ __launch_bounds__(256) void up2x_bwd_kernel(const void *__restrict__ g, void *__restrict__ dtop, const int N, const int Ht, const int Wt,
+                                                       const int C8)
+{
+    const int64_t total = (int64_t)N * Ht * Wt * C8;
+    const int W = Wt * 2, H = Ht * 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cg = (int)(i % C8);
+        int64_t p = i / C8;
+        const int xt = (int)(p % Wt); p /= Wt;
+        const int yt = (int)(p % Ht);
+        const int n = (int)(p / Ht);
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float v[8];
+                v8<DT>::ld(g, (((int64_t)n * H + 2 * yt + dy) * W + 2 * xt + dx) * C8 + cg, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] += v[j];
+            }
+        v8<DT>::st(dtop, i, s);
+    }
+}
+
 int pool_blocks(const int64_t n)
 {
     int64_t b = (n + 255) / 256;
@@ -156,6 +206,40 @@ RN_API int rn_maxpool3x3s2_backward(const uint8_t *argmax, const void *dy, void 
         case RN_F32: hipLaunchKernelGGL((maxpool_bwd_kernel<RN_F32>), g, b, 0, st, argmax, dy, dx, s); break;
         case RN_BF16: hipLaunchKernelGGL((maxpool_bwd_kernel<RN_BF16>), g, b, 0, st, argmax, dy, dx, s); break;
         default: hipLaunchKernelGGL((maxpool_bwd_kernel<RN_F16>), g, b, 0, st, argmax, dy, dx, s); break;
+    }
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+RN_API int rn_fpn_add_upsample2x(const void *lat, const void *top, void *out, int dtype, int N, int H, int W, int C, void *stream)
+{
+    if (!lat || !top || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0) return RN_EINVAL;
+    if (C % 8 || (H & 1) || (W & 1)) return RN_EUNSUPPORTED;
+    if (dtype != RN_F32 && dtype != RN_BF16 && dtype != RN_F16) return RN_EINVAL;
+    if (!rn::aligned(lat, 16) || !rn::aligned(top, 16) || !rn::aligned(out, 16)) return RN_EALIGN;
+    const dim3 g(pool_blocks((int64_t)N * H * W * (C / 8))), b(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case RN_F32: hipLaunchKernelGGL((add_up2x_kernel<RN_F32>), g, b, 0, st, lat, top, out, N, H, W, C / 8); break;
+        case RN_BF16: hipLaunchKernelGGL((add_up2x_kernel<RN_BF16>), g, b, 0, st, lat, top, out, N, H, W, C / 8); break;
+        default: hipLaunchKernelGGL((add_up2x_kernel<RN_F16>), g, b, 0, st, lat, top, out, N, H, W, C / 8); break;
+    }
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+RN_API int rn_fpn_upsample2x_backward(const void *g, void *dtop, int dtype, int N, int Ht, int Wt, int C, void *stream)
+{
+    if (!g || !dtop || N <= 0 || Ht <= 0 || Wt <= 0 || C <= 0) return RN_EINVAL;
+    if (C % 8) return RN_EUNSUPPORTED;
+    if (dtype != RN_F32 && dtype != RN_BF16 && dtype != RN_F16) return RN_EINVAL;
+    if (!rn::aligned(g, 16) || !rn::aligned(dtop, 16)) return RN_EALIGN;
+    const dim3 gr(pool_blocks((int64_t)N * Ht * Wt * (C / 8))), b(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case RN_F32: hipLaunchKernelGGL((up2x_bwd_kernel<RN_F32>), gr, b, 0, st, g, dtop, N, Ht, Wt, C / 8); break;
+        case RN_BF16: hipLaunchKernelGGL((up2x_bwd_kernel<RN_BF16>), gr, b, 0, st, g, dtop, N, Ht, Wt, C / 8); break;
+        default: hipLaunchKernelGGL((up2x_bwd_kernel<RN_F16>), gr, b, 0, st, g, dtop, N, Ht, Wt, C / 8); break;
     }
     RN_LAUNCH_CHECK();
     return RN_OK;

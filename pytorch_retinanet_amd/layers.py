@@ -19,6 +19,9 @@ from torch import Tensor, nn
 
 from . import biasact
 from .losses import RetinaNetLosses
+from .pool import add_upsample2x
+
+FUSE_FPN_UPSAMPLE = os.environ.get("RN_FUSE_FPN_UPSAMPLE", "1") != "0"     # lateral + 2x nearest upsampling in one kernel
 
 
 class FeaturePyramid(nn.Module):
@@ -49,11 +52,19 @@ class FeaturePyramid(nn.Module):
                 return self.upsample_2x(x)
         return self.upsample_2x(x)
 
+    def _lateral_plus_up(self, lat: Tensor, top: Tensor) -> Tensor:
+        "``lat + upsample_2x(top)`` (layers.py:36,52-53): one fused pass on channels-last CUDA tensors (pool.add_upsample2x)."
+        if FUSE_FPN_UPSAMPLE and lat.is_cuda:
+            out = add_upsample2x(lat, top)
+            if out is not None:
+                return out
+        return lat + self._up(top)
+
     def forward(self, inps: List[Tensor]) -> List[Tensor]:
         c3, c4, c5 = inps
         p5 = self.conv_c5_1x1(c5)
-        p4 = self.conv_c4_1x1(c4) + self._up(p5)
-        p3 = self.conv_c3_1x1(c3) + self._up(p4)
+        p4 = self._lateral_plus_up(self.conv_c4_1x1(c4), p5)
+        p3 = self._lateral_plus_up(self.conv_c3_1x1(c3), p4)
         p6 = self.conv_c6_3x3(c5)
         p7 = self.conv_c7_3x3(F.relu(p6))
         return [self.conv_c3_3x3(p3), self.conv_c4_3x3(p4), self.conv_c5_3x3(p5), p6, p7]

@@ -49,3 +49,44 @@ class FusedMaxPool2d(nn.MaxPool2d):
                 and not self.ceil_mode and not self.return_indices):
             return _MaxPool3x3s2.apply(x)
         return super().forward(x)
+
+
+class _AddUpsample2x(torch.autograd.Function):
+    """``lat + nearest_upsample_2x(top)`` of the FPN's top-down pathway in one pass (``rn_fpn_add_upsample2x``); backward:
+    the lateral's gradient is the incoming one, the top's is its 2 x 2 block sums (``rn_fpn_upsample2x_backward``)."""
+
+    @staticmethod
+    def forward(ctx, lat, top):
+        N, C, H, W = lat.shape
+        dev = lat.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        out = torch.empty_like(lat)
+        check(lib.rn_fpn_add_upsample2x(lat.data_ptr(), top.data_ptr(), out.data_ptr(), _DT[lat.dtype], N, H, W, C,
+                                        torch.cuda.current_stream().cuda_stream), "rn_fpn_add_upsample2x")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, H, W = g.shape
+        dev = g.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        if not g.is_contiguous(memory_format=torch.channels_last):
+            g = g.contiguous(memory_format=torch.channels_last)
+        dtop = None
+        if ctx.needs_input_grad[1]:
+            dtop = torch.empty((N, C, H // 2, W // 2), dtype=g.dtype, device=dev, memory_format=torch.channels_last)
+            check(lib.rn_fpn_upsample2x_backward(g.data_ptr(), dtop.data_ptr(), _DT[g.dtype], N, H // 2, W // 2, C,
+                                                 torch.cuda.current_stream().cuda_stream), "rn_fpn_upsample2x_backward")
+        return (g if ctx.needs_input_grad[0] else None), dtop
+
+
+def add_upsample2x(lat: Tensor, top: Tensor):
+    "``lat + nearest_upsample_2x(top)`` on the fused kernel, or None when the tensors are not what it takes."
+    if (lat.is_cuda and lat.dim() == 4 and lat.dtype in _DT and top.dtype == lat.dtype and lat.shape[1] % 8 == 0
+            and lat.shape[0] == top.shape[0] and lat.shape[1] == top.shape[1] and lat.shape[2] == 2 * top.shape[2]
+            and lat.shape[3] == 2 * top.shape[3] and lat.is_contiguous(memory_format=torch.channels_last)
+            and top.is_contiguous(memory_format=torch.channels_last) and lat.numel() > 0):
+        return _AddUpsample2x.apply(lat, top)
+    return None

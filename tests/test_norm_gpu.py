@@ -101,3 +101,25 @@ def test_fused_maxpool_nan_follows_torch():
     g = torch.ones_like(yr)
     y.backward(g); yr.backward(g)
     assert torch.equal(x.grad, xr.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_fpn_lateral_plus_upsample_matches_torch_bitwise(dtype):
+    """rn_fpn_add_upsample2x / rn_fpn_upsample2x_backward == lat + nn.Upsample(scale_factor=2)(top) (layers.py:36,52-53) forward
+    and backward, bit for bit: one rounding of an f32 sum either way (small-integer gradients keep the 2 x 2 sums exact)."""
+    from pytorch_retinanet_amd.pool import add_upsample2x
+    torch.manual_seed(3)
+    dev = "cuda:0"
+    lat = torch.randn(2, 16, 10, 12, device=dev).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    top = torch.randn(2, 16, 5, 6, device=dev).to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    g = torch.randint(-4, 5, (2, 16, 10, 12), device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    out = add_upsample2x(lat, top)
+    assert out is not None
+    out.backward(g)
+    got = (out.detach().clone(), lat.grad.clone(), top.grad.clone())
+    lat.grad = None; top.grad = None
+    ref = lat + torch.nn.Upsample(scale_factor=2, mode="nearest")(top)
+    ref.backward(g)
+    assert torch.equal(got[0], ref.detach()) and torch.equal(got[1], lat.grad) and torch.equal(got[2], top.grad)
+    assert add_upsample2x(lat, torch.randn(2, 16, 5, 7, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)) is None
