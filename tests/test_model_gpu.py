@@ -620,3 +620,32 @@ def test_frozen_bn_folding_equals_the_unfused_eval_path(kind):
     net.train()
     y = net.backbone(x)
     assert y[0].requires_grad
+
+
+def test_bottleneck_identity_gradient_in_conv1_gemm_equals_autograd_add():
+    """backbone._Conv1x1Skip / _SkipLink (the identity branch's gradient goes into conv1's data-gradient GEMM as its accumulator
+    input) == the plain block, where autograd adds the two gradients of the block input: outputs bit-equal, input and
+    parameter gradients equal up to one bf16 rounding of the sum."""
+    from pytorch_retinanet_amd import backbone as bb
+    torch.manual_seed(2)
+    blocks = torch.nn.Sequential(bb.Bottleneck(256, 64), bb.Bottleneck(256, 64)).to(DEV).to(memory_format=torch.channels_last).train()
+    for p in blocks.parameters():
+        if p.dim() == 4:
+            p.data = p.data.to(torch.bfloat16)
+    x0 = torch.randn(2, 256, 20, 24, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    g = torch.randn_like(x0)
+    res = {}
+    for fuse in (False, True):
+        bb.FUSE_SKIP_ADD = fuse
+        x = x0.clone().requires_grad_(True)
+        blocks.zero_grad()
+        y = blocks(x)
+        y.backward(g)
+        res[fuse] = (y.detach().clone(), x.grad.clone(), {n: p.grad.clone() for n, p in blocks.named_parameters()})
+    bb.FUSE_SKIP_ADD = True
+    assert torch.equal(res[True][0], res[False][0])
+    ref = res[False][1].float()
+    torch.testing.assert_close(res[True][1].float(), ref, rtol=2e-2, atol=2e-2 * float(ref.abs().max()))
+    for n, a in res[False][2].items():
+        b = res[True][2][n]
+        torch.testing.assert_close(b.float(), a.float(), rtol=3e-2, atol=3e-2 * float(a.float().abs().max()), msg=n)
