@@ -89,26 +89,34 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t *__restr
         float g[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) g[j] = 0.0f;
-        // windows (oy, ox) that contain (iy, ix): 2*o - 1 <= i <= 2*o + 1
+        // windows (oy, ox) that contain (iy, ix): 2*o - 1 <= i <= 2*o + 1, at most 2 x 2 of them.  All four code words and
+        // all four gradient vectors are fetched up front (clamped addresses, masked afterwards): no load waits on a compare
         const int oy0 = iy >> 1, oy1 = (iy + 1) >> 1, ox0 = ix >> 1, ox1 = (ix + 1) >> 1;
-        for (int oy = oy0; oy <= oy1; ++oy) {
-            if (oy >= s.OH) continue;
-            for (int ox = ox0; ox <= ox1; ++ox) {
-                if (ox >= s.OW) continue;
-                const int64_t w = (((int64_t)n * s.OH + oy) * s.OW + ox) * s.C8 + cg;
-                const uint32_t me = (uint32_t)((iy - (2 * oy - 1)) * 3 + (ix - (2 * ox - 1)));
-                const rn::u32x2 pk = ((const rn::u32x2 *)idx)[w];
-                const uint32_t rep = me * 0x01010101u;
-                // byte-wise compare: zero bytes of (pk ^ rep) are the channels whose arg-max is this element
-                const uint32_t d0 = pk.x ^ rep, d1 = pk.y ^ rep;
-                if (!(((d0 - 0x01010101u) & ~d0 & 0x80808080u) | ((d1 - 0x01010101u) & ~d1 & 0x80808080u))) continue;
-                float gv[8];
-                v8<DT>::ld(dy, w, gv);
+        int64_t w[4];
+        bool ok[4];
+        uint32_t rep[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    g[j] += (((d0 >> (8 * j)) & 0xffu) == 0u) ? gv[j] : 0.0f;
-                    g[j + 4] += (((d1 >> (8 * j)) & 0xffu) == 0u) ? gv[j + 4] : 0.0f;
-                }
+        for (int k = 0; k < 4; ++k) {
+            const int oy = oy0 + (k >> 1), ox = ox0 + (k & 1);
+            ok[k] = oy <= oy1 && oy < s.OH && ox <= ox1 && ox < s.OW;
+            const int oyc = ok[k] ? oy : oy0 < s.OH ? oy0 : s.OH - 1, oxc = ok[k] ? ox : ox0 < s.OW ? ox0 : s.OW - 1;
+            w[k] = (((int64_t)n * s.OH + oyc) * s.OW + oxc) * s.C8 + cg;
+            rep[k] = (uint32_t)((iy - (2 * oyc - 1)) * 3 + (ix - (2 * oxc - 1))) * 0x01010101u;
+        }
+        rn::u32x2 pk[4];
+        float gv[4][8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pk[k] = ((const rn::u32x2 *)idx)[w[k]];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v8<DT>::ld(dy, w[k], gv[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // byte-wise compare: zero bytes of (pk ^ rep) are the channels whose arg-max is this element
+            const uint32_t d0 = pk[k].x ^ rep[k], d1 = pk[k].y ^ rep[k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                g[j] += (ok[k] && ((d0 >> (8 * j)) & 0xffu) == 0u) ? gv[k][j] : 0.0f;
+                g[j + 4] += (ok[k] && ((d1 >> (8 * j)) & 0xffu) == 0u) ? gv[k][j + 4] : 0.0f;
             }
         }
         v8<DT>::st(dx, i, g);
