@@ -32,6 +32,28 @@ template <> struct v8<RN_F32> {
 
 struct PoolShape { int N, H, W, C8, OH, OW; };
 
+// (n, y, x, channel group) of flat element-group index i over [N][H][W][C8]: 32-bit divisions when the tensor has fewer than
+// 2^31 groups (a 64-bit division by a run-time value is ~150 instructions on this ISA, three of them per thread dominated
+// these kernels)
+__device__ __forceinline__ void split_index(const int64_t i, const bool small, const int C8, const int W, const int H, int &cg, int &x,
+                                            int &y, int &n)
+{
+    if (small) {
+        const uint32_t u = (uint32_t)i;
+        const uint32_t p = u / (uint32_t)C8, q = p / (uint32_t)W;
+        cg = (int)(u - p * (uint32_t)C8);
+        x = (int)(p - q * (uint32_t)W);
+        n = (int)(q / (uint32_t)H);
+        y = (int)(q - (uint32_t)n * (uint32_t)H);
+    } else {
+        cg = (int)(i % C8);
+        int64_t p = i / C8;
+        x = (int)(p % W); p /= W;
+        y = (int)(p % H);
+        n = (int)(p / H);
+    }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const void *__restrict__ x, void *__restrict__ y, uint8_t *__restrict__ idx,
                                                           const PoolShape s)
@@ -40,11 +62,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const void *__restrict
     // back to front: the producer (the stem's BN apply, 275 MB) wrote the end of x last, the Infinity Cache still holds it
     for (int64_t ii = (int64_t)blockIdx.x * 256 + threadIdx.x; ii < total; ii += (int64_t)gridDim.x * 256) {
         const int64_t i = total - 1 - ii;
-        const int cg = (int)(i % s.C8);
-        int64_t p = i / s.C8;
-        const int ox = (int)(p % s.OW); p /= s.OW;
-        const int oy = (int)(p % s.OH);
-        const int n = (int)(p / s.OH);
+        int cg, ox, oy, n;
+        split_index(i, total < (1ll << 31), s.C8, s.OW, s.OH, cg, ox, oy, n);
         float m[8];
         int k[8];
 #pragma unroll
@@ -81,11 +100,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t *__restr
 {
     const int64_t total = (int64_t)s.N * s.H * s.W * s.C8;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int cg = (int)(i % s.C8);
-        int64_t p = i / s.C8;
-        const int ix = (int)(p % s.W); p /= s.W;
-        const int iy = (int)(p % s.H);
-        const int n = (int)(p / s.H);
+        int cg, ix, iy, n;
+        split_index(i, total < (1ll << 31), s.C8, s.W, s.H, cg, ix, iy, n);
         float g[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) g[j] = 0.0f;
@@ -134,11 +150,8 @@ __global__ __launch_bounds__(256) void add_up2x_kernel(const void *__restrict__ 
     const int64_t total = (int64_t)N * H * W * C8;
     const int Wt = W >> 1, Ht = H >> 1;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int cg = (int)(i % C8);
-        int64_t p = i / C8;
-        const int x = (int)(p % W); p /= W;
-        const int y = (int)(p % H);
-        const int n = (int)(p / H);
+        int cg, x, y, n;
+        split_index(i, total < (1ll << 31), C8, W, H, cg, x, y, n);
         float a[8], b[8];
         v8<DT>::ld(lat, i, a);
         v8<DT>::ld(top, (((int64_t)n * Ht + (y >> 1)) * Wt + (x >> 1)) * C8 + cg, b);
@@ -154,11 +167,8 @@ __global__ __launch_bounds__(256) void up2x_bwd_kernel(const void *__restrict__ 
     const int64_t total = (int64_t)N * Ht * Wt * C8;
     const int W = Wt * 2, H = Ht * 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int cg = (int)(i % C8);
-        int64_t p = i / C8;
-        const int xt = (int)(p % Wt); p /= Wt;
-        const int yt = (int)(p % Ht);
-        const int n = (int)(p / Ht);
+        int cg, xt, yt, n;
+        split_index(i, total < (1ll << 31), C8, Wt, Ht, cg, xt, yt, n);
         float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
