@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RN_ABI_VERSION 1
+#define RN_ABI_VERSION 3
 #define RN_MAX_LEVELS 8
 
 enum rn_dtype { RN_F32 = 0, RN_BF16 = 1, RN_F16 = 2 };

@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
 
-from .norm import FusedBatchNorm2d, _BNAct
+from .norm import RAW_WRITES, FusedBatchNorm2d, _BNAct
 from .pool import FusedMaxPool2d
 
 __all__ = ["resnet18", "resnet34", "resnet50", "resnet101", "resnet152"]
@@ -32,17 +32,22 @@ model_urls = {
 #   w' = w * gamma / sqrt(var + eps),  b' = beta - mean * gamma / sqrt(var + eps).
 # Under no_grad with the BN layer in eval mode the blocks below run conv(x, w') and hand b' (+ residual, + ReLU) to the
 # same fused one-pass epilogue kernel the BN layers use (as an identity normalisation), so an inference step neither
-# reads the BN statistics nor re-casts fp32 weights under autocast.  The folded tensors are cached per (conv, bn, dtype)
-# and rebuilt when any of the five source tensors changes (version counters), e.g. after load_state_dict.
+# reads the BN statistics nor re-casts fp32 weights under autocast.  The folded tensors are cached on the BN module per
+# (conv, dtype) and rebuilt when any of the five source tensors changes -- torch's version counters (load_state_dict, in-place
+# torch ops) or the library's raw-pointer writes (norm.RAW_WRITES: training steps).
 FOLD_FROZEN_BN = True
-_FOLD_CACHE: Dict[tuple, tuple] = {}
 
 
 def _folded(conv: nn.Conv2d, bn: nn.BatchNorm2d, dtype: torch.dtype) -> Tuple[Tensor, ...]:
+    """Folded (weight, bias, ones, zeros, var1) of ``bn(conv(.))``, cached ON the BN module (a plain attribute: not in the
+    state dict, gone with the module) per (conv, dtype).  A hit needs the same source storages, the same torch version
+    counters AND the same ``norm.RAW_WRITES`` epoch: the library's own training kernels (fused BN forward, ``MasterSGD.step``)
+    write these tensors through raw pointers, which ``_version`` never sees."""
     src = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
-    key = (id(conv), id(bn), dtype, conv.weight.device)
-    stamp = tuple((t.data_ptr(), t._version) for t in src)
-    hit = _FOLD_CACHE.get(key)
+    stamp = (RAW_WRITES[0], id(conv)) + tuple((t.data_ptr(), t._version) for t in src)
+    cache = bn.__dict__.setdefault("_rn_fold", {})
+    key = (dtype, conv.weight.device)
+    hit = cache.get(key)
     if hit is not None and hit[0] == stamp:
         return hit[1]
     with torch.no_grad():
@@ -56,7 +61,7 @@ def _folded(conv: nn.Conv2d, bn: nn.BatchNorm2d, dtype: torch.dtype) -> Tuple[Te
         ones, zeros = torch.ones(C, device=b.device), torch.zeros(C, device=b.device)
         var1 = torch.full((C,), 1.0 - bn.eps, device=b.device)             # identity normalisation: (x - 0) / sqrt(var1 + eps) * 1 + b'
     out = (w, b, ones, zeros, var1)
-    _FOLD_CACHE[key] = (stamp, out)
+    cache[key] = (stamp, out)
     return out
 
 

@@ -26,7 +26,13 @@ from .ops import _timed          # event pairs around the MFMA conv launches whe
 _DT = {torch.float32: RN_F32, torch.bfloat16: RN_BF16, torch.float16: RN_F16}
 _WS: Dict[tuple, Tensor] = {}
 PAIR_SHEETS = os.environ.get("RN_CANVAS_SLOTS", "2") != "1"     # two images per canvas sheet (Canvas.of); RN_CANVAS_SLOTS=1: one
-MFMA_FLOP: Dict[str, float] = {}      # flop per call of every timed MFMA launch (bench.py: achieved TFLOP/s of the own conv kernels)
+MFMA_FLOP: Dict[str, float] = {}      # USEFUL flop per call of every timed MFMA launch (bench.py: achieved TFLOP/s of the own conv kernels)
+_REAL_PER_SHEET: Dict[tuple, int] = {}  # (Hp, Wp) of a canvas sheet -> feature positions on it (gaps / borders are not useful work)
+
+
+def _real_positions(N: int, Hp: int, Wp: int) -> int:
+    "Feature positions of N canvas sheets (what the flop figures count; a conv that is not on a known canvas counts all)."
+    return N * _REAL_PER_SHEET.get((Hp, Wp), Hp * Wp)
 
 
 def _mfma_call(tag: str, dev: torch.device, flop: float, status_thunk, what: str) -> None:
@@ -109,7 +115,7 @@ def _canvas_wgrad(gs, xs, ws, Wp: int, stream: int):
     if wsb is None or wsb.numel() < need:
         wsb = _WG_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
     dws = [torch.empty((256, 256, 3, 3), dtype=x0.dtype, device=dev, memory_format=torch.channels_last) for _ in range(P)]
-    _mfma_call(f"mfma_tower_wgrad_x{P}", dev, P * 2.0 * M * 256 * 2304,
+    _mfma_call(f"mfma_tower_wgrad_x{P}", dev, P * 2.0 * _real_positions(N, Hp, Wp) * 256 * 2304,
                lambda: lib.rn_conv3x3_canvas_wgrad_batched(_ptr_array(gs), _ptr_array(xs), _ptr_array(dws), P, _DT[x0.dtype], M, Wp, 256, 256,
                                                            _zero_page(dev).data_ptr(), wsb.data_ptr(), wsb.numel(), stream),
                "rn_conv3x3_canvas_wgrad_batched")
@@ -132,7 +138,7 @@ class _TowerConv(torch.autograd.Function):
         if not _cl(w):
             w = w.contiguous(memory_format=torch.channels_last)
         y = torch.empty((N, Cout, Hp, Wp), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
-        _mfma_call("mfma_tower_fwd_x1", dev, 2.0 * N * Hp * Wp * Cout * 9 * Cin,
+        _mfma_call("mfma_tower_fwd_x1", dev, 2.0 * _real_positions(N, Hp, Wp) * Cout * 9 * Cin,
                    lambda: lib.rn_conv3x3_canvas(x.data_ptr(), w.data_ptr(), bias.data_ptr(), mask.data_ptr(), y.data_ptr(), _DT[x.dtype],
                                                  N * Hp * Wp, Hp * Wp, Wp, Cin, Cout, 1, stream), "rn_conv3x3_canvas")
         ctx.save_for_backward(x, w, y, mask)
@@ -159,7 +165,7 @@ class _TowerConv(torch.autograd.Function):
         if ctx.needs_input_grad[0] and Cin % 256 == 0 and Cout % 64 == 0:
             wt = w.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)     # [Cin, Cout, 3, 3], taps reversed
             dx = torch.empty_like(x)
-            _mfma_call("mfma_tower_dgrad_x1", dev, 2.0 * M * Cout * 9 * Cin,
+            _mfma_call("mfma_tower_dgrad_x1", dev, 2.0 * _real_positions(N, Hp, Wp) * Cout * 9 * Cin,
                        lambda: lib.rn_conv3x3_canvas(g.data_ptr(), wt.data_ptr(), 0, mask.data_ptr(), dx.data_ptr(), _DT[x.dtype],
                                                      M, Hp * Wp, Wp, Cout, Cin, 0, stream), "rn_conv3x3_canvas")
         if ctx.needs_input_grad[1]:
@@ -215,7 +221,7 @@ class _TowerConvPair(torch.autograd.Function):
         rms = None
         if link is not None and FUSE_TOWER_RELU_BWD and any(ctx.needs_input_grad[:6]):
             rms = [torch.empty((N * Hp * Wp * (Cout // 8),), dtype=torch.uint8, device=dev) for _ in range(2)]
-        _mfma_call("mfma_tower_fwd_x2", dev, 2 * 2.0 * N * Hp * Wp * Cout * 9 * Cin,
+        _mfma_call("mfma_tower_fwd_x2", dev, 2 * 2.0 * _real_positions(N, Hp, Wp) * Cout * 9 * Cin,
                    lambda: lib.rn_conv3x3_canvas_batched_ex(_ptr_array([x0, x1]), _ptr_array([w0, w1]), _ptr_array([b0, b1]), mask.data_ptr(),
                                                             _ptr_array(ys), _ptr_array(rms) if rms else None, 2, _DT[x0.dtype], N * Hp * Wp,
                                                             Hp * Wp, Wp, Cin, Cout, 1, stream),
@@ -267,14 +273,14 @@ class _TowerConvPair(torch.autograd.Function):
                 if wsb is None or wsb.numel() < need:
                     wsb = _CS_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
                 dbp = [torch.empty((Cin,), dtype=torch.float32, device=dev) for _ in range(2)]
-                _mfma_call("mfma_tower_dgrad_x2", dev, 2 * 2.0 * M * Cout * 9 * Cin,
+                _mfma_call("mfma_tower_dgrad_x2", dev, 2 * 2.0 * _real_positions(N, Hp, Wp) * Cout * 9 * Cin,
                            lambda: lib.rn_conv3x3_canvas_dgrad_relu_batched(_ptr_array(gs), _ptr_array(wts), _ptr_array(prev.relu_masks), mask.data_ptr(),
                                                                             _ptr_array(dxs), _ptr_array(dbp), 2, _DT[x0.dtype], M, Hp * Wp, Wp,
                                                                             Cout, Cin, wsb.data_ptr(), wsb.numel(), stream),
                            "rn_conv3x3_canvas_dgrad_relu_batched")
                 prev.ptrs, prev.dbias = (dxs[0].data_ptr(), dxs[0]._version, dxs[1].data_ptr(), dxs[1]._version), dbp
             else:
-                _mfma_call("mfma_tower_dgrad_x2", dev, 2 * 2.0 * M * Cout * 9 * Cin,
+                _mfma_call("mfma_tower_dgrad_x2", dev, 2 * 2.0 * _real_positions(N, Hp, Wp) * Cout * 9 * Cin,
                            lambda: lib.rn_conv3x3_canvas_batched(_ptr_array(gs), _ptr_array(wts), None, mask.data_ptr(), _ptr_array(dxs), 2,
                                                                  _DT[x0.dtype], M, Hp * Wp, Wp, Cout, Cin, 0, stream), "rn_conv3x3_canvas_batched")
         dws = _canvas_wgrad(gs, [x0, x1], [w0, w1], Wp, stream)
@@ -366,6 +372,7 @@ class Canvas:
         self.mask = torch.from_numpy(m.reshape(-1)).to(device)
         self.map = torch.from_numpy(mp.reshape(-1)).to(device)
         self.fill = S * sum(h * w for h, w in self.shapes) / float(self.H * self.W)
+        _REAL_PER_SHEET[(self.H, self.W)] = S * sum(h * w for h, w in self.shapes)
 
     def sheets(self, n_images: int) -> int:
         return (n_images + self.slots - 1) // self.slots

@@ -1137,19 +1137,35 @@ RN_API int rn_conv3x3_levels_to_canvas(const void *const *gs, const rn_canvas_la
     return conv_launch_mode<MODE_FROM_LEVELS>(a, grid, (hipStream_t)stream);
 }
 
+// Position splits of the weight-gradient kernels: one workgroup per (split, tap, problem), about one wave of the chip.
+static int wgrad_splits(const int P, const int64_t M, int *tiles_per_split)
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    int S = cus / (9 * P);
+    if (S < 1) S = 1;
+    if (S > 64) S = 64;
+    const int64_t ktiles = (M + WG_POS - 1) / WG_POS;
+    const int tps = (int)((ktiles + S - 1) / S);
+    if (tiles_per_split) *tiles_per_split = tps;
+    return (int)((ktiles + tps - 1) / tps);
+}
+
+// f32 partials of the splits the launch will really use (it used to size for the 64-split maximum: 151 MB per problem)
 RN_API size_t rn_conv3x3_wgrad_workspace_bytes(int P, int64_t M)
 {
     if (P <= 0 || P > CONV_MAX_PROBLEMS || M <= 0) return 0;
-    return (size_t)P * 64 * 9 * 65536 * sizeof(float);          // up to 64 splits of the positions
+    // (the NARROW box-output launch runs P = 1 after a P - 1 launch in the same workspace: the P-problem figure covers both)
+    const int S = wgrad_splits(P, M, nullptr), S1 = wgrad_splits(1, M, nullptr);
+    return ((size_t)P * S + (size_t)S1) * 9 * 65536 * sizeof(float);
 }
 
 template <bool GATHER, bool NARROW = false>
 static int wgrad_launch(WgradArgs &a, uint16_t *const (&dw)[CONV_MAX_PROBLEMS], const int (&rows)[CONV_MAX_PROBLEMS], int P, int64_t M,
                         void *workspace, hipStream_t st, int shift_from = 0, int shift = 0, size_t *used_floats = nullptr)
 {
-    int dev = 0, cus = 0;
+    int dev = 0;
     RN_HIP(hipGetDevice(&dev));
-    RN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     {
         static bool attr_set[64] = {};
         if (dev < 0 || dev >= 64 || !attr_set[dev]) {
@@ -1158,12 +1174,7 @@ static int wgrad_launch(WgradArgs &a, uint16_t *const (&dw)[CONV_MAX_PROBLEMS], 
         }
     }
     // one workgroup per (split, tap, problem): choose the split count so that the grid is about one wave of the chip
-    int S = cus / (9 * P);
-    if (S < 1) S = 1;
-    if (S > 64) S = 64;
-    const int64_t ktiles = (M + WG_POS - 1) / WG_POS;
-    a.tiles_per_split = (int)((ktiles + S - 1) / S);
-    S = (int)((ktiles + a.tiles_per_split - 1) / a.tiles_per_split);
+    const int S = wgrad_splits(P, M, &a.tiles_per_split);
     a.S = S; a.M = M; a.partial = (float *)workspace;
     if (used_floats) *used_floats = (size_t)P * S * 9 * 65536;
     hipLaunchKernelGGL((conv3x3_wgrad_kernel<GATHER, NARROW>), dim3((unsigned)S, 9, (unsigned)P), dim3(CONV_THREADS), CONV_LDS_BYTES, st, a);

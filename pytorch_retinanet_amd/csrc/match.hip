@@ -177,7 +177,10 @@ __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_batch_kernel(
     if (fast) bb = WaveBox{wave_min(an.x), wave_min(an.y), wave_max(an.z), wave_max(an.w)};
 
     for (int b = b0; b < b1; ++b) {
-        const int j0 = gt_off[b] - g0, T = gt_off[b + 1] - gt_off[b];
+        // clamped against what was staged: an inconsistent gt_off (rows beyond the host-supplied total / beyond BATCH_GT_MAX)
+        // then matches against a truncated GT set instead of indexing past the LDS arrays
+        const int j0 = min(max(gt_off[b] - g0, 0), total);
+        const int T = min(max(gt_off[b + 1] - gt_off[b], 0), total - j0);
         float best = 0.0f;
         int bi = 0;
         Best bb2 = {0.0f, 0, false};

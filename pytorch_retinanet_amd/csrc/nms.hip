@@ -8,15 +8,16 @@
 //   inter / ((area_i + area_j) - inter) > thr,  w = max(0, xx2 - xx1), h likewise,
 // fp32, IEEE divide, no FMA contraction (file compiled with -ffp-contract=off).
 //
-// Three size classes, all launched over every segment (a block exits at once when the segment
-// is not in its class):
+// Two kernels, both launched over every segment (a block exits at once when the segment is not in its class):
 //   n <= 256   nms_mask_kernel: rank sort, pairwise suppression matrix as 64-bit ballot words in
-//              LDS, register-resident scan -- no serial loop over boxes except 4-word ORs.
-//   n <= 2048  nms_lds_kernel: bitonic sort of the 64-bit keys in LDS (keys are unique, so
-//              "stable" = key order), boxes gathered once into LDS, greedy loop with one
-//              workgroup barrier per KEPT box.
-//   larger     nms_big_kernel: LDS-chunk sort + in-HBM merge passes, HBM-resident boxes/flags
-//              (correct for any length; slower).
+//              LDS, greedy scan on SGPRs (rows fetched with v_readlane) -- no serial loop over boxes.
+//   larger     nms_large_kernel, one launch for every longer segment:
+//                n <= 2048: bitonic sort of the 64-bit keys in LDS (keys are unique, so "stable" = key
+//                           order), boxes gathered once into LDS, greedy loop with one workgroup barrier
+//                           per KEPT box;
+//                beyond:    LDS-chunk sort + in-HBM merge passes, HBM-resident boxes / flags (correct for
+//                           any length; slower).
+// nms_prep_kernel builds the 64-bit keys for the op-level entry point rn_nms_segments.
 #include "rn_internal.hpp"
 
 namespace {

@@ -99,22 +99,25 @@ class RetinaNetModel(_Base):
         else:
             raise ValueError("DATASET_KIND not supported")
 
-    def _loader(self, ds, bs, shuffle=False):
-        """Under ``torch.distributed`` every rank reads its own shard (``DistributedSampler``, what Lightning injects
-        for the reference); ``SimpleTrainer`` calls ``sampler.set_epoch`` so the shards reshuffle per epoch."""
+    def _loader(self, ds, bs, shuffle=False, shard=False):
+        """``shard``: under ``torch.distributed`` the rank reads its own shard (``DistributedSampler``, what Lightning injects
+        for the reference's train / val loaders); ``SimpleTrainer`` calls ``sampler.set_epoch`` so the shards reshuffle per
+        epoch.  The TEST loader is never sharded: ``test_epoch_end`` scores the detections a rank has seen, a shard would
+        report AP on 1/W of the images and the sampler's padding would duplicate image ids; every rank evaluates the full set."""
         import torch.distributed as dist
         sampler = None
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if shard and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             from torch.utils.data.distributed import DistributedSampler
             sampler = DistributedSampler(ds, shuffle=shuffle)
             shuffle = False
         return DataLoader(ds, bs, shuffle=shuffle, sampler=sampler, collate_fn=collate_fn, **dict(self.conf.dataloader.args))
 
     def train_dataloader(self, *args, **kwargs):
-        return self._loader(self.trn_ds, self.conf.dataloader.train_bs, shuffle=True)
+        return self._loader(self.trn_ds, self.conf.dataloader.train_bs, shuffle=True, shard=True)
 
     def val_dataloader(self, *args, **kwargs):
-        return None if self.val_ds is None else self._loader(self.val_ds, self.conf.dataloader.valid_bs)
+        # sharded: SimpleTrainer averages the validation loss over ranks (a padded duplicate shifts a mean loss by O(1/len))
+        return None if self.val_ds is None else self._loader(self.val_ds, self.conf.dataloader.valid_bs, shard=True)
 
     def test_dataloader(self, *args, **kwargs):
         from .coco_eval import CocoEvaluator, gt_from_dataset

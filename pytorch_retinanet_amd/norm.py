@@ -27,6 +27,15 @@ from ._lib import RN_BF16, RN_F16, RN_F32, check, lib
 
 _DT = {torch.float32: RN_F32, torch.bfloat16: RN_BF16, torch.float16: RN_F16}
 _WS: Dict[tuple, Tensor] = {}          # (device index, stream) -> reduction workspace
+# Bumped whenever the library writes parameters or BN buffers THROUGH RAW POINTERS (the fused training forward updates the
+# running statistics, ``optim.MasterSGD.step`` the weights, a captured step replays both): torch's ``_version`` counters do
+# not see those writes, so anything derived from such tensors (``backbone._folded``) stamps itself with this counter too.
+RAW_WRITES = [0]
+
+
+def note_raw_write() -> None:
+    RAW_WRITES[0] += 1
+
 _fwd, _bwd = lib.rn_bn_act_forward, lib.rn_bn_act_backward
 
 
@@ -64,6 +73,8 @@ class _BNAct(torch.autograd.Function):
                    num_batches_tracked.data_ptr() if num_batches_tracked is not None else 0, int(training), momentum, eps,
                    int(relu), sp, sp + 4 * Cc, sp + 8 * Cc, bits.data_ptr() if bits is not None else 0, wp, wn, stream),
               "rn_bn_act_forward")
+        if training and running_mean is not None:
+            RAW_WRITES[0] += 1                                    # running statistics updated behind torch's back
         ctx.save_for_backward(x, bits, weight, stats)
         ctx.cfg = (bool(training), bool(relu), residual is not None, M, Cc)
         ctx.link = link

@@ -18,6 +18,7 @@ import torch
 from torch import Tensor, nn
 
 from ._lib import check, lib
+from .norm import note_raw_write
 
 
 def use_bf16_conv_weights(model: nn.Module) -> int:
@@ -70,6 +71,7 @@ class MasterSGD(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        note_raw_write()                   # masters, bf16 copies and BN affine parameters change without a _version bump
         for group in self.param_groups:
             masters, moms, gptrs, p16s, ns = [], [], [], [], []
             grads16 = None

@@ -608,7 +608,7 @@ def test_frozen_bn_folding_equals_the_unfused_eval_path(kind):
         ref, got = run(False, autocast), run(True, autocast)
         for a, b in zip(ref, got):
             torch.testing.assert_close(b, a, rtol=tol, atol=tol * float(a.abs().max()))
-    assert len(backbone._FOLD_CACHE) > 0
+    assert len(net.backbone.backbone.bn1.__dict__.get("_rn_fold", {})) > 0        # the fold lives on its BN module
     before = run(True, False)
     with torch.no_grad():
         net.backbone.backbone.bn1.running_mean.add_(0.5)             # statistics change -> version counter -> the fold is rebuilt
@@ -620,6 +620,44 @@ def test_frozen_bn_folding_equals_the_unfused_eval_path(kind):
     net.train()
     y = net.backbone(x)
     assert y[0].requires_grad
+
+
+def test_frozen_bn_fold_is_rebuilt_after_the_librarys_own_training_writes():
+    """MasterSGD.step and the fused training BN forward write weights / running statistics through raw
+    pointers, which never bump torch's ``_version`` counters.  fold -> train step -> fold again must see the NEW tensors:
+    the folded eval output equals the unfolded one after the step, and differs from the one cached before it."""
+    import pytorch_retinanet_amd as P
+    from pytorch_retinanet_amd import backbone
+    from pytorch_retinanet_amd.optim import MasterSGD, use_bf16_conv_weights
+    torch.manual_seed(5)
+    net = P.Retinanet(num_classes=4, backbone_kind="resnet18", pretrained=False, min_size=128, max_size=160).to(DEV)
+    net = net.to(memory_format=torch.channels_last)
+    use_bf16_conv_weights(net)
+    opt = MasterSGD(net.parameters(), lr=0.05, momentum=0.9)
+    x = torch.randn(2, 3, 128, 160, device=DEV).contiguous(memory_format=torch.channels_last)
+
+    def eval_features(fold):
+        backbone.FOLD_FROZEN_BN = fold
+        net.eval()
+        try:
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                return [o.float() for o in net.backbone(x)]
+        finally:
+            backbone.FOLD_FROZEN_BN = True
+    before = eval_features(True)                                     # populates the fold cache
+    net.train()
+    images = [torch.rand(3, 128, 160, device=DEV) for _ in range(2)]
+    targets = [{"boxes": torch.tensor([[10., 12., 90., 100.]], device=DEV), "labels": torch.tensor([1], device=DEV)} for _ in range(2)]
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = net(images, targets)
+        (out["classification_loss"] + out["regression_loss"]).backward()
+        opt.step()
+    after, ref = eval_features(True), eval_features(False)
+    assert not torch.allclose(before[0], after[0])                   # the stale fold would have reproduced `before`
+    for a, b in zip(ref, after):
+        torch.testing.assert_close(b, a, rtol=4e-2, atol=4e-2 * float(a.abs().max()))
 
 
 def test_bottleneck_identity_gradient_in_conv1_gemm_equals_autograd_add():
