@@ -12,7 +12,9 @@ Weak scaling: per-GPU batch is fixed, `value` = all ranks' images / max-over-ran
 
 The JSON line also carries
   roofline     -- the dominant dense-head kernel (K3 loss fwd+bwd): algorithmic bytes per launch /
-                  its average duration measured with events on the launch stream inside the timed steps;
+                  its average duration measured with HIP events right around the kernel on the launch stream, in eager
+                  replays of the same step run right after the timed region (the timed steps are hipGraph replays), plus
+                  the same kernel on cold logits (`frac_cold`);
   cpu_baseline -- the CPU oracle (oracle/rn_oracle.c, OpenMP) timed on this box's host cores on the
                   same dense-head workload (rank 0, N=1 only; bounded sample).
 """
@@ -49,6 +51,8 @@ def parse():
     ap.add_argument("--torch-sgd", action="store_true", help="fp32 parameters + torch.optim.SGD instead of fp32 masters + bf16 conv weights (optim.MasterSGD); same arithmetic")
     ap.add_argument("--cpu-baseline-reps", type=int, default=30, help="batches of the dense-head workload timed on the host (about 10 s of CPU work)")
     ap.add_argument("--no-detect", action="store_true", help="skip the inference-chain (decode + NMS + top-k) roofline line (BASELINE configs[3] shape)")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel of every step from Python instead of replaying the captured hipGraph of the step (graph.CapturedTrainStep)")
+    ap.add_argument("--timing-steps", type=int, default=5, help="eager steps run AFTER the timed region with HIP events around the hand-written kernels (per-kernel figures of the JSON line)")
     return ap.parse_args()
 
 
@@ -113,7 +117,8 @@ def self_launch(args) -> int:
 def cpu_train_step_baseline(args):
     """The WHOLE train step on the host, one image: transform -> R50-FPN + heads (PyTorch's CPU kernels, fp32 -- what the
     reference itself runs on a CPU) -> anchors + IoU match + focal / smooth-L1 loss with gradients (the CPU oracle) ->
-    backward through the conv stack -> SGD(momentum) step.  One warm-up step, then the median of 2 timed steps."""
+    backward through the conv stack -> SGD(momentum) step.  One warm-up step, then the median of 4 timed steps (8-9 s each:
+    the >= 10 reps of SURVEY 8d would add two minutes to every bench run; the unit string says what was done)."""
     import oracle
     import synth
     import pytorch_retinanet_amd as P
@@ -126,7 +131,7 @@ def cpu_train_step_baseline(args):
     gtb, gtl = synth.gt_boxes(rng, args.gt, 800, 1333)
     cells = [oracle.cell_anchors(sz, synth.ANCHOR_RATIOS) for sz in synth.ANCHOR_SIZES]
     times = []
-    for _ in range(3):
+    for _ in range(5):
         t0 = time.perf_counter()
         opt.zero_grad(set_to_none=True)
         il, _ = net.transform([img], None)
@@ -138,8 +143,9 @@ def cpu_train_step_baseline(args):
         opt.step()
         times.append(time.perf_counter() - t0)
     t = float(np.median(times[1:]))
-    return {"value": round(1.0 / t, 4), "unit": "images/sec (whole train step, fp32, batch 1)", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "median of 2 steps (after 1 warm-up) of ONE 3x800x1333 image: PyTorch CPU conv stack forward + backward + SGD, "
+    return {"value": round(1.0 / t, 4), "unit": "images/sec (whole train step, fp32, batch 1; median of 4 steps after 1 warm-up)",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "median of 4 steps (after 1 warm-up) of ONE 3x800x1333 image: PyTorch CPU conv stack forward + backward + SGD, "
                       "dense head on oracle/rn_oracle.c", "s_per_step": round(t, 3)}
 
 
@@ -173,27 +179,65 @@ def detect_chain_line(device, with_cpu):
     ops.enable_timing(False)
     ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
     nbytes = B * (A * K * 2 + A * 4 * 2 + A * 16)              # logits + deltas + anchors per image
+    # bytes that can reach HBM: the logits once, ONE shared anchor set and one delta row only at the candidate anchors
+    unique = B * A * K * 2 + ncand * (4 * 2 + 16)
     line = {"bound": "hbm", "kernel": "rn_detect chain (score_scan + seg_count + seg_scatter + nms_mask + nms_large + topk)",
             "workload": f"B={B} A={A} K={K} fp16, {ncand // B} candidates/image", "achieved": round(nbytes / (ms * 1e-3) / 1e9, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_call_ms": round(ms, 4),
-            "algorithmic_bytes_per_call": nbytes}
+            "algorithmic_bytes_per_call": nbytes, "unique_bytes_per_call": unique,
+            "frac_on_unique_bytes": round(unique / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     cpu = None
     if with_cpu:
         import oracle
         oracle.build()
         c1, b1, a1 = cls[:1].float().cpu().numpy(), box[:1].float().cpu().numpy(), anc.cpu().numpy()
         times = []
-        for _ in range(4):
+        for _ in range(13):
             t0 = time.perf_counter()
             ref = oracle.detect(c1, b1, a1, hw[:1])
             times.append(time.perf_counter() - t0)
-        t = float(np.median(times[1:]))
+        t = float(np.median(times[3:]))
         assert np.array_equal(dets[0]["labels"].cpu().numpy(), ref[0]["labels"])       # the checker, checking
         cpu = {"value": round(1.0 / t, 3), "unit": "images/sec (decode + NMS + top-100 chain only, fp32 oracle)", "cores": oracle.num_threads(),
-               "kind": "port", "sample": f"3 reps of ONE image of the batch (A={A}, K={K}); the GPU line processes 16 per call",
+               "kind": "port", "sample": f"median of 10 reps after 3 warm-ups of ONE image of the batch (A={A}, K={K}); the GPU line processes 16 per call",
                "ms_per_image": round(t * 1e3, 2), "gpu_images_per_sec": round(B / (ms * 1e-3), 1)}
     del cls, box
     return line, cpu
+
+
+def k3_cold_line(device, B, T, nbytes):
+    """K3 at the train shape on COLD logits (the isolated kernel: the in-step figure of `roofline` reads logits the
+    class-output conv has just left in the 256 MiB Infinity Cache, walking them back to front).  Per-level bf16 tensors as
+    the head writes them; a 1 GiB fill between launches evicts the cache; events right around the streaming kernel."""
+    import synth
+    from pytorch_retinanet_amd import ops
+    from pytorch_retinanet_amd.anchors import AnchorGenerator
+    K = 90
+    shapes = [(100, 168), (50, 84), (25, 42), (13, 21), (7, 11)]
+    ag = AnchorGenerator().to(device)
+    anc = ops.anchors_emit(synth.levels_for(800, 1344), list(ag.cell_anchors), 0.0)
+    g = torch.Generator(device=device).manual_seed(2)
+    cls = [(torch.randn((B, h * w * 9, K), device=device, generator=g) - 4.6).to(torch.bfloat16) for h, w in shapes]
+    box = [(torch.randn((B, h * w * 9, 4), device=device, generator=g) * 0.1).to(torch.bfloat16) for h, w in shapes]
+    rng = np.random.default_rng(0)
+    gtb, gtl = zip(*[synth.gt_boxes(rng, T, 800, 1333) for _ in range(B)])
+    gt_boxes = torch.from_numpy(np.concatenate(gtb)).to(device)
+    gt_labels = torch.from_numpy(np.concatenate(gtl)).to(device)
+    off = ops.gt_offsets([T] * B, device)
+    matches, num_fg = ops.iou_match(anc, gt_boxes, off, B, 0.5, 0.4)
+    params = ops.make_loss_params(0.25, 2.0, 0.1)                      # config.py: alpha, gamma, smooth-L1 beta
+    evict = torch.empty((1 << 30,), dtype=torch.uint8, device=device)
+    ops.enable_timing(True)
+    for _ in range(13):
+        evict.fill_(1)
+        ops.loss_fwd_bwd_levels(cls, box, anc, gt_boxes, gt_labels, off, matches, num_fg, params)
+    torch.cuda.synchronize()
+    ev = ops.timing_events()["loss_stream_kernel"][3:]
+    ops.enable_timing(False)
+    ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+    return {"avg_launch_ms_cold": round(ms, 4), "achieved_cold": round(nbytes / (ms * 1e-3) / 1e9, 1),
+            "frac_cold": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "cold_sample": "median of 10 isolated launches after 3 warm-ups, 1 GiB fill between launches (Infinity Cache evicted)"}
 
 
 def main():
@@ -233,44 +277,38 @@ def main():
     ddp = P.BucketedGradAllReduce(net) if (world > 1 or args.force_ddp) else None
     images, targets = synth_batch(args.batch, args.gt, seed=rank, device=device)
 
-    def step():
-        if ddp:
-            ddp.zero_grad()
-        else:
-            optimizer.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            losses = net(images, targets)
-            loss = losses["classification_loss"] + losses["regression_loss"]
-        loss.backward()
-        if ddp:
-            ddp.finish()
-            if args.torch_sgd:
-                optimizer.step()
-            else:
-                optimizer.step(grads=ddp.grad_views())
-        else:
-            optimizer.step()
-        return loss
-
-    for _ in range(args.warmup):
-        step()
+    # One step = graph.CapturedTrainStep: zero_grad -> autocast forward -> backward -> (bucketed all-reduce) -> SGD.  The first
+    # two calls run eagerly (MIOpen find, caches, optimizer state), the third captures the step in a hipGraph, and every
+    # later call is one graph replay (--no-graph: every call enqueues its ~700 kernels from Python).
+    from pytorch_retinanet_amd.graph import CapturedTrainStep
+    stepper = CapturedTrainStep(net, optimizer, ddp, amp_dtype=torch.bfloat16, eager_steps=2, enabled=not args.no_graph)
+    n_warm = max(args.warmup, 3 if not args.no_graph else 0)       # (the capture itself must not fall into the timed region)
+    for _ in range(n_warm):
+        stepper(images, targets)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    ops.enable_timing(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        out = stepper(images, targets)
     host_enqueue = time.perf_counter() - t0      # (diagnostic: the host is done enqueueing here; the GPU usually is not)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    final_loss = float(out["loss"])
+    graph_replays = stepper.replays
+    # per-kernel figures: the same step, enqueued eagerly with a pair of HIP events around every hand-written kernel (events
+    # recorded inside a captured graph are dependency markers, not timestamps), right after the timed region, same data
+    ops.enable_timing(True)
+    for _ in range(max(args.timing_steps, 1)):
+        stepper._step(images, targets)
+    torch.cuda.synchronize()
     ev = ops.timing_events() or {}
     ops.enable_timing(False)
-    final_loss = float(loss.detach())
+    timing_steps = max(args.timing_steps, 1)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -318,7 +356,7 @@ def main():
         # MFMA share: whole step on the model's useful flops, and the hand-written conv kernels alone (events around each launch)
         from pytorch_retinanet_amd import biasact
         step_s = elapsed / args.steps
-        own = {k: (kms[k], biasact.MFMA_FLOP[k], len(ev[k]) / args.steps) for k in kms if k.startswith("mfma_") and k in biasact.MFMA_FLOP}
+        own = {k: (kms[k], biasact.MFMA_FLOP[k], len(ev[k]) / timing_steps) for k in kms if k.startswith("mfma_") and k in biasact.MFMA_FLOP}
         own_flop = sum(f * n for _, f, n in own.values())
         own_ms = sum(ms * n for ms, _, n in own.values())
         conv_mfma = {"peak_tflops": MFMA_PEAK_TFLOPS,
@@ -331,7 +369,7 @@ def main():
         line = {
             "metric": "images/sec RetinaNet-R50-FPN train step @800x1333",
             "value": round(world * args.batch * args.steps / elapsed, 3),
-            "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": n_warm,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -341,13 +379,16 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
             "roofline": roof, "roofline_other": roof_other, "conv_mfma": conv_mfma,
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 0,
+            "step_launch": {"mode": "hipGraph replay" if graph_replays else "eager", "graph_replays_in_run": graph_replays,
+                            "per_kernel_events": f"{timing_steps} eager steps after the timed region"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, A, K)
             line["cpu_baseline"]["train_step"] = cpu_train_step_baseline(args)
         if world == 1 and not args.no_detect:
-            del net, optimizer
+            del net, optimizer, stepper
             torch.cuda.empty_cache()
+            line["roofline"].update(k3_cold_line(device, args.batch, args.gt, nbytes))
             det_line, det_cpu = detect_chain_line(device, not args.no_cpu_baseline)
             line["roofline_other"]["detect_chain"] = det_line
             if det_cpu is not None:

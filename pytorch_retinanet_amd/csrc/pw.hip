@@ -1,0 +1,672 @@
+// Backbone / FPN convolutions as bf16 MFMA GEMMs on channels-last activations, with the BatchNorm work that surrounds them
+// fused in (reference: the Bottleneck of retinanet/backbone.py:105-136 -- conv1x1 -> bn -> relu ->
+// conv3x3 -> bn -> relu -> conv1x1 -> bn -> (+ identity) -> relu -- and the 1x1 / 3x3 convs of the FPN, layers.py:44-64).
+//
+// Why: at the R50 shapes (8 x 200 x 336 x {64, 256} at layer1) these convolutions are HBM-bound -- 51 .. 102 flop per byte
+// against the ~300 the chip needs to be compute-bound -- and so is every BatchNorm pass around them.  MIOpen runs
+// conv, statistics, normalise, ReLU and their gradients as separate passes over the same 69 - 275 MB tensors (2/3 of the
+// step in round 2).  Here the GEMM's operand load applies the PREVIOUS layer's BatchNorm + ReLU (forward) or BatchNorm
+// backward (the gradient GEMMs), and its epilogue produces what the NEXT BatchNorm kernel needs (per-channel sums of the
+// output; ReLU mask + the two sums of the BatchNorm backward; the residual branch's gradient), so those passes disappear.
+//
+//   pw_gemm_kernel    Y[M][N] = pro(X)[M][taps * Cin] . W[N][taps * Cin]^T      forward and data gradient
+//                     (1x1 and 3x3, stride 1 / 2 through a per-row position decode; a 3x3 data gradient is the same
+//                     kernel on the tap-reversed, role-swapped weight)
+//   pw_wgrad_kernel   dW[N][taps][Cin] = sum_m pro(G)[m][N] . pro(X)[pos(m, tap)][Cin]        weight gradient
+//
+// Both stage their operands global -> registers -> (transform) -> LDS, because the transforms need the data in registers
+// and the 3x3 / strided gathers need per-row validity; tiles are 128 x {64,128} x 64 with 4 waves, two workgroups per CU
+// overlap each other's loads and MFMAs (the convolutions this file serves are bandwidth-bound: the matrix pipe is not the
+// limit).  Numerics: bf16 operands, f32 accumulation; every fused BatchNorm expression is the one csrc/norm.hip uses
+// (same fma order, statistics taken from the bf16-ROUNDED output), so fused and unfused layers agree to the bit wherever
+// the GEMM's own summation order does.
+#include "rn_common.hpp"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int PW_BM = 128, PW_BK = 64, PW_THREADS = 256;
+constexpr int PW_MAX_GX = 512;                  // persistent row-tile walkers = BN partial rows (norm.hip: BN_MAX_BLOCKS)
+#define PW_SWZ(row) (((row) >> 1) & 7)
+
+enum { PRO_NONE = 0, PRO_AFFINE_RELU = 1, PRO_BN_BWD = 2 };
+enum { EPI_STATS = 1, EPI_RESID = 2, EPI_RELU_BWD = 4 };
+
+__device__ __forceinline__ float alive_bf16() { return __uint_as_float(0x00004000u); }   // norm.hip: relu_alive_threshold<RN_BF16>
+
+struct PwArgs {
+    const uint16_t *X, *X2;         // X: [rows][Cin];  PRO_BN_BWD: X = upstream gradient g, X2 = the BN input z (same shape)
+    const uint8_t *xbits;           // PRO_BN_BWD, relu_mode 3: ReLU bits of the BN output [rows][Cin / 8]
+    const uint16_t *W;              // [N][taps * Cin]
+    uint16_t *Y;                    // [M][N]
+    const float *pa, *pb, *pc;      // AFFINE_RELU: y = relu(x * pa + pb);  BN_BWD: dz = pa * g' + pc * z + pb   (a, k0, k1)
+    const float *fa, *fb;           // BN_BWD, relu_mode 2: g' = g * [fma(z, fa, fb) > alive]
+    float *partial;                 // EPI_STATS / EPI_RELU_BWD: [gx][2][N]
+    const uint16_t *R;              // EPI_RESID: Y += R * rbits   ([M][N] and [M][N / 8])
+    const uint8_t *rbits;
+    const uint16_t *Zp;             // EPI_RELU_BWD: Y = Y * [fma(Zp, ea, eb) > alive]; sums of Y and Y * (Zp - emean) * einv
+    const float *ea, *eb, *emean, *einv;
+    int M, Cin, N, taps;            // M output rows; K = taps * Cin
+    int relu_mode;                  // PRO_BN_BWD: 0 none, 2 recomputed from X2, 3 bits
+    int stride, pad, Ho, Wo, H, W_; // position decode of output row m = (n, ho, wo) -> input (n, ho * stride - pad + dy, ...)
+    int gx;                         // row-tile walkers per column tile
+};
+
+// one output row of the tile as this thread sees it: image base (in rows) and the top-left input coordinate
+struct RowPos { int base, y0, x0; bool ok; };
+
+__device__ __forceinline__ RowPos decode_row(const PwArgs &a, const int m)
+{
+    RowPos r;
+    r.ok = m < a.M;
+    const int mm = r.ok ? m : 0;
+    if (a.taps == 1 && a.stride == 1) { r.base = mm; r.y0 = 0; r.x0 = 0; return r; }
+    const int hw = a.Ho * a.Wo;
+    const int n = mm / hw, rem = mm - n * hw, ho = rem / a.Wo, wo = rem - ho * a.Wo;
+    r.base = n * a.H * a.W_;
+    r.y0 = ho * a.stride - a.pad;
+    r.x0 = wo * a.stride - a.pad;
+    return r;
+}
+
+__device__ __forceinline__ void ld8f(const float *p, float (&f)[8])
+{
+    const rn::f32x4 u = ((const rn::f32x4 *)p)[0], v = ((const rn::f32x4 *)p)[1];
+    f[0] = u.x; f[1] = u.y; f[2] = u.z; f[3] = u.w; f[4] = v.x; f[5] = v.y; f[6] = v.z; f[7] = v.w;
+}
+
+// The operand transforms on one 16-byte vector of 8 consecutive channels (same expressions as norm.hip).
+struct ProCoef { float a[8], b[8], c[8], fa[8], fb[8]; };
+template <int PRO>
+__device__ __forceinline__ void load_coef(ProCoef &k, const float *pa, const float *pb, const float *pc, const float *fa, const float *fb,
+                                          const int relu_mode, const int ch)
+{
+    if (PRO == PRO_NONE) return;
+    ld8f(pa + ch, k.a); ld8f(pb + ch, k.b);
+    if (PRO == PRO_BN_BWD) {
+        ld8f(pc + ch, k.c);
+        if (relu_mode == 2) { ld8f(fa + ch, k.fa); ld8f(fb + ch, k.fb); }
+    }
+}
+template <int PRO>
+__device__ __forceinline__ rn::u32x4 transform(const rn::u32x4 x, const rn::u32x4 z, const uint32_t bits, const ProCoef &k, const int relu_mode,
+                                               const bool valid)
+{
+    if (PRO == PRO_NONE) return valid ? x : rn::u32x4{0u, 0u, 0u, 0u};
+    float f[8], g[8];
+    rn::dt<RN_BF16>::unpack(x, f);
+    if (PRO == PRO_AFFINE_RELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float t = fmaf(f[j], k.a[j], k.b[j]); f[j] = t > 0.0f ? t : 0.0f; }
+    } else {
+        rn::dt<RN_BF16>::unpack(z, g);
+        const float alive = alive_bf16();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float gj = f[j];
+            if (relu_mode == 2 && !(fmaf(g[j], k.fa[j], k.fb[j]) > alive)) gj = 0.0f;
+            if (relu_mode == 3 && !((bits >> j) & 1u)) gj = 0.0f;
+            f[j] = fmaf(k.a[j], gj, fmaf(k.c[j], g[j], k.b[j]));
+        }
+    }
+    const rn::u32x4 o = rn::dt<RN_BF16>::pack(f);
+    return valid ? o : rn::u32x4{0u, 0u, 0u, 0u};
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+template <int BN, int PRO, int EPI>
+__global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
+{
+    constexpr int MI = 2, NI = BN / 64;                         // 2 x 2 waves of 64 x (BN / 2)
+    constexpr int A_TILE = PW_BM * PW_BK * 2, B_TILE = BN * PW_BK * 2, STAGE = A_TILE + B_TILE;
+    constexpr int BROWS = BN / 32;                              // weight rows staged per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // 2 stages of [A | B]; the epilogue's f32 tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.y * BN;
+    const int cpt = a.Cin / PW_BK, KT = a.taps * cpt, Ktot = a.taps * a.Cin;
+    const int c = tid & 7, r0 = tid >> 3;                       // this thread stages 16-byte chunk c of rows r0 + 32 i
+    const int MT = (a.M + PW_BM - 1) / PW_BM;
+
+    uint32_t a_off[4], b_off[4];                                // fragment addresses of the 4 k-steps (first fragment)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int chunk = kk * 2 + (lane >> 5);
+        { const int row = wm * 64 + (lane & 31); a_off[kk] = row * 128 + ((chunk ^ PW_SWZ(row)) << 4); }
+        { const int row = wn * (BN / 2) + (lane & 31); b_off[kk] = A_TILE + row * 128 + ((chunk ^ PW_SWZ(row)) << 4); }
+    }
+    uint32_t wa_off[4], wb_off[BROWS];                          // where this thread's staged chunks go
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int row = r0 + 32 * i; wa_off[i] = row * 128 + ((c ^ PW_SWZ(row)) << 4); }
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) { const int row = r0 + 32 * i; wb_off[i] = A_TILE + row * 128 + ((c ^ PW_SWZ(row)) << 4); }
+
+    // column statistics of the tiles this workgroup walks (EPI_STATS / EPI_RELU_BWD): thread = 8 fixed columns
+    constexpr int CG = BN / 8, RL = PW_THREADS / CG;            // column groups, row lanes of the epilogue
+    const int ecg = tid % CG, erl = tid / CG;
+    float ssum[8], qsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ssum[j] = 0.0f; qsum[j] = 0.0f; }
+
+    for (int mt = blockIdx.x; mt < MT; mt += a.gx) {
+        const int m0 = mt * PW_BM;
+        RowPos rp[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rp[i] = decode_row(a, m0 + r0 + 32 * i);
+
+        f32x16 acc[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+        rn::u32x4 sx[4], sz[4], sw[BROWS];
+        uint32_t sbits[4] = {0xffu, 0xffu, 0xffu, 0xffu};
+        bool sval[4];
+        ProCoef coef;
+        auto issue = [&](const int kt) {
+            const int tap = kt / cpt, c0 = (kt - tap * cpt) * PW_BK;
+            const int dy = a.taps == 1 ? 0 : tap / 3, dx = a.taps == 1 ? 0 : tap - (tap / 3) * 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int y = rp[i].y0 + dy, x = rp[i].x0 + dx;
+                const bool v = rp[i].ok && (a.taps == 1 && a.stride == 1 ? true : (y >= 0 && y < a.H && x >= 0 && x < a.W_));
+                sval[i] = v;
+                const int64_t row = v ? (int64_t)rp[i].base + (a.taps == 1 && a.stride == 1 ? 0 : y * a.W_ + x) : 0;      // clamped: always a valid address
+                const int64_t e = row * a.Cin + c0 + c * 8;
+                sx[i] = *(const rn::u32x4 *)(a.X + e);
+                if (PRO == PRO_BN_BWD) {
+                    sz[i] = *(const rn::u32x4 *)(a.X2 + e);
+                    if (a.relu_mode == 3) sbits[i] = a.xbits[e >> 3];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < BROWS; ++i)
+                sw[i] = *(const rn::u32x4 *)(a.W + (int64_t)(n0 + r0 + 32 * i) * Ktot + kt * PW_BK + c * 8);
+            load_coef<PRO>(coef, a.pa, a.pb, a.pc, a.fa, a.fb, a.relu_mode, c0 + c * 8);
+        };
+        auto commit = [&](const int stage) {
+            unsigned char *const sb = lds + stage * STAGE;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(rn::u32x4 *)(sb + wa_off[i]) = transform<PRO>(sx[i], sz[i], sbits[i], coef, a.relu_mode, sval[i]);
+#pragma unroll
+            for (int i = 0; i < BROWS; ++i) *(rn::u32x4 *)(sb + wb_off[i]) = sw[i];
+        };
+
+        issue(0);
+        commit(0);
+        __syncthreads();
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt + 1 < KT) issue(kt + 1);                     // in flight under this K-tile's MFMAs
+            const unsigned char *const sb = lds + (kt & 1) * STAGE;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                bf16x8 fa[MI], fb[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) fa[mi] = *(const bf16x8 *)(sb + a_off[kk] + mi * 4096);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) fb[ni] = *(const bf16x8 *)(sb + b_off[kk] + ni * 4096);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+            }
+            if (kt + 1 < KT) commit((kt + 1) & 1);
+            __syncthreads();
+        }
+
+        // ---- epilogue: accumulators -> f32 tile in LDS -> rows of 8-channel vectors
+        float *const tile = (float *)lds;                       // [128][BN]
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int col = wn * (BN / 2) + ni * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    tile[row * BN + col] = acc[mi][ni][r];
+                }
+            }
+        __syncthreads();
+        float ea[8], eb[8], emu[8], eis[8];
+        if (EPI & EPI_RELU_BWD) {
+            ld8f(a.ea + n0 + ecg * 8, ea); ld8f(a.eb + n0 + ecg * 8, eb);
+            ld8f(a.emean + n0 + ecg * 8, emu); ld8f(a.einv + n0 + ecg * 8, eis);
+        }
+        const float alive = alive_bf16();
+#pragma unroll
+        for (int i = 0; i < PW_BM / RL; ++i) {
+            const int row = erl + i * RL;
+            const int m = m0 + row;
+            if (m < a.M) {
+                float v[8];
+                ld8f(tile + row * BN + ecg * 8, v);
+                const int64_t e = (int64_t)m * a.N + n0 + ecg * 8;
+                if (EPI & EPI_RESID) {
+                    float r[8];
+                    rn::dt<RN_BF16>::unpack(*(const rn::u32x4 *)(a.R + e), r);
+                    const uint32_t bits = a.rbits[e >> 3];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += ((bits >> j) & 1u) ? r[j] : 0.0f;
+                }
+                rn::u32x4 o = rn::dt<RN_BF16>::pack(v);
+                if (EPI & (EPI_STATS | EPI_RELU_BWD)) {
+                    rn::dt<RN_BF16>::unpack(o, v);              // the statistics are those of the stored (rounded) tensor
+                    if (EPI & EPI_RELU_BWD) {
+                        float z[8];
+                        rn::dt<RN_BF16>::unpack(*(const rn::u32x4 *)(a.Zp + e), z);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            if (!(fmaf(z[j], ea[j], eb[j]) > alive)) v[j] = 0.0f;
+                            ssum[j] += v[j];
+                            qsum[j] = fmaf(v[j], (z[j] - emu[j]) * eis[j], qsum[j]);
+                        }
+                        o = rn::dt<RN_BF16>::pack(v);          // exact: v is a bf16 value or zero
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; qsum[j] = fmaf(v[j], v[j], qsum[j]); }
+                    }
+                }
+                *(rn::u32x4 *)(a.Y + e) = o;
+            }
+        }
+        __syncthreads();                                        // the tile is the next row tile's staging area
+    }
+
+    if (EPI & (EPI_STATS | EPI_RELU_BWD)) {
+        float *const red = (float *)lds;                        // [RL][2][BN]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[(erl * 2 + 0) * BN + ecg * 8 + j] = ssum[j]; red[(erl * 2 + 1) * BN + ecg * 8 + j] = qsum[j]; }
+        __syncthreads();
+        for (int q = tid; q < 2 * BN; q += PW_THREADS) {
+            float t = 0.0f;
+            for (int l = 0; l < RL; ++l) t += red[l * 2 * BN + q];
+            const int which = q >= BN ? 1 : 0;
+            a.partial[((int64_t)blockIdx.x * 2 + which) * a.N + n0 + (q - which * BN)] = t;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient.  dW[n][tap][c] = sum_m G'[m][n] * X'[pos(m, tap)][c]: the contraction index is the position, so both
+// operands are k-strided ([position][channel] rows); tiles are staged as they lie (64 positions x TN / TK channels) and the
+// MFMA fragments are read with the transposing ds_read_b64_tr_b16 (see conv.hip's weight-gradient kernel for the lane map).
+// 16-byte chunks of a row are XOR-swizzled so that the four rows of a transposed 4 x 16 block hit different banks.
+struct WgArgs {
+    const uint16_t *G, *G2;         // [M][N]; PRO_BN_BWD: G = upstream gradient, G2 = BN input z
+    const uint8_t *gbits;
+    const float *ga, *gb, *gc, *gfa, *gfb;
+    int g_relu_mode;
+    const uint16_t *X;              // [rows][Cin]; PRO_AFFINE_RELU: relu(x * xa + xb)
+    const float *xa, *xb;
+    float *partial;                 // [S][N][taps * Cin] f32
+    int M, N, Cin, taps, stride, pad, Ho, Wo, H, W_;
+    int S, tiles_per_split;         // K-tiles of 64 positions per split
+};
+
+template <int W> __device__ __forceinline__ int tr_swz(const int row) { return W >= 128 ? ((row & 3) << 2) : (((row >> 1) & 1) << 2); }
+
+template <int TN, int TK, int PROG, int PROX>
+__global__ __launch_bounds__(PW_THREADS, 2) void pw_wgrad_kernel(const WgArgs a)
+{
+    constexpr int MI = TN / 64, NI = TK / 64;                   // 2 x 2 waves of (TN / 2) x (TK / 2)
+    constexpr int G_ROWB = TN * 2, X_ROWB = TK * 2;
+    constexpr int G_TILE = 64 * G_ROWB, X_TILE = 64 * X_ROWB;
+    constexpr int GV = TN / 32, XV = TK / 32;                   // 16-byte vectors per thread and tile
+    constexpr int GCH = TN / 8, XCH = TK / 8;                   // chunks per row
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // [G | X]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int split = blockIdx.x;
+    const int tiles_k = a.Cin / TK, tiles_n = a.N / TN;
+    int t = blockIdx.y;
+    const int tk = t % tiles_k; t /= tiles_k;
+    const int tn = t % tiles_n; t /= tiles_n;
+    const int tap = t;
+    const int n0 = tn * TN, c0 = tk * TK;
+    const int dy = a.taps == 1 ? 0 : tap / 3, dx = a.taps == 1 ? 0 : tap - (tap / 3) * 3;
+    const bool plain = a.taps == 1 && a.stride == 1;
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // transposed-read addresses (conv.hip): lane = 16 grp + 4 q + p
+    const int grp = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    uint32_t g_off[MI], x_off[NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int ch = wm * (TN / 16) + mi * 4 + 2 * (grp & 1) + (p >> 1);
+        g_off[mi] = (uint32_t)((8 * (grp >> 1) + q) * G_ROWB + ((ch ^ tr_swz<TN>(q)) << 4) + (p & 1) * 8);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int ch = wn * (TK / 16) + ni * 4 + 2 * (grp & 1) + (p >> 1);
+        x_off[ni] = (uint32_t)(G_TILE + (8 * (grp >> 1) + q) * X_ROWB + ((ch ^ tr_swz<TK>(q)) << 4) + (p & 1) * 8);
+    }
+    const int gc_ = tid % GCH, gr0 = tid / GCH;                 // G staging: chunk gc_ of rows gr0 + i * (256 / GCH)
+    const int xc_ = tid % XCH, xr0 = tid / XCH;
+    constexpr int GRS = PW_THREADS / GCH, XRS = PW_THREADS / XCH;
+
+    ProCoef gcoef, xcoef;
+    load_coef<PROG>(gcoef, a.ga, a.gb, a.gc, a.gfa, a.gfb, a.g_relu_mode, n0 + gc_ * 8);
+    load_coef<PROX>(xcoef, a.xa, a.xb, nullptr, nullptr, nullptr, 0, c0 + xc_ * 8);
+
+    const int KT = a.tiles_per_split;
+    const int m_begin = split * KT * 64;
+    rn::u32x4 sg[GV], sg2[GV], sx[XV];
+    uint32_t sgb[GV];
+    bool gval[GV], xval[XV];
+    auto issue = [&](const int kt) {
+        const int t0 = m_begin + kt * 64;
+#pragma unroll
+        for (int i = 0; i < GV; ++i) {
+            const int m = t0 + gr0 + i * GRS;
+            gval[i] = m < a.M;
+            const int64_t e = (int64_t)(gval[i] ? m : 0) * a.N + n0 + gc_ * 8;
+            sg[i] = *(const rn::u32x4 *)(a.G + e);
+            sgb[i] = 0xffu;
+            if (PROG == PRO_BN_BWD) {
+                sg2[i] = *(const rn::u32x4 *)(a.G2 + e);
+                if (a.g_relu_mode == 3) sgb[i] = a.gbits[e >> 3];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int m = t0 + xr0 + i * XRS;
+            bool v = m < a.M;
+            int64_t row = v ? m : 0;
+            if (!plain) {
+                const int mm = (int)row, hw = a.Ho * a.Wo;
+                const int n = mm / hw, rem = mm - n * hw, ho = rem / a.Wo, wo = rem - ho * a.Wo;
+                const int y = ho * a.stride - a.pad + dy, x = wo * a.stride - a.pad + dx;
+                v = v && y >= 0 && y < a.H && x >= 0 && x < a.W_;
+                row = v ? (int64_t)n * a.H * a.W_ + y * a.W_ + x : 0;
+            }
+            xval[i] = v;
+            sx[i] = *(const rn::u32x4 *)(a.X + row * a.Cin + c0 + xc_ * 8);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < GV; ++i) {
+            const int row = gr0 + i * GRS;
+            *(rn::u32x4 *)(lds + row * G_ROWB + ((gc_ ^ tr_swz<TN>(row)) << 4)) = transform<PROG>(sg[i], sg2[i], sgb[i], gcoef, a.g_relu_mode, gval[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int row = xr0 + i * XRS;
+            *(rn::u32x4 *)(lds + G_TILE + row * X_ROWB + ((xc_ ^ tr_swz<TK>(row)) << 4)) = transform<PROX>(sx[i], sx[i], 0xffu, xcoef, 0, xval[i]);
+        }
+    };
+    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+    struct U2 { unsigned long long lo, hi; };
+    if (m_begin < a.M) {
+        issue(0);
+        for (int kt = 0; kt < KT && m_begin + kt * 64 < a.M; ++kt) {
+            commit();
+            __syncthreads();
+            if (kt + 1 < KT && m_begin + (kt + 1) * 64 < a.M) issue(kt + 1);      // in flight under the MFMAs
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                unsigned long long fg[MI][2], fx[NI][2];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fg[mi][0]) : "v"(lds_base + g_off[mi] + kk * 16 * G_ROWB));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fg[mi][1]) : "v"(lds_base + g_off[mi] + (kk * 16 + 4) * G_ROWB));
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fx[ni][0]) : "v"(lds_base + x_off[ni] + kk * 16 * X_ROWB));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fx[ni][1]) : "v"(lds_base + x_off[ni] + (kk * 16 + 4) * X_ROWB));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, U2{fg[mi][0], fg[mi][1]}),
+                                                                              __builtin_bit_cast(bf16x8, U2{fx[ni][0], fx[ni][1]}), acc[mi][ni], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+    const int Ktot = a.taps * a.Cin;
+    float *__restrict__ out = a.partial + (int64_t)split * a.N * Ktot;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = c0 + wn * (TK / 2) + ni * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + wm * (TN / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                out[(int64_t)row * Ktot + tap * a.Cin + col] = acc[mi][ni][r];
+            }
+        }
+}
+
+// dW (bf16) = sum over the splits of partial (f32), 4 elements per thread
+__global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float *__restrict__ partial, const int S, const int64_t n4, uint16_t *__restrict__ dw)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    rn::f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < S; ++sp) {
+        const rn::f32x4 v = ((const rn::f32x4 *)partial)[sp * n4 + i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    rn::u32x2 o;
+    o.x = rn::dt<RN_BF16>::pk(s.x, s.y); o.y = rn::dt<RN_BF16>::pk(s.z, s.w);
+    ((rn::u32x2 *)dw)[i] = o;
+}
+
+int cu_count()
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return cus;
+}
+
+int walkers(const int M)
+{
+    const int MT = (M + PW_BM - 1) / PW_BM;
+    if (MT <= PW_MAX_GX) return MT;
+    const int rounds = (MT + PW_MAX_GX - 1) / PW_MAX_GX;
+    return (MT + rounds - 1) / rounds;
+}
+
+template <int BN, int PRO, int EPI> int launch_gemm(const PwArgs &a, hipStream_t st)
+{
+    constexpr int lds = 2 * (PW_BM * PW_BK * 2 + BN * PW_BK * 2) > PW_BM * BN * 4 ? 2 * (PW_BM * PW_BK * 2 + BN * PW_BK * 2) : PW_BM * BN * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        RN_HIP(hipFuncSetAttribute((const void *)pw_gemm_kernel<BN, PRO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((pw_gemm_kernel<BN, PRO, EPI>), dim3((unsigned)a.gx, (unsigned)(a.N / BN)), dim3(PW_THREADS), lds, st, a);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+template <int BN, int PRO> int dispatch_epi(const PwArgs &a, const int epi, hipStream_t st)
+{
+    switch (epi) {
+        case 0: return launch_gemm<BN, PRO, 0>(a, st);
+        case EPI_STATS: return launch_gemm<BN, PRO, EPI_STATS>(a, st);
+        case EPI_RESID: return launch_gemm<BN, PRO, EPI_RESID>(a, st);
+        case EPI_RELU_BWD: return launch_gemm<BN, PRO, EPI_RELU_BWD>(a, st);
+        default: return RN_EUNSUPPORTED;
+    }
+}
+
+template <int TN, int TK, int PROG, int PROX> int launch_wgrad(const WgArgs &a, hipStream_t st)
+{
+    constexpr int lds = 64 * (TN + TK) * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        RN_HIP(hipFuncSetAttribute((const void *)pw_wgrad_kernel<TN, TK, PROG, PROX>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const unsigned gy = (unsigned)((a.N / TN) * (a.Cin / TK) * a.taps);
+    hipLaunchKernelGGL((pw_wgrad_kernel<TN, TK, PROG, PROX>), dim3((unsigned)a.S, gy), dim3(PW_THREADS), lds, st, a);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+template <int TN, int TK> int dispatch_wgrad(const WgArgs &a, const int prog, const int prox, hipStream_t st)
+{
+    if (prog == PRO_NONE && prox == PRO_NONE) return launch_wgrad<TN, TK, PRO_NONE, PRO_NONE>(a, st);
+    if (prog == PRO_NONE && prox == PRO_AFFINE_RELU) return launch_wgrad<TN, TK, PRO_NONE, PRO_AFFINE_RELU>(a, st);
+    if (prog == PRO_BN_BWD && prox == PRO_NONE) return launch_wgrad<TN, TK, PRO_BN_BWD, PRO_NONE>(a, st);
+    if (prog == PRO_BN_BWD && prox == PRO_AFFINE_RELU) return launch_wgrad<TN, TK, PRO_BN_BWD, PRO_AFFINE_RELU>(a, st);
+    return RN_EUNSUPPORTED;
+}
+
+// weight-gradient tile of an [N][Cin] problem: as much of the small matrix per workgroup as 64 accumulator registers hold
+void wgrad_tile(const int N, const int Cin, int &TN, int &TK)
+{
+    if (N >= 128 && Cin >= 128) { TN = 128; TK = 128; }
+    else if (N >= 128) { TN = N >= 256 ? 256 : 128; TK = 64; }
+    else if (Cin >= 128) { TN = 64; TK = Cin >= 256 ? 256 : 128; }
+    else { TN = 64; TK = 64; }
+}
+
+int wgrad_splits(const rn_pw_conv *d, int *tiles_per_split)
+{
+    int TN, TK;
+    wgrad_tile(d->N, d->Cin, TN, TK);
+    const int tiles = (d->N / TN) * (d->Cin / TK) * d->taps;
+    int S = (2 * cu_count() + tiles - 1) / tiles;                // about two workgroups per CU
+    const int ktiles = (d->M + 63) / 64;
+    if (S > ktiles) S = ktiles;
+    if (S > 512) S = 512;
+    if (S < 1) S = 1;
+    const int tps = (ktiles + S - 1) / S;
+    if (tiles_per_split) *tiles_per_split = tps;
+    return (ktiles + tps - 1) / tps;
+}
+
+int check_geometry(const rn_pw_conv *d)
+{
+    if (!d || d->M <= 0 || d->Cin <= 0 || d->N <= 0) return RN_EINVAL;
+    if (d->Cin % 64 || d->N % 64) return RN_EUNSUPPORTED;
+    if (d->taps != 1 && d->taps != 9) return RN_EUNSUPPORTED;
+    if (d->stride < 1 || d->pad < 0 || d->Ho <= 0 || d->Wo <= 0 || d->H <= 0 || d->W <= 0) return RN_EINVAL;
+    if (d->M % (d->Ho * d->Wo)) return RN_EINVAL;
+    if ((int64_t)(d->M / (d->Ho * d->Wo)) * d->H * d->W >= ((int64_t)1 << 31) || (int64_t)d->M * d->N >= ((int64_t)1 << 40)) return RN_EUNSUPPORTED;
+    return RN_OK;
+}
+
+}  // namespace
+
+RN_API int rn_pw_walkers(int64_t M) { return M > 0 && M < ((int64_t)1 << 31) ? walkers((int)M) : 0; }
+
+RN_API int rn_pw_conv_forward(const rn_pw_conv *d, const void *x, const void *w, void *y, const rn_pw_prologue *pro,
+                              const rn_pw_epilogue *epi, void *stream)
+{
+    const int rc = check_geometry(d);
+    if (rc != RN_OK) return rc;
+    if (!x || !w || !y) return RN_EINVAL;
+    if (!rn::aligned(x, 16) || !rn::aligned(w, 16) || !rn::aligned(y, 16)) return RN_EALIGN;
+    PwArgs a = {};
+    a.X = (const uint16_t *)x; a.W = (const uint16_t *)w; a.Y = (uint16_t *)y;
+    a.M = (int)d->M; a.Cin = d->Cin; a.N = d->N; a.taps = d->taps; a.stride = d->stride; a.pad = d->pad;
+    a.Ho = d->Ho; a.Wo = d->Wo; a.H = d->H; a.W_ = d->W;
+    a.gx = walkers(a.M);
+    int p = PRO_NONE, e = 0;
+    if (pro && pro->kind != PRO_NONE) {
+        p = pro->kind;
+        if (p == PRO_AFFINE_RELU) {
+            if (!pro->a || !pro->b) return RN_EINVAL;
+            a.pa = pro->a; a.pb = pro->b;
+        } else if (p == PRO_BN_BWD) {
+            if (!pro->a || !pro->b || !pro->c || !pro->x2) return RN_EINVAL;
+            if (pro->relu_mode == 2 && (!pro->fa || !pro->fb)) return RN_EINVAL;
+            if (pro->relu_mode == 3 && !pro->bits) return RN_EINVAL;
+            if (pro->relu_mode != 0 && pro->relu_mode != 2 && pro->relu_mode != 3) return RN_EINVAL;
+            a.pa = pro->a; a.pb = pro->b; a.pc = pro->c; a.fa = pro->fa; a.fb = pro->fb; a.X2 = (const uint16_t *)pro->x2;
+            a.xbits = pro->bits; a.relu_mode = pro->relu_mode;
+        } else return RN_EINVAL;
+    }
+    if (epi && epi->kind != 0) {
+        e = epi->kind;
+        if (e == EPI_STATS) { if (!epi->partial) return RN_EINVAL; a.partial = epi->partial; }
+        else if (e == EPI_RESID) { if (!epi->resid || !epi->rbits) return RN_EINVAL; a.R = (const uint16_t *)epi->resid; a.rbits = epi->rbits; }
+        else if (e == EPI_RELU_BWD) {
+            if (!epi->partial || !epi->zprev || !epi->ea || !epi->eb || !epi->emean || !epi->einv) return RN_EINVAL;
+            a.partial = epi->partial; a.Zp = (const uint16_t *)epi->zprev; a.ea = epi->ea; a.eb = epi->eb; a.emean = epi->emean; a.einv = epi->einv;
+        } else return RN_EINVAL;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const bool wide = d->N % 128 == 0;
+#define RN_PW_GO(BN)                                                                 \
+    switch (p) {                                                                     \
+        case PRO_NONE: return dispatch_epi<BN, PRO_NONE>(a, e, st);                  \
+        case PRO_AFFINE_RELU: return dispatch_epi<BN, PRO_AFFINE_RELU>(a, e, st);    \
+        default: return dispatch_epi<BN, PRO_BN_BWD>(a, e, st);                      \
+    }
+    if (wide) { RN_PW_GO(128) } else { RN_PW_GO(64) }
+#undef RN_PW_GO
+}
+
+RN_API size_t rn_pw_wgrad_workspace_bytes(const rn_pw_conv *d)
+{
+    if (check_geometry(d) != RN_OK) return 0;
+    const int S = wgrad_splits(d, nullptr);
+    return (size_t)S * d->N * d->taps * d->Cin * sizeof(float);
+}
+
+RN_API int rn_pw_conv_wgrad(const rn_pw_conv *d, const void *g, const void *x, void *dw, const rn_pw_prologue *gpro,
+                            const rn_pw_prologue *xpro, void *workspace, size_t workspace_bytes, void *stream)
+{
+    const int rc = check_geometry(d);
+    if (rc != RN_OK) return rc;
+    if (!g || !x || !dw || !workspace) return RN_EINVAL;
+    if (!rn::aligned(g, 16) || !rn::aligned(x, 16) || !rn::aligned(dw, 16) || !rn::aligned(workspace, 16)) return RN_EALIGN;
+    if (workspace_bytes < rn_pw_wgrad_workspace_bytes(d)) return RN_EWORKSPACE;
+    WgArgs a = {};
+    a.G = (const uint16_t *)g; a.X = (const uint16_t *)x; a.partial = (float *)workspace;
+    a.M = (int)d->M; a.N = d->N; a.Cin = d->Cin; a.taps = d->taps; a.stride = d->stride; a.pad = d->pad;
+    a.Ho = d->Ho; a.Wo = d->Wo; a.H = d->H; a.W_ = d->W;
+    a.S = wgrad_splits(d, &a.tiles_per_split);
+    int pg = PRO_NONE, px = PRO_NONE;
+    if (gpro && gpro->kind != PRO_NONE) {
+        if (gpro->kind != PRO_BN_BWD || !gpro->a || !gpro->b || !gpro->c || !gpro->x2) return RN_EINVAL;
+        if (gpro->relu_mode == 2 && (!gpro->fa || !gpro->fb)) return RN_EINVAL;
+        if (gpro->relu_mode == 3 && !gpro->bits) return RN_EINVAL;
+        if (gpro->relu_mode != 0 && gpro->relu_mode != 2 && gpro->relu_mode != 3) return RN_EINVAL;
+        pg = PRO_BN_BWD;
+        a.G2 = (const uint16_t *)gpro->x2; a.gbits = gpro->bits; a.ga = gpro->a; a.gb = gpro->b; a.gc = gpro->c; a.gfa = gpro->fa; a.gfb = gpro->fb;
+        a.g_relu_mode = gpro->relu_mode;
+    }
+    if (xpro && xpro->kind != PRO_NONE) {
+        if (xpro->kind != PRO_AFFINE_RELU || !xpro->a || !xpro->b) return RN_EINVAL;
+        px = PRO_AFFINE_RELU;
+        a.xa = xpro->a; a.xb = xpro->b;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int TN, TK, r;
+    wgrad_tile(d->N, d->Cin, TN, TK);
+    if (TN == 128 && TK == 128) r = dispatch_wgrad<128, 128>(a, pg, px, st);
+    else if (TN == 256) r = dispatch_wgrad<256, 64>(a, pg, px, st);
+    else if (TN == 128) r = dispatch_wgrad<128, 64>(a, pg, px, st);
+    else if (TK == 256) r = dispatch_wgrad<64, 256>(a, pg, px, st);
+    else if (TK == 128) r = dispatch_wgrad<64, 128>(a, pg, px, st);
+    else r = dispatch_wgrad<64, 64>(a, pg, px, st);
+    if (r != RN_OK) return r;
+    const int64_t n4 = (int64_t)d->N * d->taps * d->Cin / 4;
+    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float *)workspace, a.S, n4, (uint16_t *)dw);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}

@@ -121,15 +121,32 @@ def anchors_emit(levels: Sequence[Tuple[int, int, int]], cells: Sequence[Tensor]
     return out
 
 
+_GT_OFF_CACHE = {}          # (counts, device) -> device int32[B+1]; bounded (see gt_offsets)
+
+
 def gt_offsets(counts: Sequence[int], device: torch.device) -> Tensor:
-    off = [0]
-    for c in counts:
-        off.append(off[-1] + int(c))
-    host = torch.tensor(off, dtype=torch.int32)
-    if torch.device(device).type != "cuda":
+    """Prefix offsets of the per-image GT rows as a device int32[B+1].  Cached per (counts, device): training data repeats
+    a handful of count tuples, the upload disappears from the step, and a step captured in a hipGraph (``graph.py``) never
+    copies from temporary host memory.  Treat the result as read-only."""
+    device = torch.device(device)
+    if device.type != "cuda":
         raise RuntimeError("pytorch_retinanet_amd: gt offsets are a device array (there is no CPU fallback)")
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = (tuple(int(c) for c in counts), device.index)
+    hit = _GT_OFF_CACHE.get(key)
+    if hit is not None:
+        return hit
+    off = [0]
+    for c in key[0]:
+        off.append(off[-1] + c)
+    host = torch.tensor(off, dtype=torch.int32)
     # pinned + non_blocking: the copy is stream-ordered and does not drain the launch queue
-    return host.pin_memory().to(device, non_blocking=True)
+    dev_t = host.pin_memory().to(device, non_blocking=True)
+    if len(_GT_OFF_CACHE) >= 4096:
+        _GT_OFF_CACHE.clear()
+    _GT_OFF_CACHE[key] = dev_t
+    return dev_t
 
 
 def iou_match(anchors: Tensor, gt_boxes: Tensor, gt_off: Tensor, B: int, fg_thr: float, bg_thr: float,

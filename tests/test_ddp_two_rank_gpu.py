@@ -53,3 +53,33 @@ def test_two_ranks_equal_each_other_and_the_global_batch(tmp_path, precision, to
     # the global-batch loss is the mean of the two ranks' local losses (per-image normalisation, equal local batches)
     for s in range(len(single["losses"])):
         assert abs(single["losses"][s] - 0.5 * (r0["losses"][s] + r1["losses"][s])) <= (1e-4 if precision == "32" else 2e-2) * abs(single["losses"][s])
+
+
+def test_two_ranks_with_live_batchnorm_match_the_emulated_ranks(tmp_path):
+    """Q18 (retinanet/backbone.py:348-351: BN is only frozen at construction, DDP training runs it in train mode): per-GPU
+    batch statistics and running-stat updates under the bucket hooks.  Ranks stay bit-equal in their parameters; each rank's
+    running statistics equal those of a single process that runs that rank's shard with that rank's buffers and steps on the
+    averaged gradients."""
+    out = str(tmp_path)
+    _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+          "--master-port", str(_free_port()), TOOL, "--out", out, "--precision", "32", "--bn", "train"])
+    _run([sys.executable, TOOL, "--single", "--out", out, "--precision", "32", "--bn", "train", "--ranks", "2"])
+    r = [torch.load(os.path.join(out, f"rank{i}.pt")) for i in range(2)]
+    single = torch.load(os.path.join(out, "single.pt"))
+    for k, a in r[0]["params"].items():
+        assert torch.equal(a, r[1]["params"][k]), f"ranks diverged at {k}"
+        b = single["params"][k]
+        assert torch.allclose(a, b, rtol=0, atol=2e-5), (k, float((a - b).abs().max()))
+    differ = 0
+    for i in range(2):
+        mine, ref = r[i]["bn_buffers"][0], single["bn_buffers"][i]
+        assert mine.keys() == ref.keys() and len(mine) > 0
+        for k in mine:
+            assert torch.allclose(mine[k], ref[k], rtol=1e-5, atol=1e-6), (i, k, float((mine[k] - ref[k]).abs().max()))
+            if "num_batches_tracked" in k:
+                assert int(mine[k]) == 3
+    for k in r[0]["bn_buffers"][0]:
+        differ += int(not torch.equal(r[0]["bn_buffers"][0][k], r[1]["bn_buffers"][0][k]))
+    assert differ > 0                                 # the statistics really are per GPU (different shards)
+    for s in range(len(single["losses"])):
+        assert abs(single["losses"][s] - 0.5 * (r[0]["losses"][s] + r[1]["losses"][s])) <= 1e-4 * abs(single["losses"][s])

@@ -1,0 +1,43 @@
+"""GPU: the RCCL (``nccl`` backend) branch of the data-parallel path on hardware, at world size 1 -- the one GPU this
+build has (the reference reaches NCCL through Lightning's DDP, model.py:112-119).
+
+``bench.py --gpus 1 --force-ddp`` creates a real RCCL process group, routes every gradient through
+``BucketedGradAllReduce`` (async ``all_reduce(AVG)`` from the autograd hooks on RCCL's stream, ``finish()`` wait,
+``MasterSGD.step(grads=grad_views())``) and captures that whole step -- collectives included -- in the hipGraph.  The run is
+a child process (started before this process touches the GPU is not required: it is a spawn, not an exec); the JSON lines of
+both runs are kept under profiles/ when ``RN_KEEP_PROFILES`` is set.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _bench(*extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "3", "--no-cpu-baseline",
+           "--no-detect", "--timing-steps", "1"] + list(extra)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_world1_rccl_step_matches_the_plain_step():
+    ddp = _bench("--force-ddp")
+    plain = _bench()
+    assert ddp["rccl_ranks"] == 1 and plain["rccl_ranks"] == 0
+    assert ddp["n_gpus"] == 1 and ddp["config"]["parallelism"] == "dp1"
+    for line in (ddp, plain):
+        assert line["value"] > 0 and line["config"]["final_loss"] == line["config"]["final_loss"]      # finite (not NaN)
+        assert 0 < line["config"]["final_loss"] < 100
+    # the exchange of one rank is an identity: same throughput within run-to-run noise
+    assert abs(ddp["value"] - plain["value"]) <= 0.05 * plain["value"], (ddp["value"], plain["value"])
+    assert abs(ddp["config"]["final_loss"] - plain["config"]["final_loss"]) <= 0.05 * plain["config"]["final_loss"]
+    if os.environ.get("RN_KEEP_PROFILES"):
+        with open(os.path.join(ROOT, "gpurun_out", "r03_rccl_world1.json"), "w") as f:
+            json.dump({"force_ddp": ddp, "plain": plain}, f, indent=1)

@@ -6,11 +6,16 @@
         tools/ddp_two_rank.py --out DIR [--precision 32|bf16]
     python tools/ddp_two_rank.py --single --out DIR [--precision 32|bf16]      # same global batch, one process
 
-Model: RetinaNet-R18-FPN, K = 5, 128x160 inputs, BatchNorm frozen on its running statistics (per-GPU batch statistics
--- the reference's behaviour, Q18 -- would make a 2 x 2 split differ from a batch of 4 by construction).  Global batch
-4; rank r takes images [2r, 2r+1].  Three steps of ``BucketedGradAllReduce`` + ``MasterSGD.step(grads=grad_views())``.
-Every rank saves its fp32 parameters (masters) to DIR/rank{r}.pt, the single-process run to DIR/single.pt;
-``tests/test_ddp_two_rank_gpu.py`` compares them.
+Model: RetinaNet-R18-FPN, K = 5, 128x160 inputs.  Global batch 4; rank r takes images [2r, 2r+1].  Three steps of
+``BucketedGradAllReduce`` + ``MasterSGD.step(grads=grad_views())``.
+  --bn frozen (default): BatchNorm on its running statistics, so the 2 x 2 split equals one process on the batch of 4.
+  --bn train: BatchNorm in train mode like the reference under DDP (Q18, retinanet/backbone.py:348-351 only freezes at
+      construction; Lightning's .train() un-freezes): per-GPU batch statistics and per-GPU running-stat updates under the
+      bucket hooks.  The single-process counterpart (``--single``) then EMULATES the ranks: per step it runs each rank's
+      shard through the model with that rank's own BN buffers, accumulates loss / W gradients and steps once -- the same
+      arithmetic as the exchange, so parameters and each rank's running statistics must agree.
+Every rank saves its fp32 parameters (masters) and BN buffers to DIR/rank{r}.pt, the single-process run to DIR/single.pt
+(``bn_buffers``: one dict per emulated rank); ``tests/test_ddp_two_rank_gpu.py`` compares them.
 """
 import argparse
 import os
@@ -33,6 +38,8 @@ def main():
     ap.add_argument("--precision", default="32", choices=["32", "bf16"])
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--global-batch", type=int, default=4)
+    ap.add_argument("--bn", default="frozen", choices=["frozen", "train"])
+    ap.add_argument("--ranks", type=int, default=2, help="--single --bn train: number of ranks to emulate")
     args = ap.parse_args()
     world = 1 if args.single else int(os.environ["WORLD_SIZE"])
     rank = 0 if args.single else int(os.environ["RANK"])
@@ -51,19 +58,32 @@ def main():
             for p in net.parameters():
                 p.add_(0.01)
     net = net.to(dev).to(memory_format=torch.channels_last).train()
-    for m in net.modules():
-        if isinstance(m, torch.nn.BatchNorm2d):
-            m.eval()
+    live_bn = args.bn == "train"
+    if not live_bn:
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.eval()
     bf16 = args.precision == "bf16"
     if bf16:
         use_bf16_conv_weights(net)
     opt = MasterSGD(net.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-3)
-    ddp = P.BucketedGradAllReduce(net, bucket_mb=8.0)           # several buckets for a 20 M-parameter model
-    assert ddp.num_buckets >= 3
+    emulate = args.ranks if (args.single and live_bn) else 0
+    ddp = None if emulate else P.BucketedGradAllReduce(net, bucket_mb=8.0)           # several buckets for a 20 M-parameter model
+    assert emulate or ddp.num_buckets >= 3
+
+    def bn_buffers():
+        return {n: b.detach().clone() for n, b in net.named_buffers() if "running_" in n or "num_batches_tracked" in n}
+
+    def load_bn_buffers(bufs):
+        with torch.no_grad():
+            for n, b in net.named_buffers():
+                if n in bufs:
+                    b.copy_(bufs[n])
+    rank_bufs = [bn_buffers() for _ in range(emulate)]
 
     rng = np.random.default_rng(99)
     G = args.global_batch
-    per = G // world
+    per = G // (emulate or world)
     losses = []
     for step in range(args.steps):
         images = [torch.from_numpy(rng.random((3, 128, 160), dtype=np.float32)) for _ in range(G)]
@@ -71,6 +91,23 @@ def main():
         for _ in range(G):
             b, l = synth.gt_boxes(rng, 3, 128, 160, num_classes=5, wh_lo=20.0, wh_hi=90.0)
             targets.append({"boxes": torch.from_numpy(b), "labels": torch.from_numpy(l)})
+        if emulate:
+            opt.zero_grad(set_to_none=True)
+            tot = 0.0
+            for r in range(emulate):
+                mine = slice(r * per, (r + 1) * per)
+                imgs = [i.to(dev) for i in images[mine]]
+                tgts = [{k: v.to(dev) for k, v in t.items()} for t in targets[mine]]
+                load_bn_buffers(rank_bufs[r])
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+                    out = net(imgs, tgts)
+                    loss = out["classification_loss"] + out["regression_loss"]
+                (loss / emulate).backward()                 # gradients accumulate: the average the exchange computes
+                rank_bufs[r] = bn_buffers()
+                tot += float(loss.detach()) / emulate
+            opt.step()
+            losses.append(tot)
+            continue
         mine = slice(rank * per, (rank + 1) * per)
         imgs = [i.to(dev) for i in images[mine]]
         tgts = [{k: v.to(dev) for k, v in t.items()} for t in targets[mine]]
@@ -85,12 +122,13 @@ def main():
     torch.cuda.synchronize()
     state = {n: (p.master if hasattr(p, "master") else p.data).detach().float().cpu() for n, p in net.named_parameters()}
     os.makedirs(args.out, exist_ok=True)
-    torch.save({"params": state, "losses": losses, "buckets": ddp.bucket_bytes()},
+    bufs = [{n: b.float().cpu() for n, b in rb.items()} for rb in rank_bufs] if emulate else [{n: b.float().cpu() for n, b in bn_buffers().items()}]
+    torch.save({"params": state, "losses": losses, "buckets": ddp.bucket_bytes() if ddp else [], "bn_buffers": bufs},
                os.path.join(args.out, "single.pt" if args.single else f"rank{rank}.pt"))
     if not args.single:
         dist.barrier()
         dist.destroy_process_group()
-    print(f"rank {rank}/{world}: losses {['%.5f' % x for x in losses]} buckets {ddp.num_buckets}", flush=True)
+    print(f"rank {rank}/{world}: losses {['%.5f' % x for x in losses]} buckets {ddp.num_buckets if ddp else 0}", flush=True)
 
 
 if __name__ == "__main__":
