@@ -171,6 +171,77 @@ int rn_bn_act_backward(const void *dy, const void *y, const void *x, void *dx, v
                        const float *fwd_coef, int training, int relu, float *dgamma, float *dbeta, float *coef,
                        void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same BatchNorm arithmetic in pieces, for layers whose statistics come out of a GEMM epilogue and whose normalisation
+ * goes into a GEMM operand load (rn_pw_conv_*): every piece is the kernel rn_bn_act_* runs, bit for bit.
+ *   rn_bn_stats            statistics pass only (partial + final): fills save_mean / save_invstd / coef [2][C], updates the
+ *                          running statistics; the activation is not written.
+ *   rn_bn_stats_finalize   the final step alone, from `nblocks` rows of partial sums f32[nblocks][2][C] (sum, sum of squares)
+ *                          produced elsewhere (rn_pw_conv_forward, epilogue RN_PW_EPI_STATS).
+ *   rn_bn_apply            y = relu?(x * coef_a + coef_b (+ residual)) (+ relu_mask bits).
+ *   rn_bn_bwd_reduce       backward sums (partial + final): dgamma, dbeta and coef3 [3][C] = (a, k0, k1) of
+ *                          dx = a * g' + k1 * x + k0; relu as in rn_bn_act_backward (0 / 1 / 2).
+ *   rn_bn_bwd_finalize     the final step alone, from partial sums f32[nblocks][2][C] = (sum g', sum g' * xhat).
+ *   rn_bn_bwd_apply        dx (and dresidual = g', nullable) from coef3; relu_mode 0 none, 1 mask from y, 2 recomputed from
+ *                          x and fwd_coef, 3 bits in `y`. */
+int rn_bn_stats(const void *x, int dtype, int64_t M, int C, const float *gamma, const float *beta, float *running_mean,
+                float *running_var, int64_t *num_batches_tracked, float momentum, float eps, float *save_mean,
+                float *save_invstd, float *coef, void *workspace, size_t workspace_bytes, void *stream);
+int rn_bn_stats_finalize(const float *partial, int nblocks, int64_t M, int C, const float *gamma, const float *beta,
+                         float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum, float eps,
+                         float *save_mean, float *save_invstd, float *coef, void *stream);
+int rn_bn_apply(const void *x, const void *residual, void *y, int dtype, int64_t M, int C, const float *coef, int relu,
+                uint8_t *relu_mask, void *stream);
+int rn_bn_bwd_reduce(const void *dy, const void *y, const void *x, int dtype, int64_t M, int C, const float *gamma,
+                     const float *save_mean, const float *save_invstd, const float *fwd_coef, int training, int relu,
+                     float *dgamma, float *dbeta, float *coef3, void *workspace, size_t workspace_bytes, void *stream);
+int rn_bn_bwd_finalize(const float *partial, int nblocks, int64_t M, int C, const float *gamma, const float *save_mean,
+                       const float *save_invstd, int training, float *dgamma, float *dbeta, float *coef3, void *stream);
+int rn_bn_bwd_apply(const void *dy, const void *y, const void *x, void *dx, void *dresidual, int dtype, int64_t M, int C,
+                    const float *coef3, const float *fwd_coef, int relu_mode, void *stream);
+
+/* ---- backbone / FPN convolutions as MFMA GEMMs with the surrounding BatchNorm fused in (csrc/pw.hip) --------------------
+ * Replaces the conv -> bn -> relu chains of the reference's Bottleneck (retinanet/backbone.py:105-136: conv1x1, conv3x3,
+ * conv1x1, the strided 1x1 downsample) and their autograd backward, bf16 channels-last, f32 accumulation.
+ *   x [rows][Cin]  (= [Nimg][H][W][Cin]),  w [N][taps][Cin] (= channels-last [N][Cin][kh][kw]),  y [M][N] (= [Nimg][Ho][Wo][N]),
+ *   M = Nimg * Ho * Wo; taps 1 (1x1, pad 0) or 9 (3x3, pad 1); stride 1 or 2; Cin % 64 == 0, N % 64 == 0.
+ * Prologue (applied to the activation operand on its way into the GEMM):
+ *   RN_PW_PRO_AFFINE_RELU  x' = relu(x * a[c] + b[c])                        -- the previous layer's BatchNorm + ReLU; padding
+ *                          positions of a 3x3 conv stay zero (they pad the ACTIVATION)
+ *   RN_PW_PRO_BN_BWD       x' = a[c] * g' + c[c] * x2 + b[c], g' = x masked by the ReLU (relu_mode 0 none; 2: where
+ *                          fma(x2, fa, fb) rounds to a positive bf16; 3: bits [rows][Cin / 8]) -- BatchNorm backward of the layer
+ *                          whose gradient this GEMM consumes (a, b, c = coef3 of rn_bn_bwd_reduce / _finalize)
+ * Epilogue:
+ *   RN_PW_EPI_STATS        partial f32[rn_pw_walkers(M)][2][N]: column sums and sums of squares of the bf16 output
+ *   RN_PW_EPI_RESID        y += resid * rbits  (the identity branch's gradient: resid [M][N], rbits [M][N / 8])
+ *   RN_PW_EPI_RELU_BWD     y = y * [fma(zprev, ea, eb) > 0 in bf16]; partial f32[walkers][2][N] = (sum y, sum y * (zprev - emean) * einv)
+ *                          -- ReLU backward + the two sums of the BatchNorm backward of the layer BELOW this data gradient
+ * rn_pw_conv_wgrad: dw [N][taps][Cin] = sum_m gpro(g)[m][N] x xpro(x)[pos(m, tap)][Cin]; gpro: none / BN_BWD, xpro: none / AFFINE_RELU;
+ * workspace rn_pw_wgrad_workspace_bytes(d) (f32 partials of the position splits, summed in a fixed order). */
+enum { RN_PW_PRO_NONE = 0, RN_PW_PRO_AFFINE_RELU = 1, RN_PW_PRO_BN_BWD = 2 };
+enum { RN_PW_EPI_NONE = 0, RN_PW_EPI_STATS = 1, RN_PW_EPI_RESID = 2, RN_PW_EPI_RELU_BWD = 4 };
+typedef struct rn_pw_conv { int64_t M; int32_t Cin, N, taps, stride, pad, Ho, Wo, H, W; } rn_pw_conv;
+typedef struct rn_pw_prologue {
+    int32_t kind, relu_mode;
+    const float *a, *b, *c, *fa, *fb;
+    const void *x2;
+    const uint8_t *bits;
+} rn_pw_prologue;
+typedef struct rn_pw_epilogue {
+    int32_t kind;
+    float *partial;
+    const void *resid;
+    const uint8_t *rbits;
+    const void *zprev;
+    const float *ea, *eb, *emean, *einv;
+} rn_pw_epilogue;
+int rn_pw_walkers(int64_t M);
+int rn_pw_conv_forward(const rn_pw_conv *d, const void *x, const void *w, void *y, const rn_pw_prologue *pro,
+                       const rn_pw_epilogue *epi, void *stream);
+size_t rn_pw_wgrad_workspace_bytes(const rn_pw_conv *d);
+int rn_pw_conv_wgrad(const rn_pw_conv *d, const void *g, const void *x, void *dw, const rn_pw_prologue *gpro,
+                     const rn_pw_prologue *xpro, void *workspace, size_t workspace_bytes, void *stream);
+
+
 /* ---- K4 decode_clip ---------------------------------------------------------
  * Replaces activ_2_bbox, retinanet/box_utils.py:37-48 (including its use of
  * dx,dy for the sizes, :46) and torchvision clip_boxes_to_image at

@@ -28,6 +28,24 @@ class RnDetectParams(C.Structure):
                 ("max_det", C.c_int32), ("reg_w", C.c_float * 4)]
 
 
+class RnPwConv(C.Structure):
+    _fields_ = [("M", C.c_int64), ("Cin", C.c_int32), ("N", C.c_int32), ("taps", C.c_int32), ("stride", C.c_int32),
+                ("pad", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("H", C.c_int32), ("W", C.c_int32)]
+
+
+class RnPwPrologue(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("relu_mode", C.c_int32), ("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p),
+                ("fa", C.c_void_p), ("fb", C.c_void_p), ("x2", C.c_void_p), ("bits", C.c_void_p)]
+
+
+class RnPwEpilogue(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("partial", C.c_void_p), ("resid", C.c_void_p), ("rbits", C.c_void_p), ("zprev", C.c_void_p),
+                ("ea", C.c_void_p), ("eb", C.c_void_p), ("emean", C.c_void_p), ("einv", C.c_void_p)]
+
+
+RN_PW_PRO_NONE, RN_PW_PRO_AFFINE_RELU, RN_PW_PRO_BN_BWD = 0, 1, 2
+RN_PW_EPI_NONE, RN_PW_EPI_STATS, RN_PW_EPI_RESID, RN_PW_EPI_RELU_BWD = 0, 1, 2, 4
+
 _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
 
 # name -> (restype, argtypes); mirrors include/retinanet_hip.h one to one
@@ -54,6 +72,16 @@ SIGNATURES = {
                                     _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rn_bn_act_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int,
                                      _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rn_bn_stats": (C.c_int, [_vp, C.c_int, _i64, C.c_int, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rn_bn_stats_finalize": (C.c_int, [_vp, C.c_int, _i64, C.c_int, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "rn_bn_apply": (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp, C.c_int, _vp, _vp]),
+    "rn_bn_bwd_reduce": (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "rn_bn_bwd_finalize": (C.c_int, [_vp, C.c_int, _i64, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "rn_bn_bwd_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp, _vp, C.c_int, _vp]),
+    "rn_pw_walkers": (C.c_int, [_i64]),
+    "rn_pw_conv_forward": (C.c_int, [C.POINTER(RnPwConv), _vp, _vp, _vp, C.POINTER(RnPwPrologue), C.POINTER(RnPwEpilogue), _vp]),
+    "rn_pw_wgrad_workspace_bytes": (_sz, [C.POINTER(RnPwConv)]),
+    "rn_pw_conv_wgrad": (C.c_int, [C.POINTER(RnPwConv), _vp, _vp, _vp, C.POINTER(RnPwPrologue), C.POINTER(RnPwPrologue), _vp, _sz, _vp]),
     "rn_decode_clip": (C.c_int, [_vp, C.c_int, C.c_int, _i64, _vp, _i64, _vp, C.POINTER(_f32), _vp, _vp]),
     "rn_bias_act_forward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _i64, C.c_int, _i64, C.c_int, _vp]),
     "rn_bias_act_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _i64, C.c_int, _i64, C.c_int, _vp, _sz, _vp]),

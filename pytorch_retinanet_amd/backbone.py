@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
 
+from . import pwconv
 from .norm import RAW_WRITES, FusedBatchNorm2d, _BNAct
 from .pool import FusedMaxPool2d
 
@@ -172,6 +173,10 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x: Tensor) -> Tensor:
+        if pwconv.bottleneck_fusable(self, x):
+            # training, bf16 channels-last, BatchNorm on batch statistics: the whole block on the MFMA GEMMs of csrc/pw.hip with
+            # the BatchNorm work fused into their operand loads / epilogues (pwconv._BottleneckFn)
+            return pwconv.bottleneck(self, x)
         if (FUSE_SKIP_ADD and self.downsample is None and torch.is_grad_enabled() and x.requires_grad and x.is_cuda
                 and x.dtype in (torch.bfloat16, torch.float16) and x.is_contiguous(memory_format=torch.channels_last)
                 and self.conv1.stride == (1, 1) and self.conv1.groups == 1 and self.conv1.out_channels <= SKIP_ADD_MAX_MID):

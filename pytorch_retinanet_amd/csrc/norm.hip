@@ -470,46 +470,37 @@ int apply_blocks(const int64_t nvec)
 
 }  // namespace
 
-// workspace: partial f32[BN_MAX_BLOCKS][2][C]
-RN_API size_t rn_bn_workspace_bytes(int C) { return C > 0 ? sizeof(float) * (size_t)BN_MAX_BLOCKS * 2 * (size_t)C : 0; }
+// ---- launch helpers shared by the entry points (one per kernel: the fused calls and the pieces run the same code) ----
+namespace {
 
-RN_API int rn_bn_act_forward(const void *x, const void *residual, void *y, int dtype, int64_t M, int C,
-                             const float *gamma, const float *beta, float *running_mean, float *running_var,
-                             int64_t *num_batches_tracked, int training, float momentum, float eps, int relu,
-                             float *save_mean, float *save_invstd, float *coef /*[2][C]*/, uint8_t *relu_mask, void *workspace,
-                             size_t workspace_bytes, void *stream)
+int stats_partial_launch(const void *x, int dtype, int64_t M, int C, float *partial, hipStream_t st, int *nblocks)
 {
-    if (!x || !y || !save_mean || !save_invstd || !coef || M <= 0 || C <= 0) return RN_EINVAL;
-    if (C % 8) return RN_EUNSUPPORTED;
-    if (dtype != RN_F32 && dtype != RN_BF16 && dtype != RN_F16) return RN_EINVAL;
-    if (!rn::aligned(x, 16) || !rn::aligned(y, 16) || (residual && !rn::aligned(residual, 16)) || !rn::aligned(coef, 16) ||
-        !rn::aligned(save_mean, 16) || !rn::aligned(save_invstd, 16))
-        return RN_EALIGN;
-    if (!training && (!running_mean || !running_var)) return RN_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    float *ca = coef, *cb = coef + C;
-    if (training) {
-        if (!workspace || workspace_bytes < rn_bn_workspace_bytes(C)) return RN_EWORKSPACE;
-        const ReduceGrid rg = reduce_grid(M, C, false);
-        const int nb = rg.row_splits;
-        const dim3 grid(rg.row_splits, rg.slabs);
-        const size_t lds = rg.lds;
-        const int order = bn_order();
-        float *partial = (float *)workspace;
-        switch (dtype) {
-            case RN_F32: hipLaunchKernelGGL((bn_stats_partial_kernel<RN_F32>), grid, dim3(rg.threads), lds, st, x, M, C, partial, order); break;
-            case RN_BF16: hipLaunchKernelGGL((bn_stats_partial_kernel<RN_BF16>), grid, dim3(rg.threads), lds, st, x, M, C, partial, order); break;
-            default: hipLaunchKernelGGL((bn_stats_partial_kernel<RN_F16>), grid, dim3(rg.threads), lds, st, x, M, C, partial, order); break;
-        }
-        RN_LAUNCH_CHECK();
-        hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, st, partial, nb, M, C, gamma, beta, running_mean,
-                           running_var, num_batches_tracked, momentum, eps, save_mean, save_invstd, ca, cb);
-        RN_LAUNCH_CHECK();
-    } else {
-        hipLaunchKernelGGL(bn_eval_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, C, gamma, beta, running_mean, running_var, eps,
-                           save_mean, save_invstd, ca, cb);
-        RN_LAUNCH_CHECK();
+    const ReduceGrid rg = reduce_grid(M, C, false);
+    const dim3 grid(rg.row_splits, rg.slabs);
+    const int order = bn_order();
+    switch (dtype) {
+        case RN_F32: hipLaunchKernelGGL((bn_stats_partial_kernel<RN_F32>), grid, dim3(rg.threads), rg.lds, st, x, M, C, partial, order); break;
+        case RN_BF16: hipLaunchKernelGGL((bn_stats_partial_kernel<RN_BF16>), grid, dim3(rg.threads), rg.lds, st, x, M, C, partial, order); break;
+        default: hipLaunchKernelGGL((bn_stats_partial_kernel<RN_F16>), grid, dim3(rg.threads), rg.lds, st, x, M, C, partial, order); break;
     }
+    RN_LAUNCH_CHECK();
+    *nblocks = rg.row_splits;
+    return RN_OK;
+}
+
+int stats_final_launch(const float *partial, int nb, int64_t M, int C, const float *gamma, const float *beta, float *running_mean,
+                       float *running_var, int64_t *num_batches_tracked, float momentum, float eps, float *save_mean,
+                       float *save_invstd, float *ca, float *cb, hipStream_t st)
+{
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, st, partial, nb, M, C, gamma, beta, running_mean,
+                       running_var, num_batches_tracked, momentum, eps, save_mean, save_invstd, ca, cb);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+int apply_launch(const void *x, const void *residual, void *y, int dtype, int64_t M, int C, const float *ca, const float *cb, int relu,
+                 uint8_t *relu_mask, hipStream_t st)
+{
     const int64_t nvec = M * (C / 8);
     const dim3 g(apply_blocks(nvec)), b(BN_BLOCK);
     const int C8 = C / 8;
@@ -528,36 +519,14 @@ RN_API int rn_bn_act_forward(const void *x, const void *residual, void *y, int d
     return RN_OK;
 }
 
-RN_API int rn_bn_act_backward(const void *dy, const void *y, const void *x, void *dx, void *dresidual, int dtype, int64_t M,
-                              int C, const float *gamma, const float *save_mean, const float *save_invstd,
-                              const float *fwd_coef /*[2][C] of the forward call, nullable*/, int training,
-                              int relu, float *dgamma, float *dbeta, float *coef /*[3][C]*/, void *workspace,
-                              size_t workspace_bytes, void *stream)
+// rmode: 0 none, 1 mask from y, 2 recomputed from x and the forward coefficients, 3 bits in y
+int bwd_partial_launch(const void *dy, const void *y, const void *x, int dtype, int64_t M, int C, const float *save_mean,
+                       const float *save_invstd, const float *fa, const float *fb, int rmode, float *partial, hipStream_t st, int *nblocks)
 {
-    if (!dy || !x || !dx || !save_mean || !save_invstd || !coef || M <= 0 || C <= 0) return RN_EINVAL;
-    // ReLU mask: from y when given; without y it is recomputed from x and the forward coefficients, which is
-    // only possible when the forward had no residual input
-    // relu: 0 none; 1: mask from y (the activation) when given, else recomputed from x and fwd_coef (no residual only);
-    //       2: y points to the byte mask the forward call wrote (relu_mask), one bit per element
-    const int rmode = !relu ? 0 : (relu == 2 ? 3 : (y ? 1 : 2));
-    if (rmode == 2 && (!fwd_coef || dresidual)) return RN_EINVAL;
-    if (rmode == 3 && !y) return RN_EINVAL;
-    const float *fa = fwd_coef, *fb = fwd_coef ? fwd_coef + C : nullptr;
-    if (C % 8) return RN_EUNSUPPORTED;
-    if (dtype != RN_F32 && dtype != RN_BF16 && dtype != RN_F16) return RN_EINVAL;
-    if (!workspace || workspace_bytes < rn_bn_workspace_bytes(C)) return RN_EWORKSPACE;
-    if (!rn::aligned(dy, 16) || !rn::aligned(x, 16) || !rn::aligned(dx, 16) || (y && rmode != 3 && !rn::aligned(y, 16)) ||
-        (dresidual && !rn::aligned(dresidual, 16)) || !rn::aligned(coef, 16) || !rn::aligned(save_mean, 16) ||
-        !rn::aligned(save_invstd, 16))
-        return RN_EALIGN;
-    hipStream_t st = (hipStream_t)stream;
     const ReduceGrid rg = reduce_grid(M, C, rmode == 3);
-    const int nb = rg.row_splits;
     const dim3 grid(rg.row_splits, rg.slabs);
     const size_t lds = rg.lds;
     const int order = bn_order();
-    float *partial = (float *)workspace;
-    float *ca = coef, *k0 = coef + C, *k1 = coef + 2 * C;
 #define RN_BN_BWD_PART(DT)                                                                                                             \
     if (rmode == 1) hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 1>), grid, dim3(rg.threads), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial, order); \
     else if (rmode == 2) hipLaunchKernelGGL((bn_bwd_partial_kernel<DT, 2>), grid, dim3(rg.threads), lds, st, dy, y, x, M, C, save_mean, save_invstd, fa, fb, partial, order); \
@@ -570,9 +539,22 @@ RN_API int rn_bn_act_backward(const void *dy, const void *y, const void *x, void
     }
 #undef RN_BN_BWD_PART
     RN_LAUNCH_CHECK();
+    *nblocks = rg.row_splits;
+    return RN_OK;
+}
+
+int bwd_final_launch(const float *partial, int nb, int64_t M, int C, const float *gamma, const float *save_mean, const float *save_invstd,
+                     int training, float *dgamma, float *dbeta, float *ca, float *k0, float *k1, hipStream_t st)
+{
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, st, partial, nb, M, C, gamma, save_mean, save_invstd,
                        training, dgamma, dbeta, ca, k0, k1);
     RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+int bwd_apply_launch(const void *dy, const void *y, const void *x, void *dx, void *dresidual, int dtype, int64_t M, int C, const float *ca,
+                     const float *k0, const float *k1, const float *fa, const float *fb, int rmode, hipStream_t st)
+{
     const int64_t nvec = M * (C / 8);
     const dim3 g(apply_blocks(nvec)), b(BN_BLOCK);
     const int C8 = C / 8;
@@ -592,6 +574,159 @@ RN_API int rn_bn_act_backward(const void *dy, const void *y, const void *x, void
 #undef RN_BN_BWD_APPLY
     RN_LAUNCH_CHECK();
     return RN_OK;
+}
+
+bool dtype_ok(int dtype) { return dtype == RN_F32 || dtype == RN_BF16 || dtype == RN_F16; }
+
+}  // namespace
+
+// workspace: partial f32[BN_MAX_BLOCKS][2][C]
+RN_API size_t rn_bn_workspace_bytes(int C) { return C > 0 ? sizeof(float) * (size_t)BN_MAX_BLOCKS * 2 * (size_t)C : 0; }
+
+RN_API int rn_bn_stats(const void *x, int dtype, int64_t M, int C, const float *gamma, const float *beta, float *running_mean,
+                       float *running_var, int64_t *num_batches_tracked, float momentum, float eps, float *save_mean,
+                       float *save_invstd, float *coef, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!x || !save_mean || !save_invstd || !coef || M <= 0 || C <= 0) return RN_EINVAL;
+    if (C % 8) return RN_EUNSUPPORTED;
+    if (!dtype_ok(dtype)) return RN_EINVAL;
+    if (!rn::aligned(x, 16) || !rn::aligned(coef, 16) || !rn::aligned(save_mean, 16) || !rn::aligned(save_invstd, 16)) return RN_EALIGN;
+    if (!workspace || workspace_bytes < rn_bn_workspace_bytes(C)) return RN_EWORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int nb = 0;
+    const int rc = stats_partial_launch(x, dtype, M, C, (float *)workspace, st, &nb);
+    if (rc != RN_OK) return rc;
+    return stats_final_launch((const float *)workspace, nb, M, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                              save_mean, save_invstd, coef, coef + C, st);
+}
+
+RN_API int rn_bn_stats_finalize(const float *partial, int nblocks, int64_t M, int C, const float *gamma, const float *beta,
+                                float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum, float eps,
+                                float *save_mean, float *save_invstd, float *coef, void *stream)
+{
+    if (!partial || nblocks <= 0 || !save_mean || !save_invstd || !coef || M <= 0 || C <= 0) return RN_EINVAL;
+    return stats_final_launch(partial, nblocks, M, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, save_mean,
+                              save_invstd, coef, coef + C, (hipStream_t)stream);
+}
+
+RN_API int rn_bn_apply(const void *x, const void *residual, void *y, int dtype, int64_t M, int C, const float *coef, int relu,
+                       uint8_t *relu_mask, void *stream)
+{
+    if (!x || !y || !coef || M <= 0 || C <= 0) return RN_EINVAL;
+    if (C % 8) return RN_EUNSUPPORTED;
+    if (!dtype_ok(dtype)) return RN_EINVAL;
+    if (!rn::aligned(x, 16) || !rn::aligned(y, 16) || (residual && !rn::aligned(residual, 16)) || !rn::aligned(coef, 16)) return RN_EALIGN;
+    return apply_launch(x, residual, y, dtype, M, C, coef, coef + C, relu, relu_mask, (hipStream_t)stream);
+}
+
+RN_API int rn_bn_act_forward(const void *x, const void *residual, void *y, int dtype, int64_t M, int C,
+                             const float *gamma, const float *beta, float *running_mean, float *running_var,
+                             int64_t *num_batches_tracked, int training, float momentum, float eps, int relu,
+                             float *save_mean, float *save_invstd, float *coef /*[2][C]*/, uint8_t *relu_mask, void *workspace,
+                             size_t workspace_bytes, void *stream)
+{
+    if (!x || !y || !save_mean || !save_invstd || !coef || M <= 0 || C <= 0) return RN_EINVAL;
+    if (C % 8) return RN_EUNSUPPORTED;
+    if (!dtype_ok(dtype)) return RN_EINVAL;
+    if (!rn::aligned(x, 16) || !rn::aligned(y, 16) || (residual && !rn::aligned(residual, 16)) || !rn::aligned(coef, 16) ||
+        !rn::aligned(save_mean, 16) || !rn::aligned(save_invstd, 16))
+        return RN_EALIGN;
+    if (!training && (!running_mean || !running_var)) return RN_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    float *ca = coef, *cb = coef + C;
+    if (training) {
+        if (!workspace || workspace_bytes < rn_bn_workspace_bytes(C)) return RN_EWORKSPACE;
+        int nb = 0;
+        int rc = stats_partial_launch(x, dtype, M, C, (float *)workspace, st, &nb);
+        if (rc != RN_OK) return rc;
+        rc = stats_final_launch((const float *)workspace, nb, M, C, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps,
+                                save_mean, save_invstd, ca, cb, st);
+        if (rc != RN_OK) return rc;
+    } else {
+        hipLaunchKernelGGL(bn_eval_coef_kernel, dim3((C + 255) / 256), dim3(256), 0, st, C, gamma, beta, running_mean, running_var, eps,
+                           save_mean, save_invstd, ca, cb);
+        RN_LAUNCH_CHECK();
+    }
+    return apply_launch(x, residual, y, dtype, M, C, ca, cb, relu, relu_mask, st);
+}
+
+// relu: 0 none; 1: mask from y (the activation) when given, else recomputed from x and fwd_coef (no residual only);
+//       2: y points to the byte mask the forward call wrote (relu_mask), one bit per element
+static int bwd_rmode(const int relu, const void *y) { return !relu ? 0 : (relu == 2 ? 3 : (y ? 1 : 2)); }
+
+RN_API int rn_bn_bwd_reduce(const void *dy, const void *y, const void *x, int dtype, int64_t M, int C, const float *gamma,
+                            const float *save_mean, const float *save_invstd, const float *fwd_coef, int training, int relu,
+                            float *dgamma, float *dbeta, float *coef3, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!dy || !x || !save_mean || !save_invstd || !coef3 || M <= 0 || C <= 0) return RN_EINVAL;
+    const int rmode = bwd_rmode(relu, y);
+    if (rmode == 2 && !fwd_coef) return RN_EINVAL;
+    if (rmode == 3 && !y) return RN_EINVAL;
+    if (C % 8) return RN_EUNSUPPORTED;
+    if (!dtype_ok(dtype)) return RN_EINVAL;
+    if (!workspace || workspace_bytes < rn_bn_workspace_bytes(C)) return RN_EWORKSPACE;
+    if (!rn::aligned(dy, 16) || !rn::aligned(x, 16) || (y && rmode != 3 && !rn::aligned(y, 16)) || !rn::aligned(coef3, 16) ||
+        !rn::aligned(save_mean, 16) || !rn::aligned(save_invstd, 16))
+        return RN_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    int nb = 0;
+    const int rc = bwd_partial_launch(dy, y, x, dtype, M, C, save_mean, save_invstd, fwd_coef, fwd_coef ? fwd_coef + C : nullptr, rmode,
+                                      (float *)workspace, st, &nb);
+    if (rc != RN_OK) return rc;
+    return bwd_final_launch((const float *)workspace, nb, M, C, gamma, save_mean, save_invstd, training, dgamma, dbeta, coef3, coef3 + C,
+                            coef3 + 2 * C, st);
+}
+
+RN_API int rn_bn_bwd_finalize(const float *partial, int nblocks, int64_t M, int C, const float *gamma, const float *save_mean,
+                              const float *save_invstd, int training, float *dgamma, float *dbeta, float *coef3, void *stream)
+{
+    if (!partial || nblocks <= 0 || !save_mean || !save_invstd || !coef3 || M <= 0 || C <= 0) return RN_EINVAL;
+    return bwd_final_launch(partial, nblocks, M, C, gamma, save_mean, save_invstd, training, dgamma, dbeta, coef3, coef3 + C, coef3 + 2 * C,
+                            (hipStream_t)stream);
+}
+
+RN_API int rn_bn_bwd_apply(const void *dy, const void *y, const void *x, void *dx, void *dresidual, int dtype, int64_t M, int C,
+                           const float *coef3, const float *fwd_coef, int relu_mode, void *stream)
+{
+    if (!dy || !x || !dx || !coef3 || M <= 0 || C <= 0) return RN_EINVAL;
+    if (relu_mode < 0 || relu_mode > 3 || (relu_mode == 2 && (!fwd_coef || dresidual)) || ((relu_mode == 1 || relu_mode == 3) && !y)) return RN_EINVAL;
+    if (C % 8) return RN_EUNSUPPORTED;
+    if (!dtype_ok(dtype)) return RN_EINVAL;
+    if (!rn::aligned(dy, 16) || !rn::aligned(x, 16) || !rn::aligned(dx, 16) || (y && relu_mode != 3 && !rn::aligned(y, 16)) ||
+        (dresidual && !rn::aligned(dresidual, 16)) || !rn::aligned(coef3, 16))
+        return RN_EALIGN;
+    return bwd_apply_launch(dy, y, x, dx, dresidual, dtype, M, C, coef3, coef3 + C, coef3 + 2 * C, fwd_coef, fwd_coef ? fwd_coef + C : nullptr,
+                            relu_mode, (hipStream_t)stream);
+}
+
+RN_API int rn_bn_act_backward(const void *dy, const void *y, const void *x, void *dx, void *dresidual, int dtype, int64_t M,
+                              int C, const float *gamma, const float *save_mean, const float *save_invstd,
+                              const float *fwd_coef /*[2][C] of the forward call, nullable*/, int training,
+                              int relu, float *dgamma, float *dbeta, float *coef /*[3][C]*/, void *workspace,
+                              size_t workspace_bytes, void *stream)
+{
+    if (!dy || !x || !dx || !save_mean || !save_invstd || !coef || M <= 0 || C <= 0) return RN_EINVAL;
+    // ReLU mask: from y when given; without y it is recomputed from x and the forward coefficients, which is
+    // only possible when the forward had no residual input
+    const int rmode = bwd_rmode(relu, y);
+    if (rmode == 2 && (!fwd_coef || dresidual)) return RN_EINVAL;
+    if (rmode == 3 && !y) return RN_EINVAL;
+    const float *fa = fwd_coef, *fb = fwd_coef ? fwd_coef + C : nullptr;
+    if (C % 8) return RN_EUNSUPPORTED;
+    if (!dtype_ok(dtype)) return RN_EINVAL;
+    if (!workspace || workspace_bytes < rn_bn_workspace_bytes(C)) return RN_EWORKSPACE;
+    if (!rn::aligned(dy, 16) || !rn::aligned(x, 16) || !rn::aligned(dx, 16) || (y && rmode != 3 && !rn::aligned(y, 16)) ||
+        (dresidual && !rn::aligned(dresidual, 16)) || !rn::aligned(coef, 16) || !rn::aligned(save_mean, 16) ||
+        !rn::aligned(save_invstd, 16))
+        return RN_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    float *ca = coef, *k0 = coef + C, *k1 = coef + 2 * C;
+    int nb = 0;
+    int rc = bwd_partial_launch(dy, y, x, dtype, M, C, save_mean, save_invstd, fa, fb, rmode, (float *)workspace, st, &nb);
+    if (rc != RN_OK) return rc;
+    rc = bwd_final_launch((const float *)workspace, nb, M, C, gamma, save_mean, save_invstd, training, dgamma, dbeta, ca, k0, k1, st);
+    if (rc != RN_OK) return rc;
+    return bwd_apply_launch(dy, y, x, dx, dresidual, dtype, M, C, ca, k0, k1, fa, fb, rmode, st);
 }
 
 // ================================================================ bias (+ ReLU) (+ position mask)

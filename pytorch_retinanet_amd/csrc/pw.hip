@@ -150,12 +150,97 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
 #pragma unroll
     for (int j = 0; j < 8; ++j) { ssum[j] = 0.0f; qsum[j] = 0.0f; }
 
-    for (int mt = blockIdx.x; mt < MT; mt += a.gx) {
-        const int m0 = mt * PW_BM;
-        RowPos rp[4];
+    // Software pipeline over the row tiles this workgroup walks (these GEMMs are bandwidth-bound; what matters is bytes in
+    // flight): the first K-tile of tile t+1 is loaded while tile t's epilogue runs, and the epilogue's own operands (residual +
+    // bits, or the activation whose ReLU mask / BN sums it forms) are loaded at the top of the tile, under its MFMAs.
+    constexpr int EROWS = PW_BM / RL;                           // epilogue rows per thread
+    rn::u32x4 sx[4], sz[4], sw[BROWS];
+    uint32_t sbits[4] = {0xffu, 0xffu, 0xffu, 0xffu};
+    bool sval[4];
+    int sc0 = 0;                                                // first channel of the staged K-tile
+    RowPos rp[4];
+    // the prologue's per-channel coefficients live in LDS behind the staging area: [a | b | c | fa | fb][Cin] f32
+    constexpr int LDS_MAIN = (2 * STAGE > PW_BM * BN * 4) ? 2 * STAGE : PW_BM * BN * 4;
+    float *const s_coef = (float *)(lds + LDS_MAIN);
+    if (PRO != PRO_NONE) {
+        const int ncoef = PRO == PRO_AFFINE_RELU ? 2 : (a.relu_mode == 2 ? 5 : 3);
+        for (int q = tid; q < ncoef * a.Cin; q += PW_THREADS) {
+            const int which = q / a.Cin, ch = q - which * a.Cin;
+            const float *src = which == 0 ? a.pa : (which == 1 ? a.pb : (which == 2 ? a.pc : (which == 3 ? a.fa : a.fb)));
+            s_coef[q] = src[ch];
+        }
+        __syncthreads();
+    }
+    auto issue = [&](const int kt) {
+        const int tap = kt / cpt, c0 = (kt - tap * cpt) * PW_BK;
+        const int dy = a.taps == 1 ? 0 : tap / 3, dx = a.taps == 1 ? 0 : tap - (tap / 3) * 3;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rp[i] = decode_row(a, m0 + r0 + 32 * i);
+        for (int i = 0; i < 4; ++i) {
+            const int y = rp[i].y0 + dy, x = rp[i].x0 + dx;
+            const bool v = rp[i].ok && (a.taps == 1 && a.stride == 1 ? true : (y >= 0 && y < a.H && x >= 0 && x < a.W_));
+            sval[i] = v;
+            const int64_t row = v ? (int64_t)rp[i].base + (a.taps == 1 && a.stride == 1 ? 0 : y * a.W_ + x) : 0;      // clamped: always a valid address
+            const int64_t e = row * a.Cin + c0 + c * 8;
+            sx[i] = *(const rn::u32x4 *)(a.X + e);
+            if (PRO == PRO_BN_BWD) {
+                sz[i] = *(const rn::u32x4 *)(a.X2 + e);
+                // (the byte is fetched whatever the mode -- a load behind a run-time condition would serialise the batch)
+                sbits[i] = a.xbits ? a.xbits[e >> 3] : 0xffu;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i)
+            sw[i] = *(const rn::u32x4 *)(a.W + (int64_t)(n0 + r0 + 32 * i) * Ktot + kt * PW_BK + c * 8);
+        sc0 = c0;
+    };
+    auto commit = [&](const int stage) {
+        unsigned char *const sb = lds + stage * STAGE;
+        ProCoef coef;                                           // from the LDS copy: nothing held in registers across the MFMAs
+        if (PRO != PRO_NONE) {
+            const int ch = sc0 + c * 8;
+            ld8f(s_coef + ch, coef.a); ld8f(s_coef + a.Cin + ch, coef.b);
+            if (PRO == PRO_BN_BWD) {
+                ld8f(s_coef + 2 * a.Cin + ch, coef.c);
+                if (a.relu_mode == 2) { ld8f(s_coef + 3 * a.Cin + ch, coef.fa); ld8f(s_coef + 4 * a.Cin + ch, coef.fb); }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(rn::u32x4 *)(sb + wa_off[i]) = transform<PRO>(sx[i], sz[i], sbits[i], coef, a.relu_mode, sval[i]);
+#pragma unroll
+        for (int i = 0; i < BROWS; ++i) *(rn::u32x4 *)(sb + wb_off[i]) = sw[i];
+    };
+    // EPI_RELU_BWD: the four per-column vectors of the epilogue, in LDS behind the prologue coefficients: [ea | eb | emean | einv][BN]
+    float *const s_epi = s_coef + (PRO == PRO_NONE ? 0 : (PRO == PRO_AFFINE_RELU ? 2 : 5) * a.Cin);
+    if (EPI & EPI_RELU_BWD) {
+        for (int q = tid; q < 4 * BN; q += PW_THREADS) {
+            const int which = q / BN, col = q - which * BN;
+            const float *src = which == 0 ? a.ea : (which == 1 ? a.eb : (which == 2 ? a.emean : a.einv));
+            s_epi[q] = src[n0 + col];
+        }
+        __syncthreads();
+    }
+    const float alive = alive_bf16();
 
+    int mt = blockIdx.x;
+    if (mt < MT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rp[i] = decode_row(a, mt * PW_BM + r0 + 32 * i);
+        issue(0);
+    }
+    for (; mt < MT; mt += a.gx) {
+        const int m0 = mt * PW_BM;
+        // the epilogue's operands for this tile, in flight under the tile's staging and MFMAs
+        rn::u32x4 er[EROWS];
+        uint32_t ebits[EROWS];
+        if (EPI & (EPI_RESID | EPI_RELU_BWD)) {
+#pragma unroll
+            for (int i = 0; i < EROWS; ++i) {
+                const int m = m0 + erl + i * RL;
+                const int64_t e = (int64_t)(m < a.M ? m : a.M - 1) * a.N + n0 + ecg * 8;
+                er[i] = *(const rn::u32x4 *)(((EPI & EPI_RESID) ? a.R : a.Zp) + e);
+                ebits[i] = (EPI & EPI_RESID) ? a.rbits[e >> 3] : 0u;
+            }
+        }
         f32x16 acc[MI][NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -164,44 +249,15 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-        rn::u32x4 sx[4], sz[4], sw[BROWS];
-        uint32_t sbits[4] = {0xffu, 0xffu, 0xffu, 0xffu};
-        bool sval[4];
-        ProCoef coef;
-        auto issue = [&](const int kt) {
-            const int tap = kt / cpt, c0 = (kt - tap * cpt) * PW_BK;
-            const int dy = a.taps == 1 ? 0 : tap / 3, dx = a.taps == 1 ? 0 : tap - (tap / 3) * 3;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int y = rp[i].y0 + dy, x = rp[i].x0 + dx;
-                const bool v = rp[i].ok && (a.taps == 1 && a.stride == 1 ? true : (y >= 0 && y < a.H && x >= 0 && x < a.W_));
-                sval[i] = v;
-                const int64_t row = v ? (int64_t)rp[i].base + (a.taps == 1 && a.stride == 1 ? 0 : y * a.W_ + x) : 0;      // clamped: always a valid address
-                const int64_t e = row * a.Cin + c0 + c * 8;
-                sx[i] = *(const rn::u32x4 *)(a.X + e);
-                if (PRO == PRO_BN_BWD) {
-                    sz[i] = *(const rn::u32x4 *)(a.X2 + e);
-                    if (a.relu_mode == 3) sbits[i] = a.xbits[e >> 3];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < BROWS; ++i)
-                sw[i] = *(const rn::u32x4 *)(a.W + (int64_t)(n0 + r0 + 32 * i) * Ktot + kt * PW_BK + c * 8);
-            load_coef<PRO>(coef, a.pa, a.pb, a.pc, a.fa, a.fb, a.relu_mode, c0 + c * 8);
-        };
-        auto commit = [&](const int stage) {
-            unsigned char *const sb = lds + stage * STAGE;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *(rn::u32x4 *)(sb + wa_off[i]) = transform<PRO>(sx[i], sz[i], sbits[i], coef, a.relu_mode, sval[i]);
-#pragma unroll
-            for (int i = 0; i < BROWS; ++i) *(rn::u32x4 *)(sb + wb_off[i]) = sw[i];
-        };
-
-        issue(0);
         commit(0);
         __syncthreads();
         for (int kt = 0; kt < KT; ++kt) {
             if (kt + 1 < KT) issue(kt + 1);                     // in flight under this K-tile's MFMAs
+            else if (mt + a.gx < MT) {                          // the NEXT row tile's first K-tile, in flight under the epilogue
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rp[i] = decode_row(a, (mt + a.gx) * PW_BM + r0 + 32 * i);
+                issue(0);
+            }
             const unsigned char *const sb = lds + (kt & 1) * STAGE;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -234,14 +290,8 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
                 }
             }
         __syncthreads();
-        float ea[8], eb[8], emu[8], eis[8];
-        if (EPI & EPI_RELU_BWD) {
-            ld8f(a.ea + n0 + ecg * 8, ea); ld8f(a.eb + n0 + ecg * 8, eb);
-            ld8f(a.emean + n0 + ecg * 8, emu); ld8f(a.einv + n0 + ecg * 8, eis);
-        }
-        const float alive = alive_bf16();
 #pragma unroll
-        for (int i = 0; i < PW_BM / RL; ++i) {
+        for (int i = 0; i < EROWS; ++i) {
             const int row = erl + i * RL;
             const int m = m0 + row;
             if (m < a.M) {
@@ -250,17 +300,18 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
                 const int64_t e = (int64_t)m * a.N + n0 + ecg * 8;
                 if (EPI & EPI_RESID) {
                     float r[8];
-                    rn::dt<RN_BF16>::unpack(*(const rn::u32x4 *)(a.R + e), r);
-                    const uint32_t bits = a.rbits[e >> 3];
+                    rn::dt<RN_BF16>::unpack(er[i], r);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += ((bits >> j) & 1u) ? r[j] : 0.0f;
+                    for (int j = 0; j < 8; ++j) v[j] += ((ebits[i] >> j) & 1u) ? r[j] : 0.0f;
                 }
                 rn::u32x4 o = rn::dt<RN_BF16>::pack(v);
                 if (EPI & (EPI_STATS | EPI_RELU_BWD)) {
                     rn::dt<RN_BF16>::unpack(o, v);              // the statistics are those of the stored (rounded) tensor
                     if (EPI & EPI_RELU_BWD) {
-                        float z[8];
-                        rn::dt<RN_BF16>::unpack(*(const rn::u32x4 *)(a.Zp + e), z);
+                        float z[8], ea[8], eb[8], emu[8], eis[8];
+                        ld8f(s_epi + ecg * 8, ea); ld8f(s_epi + BN + ecg * 8, eb);
+                        ld8f(s_epi + 2 * BN + ecg * 8, emu); ld8f(s_epi + 3 * BN + ecg * 8, eis);
+                        rn::dt<RN_BF16>::unpack(er[i], z);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             if (!(fmaf(z[j], ea[j], eb[j]) > alive)) v[j] = 0.0f;
@@ -317,7 +368,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_wgrad_kernel(const WgArgs a)
 {
     constexpr int MI = TN / 64, NI = TK / 64;                   // 2 x 2 waves of (TN / 2) x (TK / 2)
     constexpr int G_ROWB = TN * 2, X_ROWB = TK * 2;
-    constexpr int G_TILE = 64 * G_ROWB, X_TILE = 64 * X_ROWB;
+    constexpr int G_TILE = 64 * G_ROWB;
     constexpr int GV = TN / 32, XV = TK / 32;                   // 16-byte vectors per thread and tile
     constexpr int GCH = TN / 8, XCH = TK / 8;                   // chunks per row
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // [G | X]
@@ -409,8 +460,16 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_wgrad_kernel(const WgArgs a)
             *(rn::u32x4 *)(lds + G_TILE + row * X_ROWB + ((xc_ ^ tr_swz<TK>(row)) << 4)) = transform<PROX>(sx[i], sx[i], 0xffu, xcoef, 0, xval[i]);
         }
     };
-    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
-    struct U2 { unsigned long long lo, hi; };
+    // transposing fragment reads through the compiler's builtin (it then tracks their lgkmcnt itself; an inline-asm read is
+    // invisible to the register allocator's copies, which may run before a hand-placed wait)
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
+    auto tr_frag = [&](const uint32_t off, const uint32_t rowb) {     // 8-deep k fragment = positions +0..3 and +4..7
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(lds + off));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(lds + off + 4 * rowb));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
     if (m_begin < a.M) {
         issue(0);
         for (int kt = 0; kt < KT && m_begin + kt * 64 < a.M; ++kt) {
@@ -419,24 +478,16 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_wgrad_kernel(const WgArgs a)
             if (kt + 1 < KT && m_begin + (kt + 1) * 64 < a.M) issue(kt + 1);      // in flight under the MFMAs
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                unsigned long long fg[MI][2], fx[NI][2];
+                bf16x8 fg[MI], fx[NI];
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fg[mi][0]) : "v"(lds_base + g_off[mi] + kk * 16 * G_ROWB));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fg[mi][1]) : "v"(lds_base + g_off[mi] + (kk * 16 + 4) * G_ROWB));
-                }
+                for (int mi = 0; mi < MI; ++mi) fg[mi] = tr_frag(g_off[mi] + kk * 16 * G_ROWB, G_ROWB);
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fx[ni][0]) : "v"(lds_base + x_off[ni] + kk * 16 * X_ROWB));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(fx[ni][1]) : "v"(lds_base + x_off[ni] + (kk * 16 + 4) * X_ROWB));
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int ni = 0; ni < NI; ++ni) fx[ni] = tr_frag(x_off[ni] + kk * 16 * X_ROWB, X_ROWB);
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, U2{fg[mi][0], fg[mi][1]}),
-                                                                              __builtin_bit_cast(bf16x8, U2{fx[ni][0], fx[ni][1]}), acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fg[mi], fx[ni], acc[mi][ni], 0, 0, 0);
             }
             __syncthreads();
         }
@@ -456,19 +507,29 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_wgrad_kernel(const WgArgs a)
         }
 }
 
-// dW (bf16) = sum over the splits of partial (f32), 4 elements per thread
+// dW (bf16) = sum over the splits of partial (f32).  A block owns 32 float4 outputs; its 8 thread rows each sum every 8th
+// split (8 loads in flight per output instead of one serial chain over S), then the 8 sums are combined in a fixed order.
 __global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float *__restrict__ partial, const int S, const int64_t n4, uint16_t *__restrict__ dw)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
+    __shared__ rn::f32x4 sh[8][32];
+    const int j = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + j;
     rn::f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int sp = 0; sp < S; ++sp) {
-        const rn::f32x4 v = ((const rn::f32x4 *)partial)[sp * n4 + i];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    if (i < n4)
+        for (int sp = slice; sp < S; sp += 8) {
+            const rn::f32x4 v = ((const rn::f32x4 *)partial)[sp * n4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    sh[slice][j] = s;
+    __syncthreads();
+    if (slice == 0 && i < n4) {
+        rn::f32x4 t = sh[0][j];
+#pragma unroll
+        for (int l = 1; l < 8; ++l) { const rn::f32x4 v = sh[l][j]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        rn::u32x2 o;
+        o.x = rn::dt<RN_BF16>::pk(t.x, t.y); o.y = rn::dt<RN_BF16>::pk(t.z, t.w);
+        ((rn::u32x2 *)dw)[i] = o;
     }
-    rn::u32x2 o;
-    o.x = rn::dt<RN_BF16>::pk(s.x, s.y); o.y = rn::dt<RN_BF16>::pk(s.z, s.w);
-    ((rn::u32x2 *)dw)[i] = o;
 }
 
 int cu_count()
@@ -488,11 +549,13 @@ int walkers(const int M)
 
 template <int BN, int PRO, int EPI> int launch_gemm(const PwArgs &a, hipStream_t st)
 {
-    constexpr int lds = 2 * (PW_BM * PW_BK * 2 + BN * PW_BK * 2) > PW_BM * BN * 4 ? 2 * (PW_BM * PW_BK * 2 + BN * PW_BK * 2) : PW_BM * BN * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    constexpr int lds_main = 2 * (PW_BM * PW_BK * 2 + BN * PW_BK * 2) > PW_BM * BN * 4 ? 2 * (PW_BM * PW_BK * 2 + BN * PW_BK * 2) : PW_BM * BN * 4;
+    const int lds = lds_main + (PRO == PRO_NONE ? 0 : (PRO == PRO_AFFINE_RELU ? 2 : 5) * a.Cin * 4) + ((EPI & EPI_RELU_BWD) ? 4 * BN * 4 : 0);
+    if (lds > 160 * 1024) return RN_EUNSUPPORTED;
+    static int attr_max = 0;
+    if (lds > attr_max) {
         RN_HIP(hipFuncSetAttribute((const void *)pw_gemm_kernel<BN, PRO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
+        attr_max = lds;
     }
     hipLaunchKernelGGL((pw_gemm_kernel<BN, PRO, EPI>), dim3((unsigned)a.gx, (unsigned)(a.N / BN)), dim3(PW_THREADS), lds, st, a);
     RN_LAUNCH_CHECK();
@@ -534,21 +597,24 @@ template <int TN, int TK> int dispatch_wgrad(const WgArgs &a, const int prog, co
 }
 
 // weight-gradient tile of an [N][Cin] problem: as much of the small matrix per workgroup as 64 accumulator registers hold
-void wgrad_tile(const int N, const int Cin, int &TN, int &TK)
+void wgrad_tile(const int N, const int Cin, int &TN, int &TK, const bool g_transform)
 {
     if (N >= 128 && Cin >= 128) { TN = 128; TK = 128; }
-    else if (N >= 128) { TN = N >= 256 ? 256 : 128; TK = 64; }
+    else if (N >= 128) { TN = (N >= 256 && !g_transform) ? 256 : 128; TK = 64; }    // (BN-backward prologue: 256-wide G staging would spill)
     else if (Cin >= 128) { TN = 64; TK = Cin >= 256 ? 256 : 128; }
     else { TN = 64; TK = 64; }
 }
 
-int wgrad_splits(const rn_pw_conv *d, int *tiles_per_split)
+int wgrad_splits(const rn_pw_conv *d, int *tiles_per_split, const bool g_transform)
 {
     int TN, TK;
-    wgrad_tile(d->N, d->Cin, TN, TK);
+    wgrad_tile(d->N, d->Cin, TN, TK, g_transform);
     const int tiles = (d->N / TN) * (d->Cin / TK) * d->taps;
     int S = (2 * cu_count() + tiles - 1) / tiles;                // about two workgroups per CU
-    const int ktiles = (d->M + 63) / 64;
+    const int ktiles = (int)((d->M + 63) / 64);
+    const int64_t split_bytes = (int64_t)d->N * d->taps * d->Cin * 4;
+    const int cap = (int)(((int64_t)16 << 20) / split_bytes);    // f32 partials: at most ~16 MiB written and re-read
+    if (S > cap) S = cap < 32 ? 32 : cap;
     if (S > ktiles) S = ktiles;
     if (S > 512) S = 512;
     if (S < 1) S = 1;
@@ -623,8 +689,8 @@ RN_API int rn_pw_conv_forward(const rn_pw_conv *d, const void *x, const void *w,
 RN_API size_t rn_pw_wgrad_workspace_bytes(const rn_pw_conv *d)
 {
     if (check_geometry(d) != RN_OK) return 0;
-    const int S = wgrad_splits(d, nullptr);
-    return (size_t)S * d->N * d->taps * d->Cin * sizeof(float);
+    const int S0 = wgrad_splits(d, nullptr, false), S1 = wgrad_splits(d, nullptr, true);
+    return (size_t)(S0 > S1 ? S0 : S1) * d->N * d->taps * d->Cin * sizeof(float);
 }
 
 RN_API int rn_pw_conv_wgrad(const rn_pw_conv *d, const void *g, const void *x, void *dw, const rn_pw_prologue *gpro,
@@ -639,7 +705,8 @@ RN_API int rn_pw_conv_wgrad(const rn_pw_conv *d, const void *g, const void *x, v
     a.G = (const uint16_t *)g; a.X = (const uint16_t *)x; a.partial = (float *)workspace;
     a.M = (int)d->M; a.N = d->N; a.Cin = d->Cin; a.taps = d->taps; a.stride = d->stride; a.pad = d->pad;
     a.Ho = d->Ho; a.Wo = d->Wo; a.H = d->H; a.W_ = d->W;
-    a.S = wgrad_splits(d, &a.tiles_per_split);
+    const bool g_transform = gpro && gpro->kind != PRO_NONE;
+    a.S = wgrad_splits(d, &a.tiles_per_split, g_transform);
     int pg = PRO_NONE, px = PRO_NONE;
     if (gpro && gpro->kind != PRO_NONE) {
         if (gpro->kind != PRO_BN_BWD || !gpro->a || !gpro->b || !gpro->c || !gpro->x2) return RN_EINVAL;
@@ -657,7 +724,7 @@ RN_API int rn_pw_conv_wgrad(const rn_pw_conv *d, const void *g, const void *x, v
     }
     hipStream_t st = (hipStream_t)stream;
     int TN, TK, r;
-    wgrad_tile(d->N, d->Cin, TN, TK);
+    wgrad_tile(d->N, d->Cin, TN, TK, g_transform);
     if (TN == 128 && TK == 128) r = dispatch_wgrad<128, 128>(a, pg, px, st);
     else if (TN == 256) r = dispatch_wgrad<256, 64>(a, pg, px, st);
     else if (TN == 128) r = dispatch_wgrad<128, 64>(a, pg, px, st);
@@ -666,7 +733,7 @@ RN_API int rn_pw_conv_wgrad(const rn_pw_conv *d, const void *g, const void *x, v
     else r = dispatch_wgrad<64, 64>(a, pg, px, st);
     if (r != RN_OK) return r;
     const int64_t n4 = (int64_t)d->N * d->taps * d->Cin / 4;
-    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float *)workspace, a.S, n4, (uint16_t *)dw);
+    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, st, (const float *)workspace, a.S, n4, (uint16_t *)dw);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

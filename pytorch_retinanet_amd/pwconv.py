@@ -1,0 +1,306 @@
+"""Backbone convolutions on the hand-written MFMA GEMMs of ``csrc/pw.hip`` with the BatchNorm work fused into their operand
+loads and epilogues -- the training path of ``backbone.Bottleneck`` (reference ``retinanet/backbone.py:105-136``:
+conv1x1 -> bn -> relu -> conv3x3 -> bn -> relu -> conv1x1 -> bn -> (+ identity) -> relu, and its autograd backward).
+
+Round 2 ran every one of those layers as its own pass over the activation (MIOpen conv, BN statistics, BN apply, and in
+backward BN sums, BN apply, data gradient, weight gradient, residual add).  At the R50 shapes the bottleneck convolutions of
+layer1 / layer2 are HBM-bound (51 - 102 flop per byte), so the passes, not the flops, were the cost.  One
+``_BottleneckFn`` per block now runs
+
+  forward   conv1  [+ column sums of z1]                    -> bn1 finalize -> a1 = relu(bn1(z1))      (materialised for conv2)
+            conv2  (MIOpen 3x3)                              -> bn2 statistics
+            conv3  [relu(bn2(z2)) applied in the operand load, + column sums of z3]   -> bn3 finalize
+            out = relu(bn3(z3) + identity)                   (one pass, ReLU bits kept for backward)
+  backward  bn3 sums -> conv3 data gradient [bn3-backward applied to (g, z3) in the operand load; ReLU mask of a2 and the two
+            bn2-backward sums in the epilogue] and conv3 weight gradient [same operand transform; a2 recomputed from z2]
+            -> bn2 finalize + apply -> conv2 backward (MIOpen) -> bn1 backward
+            -> conv1 data gradient [+ the identity branch's gradient g * bits in the epilogue: no add pass, no copy]
+            and conv1 weight gradient.
+
+Neither a2 = relu(bn2(z2)), nor dz3, nor the identity branch's gradient is ever written to memory.  Everything else
+(eval-mode BN, fp32 / fp16 models, NCHW tensors, CPU) takes the layer-by-layer path of ``backbone.py``.
+"""
+import ctypes as C
+import os
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+from . import norm
+from ._lib import (RN_BF16, RN_PW_EPI_RELU_BWD, RN_PW_EPI_RESID, RN_PW_EPI_STATS, RN_PW_PRO_AFFINE_RELU, RN_PW_PRO_BN_BWD,
+                   RnPwConv, RnPwEpilogue, RnPwPrologue, check, lib)
+from .ops import _timed
+
+FUSED_BOTTLENECK = os.environ.get("RN_FUSED_BOTTLENECK", "1") != "0"      # 0: the layer-by-layer path of round 2 (A/B)
+# Widest bottleneck (mid channels) that takes the fused block: layer1 / layer2 of a ResNet-50 are HBM-bound and gain from the
+# fusion; at layer3 / layer4 (256 / 512 mid channels, K up to 2048) the GEMMs are compute-bound and the 128 x 128 register-staged
+# tiles of csrc/pw.hip run at a third of MIOpen's rate (measured: conv3 data gradient 99 us against 36 + 22 us)
+FUSED_MAX_MID = int(os.environ.get("RN_FUSED_MAX_MID", "128"))
+_WG_WS: Dict[tuple, Tensor] = {}
+PW_FLOP: Dict[str, float] = {}        # useful flop per call of the timed pw launches (bench.py)
+
+
+def _cl(t: Tensor) -> bool:
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def _desc(x: Tensor, n_out: int, taps: int, stride: int) -> Tuple[RnPwConv, Tuple[int, int, int, int]]:
+    "Geometry of a conv over channels-last ``x`` [Nimg, Cin, H, W] -> ([Nimg, n_out, Ho, Wo])."
+    Nimg, Cin, H, W = x.shape
+    pad = 1 if taps == 9 else 0
+    k = 3 if taps == 9 else 1
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    return RnPwConv(Nimg * Ho * Wo, Cin, n_out, taps, stride, pad, Ho, Wo, H, W), (Nimg, n_out, Ho, Wo)
+
+
+def _stream(dev: torch.device) -> int:
+    if dev.index != torch.cuda.current_device():
+        torch.cuda.set_device(dev)
+    return torch.cuda.current_stream().cuda_stream
+
+
+def affine_relu(coef: Tensor) -> RnPwPrologue:
+    "x' = relu(x * a + b); coef = f32 [2 C] = (a | b), the forward coefficients of a BatchNorm."
+    Cc = coef.numel() // 2
+    p = coef.data_ptr()
+    return RnPwPrologue(RN_PW_PRO_AFFINE_RELU, 0, p, p + 4 * Cc, 0, 0, 0, 0, 0)
+
+
+def bn_bwd(coef3: Tensor, z: Tensor, relu_mode: int = 0, fwd_coef: Optional[Tensor] = None, bits: Optional[Tensor] = None) -> RnPwPrologue:
+    "x' = a g' + k1 z + k0 with coef3 = f32 [3 C] = (a | k0 | k1); g' = g masked (2: recomputed from z and fwd_coef, 3: bits)."
+    Cc = coef3.numel() // 3
+    p = coef3.data_ptr()
+    fa = fwd_coef.data_ptr() if fwd_coef is not None else 0
+    return RnPwPrologue(RN_PW_PRO_BN_BWD, relu_mode, p, p + 4 * Cc, p + 8 * Cc, fa, fa + 4 * Cc if fa else 0, z.data_ptr(),
+                        bits.data_ptr() if bits is not None else 0)
+
+
+def pw_forward(x: Tensor, w: Tensor, stride: int = 1, pro: Optional[RnPwPrologue] = None, epi: Optional[RnPwEpilogue] = None,
+               tag: str = "pw_fwd") -> Tensor:
+    """``conv2d(pro(x), w, stride, padding = k // 2)`` on channels-last bf16 tensors; w [N, Cin, k, k] channels-last, k in {1, 3}."""
+    taps = int(w.shape[2] * w.shape[3])
+    d, oshape = _desc(x, int(w.shape[0]), taps, stride)
+    y = torch.empty(oshape, dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    st = _stream(x.device)
+    PW_FLOP[tag] = 2.0 * d.M * d.N * taps * d.Cin
+    with _timed(tag, x.device):
+        check(lib.rn_pw_conv_forward(C.byref(d), x.data_ptr(), w.data_ptr(), y.data_ptr(), C.byref(pro) if pro is not None else None,
+                                     C.byref(epi) if epi is not None else None, st), "rn_pw_conv_forward")
+    return y
+
+
+def stats_epilogue(M: int, n_out: int, dev: torch.device) -> Tuple[RnPwEpilogue, Tensor, int]:
+    nb = lib.rn_pw_walkers(M)
+    partial = torch.empty((nb * 2 * n_out,), dtype=torch.float32, device=dev)
+    return RnPwEpilogue(RN_PW_EPI_STATS, partial.data_ptr(), 0, 0, 0, 0, 0, 0, 0), partial, nb
+
+
+def pw_wgrad(g: Tensor, x: Tensor, w_like: Tensor, stride: int = 1, gpro: Optional[RnPwPrologue] = None,
+             xpro: Optional[RnPwPrologue] = None, tag: str = "pw_wgrad") -> Tensor:
+    """Weight gradient of ``conv2d(xpro(x), w, stride)`` for the output gradient ``gpro(g)``; returns a tensor like ``w_like``."""
+    taps = int(w_like.shape[2] * w_like.shape[3])
+    d, oshape = _desc(x, int(w_like.shape[0]), taps, stride)
+    assert tuple(g.shape) == oshape, (tuple(g.shape), oshape)
+    dw = torch.empty_like(w_like)
+    dev = x.device
+    st = _stream(dev)
+    need = lib.rn_pw_wgrad_workspace_bytes(C.byref(d))
+    key = (dev.index, st)
+    ws = _WG_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _WG_WS[key] = torch.empty((max(need, 32 << 20),), dtype=torch.uint8, device=dev)
+    PW_FLOP[tag] = 2.0 * d.M * d.N * taps * d.Cin
+    with _timed(tag, dev):
+        check(lib.rn_pw_conv_wgrad(C.byref(d), g.data_ptr(), x.data_ptr(), dw.data_ptr(), C.byref(gpro) if gpro is not None else None,
+                                   C.byref(xpro) if xpro is not None else None, ws.data_ptr(), ws.numel(), st), "rn_pw_conv_wgrad")
+    return dw
+
+
+# ---- BatchNorm pieces (csrc/norm.hip) --------------------------------------------------------------------------------------
+def _bn_buffers(bn):
+    return (bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr() if bn.num_batches_tracked is not None else 0)
+
+
+def bn_finalize(partial: Tensor, nb: int, M: int, bn) -> Tensor:
+    "Per-channel statistics from GEMM-epilogue partial sums -> f32 [4 C] = (mean | invstd | a | b); running statistics updated."
+    Cc = bn.num_features
+    stats = torch.empty((4 * Cc,), dtype=torch.float32, device=partial.device)
+    sp = stats.data_ptr()
+    rm, rv, nbt = _bn_buffers(bn)
+    check(lib.rn_bn_stats_finalize(partial.data_ptr(), nb, M, Cc, bn.weight.data_ptr(), bn.bias.data_ptr(), rm, rv, nbt, bn.momentum, bn.eps,
+                                   sp, sp + 4 * Cc, sp + 8 * Cc, _stream(partial.device)), "rn_bn_stats_finalize")
+    norm.note_raw_write()
+    return stats
+
+
+def bn_stats(x: Tensor, bn) -> Tensor:
+    "Statistics pass over channels-last ``x`` (no apply) -> f32 [4 C]."
+    Nimg, Cc, H, W = x.shape
+    M = Nimg * H * W
+    dev = x.device
+    st = _stream(dev)
+    stats = torch.empty((4 * Cc,), dtype=torch.float32, device=dev)
+    sp = stats.data_ptr()
+    wp, wn = norm._workspace(dev, st, Cc)
+    rm, rv, nbt = _bn_buffers(bn)
+    check(lib.rn_bn_stats(x.data_ptr(), RN_BF16, M, Cc, bn.weight.data_ptr(), bn.bias.data_ptr(), rm, rv, nbt, bn.momentum, bn.eps,
+                          sp, sp + 4 * Cc, sp + 8 * Cc, wp, wn, st), "rn_bn_stats")
+    norm.note_raw_write()
+    return stats
+
+
+def bn_apply(x: Tensor, stats: Tensor, relu: bool, residual: Optional[Tensor] = None, want_bits: bool = False):
+    Nimg, Cc, H, W = x.shape
+    M = Nimg * H * W
+    y = torch.empty_like(x)
+    bits = torch.empty((M * Cc // 8,), dtype=torch.uint8, device=x.device) if want_bits else None
+    check(lib.rn_bn_apply(x.data_ptr(), residual.data_ptr() if residual is not None else 0, y.data_ptr(), RN_BF16, M, Cc,
+                          stats.data_ptr() + 8 * Cc, int(relu), bits.data_ptr() if bits is not None else 0, _stream(x.device)), "rn_bn_apply")
+    return y, bits
+
+
+class _BottleneckFn(torch.autograd.Function):
+    """One ResNet bottleneck, BatchNorm in training mode, bf16 channels-last.  Tensor arguments (all receive gradients):
+    x, conv1.weight, bn1.weight, bn1.bias, conv2.weight, bn2.weight, bn2.bias, conv3.weight, bn3.weight, bn3.bias and, for a
+    block with a downsample branch, its conv weight and BN weight / bias (else three ``None``)."""
+
+    @staticmethod
+    def forward(ctx, blk, x, w1, g1, b1, w2, g2, b2, w3, g3, b3, wd, gd, bd):
+        s = blk.conv2.stride[0]
+        dev = x.device
+        Nimg, Cin, H, W = x.shape
+        M0 = Nimg * H * W
+        # conv1 + bn1 statistics in its epilogue
+        e1, p1, nb1 = stats_epilogue(M0, w1.shape[0], dev)
+        z1 = pw_forward(x, w1, epi=e1, tag="pw_conv1_fwd")
+        st1 = bn_finalize(p1, nb1, M0, blk.bn1)
+        a1, _ = bn_apply(z1, st1, relu=True)                                 # conv2 is MIOpen's: it needs the activation
+        z2 = F.conv2d(a1, w2, None, blk.conv2.stride, blk.conv2.padding)
+        if not _cl(z2):
+            z2 = z2.contiguous(memory_format=torch.channels_last)
+        st2 = bn_stats(z2, blk.bn2)
+        M1 = z2.shape[0] * z2.shape[2] * z2.shape[3]
+        # conv3: relu(bn2(z2)) in the operand load, bn3 statistics in the epilogue
+        e3, p3, nb3 = stats_epilogue(M1, w3.shape[0], dev)
+        Cm = w2.shape[0]
+        z3 = pw_forward(z2, w3, pro=affine_relu(st2[2 * Cm:]), epi=e3, tag="pw_conv3_fwd")
+        st3 = bn_finalize(p3, nb3, M1, blk.bn3)
+        zd = std = None
+        if wd is not None:
+            ed, pd, nbd = stats_epilogue(M1, wd.shape[0], dev)
+            zd = pw_forward(x, wd, stride=blk.downsample[0].stride[0], epi=ed, tag="pw_down_fwd")
+            std = bn_finalize(pd, nbd, M1, blk.downsample[1])
+            idt, _ = bn_apply(zd, std, relu=False)
+        else:
+            idt = x
+        out, bits = bn_apply(z3, st3, relu=True, residual=idt, want_bits=True)
+        ctx.save_for_backward(x, w1, g1, w2, g2, w3, g3, wd, gd, z1, a1, z2, z3, zd, bits, st1, st2, st3, std)
+        ctx.blk = blk
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        x, w1, g1, w2, g2, w3, g3, wd, gd, z1, a1, z2, z3, zd, bits, st1, st2, st3, std = ctx.saved_tensors
+        blk = ctx.blk
+        dev = x.device
+        st = _stream(dev)
+        if g_out.dtype != x.dtype or not _cl(g_out):
+            g_out = g_out.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        C4, Cm = w3.shape[0], w2.shape[0]
+        M1 = z3.shape[0] * z3.shape[2] * z3.shape[3]
+        M0 = x.shape[0] * x.shape[2] * x.shape[3]
+        # bn3 backward sums over (g_out * bits, z3) -> coefficients of dz3 = a g' + k1 z3 + k0
+        gr3 = torch.empty((5 * C4,), dtype=torch.float32, device=dev)            # dgamma | dbeta | a | k0 | k1
+        wp, wn = norm._workspace(dev, st, C4)
+        p3 = st3.data_ptr()
+        check(lib.rn_bn_bwd_reduce(g_out.data_ptr(), bits.data_ptr(), z3.data_ptr(), RN_BF16, M1, C4, g3.data_ptr(), p3, p3 + 4 * C4, 0, 1, 2,
+                                   gr3.data_ptr(), gr3.data_ptr() + 4 * C4, gr3.data_ptr() + 8 * C4, wp, wn, st), "rn_bn_bwd_reduce")
+        pro3 = bn_bwd(gr3[2 * C4:], z3, relu_mode=3, bits=bits)
+        # conv3 data gradient with bn3-backward in the operand load; epilogue: ReLU mask of a2 + the two bn2-backward sums
+        nb2 = lib.rn_pw_walkers(M1)
+        part2 = torch.empty((nb2 * 2 * Cm,), dtype=torch.float32, device=dev)
+        p2 = st2.data_ptr()
+        epi = RnPwEpilogue(RN_PW_EPI_RELU_BWD, part2.data_ptr(), 0, 0, z2.data_ptr(), p2 + 8 * Cm, p2 + 12 * Cm, p2, p2 + 4 * Cm)
+        w3t = w3.reshape(C4, Cm).t().contiguous().view(Cm, C4, 1, 1)
+        dy2 = pw_forward(g_out, w3t, pro=pro3, epi=epi, tag="pw_conv3_dgrad")
+        dw3 = pw_wgrad(g_out, z2, w3, gpro=pro3, xpro=affine_relu(st2[2 * Cm:]), tag="pw_conv3_wgrad")
+        # bn2: finalize from the epilogue sums, apply (conv2's backward is MIOpen's and wants dz2 in memory)
+        gr2 = torch.empty((5 * Cm,), dtype=torch.float32, device=dev)
+        check(lib.rn_bn_bwd_finalize(part2.data_ptr(), nb2, M1, Cm, g2.data_ptr(), p2, p2 + 4 * Cm, 1, gr2.data_ptr(), gr2.data_ptr() + 4 * Cm,
+                                     gr2.data_ptr() + 8 * Cm, st), "rn_bn_bwd_finalize")
+        dz2 = torch.empty_like(z2)
+        check(lib.rn_bn_bwd_apply(dy2.data_ptr(), 0, z2.data_ptr(), dz2.data_ptr(), 0, RN_BF16, M1, Cm, gr2.data_ptr() + 8 * Cm, 0, 0, st),
+              "rn_bn_bwd_apply")
+        da1, dw2 = torch.ops.aten.convolution_backward(dz2, a1, w2, None, list(blk.conv2.stride), list(blk.conv2.padding), [1, 1], False,
+                                                       [0, 0], 1, [True, True, False])[:2]
+        if not _cl(da1):
+            da1 = da1.contiguous(memory_format=torch.channels_last)
+        # bn1 backward (ReLU mask recomputed from z1 and the forward coefficients)
+        gr1 = torch.empty((5 * Cm,), dtype=torch.float32, device=dev)
+        dz1 = torch.empty_like(z1)
+        p1 = st1.data_ptr()
+        wp, wn = norm._workspace(dev, st, Cm)
+        check(lib.rn_bn_act_backward(da1.data_ptr(), 0, z1.data_ptr(), dz1.data_ptr(), 0, RN_BF16, M0, Cm, g1.data_ptr(), p1, p1 + 4 * Cm,
+                                     p1 + 8 * Cm, 1, 1, gr1.data_ptr(), gr1.data_ptr() + 4 * Cm, gr1.data_ptr() + 8 * Cm, wp, wn, st),
+              "rn_bn_act_backward")
+        Cin = w1.shape[1]
+        w1t = w1.reshape(Cm, Cin).t().contiguous().view(Cin, Cm, 1, 1)
+        dwd = dgd = dbd = None
+        if wd is None:
+            # the identity branch's gradient g_out * bits joins in the data-gradient GEMM's epilogue
+            epi1 = RnPwEpilogue(RN_PW_EPI_RESID, 0, g_out.data_ptr(), bits.data_ptr(), 0, 0, 0, 0, 0)
+            dx = pw_forward(dz1, w1t, epi=epi1, tag="pw_conv1_dgrad")
+        else:
+            dn = blk.downsample
+            grd = torch.empty((5 * C4,), dtype=torch.float32, device=dev)
+            dzd = torch.empty_like(zd)
+            pd = std.data_ptr()
+            wp, wn = norm._workspace(dev, st, C4)
+            check(lib.rn_bn_act_backward(g_out.data_ptr(), bits.data_ptr(), zd.data_ptr(), dzd.data_ptr(), 0, RN_BF16, M1, C4, gd.data_ptr(), pd,
+                                         pd + 4 * C4, pd + 8 * C4, 1, 2, grd.data_ptr(), grd.data_ptr() + 4 * C4, grd.data_ptr() + 8 * C4, wp,
+                                         wn, st), "rn_bn_act_backward")
+            dgd, dbd = grd[:C4], grd[C4:2 * C4]
+            dwd = pw_wgrad(dzd, x, wd, stride=dn[0].stride[0], tag="pw_down_wgrad")
+            if dn[0].stride[0] == 1:
+                wdt = wd.reshape(C4, Cin).t().contiguous().view(Cin, C4, 1, 1)
+                dxd = pw_forward(dzd, wdt, tag="pw_down_dgrad")
+            else:
+                dxd = torch.ops.aten.convolution_backward(dzd, x, wd, None, list(dn[0].stride), [0, 0], [1, 1], False, [0, 0], 1,
+                                                          [True, False, False])[0]
+            dx = pw_forward(dz1, w1t, tag="pw_conv1_dgrad")
+            dx = dx + dxd
+        dw1 = pw_wgrad(dz1, x, w1, tag="pw_conv1_wgrad")
+        return (None, dx, dw1, gr1[:Cm], gr1[Cm:2 * Cm], dw2, gr2[:Cm], gr2[Cm:2 * Cm], dw3, gr3[:C4], gr3[C4:2 * C4], dwd, dgd, dbd)
+
+
+def bottleneck_fusable(blk, x: Tensor) -> bool:
+    if not (FUSED_BOTTLENECK and x.is_cuda and x.dtype == torch.bfloat16 and _cl(x) and torch.is_grad_enabled()):
+        return False
+    bns = [blk.bn1, blk.bn2, blk.bn3] + ([blk.downsample[1]] if blk.downsample is not None else [])
+    convs = [blk.conv1, blk.conv2, blk.conv3] + ([blk.downsample[0]] if blk.downsample is not None else [])
+    for bn in bns:
+        if not (bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None and bn.weight.dtype == torch.float32):
+            return False
+    for cv in convs:
+        if not (cv.weight.dtype == torch.bfloat16 and cv.bias is None and cv.groups == 1 and cv.in_channels % 64 == 0
+                and cv.out_channels % 64 == 0 and cv.dilation == (1, 1)):
+            return False
+    if blk.conv2.out_channels > FUSED_MAX_MID:
+        return False
+    if blk.conv1.stride != (1, 1) or blk.conv3.stride != (1, 1) or blk.conv2.stride[0] != blk.conv2.stride[1] or blk.conv2.stride[0] not in (1, 2):
+        return False
+    if not _cl(blk.conv2.weight):
+        return False
+    if x.shape[0] * x.shape[2] * x.shape[3] >= (1 << 31) // max(blk.conv3.out_channels, 1) * 8:
+        return False
+    return True
+
+
+def bottleneck(blk, x: Tensor) -> Tensor:
+    dn = blk.downsample
+    return _BottleneckFn.apply(blk, x, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias,
+                               blk.conv3.weight, blk.bn3.weight, blk.bn3.bias,
+                               dn[0].weight if dn is not None else None, dn[1].weight if dn is not None else None,
+                               dn[1].bias if dn is not None else None)

@@ -1,0 +1,261 @@
+"""GPU: the backbone convolutions on the MFMA GEMMs of csrc/pw.hip (``pwconv``) against plain PyTorch fp32 references of
+the same ops on the same bf16 inputs (reference semantics: the Bottleneck of retinanet/backbone.py:105-136 and its autograd
+backward).  Kernel level: every prologue / epilogue combination, 1x1 and 3x3, stride 1 and 2, ragged row counts.
+Block level: ``pwconv._BottleneckFn`` == the layer-by-layer path of ``backbone.Bottleneck`` (outputs, input gradient,
+parameter gradients, running statistics).  Tolerances: bf16 outputs to one rounding of the fp32 reference (rel 1e-2 of the
+tensor's max), fp32-accumulated statistics rel <= 1e-3, weight gradients rel 2e-2 of their max.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def _rand(shape, scale=1.0, seed=0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return _cl((torch.randn(shape, device=DEV, generator=g) * scale).to(torch.bfloat16))
+
+
+def _close(got, ref, rel, msg=""):
+    ref = ref.float()
+    tol = rel * float(ref.abs().max()) + 1e-6
+    err = float((got.float() - ref).abs().max())
+    assert err <= tol, f"{msg}: max err {err} > {tol}"
+
+
+def _close_grad(got, ref, rel, msg=""):
+    """Gradients of two forward passes that differ in the last bf16 bits: where an activation sits at the ReLU boundary the
+    mask flips and the whole upstream element appears / disappears, so isolated outliers are legitimate.  Bars: relative L2
+    error and the fraction of elements outside the elementwise tolerance."""
+    got, ref = got.float(), ref.float()
+    l2 = float((got - ref).norm() / (ref.norm() + 1e-12))
+    out = float(((got - ref).abs() > rel * float(ref.abs().max()) + 1e-6).float().mean())
+    assert l2 <= rel and out <= 2e-3, f"{msg}: relative L2 error {l2}, outlier fraction {out}"
+
+
+def _alive(t):              # a bf16-rounded activation is positive
+    return t.to(torch.bfloat16).float() > 0
+
+
+@pytest.mark.parametrize("shape,cout,k,stride", [((2, 256, 37, 45), 64, 1, 1), ((2, 64, 37, 45), 256, 1, 1), ((3, 128, 20, 24), 512, 1, 1),
+                                                 ((2, 256, 38, 46), 512, 1, 2), ((2, 64, 21, 25), 64, 3, 1), ((2, 128, 21, 25), 128, 3, 2),
+                                                 ((1, 1024, 9, 11), 256, 1, 1), ((1, 512, 9, 11), 2048, 1, 1)])
+def test_forward_plain_and_with_bn_relu_prologue_and_statistics(shape, cout, k, stride):
+    from pytorch_retinanet_amd import pwconv
+    from pytorch_retinanet_amd._lib import lib
+    x = _rand(shape, 1.0, 1)
+    w = _rand((cout, shape[1], k, k), 0.05, 2)
+    pad = k // 2
+    # plain
+    y = pwconv.pw_forward(x, w, stride=stride)
+    ref = F.conv2d(x.float(), w.float(), None, stride, pad)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    _close(y, ref, 1e-2, "plain conv")
+    # relu(x * a + b) in the operand load (zero padding applies to the ACTIVATION) + column statistics of the output
+    Cin = shape[1]
+    g = torch.Generator(device=DEV).manual_seed(3)
+    coef = torch.cat([torch.rand(Cin, device=DEV, generator=g) + 0.5, torch.randn(Cin, device=DEV, generator=g) * 0.3])
+    act = F.relu(torch.addcmul(coef[Cin:][None, :, None, None], x.float(), coef[:Cin][None, :, None, None])).to(torch.bfloat16)
+    M = y.shape[0] * y.shape[2] * y.shape[3]
+    epi, partial, nb = pwconv.stats_epilogue(M, cout, x.device)
+    y2 = pwconv.pw_forward(x, w, stride=stride, pro=pwconv.affine_relu(coef), epi=epi)
+    ref2 = F.conv2d(act.float(), w.float(), None, stride, pad)
+    _close(y2, ref2, 1e-2, "conv of relu(bn(x))")
+    part = partial.view(nb, 2, cout).double().sum(0)
+    yr = y2.float().permute(0, 2, 3, 1).reshape(-1, cout).double()
+    np.testing.assert_allclose(part[0].cpu().numpy(), yr.sum(0).cpu().numpy(), rtol=1e-3, atol=1e-3 * float(yr.abs().sum(0).max()))
+    np.testing.assert_allclose(part[1].cpu().numpy(), (yr * yr).sum(0).cpu().numpy(), rtol=1e-3)
+
+
+def _bn_bwd_coefs(C, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    a = torch.rand(C, device=DEV, generator=g) + 0.5
+    k0 = torch.randn(C, device=DEV, generator=g) * 0.05
+    k1 = torch.randn(C, device=DEV, generator=g) * 0.05
+    return torch.cat([a, k0, k1])
+
+
+@pytest.mark.parametrize("relu_mode", [0, 2, 3])
+@pytest.mark.parametrize("cin,cout", [(256, 64), (512, 128)])
+def test_data_gradient_with_bn_backward_prologue_and_relu_backward_epilogue(relu_mode, cin, cout):
+    "The conv3 data gradient of a bottleneck: dz3 = a g' + k1 z3 + k0 formed in the operand load, ReLU mask + BN-backward sums out."
+    from pytorch_retinanet_amd import pwconv
+    from pytorch_retinanet_amd._lib import RN_PW_EPI_RELU_BWD, RnPwEpilogue, lib
+    shape = (2, cin, 19, 23)
+    gup, z = _rand(shape, 1.0, 1), _rand(shape, 1.0, 2)
+    coef3 = _bn_bwd_coefs(cin, 3)
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    fwd = torch.cat([torch.rand(cin, device=DEV, generator=gen) + 0.5, torch.randn(cin, device=DEV, generator=gen) * 0.3])
+    M = shape[0] * shape[2] * shape[3]
+    zr = z.float().permute(0, 2, 3, 1).reshape(M, cin)
+    gr = gup.float().permute(0, 2, 3, 1).reshape(M, cin)
+    bits = None
+    if relu_mode == 2:
+        mask = _alive(torch.addcmul(fwd[cin:], zr, fwd[:cin]))
+    elif relu_mode == 3:
+        mask = torch.rand(M, cin, device=DEV, generator=gen) > 0.4
+        bits = (mask.view(M, cin // 8, 8).to(torch.int32) * (2 ** torch.arange(8, device=DEV, dtype=torch.int32))).sum(-1).to(torch.uint8).contiguous().view(-1)
+    else:
+        mask = torch.ones_like(zr, dtype=torch.bool)
+    dz = (coef3[:cin] * (gr * mask) + (coef3[2 * cin:] * zr + coef3[cin:2 * cin])).to(torch.bfloat16).float()
+    w = _rand((cout, cin, 1, 1), 0.05, 5)                       # the transposed forward weight
+    zp = _rand((2, cout, 19, 23), 1.0, 6)
+    st = torch.cat([torch.randn(cout, device=DEV, generator=gen) * 0.2, torch.rand(cout, device=DEV, generator=gen) + 0.5,
+                    torch.rand(cout, device=DEV, generator=gen) + 0.5, torch.randn(cout, device=DEV, generator=gen) * 0.3])   # mean | invstd | a | b
+    nb = lib.rn_pw_walkers(M)
+    part = torch.empty((nb * 2 * cout,), dtype=torch.float32, device=DEV)
+    p = st.data_ptr()
+    epi = RnPwEpilogue(RN_PW_EPI_RELU_BWD, part.data_ptr(), 0, 0, zp.data_ptr(), p + 8 * cout, p + 12 * cout, p, p + 4 * cout)
+    pro = pwconv.bn_bwd(coef3, z, relu_mode, fwd_coef=fwd if relu_mode == 2 else None, bits=bits)
+    dy = pwconv.pw_forward(gup, w, pro=pro, epi=epi)
+    zpr = zp.float().permute(0, 2, 3, 1).reshape(M, cout)
+    alive = _alive(torch.addcmul(st[3 * cout:], zpr, st[2 * cout:3 * cout]))
+    ref = (dz @ w.float().view(cout, cin).t()).to(torch.bfloat16).float() * alive
+    got = dy.float().permute(0, 2, 3, 1).reshape(M, cout)
+    _close(got, ref, 1.5e-2, "masked data gradient")
+    assert float((got[~alive]).abs().max()) == 0.0
+    sums = part.view(nb, 2, cout).double().sum(0)
+    xhat = ((zpr - st[:cout]) * st[cout:2 * cout]).double()
+    np.testing.assert_allclose(sums[0].cpu().numpy(), got.double().sum(0).cpu().numpy(), rtol=1e-3, atol=1e-3 * float(got.abs().sum(0).max()))
+    np.testing.assert_allclose(sums[1].cpu().numpy(), (got.double() * xhat).sum(0).cpu().numpy(), rtol=1e-3,
+                               atol=1e-3 * float((got.double() * xhat).abs().sum(0).max()))
+
+
+def test_data_gradient_with_residual_epilogue():
+    "conv1's data gradient of an identity bottleneck: + g_out * bits in the epilogue, one rounding."
+    from pytorch_retinanet_amd import pwconv
+    from pytorch_retinanet_amd._lib import RN_PW_EPI_RESID, RnPwEpilogue
+    cm, cin = 64, 256
+    dz1 = _rand((2, cm, 19, 23), 1.0, 1)
+    w1t = _rand((cin, cm, 1, 1), 0.05, 2)
+    gout = _rand((2, cin, 19, 23), 1.0, 3)
+    M = 2 * 19 * 23
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    mask = torch.rand(M, cin, device=DEV, generator=gen) > 0.5
+    bits = (mask.view(M, cin // 8, 8).to(torch.int32) * (2 ** torch.arange(8, device=DEV, dtype=torch.int32))).sum(-1).to(torch.uint8).contiguous().view(-1)
+    epi = RnPwEpilogue(RN_PW_EPI_RESID, 0, gout.data_ptr(), bits.data_ptr(), 0, 0, 0, 0, 0)
+    dx = pwconv.pw_forward(dz1, w1t, epi=epi)
+    ref = dz1.float().permute(0, 2, 3, 1).reshape(M, cm) @ w1t.float().view(cin, cm).t() + gout.float().permute(0, 2, 3, 1).reshape(M, cin) * mask
+    _close(dx.float().permute(0, 2, 3, 1).reshape(M, cin), ref, 1e-2, "data gradient + residual")
+
+
+@pytest.mark.parametrize("n_out,cin,k,stride", [(64, 256, 1, 1), (256, 64, 1, 1), (128, 512, 1, 1), (512, 128, 1, 1), (64, 64, 3, 1), (128, 128, 3, 2),
+                                               (512, 256, 1, 2), (256, 1024, 1, 1), (2048, 512, 1, 1)])
+def test_weight_gradient_plain(n_out, cin, k, stride):
+    from pytorch_retinanet_amd import pwconv
+    H, W = (21, 25) if n_out * cin < 512 * 512 else (9, 11)
+    x = _rand((2, cin, H, W), 1.0, 1)
+    w = _rand((n_out, cin, k, k), 0.05, 2)
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    g = _rand((2, n_out, Ho, Wo), 1.0, 3)
+    dw = pwconv.pw_wgrad(g, x, w, stride=stride)
+    ref = torch.ops.aten.convolution_backward(g.float(), x.float(), w.float(), None, [stride, stride], [k // 2, k // 2], [1, 1], False, [0, 0], 1,
+                                              [False, True, False])[1]
+    assert dw.shape == w.shape and dw.stride() == w.stride()
+    _close(dw, ref, 1e-2, "weight gradient")
+
+
+@pytest.mark.parametrize("c4,cm", [(256, 64), (512, 128), (1024, 256)])
+def test_weight_gradient_with_both_operand_transforms(c4, cm):
+    "conv3's weight gradient of a bottleneck: dz3 from (g, z3, bits) and a2 = relu(bn2(z2)), both formed in the operand loads."
+    from pytorch_retinanet_amd import pwconv
+    H, W = 19, 23
+    M = 2 * H * W
+    gup, z3, z2 = _rand((2, c4, H, W), 1.0, 1), _rand((2, c4, H, W), 1.0, 2), _rand((2, cm, H, W), 1.0, 3)
+    w3 = _rand((c4, cm, 1, 1), 0.05, 4)
+    coef3 = _bn_bwd_coefs(c4, 5)
+    gen = torch.Generator(device=DEV).manual_seed(6)
+    mask = torch.rand(M, c4, device=DEV, generator=gen) > 0.4
+    bits = (mask.view(M, c4 // 8, 8).to(torch.int32) * (2 ** torch.arange(8, device=DEV, dtype=torch.int32))).sum(-1).to(torch.uint8).contiguous().view(-1)
+    fwd2 = torch.cat([torch.rand(cm, device=DEV, generator=gen) + 0.5, torch.randn(cm, device=DEV, generator=gen) * 0.3])
+    dw = pwconv.pw_wgrad(gup, z2, w3, gpro=pwconv.bn_bwd(coef3, z3, 3, bits=bits), xpro=pwconv.affine_relu(fwd2))
+    zr, gr = z3.float().permute(0, 2, 3, 1).reshape(M, c4), gup.float().permute(0, 2, 3, 1).reshape(M, c4)
+    dz = (coef3[:c4] * (gr * mask) + (coef3[2 * c4:] * zr + coef3[c4:2 * c4])).to(torch.bfloat16).float()
+    a2 = F.relu(torch.addcmul(fwd2[cm:], z2.float().permute(0, 2, 3, 1).reshape(M, cm), fwd2[:cm])).to(torch.bfloat16).float()
+    ref = dz.t() @ a2
+    _close(dw.float().view(c4, cm), ref, 1e-2, "weight gradient with transforms")
+
+
+def _truth_block(blk, x0, g):
+    "The block in plain fp32 PyTorch ops with autograd (bf16 weights up-cast, batch statistics): outputs and every gradient."
+    def bn(z, m):
+        return F.batch_norm(z, None, None, m.weight, m.bias, True, 0.1, m.eps)
+    params = {n: p.detach().float().requires_grad_(True) for n, p in blk.named_parameters()}
+    x = x0.float().requires_grad_(True)
+
+    class M:        # a BatchNorm's affine parameters from the fp32 copies
+        def __init__(self, prefix, eps): self.weight, self.bias, self.eps = params[prefix + ".weight"], params[prefix + ".bias"], eps
+    s = blk.conv2.stride
+    a1 = F.relu(bn(F.conv2d(x, params["conv1.weight"]), M("bn1", blk.bn1.eps)))
+    a2 = F.relu(bn(F.conv2d(a1, params["conv2.weight"], None, s, 1), M("bn2", blk.bn2.eps)))
+    y3 = bn(F.conv2d(a2, params["conv3.weight"]), M("bn3", blk.bn3.eps))
+    idt = x
+    if blk.downsample is not None:
+        idt = bn(F.conv2d(x, params["downsample.0.weight"], None, blk.downsample[0].stride), M("downsample.1", blk.downsample[1].eps))
+    out = F.relu(y3 + idt)
+    out.backward(g.float())
+    return out.detach(), x.grad, {n: p.grad for n, p in params.items()}
+
+
+def _l2(a, b):
+    return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-12))
+
+
+@pytest.mark.parametrize("inplanes,planes,stride,down", [(256, 64, 1, False), (64, 64, 1, True), (256, 128, 2, True), (512, 128, 1, False)])
+def test_fused_bottleneck_is_as_close_to_fp32_as_the_layer_by_layer_block(inplanes, planes, stride, down):
+    """``pwconv._BottleneckFn`` against the block in fp32 PyTorch ops (the reference's Bottleneck, retinanet/backbone.py:105-136,
+    with autograd).  Two bf16 pipelines that sum in different orders cannot be compared element by element -- a pre-activation
+    at the ReLU boundary flips its mask and a whole upstream gradient element with it -- so both the fused block and the
+    layer-by-layer block (MIOpen convs + fused BN kernels, round 2's path) are measured by their relative L2 distance to the
+    fp32 result: the fused block must be within 1.25 x the layer-by-layer block's distance (+ 1e-3) for the output, the input
+    gradient and every parameter gradient, and the running statistics of the two must agree to 1e-3 (fp32-accumulated)."""
+    from pytorch_retinanet_amd import backbone as bb
+    from pytorch_retinanet_amd import pwconv
+    torch.manual_seed(7)
+    ds = None
+    if down:
+        ds = torch.nn.Sequential(bb._conv1x1(inplanes, planes * 4, stride), bb.FusedBatchNorm2d(planes * 4))
+    blk = bb.Bottleneck(inplanes, planes, stride, ds).to(DEV).to(memory_format=torch.channels_last).train()
+    with torch.no_grad():
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
+    for p in blk.parameters():
+        if p.dim() == 4:
+            p.data = p.data.to(torch.bfloat16)
+    x0 = _rand((2, inplanes, 24, 28), 1.0, 1)
+    g = _rand((2, planes * 4, 24 // stride, 28 // stride), 1.0, 2)
+    truth = _truth_block(blk, x0, g)
+    init = {n: b.clone() for n, b in blk.named_buffers()}
+    res = {}
+    for fused in (False, True):
+        pwconv.FUSED_BOTTLENECK = fused
+        with torch.no_grad():
+            for n, b in blk.named_buffers():
+                b.copy_(init[n])
+        x = x0.clone().requires_grad_(True)
+        blk.zero_grad()
+        assert pwconv.bottleneck_fusable(blk, x) == fused
+        y = blk(x)
+        y.backward(g)
+        torch.cuda.synchronize()
+        res[fused] = (y.detach().float(), x.grad.float(), {n: p.grad.float().clone() for n, p in blk.named_parameters()},
+                      {n: b.float().clone() for n, b in blk.named_buffers()})
+    pwconv.FUSED_BOTTLENECK = True
+    checks = [("output", res[True][0], res[False][0], truth[0]), ("input gradient", res[True][1], res[False][1], truth[1])]
+    checks += [(f"gradient of {n}", res[True][2][n], res[False][2][n], truth[2][n]) for n in truth[2]]
+    for what, fused_v, plain_v, ref in checks:
+        ef, ep = _l2(fused_v, ref), _l2(plain_v, ref)
+        assert ef <= 1.25 * ep + 1e-3 and ef <= 0.15, f"{what}: fused {ef} vs layer-by-layer {ep} from the fp32 block"
+    for n, a in res[False][3].items():
+        if "num_batches" in n:
+            assert int(res[True][3][n]) == int(a) == 1
+        else:
+            torch.testing.assert_close(res[True][3][n], a, rtol=1e-3, atol=1e-3 * float(a.abs().max()) + 1e-5, msg=n)
