@@ -224,13 +224,13 @@ def k3_cold_line(device, B, T, nbytes):
     gt_boxes = torch.from_numpy(np.concatenate(gtb)).to(device)
     gt_labels = torch.from_numpy(np.concatenate(gtl)).to(device)
     off = ops.gt_offsets([T] * B, device)
-    matches, num_fg = ops.iou_match(anc, gt_boxes, off, B, 0.5, 0.4)
+    matches, num_fg, special = ops.iou_match(anc, gt_boxes, off, B, 0.5, 0.4, want_special=True)
     params = ops.make_loss_params(0.25, 2.0, 0.1)                      # config.py: alpha, gamma, smooth-L1 beta
     evict = torch.empty((1 << 30,), dtype=torch.uint8, device=device)
     ops.enable_timing(True)
     for _ in range(13):
         evict.fill_(1)
-        ops.loss_fwd_bwd_levels(cls, box, anc, gt_boxes, gt_labels, off, matches, num_fg, params)
+        ops.loss_fwd_bwd_levels(cls, box, anc, gt_boxes, gt_labels, off, matches, num_fg, params, special=special)
     torch.cuda.synchronize()
     ev = ops.timing_events()["loss_stream_kernel"][3:]
     ops.enable_timing(False)

@@ -97,6 +97,16 @@ int rn_iou_match_ex(const float *anchors, int64_t anchor_bstride,
                     float fg_thr, float bg_thr, int64_t *matches, int32_t *num_fg,
                     int64_t total_gt, void *stream);
 
+/* rn_iou_match_ex that also writes the loss kernel's shortcut to the rows that are not plain background:
+ * special_rows u64[B][(A + 63) / 64] (rn_iou_match_special_bytes), bit (a & 63) of word a >> 6 = [matches[b][a] != -1]
+ * (matched or ignored rows, ~0.3 % at the reference's thresholds).  rn_loss_fwd_bwd_levels_ex then fetches a 64-row chunk's
+ * flags with two scalar loads and reads `matches` only where a bit is set, instead of streaming all of it (NULL: not written). */
+size_t rn_iou_match_special_bytes(int B, int64_t A);
+int rn_iou_match_special(const float *anchors, int64_t anchor_bstride,
+                         const float *gt_boxes, const int32_t *gt_off, int B, int64_t A,
+                         float fg_thr, float bg_thr, int64_t *matches, int32_t *num_fg,
+                         uint64_t *special_rows, int64_t total_gt, void *stream);
+
 /* ---- K3 loss_fwd_bwd --------------------------------------------------------
  * Replaces RetinaNetLosses.forward / calc_loss / focal_loss / smooth_l1_loss,
  * retinanet/losses.py:19-145, and bbox_2_activ, retinanet/box_utils.py:25-34:
@@ -131,6 +141,15 @@ int rn_loss_fwd_bwd_levels(const void *const *cls_levels, const void *const *box
 /* Same call; additionally records the caller's HIP events (hipEvent_t, may be NULL) on `stream` immediately before and
  * after the streaming kernel -- the dominant kernel of the call -- so a benchmark can time that kernel alone (the
  * one-block finalize that follows is outside the pair). */
+/* rn_loss_fwd_bwd_levels with the special-row words of rn_iou_match_special (nullable: then `matches` is streamed) and an
+ * optional pair of HIP events recorded on `stream` right around the streaming kernel (nullable; bench.py's roofline). */
+int rn_loss_fwd_bwd_levels_ex(const void *const *cls_levels, const void *const *box_levels,
+                              const int64_t *level_anchors, int L, int dtype, int B, int K,
+                              const float *anchors, int64_t anchor_bstride, const float *gt_boxes,
+                              const int64_t *gt_labels, const int32_t *gt_off, const int64_t *matches,
+                              const uint64_t *special_rows, const int32_t *num_fg, const rn_loss_params *params,
+                              float *out_loss, void *const *grad_cls_levels, void *const *grad_box_levels, void *workspace,
+                              size_t workspace_bytes, void *stream, void *event_start, void *event_stop);
 int rn_loss_fwd_bwd_levels_timed(const void *const *cls_levels, const void *const *box_levels,
                                  const int64_t *level_anchors, int L, int dtype, int B, int K,
                                  const float *anchors, int64_t anchor_bstride, const float *gt_boxes,

@@ -56,6 +56,8 @@ struct LossArgs {
     const int64_t *gt_labels;
     const int32_t *gt_off;
     const int64_t *matches;
+    const unsigned long long *special;   // nullable: [B][special_W] bit (a & 63) of word a >> 6 = [matches[b][a] != -1]  (rn_iou_match_special)
+    int64_t special_W;
     const int32_t *num_fg;
     int64_t A;               // anchors per image over all levels (row length of `matches`)
     int64_t vec_per_wave;    // stream kernel: 16-byte vectors per wave (multiple of 64)
@@ -179,7 +181,7 @@ __device__ __forceinline__ float image_gmul(const LossArgs &a, const int b)
 // plain background (positive element of a matched row, whole ignored rows) and emits the box
 // gradient / regression term of the rows whose first element it owns.  Both phases write from one
 // wave, so program order gives the right final value without any cross-wave ordering.
-constexpr int PREF_CHUNKS = 4;      // 64-row chunks of `matches` prefetched before the stream (256 rows)
+constexpr int LIST_CAP = 320;       // rows of a wave's range whose repair goes through the LDS lists (5 chunks of 64; 273 at the train shape)
 constexpr int IGN_U = 4;            // independent element loads per lane per round in the ignored-row repair
 
 template <int DT, bool GAMMA2, bool WRITE_GRAD, int PF, int NT>
@@ -188,15 +190,17 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
     typedef rn::dt<DT> D;
     constexpr int VEC = D::VEC;
     __shared__ float s_part[LOSS_WAVES][2];
-    __shared__ unsigned short s_ign_row[LOSS_WAVES][PREF_CHUNKS * RN_WAVE];   // ignored rows of the wave's range (offsets from its first row)
-    __shared__ float s_ign_gm[LOSS_WAVES][PREF_CHUNKS * RN_WAVE];            // their alpha/(max(nfg,1)*B)
+    __shared__ unsigned short s_ign_row[LOSS_WAVES][LIST_CAP];   // ignored rows of the wave's range (offsets from its first row)
+    __shared__ float s_ign_gm[LOSS_WAVES][LIST_CAP];            // their alpha/(max(nfg,1)*B)
+    __shared__ int s_pos_off[LOSS_WAVES][LIST_CAP];             // positive elements of matched rows: offset from the range's first element
+    __shared__ float s_pos_val[LOSS_WAVES][LIST_CAP];           //   and their gradient
 
     const int lane = threadIdx.x & (RN_WAVE - 1);
     // readfirstlane: the wave index and everything derived from it (ranges, trip counts, image
     // seams) is wave-uniform -> SGPRs and scalar branches.
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t gwave_raw = (int64_t)blockIdx.x * LOSS_WAVES + wave;
-    const int64_t gwave = a.reverse ? (int64_t)gridDim.x * LOSS_WAVES - 1 - gwave_raw : gwave_raw;
+    const int64_t gwave = (a.reverse & 1) ? (int64_t)gridDim.x * LOSS_WAVES - 1 - gwave_raw : gwave_raw;
     const int64_t gv_beg = gwave * a.vec_per_wave;                // this wave's range in the virtual vector space
     const int64_t gv_end = min(gv_beg + a.vec_per_wave, a.total_vec);  // (levels laid end to end)
     const int K = a.K;
@@ -223,22 +227,139 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
         const int64_t row_lo = e_beg / K;                        // rows are local to the level: r = b * A_l + a_local
         const int64_t row_hi = e_end > e_beg ? (e_end - 1) / K : row_lo - 1;     // inclusive
 
-        // this range's slice of `matches` (phase B input): loaded while the stream runs, right AFTER the first stream loads
-        // are issued (every cycle before those delays the whole wave)
-        int pm[PREF_CHUNKS];
-        auto load_matches = [&]() {
-#pragma unroll
-            for (int c = 0; c < PREF_CHUNKS; ++c) {
-                const int64_t r = row_lo + c * RN_WAVE + lane;
-                int m = -1;
-                if (r <= row_hi) {
-                    const int b = (int)((uint32_t)r / (uint32_t)lv.A_l);
-                    m = (int)a.matches[(int64_t)b * a.A + lv.base + (r - (int64_t)b * lv.A_l)];
+        // ---- Phase B, part 1 (BEFORE the stream): everything the repair of this range needs is INPUT data -- match codes, labels,
+        // GT boxes, the positive logits -- so the dependent load chains (3 - 4 round trips) run here, at the start of the wave,
+        // where the other resident waves cover them, instead of at its end, where the whole chip waits for the slowest wave
+        // (round 2: the stream alone 110 / 126 us warm / cold, with the repair behind it 135 / 144).  What has to FOLLOW the
+        // stream are only the stores that overwrite gradient elements phase A writes (the positive element of a matched row,
+        // the zeros of an ignored row): they wait in two wave-private LDS lists.  The box gradients (not touched by phase A) are
+        // final here.  A chunk of 64 rows costs two SCALAR loads when it has no special row (5 chunks of 6): the words of
+        // rn_iou_match_special; `matches` is read only by the lanes whose flag is set.
+        const int64_t cap_hi = min(row_hi, row_lo + (int64_t)LIST_CAP - 1);        // rows [row_lo, cap_hi] go through the lists
+        int n_pos = 0, n_ign = 0;
+        auto prep = [&]() {
+            if (WRITE_GRAD) {
+                // zero box gradients of the rows this wave owns, as 16-byte vectors (two 16-bit rows per lane); matched rows
+                // overwrite theirs below (same wave: program order)
+                constexpr int RB = 4 * (int)sizeof(typename D::elem);     // bytes per box row
+                const int64_t own_lo = (e_beg + K - 1) / K;
+                if (own_lo <= cap_hi) {                                   // wave-uniform
+                    unsigned char *const gb0 = (unsigned char *)lv.gbox;
+                    const int64_t b0 = own_lo * RB, b1 = (cap_hi + 1) * RB;
+                    const int64_t v0 = (b0 + 15) >> 4, v1 = b1 >> 4;
+                    for (int64_t v = v0 + lane; v < v1; v += RN_WAVE) ((rn::u32x4 *)gb0)[v] = rn::u32x4{0u, 0u, 0u, 0u};
+                    if (RB == 8) {                                        // an odd first / last row: one 8-byte store each
+                        if (lane == 0 && (b0 & 15)) *(rn::u32x2 *)(gb0 + b0) = rn::u32x2{0u, 0u};
+                        if (lane == 1 && (b1 & 15) && (v1 << 4) >= b0) *(rn::u32x2 *)(gb0 + (v1 << 4)) = rn::u32x2{0u, 0u};
+                    }
                 }
-                pm[c] = m;
+            }
+#pragma unroll 1
+            for (int64_t r0 = row_lo; r0 <= cap_hi; r0 += RN_WAVE) {                 // wave-uniform
+                const int n = (int)min((int64_t)RN_WAVE, cap_hi - r0 + 1);
+                unsigned long long m = ~0ull;                                      // no words (old entry points): look every row up
+                if (a.special) {
+                    const int b0 = (int)((uint32_t)r0 / (uint32_t)lv.A_l);
+                    const int64_t a0 = r0 - (int64_t)b0 * lv.A_l;
+                    if (a0 + n <= lv.A_l) {                                        // the chunk lies inside one image
+                        const int64_t ag0 = lv.base + a0, w = ag0 >> 6;
+                        const int sh = (int)(ag0 & 63);
+                        const unsigned long long *p = a.special + (int64_t)b0 * a.special_W + w;
+                        const unsigned long long lo = p[0];
+                        const unsigned long long hi = (sh && w + 1 < a.special_W) ? p[1] : 0ull;
+                        m = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+                    }
+                }
+                if (n < RN_WAVE) m &= (1ull << n) - 1ull;
+                if (!m) continue;
+                const int64_t r = r0 + lane;
+                const bool flagged = (m >> lane) & 1ull;
+                int pmv = -1, b = 0;
+                int64_t ag = 0;
+                if (flagged) {
+                    b = (int)((uint32_t)r / (uint32_t)lv.A_l);
+                    ag = lv.base + (r - (int64_t)b * lv.A_l);
+                    pmv = (int)a.matches[(int64_t)b * a.A + ag];
+                }
+                const bool special = flagged && pmv != -1;
+                int t0 = 0, T = 0, nf = 1;
+                if (special) { t0 = a.gt_off[b]; T = a.gt_off[b + 1] - t0; nf = a.num_fg[b]; }
+                const bool live = special && T > 0;                                // images without GT: phase A writes zeros
+                const bool matched = live && pmv >= 0, ign = live && pmv < 0;
+                const float scale = (1.0f / (float)(nf > 1 ? nf : 1)) * a.inv_B;
+                int code = -1;
+                if (matched) code = (int)a.gt_labels[t0 + pmv] - 1;
+                const int64_t e_pos = r * K + code;
+                const bool pos_ok = matched && code >= 0 && code < K && e_pos >= e_beg && e_pos < e_end;
+                float xp = 0.0f;
+                if (pos_ok) xp = D::ld(lv.cls, e_pos);
+                float gr = 0.0f;
+                if (pos_ok) {                                                      // matched row: only the positive element differs from what phase A does
+                    float wb, gbg, l;
+                    bg_elem<GAMMA2>(xp, a.p, wb, gbg);
+                    focal_elem<GAMMA2>(xp, true, a, l, gr);
+                    acc += (double)l * (double)scale - (double)wb * (double)(a.p.alpha * scale);
+                    gr *= scale;
+                }
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const unsigned long long pmask = __ballot(pos_ok);
+                if (pos_ok) {
+                    const int pos = n_pos + __popcll(pmask & below);
+                    s_pos_off[wave][pos] = (int)(e_pos - e_beg);
+                    s_pos_val[wave][pos] = gr;
+                }
+                n_pos += __popcll(pmask);
+                const bool mo = matched && r * K >= e_beg;                         // the row's first element is ours: its box gradient too
+                if (__any(mo)) {                                                   // wave-uniform
+                    if (mo) {
+                        float gb[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pred[4];
+                        box4<DT>::ld(lv.box, r, pred);
+                        const float l = reg_row(a.gt_boxes[t0 + pmv], a.anchors[(int64_t)b * a.anchor_bstride4 + ag], pred, a.p, gb);
+                        reg += l * scale;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) gb[j] *= scale;
+                        if (WRITE_GRAD) box4<DT>::st(lv.gbox, r, gb);
+                    }
+                }
+                const unsigned long long imask = __ballot(ign);
+                if (ign) {
+                    const int pos = n_ign + __popcll(imask & below);
+                    s_ign_row[wave][pos] = (unsigned short)(r - row_lo);
+                    s_ign_gm[wave][pos] = a.p.alpha * scale;
+                }
+                n_ign += __popcll(imask);
+            }
+            if (n_ign) {                                                           // wave-uniform
+                // ignored rows: their background terms (which phase A will add) come out again; reads only -- the zero stores
+                // follow the stream.  Elements spread over all lanes, IGN_U independent loads per lane per round.
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int total = n_ign * K;
+                for (int t0 = 0; t0 < total; t0 += RN_WAVE * IGN_U) {
+                    float xs[IGN_U], gms[IGN_U];
+                    bool ok[IGN_U];
+#pragma unroll
+                    for (int u = 0; u < IGN_U; ++u) {
+                        const int t = min(t0 + u * RN_WAVE + lane, total - 1);
+                        const int j = t / K, k = t - j * K;
+                        const int64_t e = (row_lo + s_ign_row[wave][j]) * K + k;
+                        gms[u] = s_ign_gm[wave][j];
+                        ok[u] = (t0 + u * RN_WAVE + lane < total) && e >= e_beg && e < e_end;
+                        xs[u] = D::ld(lv.cls, e);
+                    }
+#pragma unroll
+                    for (int u = 0; u < IGN_U; ++u) {
+                        if (ok[u]) {
+                            float wb, gbg;
+                            bg_elem<GAMMA2>(xs[u], a.p, wb, gbg);
+                            acc -= (double)wb * (double)gms[u];
+                        }
+                    }
+                }
             }
         };
-        if (v_beg >= v_end) load_matches();
+        if (v_beg >= v_end) prep();
 
         if (v_beg < v_end) {
             int b = (int)(e_beg / lv.per_image);                      // image of the first element
@@ -250,9 +371,13 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
             rn::u32x4 q[PF];
 #pragma unroll
             for (int u = 0; u < PF; ++u) q[u] = (NT & 1) ? __builtin_nontemporal_load(&src[min(v_beg + u * RN_WAVE + lane, last)]) : src[min(v_beg + u * RN_WAVE + lane, last)];
-            load_matches();
 
             int64_t v0 = v_beg;
+            // the range's repair preparation (dependent load chains, a few microseconds), under the first stream loads.
+            // (Measured alternatives, same box: after the stream as in round 2 +6 us cold -- the whole chip waits for the
+            // slowest wave's chains --; at a per-wave pseudo-random point inside the stream +5..8 us cold: the second copy of
+            // the loop costs registers and the stream its sixth wave per SIMD.)
+            prep();
             for (int64_t gi = 0; gi < groups; ++gi, v0 += PF * RN_WAVE) {
                 // next group's loads first (index clamped: straight-line code, countable vmcnt)
                 rn::u32x4 qn[PF];
@@ -343,130 +468,23 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
             }
         }
 
-        // ---- Phase B: repair this range's special elements; box gradients of the rows it owns --------
-        // The first PREF_CHUNKS * 64 rows (all of them at the headline shapes) go through a STAGED pass: every level of the
-        // dependent loads (per-image scalars -> label / GT box / anchor / prediction -> positive logit) is issued for all
-        // chunks at once, so the tail of the kernel is 3 memory round trips instead of ~4 per chunk (18 us -> a few us: the
-        // whole chip idles behind the slowest wave here).  Rows past that (small K, few waves) take the chunk loop below.
-        {
-            int t0s[PREF_CHUNKS], Ts[PREF_CHUNKS], nfs[PREF_CHUNKS];
-            bool special[PREF_CHUNKS], own[PREF_CHUNKS];
-            auto row_of = [&](const int c) { return row_lo + c * RN_WAVE + lane; };
-            // stage 1: per-image scalars of the special rows
-#pragma unroll
-            for (int c = 0; c < PREF_CHUNKS; ++c) {
-                const int64_t r = row_of(c);
-                const bool valid = r <= row_hi;
-                own[c] = valid && r * K >= e_beg;
-                special[c] = valid && pm[c] != -1;
-                t0s[c] = 0; Ts[c] = 0; nfs[c] = 1;
-                if (special[c]) {
-                    const int b = (int)((uint32_t)r / (uint32_t)lv.A_l);
-                    t0s[c] = a.gt_off[b]; Ts[c] = a.gt_off[b + 1]; nfs[c] = a.num_fg[b];
-                }
+        // ---- Phase B, part 2 (after the stream): the stores that overwrite what phase A wrote, from the two lists -- no loads
+        if (WRITE_GRAD && (n_pos | n_ign)) {                                       // wave-uniform
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int i = lane; i < n_pos; i += RN_WAVE) D::st(lv.gcls, e_beg + s_pos_off[wave][i], s_pos_val[wave][i]);
+            const int total = n_ign * K;
+            for (int t = lane; t < total; t += RN_WAVE) {
+                const int j = t / K, k = t - j * K;
+                const int64_t e = (row_lo + s_ign_row[wave][j]) * K + k;
+                if (e >= e_beg && e < e_end) D::st(lv.gcls, e, 0.0f);
             }
-            // stage 2: labels of matched rows
-            int code[PREF_CHUNKS];
-            bool matched[PREF_CHUNKS], ign[PREF_CHUNKS];
-            float scale[PREF_CHUNKS];
-#pragma unroll
-            for (int c = 0; c < PREF_CHUNKS; ++c) {
-                const bool live = special[c] && (Ts[c] - t0s[c]) > 0;  // images without GT: phase A already wrote zeros
-                matched[c] = live && pm[c] >= 0;
-                ign[c] = live && pm[c] < 0;
-                scale[c] = (1.0f / (float)(nfs[c] > 1 ? nfs[c] : 1)) * a.inv_B;
-                code[c] = -1;
-                if (matched[c]) code[c] = (int)a.gt_labels[t0s[c] + pm[c]] - 1;
-            }
-            // stage 3: the positive logit
-            float xp[PREF_CHUNKS];
-            bool pos_ok[PREF_CHUNKS];
-#pragma unroll
-            for (int c = 0; c < PREF_CHUNKS; ++c) {
-                const int64_t e_pos = row_of(c) * K + code[c];
-                pos_ok[c] = matched[c] && code[c] >= 0 && code[c] < K && e_pos >= e_beg && e_pos < e_end;
-                xp[c] = 0.0f;
-                if (pos_ok[c]) xp[c] = D::ld(lv.cls, e_pos);
-            }
-            // stage 4: the positive element's loss and gradient
-#pragma unroll
-            for (int c = 0; c < PREF_CHUNKS; ++c) {
-                if (pos_ok[c]) {                                          // matched row: only the positive element differs from what phase A did
-                    float wb, gbg, l, gr;
-                    bg_elem<GAMMA2>(xp[c], a.p, wb, gbg);
-                    focal_elem<GAMMA2>(xp[c], true, a, l, gr);
-                    acc += (double)l * (double)scale[c] - (double)wb * (double)(a.p.alpha * scale[c]);
-                    if (WRITE_GRAD) D::st(lv.gcls, row_of(c) * K + code[c], gr * scale[c]);
-                }
-            }
-            // stage 5: box gradients of the rows this wave owns -- zeros, except for matched rows (chunks with one: rare)
-#pragma unroll
-            for (int c = 0; c < PREF_CHUNKS; ++c) {
-                float gb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                const bool mo = matched[c] && own[c];
-                if (__any(mo)) {                                          // wave-uniform
-                    if (mo) {
-                        const int64_t r = row_of(c);
-                        const int b = (int)((uint32_t)r / (uint32_t)lv.A_l);
-                        float pred[4];
-                        box4<DT>::ld(lv.box, r, pred);
-                        const float l = reg_row(a.gt_boxes[t0s[c] + pm[c]],
-                                                a.anchors[(int64_t)b * a.anchor_bstride4 + lv.base + (r - (int64_t)b * lv.A_l)], pred, a.p, gb);
-                        reg += l * scale[c];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) gb[j] *= scale[c];
-                    }
-                }
-                if (WRITE_GRAD && own[c]) box4<DT>::st(lv.gbox, row_of(c), gb);
-            }
-            // ignored rows: remove their background contribution and zero their gradient.  The rows of all
-            // chunks are compacted into one wave-private LDS list and their elements spread over all lanes, IGN_U independent
-            // loads per lane per round (elements outside this wave's range are masked).
-            int n_ign = 0;
-#pragma unroll
-            for (int c = 0; c < PREF_CHUNKS; ++c) {
-                const unsigned long long imask = __ballot(ign[c]);
-                if (ign[c]) {
-                    const int pos = n_ign + __popcll(imask & ((1ull << lane) - 1ull));
-                    s_ign_row[wave][pos] = (unsigned short)(c * RN_WAVE + lane);
-                    s_ign_gm[wave][pos] = a.p.alpha * scale[c];
-                }
-                n_ign += __popcll(imask);
-            }
-            if (n_ign) {                                                   // wave-uniform
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int total = n_ign * K;
-                for (int t0 = 0; t0 < total; t0 += RN_WAVE * IGN_U) {
-                    float xs[IGN_U], gms[IGN_U];
-                    int64_t es[IGN_U];
-                    bool ok[IGN_U];
-#pragma unroll
-                    for (int u = 0; u < IGN_U; ++u) {
-                        const int t = min(t0 + u * RN_WAVE + lane, total - 1);
-                        const int j = t / K, k = t - j * K;
-                        es[u] = (row_lo + s_ign_row[wave][j]) * K + k;
-                        gms[u] = s_ign_gm[wave][j];
-                        ok[u] = (t0 + u * RN_WAVE + lane < total) && es[u] >= e_beg && es[u] < e_end;
-                        xs[u] = D::ld(lv.cls, es[u]);
-                    }
-#pragma unroll
-                    for (int u = 0; u < IGN_U; ++u) {
-                        if (ok[u]) {
-                            float wb, gbg;
-                            bg_elem<GAMMA2>(xs[u], a.p, wb, gbg);
-                            acc -= (double)wb * (double)gms[u];
-                            if (WRITE_GRAD) D::st(lv.gcls, es[u], 0.0f);
-                        }
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        // rows past the staged pass
-        for (int64_t c0 = row_lo + PREF_CHUNKS * RN_WAVE, c = PREF_CHUNKS; c0 <= row_hi; c0 += RN_WAVE, ++c) {
+        // rows past the lists' capacity (ranges longer than LIST_CAP rows: small K or few waves), chunk by chunk after the stream
+        for (int64_t c0 = row_lo + LIST_CAP; c0 <= row_hi; c0 += RN_WAVE) {
             const int64_t r = c0 + lane;
             bool ignored = false;
             float ign_gm = 0.0f;
@@ -710,13 +728,13 @@ RN_API size_t rn_loss_workspace_bytes(int B, int64_t A, int K)
     return sizeof(float2) * (size_t)LOSS_MAX_BLOCKS * 2 + 16;
 }
 
-RN_API int rn_loss_fwd_bwd_levels(const void *const *cls_levels, const void *const *box_levels,
-                                  const int64_t *level_anchors, int L, int dtype, int B, int K,
-                                  const float *anchors, int64_t anchor_bstride, const float *gt_boxes,
-                                  const int64_t *gt_labels, const int32_t *gt_off, const int64_t *matches,
-                                  const int32_t *num_fg, const rn_loss_params *params, float *out_loss,
-                                  void *const *grad_cls_levels, void *const *grad_box_levels, void *workspace,
-                                  size_t workspace_bytes, void *stream)
+static int loss_levels_core(const void *const *cls_levels, const void *const *box_levels,
+                            const int64_t *level_anchors, int L, int dtype, int B, int K,
+                            const float *anchors, int64_t anchor_bstride, const float *gt_boxes,
+                            const int64_t *gt_labels, const int32_t *gt_off, const int64_t *matches, const uint64_t *special_rows,
+                            const int32_t *num_fg, const rn_loss_params *params, float *out_loss,
+                            void *const *grad_cls_levels, void *const *grad_box_levels, void *workspace,
+                            size_t workspace_bytes, void *stream)
 {
     if (!cls_levels || !box_levels || !level_anchors || !anchors || !gt_off || !matches || !num_fg || !params || !out_loss ||
         !workspace)
@@ -759,6 +777,8 @@ RN_API int rn_loss_fwd_bwd_levels(const void *const *cls_levels, const void *con
     a.anchors = (const rn::f32x4 *)anchors; a.anchor_bstride4 = anchor_bstride / 4;
     a.gt_boxes = (const rn::f32x4 *)gt_boxes; a.gt_labels = gt_labels; a.gt_off = gt_off;
     a.matches = matches; a.num_fg = num_fg;
+    if (special_rows && !rn::aligned(special_rows, 8)) return RN_EALIGN;
+    a.special = (const unsigned long long *)special_rows; a.special_W = (A + 63) >> 6;
     a.A = A; a.K = K; a.B = B;
     a.vec_per_wave = RN_WAVE;
     a.inv_B = 1.0f / (float)B;
@@ -781,6 +801,34 @@ RN_API int rn_loss_fwd_bwd_levels(const void *const *cls_levels, const void *con
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float2 *)a.part_stream, ns, out_loss);
     RN_LAUNCH_CHECK();
     return RN_OK;
+}
+
+RN_API int rn_loss_fwd_bwd_levels(const void *const *cls_levels, const void *const *box_levels,
+                                  const int64_t *level_anchors, int L, int dtype, int B, int K,
+                                  const float *anchors, int64_t anchor_bstride, const float *gt_boxes,
+                                  const int64_t *gt_labels, const int32_t *gt_off, const int64_t *matches,
+                                  const int32_t *num_fg, const rn_loss_params *params, float *out_loss,
+                                  void *const *grad_cls_levels, void *const *grad_box_levels, void *workspace,
+                                  size_t workspace_bytes, void *stream)
+{
+    return loss_levels_core(cls_levels, box_levels, level_anchors, L, dtype, B, K, anchors, anchor_bstride, gt_boxes, gt_labels, gt_off,
+                            matches, nullptr, num_fg, params, out_loss, grad_cls_levels, grad_box_levels, workspace, workspace_bytes, stream);
+}
+
+RN_API int rn_loss_fwd_bwd_levels_ex(const void *const *cls_levels, const void *const *box_levels,
+                                     const int64_t *level_anchors, int L, int dtype, int B, int K,
+                                     const float *anchors, int64_t anchor_bstride, const float *gt_boxes,
+                                     const int64_t *gt_labels, const int32_t *gt_off, const int64_t *matches,
+                                     const uint64_t *special_rows, const int32_t *num_fg, const rn_loss_params *params,
+                                     float *out_loss, void *const *grad_cls_levels, void *const *grad_box_levels, void *workspace,
+                                     size_t workspace_bytes, void *stream, void *event_start, void *event_stop)
+{
+    g_prof.start = (hipEvent_t)event_start; g_prof.stop = (hipEvent_t)event_stop;
+    const int rc = loss_levels_core(cls_levels, box_levels, level_anchors, L, dtype, B, K, anchors, anchor_bstride, gt_boxes, gt_labels,
+                                    gt_off, matches, special_rows, num_fg, params, out_loss, grad_cls_levels, grad_box_levels, workspace,
+                                    workspace_bytes, stream);
+    g_prof.start = g_prof.stop = nullptr;
+    return rc;
 }
 
 RN_API int rn_loss_fwd_bwd_levels_timed(const void *const *cls_levels, const void *const *box_levels,

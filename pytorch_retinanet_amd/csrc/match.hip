@@ -138,12 +138,23 @@ __device__ __forceinline__ int64_t classify(const float best, const int bi, cons
     return r;
 }
 
+// The loss kernel's shortcut to the rows that are not plain background: special[b][a >> 6] bit (a & 63) = [matches[b][a] != -1]
+// (matched or ignored: ~0.3 % of the rows at the reference's thresholds).  Every kernel below hands each wave 64 consecutive
+// anchors that start on a multiple of 64, so a word is one ballot; K3 then fetches a 64-row chunk's flags with two SCALAR loads
+// instead of a 512-byte vector load of `matches`, and reads `matches` only where a bit is set.
+__device__ __forceinline__ void special_word(unsigned long long *__restrict__ special, const int b, const int64_t A, const int64_t a_idx,
+                                             const bool flag)
+{
+    const unsigned long long w = __ballot(flag);
+    if ((threadIdx.x & (RN_WAVE - 1)) == 0 && (a_idx & ~(int64_t)63) < A) special[(int64_t)b * ((A + 63) >> 6) + (a_idx >> 6)] = w;
+}
+
 // ============================================================================================================
 // Shared anchors, small GT sets: one thread = one anchor x `ipb` images of the batch (blockIdx.y selects the image group).
 __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_batch_kernel(
     const rn::f32x4 *__restrict__ anchors, const rn::f32x4 *__restrict__ gt, const int32_t *__restrict__ gt_off,
     const int B, const int ipb, const int64_t A, const float fg_thr, const float bg_thr, int64_t *__restrict__ matches,
-    int32_t *__restrict__ num_fg)
+    int32_t *__restrict__ num_fg, unsigned long long *__restrict__ special)
 {
     __shared__ rn::f32x4 s_box[BATCH_GT_MAX + RN_WAVE];   // (a wave reads 64 entries at a time, possibly past the last row)
     __shared__ float s_area[BATCH_GT_MAX + RN_WAVE];
@@ -209,6 +220,7 @@ __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_batch_kernel(
         if (!fast) { best = bb2.v; bi = bb2.i; }
         const int64_t r = classify(best, bi, T, fg_thr, bg_thr);
         if (live) matches[(int64_t)b * A + a_idx] = r;
+        if (special) special_word(special, b, A, a_idx, live && r != -1);
         if (num_fg) {
             const unsigned long long fg = __ballot(live && r >= 0);
             if ((tid & (RN_WAVE - 1)) == 0 && fg) atomicAdd(&num_fg[b], __popcll(fg));
@@ -222,7 +234,8 @@ template <int R>
 __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_tile_kernel(
     const rn::f32x4 *__restrict__ anchors, const int64_t anchor_bstride4,
     const rn::f32x4 *__restrict__ gt, const int32_t *__restrict__ gt_off, const int64_t A,
-    const float fg_thr, const float bg_thr, int64_t *__restrict__ matches, int32_t *__restrict__ num_fg)
+    const float fg_thr, const float bg_thr, int64_t *__restrict__ matches, int32_t *__restrict__ num_fg,
+    unsigned long long *__restrict__ special)
 {
     __shared__ rn::f32x4 s_box[GT_TILE];
     __shared__ float s_area[GT_TILE];
@@ -327,6 +340,7 @@ __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_tile_kernel(
             matches[(int64_t)b * A + a_idx] = m;
             nfg += m >= 0 ? 1 : 0;
         }
+        if (special) special_word(special, b, A, a_idx, a_idx < A && m != -1);
     }
     if (num_fg) {                                          // one global atomic per workgroup (same-address atomics serialise)
         nfg = rn::wave_sum_i(nfg);
@@ -481,7 +495,7 @@ constexpr int FIN_BLOCK = 1024;
 __global__ __launch_bounds__(FIN_BLOCK) void iou_match_finalize_kernel(
     const rn::f32x4 *__restrict__ anchors, const int64_t anchor_bstride4, const rn::f32x4 *__restrict__ gt,
     const int32_t *__restrict__ gt_off, const int64_t A, const float fg_thr, const float bg_thr,
-    int64_t *__restrict__ matches, int32_t *__restrict__ num_fg)
+    int64_t *__restrict__ matches, int32_t *__restrict__ num_fg, unsigned long long *__restrict__ special)
 {
     const int b = blockIdx.y;
     const int t0 = gt_off[b], T = gt_off[b + 1] - t0;
@@ -517,6 +531,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void iou_match_finalize_kernel(
         r = classify(best, bi, T, fg_thr, bg_thr);
         matches[(int64_t)b * A + a_idx] = r;
     }
+    if (special) special_word(special, b, A, a_idx, live && r != -1);
     if (num_fg) {
         // thousands of foreground anchors per image here: one global atomic per 1024 anchors (same-address atomics from every
         // wave serialise at ~50 per microsecond and address: 35 us of a 69 us kernel before)
@@ -539,6 +554,17 @@ RN_API int rn_iou_match_ex(const float *anchors, int64_t anchor_bstride, const f
                            int B, int64_t A, float fg_thr, float bg_thr, int64_t *matches, int32_t *num_fg,
                            int64_t total_gt, void *stream)
 {
+    return rn_iou_match_special(anchors, anchor_bstride, gt_boxes, gt_off, B, A, fg_thr, bg_thr, matches, num_fg, nullptr, total_gt, stream);
+}
+
+RN_API size_t rn_iou_match_special_bytes(int B, int64_t A) { return (B > 0 && A > 0) ? sizeof(uint64_t) * (size_t)B * (size_t)((A + 63) >> 6) : 0; }
+
+RN_API int rn_iou_match_special(const float *anchors, int64_t anchor_bstride, const float *gt_boxes, const int32_t *gt_off,
+                                int B, int64_t A, float fg_thr, float bg_thr, int64_t *matches, int32_t *num_fg,
+                                uint64_t *special_rows, int64_t total_gt, void *stream)
+{
+    unsigned long long *special = (unsigned long long *)special_rows;
+    if (special && !rn::aligned(special, 8)) return RN_EALIGN;
     if (!anchors || !gt_off || !matches || B <= 0 || A <= 0 || B > 65535) return RN_EINVAL;
     if (!(fg_thr > bg_thr)) return RN_ETHRESH;
     if (!rn::aligned(anchors, 16) || (gt_boxes && !rn::aligned(gt_boxes, 16)) || (anchor_bstride & 3)) return RN_EALIGN;
@@ -554,7 +580,7 @@ RN_API int rn_iou_match_ex(const float *anchors, int64_t anchor_bstride, const f
         const int ipb = (B + by - 1) / by;
         const dim3 grid((unsigned)bx, (unsigned)((B + ipb - 1) / ipb));
         hipLaunchKernelGGL(iou_match_batch_kernel, grid, dim3(MATCH_BLOCK), 0, st, (const rn::f32x4 *)anchors,
-                           (const rn::f32x4 *)gt_boxes, gt_off, B, ipb, A, fg_thr, bg_thr, matches, num_fg);
+                           (const rn::f32x4 *)gt_boxes, gt_off, B, ipb, A, fg_thr, bg_thr, matches, num_fg, special);
     } else if (total_gt > 192 * (int64_t)B && A * (int64_t)B < ((int64_t)1 << 40)) {
         // hundreds of GT boxes per image: split the GT axis too (see iou_match_chunk_kernel); z workgroups per anchor strip
         int z = (int)((total_gt / B + CHUNK_TILE - 1) / CHUNK_TILE);
@@ -566,15 +592,15 @@ RN_API int rn_iou_match_ex(const float *anchors, int64_t anchor_bstride, const f
         RN_LAUNCH_CHECK();
         const dim3 fgrid((unsigned)((A + FIN_BLOCK - 1) / FIN_BLOCK), (unsigned)B);
         hipLaunchKernelGGL(iou_match_finalize_kernel, fgrid, dim3(FIN_BLOCK), 0, st, (const rn::f32x4 *)anchors, anchor_bstride / 4,
-                           (const rn::f32x4 *)gt_boxes, gt_off, A, fg_thr, bg_thr, matches, num_fg);
+                           (const rn::f32x4 *)gt_boxes, gt_off, A, fg_thr, bg_thr, matches, num_fg, special);
     } else if (total_gt >= 0 && total_gt <= 32 * (int64_t)B) {
         const dim3 grid((unsigned)((A + MATCH_BLOCK * 2 - 1) / (MATCH_BLOCK * 2)), (unsigned)B);
         hipLaunchKernelGGL(iou_match_tile_kernel<2>, grid, dim3(MATCH_BLOCK), 0, st, (const rn::f32x4 *)anchors, anchor_bstride / 4,
-                           (const rn::f32x4 *)gt_boxes, gt_off, A, fg_thr, bg_thr, matches, num_fg);
+                           (const rn::f32x4 *)gt_boxes, gt_off, A, fg_thr, bg_thr, matches, num_fg, special);
     } else {
         const dim3 grid((unsigned)((A + MATCH_BLOCK * 4 - 1) / (MATCH_BLOCK * 4)), (unsigned)B);
         hipLaunchKernelGGL(iou_match_tile_kernel<4>, grid, dim3(MATCH_BLOCK), 0, st, (const rn::f32x4 *)anchors, anchor_bstride / 4,
-                           (const rn::f32x4 *)gt_boxes, gt_off, A, fg_thr, bg_thr, matches, num_fg);
+                           (const rn::f32x4 *)gt_boxes, gt_off, A, fg_thr, bg_thr, matches, num_fg, special);
     }
     RN_LAUNCH_CHECK();
     return RN_OK;

@@ -244,5 +244,5 @@ class RetinaNetHead(nn.Module):
             return {"cls_levels": ch.output_levels(cls_t, pad_classes), "bbox_levels": box_levels}
         return {"cls_levels": ch.forward_levels(xb, pad_classes), "bbox_levels": rh.forward_levels(xb)}
 
-    def compute_loss_levels(self, targets, outputs: Dict[str, List[Tensor]], anchors) -> Dict[str, Tensor]:
-        return self.losses.forward_levels(targets, outputs["cls_levels"], outputs["bbox_levels"], anchors)
+    def compute_loss_levels(self, targets, outputs: Dict[str, List[Tensor]], anchors, ahead=None) -> Dict[str, Tensor]:
+        return self.losses.forward_levels(targets, outputs["cls_levels"], outputs["bbox_levels"], anchors, ahead=ahead)

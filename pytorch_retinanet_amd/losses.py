@@ -7,7 +7,7 @@ writes the gradients in the same pass that computes the loss values, so
 ``backward`` only has to apply the upstream scalar (a device-side no-op when it
 is 1, the ``loss.backward()`` case).
 """
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -47,17 +47,37 @@ class _FusedDenseHeadLoss(torch.autograd.Function):
         return gcls.view(ctx.cls_shape), gbox.view(ctx.box_shape), None, None, None, None, None, None, None
 
 
+class MatchAhead:
+    """K2's results, launched ahead of the head convolutions on a side stream (``RetinaNetLosses.match_ahead``): the matcher needs
+    only the anchors and the GT boxes, so it does not have to sit on the critical path between the class-output conv and K3."""
+    __slots__ = ("gt_boxes", "gt_labels", "gt_off", "matches", "num_fg", "special", "done", "anchors")
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
+    s = _SIDE_STREAMS.get(dev.index)
+    if s is None:
+        s = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+    return s
+
+
 class _FusedDenseHeadLossLevels(torch.autograd.Function):
     """Per-level head outputs (cls_0..cls_{L-1}, box_0..box_{L-1}) -> f32[2]; no concatenation."""
 
     @staticmethod
-    def forward(ctx, anchors, gt_boxes, gt_labels, gt_off, params, fg_thr, bg_thr, L, *levels):
+    def forward(ctx, anchors, gt_boxes, gt_labels, gt_off, params, fg_thr, bg_thr, L, ahead, *levels):
         cls_levels, box_levels = levels[:L], levels[L:]
         B = cls_levels[0].shape[0]
-        matches, num_fg = ops.iou_match(anchors, gt_boxes, gt_off, B, fg_thr, bg_thr)
-        want_grad = any(ctx.needs_input_grad[8:])
+        if ahead is not None:
+            torch.cuda.current_stream(cls_levels[0].device).wait_event(ahead.done)        # K2 ran beside the head convolutions
+            matches, num_fg, special = ahead.matches, ahead.num_fg, ahead.special
+        else:
+            matches, num_fg, special = ops.iou_match(anchors, gt_boxes, gt_off, B, fg_thr, bg_thr, want_special=True)
+        want_grad = any(ctx.needs_input_grad[9:])
         loss, gcls, gbox = ops.loss_fwd_bwd_levels(cls_levels, box_levels, anchors, gt_boxes, gt_labels, gt_off, matches,
-                                                   num_fg, params, want_grad)
+                                                   num_fg, params, want_grad, special=special)
         ctx.grads = (gcls, gbox)
         ctx.meta = [(c.shape, c.dtype) for c in cls_levels] + [(b.shape, b.dtype) for b in box_levels]
         # two scalar outputs (views of the kernel's f32[2]): backward then receives the two upstream scalars directly, without
@@ -76,7 +96,7 @@ class _FusedDenseHeadLossLevels(torch.autograd.Function):
         g1 = torch.zeros((1,), device=dev) if g1 is None else g1.reshape(1)
         ops.scale_inplace_batched(list(gcls) + list(gbox), [g0] * len(gcls) + [g1] * len(gbox))      # one launch
         outs = [t.view(shape) if t.dtype == dt else t.to(dt).view(shape) for t, (shape, dt) in zip(list(gcls) + list(gbox), ctx.meta)]
-        return (None,) * 8 + tuple(outs)
+        return (None,) * 9 + tuple(outs)
 
 
 def _stack_anchors(anchors) -> Tensor:
@@ -131,18 +151,48 @@ class RetinaNetLosses(nn.Module):
         return _FusedDenseHeadLoss.apply(cls, box, _stack_anchors(anchors), gt_boxes, gt_labels, gt_off,
                                          self._params(), IOU_THRESHOLDS_FOREGROUND, IOU_THRESHOLDS_BACKGROUND)
 
-    def forward_levels(self, targets: List[Dict[str, Tensor]], cls_levels: Sequence[Tensor], box_levels: Sequence[Tensor],
-                       anchors) -> Dict[str, Tensor]:
-        """Same result as ``forward`` on ``torch.cat(levels, dim=1)``, without materialising the cat
-        (the loss kernel reads the per-level conv outputs where they are)."""
-        dev = cls_levels[0].device
+    @staticmethod
+    def _gt_arrays(targets, dev):
         boxes, labels = [t["boxes"] for t in targets], [t["labels"] for t in targets]
         counts = [int(b.reshape(-1, 4).shape[0]) for b in boxes]
         gt_boxes = torch.cat([b.reshape(-1, 4).to(device=dev, dtype=torch.float32) for b in boxes])
         gt_labels = torch.cat([l.reshape(-1).to(device=dev, dtype=torch.int64) for l in labels])
-        gt_off = ops.gt_offsets(counts, dev)
-        out = _FusedDenseHeadLossLevels.apply(_stack_anchors(anchors), gt_boxes, gt_labels, gt_off, self._params(),
-                                              IOU_THRESHOLDS_FOREGROUND, IOU_THRESHOLDS_BACKGROUND, len(cls_levels),
+        return gt_boxes, gt_labels, ops.gt_offsets(counts, dev)
+
+    def match_ahead(self, targets: List[Dict[str, Tensor]], anchors) -> MatchAhead:
+        """Launch K2 (IoU + matcher, box_utils.py:51-80) NOW, on a side stream: it depends only on the anchors and the GT boxes,
+        both known as soon as the feature-map shapes are, and then runs beside the head convolutions instead of between the
+        class-output conv and K3.  Pass the result to ``forward_levels(..., ahead=...)``, which makes the loss kernel wait
+        for it.  The outputs belong to the CALLING stream (allocated before the fork, consumed after the join)."""
+        anchors = _stack_anchors(anchors)
+        dev = anchors.device
+        h = MatchAhead()
+        h.anchors = anchors
+        h.gt_boxes, h.gt_labels, h.gt_off = self._gt_arrays(targets, dev)
+        B = len(targets)
+        h.matches, h.num_fg, h.special = ops.iou_match_outputs(B, int(anchors.shape[-2]), dev)
+        main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ops.iou_match(anchors, h.gt_boxes, h.gt_off, B, IOU_THRESHOLDS_FOREGROUND, IOU_THRESHOLDS_BACKGROUND,
+                          out=(h.matches, h.num_fg, h.special))
+            h.done = torch.cuda.Event()
+            h.done.record(side)
+        return h
+
+    def forward_levels(self, targets: List[Dict[str, Tensor]], cls_levels: Sequence[Tensor], box_levels: Sequence[Tensor],
+                       anchors, ahead: Optional[MatchAhead] = None) -> Dict[str, Tensor]:
+        """Same result as ``forward`` on ``torch.cat(levels, dim=1)``, without materialising the cat
+        (the loss kernel reads the per-level conv outputs where they are).  ``ahead``: ``match_ahead``'s
+        handle for these targets / anchors (K2 already in flight on a side stream)."""
+        dev = cls_levels[0].device
+        if ahead is not None:
+            gt_boxes, gt_labels, gt_off, anchors_t = ahead.gt_boxes, ahead.gt_labels, ahead.gt_off, ahead.anchors
+        else:
+            gt_boxes, gt_labels, gt_off = self._gt_arrays(targets, dev)
+            anchors_t = _stack_anchors(anchors)
+        out = _FusedDenseHeadLossLevels.apply(anchors_t, gt_boxes, gt_labels, gt_off, self._params(),
+                                              IOU_THRESHOLDS_FOREGROUND, IOU_THRESHOLDS_BACKGROUND, len(cls_levels), ahead,
                                               *cls_levels, *box_levels)
         return {"classification_loss": out[0], "regression_loss": out[1]}
 

@@ -129,10 +129,17 @@ class Retinanet(nn.Module):
             batch = batch.contiguous(memory_format=torch.channels_last)        # no-op after the fused transform
         feature_maps = self.fpn(self.backbone(batch))
         anchors = self.anchor_generator(images, feature_maps)
+        # K2 (IoU + matcher) needs only the anchors and the GT boxes: it goes out on a side stream here and runs beside the
+        # head convolutions; K3 waits for it (losses.RetinaNetLosses.match_ahead).  NOT while the step is being captured into a
+        # hipGraph: a graph with a forked branch costs hipGraphLaunch 20 ms of host time per replay on ROCm 7.0 (0.4 ms for
+        # the linear graph of the same step, bench.py host_enqueue_ms_per_step) -- 25 us of GPU time are not worth that.
+        ahead = None
+        if batch.is_cuda and not torch.cuda.is_current_stream_capturing():
+            ahead = self.retinanet_head.losses.match_ahead(targets, anchors)
         # same losses as compute_loss(targets, retinanet_head(feature_maps), anchors), but the loss kernel
         # reads the five per-level conv outputs in place instead of their torch.cat (layers.py:195, :259)
         outputs = self.retinanet_head.forward_levels(feature_maps)
-        return self.retinanet_head.compute_loss_levels(targets, outputs, anchors)
+        return self.retinanet_head.compute_loss_levels(targets, outputs, anchors, ahead=ahead)
 
     # -- inference ---------------------------------------------------------------------------
     def process_detections(self, outputs: Dict[str, Tensor], anchors: List[Tensor],

@@ -150,22 +150,36 @@ def gt_offsets(counts: Sequence[int], device: torch.device) -> Tensor:
 
 
 def iou_match(anchors: Tensor, gt_boxes: Tensor, gt_off: Tensor, B: int, fg_thr: float, bg_thr: float,
-              want_num_fg: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+              want_num_fg: bool = True, want_special: bool = False, out: Optional[tuple] = None):
     """K2.  anchors [A,4] or [B,A,4]; gt_boxes f32 [sum T,4]; gt_off i32 [B+1] (device).
-    -> (matches i64 [B,A], num_fg i32 [B])."""
+    -> (matches i64 [B,A], num_fg i32 [B]) and, with ``want_special``, a third tensor ``special`` i64 [B, ceil(A/64)]:
+    bit (a & 63) of word a >> 6 is set where ``matches[b, a] != -1`` (what ``loss_fwd_bwd_levels(special=...)`` reads instead of
+    streaming ``matches``).  ``out``: pre-allocated (matches, num_fg, special) -- for a caller that launches K2 on a side
+    stream and wants the outputs to belong to its main stream (``losses.RetinaNetLosses.match_ahead``)."""
     dev = _need_dev(anchors, gt_boxes, gt_off)
     A = anchors.shape[-2]
     anchors, bstride = _anchor_args(anchors, B, A)
     gt_boxes = _c(gt_boxes.float()).reshape(-1, 4)
     if not fg_thr > bg_thr:
         raise AssertionError("match_thr must be greater than back_thr")   # box_utils.py:66
-    matches = torch.empty((B, A), dtype=torch.int64, device=dev)
-    num_fg = torch.empty((B,), dtype=torch.int32, device=dev) if want_num_fg else None
+    if out is not None:
+        matches, num_fg, special = out
+    else:
+        matches, num_fg, special = iou_match_outputs(B, A, dev, want_num_fg, want_special)
     with torch.cuda.device(dev), _timed("iou_match", dev):
         # gt_off[B] - gt_off[0] == the row count of gt_boxes (host-known): lets the library pick the batch-shaped kernel
-        check(lib.rn_iou_match_ex(_ptr(anchors), bstride, _ptr(gt_boxes), _ptr(gt_off), B, A, fg_thr, bg_thr,
-                                  _ptr(matches), _ptr(num_fg), int(gt_boxes.shape[0]), _stream(dev)), "rn_iou_match_ex")
-    return matches, num_fg
+        check(lib.rn_iou_match_special(_ptr(anchors), bstride, _ptr(gt_boxes), _ptr(gt_off), B, A, fg_thr, bg_thr,
+                                       _ptr(matches), _ptr(num_fg), _ptr(special), int(gt_boxes.shape[0]), _stream(dev)),
+              "rn_iou_match_special")
+    return (matches, num_fg, special) if (want_special or out is not None) else (matches, num_fg)
+
+
+def iou_match_outputs(B: int, A: int, dev: torch.device, want_num_fg: bool = True, want_special: bool = True):
+    "Uninitialised output tensors of ``iou_match`` (matches, num_fg, special), allocated on the current stream."
+    matches = torch.empty((B, A), dtype=torch.int64, device=dev)
+    num_fg = torch.empty((B,), dtype=torch.int32, device=dev) if want_num_fg else None
+    special = torch.empty((B, (A + 63) // 64), dtype=torch.int64, device=dev) if want_special else None
+    return matches, num_fg, special
 
 
 def make_loss_params(alpha: float, gamma: float, beta: float, logit_shift: float = 1.0, log_eps: float = 1e-8,
@@ -202,9 +216,10 @@ def loss_fwd_bwd(cls: Tensor, box: Tensor, anchors: Tensor, gt_boxes: Tensor, gt
 
 def loss_fwd_bwd_levels(cls_levels: Sequence[Tensor], box_levels: Sequence[Tensor], anchors: Tensor, gt_boxes: Tensor,
                         gt_labels: Tensor, gt_off: Tensor, matches: Tensor, num_fg: Tensor, params: RnLossParams,
-                        want_grad: bool = True):
+                        want_grad: bool = True, special: Optional[Tensor] = None):
     """K3 on per-level head outputs (no concatenation): cls_levels[l] [B,A_l,K], box_levels[l] [B,A_l,4].
-    -> (loss f32[2], [grad_cls_l], [grad_box_l])."""
+    -> (loss f32[2], [grad_cls_l], [grad_box_l]).  ``special``: the third output of ``iou_match(want_special=True)`` --
+    the kernel then reads ``matches`` only at the rows flagged there instead of streaming all of it."""
     L = len(cls_levels)
     if L == 0 or L > _lib.RN_MAX_LEVELS or len(box_levels) != L:
         raise ValueError("need 1..8 levels of (cls, box) outputs")
@@ -234,12 +249,14 @@ def loss_fwd_bwd_levels(cls_levels: Sequence[Tensor], box_levels: Sequence[Tenso
         k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         k0.record(torch.cuda.current_stream(dev)); k1.record(torch.cuda.current_stream(dev))      # creates the handles
     with torch.cuda.device(dev), _timed("loss_fwd_bwd" if want_grad else "loss_fwd", dev):
-        check(lib.rn_loss_fwd_bwd_levels_timed(arr(cls_levels), arr(box_levels), (C.c_int64 * L)(*counts), L, _dtype_code(cls_levels[0]),
-                                                B, K, _ptr(anchors), bstride, _ptr(gt_boxes), _ptr(gt_labels), _ptr(gt_off),
-                                                _ptr(matches), _ptr(num_fg), C.byref(params), _ptr(out),
-                                                arr(gcls) if want_grad else None, arr(gbox) if want_grad else None,
-                                                _ptr(ws), ws_bytes, _stream(dev), k0.cuda_event if k0 else None,
-                                                k1.cuda_event if k1 else None), "rn_loss_fwd_bwd_levels_timed")
+        if special is not None and (special.dtype != torch.int64 or tuple(special.shape) != (B, (A + 63) // 64) or not special.is_contiguous()):
+            raise ValueError(f"special-row words: expected int64 [{B}, {(A + 63) // 64}], got {special.dtype} {tuple(special.shape)}")
+        check(lib.rn_loss_fwd_bwd_levels_ex(arr(cls_levels), arr(box_levels), (C.c_int64 * L)(*counts), L, _dtype_code(cls_levels[0]),
+                                             B, K, _ptr(anchors), bstride, _ptr(gt_boxes), _ptr(gt_labels), _ptr(gt_off),
+                                             _ptr(matches), _ptr(special), _ptr(num_fg), C.byref(params), _ptr(out),
+                                             arr(gcls) if want_grad else None, arr(gbox) if want_grad else None,
+                                             _ptr(ws), ws_bytes, _stream(dev), k0.cuda_event if k0 else None,
+                                             k1.cuda_event if k1 else None), "rn_loss_fwd_bwd_levels_ex")
     if k0 is not None:
         _TIMERS.setdefault("loss_stream_kernel" if want_grad else "loss_stream_kernel_fwd", []).append((k0, k1))
     return out, gcls, gbox
