@@ -151,10 +151,10 @@ class _Conv1x1Skip(torch.autograd.Function):
         return dx, dw, None
 
 
-FUSE_SKIP_ADD = os.environ.get("RN_FUSE_SKIP_ADD", "1") != "0"
+FUSE_SKIP_ADD = True
 # layer1 / layer2 only (64 / 128 mid channels): 491 us for the five GEMMs against 285 us of MIOpen data gradients + 438 us of adds;
 # layer3 is a tie (5 x 54 us vs 125 + 150), layer4 a loss (2 x 38 vs 24 + 30) -- step timeline, hipBLASLt's stream-K picks
-SKIP_ADD_MAX_MID = int(os.environ.get("RN_SKIP_ADD_MAX_MID", "128"))
+SKIP_ADD_MAX_MID = 128
 
 
 class Bottleneck(nn.Module):

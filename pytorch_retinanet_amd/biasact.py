@@ -25,7 +25,7 @@ from .ops import _timed          # event pairs around the MFMA conv launches whe
 
 _DT = {torch.float32: RN_F32, torch.bfloat16: RN_BF16, torch.float16: RN_F16}
 _WS: Dict[tuple, Tensor] = {}
-PAIR_SHEETS = os.environ.get("RN_CANVAS_SLOTS", "2") != "1"     # two images per canvas sheet (Canvas.of); RN_CANVAS_SLOTS=1: one
+PAIR_SHEETS = True     # two images per canvas sheet (Canvas.of) when that takes fewer positions
 MFMA_FLOP: Dict[str, float] = {}      # USEFUL flop per call of every timed MFMA launch (bench.py: achieved TFLOP/s of the own conv kernels)
 _REAL_PER_SHEET: Dict[tuple, int] = {}  # (Hp, Wp) of a canvas sheet -> feature positions on it (gaps / borders are not useful work)
 
@@ -96,7 +96,7 @@ class _BiasAct(torch.autograd.Function):
 
 
 _WG_WS: Dict[tuple, Tensor] = {}
-MFMA_WGRAD = os.environ.get("RN_MFMA_WGRAD", "1") != "0"      # weight gradient of the canvas convs on the MFMA kernel (0: MIOpen)
+MFMA_WGRAD = True      # weight gradient of the canvas convs on the MFMA kernel (False: MIOpen)
 
 
 def _canvas_wgrad(gs, xs, ws, Wp: int, stream: int):
@@ -198,9 +198,9 @@ class TowerLink:
 
 
 _CS_WS: Dict[tuple, Tensor] = {}
-FUSE_TOWER_RELU_BWD = os.environ.get("RN_FUSE_TOWER_RELU_BWD", "1") != "0"
-BOX_OUTPUT_WGRAD_MFMA = os.environ.get("RN_BOX_OUTPUT_WGRAD", "mfma") != "miopen"   # ... and its weight gradient on the narrow gathering kernel
-BOX_OUTPUT_FWD_MFMA = os.environ.get("RN_BOX_OUTPUT_FWD", "mfma") != "miopen"     # box-output conv forward on the narrow MFMA level-mode kernel
+FUSE_TOWER_RELU_BWD = True
+BOX_OUTPUT_WGRAD_MFMA = True   # ... and its weight gradient on the narrow gathering kernel
+BOX_OUTPUT_FWD_MFMA = True     # box-output conv forward on the narrow MFMA level-mode kernel
 
 
 class _TowerConvPair(torch.autograd.Function):

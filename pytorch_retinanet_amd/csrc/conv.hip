@@ -1103,8 +1103,7 @@ RN_API int rn_conv3x3_canvas_to_levels(const void *x, const void *w, const float
     a.zeros = (const uint16_t *)zeros;
     const unsigned tiles_m = (unsigned)((a.M + CONV_BM - 1) / CONV_BM);
     const int full = Cout / CONV_BN, rest = Cout % CONV_BN;
-    static const bool narrow_ok = [] { const char *e = getenv("RN_CONV_NARROW"); return !e || atoi(e) != 0; }();
-    if (narrow_ok && rest > 0 && rest <= 64) {
+    if (rest > 0 && rest <= 64) {
         // whole 256-column tiles, then the ragged last one (<= 64 columns; the only one of the 36-channel box-output conv) on
         // the NARROW kernel
         if (full > 0) {
@@ -1229,8 +1228,7 @@ RN_API int rn_conv3x3_levels_wgrad(const void *const *gs, const rn_canvas_layout
     a.Wp = Wp; a.HWp = (int64_t)Hp * Wp; a.zeros = (const uint16_t *)zeros;
     // tile-local position and size of the straddling piece's shift (see the kernel): last problem only
     const int tail = row_elems % 8, e_last = row_elems - tail - (P - 1) * 256;
-    static const bool narrow_ok = [] { const char *e = getenv("RN_CONV_NARROW"); return !e || atoi(e) != 0; }();
-    if (narrow_ok && P == 1 && rows[0] <= 64 && (!tail || e_last + 8 <= 64)) {
+    if (P == 1 && rows[0] <= 64 && (!tail || e_last + 8 <= 64)) {
         // a conv with at most 64 output channels (the 36-channel box-output conv) on the NARROW kernel.  (Splitting the ragged last
         // row tile of the 810-channel conv off the same way was measured and is slower -- 0.94 vs 0.91 ms: a K-tile of the
         // gathering kernel costs the same 1.9 us with a quarter of the MFMAs, it is bound by staging, not by the matrix pipe.)

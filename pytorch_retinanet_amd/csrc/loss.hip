@@ -687,9 +687,8 @@ int launch_stream(StreamT stream_k, LossArgs &a, int vec, hipStream_t st, int *n
     {
         // default 1: in the train step the class-output conv has just written the logits, column pass by column pass; the
         // Infinity Cache (256 MiB) still holds the last three passes and the tail rows of the first, and a back-to-front walk
-        // reads exactly those first: 131 -> 117 us on one box (RN_K3_ORDER=0/1 A/B, tools/k3_order_ab.sh); no effect on cold data
-        static const int order = [] { const char *e = getenv("RN_K3_ORDER"); return e ? atoi(e) : 1; }();
-        a.reverse = order;
+        // reads exactly those first: 131 -> 117 us on one box (round-2 A/B of the two orders); no effect on cold data
+        a.reverse = 1;
     }
     (void)vec;
     int64_t need = ((nvec + vpw - 1) / vpw + LOSS_WAVES - 1) / LOSS_WAVES;

@@ -130,11 +130,10 @@ __device__ __forceinline__ RowWalk row_walk(const int order, const int64_t M, co
 }
 
 // Default 2 (in-step A/B on two boxes, 4 pairs: +0.6 ... +1.3 % images/s over order 0, order 1 in between; choosing by tensor
-// size was no better); RN_BN_ORDER=0/1/2 forces one order.
+// size was no better).
 inline int bn_order()
 {
-    static const int order = [] { const char *e = getenv("RN_BN_ORDER"); return e ? atoi(e) : 2; }();
-    return order;
+    return 2;
 }
 
 // ---------------------------------------------------------------- forward statistics
@@ -445,10 +444,8 @@ ReduceGrid reduce_grid(const int64_t M, const int C, const bool wide)
     while (g.row_splits * g.slabs * 2 <= 512 && C8 % (g.slabs * 2) == 0 && C8 / (g.slabs * 2) >= 32) g.slabs *= 2;
     // 512-thread blocks for the backward reduction of residual layers (it reads a byte of ReLU mask per 16 bytes of gradient
     // and wants the extra waves: -28 % at every layer size in the step); 256 everywhere else (512 / 1024: no gain or a loss)
-    static const int forced = [] { const char *e = getenv("RN_BN_RTHREADS"); return e ? atoi(e) : 0; }();
     const int Cs8 = C8 / g.slabs;
     g.threads = wide ? 2 * BN_BLOCK : BN_BLOCK;
-    if (forced >= 64 && forced <= BN_RBLOCK_MAX) g.threads = forced;
     const int lanes = (Cs8 >= g.threads) ? 1 : g.threads / Cs8;
     g.lds = lanes > 1 ? sizeof(float) * (size_t)lanes * 2 * (size_t)Cs8 * 8 : 0;
     return g;

@@ -21,7 +21,7 @@ from . import biasact
 from .losses import RetinaNetLosses
 from .pool import add_upsample2x
 
-FUSE_FPN_UPSAMPLE = os.environ.get("RN_FUSE_FPN_UPSAMPLE", "1") != "0"     # lateral + 2x nearest upsampling in one kernel
+FUSE_FPN_UPSAMPLE = True     # lateral + 2x nearest upsampling in one kernel
 
 
 class FeaturePyramid(nn.Module):
@@ -47,7 +47,7 @@ class FeaturePyramid(nn.Module):
     def _up(self, x: Tensor) -> Tensor:
         # autocast runs nearest upsampling in fp32 and thereby promotes the whole top-down pathway (adds, their
         # backward, the casts in front of the 3x3 convs) to fp32; a 2x nearest upsampling is a copy, so keep the dtype
-        if x.is_cuda and torch.is_autocast_enabled("cuda") and os.environ.get("RN_FPN_FP32_UPSAMPLE", "0") != "1":
+        if x.is_cuda and torch.is_autocast_enabled("cuda"):
             with torch.autocast("cuda", enabled=False):
                 return self.upsample_2x(x)
         return self.upsample_2x(x)
@@ -185,13 +185,13 @@ class RetinaNetHead(nn.Module):
         self.regression_head = RetinaNetBoxSubnet(in_channels, out_channels, num_anchors)
         self.losses = RetinaNetLosses(num_classes)
         # bf16 canvas towers: "pair" = hand-written MFMA conv, cls + box tower batched per layer; "single" = the same kernel,
-        # one launch per conv; "miopen" = MIOpen conv + fused epilogue kernel.  RN_TOWERS overrides (A/B measurements).
+        # one launch per conv; "miopen" = MIOpen conv + fused epilogue kernel.  RN_TOWERS overrides (one of the three documented A/B switches, README).
         mode = os.environ.get("RN_TOWERS", "pair")
         self.mfma_towers = mode != "miopen"
         self.pair_towers = mode == "pair"
         # class-output conv on the hand-written MFMA kernel with dense 9*K-channel output (0: MIOpen on 9*ceil8(K) channels)
-        self.mfma_cls_output = os.environ.get("RN_CLS_OUTPUT", "mfma") != "miopen"
-        self.mfma_box_output = os.environ.get("RN_BOX_OUTPUT", "mfma") != "miopen"      # box-output conv: MFMA data gradient (biasact._BoxOutputConv)
+        self.mfma_cls_output = True          # (False: MIOpen on 9 * ceil8(K) channels with dead classes -- also the automatic path of fp32 / fp16 models)
+        self.mfma_box_output = True      # box-output conv: MFMA data gradient (biasact._BoxOutputConv)
 
     def compute_loss(self, targets: List[Dict[str, Tensor]], outputs: Dict[str, Tensor],
                      anchors: List[Tensor]) -> Dict[str, Tensor]:

@@ -146,8 +146,9 @@ def test_predict_matches_the_reference_fp32(golden):
 @pytest.mark.gpu
 def test_forward_and_predict_bf16_autocast(golden):
     """The headline numeric configuration (bf16 autocast, MFMA towers, fp32 masters): losses within 2e-2 of the fp32
-    reference; detections: the reference's confident boxes are found (IoU >= 0.9, same label) -- bf16 logits move
-    scores near the 0.05 threshold and near-tie NMS decisions, so the fp32 criterion does not apply."""
+    reference; detections: >= 90 % of the reference's confident boxes have a same-label partner at IoU >= 0.9 with a score
+    within 5e-3, median IoU >= 0.97 -- bf16 logits move scores near the 0.05 threshold, the top-100 cut-off and near-tie NMS
+    decisions, so the fp32 criterion (99 % at IoU 0.999) does not apply; the exact check is the oracle test below."""
     g = golden("e2e.npz")
     net = _model(g, DEV).train()
     images, targets = _inputs(g, DEV)
@@ -158,13 +159,53 @@ def test_forward_and_predict_bf16_autocast(golden):
     net = _model(g, DEV).eval()
     with torch.autocast("cuda", dtype=torch.bfloat16):
         dets = net.predict(images)
+    n_top = 0
     for b, d in enumerate(dets):
         ref = {"boxes": g[f"det_boxes{b}"], "scores": g[f"det_scores{b}"], "labels": g[f"det_labels{b}"]}
         got = {k: v.float().cpu().numpy() if v.dtype != torch.int64 else v.cpu().numpy() for k, v in d.items()}
         top = ref["scores"] >= 0.06                                   # clear of the 0.05 threshold
+        n_top += int(top.sum())
         if top.any():
-            ok = (_iou(ref["boxes"][top], got["boxes"]) >= 0.9) & (ref["labels"][top][:, None] == got["labels"][None, :])
+            # the fp32 reference's confident detections are found by the bf16 pipeline.  What bf16 head outputs allow (measured on
+            # this fixture): box deltas carry 8 bits of mantissa, so the median IoU with the fp32 box is 0.98 - 0.99, and 93 - 96 %
+            # of the reference's boxes have a same-label partner at IoU >= 0.9 whose score is within 5e-3 (the rest sit at the
+            # top-100 cut-off of an image with more than 100 candidates, where 1e-3 of score decides membership).  The EXACT
+            # check of this configuration's detection chain is the oracle test below.
+            iou = _iou(ref["boxes"][top], got["boxes"])
+            same = ref["labels"][top][:, None] == got["labels"][None, :]
+            near = np.abs(ref["scores"][top][:, None] - got["scores"][None, :]) <= 5e-3
+            ok = (iou >= 0.9) & same & near
             assert ok.any(1).mean() >= 0.9, (b, ok.any(1).mean())
+            best = np.where(same, iou, 0.0).max(1)
+            assert np.median(best) >= 0.97, (b, np.median(best))
+    assert n_top > 0                                                   # the fixture does have confident detections to find
+
+
+@pytest.mark.gpu
+def test_bf16_head_outputs_through_the_oracle_give_the_models_detections(golden, oracle_lib):
+    """The detection chain (K4-K7) of the headline numeric configuration, exactly: the model's OWN bf16 head outputs (packed
+    canvas, MFMA towers, dense class-output conv) fed to the CPU oracle's process_detections (reference models.py:160-243)
+    must give the labels, boxes and scores ``process_detections_levels`` returns for them -- no tolerance on labels and order."""
+    g = golden("e2e.npz")
+    net = _model(g, DEV).eval()
+    images, _ = _inputs(g, DEV)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        il, _ = net.transform(images, None, **net._batch_layout())
+        fmaps = net.fpn(net.backbone(il.tensors))
+        anchors = net.anchor_generator(il, fmaps)
+        lv = net.retinanet_head.forward_levels(fmaps)
+        assert lv["cls_levels"][0].dtype == torch.bfloat16
+        cls = torch.cat([c.float() for c in lv["cls_levels"]], 1).cpu().numpy()
+        box = torch.cat([b_.float() for b_ in lv["bbox_levels"]], 1).cpu().numpy()
+        dets = net.process_detections_levels(lv, anchors, il.image_sizes)
+    ref = oracle_lib.detect(cls[..., :net.num_classes], box, anchors[0].cpu().numpy(), il.image_sizes)
+    total = 0
+    for got, r in zip(dets, ref):
+        assert np.array_equal(got["labels"].cpu().numpy(), r["labels"])
+        np.testing.assert_allclose(got["boxes"].cpu().numpy(), r["boxes"], rtol=1e-5, atol=1e-3)
+        np.testing.assert_allclose(got["scores"].cpu().numpy(), r["scores"], rtol=0, atol=1e-6)
+        total += len(r["labels"])
+    assert total > 0
 
 
 @pytest.mark.reference

@@ -163,6 +163,59 @@ def test_lightning_module_with_simple_trainer():
     assert len(outs) == 2 and all("detections" in o for o in outs)
 
 
+def test_test_step_through_the_evaluator_equals_bbox_eval_on_the_oracles_detections(oracle_lib):
+    """The evaluation path end to end (reference model.py:132-146: test_step -> CocoEvaluator.update -> test_epoch_end ->
+    accumulate / summarize -> stats[0]) on GPU detections, against ``BBoxEval`` fed the CPU oracle's detections
+    (reference models.py:160-243 restated) for the same head outputs: all 12 COCO statistics agree.  The ground truth is a
+    few of the model's own detections (so the statistics are not all zero) plus boxes it cannot find.  (``BBoxEval`` itself is
+    pinned to the published COCO protocol by hand-derived cases, not to a pycocotools run: tests/test_coco_eval.py.)"""
+    import pytorch_retinanet_amd as P
+    from pytorch_retinanet_amd.coco_eval import BBoxEval, gt_from_dataset, prepare_for_coco_detection
+    conf = P.load_hparams()
+    conf.model.update(backbone_kind="resnet18", pretrained=False, num_classes=5, min_size=128, max_size=160)
+    conf.dataset.kind = "synthetic"
+    conf.dataset.update(length=4, height=128, width=160, boxes_per_image=3)
+    conf.dataloader.test_bs = 2
+    conf.dataloader.args.pin_memory = False
+    torch.manual_seed(21)
+    model = P.RetinaNetModel(conf).to(DEV).eval()
+    with torch.no_grad():                                        # scores around 0.1 .. 0.5 instead of the 0.01 prior: detections exist
+        model.net.retinanet_head.classification_head.class_subnet_output.bias.fill_(-1.0)
+        model.net.retinanet_head.classification_head.class_subnet_output.weight.mul_(30.0)
+    g = torch.Generator().manual_seed(3)
+    images = [torch.rand(3, 128, 160, generator=g) for _ in range(4)]
+    with torch.no_grad():
+        first = model.net.predict([im.to(DEV) for im in images])
+    assert all(len(d["labels"]) >= 6 for d in first)
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self): return 4
+        def __getitem__(self, i):
+            d = first[i]
+            pick = [0, 3, 5]                                     # three of its own detections + one box nothing will match
+            boxes = torch.cat([d["boxes"][pick].cpu(), torch.tensor([[2.0, 2.0, 9.0, 9.0]])])
+            labels = torch.cat([d["labels"][pick].cpu(), torch.tensor([1])])
+            return images[i], {"boxes": boxes, "labels": labels, "image_id": torch.tensor([10 + i])}, 10 + i
+    model.test_ds = DS()
+    res, outs = P.SimpleTrainer(device=DEV, precision="32").test(model)
+    stats = np.asarray(model.test_evaluator.coco_eval["bbox"].stats, dtype=np.float64)
+    assert stats.shape == (12,) and float(res["AP"]) == pytest.approx(stats[0])
+    # the oracle's detections for the same head outputs
+    rows = []
+    with torch.no_grad():
+        for lo in (0, 2):
+            ims = [im.to(DEV) for im in images[lo:lo + 2]]
+            il, _ = model.net.transform(ims, None)
+            fm, out = model.net._features(il.tensors)
+            anchors = model.net.anchor_generator(il, fm)[0].cpu().numpy()
+            ref = oracle_lib.detect(out["cls_preds"].float().cpu().numpy(), out["bbox_preds"].float().cpu().numpy(), anchors, il.image_sizes)
+            rows += prepare_for_coco_detection({10 + lo + j: {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in r.items()}
+                                                for j, r in enumerate(ref)})
+    want = BBoxEval(gt_from_dataset(model.test_ds), rows).evaluate().summarize(verbose=False)
+    np.testing.assert_allclose(stats, np.asarray(want, dtype=np.float64), rtol=0, atol=2e-3)
+    assert 0.0 < stats[0] < 1.0 and stats[8] > 0.0              # a real precision / recall curve, not a degenerate one
+
+
 def test_per_level_loss_equals_concatenated(golden):
     """rn_loss_fwd_bwd_levels (head outputs left per pyramid level) == rn_loss_fwd_bwd on their concatenation:
     values and gradients bit-identical per element, incl. ragged level sizes and an image without GT."""
