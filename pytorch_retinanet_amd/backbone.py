@@ -78,7 +78,7 @@ def conv_bn(conv: nn.Conv2d, bn: FusedBatchNorm2d, x: Tensor, relu: bool = False
         if residual is not None:
             y = y + residual
         return F.relu(y) if relu else y
-    return bn(conv(x), relu=relu, residual=residual)
+    return bn(pwconv.conv1x1(conv, x), relu=relu, residual=residual)
 
 
 def _conv3x3(cin: int, cout: int, stride: int = 1) -> nn.Conv2d:

@@ -62,9 +62,10 @@ class FeaturePyramid(nn.Module):
 
     def forward(self, inps: List[Tensor]) -> List[Tensor]:
         c3, c4, c5 = inps
-        p5 = self.conv_c5_1x1(c5)
-        p4 = self._lateral_plus_up(self.conv_c4_1x1(c4), p5)
-        p3 = self._lateral_plus_up(self.conv_c3_1x1(c3), p4)
+        from .pwconv import conv1x1            # laterals: 1x1 GEMMs on the fastest of MIOpen / hipBLASLt / csrc/pw.hip per product
+        p5 = conv1x1(self.conv_c5_1x1, c5)
+        p4 = self._lateral_plus_up(conv1x1(self.conv_c4_1x1, c4), p5)
+        p3 = self._lateral_plus_up(conv1x1(self.conv_c3_1x1, c3), p4)
         p6 = self.conv_c6_3x3(c5)
         p7 = self.conv_c7_3x3(F.relu(p6))
         return [self.conv_c3_3x3(p3), self.conv_c4_3x3(p4), self.conv_c5_3x3(p5), p6, p7]

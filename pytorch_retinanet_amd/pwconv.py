@@ -304,3 +304,70 @@ def bottleneck(blk, x: Tensor) -> Tensor:
                                blk.conv3.weight, blk.bn3.weight, blk.bn3.bias,
                                dn[0].weight if dn is not None else None, dn[1].weight if dn is not None else None,
                                dn[1].bias if dn is not None else None)
+
+
+# ---- 1x1 convolutions outside the fused blocks (layer3 / layer4, downsample branches, FPN laterals): the fastest of three ----------
+# For a 1x1 / stride-1 convolution on channels-last activations all three products are plain GEMMs on the [M, C] views.  Measured
+# on MI355X at the R50 shapes (tools: scratch probe of round 3, isolated, bf16): hipBLASLt beats MIOpen's convolution kernels for
+# the forward product when the contraction is >= 1024 channels (l3.conv1 24 vs 35 us, l4.conv1 24 vs 41) and for the data
+# gradient whenever the convolution is wide (l3.conv3 25 vs 50, l4.conv3 26 vs 61, l3.conv1 44 vs 59) -- MIOpen launches 132
+# tiles of 256 x 256 on 256 CUs there --; for the weight gradient hipBLASLt is 2 - 5 x slower than MIOpen (k-strided operands),
+# and the position-contraction kernel of csrc/pw.hip is the fastest (37 - 43 us against 49 - 52 + the zero / cast helpers).
+MM_1X1 = os.environ.get("RN_MM_1X1", "1") != "0"
+
+
+def _fwd_by_mm(M: int, cin: int, cout: int) -> bool:
+    return cin >= 1024 and M <= 40000
+
+
+def _dgrad_by_mm(M: int, cin: int, cout: int) -> bool:
+    return cout >= 1024 or (cin >= 512 and not (M < 10000 and cout <= 256))
+
+
+class _Conv1x1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        Nimg, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        M = Nimg * H * W
+        if _fwd_by_mm(M, Cin, Cout):
+            x2, w2 = x.permute(0, 2, 3, 1).reshape(M, Cin), w.reshape(Cout, Cin)
+            y2 = torch.addmm(bias.to(x.dtype), x2, w2.t()) if bias is not None else x2 @ w2.t()
+            y = y2.view(Nimg, H, W, Cout).permute(0, 3, 1, 2)
+        else:
+            y = F.conv2d(x, w, bias.to(x.dtype) if bias is not None else None)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        Nimg, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        M = Nimg * H * W
+        if g.dtype != x.dtype or not _cl(g):
+            g = g.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        dx = dw = db = None
+        g2 = g.permute(0, 2, 3, 1).reshape(M, Cout)
+        if ctx.needs_input_grad[0]:
+            if _dgrad_by_mm(M, Cin, Cout):
+                dx = (g2 @ w.reshape(Cout, Cin)).view(Nimg, H, W, Cin).permute(0, 3, 1, 2)
+            else:
+                dx = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            dw = pw_wgrad(g, x, w, tag="pw_1x1_wgrad")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = g2.sum(0, dtype=torch.float32)
+        return dx, dw, db
+
+
+def conv1x1(conv, x: Tensor) -> Tensor:
+    """``conv(x)`` for a 1x1 / stride-1 ``nn.Conv2d`` on bf16 channels-last activations with every product on the fastest of
+    MIOpen / hipBLASLt / csrc/pw.hip (``_Conv1x1``); anything else is ``conv(x)``."""
+    w = conv.weight
+    if (MM_1X1 and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and _cl(x) and conv.kernel_size == (1, 1)
+            and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and conv.in_channels % 64 == 0
+            and conv.out_channels % 64 == 0 and torch.is_grad_enabled() and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 24)):
+        return _Conv1x1.apply(x, w, conv.bias)
+    return conv(x)
