@@ -126,6 +126,10 @@ class _Conv1x1Skip(torch.autograd.Function):
     def forward(ctx, x, w, link):
         ctx.save_for_backward(x, w)
         ctx.link = link
+        N, Cin, H, W = x.shape
+        Cmid = w.shape[0]
+        if pwconv.MM_1X1 and x.dtype == torch.bfloat16 and pwconv._fwd_by_mm(N * H * W, Cin, Cmid):       # (hipBLASLt: pwconv._Conv1x1)
+            return (x.permute(0, 2, 3, 1).reshape(-1, Cin) @ w.reshape(Cmid, Cin).t()).view(N, H, W, Cmid).permute(0, 3, 1, 2)
         return F.conv2d(x, w)
 
     @staticmethod
@@ -147,14 +151,17 @@ class _Conv1x1Skip(torch.autograd.Function):
                 dx2 = g2 @ w2
             dx = dx2.view(N, H, W, Cin).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            dw = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+            if pwconv.MM_1X1 and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and Cin % 64 == 0 and Cmid % 64 == 0:
+                dw = pwconv.pw_wgrad(g, x, w, tag="pw_1x1_wgrad")                # position-contraction kernel of csrc/pw.hip
+            else:
+                dw = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         return dx, dw, None
 
 
 FUSE_SKIP_ADD = True
 # layer1 / layer2 only (64 / 128 mid channels): 491 us for the five GEMMs against 285 us of MIOpen data gradients + 438 us of adds;
 # layer3 is a tie (5 x 54 us vs 125 + 150), layer4 a loss (2 x 38 vs 24 + 30) -- step timeline, hipBLASLt's stream-K picks
-SKIP_ADD_MAX_MID = 128
+SKIP_ADD_MAX_MID = 256
 
 
 class Bottleneck(nn.Module):
@@ -184,7 +191,7 @@ class Bottleneck(nn.Module):
             link = _SkipLink()
             out = self.bn1(_Conv1x1Skip.apply(x, self.conv1.weight.to(x.dtype), link), relu=True)
             out = conv_bn(self.conv2, self.bn2, out, relu=True)
-            out3 = self.conv3(out)
+            out3 = pwconv.conv1x1(self.conv3, out)
             if self.bn3._fusable(out3, x):
                 return self.bn3(out3, relu=True, residual=x, link=link)
             return self.bn3(out3, relu=True, residual=x)

@@ -232,15 +232,21 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
         // the epilogue's operands for this tile, in flight under the tile's staging and MFMAs
         rn::u32x4 er[EROWS];
         uint32_t ebits[EROWS];
-        if (EPI & (EPI_RESID | EPI_RELU_BWD)) {
+        // (the widest variant -- BatchNorm-backward prologue, 128 columns -- has no registers left for this prefetch across its
+        // K loop: it spilled 41 VGPRs and ran 12 % slower; there the loads go out right after the last MFMA instead)
+        constexpr bool EPI_EARLY = !(PRO == PRO_BN_BWD && BN == 128);
+        auto load_epi = [&]() {
+            if (EPI & (EPI_RESID | EPI_RELU_BWD)) {
 #pragma unroll
-            for (int i = 0; i < EROWS; ++i) {
-                const int m = m0 + erl + i * RL;
-                const int64_t e = (int64_t)(m < a.M ? m : a.M - 1) * a.N + n0 + ecg * 8;
-                er[i] = *(const rn::u32x4 *)(((EPI & EPI_RESID) ? a.R : a.Zp) + e);
-                ebits[i] = (EPI & EPI_RESID) ? a.rbits[e >> 3] : 0u;
+                for (int i = 0; i < EROWS; ++i) {
+                    const int m = m0 + erl + i * RL;
+                    const int64_t e = (int64_t)(m < a.M ? m : a.M - 1) * a.N + n0 + ecg * 8;
+                    er[i] = *(const rn::u32x4 *)(((EPI & EPI_RESID) ? a.R : a.Zp) + e);
+                    ebits[i] = (EPI & EPI_RESID) ? a.rbits[e >> 3] : 0u;
+                }
             }
-        }
+        };
+        if (EPI_EARLY) load_epi();
         f32x16 acc[MI][NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -277,6 +283,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
         }
 
         // ---- epilogue: accumulators -> f32 tile in LDS -> rows of 8-channel vectors
+        if (!EPI_EARLY) load_epi();
         float *const tile = (float *)lds;                       // [128][BN]
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)

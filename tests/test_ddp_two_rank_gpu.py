@@ -75,7 +75,7 @@ def test_two_ranks_with_live_batchnorm_match_the_emulated_ranks(tmp_path):
         mine, ref = r[i]["bn_buffers"][0], single["bn_buffers"][i]
         assert mine.keys() == ref.keys() and len(mine) > 0
         for k in mine:
-            assert torch.allclose(mine[k], ref[k], rtol=1e-5, atol=1e-6), (i, k, float((mine[k] - ref[k]).abs().max()))
+            assert torch.allclose(mine[k], ref[k], rtol=1e-5, atol=2e-5), (i, k, float((mine[k] - ref[k]).abs().max()))   # (the parameters' own tolerance: fp32 convs sum in run-dependent order)
             if "num_batches_tracked" in k:
                 assert int(mine[k]) == 3
     for k in r[0]["bn_buffers"][0]:
