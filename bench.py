@@ -326,11 +326,11 @@ def main():
         streamed = k3_bytes(args.batch, A, K_run, args.gt, s)
         k3_ms = kms.get("loss_stream_kernel")             # events recorded by the library right around the streaming kernel
         traffic, traffic_source = None, None
-        pmc = os.path.join(ROOT, "profiles", "r02_k3_pmc.json")
+        pmc = os.path.join(ROOT, "profiles", "r03_k3_pmc.json")
         if os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                traffic_source = "profiles/r02_k3_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)"
+                traffic_source = "profiles/r03_k3_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)"
             except Exception:          # noqa: BLE001
                 traffic = None
         roof = {"bound": "hbm", "kernel": "loss_stream_kernel<bf16> (K3 focal + smooth-L1 loss, forward + gradients; HIP events right around the kernel)",

@@ -87,9 +87,10 @@ def bench_k3(reps, dtype, B=8, want_grad=True, T=8):
     g = torch.Generator(device=DEV).manual_seed(0)
     cls = (torch.randn((B, A, K), device=DEV, generator=g) - 4.6).to(dtype)
     box = (torch.randn((B, A, 4), device=DEV, generator=g) * 0.1).to(dtype)
-    m, nfg = ops.iou_match(anc, gt, off, B, 0.5, 0.4)
+    m, nfg, sp = ops.iou_match(anc, gt, off, B, 0.5, 0.4, want_special=True)
     p = ops.make_loss_params(0.25, 2.0, 0.1)
-    ms = timeit(lambda: ops.loss_fwd_bwd(cls, box, anc, gt, gl, off, m, nfg, p, want_grad), reps)
+    # (the model's path: special-row words from K2, `matches` read only at flagged rows)
+    ms = timeit(lambda: ops.loss_fwd_bwd_levels([cls], [box], anc, gt, gl, off, m, nfg, p, want_grad, special=sp), reps)
     s = cls.element_size()
     nbytes = B * ((2 if want_grad else 1) * (A * K * s + A * 4 * s) + A * 8 + T * 24)
     report(f"K3 loss_{'fwd_bwd' if want_grad else 'fwd'} {str(dtype).split('.')[-1]} B={B} A={A} K={K} T={T}", ms, nbytes,

@@ -1,16 +1,16 @@
 #!/bin/bash
 # rocprofv3 summaries of the headline bench for profiles/: kernel-trace stats, then separate PMC passes
 # for the K3 kernel (FETCH_SIZE / WRITE_SIZE cannot share a pass; MI355X_MICROARCH.md, HBM section).
-tag=${1:-r02}
+tag=${1:-r03}
 out=$GRAFT_REPO_ROOT/gpurun_out/profile_$tag
 mkdir -p $out; rm -f $out/k3_pmc.txt
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/bench_kernel_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -- python bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-detect --timing-steps 2 > $out/bench_kernel_trace.log 2>&1
 cp /tmp/pb/*/*kernel_stats.csv $out/bench_kernel_stats.csv
-python tools/steady_stats.py /tmp/pb/*/*kernel_trace.csv $out/bench_kernel_stats_steady.csv 3 | tee $out/steady_summary.txt
+python tools/steady_stats.py /tmp/pb/*/*kernel_trace.csv $out/bench_kernel_stats_steady.csv 4 | tee $out/steady_summary.txt
 grep "^{\"metric" $out/bench_kernel_trace.log | tail -1 > $out/bench_line_under_rocprof.json
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rm -f $out/k3_pmc.txt.tmp; rm -rf /tmp/pc; rocprofv3 --pmc $ctr --output-format csv -d /tmp/pc -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline > /tmp/pc.log 2>&1
+  rm -f $out/k3_pmc.txt.tmp; rm -rf /tmp/pc; rocprofv3 --pmc $ctr --output-format csv -d /tmp/pc -- python bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-detect --timing-steps 1 > /tmp/pc.log 2>&1
   python - $ctr >> $out/k3_pmc.txt <<PY
 import csv,glob,sys
 vals=[]
@@ -39,6 +39,6 @@ json.dump({"kernel": "loss_stream_kernel<bf16,gamma2,grad> (per-level rn_loss_fw
            "hbm_bytes_per_launch": int(round((2 * f + w) * 1024)),
            "algorithmic_bytes_per_launch": line["roofline"]["algorithmic_bytes_per_launch"],
            "kernel_avg_us_rocprof": avg,
-           "source": "tools/profile_bench.sh (rocprofv3 --pmc, separate passes), bench.py --steps 3"}, open(out + "/k3_pmc.json", "w"), indent=1)
+           "source": "tools/profile_bench.sh (rocprofv3 --pmc, separate passes), bench.py --steps 3 --warmup 3 --no-detect (hipGraph replays + 1 eager step)"}, open(out + "/k3_pmc.json", "w"), indent=1)
 print(open(out + "/k3_pmc.json").read())
 PY

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel-trace summary of the dense-head microbenchmarks (K2 at T=8 and T=500, K3 bf16/f32, the
 # inference chain at the cfg-4 shape) -> gpurun_out/profile_r01/kernels_*; copy into profiles/.
-tag=${1:-r02}; shift
+tag=${1:-r03}; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/profile_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
