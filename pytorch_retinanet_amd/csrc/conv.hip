@@ -176,18 +176,13 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     const int n0 = blockIdx.y * CONV_BN + args.n_base;
     const int cpt = args.Cin / CONV_BK, KT = 9 * cpt;
     constexpr int TILE = CONV_BM * CONV_BK * 2;
-    // BAND (canvas / to-levels modes): the activation operand of the three horizontal taps of a kernel row is ONE band of
-    // 256 + 2 consecutive canvas positions (the tile's rows shifted by -1 / 0 / +1), staged once per (channel chunk, kernel row)
-    // and read three times with the fragment rows shifted by the tap -- activation LDS-DMA traffic 9 -> 3 per channel chunk.
-    // 2 band stages + 2 weight stages.  Measured (round 3, tower pair in the step): 418 -> 405 us forward, 402 -> 389 us data
-    // gradient: -3 %, not the -30 % a staging-bandwidth-bound tile would give.  Ablations on the same kernel (no weight DMA
-    // -11 %, no band DMA -14 %, neither -28 %: 1 230 TFLOP/s) say the fragment-read / MFMA / barrier cadence itself runs at
-    // ~62 % of the matrix pipe at the clock the chip holds; what the DMAs cost is their ISSUE slots in the load phases
-    // (6 instead of 8 per K-tile now) and the weight tile's half-K-tile prefetch distance (a third weight stage does not fit:
-    // 2 x 33 KiB + 3 x 32 KiB = 160.5 KiB).
-    constexpr bool BAND = MODE != MODE_FROM_LEVELS;
-    constexpr int BAND_ROWS = CONV_BM + 2, BAND_BYTES = (CONV_BM + 8) * 128;      // 33 KiB per stage (rows 258 .. 263 unused)
-    unsigned char *const Abase = lds, *const Bbase = lds + (BAND ? 2 * BAND_BYTES : 3 * TILE);
+    // (Round 3 also built a BAND variant for the canvas / to-levels modes: one band of 256 + 2 positions per (channel chunk,
+    // kernel row) staged once and read by the three horizontal taps with shifted fragment rows -- activation LDS-DMA traffic
+    // 9 -> 3 per chunk.  Correct, and -3 % with the 32 x 32 x 16 instruction; +9 % slower than this loop with 16 x 16 x 32 (its
+    // full vmcnt(0) drain at every band's last tap costs more when the matrix instruction leaves the partner wave half the
+    // issue slots).  Ablations on it: no weight DMA -11 %, no band DMA -14 %, neither -28 % -- the tile is bound by the
+    // fragment-read / MFMA / barrier cadence and the DMA ISSUE slots, not by staging bandwidth.  Removed; see git history.)
+    unsigned char *const Abase = lds, *const Bbase = lds + 3 * TILE;
     // K walk.  CANVAS / TO_LEVELS: chunk outer, tap inner (a tile's input lines stay in L2 across its taps).
     // FROM_LEVELS: tap outer, chunk inner -- the gathered row pointers of a tap are computed once per 13 K-tiles.
     // The walk is kept as (tap, chunk, stage) counters -- no division in the loop.
@@ -196,28 +191,31 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
         else { if (++w.tap == 9) { w.tap = 0; ++w.chunk; } }
     };
 
-    f32x16 acc[MI][2];
+    // Matrix instruction: v_mfma_f32_16x16x32_bf16 (round 3; 32x32x16 before).  Same flop per cycle, same LDS image, same
+    // number of fragment reads (12 ds_read_b128 per phase: 8 row tiles + 4 column tiles of one 32-deep k-step instead of
+    // 2 x (4 + 2) of two 16-deep ones) -- but under load the chip holds a higher clock on this shape (MI355X_MICROARCH.md, DVFS
+    // give-back item 7: +12 .. 15 % FLOP/s at equal cycles on random data).
+    constexpr int MT = 2 * MI, NT = 4;                            // 16 x 16 accumulator tiles per wave: rows x columns
+    typedef __attribute__((ext_vector_type(4))) float f32x4v;
+    f32x4v acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0f;
 
     // fragment addresses: rows 32 apart share their swizzle ((row >> 1) & 7), so fragment mi / ni of a k-step is the
     // first one plus mi * 4096 bytes -- an immediate offset of the ds_read, not a register
-    uint32_t a_off[4], b_off[4];
-    uint32_t a_band[3][4];                                        // BAND: fragment addresses per horizontal tap (band row = tile row + dx)
+    // (rows 16 apart share their swizzle ((row >> 1) & 7): tile mi / ni of a k-step is the first one plus mi * 2048 bytes, an
+    // immediate offset of the ds_read.  Lane l reads row (l & 15), 16-byte chunk 4 s + (l >> 4) of k-step s: the 16 lanes of a
+    // ds_read_b128 group land on 64 distinct banks with this swizzle, as the 32-row fragments did.)
+    uint32_t a_off[2], b_off[2];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        const int chunk = kk * 2 + (lane >> 5);
-        { const int row = wm * (32 * MI) + (lane & 31); a_off[kk] = row * 128 + ((chunk ^ SWZ(row)) << 4); }
-        { const int row = wn * 64 + (lane & 31); b_off[kk] = row * 128 + ((chunk ^ SWZ(row)) << 4); }
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            const int row = wm * (32 * MI) + (lane & 31) + dx;   // (+ 32 rows per mi: same swizzle, an immediate offset)
-            a_band[dx][kk] = row * 128 + ((chunk ^ SWZ(row)) << 4);
-        }
+    for (int ks = 0; ks < 2; ++ks) {
+        const int chunk = ks * 4 + (lane >> 4);
+        { const int row = wm * (32 * MI) + (lane & 15); a_off[ks] = row * 128 + ((chunk ^ SWZ(row)) << 4); }
+        { const int row = wn * 64 + (lane & 15); b_off[ks] = row * 128 + ((chunk ^ SWZ(row)) << 4); }
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
 
@@ -306,181 +304,88 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
             __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
         }
     };
-    // BAND staging.  Band b = (channel chunk b / 3, kernel row b % 3); band row j <-> canvas position m0 + (dy - 1) * Wp - 1 + j.
-    // part 0 / 1: two of the four 64-row pieces of rows 1 .. 256 (each wave 8 rows per piece); part 2: the two halo rows 0 and 257
-    // (8 lanes each; every wave issues them, to identical addresses, so that all waves count the same number of DMAs).
-    uint32_t voff_band[4], voff_halo[2];                          // per-thread byte offsets of the band pieces from the band's first position
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int j = 1 + i * 64 + wave * 8 + (lane >> 3), cp = lane & 7;
-        voff_band[i] = (uint32_t)(j * args.Cin + ((cp ^ SWZ(j)) << 3)) * 2u;
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int j = h ? BAND_ROWS - 1 : 0, cp = lane & 7;
-        voff_halo[h] = (uint32_t)(j * args.Cin + ((cp ^ SWZ(j)) << 3)) * 2u;
-    }
-    auto band_part = [&](const int b, const int part) {
-        const int chunk_c = b / 3, dy = b - chunk_c * 3;
-        const int c0 = chunk_c * CONV_BK;
-        const int64_t p0 = m0 + (int64_t)(dy - 1) * args.Wp - 1;            // position of band row 0 (wave-uniform)
-        unsigned char *const sb = Abase + (b & 1) * BAND_BYTES;
-        const unsigned char *const base = (const unsigned char *)a.X + (p0 * args.Cin + c0) * 2;     // (never dereferenced when a_edge)
-        if (part < 2) {
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
-                const int i = part * 2 + ii;
-                unsigned char *const dst = sb + 128 + i * 8192 + wave * 1024;
-                if (!a_edge) {
-                    __builtin_amdgcn_global_load_lds((const void *)(base + voff_band[i]), (lds_void_ptr)dst, 16, 0, 0);
-                } else {
-                    const int j = 1 + i * 64 + wave * 8 + (lane >> 3), cp = lane & 7;
-                    int64_t m = p0 + j;
-                    m = m < 0 ? 0 : (m >= args.M ? args.M - 1 : m);
-                    const uint16_t *g = a.X + m * args.Cin + c0 + ((cp ^ SWZ(j)) << 3);
-                    __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)dst, 16, 0, 0);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int j = h ? BAND_ROWS - 1 : 0, cp = lane & 7;
-                const void *g = base + voff_halo[h];
-                if (a_edge) {
-                    int64_t m = p0 + j;
-                    m = m < 0 ? 0 : (m >= args.M ? args.M - 1 : m);
-                    g = a.X + m * args.Cin + c0 + ((cp ^ SWZ(j)) << 3);
-                }
-                if (lane < 8) __builtin_amdgcn_global_load_lds(g, (lds_void_ptr)(sb + j * 128), 16, 0, 0);
-            }
-        }
-    };
-    bf16x8 fa[2][MI], fb[2][2];
+    bf16x8 fa[MT], fb[NT];
 #define RN_DS_READ(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
-#define RN_LOAD_FRAGS_AT(AA, KK, SET)                                              \
-    { const uint32_t ba = bbase + b_off[KK], aa = (AA);                            \
-      RN_DS_READ(fb[SET][0], ba, 0); RN_DS_READ(fb[SET][1], ba, 4096);             \
-      RN_DS_READ(fa[SET][0], aa, 0);                                               \
-      if (MI == 4) { RN_DS_READ(fa[SET][MI - 3], aa, 4096); RN_DS_READ(fa[SET][MI - 2], aa, 8192); RN_DS_READ(fa[SET][MI - 1], aa, 12288); } }
-#define RN_LOAD_FRAGS(KK, SET) RN_LOAD_FRAGS_AT(abase + a_off[KK], KK, SET)
-#define RN_MFMA8(SET)                                                              \
-    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                              \
-        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                           \
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][mi], fb[SET][ni], acc[mi][ni], 0, 0, 0);
+#define RN_LOAD_FRAGS_AT(AA, KS)                                                   \
+    { const uint32_t ba = bbase + b_off[KS], aa = (AA);                            \
+      RN_DS_READ(fb[0], ba, 0); RN_DS_READ(fb[1], ba, 2048); RN_DS_READ(fb[2], ba, 4096); RN_DS_READ(fb[3], ba, 6144); \
+      RN_DS_READ(fa[0], aa, 0); RN_DS_READ(fa[1], aa, 2048);                        \
+      if (MT == 8) { RN_DS_READ(fa[MT - 6], aa, 4096); RN_DS_READ(fa[MT - 5], aa, 6144); RN_DS_READ(fa[MT - 4], aa, 8192);   \
+                     RN_DS_READ(fa[MT - 3], aa, 10240); RN_DS_READ(fa[MT - 2], aa, 12288); RN_DS_READ(fa[MT - 1], aa, 14336); } }
+#define RN_LOAD_FRAGS(KS) RN_LOAD_FRAGS_AT(abase + a_off[KS], KS)
+#define RN_MFMA_ALL()                                                              \
+    _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                              \
+        _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)                          \
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
 #define RN_MFMA_PHASE()                                                            \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);          \
     __builtin_amdgcn_s_setprio(1);                                                 \
-    RN_MFMA8(0) RN_MFMA8(1)                                                        \
+    RN_MFMA_ALL()                                                                  \
     __builtin_amdgcn_s_setprio(0);                                                 \
     __builtin_amdgcn_sched_barrier(0);                                             \
     __builtin_amdgcn_s_barrier();
 
-    if constexpr (BAND) {
-        Walk wb = {0, 0};                                           // K-tile whose weight pieces are issued next
-        auto advance_b = [&](Walk &w) { if (++w.tap == 9) { w.tap = 0; ++w.chunk; } };
-        const int NB = cpt * 3;                                     // bands: (channel chunk, kernel row)
-        band_part(0, 0); band_part(0, 1); band_part(0, 2);
+    Walk wa = {0, 0}, wb = {0, 0};                                  // K-tile whose A / B pieces are issued next
+    int sa = 0;                                                     // its A stage (mod 3)
+    if (MODE == MODE_FROM_LEVELS) gather_tap(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) piece_b(wb, 0, i);
-        advance_b(wb);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (grp == 1) __builtin_amdgcn_s_barrier();                // group 1 runs one barrier interval behind group 0
-        int kt = 0;
-        for (int b = 0; b < NB; ++b) {
-            const uint32_t aband = lds_base + (uint32_t)((b & 1) * BAND_BYTES);
+    for (int i = 0; i < 4; ++i) piece_a(wa, 0, i);
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx, ++kt) {
-                const uint32_t bbase = lds_base + (uint32_t)(2 * BAND_BYTES + (kt & 1) * TILE);
-                // load phase 2kt: fragments of k-steps 0,1 (band rows shifted by the tap); the weight pieces of tile kt+1
-                RN_LOAD_FRAGS_AT(aband + a_band[dx][0], 0, 0) RN_LOAD_FRAGS_AT(aband + a_band[dx][1], 1, 1)
-                __builtin_amdgcn_sched_barrier(0);
-                if (kt + 1 < KT) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) piece_b(wb, (kt + 1) & 1, i);
-                    advance_b(wb);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                RN_MFMA_PHASE()
-                // load phase 2kt+1: fragments of k-steps 2,3; a third of the NEXT band; retire the weights of tile kt+1 (and, at the
-                // band's last tap, the whole next band: it is read in the next phase)
-                RN_LOAD_FRAGS_AT(aband + a_band[dx][2], 2, 0) RN_LOAD_FRAGS_AT(aband + a_band[dx][3], 3, 1)
-                __builtin_amdgcn_sched_barrier(0);
-                if (b + 1 < NB) {
-                    band_part(b + 1, dx);
-                    if (dx < 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                RN_MFMA_PHASE()
-            }
-        }
-    } else {
-        Walk wa = {0, 0}, wb = {0, 0};                                  // K-tile whose A / B pieces are issued next
-        int sa = 0;                                                     // its A stage (mod 3)
-        if (MODE == MODE_FROM_LEVELS) gather_tap(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) piece_a(wa, 0, i);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) piece_b(wb, 0, i);
-        advance(wa); advance(wb);                                       // -> K-tile 1
-        if (MODE == MODE_FROM_LEVELS && cpt == 1) {
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // the fetch of tap 1 is older than tile 0's 8 pieces
-            map_landed(g_entry);
-            gather_tap(1);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) piece_a(wa, 1, i);
-        advance(wa);                                                    // -> K-tile 2
-        sa = 2;
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        if (MODE == MODE_FROM_LEVELS) map_landed(g_entry);
-        __builtin_amdgcn_s_barrier();
-        if (grp == 1) __builtin_amdgcn_s_barrier();                    // group 1 runs one barrier interval behind group 0
-
-
-        int scur = 0;                                                   // A stage of K-tile kt (mod 3)
-        for (int kt = 0; kt < KT; ++kt) {
-            const uint32_t abase = lds_base + (uint32_t)(scur * TILE), bbase = lds_base + (uint32_t)(3 * TILE + (kt & 1) * TILE);
-            scur = scur == 2 ? 0 : scur + 1;
-            // load phase 2kt: fragments of k-steps 0,1; the weight pieces of tile kt+1
-            RN_LOAD_FRAGS(0, 0) RN_LOAD_FRAGS(1, 1)
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + 1 < KT) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) piece_b(wb, (kt + 1) & 1, i);
-                advance(wb);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            RN_MFMA_PHASE()
-            // load phase 2kt+1: fragments of k-steps 2,3; the activation pieces of tile kt+2; retire tile kt+1
-            RN_LOAD_FRAGS(2, 0) RN_LOAD_FRAGS(3, 1)
-            __builtin_amdgcn_sched_barrier(0);
-            if (kt + 2 < KT) {
-                if (MODE == MODE_FROM_LEVELS && wa.chunk == 0) gather_tap(wa.tap);     // wave-uniform: a new tap starts
-#pragma unroll
-                for (int i = 0; i < 4; ++i) piece_a(wa, sa, i);
-                advance(wa);
-                sa = sa == 2 ? 0 : sa + 1;
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                if (MODE == MODE_FROM_LEVELS) map_landed(g_entry);
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            RN_MFMA_PHASE()
-        }
+    for (int i = 0; i < 4; ++i) piece_b(wb, 0, i);
+    advance(wa); advance(wb);                                       // -> K-tile 1
+    if (MODE == MODE_FROM_LEVELS && cpt == 1) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // the fetch of tap 1 is older than tile 0's 8 pieces
+        map_landed(g_entry);
+        gather_tap(1);
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) piece_a(wa, 1, i);
+    advance(wa);                                                    // -> K-tile 2
+    sa = 2;
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (MODE == MODE_FROM_LEVELS) map_landed(g_entry);
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();                    // group 1 runs one barrier interval behind group 0
+
+
+    int scur = 0;                                                   // A stage of K-tile kt (mod 3)
+    for (int kt = 0; kt < KT; ++kt) {
+        const uint32_t abase = lds_base + (uint32_t)(scur * TILE), bbase = lds_base + (uint32_t)(3 * TILE + (kt & 1) * TILE);
+        scur = scur == 2 ? 0 : scur + 1;
+        // load phase 2kt: fragments of k-steps 0,1; the weight pieces of tile kt+1
+        RN_LOAD_FRAGS(0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < KT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) piece_b(wb, (kt + 1) & 1, i);
+            advance(wb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        RN_MFMA_PHASE()
+        // load phase 2kt+1: fragments of k-steps 2,3; the activation pieces of tile kt+2; retire tile kt+1
+        RN_LOAD_FRAGS(1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < KT) {
+            if (MODE == MODE_FROM_LEVELS && wa.chunk == 0) gather_tap(wa.tap);     // wave-uniform: a new tap starts
+#pragma unroll
+            for (int i = 0; i < 4; ++i) piece_a(wa, sa, i);
+            advance(wa);
+            sa = sa == 2 ? 0 : sa + 1;
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (MODE == MODE_FROM_LEVELS) map_landed(g_entry);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        RN_MFMA_PHASE()
+    }
+
 #undef RN_DS_READ
 #undef RN_LOAD_FRAGS
 #undef RN_LOAD_FRAGS_AT
-#undef RN_MFMA8
+#undef RN_MFMA_ALL
 #undef RN_MFMA_PHASE
     if (grp == 0) __builtin_amdgcn_s_barrier();                    // group 0 catches up with group 1's extra barrier
 
@@ -496,14 +401,14 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
         if (m0 + row < args.M) rm_pre = *(const uint4 *)(relu_mask + (m0 + row) * (args.Cout >> 3) + (n0 >> 3) + half * 16);
     }
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int col = wn * 64 + ni * 32 + (lane & 31);
+        for (int ni = 0; ni < NT; ++ni) {
+            const int col = wn * 64 + ni * 16 + (lane & 15);          // 16 x 16 result tile: column = lane & 15, rows 4 (lane >> 4) + r
             const float b = (a.bias && (MODE != MODE_TO_LEVELS || n0 + col < args.Cout)) ? a.bias[n0 + col] : 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * (32 * MI) + mi * 16 + 4 * (lane >> 4) + r;
                 float v = acc[mi][ni][r] + b;
                 if (args.relu & 1) v = v > 0.0f ? v : 0.0f;
                 Ys[row * CONV_BN + col] = f2bf(v);
