@@ -12,16 +12,21 @@
 // Cin/64 channel chunks x 9 taps (chunk outer: a tile's input lines stay in L2 across its taps).
 //
 // Kernel (bf16 in, f32 accumulate, bf16 out): one 256(m) x 256(n) output tile per workgroup, 8 waves of 128 x 64
-// (4 x 2 v_mfma_f32_32x32x16_bf16 tiles, 128 accumulator registers); operands staged global -> LDS by 16-byte
+// (8 x 4 v_mfma_f32_16x16x32_bf16 tiles, 128 accumulator registers); operands staged global -> LDS by 16-byte
 // LDS-DMA (global_load_lds) into 128-byte rows whose 16-byte chunks are XOR-swizzled with (row >> 1) & 7 (source-side
 // swizzle + the same XOR on the ds_read_b128: conflict-free for its 16-lane groups); 3 activation stages + 2 weight
 // stages = 160 KiB of LDS, activations prefetched two K-tiles ahead, weights one.  The two waves of every SIMD run
-// in PING-PONG: waves 0-3 and 4-7 are one barrier interval apart, so while one group issues its 16 MFMAs the other
-// reads the fragments of its next 16 (12 ds_read_b128) and issues 4 LDS-DMA pieces; a K-tile is two (load, MFMA)
+// in PING-PONG: waves 0-3 and 4-7 are one barrier interval apart, so while one group issues its 32 MFMAs the other
+// reads the fragments of its next 32 (12 ds_read_b128) and issues 4 LDS-DMA pieces; a K-tile is two (load, MFMA)
 // phase pairs = 4 barriers.  LDS-DMA retirement: counted vmcnt at the end of the second load phase, one barrier
 // before any wave of either group reads the tile; raw s_barrier (a __syncthreads would drain the DMA).
-// Measured on MI355X, random data, [8,153,170,256] -> 256: 313 us = 785 TFLOP/s (939 without the 4th partial wave of
-// tiles); MIOpen: forward 301-315 us + 32 us for the separate bias/ReLU/mask pass, data gradient 415 us.
+// Instruction shape: the same loop on 32x32x16 tiles (round 2) issues the same number of MFMA cycles and LDS reads but
+// ran 5 - 17 % slower on random data -- the part holds a higher clock under the 16x16x32 shape (rocprof: same busy
+// cycles, shorter duration).  The weight-gradient kernel below was tried on 16x16x32 as well and was 5 - 9 % SLOWER
+// there (A/B on one box: towers 380 -> 398 us, class-output 955 -> 1046 us), so it keeps 32x32x16.
+// Measured on MI355X, random data, two [8,153,170,256] -> 256 towers per launch: forward 377 - 396 us (1070 - 1120 TFLOP/s
+// on the canvas positions), data gradient 356 - 370 us; MIOpen: forward 301-315 us per tower + 32 us for the separate
+// bias/ReLU/mask pass, data gradient 415 us.
 #include "rn_common.hpp"
 #include <type_traits>
 #include <cstdlib>
