@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RN_ABI_VERSION 3
+#define RN_ABI_VERSION 4
 #define RN_MAX_LEVELS 8
 
 enum rn_dtype { RN_F32 = 0, RN_BF16 = 1, RN_F16 = 2 };
@@ -311,6 +311,26 @@ size_t rn_conv3x3_wgrad_workspace_bytes(int P, int64_t M);
 int rn_conv3x3_canvas_wgrad_batched(const void *const *gs, const void *const *xs, void *const *dws, int P, int dtype,
                                     int64_t M, int Wp, int Cin, int Cout, const void *zeros, void *workspace,
                                     size_t workspace_bytes, void *stream);
+
+/* The same kernels on plain DENSE tensors, for P <= 4 convolutions that each have their own geometry and weights, in
+ * one launch (the FPN's 3x3 output convolutions on P3 / P4 / P5 -- /root/reference/retinanet/layers.py:34-38 applied at
+ * :62-64 -- which the reference runs level by level through nn.Conv2d):
+ *   ys[p][n][y][x][co] = biases[p][co] + sum_{r,s,ci} xs[p][n][y + r - 1][x + s - 1][ci] * ws[p][co][r][s][ci]   (zero padding)
+ * xs[p]: [N][hs[p]][wds[p]][Cin], ys[p]: [N][hs[p]][wds[p]][Cout], ws[p]: [Cout][3][3][Cin], all bf16 (channels-last
+ * memory of NCHW tensors), biases[p]: f32 [Cout] or NULL (biases itself may be NULL).  Cin % 64 == 0, Cout % 256 == 0,
+ * N * h * w < 2^22 per problem.  The row tiles of all problems form one grid; a tap that leaves its image reads `zeros`
+ * (>= 16 bytes of zeros, 16-byte aligned).  The data gradient is the same call on the output gradients with the weights
+ * of rn_conv3x3_dgrad_weight_batched and no bias. */
+int rn_conv3x3_dense_batched(const void *const *xs, const void *const *ws, const float *const *biases, void *const *ys, int P,
+                             int dtype, int N, const int *hs, const int *wds, int Cin, int Cout, const void *zeros,
+                             void *stream);
+/* Its weight gradient (256 -> 256): dws[p][co][3][3][ci] = sum over positions of gs[p][pos][co] * xs[p][pos + tap][ci];
+ * every problem gets a number of position splits proportional to its size (one round of workgroups in total), a second
+ * kernel sums the f32 partials.  workspace: rn_conv3x3_dense_wgrad_workspace_bytes(P); zeros: >= 256 bytes of zeros. */
+size_t rn_conv3x3_dense_wgrad_workspace_bytes(int P);
+int rn_conv3x3_dense_wgrad_batched(const void *const *gs, const void *const *xs, void *const *dws, int P, int dtype, int N,
+                                   const int *hs, const int *wds, int Cin, int Cout, const void *zeros, void *workspace,
+                                   size_t workspace_bytes, void *stream);
 
 /* rn_conv3x3_canvas_batched that also writes, per problem, the ReLU bits of its outputs: relu_mask_outs[p] = [M][Cout / 8]
  * bytes, bit j of byte (m, c / 8) = [ys[p][m][c + j] > 0] (relu must be set; 16-byte aligned; NULL = plain

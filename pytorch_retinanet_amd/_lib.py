@@ -114,6 +114,9 @@ SIGNATURES = {
                                                        _vp, _sz, _vp]),
     "rn_conv3x3_wgrad_workspace_bytes": (_sz, [C.c_int, _i64]),
     "rn_conv3x3_canvas_wgrad_batched": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _sz, _vp]),
+    "rn_conv3x3_dense_batched": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "rn_conv3x3_dense_wgrad_workspace_bytes": (_sz, [C.c_int]),
+    "rn_conv3x3_dense_wgrad_batched": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _sz, _vp]),
     "rn_transform_batch": (C.c_int, [_vp, _vp, _vp, C.c_int, C.POINTER(_f32), C.POINTER(_f32), C.c_int, C.c_int, _vp,
                                      C.c_int, C.c_int, _vp]),
     "rn_nms_workspace_bytes": (_sz, [_i64, C.c_int]),

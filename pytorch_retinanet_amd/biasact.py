@@ -723,3 +723,94 @@ def cls_output_conv(x: Tensor, conv, canvas: "Canvas", num_classes: int, n_image
     ``n_images`` defaults to every slot of every sheet."""
     n = x.shape[0] * canvas.slots if n_images is None else int(n_images)
     return list(_ClsOutputConv.apply(x, conv.weight.to(x.dtype), conv.bias, canvas, num_classes, n))
+
+
+# ---------------------------------------------------------------------------------------------------
+# The FPN's 3x3 output convs (retinanet/layers.py:34-38, applied at :62-64) on the dense MFMA kernels
+DENSE_GROUP = True     # False: every level through its nn.Conv2d (MIOpen)
+_DENSE_WS: Dict[tuple, Tensor] = {}
+
+
+def dense_group_fusable(xs: Sequence[Tensor], convs) -> bool:
+    "bf16 channels-last CUDA activations, 3x3 / stride 1 / pad 1, 256 -> 256 with a bias, at most 4 levels of one batch size."
+    if not (DENSE_GROUP and 0 < len(xs) <= 4 and len(xs) == len(convs)):
+        return False
+    N = xs[0].shape[0]
+    for x, conv in zip(xs, convs):
+        if not (x.is_cuda and x.dtype == torch.bfloat16 and _cl(x) and x.shape[0] == N and x.shape[1] == 256 and
+                N * x.shape[2] * x.shape[3] < (1 << 22) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and
+                conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is not None and
+                conv.in_channels == 256 and conv.out_channels == 256 and conv.bias.dtype == torch.float32):
+            return False
+    return True
+
+
+def _int_array(v):
+    return (C.c_int * len(v))(*[int(i) for i in v])
+
+
+class _DenseConvGroup(torch.autograd.Function):
+    """``[conv_p(x_p) for p]`` -- P <= 4 convolutions 3x3 / pad 1, 256 -> 256, each with its own weights and its own
+    ``[N, 256, h_p, w_p]`` channels-last bf16 input -- as ONE launch of the MFMA implicit GEMM each way
+    (``rn_conv3x3_dense_batched``: the levels' row tiles share the grid, taps that leave the image read zeros), one launch of
+    the position-contraction weight-gradient kernel (``rn_conv3x3_dense_wgrad_batched``) and the bias fused into the
+    forward epilogue.  Arguments: x_0 .. x_{P-1}, w_0 .. (bf16, channels-last), b_0 .. (f32)."""
+
+    @staticmethod
+    def forward(ctx, *args):
+        P = len(args) // 3
+        xs, ws, bs = args[:P], [w if _cl(w) else w.contiguous(memory_format=torch.channels_last) for w in args[P:2 * P]], args[2 * P:]
+        dev = xs[0].device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        N = xs[0].shape[0]
+        hs, wds = [x.shape[2] for x in xs], [x.shape[3] for x in xs]
+        ys = [torch.empty_like(x) for x in xs]
+        flop = sum(2.0 * N * h * w * 256 * 2304 for h, w in zip(hs, wds))
+        _mfma_call(f"mfma_fpn_output_fwd_x{P}", dev, flop,
+                   lambda: lib.rn_conv3x3_dense_batched(_ptr_array(xs), _ptr_array(ws), _ptr_array(bs), _ptr_array(ys), P, RN_BF16, N,
+                                                        _int_array(hs), _int_array(wds), 256, 256, _zero_page(dev).data_ptr(), stream),
+                   "rn_conv3x3_dense_batched")
+        ctx.save_for_backward(*xs, *ws)
+        ctx.geom = (P, N, hs, wds, flop)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        P, N, hs, wds, flop = ctx.geom
+        xs, ws = ctx.saved_tensors[:P], ctx.saved_tensors[P:]
+        dev = xs[0].device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        gs = [dy if (dy.dtype == torch.bfloat16 and _cl(dy)) else dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for dy in dys]
+        dxs = [None] * P
+        if any(ctx.needs_input_grad[:P]):
+            wts = [torch.empty((256, 256, 3, 3), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last) for _ in range(P)]
+            check(lib.rn_conv3x3_dgrad_weight_batched(_ptr_array(ws), _ptr_array(wts), P, 256, 256, stream), "rn_conv3x3_dgrad_weight_batched")
+            dxs = [torch.empty_like(x) for x in xs]
+            _mfma_call(f"mfma_fpn_output_dgrad_x{P}", dev, flop,
+                       lambda: lib.rn_conv3x3_dense_batched(_ptr_array(gs), _ptr_array(wts), None, _ptr_array(dxs), P, RN_BF16, N,
+                                                            _int_array(hs), _int_array(wds), 256, 256, _zero_page(dev).data_ptr(), stream),
+                       "rn_conv3x3_dense_batched")
+        dws = [None] * P
+        if any(ctx.needs_input_grad[P:2 * P]):
+            need = lib.rn_conv3x3_dense_wgrad_workspace_bytes(P)
+            key = (dev.index, stream)
+            wsb = _DENSE_WS.get(key)
+            if wsb is None or wsb.numel() < need:
+                wsb = _DENSE_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
+            dws = [torch.empty((256, 256, 3, 3), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last) for _ in range(P)]
+            _mfma_call(f"mfma_fpn_output_wgrad_x{P}", dev, flop,
+                       lambda: lib.rn_conv3x3_dense_wgrad_batched(_ptr_array(gs), _ptr_array(xs), _ptr_array(dws), P, RN_BF16, N, _int_array(hs),
+                                                                  _int_array(wds), 256, 256, _zero_page(dev).data_ptr(), wsb.data_ptr(),
+                                                                  wsb.numel(), stream),
+                       "rn_conv3x3_dense_wgrad_batched")
+        dbs = [(_colsum_levels([g.permute(0, 2, 3, 1).reshape(N, -1)], 256) if ctx.needs_input_grad[2 * P + p] else None) for p, g in enumerate(gs)]
+        return (*dxs, *dws, *dbs)
+
+
+def dense_conv_group(xs: Sequence[Tensor], convs) -> List[Tensor]:
+    "``[conv(x) for x, conv in zip(xs, convs)]`` for ``dense_group_fusable`` inputs; weights are cast to bf16 here (autocast's cast)."
+    return list(_DenseConvGroup.apply(*xs, *[c.weight.to(torch.bfloat16) for c in convs], *[c.bias for c in convs]))

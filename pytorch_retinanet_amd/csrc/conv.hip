@@ -135,7 +135,17 @@ __device__ __forceinline__ const uint16_t *pair_ptr(const uint16_t *p, const boo
 // per-level tensors out, any even Cout (weight rows >= Cout read zeros; the class-output conv forward).  FROM_LEVELS: the
 // activation operand is gathered from dense per-level tensors whose row length need not be a multiple of 64 (the data
 // gradient of the class-output conv: contraction over 9 taps x 810 channels), canvas out.
-enum { MODE_CANVAS = 0, MODE_TO_LEVELS = 1, MODE_FROM_LEVELS = 2 };
+// DENSE: up to 4 convolutions with their OWN geometry and weights in one launch, activations and outputs as plain dense
+// [N][h][w][C] tensors without any border (the FPN's 3x3 output convs on P3 / P4 / P5, retinanet/layers.py:34-38, 62-64): the
+// tile list is the concatenation of the problems' row tiles (blockIdx.x -> problem by DenseGeom::tile_beg), and a tap that
+// leaves its image reads the zero page instead -- a per-thread 9-bit validity mask for each of the 4 rows it stages, computed
+// once per tile (valid taps are always inside the tensor, so no address clamping exists in this mode).
+enum { MODE_CANVAS = 0, MODE_TO_LEVELS = 1, MODE_FROM_LEVELS = 2, MODE_DENSE = 3 };
+struct DenseGeom {
+    int64_t M[CONV_MAX_PROBLEMS];               // N * h * w
+    int32_t h[CONV_MAX_PROBLEMS], w[CONV_MAX_PROBLEMS];
+    int32_t tile_beg[CONV_MAX_PROBLEMS + 1];    // first row tile (weight-gradient kernel: first split) of problem p; INT_MAX past the last
+};
 
 // Up to 4 convolutions of identical geometry in one launch (blockIdx.z = problem): the cls and the box tower run the
 // same shapes side by side, and 2 x 813 tiles fill 7 waves of 256 workgroups where two launches take 2 x 4.
@@ -156,6 +166,7 @@ struct ConvArgs {
     int Cin, Cout, Wp, relu;    // Cin = channels walked per tap (FROM_LEVELS: the padded row length, a multiple of 64)
     int n_base;                 // first output channel of blockIdx.y = 0 (the NARROW launch of the last column tile)
     LevelSet lv;
+    DenseGeom dn;               // MODE_DENSE only (M, HWp, Wp, mask unused there)
 };
 struct ConvProblem { const uint16_t *X, *W; const float *bias; uint16_t *Y; };
 
@@ -170,14 +181,23 @@ template <int MODE, bool NARROW = false>
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const ConvArgs args)
 {
     constexpr int MI = NARROW ? 1 : 4;                            // 32-row accumulator tiles per wave
+    int prob = blockIdx.z;
+    int64_t m0 = (int64_t)blockIdx.x * CONV_BM, M = args.M, HWp = args.HWp;
+    int Wp = args.Wp, dense_h = 0;
+    if (MODE == MODE_DENSE) {                                     // blockIdx.x walks the problems' row tiles one after the other
+        prob = 0;
+#pragma unroll
+        for (int p = 1; p < CONV_MAX_PROBLEMS; ++p) prob = (int)blockIdx.x >= args.dn.tile_beg[p] ? p : prob;
+        m0 = (int64_t)((int)blockIdx.x - args.dn.tile_beg[prob]) * CONV_BM;
+        M = args.dn.M[prob]; Wp = args.dn.w[prob]; dense_h = args.dn.h[prob]; HWp = (int64_t)Wp * dense_h;
+    }
     ConvProblem a;
-    a.X = args.Xs[blockIdx.z]; a.W = args.Ws[blockIdx.z]; a.bias = args.biases[blockIdx.z]; a.Y = args.Ys[blockIdx.z];
+    a.X = args.Xs[prob]; a.W = args.Ws[prob]; a.bias = args.biases[prob]; a.Y = args.Ys[prob];
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];                 // [A0 A1 A2 | B0 B1] x 32 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform: LDS-DMA bases and wave roles live in SGPRs
     const int wm = NARROW ? wave : wave >> 2, wn = NARROW ? 0 : wave & 3;
     const int grp = wave >> 2;                                    // ping-pong group: waves 0-3 / 4-7 (one wave of each per SIMD)
-    const int64_t m0 = (int64_t)blockIdx.x * CONV_BM;
     const int n0 = blockIdx.y * CONV_BN + args.n_base;
     const int cpt = args.Cin / CONV_BK, KT = 9 * cpt;
     constexpr int TILE = CONV_BM * CONV_BK * 2;
@@ -231,24 +251,24 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     // (j >> 3) * 64 + wave * 8 + (j & 7) once per tap (9 times per tile) and the wave shares the pointers by shuffles.
     // The map entry of the NEXT tap is fetched when a tap's pointers are formed (map_fetch / map_landed above).
     LevelRegs lregs = {};
-    if (MODE != MODE_CANVAS) lregs = level_regs(args.lv);
+    if (MODE == MODE_TO_LEVELS || MODE == MODE_FROM_LEVELS) lregs = level_regs(args.lv);
     int g_n = 0, g_pos = 0;
     int32_t g_entry = -1;
     bool g_valid = false;
-    auto tap_pos = [&](const int t) { return g_pos + (t / 3 - 1) * args.Wp + (t % 3 - 1); };
+    auto tap_pos = [&](const int t) { return g_pos + (t / 3 - 1) * Wp + (t % 3 - 1); };
     if (MODE == MODE_FROM_LEVELS) {
         const int j = lane & 31;
         int64_t m = m0 + (j >> 3) * 64 + wave * 8 + (j & 7);
-        m = m < args.M ? m : args.M - 1;
-        sheet_coords((int)m, (int)args.HWp, g_n, g_pos);
+        m = m < M ? m : M - 1;
+        sheet_coords((int)m, (int)HWp, g_n, g_pos);
         const int p0 = tap_pos(0);
-        g_valid = p0 >= 0 && p0 < (int)args.HWp;
+        g_valid = p0 >= 0 && p0 < (int)HWp;
         g_entry = args.lv.map[g_valid ? p0 : 0];                  // (prologue: nothing in flight yet)
     }
     auto gather_tap = [&](const int t) {
         const uint16_t *mine = level_row(args.lv, lregs, g_n, g_valid ? g_entry : -1);
         const int pn = tap_pos(t + 1 < 9 ? t + 1 : t);
-        g_valid = pn >= 0 && pn < (int)args.HWp;
+        g_valid = pn >= 0 && pn < (int)HWp;
         map_fetch(g_entry, args.lv.map + (g_valid ? pn : 0));
 #pragma unroll
         for (int i = 0; i < 4; ++i) grow[i] = bperm_ptr(mine, i * 8 + (lane >> 3));
@@ -265,7 +285,20 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
         voff_a[i] = (uint32_t)(row * args.Cin + ((cp ^ SWZ(row)) << 3)) * 2u;
         voff_b[i] = (uint32_t)(row * 9 * args.Cin + ((cp ^ SWZ(row)) << 3)) * 2u;
     }
-    const bool a_edge = m0 - (args.Wp + 1) < 0 || m0 + CONV_BM + args.Wp + 1 > args.M;             // wave-uniform
+    const bool a_edge = m0 - (Wp + 1) < 0 || m0 + CONV_BM + Wp + 1 > M;             // wave-uniform
+    uint32_t tap_ok[4] = {0u, 0u, 0u, 0u};                         // DENSE: bit t = tap t of staged row i lies inside the row's image
+    if (MODE == MODE_DENSE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t m = m0 + ((i * CONV_THREADS + tid) >> 3);
+            if (m < M) {
+                const int yl = (int)m / Wp, x = (int)m - yl * Wp, y = yl % dense_h;      // (host: M < 2^31)
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    tap_ok[i] |= ((unsigned)(y + t / 3 - 1) < (unsigned)dense_h && (unsigned)(x + t % 3 - 1) < (unsigned)Wp) ? 1u << t : 0u;
+            }
+        }
+    }
     const bool b_ragged = MODE == MODE_TO_LEVELS && n0 + CONV_BN > args.Cout;
     auto lds_piece = [&](unsigned char *stage_base, const int i) {                                  // wave-uniform LDS base of piece i
         return stage_base + i * (CONV_THREADS * 16) + wave * (RN_WAVE * 16);
@@ -283,13 +316,17 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
             const uint16_t *g = (grow[i] && e < args.lv.row_elems) ? grow[i] + es : args.zeros + ((cp ^ SWZ(row)) << 3);
             __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
         } else {
-            const int off = (t / 3 - 1) * args.Wp + (t % 3 - 1);
-            if (!a_edge) {
+            const int off = (t / 3 - 1) * Wp + (t % 3 - 1);
+            if (MODE == MODE_DENSE) {
+                const unsigned char *base = (const unsigned char *)a.X + ((m0 + off) * args.Cin + c0) * 2;
+                const void *src = (tap_ok[i] >> t) & 1u ? (const void *)(base + voff_a[i]) : (const void *)args.zeros;
+                __builtin_amdgcn_global_load_lds(src, (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
+            } else if (!a_edge) {
                 const unsigned char *base = (const unsigned char *)a.X + ((m0 + off) * args.Cin + c0) * 2;
                 __builtin_amdgcn_global_load_lds((const void *)(base + voff_a[i]), (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
             } else {
                 int64_t m = m0 + row + off;
-                m = m < 0 ? 0 : (m >= args.M ? args.M - 1 : m);
+                m = m < 0 ? 0 : (m >= M ? M - 1 : m);
                 const uint16_t *g = a.X + m * args.Cin + c0 + ((cp ^ SWZ(row)) << 3);
                 __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
             }
@@ -399,11 +436,11 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     uint16_t **Yrow = (uint16_t **)(lds + CONV_BM * CONV_BN * 2);  // TO_LEVELS: destination row of each tile row (2 KiB)
     float *s_cs = (float *)(lds + CONV_BM * CONV_BN * 2 + 2048);  // fused ReLU backward: column sums [16][256] f32 (16 KiB)
     uint8_t *s_rmask = lds + CONV_BM * CONV_BN * 2 + 2048 + 16384; //   and the tile's ReLU bits [256][32] bytes (8 KiB)
-    const uint8_t *relu_mask = MODE == MODE_TO_LEVELS ? nullptr : args.relu_masks[blockIdx.z];
+    const uint8_t *relu_mask = MODE == MODE_TO_LEVELS ? nullptr : args.relu_masks[prob];
     uint4 rm_pre = make_uint4(0, 0, 0, 0);
     if (relu_mask) {                                              // fetched now, consumed after the staging below: latency hidden
         const int row = tid >> 1, half = tid & 1;
-        if (m0 + row < args.M) rm_pre = *(const uint4 *)(relu_mask + (m0 + row) * (args.Cout >> 3) + (n0 >> 3) + half * 16);
+        if (m0 + row < M) rm_pre = *(const uint4 *)(relu_mask + (m0 + row) * (args.Cout >> 3) + (n0 >> 3) + half * 16);
     }
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
@@ -422,9 +459,9 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     if (MODE == MODE_TO_LEVELS && tid < CONV_BM) {
         const int64_t m = m0 + tid;
         uint16_t *dst = nullptr;
-        if (m < args.M) {
+        if (m < M) {
             int n, pos;
-            sheet_coords((int)m, (int)args.HWp, n, pos);
+            sheet_coords((int)m, (int)HWp, n, pos);
             dst = level_row(args.lv, lregs, n, args.lv.map[pos]);
         }
         Yrow[tid] = dst;
@@ -452,19 +489,19 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
         }
     } else {
         // position of the tile's first row on its sheet: one scalar 64-bit modulo per tile, then 32-bit steps
-        const int64_t pos0 = m0 % args.HWp;
-        uint8_t *rmask_out = MODE == MODE_TO_LEVELS ? nullptr : args.relu_mask_outs[blockIdx.z];
+        const int64_t pos0 = m0 % HWp;
+        uint8_t *rmask_out = MODE == MODE_TO_LEVELS ? nullptr : args.relu_mask_outs[prob];
         float cs[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        const bool one_wrap = args.HWp >= CONV_BM;                  // the tile crosses at most one sheet boundary
+        const bool one_wrap = HWp >= CONV_BM;                  // the tile crosses at most one sheet boundary
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int q = i * CONV_THREADS + tid, row = q >> 5, piece = q & 31;
             const int64_t m = m0 + row;
-            if (m < args.M) {
+            if (m < M) {
                 uint4 v = *(const uint4 *)(Ys + row * CONV_BN + piece * 8);
                 if (args.mask) {
                     int64_t pos = pos0 + row;
-                    if (one_wrap) pos = pos >= args.HWp ? pos - args.HWp : pos; else pos %= args.HWp;
+                    if (one_wrap) pos = pos >= HWp ? pos - HWp : pos; else pos %= HWp;
                     if (!args.mask[pos]) v = make_uint4(0, 0, 0, 0);
                 }
                 if (relu_mask) {
@@ -501,7 +538,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
                 float t = 0.0f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) t += s_cs[r * CONV_BN + tid];
-                args.colsums[blockIdx.z][(int64_t)blockIdx.x * args.Cout + n0 + tid] = t;
+                args.colsums[prob][(int64_t)blockIdx.x * args.Cout + n0 + tid] = t;
             }
         }
     }
@@ -520,6 +557,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
 // workgroup, 8 waves of 128 x 64 as in the forward kernel, same staging pipeline (3 G stages + 2 X stages, ping-pong
 // wave groups, counted vmcnt).  Partials go to a workspace and a second kernel sums the splits into bf16.
 constexpr int WG_POS = 64;                                       // positions per K-tile
+__device__ __forceinline__ int wg_swz_row(const int row) { return (row & 3) << 2; }
 
 struct WgradArgs {
     const uint16_t *Gs[CONV_MAX_PROBLEMS];      // [M][256] bf16 (GATHER: unused, the gradient rows come from `lv`)
@@ -530,6 +568,8 @@ struct WgradArgs {
     int Wp, S, tiles_per_split;                 // K-tiles (64 positions) per split
     int ch_base;                                // GATHER: first output channel of problem 0 (the NARROW launch of the last row tile)
     LevelSet lv;                                // GATHER: dense per-level gradient tensors [N][h][w][row_elems]; problem p = output channels 256 p ..
+    DenseGeom dn;                               // DENSE: per-problem geometry; tile_beg = first split of the problem (blockIdx.x walks them all)
+    int dn_tps[CONV_MAX_PROBLEMS];              //        K-tiles per split of problem p
 };
 
 // GATHER = false: G and X are canvases (the head towers).  GATHER = true: the gradient operand is gathered, position by
@@ -538,7 +578,11 @@ struct WgradArgs {
 // NARROW (GATHER only): a row tile of at most 64 output channels -- the ragged last tile of the 810-channel class-output conv
 // (42 rows) and the whole 36-channel box-output conv.  All 8 waves split the 256 input channels (32 each) and compute
 // 64 x 32: a quarter of the MFMAs and half of the fragment reads of a full tile whose other 192 rows would be zeros.
-template <bool GATHER, bool NARROW = false>
+// DENSE (not GATHER): G and X are plain dense [N][h][w][256] tensors of up to 4 problems with their own geometry (MODE_DENSE of
+// the forward kernel); every problem has its own number of splits -- proportional to its positions, so that all workgroups
+// walk about the same number of K-tiles -- and an X row whose tap leaves the image reads the zero page: row / column of the
+// 4 rows a thread stages are recomputed per K-tile (two reciprocal multiplications each, sheet_coords).
+template <bool GATHER, bool NARROW = false, bool DENSE = false>
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const WgradArgs a)
 {
     constexpr int MI = NARROW ? 2 : 4, NI = NARROW ? 1 : 2;
@@ -547,11 +591,19 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform (LDS-DMA bases, wave roles)
     const int wm = NARROW ? 0 : wave >> 2, wn = NARROW ? wave : wave & 3;       // NARROW: wn counts 32-channel columns
     const int pp = wave >> 2;                                     // ping-pong group: waves 0-3 / 4-7
-    const int split = blockIdx.x, tap = blockIdx.y, prob = blockIdx.z;
+    int split = blockIdx.x, prob = blockIdx.z, KT = a.tiles_per_split, Wp = a.Wp, dense_h = 0;
+    const int tap = blockIdx.y;
+    int64_t M = a.M;
+    if (DENSE) {
+        prob = 0;
+#pragma unroll
+        for (int p = 1; p < CONV_MAX_PROBLEMS; ++p) prob = (int)blockIdx.x >= a.dn.tile_beg[p] ? p : prob;
+        split = (int)blockIdx.x - a.dn.tile_beg[prob];
+        KT = a.dn_tps[prob]; Wp = a.dn.w[prob]; dense_h = a.dn.h[prob]; M = a.dn.M[prob];
+    }
     const uint16_t *__restrict__ G = a.Gs[prob], *__restrict__ X = a.Xs[GATHER ? 0 : prob];
-    const int KT = a.tiles_per_split;
     const int64_t m_begin = (int64_t)split * KT * WG_POS;
-    const int off = (tap / 3 - 1) * a.Wp + (tap % 3 - 1);
+    const int off = (tap / 3 - 1) * Wp + (tap % 3 - 1);
     constexpr int TILE = WG_POS * 512;                            // 32 KiB
     unsigned char *const Abase = lds, *const Bbase = lds + 3 * TILE;
 
@@ -594,16 +646,25 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
     auto piece_b = [&](const int kt, const int i) {
         const int64_t t0 = m_begin + (int64_t)kt * WG_POS;                                   // first position of the K-tile
         unsigned char *const sb = Bbase + (kt & 1) * TILE;
-        if (t0 + off >= 0 && t0 + off + WG_POS <= a.M) {                                      // wave-uniform
+        if (DENSE) {
+            const int qi = i * CONV_THREADS + tid, row = qi >> 5, cp = qi & 31;
+            const int m = (int)t0 + row;                                                      // (host: M < 2^22)
+            int yl, x, n, y;
+            sheet_coords(m, Wp, yl, x);
+            sheet_coords(yl, dense_h, n, y);
+            const bool ok = m < (int)M && (unsigned)(y + tap / 3 - 1) < (unsigned)dense_h && (unsigned)(x + tap % 3 - 1) < (unsigned)Wp;
+            const uint16_t *g = ok ? X + ((int64_t)m + off) * 256 + ((cp ^ wg_swz_row(row)) << 3) : a.zeros + ((cp & 15) << 3);
+            __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
+        } else if (t0 + off >= 0 && t0 + off + WG_POS <= M) {                                      // wave-uniform
             const unsigned char *base = (const unsigned char *)X + (t0 + off) * 512;
             __builtin_amdgcn_global_load_lds((const void *)(base + voff[i]), (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
         } else {
             const int qi = i * CONV_THREADS + tid, row = qi >> 5, cp = qi & 31;
             const int64_t m = t0 + row;
             int64_t ms = m + off;
-            ms = ms < 0 ? 0 : (ms >= a.M ? a.M - 1 : ms);
+            ms = ms < 0 ? 0 : (ms >= M ? M - 1 : ms);
             const uint16_t *g = X + ms * 256 + ((cp ^ ((row & 3) << 2)) << 3);
-            if (m >= a.M) g = a.zeros + ((cp & 15) << 3);             // positions past the end contribute nothing
+            if (m >= M) g = a.zeros + ((cp & 15) << 3);             // positions past the end contribute nothing
             __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
         }
     };
@@ -619,9 +680,9 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
     auto rows_pos = [&](const int kt) {                            // -> w_n, w_valid; returns the (clamped) sheet position
         const int j = lane & 7;
         const int64_t m = m_begin + (int64_t)kt * WG_POS + (j >> 1) * 16 + wave * 2 + (j & 1);
-        w_valid = m < a.M;
+        w_valid = m < M;
         int pos;
-        sheet_coords((int)(w_valid ? m : a.M - 1), (int)a.HWp, w_n, pos);
+        sheet_coords((int)(w_valid ? m : M - 1), (int)a.HWp, w_n, pos);
         return pos;
     };
     if (GATHER) w_entry = a.lv.map[rows_pos(0)];                   // (prologue: nothing in flight yet)
@@ -643,14 +704,14 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
             const int es = e + 8 > a.lv.row_elems ? a.lv.row_elems - 8 : e;
             const uint16_t *g = (grow[i] && e < a.lv.row_elems) ? grow[i] + es : a.zeros + ((cp & 15) << 3);
             __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
-        } else if (t0 + WG_POS <= a.M) {                                          // wave-uniform
+        } else if (t0 + WG_POS <= M) {                                          // wave-uniform
             const unsigned char *base = (const unsigned char *)G + t0 * 512;
             __builtin_amdgcn_global_load_lds((const void *)(base + voff[i]), (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
         } else {
             const int64_t m = t0 + row;
-            const int64_t ms = m >= a.M ? a.M - 1 : m;
+            const int64_t ms = m >= M ? M - 1 : m;
             const uint16_t *g = G + ms * 256 + ((cp ^ ((row & 3) << 2)) << 3);
-            if (m >= a.M) g = a.zeros + ((cp & 15) << 3);
+            if (m >= M) g = a.zeros + ((cp & 15) << 3);
             __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
         }
     };
@@ -737,7 +798,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
     if (pp == 0) __builtin_amdgcn_s_barrier();
 
     // partial tile [n][c] f32 of this (problem, split, tap)
-    float *__restrict__ out = a.partial + (((int64_t)prob * a.S + split) * 9 + tap) * 65536;
+    float *__restrict__ out = a.partial + (DENSE ? (int64_t)blockIdx.x * 9 + tap : ((int64_t)prob * a.S + split) * 9 + tap) * 65536;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -781,6 +842,28 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     rn::u32x2 o;
     o.x = rn::dt<RN_BF16>::pk(s.x, s.y); o.y = rn::dt<RN_BF16>::pk(s.z, s.w);
     *(rn::u32x2 *)(dw + ((int64_t)n_out * 9 + t) * 256 + c) = o;
+}
+
+// The same sum for the DENSE launch, whose problems own different numbers of splits: partial[split][t][n][c], splits
+// beg[p] .. beg[p + 1] belong to problem p.
+struct DenseSplits { int beg[CONV_MAX_PROBLEMS + 1]; };
+__global__ __launch_bounds__(256) void wgrad_reduce_dense_kernel(const float *__restrict__ partial, const DenseSplits sp, uint16_t *dw0,
+                                                                 uint16_t *dw1, uint16_t *dw2, uint16_t *dw3)
+{
+    const int prob = blockIdx.y;
+    uint16_t *dw = prob == 0 ? dw0 : (prob == 1 ? dw1 : (prob == 2 ? dw2 : dw3));
+    const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;          // over 9 * 256 * 256 / 4 float4 groups of [t][n][c]
+    if (i4 >= 9 * 65536 / 4) return;
+    const int64_t e = i4 * 4;
+    const int t = (int)(e / 65536), n = (int)((e % 65536) / 256), c = (int)(e % 256);
+    rn::f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int q = sp.beg[prob]; q < sp.beg[prob + 1]; ++q) {
+        const rn::f32x4 v = ((const rn::f32x4 *)(partial + (int64_t)q * 9 * 65536))[i4];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    rn::u32x2 o;
+    o.x = rn::dt<RN_BF16>::pk(s.x, s.y); o.y = rn::dt<RN_BF16>::pk(s.z, s.w);
+    *(rn::u32x2 *)(dw + ((int64_t)n * 9 + t) * 256 + c) = o;
 }
 
 
@@ -1268,4 +1351,124 @@ RN_API int rn_conv3x3_levels_wgrad(const void *const *gs, const rn_canvas_layout
         return wgrad_launch<true, true>(a, dw1, rows1, 1, M, (float *)workspace + used, (hipStream_t)stream, tail ? e_last : 0, tail ? 8 - tail : 0);
     }
     return wgrad_launch<true>(a, dws, rows, P, M, workspace, (hipStream_t)stream, tail ? e_last : 0, tail ? 8 - tail : 0);
+}
+
+
+// ---- MODE_DENSE entry points: P <= 4 convolutions 3x3 / stride 1 / pad 1 with their own [N][h_p][w_p] geometry and weights ----
+static int dense_geom(DenseGeom &g, int P, int N, const int *hs, const int *wds)
+{
+    if (!hs || !wds || P <= 0 || P > CONV_MAX_PROBLEMS || N <= 0) return RN_EINVAL;
+    for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) {
+        const int q = p < P ? p : 0;
+        if (hs[q] <= 0 || wds[q] <= 0) return RN_EINVAL;
+        const int64_t M = (int64_t)N * hs[q] * wds[q];
+        if (M >= (1 << 22)) return RN_EUNSUPPORTED;                 // sheet_coords' range (weight gradient); 32-bit row arithmetic
+        g.M[p] = M; g.h[p] = hs[q]; g.w[p] = wds[q];
+    }
+    return RN_OK;
+}
+
+RN_API int rn_conv3x3_dense_batched(const void *const *xs, const void *const *ws, const float *const *biases, void *const *ys, int P,
+                                    int dtype, int N, const int *hs, const int *wds, int Cin, int Cout, const void *zeros, void *stream)
+{
+    if (!xs || !ws || !ys || !zeros || Cin <= 0 || Cout <= 0) return RN_EINVAL;
+    if (dtype != RN_BF16 || Cin % CONV_BK || Cout % CONV_BN) return RN_EUNSUPPORTED;
+    ConvArgs a = {};
+    int rc = dense_geom(a.dn, P, N, hs, wds);
+    if (rc != RN_OK) return rc;
+    if (!rn::aligned(zeros, 16)) return RN_EALIGN;
+    int tiles = 0;
+    for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) {
+        const int q = p < P ? p : 0;
+        if (!xs[q] || !ws[q] || !ys[q]) return RN_EINVAL;
+        if (!rn::aligned(xs[q], 16) || !rn::aligned(ws[q], 16) || !rn::aligned(ys[q], 16)) return RN_EALIGN;
+        a.Xs[p] = (const uint16_t *)xs[q]; a.Ws[p] = (const uint16_t *)ws[q]; a.Ys[p] = (uint16_t *)ys[q];
+        a.biases[p] = biases ? biases[q] : nullptr;
+        a.dn.tile_beg[p] = p < P ? tiles : 0x7fffffff;
+        if (p < P) tiles += (int)((a.dn.M[p] + CONV_BM - 1) / CONV_BM);
+    }
+    a.dn.tile_beg[CONV_MAX_PROBLEMS] = 0x7fffffff;
+    a.mask = nullptr; a.M = 0; a.HWp = 1; a.Wp = 1; a.Cin = Cin; a.Cout = Cout; a.relu = 0; a.zeros = (const uint16_t *)zeros;
+    return conv_launch_mode<MODE_DENSE>(a, dim3((unsigned)tiles, (unsigned)(Cout / CONV_BN), 1), (hipStream_t)stream);
+}
+
+// splits of the DENSE weight gradient: every split walks `tps` K-tiles (the last one of a problem fewer), as many splits in
+// total as fit one round of the chip (cus / 9 workgroups per tap)
+static int dense_splits(const DenseGeom &g, int P, int *beg, int *tps_out)
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    int budget = cus / 9;
+    if (budget < P) budget = P;
+    int64_t kt[CONV_MAX_PROBLEMS], total = 0;
+    for (int p = 0; p < P; ++p) { kt[p] = (g.M[p] + WG_POS - 1) / WG_POS; total += kt[p]; }
+    int64_t tps = (total + budget - 1) / budget;
+    if (tps < 1) tps = 1;
+    while (true) {
+        int n = 0;
+        for (int p = 0; p < P; ++p) n += (int)((kt[p] + tps - 1) / tps);
+        if (n <= budget) break;
+        ++tps;
+    }
+    int n = 0;
+    for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) {
+        beg[p] = p < P ? n : 0x7fffffff;
+        if (p < P) n += (int)((kt[p] + tps - 1) / tps);
+    }
+    beg[CONV_MAX_PROBLEMS] = 0x7fffffff;
+    *tps_out = (int)tps;
+    return n;
+}
+
+RN_API size_t rn_conv3x3_dense_wgrad_workspace_bytes(int P)
+{
+    if (P <= 0 || P > CONV_MAX_PROBLEMS) return 0;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    const int budget = cus / 9 < P ? P : cus / 9;
+    return (size_t)budget * 9 * 65536 * sizeof(float);
+}
+
+RN_API int rn_conv3x3_dense_wgrad_batched(const void *const *gs, const void *const *xs, void *const *dws, int P, int dtype, int N,
+                                          const int *hs, const int *wds, int Cin, int Cout, const void *zeros, void *workspace,
+                                          size_t workspace_bytes, void *stream)
+{
+    if (!gs || !xs || !dws || !zeros || !workspace) return RN_EINVAL;
+    if (dtype != RN_BF16 || Cin != 256 || Cout != 256) return RN_EUNSUPPORTED;
+    WgradArgs a = {};
+    int rc = dense_geom(a.dn, P, N, hs, wds);
+    if (rc != RN_OK) return rc;
+    if (workspace_bytes < rn_conv3x3_dense_wgrad_workspace_bytes(P)) return RN_EWORKSPACE;
+    if (!rn::aligned(zeros, 16) || !rn::aligned(workspace, 16)) return RN_EALIGN;
+    uint16_t *dw[CONV_MAX_PROBLEMS] = {nullptr, nullptr, nullptr, nullptr};
+    for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) {
+        const int q = p < P ? p : 0;
+        if (!gs[q] || !xs[q] || !dws[q]) return RN_EINVAL;
+        if (!rn::aligned(gs[q], 16) || !rn::aligned(xs[q], 16) || !rn::aligned(dws[q], 16)) return RN_EALIGN;
+        a.Gs[p] = (const uint16_t *)gs[q]; a.Xs[p] = (const uint16_t *)xs[q];
+        dw[p] = (uint16_t *)dws[q];
+    }
+    DenseSplits sp;
+    int tps = 1;
+    const int total = dense_splits(a.dn, P, sp.beg, &tps);
+    for (int p = 0; p <= CONV_MAX_PROBLEMS; ++p) a.dn.tile_beg[p] = sp.beg[p];
+    for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) a.dn_tps[p] = tps;
+    sp.beg[P] = total;                                              // end of the last problem for the reduction
+    a.zeros = (const uint16_t *)zeros; a.partial = (float *)workspace; a.S = total; a.M = 0; a.Wp = 1; a.HWp = 1; a.tiles_per_split = tps;
+    hipStream_t st = (hipStream_t)stream;
+    int dev = 0;
+    RN_HIP(hipGetDevice(&dev));
+    {
+        static bool attr_set[64] = {};
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            RN_HIP(hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES));
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<false, false, true>), dim3((unsigned)total, 9, 1), dim3(CONV_THREADS), CONV_LDS_BYTES, st, a);
+    RN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(wgrad_reduce_dense_kernel, dim3(9 * 65536 / 4 / 256, (unsigned)P), dim3(256), 0, st, (const float *)workspace, sp, dw[0],
+                       dw[1], dw[2], dw[3]);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
 }

@@ -68,7 +68,10 @@ class FeaturePyramid(nn.Module):
         p3 = self._lateral_plus_up(conv1x1(self.conv_c3_1x1, c3), p4)
         p6 = self.conv_c6_3x3(c5)
         p7 = self.conv_c7_3x3(F.relu(p6))
-        return [self.conv_c3_3x3(p3), self.conv_c4_3x3(p4), self.conv_c5_3x3(p5), p6, p7]
+        outs, convs = [p3, p4, p5], [self.conv_c3_3x3, self.conv_c4_3x3, self.conv_c5_3x3]
+        if biasact.dense_group_fusable(outs, convs):       # one MFMA launch each way for the three levels (csrc/conv.hip, MODE_DENSE)
+            return biasact.dense_conv_group(outs, convs) + [p6, p7]
+        return [conv(p) for conv, p in zip(convs, outs)] + [p6, p7]
 
 
 def _tower(in_channels: int, out_channels: int) -> nn.Sequential:
