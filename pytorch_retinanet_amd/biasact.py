@@ -814,3 +814,64 @@ class _DenseConvGroup(torch.autograd.Function):
 def dense_conv_group(xs: Sequence[Tensor], convs) -> List[Tensor]:
     "``[conv(x) for x, conv in zip(xs, convs)]`` for ``dense_group_fusable`` inputs; weights are cast to bf16 here (autocast's cast)."
     return list(_DenseConvGroup.apply(*xs, *[c.weight.to(torch.bfloat16) for c in convs], *[c.bias for c in convs]))
+
+
+# ---------------------------------------------------------------------------------------------------
+# Bottleneck conv2 of layer3 (3x3 / stride 1, 256 -> 256, 33 600 positions at the bench shape): forward stays on MIOpen (CK's
+# kernel runs it at 1.2 PFLOP/s, a half-empty round of 256 x 256 tiles cannot match that), the two gradients run on the dense
+# MFMA kernels: MIOpen's data gradient 95 us + weight gradient 87 us + 15 us of zero / cast helpers against 62 + 50 us.
+CONV3X3_BWD = True
+
+
+def conv3x3_bwd_fusable(conv, x: Tensor) -> bool:
+    return (CONV3X3_BWD and x.is_cuda and x.dtype == torch.bfloat16 and conv.weight.dtype == torch.bfloat16 and _cl(x) and
+            conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and
+            conv.groups == 1 and conv.bias is None and conv.in_channels == 256 and conv.out_channels == 256 and
+            torch.is_grad_enabled() and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 22))
+
+
+class _Conv3x3MfmaBwd(torch.autograd.Function):
+    "``F.conv2d(x, w, None, 1, 1)`` (256 -> 256, bf16 channels-last) with both gradients on ``rn_conv3x3_dense_*`` (P = 1)."
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return F.conv2d(x, w, None, 1, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        N, _, h, wd = x.shape
+        dev = x.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        g = dy if (dy.dtype == torch.bfloat16 and _cl(dy)) else dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        wc = w if _cl(w) else w.contiguous(memory_format=torch.channels_last)
+        flop = 2.0 * N * h * wd * 256 * 2304
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wt = torch.empty((256, 256, 3, 3), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+            check(lib.rn_conv3x3_dgrad_weight_batched(_ptr_array([wc]), _ptr_array([wt]), 1, 256, 256, stream), "rn_conv3x3_dgrad_weight_batched")
+            dx = torch.empty_like(x)
+            _mfma_call("mfma_conv2_dgrad", dev, flop,
+                       lambda: lib.rn_conv3x3_dense_batched(_ptr_array([g]), _ptr_array([wt]), None, _ptr_array([dx]), 1, RN_BF16, N,
+                                                            _int_array([h]), _int_array([wd]), 256, 256, _zero_page(dev).data_ptr(), stream),
+                       "rn_conv3x3_dense_batched")
+        if ctx.needs_input_grad[1]:
+            need = lib.rn_conv3x3_dense_wgrad_workspace_bytes(1)
+            key = (dev.index, stream)
+            wsb = _DENSE_WS.get(key)
+            if wsb is None or wsb.numel() < need:
+                wsb = _DENSE_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
+            dw = torch.empty((256, 256, 3, 3), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+            _mfma_call("mfma_conv2_wgrad", dev, flop,
+                       lambda: lib.rn_conv3x3_dense_wgrad_batched(_ptr_array([g]), _ptr_array([x]), _ptr_array([dw]), 1, RN_BF16, N, _int_array([h]),
+                                                                  _int_array([wd]), 256, 256, _zero_page(dev).data_ptr(), wsb.data_ptr(),
+                                                                  wsb.numel(), stream),
+                       "rn_conv3x3_dense_wgrad_batched")
+        return dx, dw
+
+
+def conv3x3_mfma_bwd(conv, x: Tensor) -> Tensor:
+    return _Conv3x3MfmaBwd.apply(x, conv.weight)

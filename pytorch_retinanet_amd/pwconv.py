@@ -370,4 +370,7 @@ def conv1x1(conv, x: Tensor) -> Tensor:
             and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and conv.in_channels % 64 == 0
             and conv.out_channels % 64 == 0 and torch.is_grad_enabled() and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 24)):
         return _Conv1x1.apply(x, w, conv.bias)
+    from . import biasact
+    if biasact.conv3x3_bwd_fusable(conv, x):        # 3x3 / 256 -> 256 (layer3's conv2): MIOpen forward, gradients on csrc/conv.hip
+        return biasact.conv3x3_mfma_bwd(conv, x)
     return conv(x)

@@ -93,3 +93,21 @@ def test_feature_pyramid_uses_the_dense_group_and_matches_the_per_level_path():
         assert _rel(a, b) < 2e-2
     for n in p1:
         assert _rel(p1[n], p0[n]) < 2e-2, n
+
+
+def test_conv3x3_gradients_on_the_dense_kernels_match_torch():
+    "Bottleneck conv2 of layer3 (256 -> 256, no bias): MIOpen forward, both gradients on the dense MFMA kernels."
+    from pytorch_retinanet_amd import biasact
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    conv = nn.Conv2d(256, 256, 3, 1, 1, bias=False).to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
+    x = torch.randn((4, 256, 50, 84), device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_()
+    dy = torch.randn((4, 256, 50, 84), device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert biasact.conv3x3_bwd_fusable(conv, x)
+    y = biasact.conv3x3_mfma_bwd(conv, x)
+    y.backward(dy)
+    dx, dw = x.grad.clone(), conv.weight.grad.clone()
+    xf, wf = x.detach().float().requires_grad_(), conv.weight.detach().float().requires_grad_()
+    yf = F.conv2d(xf, wf, None, 1, 1)
+    yf.backward(dy.float())
+    assert _rel(y, yf) < 4e-3 and _rel(dx, xf.grad) < 4e-3 and _rel(dw, wf.grad) < 4e-3, (_rel(y, yf), _rel(dx, xf.grad), _rel(dw, wf.grad))
