@@ -24,6 +24,9 @@
 // ran 5 - 17 % slower on random data -- the part holds a higher clock under the 16x16x32 shape (rocprof: same busy
 // cycles, shorter duration).  The weight-gradient kernel below was tried on 16x16x32 as well and was 5 - 9 % SLOWER
 // there (A/B on one box: towers 380 -> 398 us, class-output 955 -> 1046 us), so it keeps 32x32x16.
+// Tile rounds: 1 626 equal tiles on 256 CUs fill 6.35 rounds and take 7; running the last 90 as 180 half tiles (128 rows, 8
+// waves of 64 x 64, one extra launch) was built and tested in round 3 and changed nothing (386 -> 389 us): a half tile takes as
+// long as a full one's share of the round, i.e. the launch is bound chip-wide (power / clock), not by the per-CU tile schedule.
 // Measured on MI355X, random data, two [8,153,170,256] -> 256 towers per launch: forward 377 - 396 us (1070 - 1120 TFLOP/s
 // on the canvas positions), data gradient 356 - 370 us; MIOpen: forward 301-315 us per tower + 32 us for the separate
 // bias/ReLU/mask pass, data gradient 415 us.

@@ -376,7 +376,8 @@ def _canvas_conv_reference(x, w, b, mask2d):
     return y * mask2d[None, None].float()
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 256, 9, 11), (1, 256, 256, 14, 37), (3, 512, 256, 6, 8), (2, 256, 512, 5, 7)])
+@pytest.mark.parametrize("shape", [(2, 64, 256, 9, 11), (1, 256, 256, 14, 37), (3, 512, 256, 6, 8), (2, 256, 512, 5, 7),
+                                   (1, 256, 256, 250, 300)])      # 293 row tiles: more than one round of workgroups
 def test_mfma_canvas_conv_forward_backward_vs_torch(shape):
     """rn_conv3x3_canvas (forward + data gradient) and the MIOpen weight gradient, against torch's conv2d in fp32 on
     the same bf16 values; zero-bordered canvas with a random interior mask (gaps)."""
@@ -397,11 +398,13 @@ def test_mfma_canvas_conv_forward_backward_vs_torch(shape):
     wr = w.detach().to(torch.bfloat16).float().requires_grad_(True)       # the kernel sees the bf16-rounded weights
     br = b.detach().clone().requires_grad_(True)
     yr = _canvas_conv_reference(xr, wr, br, mask2d)
-    yr.backward(g.float())
     scale = float(yr.detach().abs().max())
-    torch.testing.assert_close(y.float(), yr, rtol=2e-2, atol=1e-2 * scale)
+    torch.testing.assert_close(y.float(), yr.detach(), rtol=2e-2, atol=1e-2 * scale)
     assert not y.float()[:, :, mask2d == 0].any()                         # border and gaps are exact zeros
-    # gradients: the ReLU decision is taken on the rounded y; skip the elements whose pre-activation is within rounding of 0
+    # gradients: through the ReLU decisions the KERNEL took (y > 0 on its bf16 output) -- a pre-activation within rounding of 0
+    # may fall on the other side in fp32, and at 75 000 positions x 256 channels a few always do
+    pre = torch.nn.functional.conv2d(xr, wr, br, padding=1)
+    (pre * (y.detach().float() > 0) * mask2d[None, None].float()).backward(g.float())
     gs = float(xr.grad.abs().max())
     interior = mask2d[None, None].bool().expand_as(xr.grad)
     torch.testing.assert_close(x.grad.float()[interior], xr.grad[interior], rtol=5e-2, atol=3e-2 * gs)
@@ -449,15 +452,15 @@ def test_head_mfma_towers_equal_miopen_towers_bf16():
         torch.testing.assert_close(outs[True][2][n].float(), a.float(), rtol=1e-1, atol=5e-2 * float(a.float().abs().max()))
 
 
-@pytest.mark.parametrize("N", [2, 3])
-def test_tower_relu_backward_fused_into_the_data_gradient_kernel(N):
+@pytest.mark.parametrize("N,shapes", [(2, [(9, 12), (5, 6), (3, 3)]), (3, [(9, 12), (5, 6), (3, 3)]),
+                                      (2, [(120, 150), (60, 75), (30, 38)])])     # 2 x ~170 row tiles: more than one round of workgroups
+def test_tower_relu_backward_fused_into_the_data_gradient_kernel(N, shapes):
     """A chain of tower_conv_pair layers with TowerLink hand-over (the ReLU backward and bias gradient of layer l - 1 ride in
     layer l's data-gradient kernel: rn_conv3x3_canvas_dgrad_relu_batched) == the same chain with the separate
     rn_bias_act_backward passes: input gradients bit-equal, weight gradients bit-equal, bias gradients to fp32 summation
     order; and a layer whose output has a second consumer falls back to the separate pass."""
     from pytorch_retinanet_amd import biasact
     torch.manual_seed(3)
-    shapes = [(9, 12), (5, 6), (3, 3)]
     feats = [torch.randn(N, 256, h, w, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for h, w in shapes]
     cv = biasact.Canvas.of(feats, pad=1)
     ws = [[(torch.randn(256, 256, 3, 3, device=DEV) * 0.02).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
@@ -498,6 +501,7 @@ def test_tower_relu_backward_fused_into_the_data_gradient_kernel(N):
                                               (2, 6, [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)], 2),   # the same, both images on one sheet
                                               (1, 90, [(13, 17), (7, 9), (4, 5)], 1),                 # Cout = 810: 4 tiles, 810 % 8 = 2
                                               (3, 90, [(13, 17), (7, 9), (4, 5)], 2),                 # odd batch: the last sheet's second slot is empty
+                                              (2, 6, [(200, 180), (8, 10)], 1),                     # ~300 row tiles: more than one round of workgroups
                                               (3, 32, [(9, 11), (5, 6), (3, 3), (2, 2), (1, 1)], 1),  # Cout = 288: 2 tiles, multiple of 8
                                               (4, 32, [(9, 11), (5, 6), (3, 3), (2, 2), (1, 1)], 2)])
 def test_cls_output_conv_on_canvas_vs_torch(N, K, shapes, slots):
