@@ -236,21 +236,29 @@ __global__ __launch_bounds__(MASK_CAP) void nms_mask_kernel(const rn::NmsLaunch 
         uint64_t rem[MASK_WORDS];
 #pragma unroll
         for (int w = 0; w < MASK_WORDS; ++w) rem[w] = 0;
+        // Only a kept row that suppresses something changes the state, so the serial chain walks those rows alone: `todo` = rows
+        // of this word with a non-empty mask row, not yet visited; each step takes the lowest one that is still alive.  (A row with
+        // an empty mask row is kept or dropped by what is in `rem` when the scan ends -- nothing to do for it.)  With ~120 boxes
+        // per segment and a handful of overlapping pairs this is a few steps instead of one per box.
 #pragma unroll
         for (int w = 0; w < MASK_WORDS; ++w) {
-            const int i0 = w * 64;
-            if (i0 < n) {
-                const int cnt = min(64, n - i0);
-                for (int bit = 0; bit < cnt; ++bit) {
-                    if (!((rem[w] >> bit) & 1ull)) {
+            if (w * 64 < n) {
+                uint64_t any = 0;
 #pragma unroll
-                        for (int ww = 0; ww < MASK_WORDS; ++ww)
-                            if (ww >= w) {
-                                const unsigned lo = __builtin_amdgcn_readlane((unsigned)row[w][ww], bit);
-                                const unsigned hi = __builtin_amdgcn_readlane((unsigned)(row[w][ww] >> 32), bit);
-                                rem[ww] |= ((uint64_t)hi << 32) | lo;
-                            }
-                    }
+                for (int ww = 0; ww < MASK_WORDS; ++ww) if (ww >= w) any |= row[w][ww];
+                uint64_t todo = __ballot(any != 0ull);
+                while (true) {
+                    const uint64_t live = todo & ~rem[w];
+                    if (!live) break;
+                    const int bit = __builtin_ctzll(live);
+#pragma unroll
+                    for (int ww = 0; ww < MASK_WORDS; ++ww)
+                        if (ww >= w) {
+                            const unsigned lo = __builtin_amdgcn_readlane((unsigned)row[w][ww], bit);
+                            const unsigned hi = __builtin_amdgcn_readlane((unsigned)(row[w][ww] >> 32), bit);
+                            rem[ww] |= ((uint64_t)hi << 32) | lo;
+                        }
+                    todo &= ~((2ull << bit) - 1ull);                 // rows up to `bit` are done
                 }
             }
         }
