@@ -252,6 +252,12 @@ typedef struct rn_pw_epilogue {
     const uint8_t *rbits;
     const void *zprev;
     const float *ea, *eb, *emean, *einv;
+    /* RN_PW_EPI_RESID: rbits may be NULL (y += resid, no mask).  res_stride == 2: resid lives on the stride-2 grid
+     * [n][ceil(res_h / 2)][ceil(res_w / 2)][N] of the output grid [n][res_h][res_w] and is added at the rows with even
+     * (y, x) only -- the data gradient of a 1x1 / stride-2 convolution (the bottleneck's downsample branch,
+     * /root/reference/retinanet/backbone.py:179-186) joining conv1's data gradient without being scattered first.
+     * 0 / 1: resid is [M][N] like y. */
+    int32_t res_stride, res_h, res_w;
 } rn_pw_epilogue;
 int rn_pw_walkers(int64_t M);
 int rn_pw_conv_forward(const rn_pw_conv *d, const void *x, const void *w, void *y, const rn_pw_prologue *pro,

@@ -40,7 +40,8 @@ class RnPwPrologue(C.Structure):
 
 class RnPwEpilogue(C.Structure):
     _fields_ = [("kind", C.c_int32), ("partial", C.c_void_p), ("resid", C.c_void_p), ("rbits", C.c_void_p), ("zprev", C.c_void_p),
-                ("ea", C.c_void_p), ("eb", C.c_void_p), ("emean", C.c_void_p), ("einv", C.c_void_p)]
+                ("ea", C.c_void_p), ("eb", C.c_void_p), ("emean", C.c_void_p), ("einv", C.c_void_p),
+                ("res_stride", C.c_int32), ("res_h", C.c_int32), ("res_w", C.c_int32)]
 
 
 RN_PW_PRO_NONE, RN_PW_PRO_AFFINE_RELU, RN_PW_PRO_BN_BWD = 0, 1, 2

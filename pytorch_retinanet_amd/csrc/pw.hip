@@ -44,8 +44,10 @@ struct PwArgs {
     const float *pa, *pb, *pc;      // AFFINE_RELU: y = relu(x * pa + pb);  BN_BWD: dz = pa * g' + pc * z + pb   (a, k0, k1)
     const float *fa, *fb;           // BN_BWD, relu_mode 2: g' = g * [fma(z, fa, fb) > alive]
     float *partial;                 // EPI_STATS / EPI_RELU_BWD: [gx][2][N]
-    const uint16_t *R;              // EPI_RESID: Y += R * rbits   ([M][N] and [M][N / 8])
+    const uint16_t *R;              // EPI_RESID: Y += R * rbits   ([M][N] and [M][N / 8]; rbits null: Y += R)
     const uint8_t *rbits;
+    int rs, rH, rW;                 // rs == 2: R lives on the stride-2 grid [n][ceil(rH / 2)][ceil(rW / 2)] of the output grid [n][rH][rW] and
+                                    //          joins the rows with even (y, x) only (the data gradient of a 1x1 / stride-2 convolution)
     const uint16_t *Zp;             // EPI_RELU_BWD: Y = Y * [fma(Zp, ea, eb) > alive]; sums of Y and Y * (Zp - emean) * einv
     const float *ea, *eb, *emean, *einv;
     int M, Cin, N, taps;            // M output rows; K = taps * Cin
@@ -239,10 +241,17 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
             if (EPI & (EPI_RESID | EPI_RELU_BWD)) {
 #pragma unroll
                 for (int i = 0; i < EROWS; ++i) {
-                    const int m = m0 + erl + i * RL;
-                    const int64_t e = (int64_t)(m < a.M ? m : a.M - 1) * a.N + n0 + ecg * 8;
-                    er[i] = *(const rn::u32x4 *)(((EPI & EPI_RESID) ? a.R : a.Zp) + e);
-                    ebits[i] = (EPI & EPI_RESID) ? a.rbits[e >> 3] : 0u;
+                    const int m = m0 + erl + i * RL, mc = m < a.M ? m : a.M - 1;
+                    int64_t e = (int64_t)mc * a.N + n0 + ecg * 8;
+                    bool on = true;
+                    if ((EPI & EPI_RESID) && a.rs == 2) {
+                        const int hw = a.rH * a.rW, n = mc / hw, rem = mc - n * hw, y = rem / a.rW, x = rem - y * a.rW;
+                        on = ((y | x) & 1) == 0;
+                        e = (((int64_t)n * ((a.rH + 1) >> 1) + (y >> 1)) * ((a.rW + 1) >> 1) + (x >> 1)) * a.N + n0 + ecg * 8;
+                    }
+                    const rn::u32x4 zero4 = {0u, 0u, 0u, 0u};
+                    er[i] = on ? *(const rn::u32x4 *)(((EPI & EPI_RESID) ? a.R : a.Zp) + e) : zero4;
+                    ebits[i] = (EPI & EPI_RESID) ? (on ? (a.rbits ? (uint32_t)a.rbits[e >> 3] : 0xffu) : 0u) : 0u;
                 }
             }
         };
@@ -675,7 +684,15 @@ RN_API int rn_pw_conv_forward(const rn_pw_conv *d, const void *x, const void *w,
     if (epi && epi->kind != 0) {
         e = epi->kind;
         if (e == EPI_STATS) { if (!epi->partial) return RN_EINVAL; a.partial = epi->partial; }
-        else if (e == EPI_RESID) { if (!epi->resid || !epi->rbits) return RN_EINVAL; a.R = (const uint16_t *)epi->resid; a.rbits = epi->rbits; }
+        else if (e == EPI_RESID) {
+            if (!epi->resid) return RN_EINVAL;
+            if (epi->res_stride != 0 && epi->res_stride != 1 && epi->res_stride != 2) return RN_EUNSUPPORTED;
+            a.R = (const uint16_t *)epi->resid; a.rbits = epi->rbits; a.rs = epi->res_stride == 2 ? 2 : 1;
+            if (a.rs == 2) {
+                if (epi->res_h <= 0 || epi->res_w <= 0 || d->M % ((int64_t)epi->res_h * epi->res_w)) return RN_EINVAL;
+                a.rH = epi->res_h; a.rW = epi->res_w;
+            }
+        }
         else if (e == EPI_RELU_BWD) {
             if (!epi->partial || !epi->zprev || !epi->ea || !epi->eb || !epi->emean || !epi->einv) return RN_EINVAL;
             a.partial = epi->partial; a.Zp = (const uint16_t *)epi->zprev; a.ea = epi->ea; a.eb = epi->eb; a.emean = epi->emean; a.einv = epi->einv;

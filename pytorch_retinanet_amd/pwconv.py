@@ -263,14 +263,19 @@ class _BottleneckFn(torch.autograd.Function):
                                          wn, st), "rn_bn_act_backward")
             dgd, dbd = grd[:C4], grd[C4:2 * C4]
             dwd = pw_wgrad(dzd, x, wd, stride=dn[0].stride[0], tag="pw_down_wgrad")
-            if dn[0].stride[0] == 1:
-                wdt = wd.reshape(C4, Cin).t().contiguous().view(Cin, C4, 1, 1)
-                dxd = pw_forward(dzd, wdt, tag="pw_down_dgrad")
+            # the downsample branch's data gradient is a GEMM on ITS grid (the stride-2 grid of x for layer2 .. layer4's first
+            # blocks) and joins conv1's data gradient in that GEMM's epilogue -- no scatter into a zero-filled tensor (MIOpen's
+            # strided data gradient) and no add pass over the block's largest tensor (0.14 + 0.03 ms per step at the bench shape)
+            sd = dn[0].stride[0]
+            wdt = wd.reshape(C4, Cin).t().contiguous().view(Cin, C4, 1, 1)
+            dxd = pw_forward(dzd, wdt, tag="pw_down_dgrad")
+            if sd in (1, 2):
+                epi1 = RnPwEpilogue(RN_PW_EPI_RESID, 0, dxd.data_ptr(), 0, 0, 0, 0, 0, 0, sd, x.shape[2], x.shape[3])
+                dx = pw_forward(dz1, w1t, epi=epi1, tag="pw_conv1_dgrad")
             else:
-                dxd = torch.ops.aten.convolution_backward(dzd, x, wd, None, list(dn[0].stride), [0, 0], [1, 1], False, [0, 0], 1,
-                                                          [True, False, False])[0]
-            dx = pw_forward(dz1, w1t, tag="pw_conv1_dgrad")
-            dx = dx + dxd
+                full = torch.zeros_like(x)
+                full[:, :, ::sd, ::sd] = dxd
+                dx = pw_forward(dz1, w1t, tag="pw_conv1_dgrad") + full
         dw1 = pw_wgrad(dz1, x, w1, tag="pw_conv1_wgrad")
         return (None, dx, dw1, gr1[:Cm], gr1[Cm:2 * Cm], dw2, gr2[:Cm], gr2[Cm:2 * Cm], dw3, gr3[:C4], gr3[C4:2 * C4], dwd, dgd, dbd)
 

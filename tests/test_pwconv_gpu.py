@@ -146,6 +146,30 @@ def test_data_gradient_with_residual_epilogue():
     _close(dx.float().permute(0, 2, 3, 1).reshape(M, cin), ref, 1e-2, "data gradient + residual")
 
 
+@pytest.mark.parametrize("H,W,cm,cin", [(19, 23, 64, 256), (20, 24, 128, 256), (1, 7, 64, 64)])
+def test_data_gradient_joined_by_the_stride2_downsample_gradient(H, W, cm, cin):
+    """conv1's data gradient of a bottleneck with a 1x1 / stride-2 downsample branch: the branch's data gradient, a GEMM on the
+    stride-2 grid, is added at the rows with even (y, x) in the epilogue (no mask) == conv1 dgrad + the scattered gradient."""
+    from pytorch_retinanet_amd import pwconv
+    from pytorch_retinanet_amd._lib import RN_PW_EPI_RESID, RnPwEpilogue
+    N = 2
+    dz1 = _rand((N, cm, H, W), 1.0, 1)
+    w1t = _rand((cin, cm, 1, 1), 0.05, 2)
+    Hc, Wc = (H + 1) // 2, (W + 1) // 2
+    dxd = _rand((N, cin, Hc, Wc), 1.0, 3)
+    M = N * H * W
+    for sd, res in ((2, dxd), (1, _rand((N, cin, H, W), 1.0, 5))):
+        epi = RnPwEpilogue(RN_PW_EPI_RESID, 0, res.data_ptr(), 0, 0, 0, 0, 0, 0, sd, H, W)
+        dx = pwconv.pw_forward(dz1, w1t, epi=epi)
+        full = torch.zeros((N, cin, H, W), device=DEV)
+        if sd == 2:
+            full[:, :, ::2, ::2] = res.float()
+        else:
+            full = res.float()
+        ref = (dz1.float().permute(0, 2, 3, 1).reshape(M, cm) @ w1t.float().view(cin, cm).t()).view(N, H, W, cin).permute(0, 3, 1, 2) + full
+        _close(dx.float(), ref, 1e-2, f"data gradient + stride-{sd} branch gradient")
+
+
 @pytest.mark.parametrize("n_out,cin,k,stride", [(64, 256, 1, 1), (256, 64, 1, 1), (128, 512, 1, 1), (512, 128, 1, 1), (64, 64, 3, 1), (128, 128, 3, 2),
                                                (512, 256, 1, 2), (256, 1024, 1, 1), (2048, 512, 1, 1)])
 def test_weight_gradient_plain(n_out, cin, k, stride):
