@@ -210,6 +210,12 @@ int rn_bn_stats_finalize(const float *partial, int nblocks, int64_t M, int C, co
                          float *save_mean, float *save_invstd, float *coef, void *stream);
 int rn_bn_apply(const void *x, const void *residual, void *y, int dtype, int64_t M, int C, const float *coef, int relu,
                 uint8_t *relu_mask, void *stream);
+/* rn_bn_apply with relu = 1 whose residual is itself a BatchNorm output that was never written: `residual` holds that
+ * layer's INPUT and res_coef [2][C] its coefficients; y = relu(x * a + b + round(residual * ra + rb)) -- the value a
+ * separate rn_bn_apply pass would have stored (the downsample branch of a bottleneck,
+ * /root/reference/retinanet/backbone.py:122-136). */
+int rn_bn_apply_res_affine(const void *x, const void *residual, const float *res_coef, void *y, int dtype, int64_t M, int C,
+                           const float *coef, uint8_t *relu_mask, void *stream);
 int rn_bn_bwd_reduce(const void *dy, const void *y, const void *x, int dtype, int64_t M, int C, const float *gamma,
                      const float *save_mean, const float *save_invstd, const float *fwd_coef, int training, int relu,
                      float *dgamma, float *dbeta, float *coef3, void *workspace, size_t workspace_bytes, void *stream);

@@ -81,6 +81,7 @@ SIGNATURES = {
     "rn_bn_stats": (C.c_int, [_vp, C.c_int, _i64, C.c_int, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rn_bn_stats_finalize": (C.c_int, [_vp, C.c_int, _i64, C.c_int, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp]),
     "rn_bn_apply": (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp, C.c_int, _vp, _vp]),
+    "rn_bn_apply_res_affine": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp, _vp, _vp]),
     "rn_bn_bwd_reduce": (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rn_bn_bwd_finalize": (C.c_int, [_vp, C.c_int, _i64, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "rn_bn_bwd_apply": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _i64, C.c_int, _vp, _vp, C.c_int, _vp]),

@@ -254,22 +254,43 @@ template <> __device__ __forceinline__ float relu_alive_threshold<RN_F32>() { re
 template <> __device__ __forceinline__ float relu_alive_threshold<RN_BF16>() { return __uint_as_float(0x00004000u); }   // 2^-134: half the smallest bf16 subnormal (ties to even -> 0)
 template <> __device__ __forceinline__ float relu_alive_threshold<RN_F16>() { return __uint_as_float(0x33000000u); }    // 2^-25: half the smallest f16 subnormal
 
+// value of f after a store in DT and a load back
+template <int DT> __device__ __forceinline__ float round_dt(const float f);
+template <> __device__ __forceinline__ float round_dt<RN_F32>(const float f) { return f; }
+template <> __device__ __forceinline__ float round_dt<RN_BF16>(const float f) { return __uint_as_float(rn::dt<RN_BF16>::pk(f, 0.0f) << 16); }
+template <> __device__ __forceinline__ float round_dt<RN_F16>(const float f) { return (float)(_Float16)f; }
+
 // ---------------------------------------------------------------- forward apply: y = act(x*a + b (+ res))
-template <int DT, bool RELU, bool RES>
+// RA (with RES): the residual is itself a BatchNorm output that was never written -- res holds that layer's INPUT and
+// (res_a, res_b) its coefficients; the value added is round_DT(fma(res, res_a, res_b)), exactly what a separate apply pass
+// would have stored (the downsample branch of a bottleneck: one pass over the block's largest tensor less, read + write).
+template <int DT, bool RELU, bool RES, bool RA = false>
 __global__ __launch_bounds__(BN_BLOCK) void bn_apply_kernel(const void *__restrict__ x, const void *__restrict__ res, void *__restrict__ y,
                                                             const int64_t nvec, const int C8, const float *__restrict__ coef_a,
-                                                            const float *__restrict__ coef_b, uint8_t *__restrict__ relu_mask)
+                                                            const float *__restrict__ coef_b, uint8_t *__restrict__ relu_mask,
+                                                            const float *__restrict__ res_a = nullptr, const float *__restrict__ res_b = nullptr)
 {
     const float alive = relu_alive_threshold<DT>();
     // C8 | 256 (every ResNet width): a thread always lands on the same channel group -> coefficients in registers
     const bool fixed = (BN_BLOCK % C8) == 0;
-    float a[8], b[8];
-    if (fixed) { vec8<RN_F32>::ld(coef_a, threadIdx.x % C8, a); vec8<RN_F32>::ld(coef_b, threadIdx.x % C8, b); }
+    float a[8], b[8], ra[8], rb[8];
+    if (fixed) {
+        vec8<RN_F32>::ld(coef_a, threadIdx.x % C8, a); vec8<RN_F32>::ld(coef_b, threadIdx.x % C8, b);
+        if (RA) { vec8<RN_F32>::ld(res_a, threadIdx.x % C8, ra); vec8<RN_F32>::ld(res_b, threadIdx.x % C8, rb); }
+    }
     for (int64_t v = (int64_t)blockIdx.x * BN_BLOCK + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * BN_BLOCK) {
         float f[8], r[8];
         vec8<DT>::ld(x, v, f);
         if (RES) vec8<DT>::ld(res, v, r);
-        if (!fixed) { const int cg = (int)(v % C8); vec8<RN_F32>::ld(coef_a, cg, a); vec8<RN_F32>::ld(coef_b, cg, b); }
+        if (!fixed) {
+            const int cg = (int)(v % C8);
+            vec8<RN_F32>::ld(coef_a, cg, a); vec8<RN_F32>::ld(coef_b, cg, b);
+            if (RA) { vec8<RN_F32>::ld(res_a, cg, ra); vec8<RN_F32>::ld(res_b, cg, rb); }
+        }
+        if (RA) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = round_dt<DT>(fmaf(r[j], ra[j], rb[j]));
+        }
         unsigned bits = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -496,11 +517,22 @@ int stats_final_launch(const float *partial, int nb, int64_t M, int C, const flo
 }
 
 int apply_launch(const void *x, const void *residual, void *y, int dtype, int64_t M, int C, const float *ca, const float *cb, int relu,
-                 uint8_t *relu_mask, hipStream_t st)
+                 uint8_t *relu_mask, hipStream_t st, const float *res_a = nullptr, const float *res_b = nullptr)
 {
     const int64_t nvec = M * (C / 8);
     const dim3 g(apply_blocks(nvec)), b(BN_BLOCK);
     const int C8 = C / 8;
+    if (res_a) {                                                     // residual = an unwritten BatchNorm output (ReLU form only)
+#define RN_BN_APPLY_RA(DT) hipLaunchKernelGGL((bn_apply_kernel<DT, true, true, true>), g, b, 0, st, x, residual, y, nvec, C8, ca, cb, relu_mask, res_a, res_b);
+        switch (dtype) {
+            case RN_F32: RN_BN_APPLY_RA(RN_F32) break;
+            case RN_BF16: RN_BN_APPLY_RA(RN_BF16) break;
+            default: RN_BN_APPLY_RA(RN_F16) break;
+        }
+#undef RN_BN_APPLY_RA
+        RN_LAUNCH_CHECK();
+        return RN_OK;
+    }
 #define RN_BN_APPLY(DT)                                                                                                          \
     if (relu) { if (residual) hipLaunchKernelGGL((bn_apply_kernel<DT, true, true>), g, b, 0, st, x, residual, y, nvec, C8, ca, cb, relu_mask);    \
                 else hipLaunchKernelGGL((bn_apply_kernel<DT, true, false>), g, b, 0, st, x, residual, y, nvec, C8, ca, cb, relu_mask); }           \
@@ -614,6 +646,16 @@ RN_API int rn_bn_apply(const void *x, const void *residual, void *y, int dtype, 
     if (!dtype_ok(dtype)) return RN_EINVAL;
     if (!rn::aligned(x, 16) || !rn::aligned(y, 16) || (residual && !rn::aligned(residual, 16)) || !rn::aligned(coef, 16)) return RN_EALIGN;
     return apply_launch(x, residual, y, dtype, M, C, coef, coef + C, relu, relu_mask, (hipStream_t)stream);
+}
+
+RN_API int rn_bn_apply_res_affine(const void *x, const void *residual, const float *res_coef, void *y, int dtype, int64_t M, int C,
+                                  const float *coef, uint8_t *relu_mask, void *stream)
+{
+    if (!x || !y || !coef || !residual || !res_coef || M <= 0 || C <= 0) return RN_EINVAL;
+    if (C % 8) return RN_EUNSUPPORTED;
+    if (!dtype_ok(dtype)) return RN_EINVAL;
+    if (!rn::aligned(x, 16) || !rn::aligned(y, 16) || !rn::aligned(residual, 16) || !rn::aligned(coef, 16) || !rn::aligned(res_coef, 16)) return RN_EALIGN;
+    return apply_launch(x, residual, y, dtype, M, C, coef, coef + C, 1, relu_mask, (hipStream_t)stream, res_coef, res_coef + C);
 }
 
 RN_API int rn_bn_act_forward(const void *x, const void *residual, void *y, int dtype, int64_t M, int C,

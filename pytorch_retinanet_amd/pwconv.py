@@ -151,11 +151,19 @@ def bn_stats(x: Tensor, bn) -> Tensor:
     return stats
 
 
-def bn_apply(x: Tensor, stats: Tensor, relu: bool, residual: Optional[Tensor] = None, want_bits: bool = False):
+def bn_apply(x: Tensor, stats: Tensor, relu: bool, residual: Optional[Tensor] = None, want_bits: bool = False,
+             res_stats: Optional[Tensor] = None):
+    "``res_stats``: the residual is the INPUT of another BatchNorm whose statistics these are (its output is formed on the fly)."
     Nimg, Cc, H, W = x.shape
     M = Nimg * H * W
     y = torch.empty_like(x)
     bits = torch.empty((M * Cc // 8,), dtype=torch.uint8, device=x.device) if want_bits else None
+    if res_stats is not None:
+        assert relu and residual is not None
+        check(lib.rn_bn_apply_res_affine(x.data_ptr(), residual.data_ptr(), res_stats.data_ptr() + 8 * Cc, y.data_ptr(), RN_BF16, M, Cc,
+                                         stats.data_ptr() + 8 * Cc, bits.data_ptr() if bits is not None else 0, _stream(x.device)),
+              "rn_bn_apply_res_affine")
+        return y, bits
     check(lib.rn_bn_apply(x.data_ptr(), residual.data_ptr() if residual is not None else 0, y.data_ptr(), RN_BF16, M, Cc,
                           stats.data_ptr() + 8 * Cc, int(relu), bits.data_ptr() if bits is not None else 0, _stream(x.device)), "rn_bn_apply")
     return y, bits
@@ -192,10 +200,10 @@ class _BottleneckFn(torch.autograd.Function):
             ed, pd, nbd = stats_epilogue(M1, wd.shape[0], dev)
             zd = pw_forward(x, wd, stride=blk.downsample[0].stride[0], epi=ed, tag="pw_down_fwd")
             std = bn_finalize(pd, nbd, M1, blk.downsample[1])
-            idt, _ = bn_apply(zd, std, relu=False)
+            # the branch's BatchNorm output is never written: the block-output pass forms it from zd and its coefficients
+            out, bits = bn_apply(z3, st3, relu=True, residual=zd, res_stats=std, want_bits=True)
         else:
-            idt = x
-        out, bits = bn_apply(z3, st3, relu=True, residual=idt, want_bits=True)
+            out, bits = bn_apply(z3, st3, relu=True, residual=x, want_bits=True)
         ctx.save_for_backward(x, w1, g1, w2, g2, w3, g3, wd, gd, z1, a1, z2, z3, zd, bits, st1, st2, st3, std)
         ctx.blk = blk
         return out
