@@ -273,6 +273,19 @@ int rn_pw_conv_wgrad(const rn_pw_conv *d, const void *g, const void *x, void *dw
                      const rn_pw_prologue *xpro, void *workspace, size_t workspace_bytes, void *stream);
 
 
+/* ---- the ResNet stem convolution (7x7 / stride 2 / pad 3, 3 -> 64 channels, bias-free) -------------------------------
+ * Replaces `self.conv1` of /root/reference/retinanet/backbone.py:152 (applied at :246) for bf16 channels-last tensors.
+ *   x  [B][H][W][3] bf16 (channels-last memory of [B, 3, H, W]),  w [64][7][7][3] bf16 (channels-last memory of [64, 3, 7, 7]),
+ *   y  [B][Ho][Wo][64] bf16, Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1.
+ * xp: scratch of rn_stem_padded_bytes(B, H, W) bytes (the zero-bordered NHWC4 copy of x the MFMA kernel reads),
+ * wk: scratch of 64 * 7 * 32 * 2 bytes (the weights in the kernel's k order); both are rewritten by every call.
+ * partial (nullable): f32 [rn_stem_partial_rows(B, H, W)][2][64] = per-workgroup sum / sum of squares of the STORED
+ * (bf16-rounded) outputs, the input of rn_bn_stats_finalize for the BatchNorm that follows (backbone.py:153). */
+size_t rn_stem_padded_bytes(int B, int H, int W);
+int rn_stem_partial_rows(int B, int H, int W);
+int rn_stem_conv_forward(const void *x, const void *w, void *xp, void *wk, void *y, float *partial, int dtype, int B, int H, int W,
+                         void *stream);
+
 /* ---- K4 decode_clip ---------------------------------------------------------
  * Replaces activ_2_bbox, retinanet/box_utils.py:37-48 (including its use of
  * dx,dy for the sizes, :46) and torchvision clip_boxes_to_image at

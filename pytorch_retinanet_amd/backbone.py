@@ -239,7 +239,10 @@ class ResNetBackbone(nn.Module):
         return nn.Sequential(*stack)
 
     def _forward_impl(self, x: Tensor) -> Dict[str, Tensor]:
-        x = self.maxpool(conv_bn(self.conv1, self.bn1, x, relu=True))
+        if pwconv.stem_fusable(self.conv1, self.bn1, x):     # training, bf16: the MFMA stem kernel with bn1's statistics in its epilogue
+            x = self.maxpool(pwconv.stem(self.conv1, self.bn1, x))
+        else:
+            x = self.maxpool(conv_bn(self.conv1, self.bn1, x, relu=True))
         x = self.layer1(x)
         c3 = self.layer2(x)
         c4 = self.layer3(c3)

@@ -387,3 +387,69 @@ def conv1x1(conv, x: Tensor) -> Tensor:
     if biasact.conv3x3_bwd_fusable(conv, x):        # 3x3 / 256 -> 256 (layer3's conv2): MIOpen forward, gradients on csrc/conv.hip
         return biasact.conv3x3_mfma_bwd(conv, x)
     return conv(x)
+
+
+# ---- the stem: conv 7x7 / stride 2 (3 -> 64) + BatchNorm (batch statistics) + ReLU on csrc/stem.hip ---------------------------------
+FUSED_STEM = True
+_STEM_WS: Dict[tuple, Tuple[Tensor, Tensor]] = {}
+
+
+def stem_fusable(conv, bn, x: Tensor) -> bool:
+    return (FUSED_STEM and x.is_cuda and x.dtype == torch.bfloat16 and _cl(x) and torch.is_grad_enabled() and x.shape[1] == 3 and
+            conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.dilation == (1, 1) and
+            conv.groups == 1 and conv.bias is None and conv.out_channels == 64 and conv.weight.dtype == torch.bfloat16 and
+            bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None and bn.weight.dtype == torch.float32 and
+            x.shape[0] * (x.shape[2] + 6) * (x.shape[3] + 8) < (1 << 31))
+
+
+class _StemFn(torch.autograd.Function):
+    """``relu(bn(conv7x7s2(x)))`` in training mode on bf16 channels-last tensors: the MFMA stem kernel with the BatchNorm statistics
+    in its epilogue (``rn_stem_conv_forward``), the finalize step, one apply pass; backward: the BatchNorm backward pair, the weight
+    gradient (MIOpen for now); the image gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, bn, x, w, gamma, beta):
+        B, _, H, W = x.shape
+        dev = x.device
+        st = _stream(dev)
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        key = (dev.index, st, B, H, W)
+        ws = _STEM_WS.get(key)
+        if ws is None:
+            ws = _STEM_WS[key] = (torch.empty((lib.rn_stem_padded_bytes(B, H, W),), dtype=torch.uint8, device=dev),
+                                  torch.empty((64 * 7 * 32,), dtype=torch.bfloat16, device=dev))
+        wc = w if _cl(w) else w.contiguous(memory_format=torch.channels_last)
+        z = torch.empty((B, 64, Ho, Wo), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+        nb = lib.rn_stem_partial_rows(B, H, W)
+        partial = torch.empty((nb * 2 * 64,), dtype=torch.float32, device=dev)
+        PW_FLOP["stem_fwd"] = 2.0 * B * Ho * Wo * 64 * 147
+        with _timed("stem_fwd", dev):
+            check(lib.rn_stem_conv_forward(x.data_ptr(), wc.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), z.data_ptr(), partial.data_ptr(),
+                                           RN_BF16, B, H, W, st), "rn_stem_conv_forward")
+        stats = bn_finalize(partial, nb, B * Ho * Wo, bn)
+        a, _ = bn_apply(z, stats, relu=True)
+        ctx.save_for_backward(x, wc, gamma, z, stats)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        x, w, gamma, z, stats = ctx.saved_tensors
+        dev = z.device
+        st = _stream(dev)
+        Cc = 64
+        M = z.shape[0] * z.shape[2] * z.shape[3]
+        if not (da.dtype == torch.bfloat16 and _cl(da)):
+            da = da.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        gr = torch.empty((5 * Cc,), dtype=torch.float32, device=dev)
+        dz = torch.empty_like(z)
+        sp = stats.data_ptr()
+        wp, wn = norm._workspace(dev, st, Cc)
+        check(lib.rn_bn_act_backward(da.data_ptr(), 0, z.data_ptr(), dz.data_ptr(), 0, RN_BF16, M, Cc, gamma.data_ptr(), sp, sp + 4 * Cc,
+                                     sp + 8 * Cc, 1, 1, gr.data_ptr(), gr.data_ptr() + 4 * Cc, gr.data_ptr() + 8 * Cc, wp, wn, st),
+              "rn_bn_act_backward")
+        dw = torch.ops.aten.convolution_backward(dz, x, w, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        return None, None, dw, gr[:Cc], gr[Cc:2 * Cc]
+
+
+def stem(conv, bn, x: Tensor) -> Tensor:
+    return _StemFn.apply(bn, x, conv.weight, bn.weight, bn.bias)

@@ -283,3 +283,54 @@ def test_fused_bottleneck_is_as_close_to_fp32_as_the_layer_by_layer_block(inplan
             assert int(res[True][3][n]) == int(a) == 1
         else:
             torch.testing.assert_close(res[True][3][n], a, rtol=1e-3, atol=1e-3 * float(a.abs().max()) + 1e-5, msg=n)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 37, 53), (3, 32, 1000), (1, 7, 7)])
+def test_stem_conv_forward_and_statistics(B, H, W):
+    """rn_stem_conv_forward (7x7 / stride 2 / pad 3, 3 -> 64, the zero-bordered NHWC4 copy + MFMA kernel) against torch's fp32
+    convolution of the same bf16 values; the statistics partials against the sums of the stored output."""
+    import ctypes as C
+    from pytorch_retinanet_amd._lib import RN_BF16, check, lib
+    x = _rand((B, 3, H, W), 1.0, 1)
+    w = _rand((64, 3, 7, 7), 0.1, 2)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    xp = torch.empty((lib.rn_stem_padded_bytes(B, H, W),), dtype=torch.uint8, device=DEV)
+    wk = torch.empty((64 * 7 * 32,), dtype=torch.bfloat16, device=DEV)
+    z = torch.empty((B, 64, Ho, Wo), dtype=torch.bfloat16, device=DEV, memory_format=torch.channels_last)
+    nb = lib.rn_stem_partial_rows(B, H, W)
+    part = torch.full((nb * 2 * 64,), float("nan"), device=DEV)
+    check(lib.rn_stem_conv_forward(x.data_ptr(), w.data_ptr(), xp.data_ptr(), wk.data_ptr(), z.data_ptr(), part.data_ptr(), RN_BF16, B, H, W,
+                                   torch.cuda.current_stream().cuda_stream), "rn_stem_conv_forward")
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), None, 2, 3)
+    assert tuple(z.shape) == tuple(ref.shape)
+    _close(z.float(), ref, 1e-2, "stem conv")
+    assert float((z.float() - ref).abs().max()) < 0.02 * float(ref.abs().max())
+    sums = part.view(nb, 2, 64).double().sum(0)
+    zz = z.float().permute(0, 2, 3, 1).reshape(-1, 64).double()
+    np.testing.assert_allclose(sums[0].cpu().numpy(), zz.sum(0).cpu().numpy(), rtol=1e-4, atol=1e-3 * float(zz.abs().sum(0).max()))
+    np.testing.assert_allclose(sums[1].cpu().numpy(), (zz * zz).sum(0).cpu().numpy(), rtol=1e-4)
+
+
+def test_stem_function_matches_the_layer_by_layer_path():
+    "backbone stem in training mode: _StemFn (conv + statistics epilogue + apply) vs conv_bn on MIOpen + the BatchNorm kernels."
+    from pytorch_retinanet_amd import backbone, pwconv
+    torch.manual_seed(2)
+    outs = {}
+    for flag in (True, False):
+        pwconv.FUSED_STEM = flag
+        try:
+            torch.manual_seed(5)
+            net = backbone.resnet18(pretrained=False).to(DEV).to(memory_format=torch.channels_last)
+            net.conv1.weight.data = net.conv1.weight.data.to(torch.bfloat16)
+            net.train()
+            x = _rand((2, 3, 96, 128), 1.0, 7)
+            assert pwconv.stem_fusable(net.conv1, net.bn1, x) == flag
+            y = pwconv.stem(net.conv1, net.bn1, x) if flag else backbone.conv_bn(net.conv1, net.bn1, x, relu=True)
+            (y.float() ** 2).mean().backward()
+            outs[flag] = (y.detach().float(), net.conv1.weight.grad.float().clone(), net.bn1.weight.grad.clone(), net.bn1.bias.grad.clone(),
+                          net.bn1.running_mean.clone(), net.bn1.running_var.clone())
+        finally:
+            pwconv.FUSED_STEM = True
+    names = ("output", "conv weight gradient", "bn weight gradient", "bn bias gradient", "running mean", "running var")
+    for n, a, b in zip(names, outs[True], outs[False]):
+        _close(a, b, 2e-2, n)
