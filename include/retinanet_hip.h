@@ -285,6 +285,12 @@ size_t rn_stem_padded_bytes(int B, int H, int W);
 int rn_stem_partial_rows(int B, int H, int W);
 int rn_stem_conv_forward(const void *x, const void *w, void *xp, void *wk, void *y, float *partial, int dtype, int B, int H, int W,
                          void *stream);
+/* Its weight gradient: dw [64][7][7][3] bf16 (channels-last memory of a [64, 3, 7, 7] gradient) from g = the gradient at the
+ * conv output [B][Ho][Wo][64] bf16 and the padded copy xp that rn_stem_conv_forward wrote for the same x (the image itself is
+ * not read again).  workspace: rn_stem_wgrad_workspace_bytes(B, H, W) bytes of f32 partials. */
+size_t rn_stem_wgrad_workspace_bytes(int B, int H, int W);
+int rn_stem_conv_wgrad(const void *g, const void *xp, void *dw, int dtype, int B, int H, int W, void *workspace,
+                       size_t workspace_bytes, void *stream);
 
 /* ---- K4 decode_clip ---------------------------------------------------------
  * Replaces activ_2_bbox, retinanet/box_utils.py:37-48 (including its use of

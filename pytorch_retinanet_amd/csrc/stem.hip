@@ -33,14 +33,16 @@ struct StemPadArgs {
 // one thread = one padded pixel (8 bytes)
 __global__ __launch_bounds__(256) void stem_pad_kernel(const StemPadArgs a)
 {
-    const int64_t total = (int64_t)a.B * a.Hp2 * a.Wpp;
+    // (+ 2 rows of slack behind the last image, zeroed: the kernels' masked lanes read there, and the weight gradient multiplies
+    // what they read by zeros -- it must be finite)
+    const int64_t total = ((int64_t)a.B * a.Hp2 + 2) * a.Wpp;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int xq = (int)(i % a.Wpp);
         const int64_t rowid = i / a.Wpp;
         const int yq = (int)(rowid % a.Hp2), b = (int)(rowid / a.Hp2);
         const int xs = xq - 3, ys = yq - 3;
         rn::u32x2 o = {0u, 0u};
-        if (xs >= 0 && xs < a.W && ys >= 0 && ys < a.H) {
+        if (b < a.B && xs >= 0 && xs < a.W && ys >= 0 && ys < a.H) {
             const uint16_t *p = a.x + (((int64_t)b * a.H + ys) * a.W + xs) * 3;
             o.x = (uint32_t)p[0] | ((uint32_t)p[1] << 16);
             o.y = (uint32_t)p[2];
@@ -199,6 +201,153 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_fwd_kernel(const StemArgs a
     }
 }
 
+// ---- weight gradient -----------------------------------------------------------------------------------------------------------
+// dW[ch][r][k] = sum over output pixels of G[px][ch] * xp[2 yo + r][2 xo .. ][k]   (k = 4 * tap pixel + channel, as above).
+// The contraction index is the output pixel, so BOTH MFMA operands are pixel-strided in memory; they are staged as they lie --
+// a stage = 64 consecutive output pixels of one row: the 64 x 64 gradient rows and, per kernel row r, ONE raw strip of the padded
+// image (134 pixels x 8 bytes: the 64 pixels' 32-element windows overlap, start 16 bytes apart) -- and read with the transposing
+// ds_read_b64_tr_b16, whose lanes supply their own row addresses: a 16-byte row pitch over the raw strip IS the im2col matrix.
+// Wave (mp, kp) of the 4 owns channel tiles {2 mp, 2 mp + 1} x k-tiles {(r, kp)}: 14 accumulator tiles, 18 fragment reads per 14
+// MFMAs and 32-pixel k-step.  One workgroup walks a contiguous range of stages and writes one f32 partial [64][7][32]; a second
+// kernel sums the partials into the [64][7][7][3] bf16 gradient.
+constexpr int SW_STAGE = 64;                     // output pixels per stage (two 32-deep k-steps)
+constexpr int SW_GPITCH = 136;                   // bytes per staged gradient row (128 + 8: the 4 rows of a transposing read land on different banks)
+constexpr int SW_SPITCH = 1088;                  // bytes per staged strip (134 pixels x 8 = 1072, rounded up to 16-byte chunks of 68)
+constexpr int SW_GBYTES = SW_STAGE * SW_GPITCH, SW_BUF = SW_GBYTES + 7 * SW_SPITCH;
+
+struct StemWgradArgs {
+    const uint16_t *g;      // [B][Ho][Wo][64] bf16: gradient at the conv output
+    const uint16_t *xp;     // [B][Hp2][Wpp][4]
+    float *partial;         // [gridDim.x][64][7][32]
+    int B, Ho, Wo, Hp2, Wpp;
+    int tiles_x, total_stages, stages_per_wg;
+};
+
+__global__ __launch_bounds__(STEM_THREADS) void stem_wgrad_kernel(const StemWgradArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * SW_BUF];
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mp = wave >> 1, kp = wave & 1;
+    const int grp = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3;   // transposing read: group grp reads pixels 8 grp + q (+ 4), columns 4 p4 ..
+
+    f32x4v acc[2][7];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 7; ++r) acc[i][r] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int s_beg = blockIdx.x * a.stages_per_wg, s_end = min(s_beg + a.stages_per_wg, a.total_stages);
+    // staging: thread -> two 16-byte chunks of the gradient rows (512 chunks) and two of the strips (7 x 67 = 469 chunks)
+    rn::u32x4 rg[2], rs[2];
+    auto fetch = [&](const int s) {
+        const int tx = s % a.tiles_x, rowid = s / a.tiles_x, yo = rowid % a.Ho, b = rowid / a.Ho, x0 = tx * SW_STAGE;
+        const uint16_t *grow = a.g + (((int64_t)b * a.Ho + yo) * a.Wo + x0) * 64;
+        const rn::u32x4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = i * STEM_THREADS + tid, px = c >> 3;                    // chunk c: pixel c / 8, channels 8 (c % 8) ..
+            rg[i] = (x0 + px < a.Wo) ? *(const rn::u32x4 *)(grow + c * 8) : zero4; // pixels past the row end contribute nothing
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = i * STEM_THREADS + tid, r = c / 67, cc = c - r * 67;
+            const uint16_t *src = a.xp + (((int64_t)b * a.Hp2 + 2 * yo + r) * a.Wpp + 2 * x0) * 4 + cc * 8;
+            rs[i] = (c < 7 * 67) ? *(const rn::u32x4 *)src : zero4;
+        }
+    };
+    auto commit = [&](unsigned char *buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = i * STEM_THREADS + tid, px = c >> 3, ch8 = c & 7;
+            // (136-byte rows: 16-byte chunks are only 8-byte aligned -> two 8-byte stores)
+            *(rn::u32x2 *)(buf + px * SW_GPITCH + ch8 * 16) = rn::u32x2{rg[i].x, rg[i].y};
+            *(rn::u32x2 *)(buf + px * SW_GPITCH + ch8 * 16 + 8) = rn::u32x2{rg[i].z, rg[i].w};
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = i * STEM_THREADS + tid, r = c / 67, cc = c - r * 67;
+            if (c < 7 * 67) *(rn::u32x4 *)(buf + SW_GBYTES + r * SW_SPITCH + cc * 16) = rs[i];
+        }
+    };
+    auto tr_frag = [&](const unsigned char *base, const int rowb) {      // pixels +0..3 and +4..7 of this lane group's 8
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base + 4 * rowb));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    if (s_beg < s_end) { fetch(s_beg); commit(lds); }
+    __syncthreads();
+    for (int s = s_beg; s < s_end; ++s) {
+        unsigned char *cur = lds + ((s - s_beg) & 1) * SW_BUF, *nxt = lds + (((s - s_beg) & 1) ^ 1) * SW_BUF;
+        if (s + 1 < s_end) fetch(s + 1);                                   // next stage's global loads under this stage's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int px = ks * 32 + 8 * grp + q;                           // this lane's row of the transposing reads
+            bf16x8 gf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) gf[i] = tr_frag(cur + px * SW_GPITCH + ((2 * mp + i) * 16 + 4 * p4) * 2, SW_GPITCH);
+#pragma unroll
+            for (int r = 0; r < 7; ++r) {
+                const bf16x8 xf = tr_frag(cur + SW_GBYTES + r * SW_SPITCH + px * 16 + (kp * 16 + 4 * p4) * 2, 16);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc[i][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i], xf, acc[i][r], 0, 0, 0);
+            }
+        }
+        if (s + 1 < s_end) commit(nxt);
+        __syncthreads();
+    }
+    // D lane: column (k) = lane & 15, rows (channels) 4 (lane >> 4) + j
+    float *out = a.partial + (int64_t)blockIdx.x * 64 * 7 * STEM_KROW;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 7; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ch = (2 * mp + i) * 16 + 4 * (lane >> 4) + j;
+                out[(ch * 7 + r) * STEM_KROW + kp * 16 + (lane & 15)] = acc[i][r][j];
+            }
+}
+
+// dw [64][7][7][3] bf16 = sum of the partials (k = 4 * px + c; the pad columns are dropped).  Block = 16 outputs x 16 slices of
+// the partials, combined through LDS in a fixed order (a thread per output summing 512 partials alone took 45 us).
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float *__restrict__ partial, const int n, uint16_t *__restrict__ dw)
+{
+    __shared__ float sh[16][17];
+    const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + o;                                      // over [64][7][32]
+    float s0 = 0.0f, s1 = 0.0f;
+    if (i < 64 * 7 * STEM_KROW) {
+        int b = sl;
+        for (; b + 16 < n; b += 32) { s0 += partial[(int64_t)b * 64 * 7 * STEM_KROW + i]; s1 += partial[(int64_t)(b + 16) * 64 * 7 * STEM_KROW + i]; }
+        for (; b < n; b += 16) s0 += partial[(int64_t)b * 64 * 7 * STEM_KROW + i];
+    }
+    sh[sl][o] = s0 + s1;
+    __syncthreads();
+    if (sl == 0 && i < 64 * 7 * STEM_KROW) {
+        float t = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += sh[j][o];
+        const int k = i % STEM_KROW, r = (i / STEM_KROW) % 7, ch = i / (7 * STEM_KROW), px = k >> 2, c = k & 3;
+        if (px < 7 && c < 3) dw[((ch * 7 + r) * 7 + px) * 3 + c] = (uint16_t)(rn::dt<RN_BF16>::pk(t, 0.0f) & 0xffffu);
+    }
+}
+
+int stem_wgrad_grid(const int total_stages, int *stages_per_wg)
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    int wgs = cus * 2;
+    if (wgs > total_stages) wgs = total_stages;
+    if (wgs < 1) wgs = 1;
+    const int spw = (total_stages + wgs - 1) / wgs;
+    *stages_per_wg = spw;
+    return (total_stages + spw - 1) / spw;
+}
+
 int stem_grid(const int total_tiles, int *tiles_per_wg)
 {
     int dev = 0, cus = 0;
@@ -253,6 +402,36 @@ RN_API int rn_stem_conv_forward(const void *x, const void *w, void *xp, void *wk
     a.tiles_x = (a.Wo + 15) / 16; a.total_tiles = B * a.Ho * a.tiles_x;
     const int wgs = stem_grid(a.total_tiles, &a.tiles_per_wg);
     hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)wgs), dim3(STEM_THREADS), 0, st, a);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+RN_API size_t rn_stem_wgrad_workspace_bytes(int B, int H, int W)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    int spw = 0;
+    const int wgs = stem_wgrad_grid(B * Ho * ((Wo + SW_STAGE - 1) / SW_STAGE), &spw);
+    return (size_t)wgs * 64 * 7 * STEM_KROW * sizeof(float);
+}
+
+RN_API int rn_stem_conv_wgrad(const void *g, const void *xp, void *dw, int dtype, int B, int H, int W, void *workspace,
+                              size_t workspace_bytes, void *stream)
+{
+    if (!g || !xp || !dw || !workspace || B <= 0 || H <= 0 || W <= 0) return RN_EINVAL;
+    if (dtype != RN_BF16) return RN_EUNSUPPORTED;
+    if (workspace_bytes < rn_stem_wgrad_workspace_bytes(B, H, W)) return RN_EWORKSPACE;
+    if (!rn::aligned(g, 16) || !rn::aligned(xp, 16) || !rn::aligned(workspace, 16)) return RN_EALIGN;
+    StemWgradArgs a;
+    a.g = (const uint16_t *)g; a.xp = (const uint16_t *)xp; a.partial = (float *)workspace;
+    a.B = B; a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1; a.Hp2 = H + 6; a.Wpp = (W + 6 + 1) & ~1;
+    a.tiles_x = (a.Wo + SW_STAGE - 1) / SW_STAGE; a.total_stages = B * a.Ho * a.tiles_x;
+    const int wgs = stem_wgrad_grid(a.total_stages, &a.stages_per_wg);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)wgs), dim3(STEM_THREADS), 0, st, a);
+    RN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((64 * 7 * STEM_KROW + 15) / 16), dim3(256), 0, st, (const float *)workspace, wgs,
+                       (uint16_t *)dw);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

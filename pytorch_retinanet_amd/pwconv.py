@@ -391,7 +391,8 @@ def conv1x1(conv, x: Tensor) -> Tensor:
 
 # ---- the stem: conv 7x7 / stride 2 (3 -> 64) + BatchNorm (batch statistics) + ReLU on csrc/stem.hip ---------------------------------
 FUSED_STEM = True
-_STEM_WS: Dict[tuple, Tuple[Tensor, Tensor]] = {}
+STEM_WGRAD = True      # weight gradient on csrc/stem.hip as well (False: MIOpen)
+_STEM_WS: Dict[tuple, Tensor] = {}
 
 
 def stem_fusable(conv, bn, x: Tensor) -> bool:
@@ -405,7 +406,7 @@ def stem_fusable(conv, bn, x: Tensor) -> bool:
 class _StemFn(torch.autograd.Function):
     """``relu(bn(conv7x7s2(x)))`` in training mode on bf16 channels-last tensors: the MFMA stem kernel with the BatchNorm statistics
     in its epilogue (``rn_stem_conv_forward``), the finalize step, one apply pass; backward: the BatchNorm backward pair, the weight
-    gradient (MIOpen for now); the image gets no gradient."""
+    gradient on the transposing-read MFMA kernel (``rn_stem_conv_wgrad``); the image gets no gradient."""
 
     @staticmethod
     def forward(ctx, bn, x, w, gamma, beta):
@@ -413,11 +414,9 @@ class _StemFn(torch.autograd.Function):
         dev = x.device
         st = _stream(dev)
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        key = (dev.index, st, B, H, W)
-        ws = _STEM_WS.get(key)
-        if ws is None:
-            ws = _STEM_WS[key] = (torch.empty((lib.rn_stem_padded_bytes(B, H, W),), dtype=torch.uint8, device=dev),
-                                  torch.empty((64 * 7 * 32,), dtype=torch.bfloat16, device=dev))
+        # xp: the zero-bordered NHWC4 copy of the image; the weight gradient reads it again, so it belongs to this call
+        ws = (torch.empty((lib.rn_stem_padded_bytes(B, H, W),), dtype=torch.uint8, device=dev),
+              torch.empty((64 * 7 * 32,), dtype=torch.bfloat16, device=dev))
         wc = w if _cl(w) else w.contiguous(memory_format=torch.channels_last)
         z = torch.empty((B, 64, Ho, Wo), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
         nb = lib.rn_stem_partial_rows(B, H, W)
@@ -428,12 +427,12 @@ class _StemFn(torch.autograd.Function):
                                            RN_BF16, B, H, W, st), "rn_stem_conv_forward")
         stats = bn_finalize(partial, nb, B * Ho * Wo, bn)
         a, _ = bn_apply(z, stats, relu=True)
-        ctx.save_for_backward(x, wc, gamma, z, stats)
+        ctx.save_for_backward(x, wc, gamma, z, stats, ws[0])
         return a
 
     @staticmethod
     def backward(ctx, da):
-        x, w, gamma, z, stats = ctx.saved_tensors
+        x, w, gamma, z, stats, xp = ctx.saved_tensors
         dev = z.device
         st = _stream(dev)
         Cc = 64
@@ -447,7 +446,20 @@ class _StemFn(torch.autograd.Function):
         check(lib.rn_bn_act_backward(da.data_ptr(), 0, z.data_ptr(), dz.data_ptr(), 0, RN_BF16, M, Cc, gamma.data_ptr(), sp, sp + 4 * Cc,
                                      sp + 8 * Cc, 1, 1, gr.data_ptr(), gr.data_ptr() + 4 * Cc, gr.data_ptr() + 8 * Cc, wp, wn, st),
               "rn_bn_act_backward")
-        dw = torch.ops.aten.convolution_backward(dz, x, w, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        B, _, H, W = x.shape
+        if STEM_WGRAD:
+            need = lib.rn_stem_wgrad_workspace_bytes(B, H, W)
+            key = (dev.index, st)
+            wsb = _STEM_WS.get(key)
+            if wsb is None or wsb.numel() < need:
+                wsb = _STEM_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
+            dw = torch.empty_like(w)
+            PW_FLOP["stem_wgrad"] = 2.0 * M * 64 * 147
+            with _timed("stem_wgrad", dev):
+                check(lib.rn_stem_conv_wgrad(dz.data_ptr(), xp.data_ptr(), dw.data_ptr(), RN_BF16, B, H, W, wsb.data_ptr(), wsb.numel(), st),
+                      "rn_stem_conv_wgrad")
+        else:
+            dw = torch.ops.aten.convolution_backward(dz, x, w, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         return None, None, dw, gr[:Cc], gr[Cc:2 * Cc]
 
 

@@ -334,3 +334,27 @@ def test_stem_function_matches_the_layer_by_layer_path():
     names = ("output", "conv weight gradient", "bn weight gradient", "bn bias gradient", "running mean", "running var")
     for n, a, b in zip(names, outs[True], outs[False]):
         _close(a, b, 2e-2, n)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 37, 53), (2, 30, 600), (1, 7, 7)])
+def test_stem_conv_weight_gradient(B, H, W):
+    "rn_stem_conv_wgrad (transposing LDS reads over the raw padded strips) against torch's fp32 weight gradient."
+    from pytorch_retinanet_amd._lib import RN_BF16, check, lib
+    x = _rand((B, 3, H, W), 1.0, 1)
+    w = _rand((64, 3, 7, 7), 0.1, 2)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    g = _rand((B, 64, Ho, Wo), 1.0, 3)
+    st = torch.cuda.current_stream().cuda_stream
+    xp = torch.empty((lib.rn_stem_padded_bytes(B, H, W),), dtype=torch.uint8, device=DEV)
+    xp.view(torch.int16).fill_(0x7fc0)                                           # bf16 NaNs everywhere: the pad kernel must overwrite all of it
+    wk = torch.empty((64 * 7 * 32,), dtype=torch.bfloat16, device=DEV)
+    z = torch.empty((B, 64, Ho, Wo), dtype=torch.bfloat16, device=DEV, memory_format=torch.channels_last)
+    check(lib.rn_stem_conv_forward(x.data_ptr(), w.data_ptr(), xp.data_ptr(), wk.data_ptr(), z.data_ptr(), 0, RN_BF16, B, H, W, st), "fwd")
+    need = lib.rn_stem_wgrad_workspace_bytes(B, H, W)
+    wsb = torch.empty((need,), dtype=torch.uint8, device=DEV)
+    dw = torch.full_like(w, float("nan"))
+    check(lib.rn_stem_conv_wgrad(g.data_ptr(), xp.data_ptr(), dw.data_ptr(), RN_BF16, B, H, W, wsb.data_ptr(), need, st), "rn_stem_conv_wgrad")
+    ref = torch.ops.aten.convolution_backward(g.float(), x.float(), w.float(), None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+                                              [False, True, False])[1]
+    assert dw.shape == ref.shape and dw.stride() == w.stride()
+    _close(dw, ref, 1e-2, "stem weight gradient")
