@@ -436,6 +436,10 @@ int rn_conv3x3_levels_wgrad(const void *const *gs, const rn_canvas_layout *layou
  * inference): position 0..8 of the maximum inside its window with PyTorch's scan rule (first maximum; the last
  * NaN wins) -- one byte per element instead of PyTorch's int64 index; the backward gathers from it. */
 int rn_maxpool3x3s2_forward(const void *x, void *y, uint8_t *argmax, int dtype, int N, int H, int W, int C, void *stream);
+/* The same pooling of relu(x * coef[0][c] + coef[1][c]) rounded to dtype -- the stem's BatchNorm + ReLU (backbone.py:247-251)
+ * applied on the fly, its output never written; y and argmax equal those of rn_bn_apply followed by rn_maxpool3x3s2_forward. */
+int rn_bn_relu_maxpool3x3s2_forward(const void *x, const float *coef, void *y, uint8_t *argmax, int dtype, int N, int H, int W, int C,
+                                    void *stream);
 int rn_maxpool3x3s2_backward(const uint8_t *argmax, const void *dy, void *dx, int dtype,
                              int N, int H, int W, int C, void *stream);
 

@@ -96,6 +96,7 @@ SIGNATURES = {
     "rn_conv3x3_canvas_batched": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _i64, _i64, C.c_int, C.c_int, C.c_int,
                                             C.c_int, _vp]),
     "rn_maxpool3x3s2_forward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "rn_bn_relu_maxpool3x3s2_forward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "rn_maxpool3x3s2_backward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "rn_sgd_master_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32, _f32, _f32, C.c_int, C.c_int, _vp]),
     "rn_conv3x3_canvas_to_levels": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -240,7 +240,7 @@ class ResNetBackbone(nn.Module):
 
     def _forward_impl(self, x: Tensor) -> Dict[str, Tensor]:
         if pwconv.stem_fusable(self.conv1, self.bn1, x):     # training, bf16: the MFMA stem kernel with bn1's statistics in its epilogue
-            x = self.maxpool(pwconv.stem(self.conv1, self.bn1, x))
+            x = pwconv.stem(self.conv1, self.bn1, x, pool=self.maxpool)      # ... and bn1's apply + ReLU inside the max pooling
         else:
             x = self.maxpool(conv_bn(self.conv1, self.bn1, x, relu=True))
         x = self.layer1(x)

@@ -54,9 +54,19 @@ __device__ __forceinline__ void split_index(const int64_t i, const bool small, c
     }
 }
 
-template <int DT>
+// value of f after a store in DT and a load back (rn_common: bf16 RNE / f16)
+template <int DT> __device__ __forceinline__ float pool_round(const float f);
+template <> __device__ __forceinline__ float pool_round<RN_F32>(const float f) { return f; }
+template <> __device__ __forceinline__ float pool_round<RN_BF16>(const float f) { return __uint_as_float(rn::dt<RN_BF16>::pk(f, 0.0f) << 16); }
+template <> __device__ __forceinline__ float pool_round<RN_F16>(const float f) { return (float)(_Float16)f; }
+
+// AFF: x is the INPUT of a BatchNorm + ReLU whose output was never written; every element read is first turned into
+// round_DT(max(fma(x, a, b), 0)) -- what the apply pass would have stored -- so results and codes equal those of the two-pass form
+// (the stem: one 275 MB read + 275 MB write less).
+template <int DT, bool AFF = false>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const void *__restrict__ x, void *__restrict__ y, uint8_t *__restrict__ idx,
-                                                          const PoolShape s)
+                                                          const PoolShape s, const float *__restrict__ coef_a = nullptr,
+                                                          const float *__restrict__ coef_b = nullptr)
 {
     const int64_t total = (int64_t)s.N * s.OH * s.OW * s.C8;
     // back to front: the producer (the stem's BN apply, 275 MB) wrote the end of x last, the Infinity Cache still holds it
@@ -64,10 +74,14 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const void *__restrict
         const int64_t i = total - 1 - ii;
         int cg, ox, oy, n;
         split_index(i, total < (1ll << 31), s.C8, s.OW, s.OH, cg, ox, oy, n);
-        float m[8];
+        float m[8], ca[8], cb[8];
         int k[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; k[j] = -1; }
+        if (AFF) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { ca[j] = coef_a[cg * 8 + j]; cb[j] = coef_b[cg * 8 + j]; }
+        }
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int iy = 2 * oy - 1 + r;
@@ -78,6 +92,10 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const void *__restrict
                 if (ix < 0 || ix >= s.W) continue;
                 float f[8];
                 v8<DT>::ld(x, (((int64_t)n * s.H + iy) * s.W + ix) * s.C8 + cg, f);
+                if (AFF) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float t = fmaf(f[j], ca[j], cb[j]); f[j] = pool_round<DT>(t > 0.0f ? t : 0.0f); }
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
                     if (k[j] < 0 || f[j] > m[j] || f[j] != f[j]) { m[j] = f[j]; k[j] = r * 3 + q; }   // PyTorch's scan: first maximum, last NaN
@@ -202,9 +220,28 @@ RN_API int rn_maxpool3x3s2_forward(const void *x, void *y, uint8_t *argmax, int 
     const dim3 g(pool_blocks((int64_t)N * s.OH * s.OW * s.C8)), b(256);
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
-        case RN_F32: hipLaunchKernelGGL((maxpool_fwd_kernel<RN_F32>), g, b, 0, st, x, y, argmax, s); break;
-        case RN_BF16: hipLaunchKernelGGL((maxpool_fwd_kernel<RN_BF16>), g, b, 0, st, x, y, argmax, s); break;
-        default: hipLaunchKernelGGL((maxpool_fwd_kernel<RN_F16>), g, b, 0, st, x, y, argmax, s); break;
+        case RN_F32: hipLaunchKernelGGL((maxpool_fwd_kernel<RN_F32>), g, b, 0, st, x, y, argmax, s, nullptr, nullptr); break;
+        case RN_BF16: hipLaunchKernelGGL((maxpool_fwd_kernel<RN_BF16>), g, b, 0, st, x, y, argmax, s, nullptr, nullptr); break;
+        default: hipLaunchKernelGGL((maxpool_fwd_kernel<RN_F16>), g, b, 0, st, x, y, argmax, s, nullptr, nullptr); break;
+    }
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+RN_API int rn_bn_relu_maxpool3x3s2_forward(const void *x, const float *coef, void *y, uint8_t *argmax, int dtype, int N, int H, int W, int C,
+                                           void *stream)
+{
+    if (!x || !y || !coef || N <= 0 || H <= 0 || W <= 0 || C <= 0) return RN_EINVAL;
+    if (C % 8) return RN_EUNSUPPORTED;
+    if (dtype != RN_F32 && dtype != RN_BF16 && dtype != RN_F16) return RN_EINVAL;
+    if (!rn::aligned(x, 16) || !rn::aligned(y, 16) || (argmax && !rn::aligned(argmax, 8))) return RN_EALIGN;
+    const PoolShape s{N, H, W, C / 8, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
+    const dim3 g(pool_blocks((int64_t)N * s.OH * s.OW * s.C8)), b(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (dtype) {
+        case RN_F32: hipLaunchKernelGGL((maxpool_fwd_kernel<RN_F32, true>), g, b, 0, st, x, y, argmax, s, coef, coef + C); break;
+        case RN_BF16: hipLaunchKernelGGL((maxpool_fwd_kernel<RN_BF16, true>), g, b, 0, st, x, y, argmax, s, coef, coef + C); break;
+        default: hipLaunchKernelGGL((maxpool_fwd_kernel<RN_F16, true>), g, b, 0, st, x, y, argmax, s, coef, coef + C); break;
     }
     RN_LAUNCH_CHECK();
     return RN_OK;

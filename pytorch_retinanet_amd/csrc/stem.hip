@@ -22,6 +22,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4v;
 
 constexpr int STEM_THREADS = 256, STEM_WAVES = 4;
 constexpr int STEM_KROW = 32;                    // k elements per kernel row: 7 pixels x 4 channels + 4 zeros
+constexpr int STEM_SLACK_PX = 160;               // (a weight-gradient stage reads 134 pixels from its first one, whatever the row length)
 constexpr int STEM_NB = 2;                       // fragment sets per wave (one computing, one in flight; 3 .. 8 sets at one wave per SIMD: no gain)
 
 struct StemPadArgs {
@@ -33,9 +34,9 @@ struct StemPadArgs {
 // one thread = one padded pixel (8 bytes)
 __global__ __launch_bounds__(256) void stem_pad_kernel(const StemPadArgs a)
 {
-    // (+ 2 rows of slack behind the last image, zeroed: the kernels' masked lanes read there, and the weight gradient multiplies
+    // (+ 2 rows + 160 pixels of slack behind the last image, zeroed: the kernels' masked lanes read there, and the weight gradient multiplies
     // what they read by zeros -- it must be finite)
-    const int64_t total = ((int64_t)a.B * a.Hp2 + 2) * a.Wpp;
+    const int64_t total = ((int64_t)a.B * a.Hp2 + 2) * a.Wpp + STEM_SLACK_PX;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int xq = (int)(i % a.Wpp);
         const int64_t rowid = i / a.Wpp;
@@ -368,7 +369,7 @@ RN_API size_t rn_stem_padded_bytes(int B, int H, int W)
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const int Wpp = (W + 6 + 1) & ~1;
     // + 2 rows of slack: the masked lanes of a row's last tile read (never use) up to 36 pixels past the row end
-    return ((size_t)B * (H + 6) + 2) * (size_t)Wpp * 8;
+    return (((size_t)B * (H + 6) + 2) * (size_t)Wpp + STEM_SLACK_PX) * 8;
 }
 
 RN_API int rn_stem_partial_rows(int B, int H, int W)

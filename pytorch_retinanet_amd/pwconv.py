@@ -409,7 +409,7 @@ class _StemFn(torch.autograd.Function):
     gradient on the transposing-read MFMA kernel (``rn_stem_conv_wgrad``); the image gets no gradient."""
 
     @staticmethod
-    def forward(ctx, bn, x, w, gamma, beta):
+    def forward(ctx, bn, pool, x, w, gamma, beta):
         B, _, H, W = x.shape
         dev = x.device
         st = _stream(dev)
@@ -426,19 +426,33 @@ class _StemFn(torch.autograd.Function):
             check(lib.rn_stem_conv_forward(x.data_ptr(), wc.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), z.data_ptr(), partial.data_ptr(),
                                            RN_BF16, B, H, W, st), "rn_stem_conv_forward")
         stats = bn_finalize(partial, nb, B * Ho * Wo, bn)
-        a, _ = bn_apply(z, stats, relu=True)
-        ctx.save_for_backward(x, wc, gamma, z, stats, ws[0])
-        return a
+        if pool:
+            # BatchNorm apply + ReLU inside the 3x3 / stride-2 max pooling: the 275 MB activation between them is never written
+            Hq, Wq = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+            out = torch.empty((B, 64, Hq, Wq), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+            arg = torch.empty(out.shape, dtype=torch.uint8, device=dev, memory_format=torch.channels_last)
+            check(lib.rn_bn_relu_maxpool3x3s2_forward(z.data_ptr(), stats.data_ptr() + 8 * 64, out.data_ptr(), arg.data_ptr(), RN_BF16, B, Ho, Wo,
+                                                      64, st), "rn_bn_relu_maxpool3x3s2_forward")
+        else:
+            out, _ = bn_apply(z, stats, relu=True)
+            arg = None
+        ctx.pool = pool
+        ctx.save_for_backward(x, wc, gamma, z, stats, ws[0], arg)
+        return out
 
     @staticmethod
     def backward(ctx, da):
-        x, w, gamma, z, stats, xp = ctx.saved_tensors
+        x, w, gamma, z, stats, xp, arg = ctx.saved_tensors
         dev = z.device
         st = _stream(dev)
         Cc = 64
         M = z.shape[0] * z.shape[2] * z.shape[3]
         if not (da.dtype == torch.bfloat16 and _cl(da)):
             da = da.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        if ctx.pool:                                                 # `da` is the pooled gradient: back through the arg-max codes first
+            dpool, da = da, torch.empty_like(z)
+            check(lib.rn_maxpool3x3s2_backward(arg.data_ptr(), dpool.data_ptr(), da.data_ptr(), RN_BF16, z.shape[0], z.shape[2], z.shape[3], Cc, st),
+                  "rn_maxpool3x3s2_backward")
         gr = torch.empty((5 * Cc,), dtype=torch.float32, device=dev)
         dz = torch.empty_like(z)
         sp = stats.data_ptr()
@@ -460,8 +474,12 @@ class _StemFn(torch.autograd.Function):
                       "rn_stem_conv_wgrad")
         else:
             dw = torch.ops.aten.convolution_backward(dz, x, w, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False])[1]
-        return None, None, dw, gr[:Cc], gr[Cc:2 * Cc]
+        return None, None, None, dw, gr[:Cc], gr[Cc:2 * Cc]
 
 
-def stem(conv, bn, x: Tensor) -> Tensor:
-    return _StemFn.apply(bn, x, conv.weight, bn.weight, bn.bias)
+def stem(conv, bn, x: Tensor, pool=None) -> Tensor:
+    "``relu(bn(conv(x)))``, or ``pool(relu(bn(conv(x))))`` when ``pool`` is the stem's 3x3 / stride-2 / pad-1 max pooling module."
+    fuse = (pool is not None and pool.kernel_size == 3 and pool.stride == 2 and pool.padding == 1 and pool.dilation == 1
+            and not pool.ceil_mode and not pool.return_indices)
+    y = _StemFn.apply(bn, fuse, x, conv.weight, bn.weight, bn.bias)
+    return y if fuse or pool is None else pool(y)

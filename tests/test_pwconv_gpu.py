@@ -325,7 +325,7 @@ def test_stem_function_matches_the_layer_by_layer_path():
             net.train()
             x = _rand((2, 3, 96, 128), 1.0, 7)
             assert pwconv.stem_fusable(net.conv1, net.bn1, x) == flag
-            y = pwconv.stem(net.conv1, net.bn1, x) if flag else backbone.conv_bn(net.conv1, net.bn1, x, relu=True)
+            y = pwconv.stem(net.conv1, net.bn1, x, pool=net.maxpool) if flag else net.maxpool(backbone.conv_bn(net.conv1, net.bn1, x, relu=True))
             (y.float() ** 2).mean().backward()
             outs[flag] = (y.detach().float(), net.conv1.weight.grad.float().clone(), net.bn1.weight.grad.clone(), net.bn1.bias.grad.clone(),
                           net.bn1.running_mean.clone(), net.bn1.running_var.clone())
@@ -333,7 +333,13 @@ def test_stem_function_matches_the_layer_by_layer_path():
             pwconv.FUSED_STEM = True
     names = ("output", "conv weight gradient", "bn weight gradient", "bn bias gradient", "running mean", "running var")
     for n, a, b in zip(names, outs[True], outs[False]):
-        _close(a, b, 2e-2, n)
+        if "gradient" in n:
+            # two bf16 pipelines: a conv output that differs by one ulp moves a ReLU decision or a pooling arg-max, and the gradient
+            # of that window goes elsewhere -- compare in the l2 norm, as the block tests above do
+            rel = float((a - b).norm() / b.norm().clamp_min(1e-12))
+            assert rel < 5e-2, (n, rel)
+        else:
+            _close(a, b, 2e-2, n)
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 37, 53), (2, 30, 600), (1, 7, 7)])
@@ -358,3 +364,26 @@ def test_stem_conv_weight_gradient(B, H, W):
                                               [False, True, False])[1]
     assert dw.shape == ref.shape and dw.stride() == w.stride()
     _close(dw, ref, 1e-2, "stem weight gradient")
+
+
+def test_bn_relu_inside_maxpool_equals_the_two_pass_form():
+    "rn_bn_relu_maxpool3x3s2_forward == rn_bn_apply (ReLU) followed by rn_maxpool3x3s2_forward: values and arg-max codes, bit for bit."
+    from pytorch_retinanet_amd._lib import RN_BF16, check, lib
+    N, Cc, H, W = 2, 64, 37, 53
+    z = _rand((N, Cc, H, W), 2.0, 1)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    coef = torch.cat([torch.rand(Cc, device=DEV, generator=gen) + 0.5, torch.randn(Cc, device=DEV, generator=gen)]).contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    a = torch.empty_like(z)
+    check(lib.rn_bn_apply(z.data_ptr(), 0, a.data_ptr(), RN_BF16, N * H * W, Cc, coef.data_ptr(), 1, 0, st), "rn_bn_apply")
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    outs = []
+    for fused in (False, True):
+        y = torch.empty((N, Cc, Ho, Wo), dtype=torch.bfloat16, device=DEV, memory_format=torch.channels_last)
+        arg = torch.empty(y.shape, dtype=torch.uint8, device=DEV, memory_format=torch.channels_last)
+        if fused:
+            check(lib.rn_bn_relu_maxpool3x3s2_forward(z.data_ptr(), coef.data_ptr(), y.data_ptr(), arg.data_ptr(), RN_BF16, N, H, W, Cc, st), "fused")
+        else:
+            check(lib.rn_maxpool3x3s2_forward(a.data_ptr(), y.data_ptr(), arg.data_ptr(), RN_BF16, N, H, W, Cc, st), "pool")
+        outs.append((y, arg))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
