@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--torch-sgd", action="store_true", help="fp32 parameters + torch.optim.SGD instead of fp32 masters + bf16 conv weights (optim.MasterSGD); same arithmetic")
     ap.add_argument("--cpu-baseline-reps", type=int, default=30, help="batches of the dense-head workload timed on the host (about 10 s of CPU work)")
     ap.add_argument("--no-detect", action="store_true", help="skip the inference-chain (decode + NMS + top-k) roofline line (BASELINE configs[3] shape)")
+    ap.add_argument("--ddp-graph", action="store_true", help="capture the step in a hipGraph also when gradients are exchanged (default there: eager steps -- the captured step with RCCL's forked stream branches replays 3.5 %% slower than eager enqueueing, DESIGN.md section 6)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel of every step from Python instead of replaying the captured hipGraph of the step (graph.CapturedTrainStep)")
     ap.add_argument("--timing-steps", type=int, default=5, help="eager steps run AFTER the timed region with HIP events around the hand-written kernels (per-kernel figures of the JSON line)")
     return ap.parse_args()
@@ -281,8 +282,12 @@ def main():
     # two calls run eagerly (MIOpen find, caches, optimizer state), the third captures the step in a hipGraph, and every
     # later call is one graph replay (--no-graph: every call enqueues its ~700 kernels from Python).
     from pytorch_retinanet_amd.graph import CapturedTrainStep
-    stepper = CapturedTrainStep(net, optimizer, ddp, amp_dtype=torch.bfloat16, eager_steps=2, enabled=not args.no_graph)
-    n_warm = max(args.warmup, 3 if not args.no_graph else 0)       # (the capture itself must not fall into the timed region)
+    # With a gradient exchange the step is NOT captured by default: torch's process group runs the all-reduces on its own stream, the
+    # capture turns that into forked graph branches, and ROCm replays such a graph slower than Python enqueues the same kernels
+    # (world 1, same box: 279 captured / 289 eager / 302 without the exchange); eager keeps the overlap of exchange and backward.
+    use_graph = not args.no_graph and (ddp is None or args.ddp_graph)
+    stepper = CapturedTrainStep(net, optimizer, ddp, amp_dtype=torch.bfloat16, eager_steps=2, enabled=use_graph)
+    n_warm = max(args.warmup, 3 if use_graph else 0)               # (the capture itself must not fall into the timed region)
     for _ in range(n_warm):
         stepper(images, targets)
     torch.cuda.synchronize()

@@ -3,8 +3,9 @@ build has (the reference reaches NCCL through Lightning's DDP, model.
 
 ``bench.py --gpus 1 --force-ddp`` creates a real RCCL process group, routes every gradient through
 ``BucketedGradAllReduce`` (async ``all_reduce(AVG)`` from the autograd hooks on RCCL's stream, ``finish()`` wait,
-``MasterSGD.step(grads=grad_views())``) and captures that whole step -- collectives included -- in the hipGraph.  The run is
-a child process (started before this process touches the GPU is not required: it is a spawn, not an exec); the JSON lines of
+``MasterSGD.step(grads=grad_views())``).  By default such a step is enqueued eagerly (the exchange overlaps backward on RCCL's
+stream); ``--ddp-graph`` captures the whole step -- collectives included -- in the hipGraph, which ROCm replays slower (forked
+stream branches): both are run here.  The run is a child process (started before this process touches the GPU is not required: it is a spawn, not an exec); the JSON lines of
 both runs are kept under profiles/ when ``RN_KEEP_PROFILES`` is set.
 """
 import json
@@ -29,17 +30,21 @@ def _bench(*extra):
 
 def test_world1_rccl_step_matches_the_plain_step():
     ddp = _bench("--force-ddp")
+    ddp_graph = _bench("--force-ddp", "--ddp-graph")
     plain = _bench()
-    assert ddp["rccl_ranks"] == 1 and plain["rccl_ranks"] == 0
+    assert ddp["rccl_ranks"] == 1 and ddp_graph["rccl_ranks"] == 1 and plain["rccl_ranks"] == 0
     assert ddp["n_gpus"] == 1 and ddp["config"]["parallelism"] == "dp1"
-    for line in (ddp, plain):
+    for line in (ddp, ddp_graph, plain):
         assert line["value"] > 0 and line["config"]["final_loss"] == line["config"]["final_loss"]      # finite (not NaN)
         assert 0 < line["config"]["final_loss"] < 100
-    # one rank: the exchange is an identity, but the bucket gather and the 153 MB single-rank all-reduce sit on the critical
-    # path here (nothing to overlap with at the end of backward): measured 5 - 6 % below the plain step
+    # one rank: the exchange is an identity, but the bucket gather and the 153 MB single-rank all-reduce are extra work, and
+    # the eager step pays Python's enqueue: measured 4 % (eager) / 7.5 % (captured) below the plain captured step
     assert plain["value"] * 0.88 <= ddp["value"] <= plain["value"] * 1.03, (ddp["value"], plain["value"])
-    assert ddp["step_launch"]["mode"] == "hipGraph replay" and plain["step_launch"]["mode"] == "hipGraph replay"
-    assert abs(ddp["config"]["final_loss"] - plain["config"]["final_loss"]) <= 0.05 * plain["config"]["final_loss"]
+    assert plain["value"] * 0.85 <= ddp_graph["value"] <= plain["value"] * 1.03, (ddp_graph["value"], plain["value"])
+    assert ddp["step_launch"]["mode"] == "eager" and ddp_graph["step_launch"]["mode"] == "hipGraph replay"
+    assert plain["step_launch"]["mode"] == "hipGraph replay"
+    for line in (ddp, ddp_graph):
+        assert abs(line["config"]["final_loss"] - plain["config"]["final_loss"]) <= 0.05 * plain["config"]["final_loss"]
     if os.environ.get("RN_KEEP_PROFILES"):
         with open(os.path.join(ROOT, "gpurun_out", "r03_rccl_world1.json"), "w") as f:
-            json.dump({"force_ddp": ddp, "plain": plain}, f, indent=1)
+            json.dump({"force_ddp": ddp, "force_ddp_graph": ddp_graph, "plain": plain}, f, indent=1)
