@@ -379,6 +379,12 @@ def gen_transform():
     save("transform.npz", **out)
 
 
+def hash_key(k: str) -> int:
+    "stable 32-bit hash of a parameter name (seeds the projection direction; Python's hash() is salted per process)"
+    import zlib
+    return zlib.crc32(k.encode())
+
+
 def gen_e2e():
     """Retinanet.forward (models.py:274-288) and Retinanet.predict (models.py:245-272) of the REFERENCE model itself, for a
     seed-reproducible state dict: the fixture the assembled GPU model is held to."""
@@ -414,6 +420,21 @@ def gen_e2e():
     out["grad_probe_keys"] = np.array(probes)
     out["grad_probe_norms"] = np.array([float(named[k].grad.double().norm()) for k in probes])
     out["grad_probe_head"] = np.stack([named[k].grad.reshape(-1)[:8].numpy().astype(np.float64) for k in probes])
+    # ... and of EVERY parameter: norm, the projection on a seeded N(0, 1) direction (sign / direction, not only size) and 32
+    # elements at seeded positions
+    keys = [k for k, p in named.items() if p.grad is not None]
+    rng = np.random.default_rng(20260101)
+    norms, projs, samples, pos = [], [], [], []
+    for k in keys:
+        gflat = named[k].grad.reshape(-1).double().numpy()
+        r = np.random.default_rng(abs(hash_key(k)) % (1 << 32)).standard_normal(gflat.size)
+        idx = rng.integers(0, gflat.size, 32)
+        norms.append(float(np.linalg.norm(gflat))); projs.append(float(gflat @ r)); samples.append(gflat[idx]); pos.append(idx)
+    out["grad_all_keys"] = np.array(keys)
+    out["grad_all_norms"] = np.array(norms)
+    out["grad_all_proj"] = np.array(projs)
+    out["grad_all_samples"] = np.stack(samples)
+    out["grad_all_pos"] = np.stack(pos).astype(np.int64)
     # running statistics after that ONE training forward (momentum update of every BN layer)
     out["bn1_running_mean_after"] = ref.backbone.backbone.bn1.running_mean.numpy().copy()
     print(f"  train: cls={out['train_losses'][0]:.6f} reg={out['train_losses'][1]:.6f}")

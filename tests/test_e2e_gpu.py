@@ -84,7 +84,7 @@ def box_set_agreement(got, ref, iou_thr=0.999):
 
 @pytest.mark.gpu
 def test_forward_losses_and_gradients_match_the_reference_fp32(golden):
-    "Retinanet.forward in train-mode BN, fp32: loss dict rel <= 1e-4, parameter-gradient fingerprints rel <= 2e-3."
+    "Retinanet.forward in train-mode BN, fp32: loss dict rel <= 1e-4; EVERY parameter gradient: norm 3e-3, a seeded projection, 32 elements."
     g = golden("e2e.npz")
     net = _model(g, DEV).train()
     images, targets = _inputs(g, DEV)
@@ -100,6 +100,21 @@ def test_forward_losses_and_gradients_match_the_reference_fp32(golden):
         # (single elements: fp32 convolutions whose algorithm MIOpen picks per run -- compare against the gradient's rms)
         np.testing.assert_allclose(gr.reshape(-1)[:8].double().cpu().numpy(), head, rtol=5e-2, atol=1e-2 * norm / np.sqrt(gr.numel()),
                                    err_msg=str(k))
+    # every parameter: gradient norm, projection on a seeded random direction, 32 seeded elements (fixture: the reference's autograd)
+    import zlib
+    bad = []
+    for k, norm, proj, samp, pos in zip(g["grad_all_keys"], g["grad_all_norms"], g["grad_all_proj"], g["grad_all_samples"], g["grad_all_pos"]):
+        gr = named[str(k)].grad
+        assert gr is not None, k
+        flat = gr.reshape(-1).double().cpu().numpy()
+        r = np.random.default_rng(zlib.crc32(str(k).encode())).standard_normal(flat.size)
+        rms = norm / np.sqrt(flat.size)
+        ok = (abs(np.linalg.norm(flat) - norm) <= 3e-3 * norm + 1e-9 and abs(flat @ r - proj) <= 1e-2 * norm + 1e-9
+              and np.all(np.abs(flat[pos] - samp) <= 5e-2 * np.abs(samp) + 2e-2 * rms + 1e-12))
+        if not ok:
+            bad.append((str(k), float(np.linalg.norm(flat)), float(norm), float(flat @ r), float(proj)))
+    assert not bad, bad[:5]
+    assert len(g["grad_all_keys"]) == sum(1 for p in net.parameters() if p.requires_grad)
     # one training forward moved the BN running statistics exactly like the reference's
     np.testing.assert_allclose(net.backbone.backbone.bn1.running_mean.cpu().numpy(), g["bn1_running_mean_after"], rtol=1e-4, atol=1e-6)
 
