@@ -292,6 +292,10 @@ size_t rn_stem_wgrad_workspace_bytes(int B, int H, int W);
 int rn_stem_conv_wgrad(const void *g, const void *xp, void *dw, int dtype, int B, int H, int W, void *workspace,
                        size_t workspace_bytes, void *stream);
 
+/* n device-to-device copies (dsts[i] <- srcs[i], nbytes[i] bytes, non-overlapping) in one launch per 64: the inputs of a step
+ * into the static buffers of its captured hipGraph (graph.CapturedTrainStep).  srcs / dsts / nbytes are HOST arrays. */
+int rn_copy_many(const void *const *srcs, void *const *dsts, const int64_t *nbytes, int n, void *stream);
+
 /* ---- K4 decode_clip ---------------------------------------------------------
  * Replaces activ_2_bbox, retinanet/box_utils.py:37-48 (including its use of
  * dx,dy for the sizes, :46) and torchvision clip_boxes_to_image at

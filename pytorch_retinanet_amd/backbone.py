@@ -145,7 +145,11 @@ class _Conv1x1Skip(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             g2 = g.permute(0, 2, 3, 1).reshape(-1, Cmid)
             w2 = w.reshape(Cmid, Cin)
-            if dres is not None:
+            if dres is not None and dres.is_contiguous(memory_format=torch.channels_last):
+                # accumulate INTO the identity gradient (bn3's backward wrote it for this block alone): the out-of-place addmm
+                # first copies its 69 MB into the result (25 us per layer3 block)
+                dx2 = dres.permute(0, 2, 3, 1).reshape(-1, Cin).addmm_(g2, w2)
+            elif dres is not None:
                 dx2 = torch.addmm(dres.permute(0, 2, 3, 1).reshape(-1, Cin), g2, w2)
             else:
                 dx2 = g2 @ w2

@@ -120,3 +120,46 @@ RN_API int rn_sgd_master_step(float *const *masters, float *const *momenta, cons
     }
     return RN_OK;
 }
+
+// ---- many small device-to-device copies in one launch ---------------------------------------------------------------------------
+// The captured train step copies its inputs (8 images + 16 target tensors) into the graph's static buffers before every replay:
+// 24 hipMemcpyAsync calls cost 0.19 ms of GPU time per step (11 us each, mostly fixed cost); one launch moves the same 102 MB.
+namespace {
+constexpr int COPY_MAX = 64;
+struct CopyTable { const unsigned char *src[COPY_MAX]; unsigned char *dst[COPY_MAX]; int64_t nbytes[COPY_MAX]; };
+
+__global__ __launch_bounds__(256) void copy_many_kernel(const CopyTable t)
+{
+    const int ti = blockIdx.y;
+    const unsigned char *__restrict__ s = t.src[ti];
+    unsigned char *__restrict__ d = t.dst[ti];
+    const int64_t n = t.nbytes[ti];
+    const bool vec = ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0;
+    const int64_t n16 = vec ? n >> 4 : 0;
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < n16; v += (int64_t)gridDim.x * 256)
+        ((rn::u32x4 *)d)[v] = ((const rn::u32x4 *)s)[v];
+    for (int64_t b = n16 * 16 + (int64_t)blockIdx.x * 256 + threadIdx.x; b < n; b += (int64_t)gridDim.x * 256) d[b] = s[b];
+}
+}  // namespace
+
+RN_API int rn_copy_many(const void *const *srcs, void *const *dsts, const int64_t *nbytes, int n, void *stream)
+{
+    if (!srcs || !dsts || !nbytes || n < 0) return RN_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    for (int base = 0; base < n; base += COPY_MAX) {
+        CopyTable t;
+        const int cnt = (n - base) < COPY_MAX ? (n - base) : COPY_MAX;
+        int64_t most = 0;
+        for (int i = 0; i < COPY_MAX; ++i) {
+            const int q = i < cnt ? base + i : base;
+            if (!srcs[q] || !dsts[q] || nbytes[q] < 0) return RN_EINVAL;
+            t.src[i] = (const unsigned char *)srcs[q]; t.dst[i] = (unsigned char *)dsts[q]; t.nbytes[i] = i < cnt ? nbytes[q] : 0;
+            if (t.nbytes[i] > most) most = t.nbytes[i];
+        }
+        int64_t bx = (most / 16 + 255) / 256;
+        bx = bx > 512 ? 512 : (bx < 1 ? 1 : bx);
+        hipLaunchKernelGGL(copy_many_kernel, dim3((unsigned)bx, (unsigned)cnt), dim3(256), 0, st, t);
+        RN_LAUNCH_CHECK();
+    }
+    return RN_OK;
+}

@@ -21,6 +21,7 @@ before the next call).  The first ``eager_steps`` calls with a new signature run
 MIOpen's find, the caches and the optimizer state); the next one captures and replays.  At most ``max_graphs`` signatures
 are kept (least recently used goes first); a capture that fails falls back to eager for that signature.
 """
+import ctypes as C
 import logging
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -28,6 +29,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 from torch import Tensor
 
+from ._lib import check, lib
 from .norm import note_raw_write
 
 _log = logging.getLogger(__name__)
@@ -119,12 +121,16 @@ class CapturedTrainStep:
             dsts, srcs = [], []
             pairs = list(zip(e.images, images)) + [(dt[k], v) for dt, st in zip(e.targets, targets) for k, v in st.items() if isinstance(v, Tensor)]
             for dst, src in pairs:
-                if src.device == dst.device and src.dtype == dst.dtype and src.shape == dst.shape:
+                if src.device == dst.device and src.dtype == dst.dtype and src.shape == dst.shape and src.is_contiguous() and dst.is_contiguous():
                     dsts.append(dst); srcs.append(src)
                 else:
                     dst.copy_(src, non_blocking=True)
             if dsts:
-                torch._foreach_copy_(dsts, srcs)
+                # (torch._foreach_copy_ still issues one hipMemcpyAsync per tensor: 24 x 11 us of GPU time)
+                n = len(dsts)
+                check(lib.rn_copy_many((C.c_void_p * n)(*[t.data_ptr() for t in srcs]), (C.c_void_p * n)(*[t.data_ptr() for t in dsts]),
+                                       (C.c_int64 * n)(*[t.numel() * t.element_size() for t in dsts]), n,
+                                       torch.cuda.current_stream(dsts[0].device).cuda_stream), "rn_copy_many")
         e.graph.replay()
         note_raw_write()                                      # parameters and BN statistics changed behind torch's back
         self.replays += 1
