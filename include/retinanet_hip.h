@@ -296,6 +296,14 @@ int rn_stem_conv_wgrad(const void *g, const void *xp, void *dw, int dtype, int B
  * into the static buffers of its captured hipGraph (graph.CapturedTrainStep).  srcs / dsts / nbytes are HOST arrays. */
 int rn_copy_many(const void *const *srcs, void *const *dsts, const int64_t *nbytes, int n, void *stream);
 
+/* dsts[i] [cols[i]][rows[i]] = transpose of srcs[i] [rows[i]][cols[i]], 16-bit elements, n <= 16 matrices in one launch (the
+ * data-gradient weights of a bottleneck's 1x1 convolutions).  srcs / dsts / rows / cols are HOST arrays. */
+int rn_transpose_many(const void *const *srcs, void *const *dsts, const int *rows, const int *cols, int n, void *stream);
+/* The weight rn_conv3x3_levels_to_canvas expects, from the forward weight w [Cout][3][3][Cin] (16-bit): out [Cin][3][3][Kpad],
+ * taps reversed, channel roles swapped, contraction axis laid out as that kernel walks it (the piece that straddles the end
+ * of a Cout % 8 != 0 row carries the row's last 8 channels, zero weights on the repeated ones; zeros up to Kpad). */
+int rn_conv3x3_levels_dgrad_weight(const void *w, void *out, int Cout, int Cin, int Kpad, void *stream);
+
 /* ---- K4 decode_clip ---------------------------------------------------------
  * Replaces activ_2_bbox, retinanet/box_utils.py:37-48 (including its use of
  * dx,dy for the sizes, :46) and torchvision clip_boxes_to_image at

@@ -126,6 +126,8 @@ SIGNATURES = {
     "rn_stem_wgrad_workspace_bytes": (_sz, [C.c_int, C.c_int, C.c_int]),
     "rn_stem_conv_wgrad": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _sz, _vp]),
     "rn_copy_many": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
+    "rn_transpose_many": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "rn_conv3x3_levels_dgrad_weight": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "rn_transform_batch": (C.c_int, [_vp, _vp, _vp, C.c_int, C.POINTER(_f32), C.POINTER(_f32), C.c_int, C.c_int, _vp,
                                      C.c_int, C.c_int, _vp]),
     "rn_nms_workspace_bytes": (_sz, [_i64, C.c_int]),

@@ -529,6 +529,12 @@ def _dgrad_weight(w: Tensor) -> Tensor:
     e .. e+7 carry channels Cout-8 .. Cout-1 with zero weight on the repeated ones; zeros up to Kpad."""
     Cout, Cin = w.shape[0], w.shape[1]
     Kpad = (Cout + 63) // 64 * 64
+    if w.is_cuda and w.dtype in (torch.bfloat16, torch.float16) and _cl(w) and Cout >= 8:
+        # one launch (the torch form below is a flip, a fill and two or three strided copies: ~35 us of 5-us kernels per conv)
+        out = torch.empty((Cin, Kpad, 3, 3), dtype=w.dtype, device=w.device, memory_format=torch.channels_last)
+        check(lib.rn_conv3x3_levels_dgrad_weight(w.data_ptr(), out.data_ptr(), Cout, Cin, Kpad, torch.cuda.current_stream(w.device).cuda_stream),
+              "rn_conv3x3_levels_dgrad_weight")
+        return out
     wt = w.flip(2, 3).transpose(0, 1)                                   # [Cin, Cout, 3, 3]
     out = torch.zeros((Cin, Kpad, 3, 3), dtype=w.dtype, device=w.device).contiguous(memory_format=torch.channels_last)
     e = Cout - Cout % 8

@@ -163,3 +163,80 @@ RN_API int rn_copy_many(const void *const *srcs, void *const *dsts, const int64_
     }
     return RN_OK;
 }
+
+// ---- transposes of up to 16 small 16-bit matrices in one launch ----------------------------------------------------------------
+// dsts[i] [cols_i][rows_i] = srcs[i] [rows_i][cols_i]^T: the data-gradient weights of a bottleneck's 1x1 convolutions (three
+// `w.t().contiguous()` launches of ~5 us each per block and step before).
+namespace {
+constexpr int TR_MAX = 16;
+struct TransposeTable { const uint16_t *src[TR_MAX]; uint16_t *dst[TR_MAX]; int rows[TR_MAX], cols[TR_MAX]; };
+
+__global__ __launch_bounds__(256) void transpose_many_kernel(const TransposeTable t)
+{
+    __shared__ uint16_t tile[32][33];
+    const int ti = blockIdx.y, R = t.rows[ti], Cc = t.cols[ti];
+    const int tiles_c = (Cc + 31) / 32, tiles = ((R + 31) / 32) * tiles_c;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                  // 32 x 8
+    for (int tl = blockIdx.x; tl < tiles; tl += gridDim.x) {
+        const int r0 = (tl / tiles_c) * 32, c0 = (tl % tiles_c) * 32;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = r0 + ty + 8 * j, c = c0 + tx;
+            if (r < R && c < Cc) tile[ty + 8 * j][tx] = t.src[ti][(int64_t)r * Cc + c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + ty + 8 * j, r = r0 + tx;
+            if (r < R && c < Cc) t.dst[ti][(int64_t)c * R + r] = tile[tx][ty + 8 * j];
+        }
+        __syncthreads();
+    }
+}
+
+// The data-gradient weight of a level-mode 3x3 convolution (biasact._dgrad_weight): out [Cin][9][Kpad], slot k of tap t:
+//   k < e = Cout - Cout % 8: w[k][8 - t][ci];  Cout % 8 != 0: slots e + s .. e + 7 (s = 8 - Cout % 8) carry channels e .. Cout - 1,
+//   slots e .. e + s - 1 and everything from e + 8 (or e) up to Kpad are zero.   w [Cout][9][Cin], 16-bit elements.
+__global__ __launch_bounds__(256) void levels_dgrad_weight_kernel(const uint16_t *__restrict__ w, uint16_t *__restrict__ out, const int Cout,
+                                                                  const int Cin, const int Kpad)
+{
+    const int64_t total = (int64_t)Cin * 9 * Kpad;
+    const int e = Cout - Cout % 8, sft = Cout % 8 ? 8 - Cout % 8 : 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int k = (int)(i % Kpad), t = (int)((i / Kpad) % 9), ci = (int)(i / ((int64_t)Kpad * 9));
+        int ch = -1;
+        if (k < e) ch = k;
+        else if (sft && k >= e + sft && k < e + 8) ch = k - sft;
+        out[i] = ch >= 0 ? w[((int64_t)ch * 9 + (8 - t)) * Cin + ci] : (uint16_t)0;
+    }
+}
+}  // namespace
+
+RN_API int rn_transpose_many(const void *const *srcs, void *const *dsts, const int *rows, const int *cols, int n, void *stream)
+{
+    if (!srcs || !dsts || !rows || !cols || n <= 0 || n > TR_MAX) return RN_EINVAL;
+    TransposeTable t;
+    int most = 1;
+    for (int i = 0; i < TR_MAX; ++i) {
+        const int q = i < n ? i : 0;
+        if (!srcs[q] || !dsts[q] || rows[q] <= 0 || cols[q] <= 0 || srcs[q] == dsts[q]) return RN_EINVAL;
+        t.src[i] = (const uint16_t *)srcs[q]; t.dst[i] = (uint16_t *)dsts[q]; t.rows[i] = rows[q]; t.cols[i] = cols[q];
+        const int tl = ((rows[q] + 31) / 32) * ((cols[q] + 31) / 32);
+        if (tl > most) most = tl;
+    }
+    hipLaunchKernelGGL(transpose_many_kernel, dim3((unsigned)(most > 1024 ? 1024 : most), (unsigned)n), dim3(256), 0, (hipStream_t)stream, t);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+RN_API int rn_conv3x3_levels_dgrad_weight(const void *w, void *out, int Cout, int Cin, int Kpad, void *stream)
+{
+    if (!w || !out || Cout < 8 || Cin <= 0 || Kpad < Cout || w == out) return RN_EINVAL;
+    const int64_t total = (int64_t)Cin * 9 * Kpad;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(levels_dgrad_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)w, (uint16_t *)out,
+                       Cout, Cin, Kpad);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}

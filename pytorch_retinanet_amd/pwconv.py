@@ -231,7 +231,16 @@ class _BottleneckFn(torch.autograd.Function):
         part2 = torch.empty((nb2 * 2 * Cm,), dtype=torch.float32, device=dev)
         p2 = st2.data_ptr()
         epi = RnPwEpilogue(RN_PW_EPI_RELU_BWD, part2.data_ptr(), 0, 0, z2.data_ptr(), p2 + 8 * Cm, p2 + 12 * Cm, p2, p2 + 4 * Cm)
-        w3t = w3.reshape(C4, Cm).t().contiguous().view(Cm, C4, 1, 1)
+        # the three data-gradient weights of the block in one launch
+        Cin = w1.shape[1]
+        mats = [(w3, C4, Cm), (w1, Cm, Cin)] + ([(wd, C4, Cin)] if wd is not None else [])
+        wts = [torch.empty((c, r, 1, 1), dtype=m.dtype, device=dev) for m, r, c in mats]
+        nm = len(mats)
+        check(lib.rn_transpose_many((C.c_void_p * nm)(*[m.data_ptr() for m, _, _ in mats]), (C.c_void_p * nm)(*[t.data_ptr() for t in wts]),
+                                    (C.c_int * nm)(*[r for _, r, _ in mats]), (C.c_int * nm)(*[c for _, _, c in mats]), nm, st),
+              "rn_transpose_many")
+        w3t, w1t = wts[0], wts[1]
+        wdt = wts[2] if wd is not None else None
         dy2 = pw_forward(g_out, w3t, pro=pro3, epi=epi, tag="pw_conv3_dgrad")
         dw3 = pw_wgrad(g_out, z2, w3, gpro=pro3, xpro=affine_relu(st2[2 * Cm:]), tag="pw_conv3_wgrad")
         # bn2: finalize from the epilogue sums, apply (conv2's backward is MIOpen's and wants dz2 in memory)
@@ -253,8 +262,6 @@ class _BottleneckFn(torch.autograd.Function):
         check(lib.rn_bn_act_backward(da1.data_ptr(), 0, z1.data_ptr(), dz1.data_ptr(), 0, RN_BF16, M0, Cm, g1.data_ptr(), p1, p1 + 4 * Cm,
                                      p1 + 8 * Cm, 1, 1, gr1.data_ptr(), gr1.data_ptr() + 4 * Cm, gr1.data_ptr() + 8 * Cm, wp, wn, st),
               "rn_bn_act_backward")
-        Cin = w1.shape[1]
-        w1t = w1.reshape(Cm, Cin).t().contiguous().view(Cin, Cm, 1, 1)
         dwd = dgd = dbd = None
         if wd is None:
             # the identity branch's gradient g_out * bits joins in the data-gradient GEMM's epilogue
@@ -275,7 +282,6 @@ class _BottleneckFn(torch.autograd.Function):
             # blocks) and joins conv1's data gradient in that GEMM's epilogue -- no scatter into a zero-filled tensor (MIOpen's
             # strided data gradient) and no add pass over the block's largest tensor (0.14 + 0.03 ms per step at the bench shape)
             sd = dn[0].stride[0]
-            wdt = wd.reshape(C4, Cin).t().contiguous().view(Cin, C4, 1, 1)
             dxd = pw_forward(dzd, wdt, tag="pw_down_dgrad")
             if sd in (1, 2):
                 epi1 = RnPwEpilogue(RN_PW_EPI_RESID, 0, dxd.data_ptr(), 0, 0, 0, 0, 0, 0, sd, x.shape[2], x.shape[3])
