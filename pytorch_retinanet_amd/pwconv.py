@@ -377,7 +377,8 @@ class _Conv1x1(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = pw_wgrad(g, x, w, tag="pw_1x1_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = g2.sum(0, dtype=torch.float32)
+            from .biasact import _colsum_levels                 # column sums in two launches (torch: fill + reduce, slower per byte)
+            db = _colsum_levels([g2.reshape(1, -1)], Cout) if g2.is_contiguous() else g2.sum(0, dtype=torch.float32)
         return dx, dw, db
 
 
