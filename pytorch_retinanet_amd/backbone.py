@@ -199,8 +199,9 @@ class Bottleneck(nn.Module):
             if self.bn3._fusable(out3, x):
                 return self.bn3(out3, relu=True, residual=x, link=link)
             return self.bn3(out3, relu=True, residual=x)
-        identity = x if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], x)
+        # (conv1 before the downsample branch: the first 1x1 consumer of x receives the other consumers' gradients, pwconv._GradJoin)
         out = conv_bn(self.conv1, self.bn1, x, relu=True)
+        identity = x if self.downsample is None else conv_bn(self.downsample[0], self.downsample[1], x)
         out = conv_bn(self.conv2, self.bn2, out, relu=True)
         return conv_bn(self.conv3, self.bn3, out, relu=True, residual=identity)      # relu(bn3(.) + identity), one kernel
 
@@ -248,8 +249,9 @@ class ResNetBackbone(nn.Module):
         else:
             x = self.maxpool(conv_bn(self.conv1, self.bn1, x, relu=True))
         x = self.layer1(x)
-        c3 = self.layer2(x)
-        c4 = self.layer3(c3)
+        # C3 / C4 feed the next layer's conv1 + stride-2 downsample conv and an FPN lateral: their data gradients join in one GEMM
+        c3 = pwconv.share_gradients(self.layer2(x))
+        c4 = pwconv.share_gradients(self.layer3(c3))
         c5 = self.layer4(c4)
         return {"layer_2": c3, "layer_3": c4, "layer_4": c5}
 

@@ -343,9 +343,61 @@ def _dgrad_by_mm(M: int, cin: int, cout: int) -> bool:
     return cout >= 1024 or (cin >= 512 and not (M < 10000 and cout <= 256))
 
 
+# ---- joining the gradients of ONE activation that feeds several 1x1 convolutions ------------------------------------------------
+# C3 / C4 feed the next layer's conv1, its stride-2 downsample conv and an FPN lateral: autograd adds the three data gradients with two
+# elementwise kernels over the 137 / 69 MB tensor (and MIOpen first scatters the downsample's gradient into a zero-filled one).  All
+# three are GEMMs.  The first 1x1 / stride-1 consumer of a tensor (in forward order: conv1 of the next block) becomes the RECEIVER of a
+# `_GradJoin` hung on the tensor; later consumers are DONORS: their backward runs first (autograd executes in reverse creation order),
+# leaves its result in the join and returns no gradient; the receiver's data-gradient GEMM then accumulates INTO the donated tensor
+# (`addmm_`) and adds the compact stride-2 gradients at their pixels.  A donor donates only when the engine reports that the receiver's
+# node WILL execute in this backward pass and has not run yet (`torch._C._will_engine_execute_node`); otherwise it returns its gradient the
+# ordinary way, so the result is the same sum whatever the execution order and whatever part of the graph the loss uses.
+JOIN_GRADS = True
+JOIN_STATS = {"full": 0, "compact": 0}     # donated gradients since import (tests)
+
+
+class _GradJoin:
+    __slots__ = ("recv_done", "full", "compact", "_has_receiver", "recv_node")
+
+    def __init__(self):
+        self.recv_done, self.full, self.compact, self._has_receiver, self.recv_node = False, None, [], False, None
+
+
+def share_gradients(x: Tensor) -> Tensor:
+    """Opt-in for ``x`` (called where the consumers are known: ResNetBackbone for C3 / C4): its 1x1 consumers join their data
+    gradients."""
+    if JOIN_GRADS and x.is_cuda and x.requires_grad and torch.is_grad_enabled() and getattr(x, "_rn_join", None) is None:
+        x._rn_join = _GradJoin()
+    return x
+
+
+def _receiver_will_run(j: "_GradJoin") -> bool:
+    """Inside a backward pass: is the receiver's autograd node part of THIS pass?  (A donor must not leave its gradient for a
+    receiver that never executes -- e.g. a loss that uses the lateral's output but nothing behind the next layer.)"""
+    node = j.recv_node
+    if node is None or j.recv_done:
+        return False
+    try:
+        return bool(torch._C._will_engine_execute_node(node))
+    except Exception:                    # noqa: BLE001 -- not inside an engine run / API missing: take the ordinary path
+        return False
+
+
+def _join_of(x: Tensor):
+    "-> (join, receiver?): the first 1x1 / stride-1 consumer of a tensor opted in by ``share_gradients`` is the receiver"
+    j = getattr(x, "_rn_join", None)
+    if j is None:
+        return None, False
+    if not j._has_receiver:
+        j._has_receiver = True
+        return j, True
+    return j, False
+
+
 class _Conv1x1(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias):
+    def forward(ctx, x, w, bias, join=None, receiver=False):
+        ctx.join, ctx.receiver = join, receiver
         Nimg, Cin, H, W = x.shape
         Cout = w.shape[0]
         M = Nimg * H * W
@@ -369,17 +421,69 @@ class _Conv1x1(torch.autograd.Function):
             g = g.to(x.dtype).contiguous(memory_format=torch.channels_last)
         dx = dw = db = None
         g2 = g.permute(0, 2, 3, 1).reshape(M, Cout)
+        join = ctx.join
         if ctx.needs_input_grad[0]:
+            acc = None
+            if join is not None and ctx.receiver:
+                acc, join.full = join.full, None
+                if acc is not None and not (acc.dtype == x.dtype and acc.shape == x.shape and _cl(acc)):
+                    acc = acc.to(x.dtype).contiguous(memory_format=torch.channels_last)
             if _dgrad_by_mm(M, Cin, Cout):
-                dx = (g2 @ w.reshape(Cout, Cin)).view(Nimg, H, W, Cin).permute(0, 3, 1, 2)
+                if acc is not None:
+                    dx = acc.permute(0, 2, 3, 1).reshape(M, Cin).addmm_(g2, w.reshape(Cout, Cin)).view(Nimg, H, W, Cin).permute(0, 3, 1, 2)
+                else:
+                    dx = (g2 @ w.reshape(Cout, Cin)).view(Nimg, H, W, Cin).permute(0, 3, 1, 2)
             else:
                 dx = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+                if acc is not None:
+                    dx = acc.add_(dx)
+            if join is not None and ctx.receiver:
+                for comp, sd in join.compact:                    # stride-2 consumers' gradients, on their own grid
+                    dx[:, :, ::sd, ::sd] += comp
+                join.compact, join.recv_done = [], True
+            elif join is not None and join.full is None and _receiver_will_run(join):
+                join.full, dx = dx, None                         # donor: the receiver's GEMM will accumulate into this tensor
+                JOIN_STATS["full"] += 1
         if ctx.needs_input_grad[1]:
             dw = pw_wgrad(g, x, w, tag="pw_1x1_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             from .biasact import _colsum_levels                 # column sums in two launches (torch: fill + reduce, slower per byte)
             db = _colsum_levels([g2.reshape(1, -1)], Cout) if g2.is_contiguous() else g2.sum(0, dtype=torch.float32)
-        return dx, dw, db
+        return dx, dw, db, None, None
+
+
+class _Conv1x1S2(torch.autograd.Function):
+    """A 1x1 / stride-2 convolution without bias (the downsample branch of layer2 .. layer4's first blocks): MIOpen forward; the data
+    gradient is a GEMM on the OUTPUT grid (hipBLASLt) that stays compact when a `_GradJoin` receiver will add it at its pixels; the
+    weight gradient stays on MIOpen."""
+
+    @staticmethod
+    def forward(ctx, x, w, join):
+        ctx.join = join
+        ctx.save_for_backward(x, w)
+        return F.conv2d(x, w, None, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        Nimg, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        if g.dtype != x.dtype or not _cl(g):
+            g = g.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        Ho, Wo = g.shape[2], g.shape[3]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            comp = (g.permute(0, 2, 3, 1).reshape(-1, Cout) @ w.reshape(Cout, Cin)).view(Nimg, Ho, Wo, Cin).permute(0, 3, 1, 2)
+            join = ctx.join
+            if join is not None and _receiver_will_run(join):
+                join.compact.append((comp, 2))
+                JOIN_STATS["compact"] += 1
+            else:
+                dx = torch.zeros_like(x)
+                dx[:, :, ::2, ::2] = comp
+        if ctx.needs_input_grad[1]:
+            dw = torch.ops.aten.convolution_backward(g, x, w, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        return dx, dw, None
 
 
 def conv1x1(conv, x: Tensor) -> Tensor:
@@ -389,7 +493,16 @@ def conv1x1(conv, x: Tensor) -> Tensor:
     if (MM_1X1 and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and _cl(x) and conv.kernel_size == (1, 1)
             and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and conv.in_channels % 64 == 0
             and conv.out_channels % 64 == 0 and torch.is_grad_enabled() and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 24)):
-        return _Conv1x1.apply(x, w, conv.bias)
+        join, receiver = _join_of(x)
+        y = _Conv1x1.apply(x, w, conv.bias, join, receiver)
+        if receiver:
+            join.recv_node = y.grad_fn
+        return y
+    if (MM_1X1 and JOIN_GRADS and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and _cl(x) and conv.kernel_size == (1, 1)
+            and conv.stride == (2, 2) and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and conv.in_channels % 64 == 0
+            and conv.out_channels % 64 == 0 and torch.is_grad_enabled() and x.requires_grad and getattr(x, "_rn_join", None) is not None
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 24)):
+        return _Conv1x1S2.apply(x, w, x._rn_join)          # a stride-2 consumer of a tensor that already has a receiver
     from . import biasact
     if biasact.conv3x3_bwd_fusable(conv, x):        # 3x3 / 256 -> 256 (layer3's conv2): MIOpen forward, gradients on csrc/conv.hip
         return biasact.conv3x3_mfma_bwd(conv, x)

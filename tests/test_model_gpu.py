@@ -744,3 +744,66 @@ def test_bottleneck_identity_gradient_in_conv1_gemm_equals_autograd_add():
     for n, a in res[False][2].items():
         b = res[True][2][n]
         torch.testing.assert_close(b.float(), a.float(), rtol=3e-2, atol=3e-2 * float(a.float().abs().max()), msg=n)
+
+
+def test_joined_gradients_of_c3_c4_equal_autograds_adds():
+    """C3 / C4 feed the next layer's conv1, its stride-2 downsample conv and an FPN lateral (reference: backbone.py:246-263 +
+    layers.py:44-64; autograd adds the three data gradients): with ``pwconv.share_gradients`` the donors' gradients join the
+    receiver's GEMM.  Every parameter gradient of trunk + FPN with joins == without, to bf16 summation-order noise; and a donor whose
+    receiver does not take part in the backward pass returns its gradient the ordinary way."""
+    from pytorch_retinanet_amd import backbone, pwconv
+    from pytorch_retinanet_amd.layers import FeaturePyramid
+    from pytorch_retinanet_amd.optim import use_bf16_conv_weights
+    torch.manual_seed(0)
+    m = torch.nn.ModuleDict({"trunk": backbone.resnet50(pretrained=False), "fpn": FeaturePyramid(512, 1024, 2048)})
+    # (BatchNorm on its running statistics: with batch statistics over the 40 - 160 positions of these small maps the comparison of two
+    # bf16 pipelines is ill-conditioned -- a rounding difference anywhere moves every gradient upstream by tens of percent)
+    m = m.to(DEV).to(memory_format=torch.channels_last).eval()
+    use_bf16_conv_weights(m)
+    x = torch.randn(2, 3, 192, 256, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    def run(flag):
+        pwconv.JOIN_GRADS = flag
+        for p in m.parameters():
+            p.grad = None
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                f = m["trunk"](x)
+                outs = m["fpn"]([f["layer_2"], f["layer_3"], f["layer_4"]])
+                loss = sum((o.float() ** 2).mean() for o in outs)
+            loss.backward()
+        finally:
+            pwconv.JOIN_GRADS = True
+        return {n: p.grad.float().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    before = dict(pwconv.JOIN_STATS)
+    joined = run(True)
+    assert pwconv.JOIN_STATS["full"] - before["full"] == 2 and pwconv.JOIN_STATS["compact"] - before["compact"] == 2      # C3 and C4
+    plain, plain2 = run(False), run(False)
+    assert joined.keys() == plain.keys()
+
+    def rel(u, v):
+        return {n: float((u[n] - v[n]).norm() / v[n].norm().clamp_min(1e-12)) for n in v}
+    # two runs of the SAME bf16 pipeline already differ (MIOpen's weight gradients accumulate with atomics, and every difference is
+    # carried upstream through 50 layers): the joined run must sit inside that spread
+    floor, err = rel(plain2, plain), rel(joined, plain)
+    bad = [(n, err[n], floor[n]) for n in err if err[n] > 3.0 * max(floor.values()) + 1e-2]
+    assert not bad, (bad[:6], max(floor.values()))
+    # a receiver that never runs: the loss uses C3's lateral alone (layer3 and everything behind it get no gradient) -- the donor must
+    # notice and return its gradient the ordinary way, or layer1 / layer2 / the stem would be left without one
+    def lateral_only(flag):
+        pwconv.JOIN_GRADS = flag
+        for p in m.parameters():
+            p.grad = None
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                f = m["trunk"](x)
+                (pwconv.conv1x1(m["fpn"].conv_c3_1x1, f["layer_2"]).float() ** 2).mean().backward()
+        finally:
+            pwconv.JOIN_GRADS = True
+        return {n: p.grad.float().clone() for n, p in m.named_parameters() if p.grad is not None}
+    a, b, b2 = lateral_only(True), lateral_only(False), lateral_only(False)
+    assert a.keys() == b.keys() and "trunk.conv1.weight" in a and "trunk.layer2.3.conv3.weight" in a
+    floor, err = rel(b2, b), rel(a, b)
+    bad = [(n, err[n], floor[n]) for n in err if err[n] > 3.0 * max(floor.values()) + 1e-2]
+    assert not bad, (bad[:6], max(floor.values()))
