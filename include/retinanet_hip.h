@@ -436,6 +436,14 @@ int rn_conv3x3_canvas_to_levels(const void *x, const void *w, const float *bias,
 int rn_conv3x3_levels_to_canvas(const void *const *gs, const rn_canvas_layout *layout, int row_elems,
                                 const void *w, const uint8_t *mask, void *y, int dtype, int N, int Hp, int Wp,
                                 int Kpad, int Cout, const void *zeros, void *stream);
+/* The same when the conv's INPUT was a ReLU output that feeds nothing else (the last tower layer, layers.py:147-171 /
+ * :217-241, in front of class_subnet_output / box_subnet_output): y is also multiplied by relu_mask ([M][Cout / 8] bytes, the
+ * bits rn_conv3x3_canvas_batched_ex wrote for that activation) and its column sums -- the tower layer's bias gradient -- go to
+ * dbias f32[Cout]; workspace: rn_conv3x3_colsum_workspace_bytes(1, N * Hp * Wp, Cout). */
+int rn_conv3x3_levels_to_canvas_relu(const void *const *gs, const rn_canvas_layout *layout, int row_elems, const void *w,
+                                     const uint8_t *relu_mask, const uint8_t *mask, void *y, float *dbias, int dtype, int N, int Hp,
+                                     int Wp, int Kpad, int Cout, const void *zeros, void *workspace, size_t workspace_bytes,
+                                     void *stream);
 /* Its weight gradient: dw [row_elems][3][3][Cin = 256] bf16 = sum over canvas positions of gs (gathered) x the
  * tapped canvas input x [M][256].  workspace: rn_conv3x3_wgrad_workspace_bytes((row_elems + 255) / 256, M). */
 int rn_conv3x3_levels_wgrad(const void *const *gs, const rn_canvas_layout *layout, int row_elems,

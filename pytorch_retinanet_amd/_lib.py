@@ -103,6 +103,8 @@ SIGNATURES = {
                                               _vp, _vp]),
     "rn_conv3x3_levels_to_canvas": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                               C.c_int, _vp, _vp]),
+    "rn_conv3x3_levels_to_canvas_relu": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                   C.c_int, _vp, _vp, _sz, _vp]),
     "rn_conv3x3_levels_wgrad": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp,
                                           _sz, _vp]),
     "rn_conv3x3_canvas_batched_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _i64, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),

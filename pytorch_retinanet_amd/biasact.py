@@ -191,10 +191,13 @@ class TowerLink:
     only if the gradient tensors autograd hands it are exactly the ones layer l returned -- same storage AND same version
     counter: when the output has another consumer autograd may add that gradient IN PLACE into the returned buffer -- ;
     anything else takes the ordinary ``rn_bias_act_backward`` pass (masking a pre-masked gradient again is harmless)."""
-    __slots__ = ("ptrs", "dbias", "relu_masks")
+    __slots__ = ("ptrs", "dbias", "relu_masks", "half")
 
     def __init__(self):
         self.ptrs, self.dbias, self.relu_masks = None, None, None     # relu_masks: the ReLU bits of the layer's outputs (forward)
+        # the LAST tower layer: its two outputs feed two different convs (class- / box-output), each of which deposits its half
+        # here -- (gradient data_ptr, version, bias gradient) -- after applying this layer's ReLU mask in its own data-gradient kernel
+        self.half = [None, None]
 
 
 _CS_WS: Dict[tuple, Tensor] = {}
@@ -250,7 +253,11 @@ class _TowerConvPair(torch.autograd.Function):
             gs, dbs = [dy0, dy1], list(link.dbias)            # the layer above already applied this layer's ReLU mask
         else:
             wp, wn = _workspace(dev, stream, Cout)
-            for dy, y in ((dy0, y0), (dy1, y1)):
+            for i, (dy, y) in enumerate(((dy0, y0), (dy1, y1))):
+                h = link.half[i] if link is not None else None
+                if h is not None and h[:2] == (dy.data_ptr(), dy._version) and dy.dtype == x0.dtype and _cl(dy):
+                    gs.append(dy); dbs.append(h[2])              # the output conv above already applied this layer's ReLU mask
+                    continue
                 if dy.dtype != x0.dtype or not _cl(dy):
                     dy = dy.to(x0.dtype).contiguous(memory_format=torch.channels_last)
                 g = torch.empty_like(dy)
@@ -259,7 +266,7 @@ class _TowerConvPair(torch.autograd.Function):
                                                M, Cout, Hp * Wp, 1, wp, wn, stream), "rn_bias_act_backward")
                 gs.append(g); dbs.append(db)
         if link is not None:
-            link.ptrs, link.dbias = None, None
+            link.ptrs, link.dbias, link.half = None, None, [None, None]
         dxs = [None, None]
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             wts = [torch.empty((Cin, Cout, 3, 3), dtype=w0.dtype, device=dev, memory_format=torch.channels_last) for _ in range(2)]
@@ -551,7 +558,8 @@ class _ClsOutputConv(torch.autograd.Function):
     copy); data and weight gradients gather the dense per-level gradients back (``csrc/conv.hip``, level modes)."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, canvas, num_classes, n_images):
+    def forward(ctx, x, w, bias, canvas, num_classes, n_images, relu_link=None):
+        ctx.relu_link = relu_link
         sheets, Cin, Hp, Wp = x.shape
         N = int(n_images)
         Cout = w.shape[0]
@@ -595,8 +603,7 @@ class _ClsOutputConv(torch.autograd.Function):
             dx = torch.empty_like(x)
             wt = _dgrad_weight(w)
             _mfma_call("mfma_cls_output_dgrad", dev, 2.0 * real * Cout * 9 * Cin,
-                       lambda: lib.rn_conv3x3_levels_to_canvas(_ptr_array(gs), lv, Cout, wt.data_ptr(), cv.mask.data_ptr(), dx.data_ptr(),
-                                                               _DT[x.dtype], sheets, Hp, Wp, wt.shape[1], Cin, _zero_page(dev).data_ptr(), stream),
+                       lambda: _levels_dgrad(ctx.relu_link, gs, lv, Cout, wt, cv, dx, x, sheets, Hp, Wp, Cin, stream),
                        "rn_conv3x3_levels_to_canvas")
         if ctx.needs_input_grad[1]:
             need = lib.rn_conv3x3_wgrad_workspace_bytes((Cout + 255) // 256, sheets * Hp * Wp)
@@ -611,7 +618,7 @@ class _ClsOutputConv(torch.autograd.Function):
                        "rn_conv3x3_levels_wgrad")
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum_levels(gs, Cout)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 def _colsum_levels(gs: Sequence[Tensor], C_: int) -> Tensor:
@@ -639,7 +646,8 @@ class _BoxOutputConv(torch.autograd.Function):
     165 us); the weight gradient stays with MIOpen on the re-assembled canvas gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, canvas, n_images):
+    def forward(ctx, x, w, bias, canvas, n_images, relu_link=None):
+        ctx.relu_link = relu_link
         ctx.save_for_backward(x, w)
         ctx.canvas, ctx.n_images, ctx.has_bias = canvas, int(n_images), bias is not None
         N = ctx.n_images
@@ -682,8 +690,7 @@ class _BoxOutputConv(torch.autograd.Function):
             dx = torch.empty_like(x)
             wt = _dgrad_weight(w)
             _mfma_call("mfma_box_output_dgrad", dev, 2.0 * N * sum(h * wd for h, wd in cv.shapes) * Cout * 9 * Cin,
-                       lambda: lib.rn_conv3x3_levels_to_canvas(_ptr_array(gs), _layout(cv, N), Cout, wt.data_ptr(), cv.mask.data_ptr(), dx.data_ptr(),
-                                                               _DT[x.dtype], sheets, Hp, Wp, wt.shape[1], Cin, _zero_page(dev).data_ptr(), stream),
+                       lambda: _levels_dgrad(ctx.relu_link, gs, _layout(cv, N), Cout, wt, cv, dx, x, sheets, Hp, Wp, Cin, stream),
                        "rn_conv3x3_levels_to_canvas")
         if ctx.needs_input_grad[1] and BOX_OUTPUT_WGRAD_MFMA and Cin == 256:
             # the narrow (<= 64 rows) variant of the gathering MFMA weight-gradient kernel
@@ -703,16 +710,39 @@ class _BoxOutputConv(torch.autograd.Function):
             dw = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum_levels(gs, Cout)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 def box_output_conv_fusable(x: Tensor, conv, canvas: "Canvas") -> bool:
     return cls_output_conv_fusable(x, conv, canvas) and conv.out_channels % 4 == 0
 
 
-def box_output_conv(x: Tensor, conv, canvas: "Canvas", n_images: int) -> List[Tensor]:
+def _levels_dgrad(relu_link, gs, lv, Cout, wt, cv, dx, x, sheets, Hp, Wp, Cin, stream) -> int:
+    """Data gradient of a level-mode output conv.  ``relu_link = (TowerLink, i)``: x was output i of the last tower layer and feeds
+    nothing else -- that layer's ReLU backward and bias gradient ride in this kernel's epilogue (``rn_conv3x3_levels_to_canvas_relu``)
+    and the result is deposited in the link for ``_TowerConvPair.backward`` to pick up."""
+    dev = x.device
+    link, i = relu_link if relu_link is not None else (None, 0)
+    if link is None or link.relu_masks is None or not FUSE_TOWER_RELU_BWD:
+        return lib.rn_conv3x3_levels_to_canvas(_ptr_array(gs), lv, Cout, wt.data_ptr(), cv.mask.data_ptr(), dx.data_ptr(), _DT[x.dtype], sheets,
+                                               Hp, Wp, wt.shape[1], Cin, _zero_page(dev).data_ptr(), stream)
+    need = lib.rn_conv3x3_colsum_workspace_bytes(1, sheets * Hp * Wp, Cin)
+    key = (dev.index, stream, "lv")
+    wsb = _CS_WS.get(key)
+    if wsb is None or wsb.numel() < need:
+        wsb = _CS_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
+    db = torch.empty((Cin,), dtype=torch.float32, device=dev)
+    rc = lib.rn_conv3x3_levels_to_canvas_relu(_ptr_array(gs), lv, Cout, wt.data_ptr(), link.relu_masks[i].data_ptr(), cv.mask.data_ptr(),
+                                              dx.data_ptr(), db.data_ptr(), _DT[x.dtype], sheets, Hp, Wp, wt.shape[1], Cin,
+                                              _zero_page(dev).data_ptr(), wsb.data_ptr(), wsb.numel(), stream)
+    if rc == 0:
+        link.half[i] = (dx.data_ptr(), dx._version, db)
+    return rc
+
+
+def box_output_conv(x: Tensor, conv, canvas: "Canvas", n_images: int, relu_link=None) -> List[Tensor]:
     "``conv(x)`` for the box-output conv on a canvas -> per-level deltas ``[n_images, h*w*A, 4]`` (dense)."
-    return list(_BoxOutputConv.apply(x, conv.weight.to(x.dtype), conv.bias, canvas, n_images))
+    return list(_BoxOutputConv.apply(x, conv.weight.to(x.dtype), conv.bias, canvas, n_images, relu_link))
 
 
 def cls_output_conv_fusable(x: Tensor, conv, canvas: "Canvas") -> bool:
@@ -724,11 +754,11 @@ def cls_output_conv_fusable(x: Tensor, conv, canvas: "Canvas") -> bool:
             and (conv.bias is None or conv.bias.dtype == torch.float32))
 
 
-def cls_output_conv(x: Tensor, conv, canvas: "Canvas", num_classes: int, n_images: Optional[int] = None) -> List[Tensor]:
+def cls_output_conv(x: Tensor, conv, canvas: "Canvas", num_classes: int, n_images: Optional[int] = None, relu_link=None) -> List[Tensor]:
     """``conv(x)`` for the class-output conv on a canvas -> per-level logits ``[n_images, h*w*A, num_classes]`` (dense);
     ``n_images`` defaults to every slot of every sheet."""
     n = x.shape[0] * canvas.slots if n_images is None else int(n_images)
-    return list(_ClsOutputConv.apply(x, conv.weight.to(x.dtype), conv.bias, canvas, num_classes, n))
+    return list(_ClsOutputConv.apply(x, conv.weight.to(x.dtype), conv.bias, canvas, num_classes, n, relu_link))
 
 
 # ---------------------------------------------------------------------------------------------------

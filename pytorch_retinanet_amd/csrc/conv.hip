@@ -1247,6 +1247,40 @@ RN_API int rn_conv3x3_levels_to_canvas(const void *const *gs, const rn_canvas_la
     return conv_launch_mode<MODE_FROM_LEVELS>(a, grid, (hipStream_t)stream);
 }
 
+// rn_conv3x3_levels_to_canvas whose INPUT-side activation was a ReLU output (the last tower layer in front of the class- / box-
+// output conv): the result is also multiplied by the ReLU bits of that activation and its column sums -- the bias gradient of the
+// layer below -- go to dbias (rn_conv3x3_canvas_dgrad_relu_batched's epilogue on the gathering kernel).
+RN_API int rn_conv3x3_levels_to_canvas_relu(const void *const *gs, const rn_canvas_layout *layout, int row_elems, const void *w,
+                                            const uint8_t *relu_mask, const uint8_t *mask, void *y, float *dbias, int dtype, int N, int Hp,
+                                            int Wp, int Kpad, int Cout, const void *zeros, void *workspace, size_t workspace_bytes,
+                                            void *stream)
+{
+    if (!gs || !w || !y || !zeros || !relu_mask || !dbias || !workspace || N <= 0 || Hp <= 2 || Wp <= 2 || Kpad <= 0 || Cout <= 0) return RN_EINVAL;
+    if (dtype != RN_BF16 || Kpad % CONV_BK || Cout % CONV_BN || Kpad < row_elems || Kpad - row_elems >= CONV_BK ||
+        (int64_t)N * Hp * Wp >= (1 << 22) || row_elems < 8)
+        return RN_EUNSUPPORTED;
+    if (!rn::aligned(w, 16) || !rn::aligned(y, 16) || !rn::aligned(zeros, 16) || !rn::aligned(relu_mask, 16)) return RN_EALIGN;
+    const int64_t M = (int64_t)N * Hp * Wp;
+    if (workspace_bytes < rn_conv3x3_colsum_workspace_bytes(1, M, Cout)) return RN_EWORKSPACE;
+    ConvArgs a = {};
+    const int rc = fill_levels(a.lv, layout, row_elems, const_cast<void *const *>(gs), N, Hp, Wp);
+    if (rc != RN_OK) return rc;
+    for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) {
+        a.Xs[p] = nullptr; a.Ws[p] = (const uint16_t *)w; a.biases[p] = nullptr; a.Ys[p] = (uint16_t *)y;
+        a.relu_masks[p] = relu_mask; a.colsums[p] = (float *)workspace;
+    }
+    a.mask = mask; a.M = M; a.HWp = (int64_t)Hp * Wp; a.Cin = Kpad; a.Cout = Cout; a.Wp = Wp; a.relu = 0;
+    a.zeros = (const uint16_t *)zeros;
+    const int64_t tiles = (M + CONV_BM - 1) / CONV_BM;
+    const dim3 grid((unsigned)tiles, (unsigned)(Cout / CONV_BN), 1);
+    const int rc2 = conv_launch_mode<MODE_FROM_LEVELS>(a, grid, (hipStream_t)stream);
+    if (rc2 != RN_OK) return rc2;
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((Cout + 7) / 8), 1), dim3(256), 0, (hipStream_t)stream, (const float *)workspace,
+                       (int)tiles, Cout, dbias, dbias, dbias, dbias);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
 // Position splits of the weight-gradient kernels: one workgroup per (split, tap, problem), about one wave of the chip.
 static int wgrad_splits(const int P, const int64_t M, int *tiles_per_split)
 {

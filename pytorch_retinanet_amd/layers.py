@@ -217,6 +217,7 @@ class RetinaNetHead(nn.Module):
             mfma = self.mfma_towers and all(biasact.tower_conv_fusable(xb[0], m) for m in convs)
             cv = biasact.Canvas.of(xb, pad=1 if mfma else 0)
             packed = biasact.pack_levels(cv, xb)
+            top = None                             # TowerLink of the towers' last layer (paired towers only)
             cc = [m for m in ch.class_subnet if isinstance(m, nn.Conv2d)]
             bc = [m for m in rh.box_subnet if isinstance(m, nn.Conv2d)]
             if mfma and self.pair_towers and len(cc) == len(bc) and all(c.weight.shape == b.weight.shape and c.in_channels % 256 == 0
@@ -224,10 +225,11 @@ class RetinaNetHead(nn.Module):
                 xc = xb_ = packed                  # both towers layer by layer, one batched launch per layer and direction
                 prev = None                        # (a layer's outputs feed only the next layer: its ReLU backward rides in
                 for i, (c, b) in enumerate(zip(cc, bc)):       #  that layer's data-gradient kernel, biasact.TowerLink)
-                    link = biasact.TowerLink() if i + 1 < len(cc) else None
+                    link = biasact.TowerLink()           # (the last layer's link goes to the two output convs below)
                     xc, xb_ = biasact.tower_conv_pair(xc, xb_, c.weight, b.weight, c.bias, b.bias, cv.mask, prev, link)
                     prev = link
                 cls_c, box_t = xc, xb_
+                top = prev
             else:
                 cls_c = _tower_on_canvas(ch.class_subnet, packed, cv.mask, mfma)
                 box_t = _tower_on_canvas(rh.box_subnet, packed, cv.mask, mfma)
@@ -235,14 +237,15 @@ class RetinaNetHead(nn.Module):
             # small output instead of the 256-channel tower output
             n_img = xb[0].shape[0]
             if mfma and self.mfma_box_output and biasact.box_output_conv_fusable(box_t, rh.box_subnet_output, cv):
-                box_levels = biasact.box_output_conv(box_t, rh.box_subnet_output, cv, n_img)      # MFMA data gradient
+                box_levels = biasact.box_output_conv(box_t, rh.box_subnet_output, cv, n_img, relu_link=(top, 1) if top is not None else None)
             else:
                 box_c = rh.box_subnet_output(box_t)
                 box_levels = [_to_anchor_major(t, 4) for t in biasact.unpack_levels(cv, box_c, n_img)]
             if mfma and self.mfma_cls_output and biasact.cls_output_conv_fusable(cls_c, ch.class_subnet_output, cv):
                 # class-output conv straight from the canvas to dense per-level logits [N, h*w*A, K]: exactly A*K channels
                 # (no dead classes for the loss kernel to stream) and no unpack copy of the 256-channel tower output
-                return {"cls_levels": biasact.cls_output_conv(cls_c, ch.class_subnet_output, cv, ch.num_classes, n_img),
+                return {"cls_levels": biasact.cls_output_conv(cls_c, ch.class_subnet_output, cv, ch.num_classes, n_img,
+                                                              relu_link=(top, 0) if top is not None else None),
                         "bbox_levels": box_levels}
             cls_t = biasact.unpack_levels(cv, cls_c, n_img)
             return {"cls_levels": ch.output_levels(cls_t, pad_classes), "bbox_levels": box_levels}

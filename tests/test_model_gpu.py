@@ -807,3 +807,59 @@ def test_joined_gradients_of_c3_c4_equal_autograds_adds():
     floor, err = rel(b2, b), rel(a, b)
     bad = [(n, err[n], floor[n]) for n in err if err[n] > 3.0 * max(floor.values()) + 1e-2]
     assert not bad, (bad[:6], max(floor.values()))
+
+
+def test_top_tower_layer_relu_backward_rides_in_the_output_convs_data_gradient():
+    """The last tower layer's ReLU backward + bias gradient in the epilogue of the class- / box-output convs' data-gradient kernel
+    (``rn_conv3x3_levels_to_canvas_relu``) == the separate ``rn_bias_act_backward`` pass: every head parameter gradient and the input
+    gradients bit-equal (bias gradients: fp32 summation order)."""
+    from pytorch_retinanet_amd import biasact
+    from pytorch_retinanet_amd.layers import RetinaNetHead
+    torch.manual_seed(1)
+    head = RetinaNetHead(256, 256, 9, 6, 0.01).to(DEV).to(memory_format=torch.channels_last)
+    for m in head.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.normal_(m.weight, std=0.03)
+            torch.nn.init.normal_(m.bias, std=0.1)
+    feats = [torch.randn(2, 256, h, w, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+             for h, w in ((16, 20), (8, 10), (4, 5), (2, 3), (1, 2))]
+    calls = {"n": 0}
+    real = biasact.lib.rn_conv3x3_levels_to_canvas_relu
+
+    def run(flag):
+        biasact.FUSE_TOWER_RELU_BWD = flag
+        head.zero_grad()
+        for f in feats:
+            f.grad = None
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                out = head.forward_levels(feats)
+                loss = sum((t.float() ** 2).sum() for t in out["cls_levels"]) + sum((t.float() ** 3).sum() for t in out["bbox_levels"])
+            loss.backward()
+        finally:
+            biasact.FUSE_TOWER_RELU_BWD = True
+        return [f.grad.clone() for f in feats], {n: p.grad.clone() for n, p in head.named_parameters()}
+
+    half_seen = []
+    orig = biasact._levels_dgrad
+
+    def spy(relu_link, *a, **k):
+        rc = orig(relu_link, *a, **k)
+        half_seen.append(relu_link is not None and relu_link[0] is not None and relu_link[0].half[relu_link[1]] is not None)
+        return rc
+    biasact._levels_dgrad = spy
+    try:
+        fused = run(True)
+        assert half_seen == [True, True] or half_seen == [True, True][::-1], half_seen      # both output convs deposited their half
+        half_seen.clear()
+        plain = run(False)
+        assert half_seen == [False, False]
+    finally:
+        biasact._levels_dgrad = orig
+    for a, b in zip(fused[0], plain[0]):
+        assert torch.equal(a, b)
+    for n in plain[1]:
+        if n.endswith("bias"):
+            torch.testing.assert_close(fused[1][n], plain[1][n], rtol=1e-4, atol=1e-4 * float(plain[1][n].abs().max()))
+        else:
+            assert torch.equal(fused[1][n], plain[1][n]), n
