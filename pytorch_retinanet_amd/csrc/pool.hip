@@ -68,27 +68,89 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const void *__restrict
                                                           const PoolShape s, const float *__restrict__ coef_a = nullptr,
                                                           const float *__restrict__ coef_b = nullptr)
 {
-    const int64_t total = (int64_t)s.N * s.OH * s.OW * s.C8;
-    // back to front: the producer (the stem's BN apply, 275 MB) wrote the end of x last, the Infinity Cache still holds it
+    // A thread owns the 2 x 2 block of OUTPUT elements (2A .. 2A+1, 2B .. 2B+1): their windows span 5 x 5 input elements, which are
+    // loaded (and, with AFF, normalised) once -- 25 loads for 4 outputs instead of 36.  Input elements are visited in row-major order,
+    // which restricted to one window is that window's scan order: PyTorch's rule (first maximum, last NaN) is kept.
+    const int HB = (s.OH + 1) >> 1, WB = (s.OW + 1) >> 1;
+    const int64_t total = (int64_t)s.N * HB * WB * s.C8;
+    // back to front: the producer (the stem's conv / BN apply, 275 MB) wrote the end of x last, the Infinity Cache still holds it
     for (int64_t ii = (int64_t)blockIdx.x * 256 + threadIdx.x; ii < total; ii += (int64_t)gridDim.x * 256) {
         const int64_t i = total - 1 - ii;
-        int cg, ox, oy, n;
-        split_index(i, total < (1ll << 31), s.C8, s.OW, s.OH, cg, ox, oy, n);
-        float m[8], ca[8], cb[8];
-        int k[8];
+        int cg, B, A, n;
+        split_index(i, total < (1ll << 31), s.C8, WB, HB, cg, B, A, n);
+        if constexpr (AFF && DT != RN_F32) {
+            // After the ReLU every value is a non-negative 16-bit float (a NaN input has become 0, as in bn_apply_kernel), so values
+            // order like their bit patterns: key = bits << 16 | (15 - window position), one v_max_u32 per element and output keeps
+            // the maximum and, among equal values, the FIRST position -- PyTorch's rule -- instead of a compare / select chain.
+            uint32_t key[4][8];
+            float ca[8], cb[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; k[j] = -1; }
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) key[o][j] = 0u;            // below every real key (position field >= 7)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { ca[j] = coef_a[cg * 8 + j]; cb[j] = coef_b[cg * 8 + j]; }
+#pragma unroll
+            for (int ri = 0; ri < 5; ++ri) {
+                const int iy = 4 * A - 1 + ri;
+                if (iy < 0 || iy >= s.H) continue;
+#pragma unroll
+                for (int ci = 0; ci < 5; ++ci) {
+                    const int ix = 4 * B - 1 + ci;
+                    if (ix < 0 || ix >= s.W) continue;
+                    float f[8];
+                    v8<DT>::ld(x, (((int64_t)n * s.H + iy) * s.W + ix) * s.C8 + cg, f);
+                    uint32_t hb[8];                                     // value bits in the HIGH half
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const float t0 = fmaf(f[j], ca[j], cb[j]), t1 = fmaf(f[j + 1], ca[j + 1], cb[j + 1]);
+                        const uint32_t pkd = rn::dt<DT>::pk(t0 > 0.0f ? t0 : 0.0f, t1 > 0.0f ? t1 : 0.0f);
+                        hb[j] = pkd << 16; hb[j + 1] = pkd & 0xffff0000u;
+                    }
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        const int r = ri - 2 * (o >> 1), q = ci - 2 * (o & 1);
+                        if (r < 0 || r > 2 || q < 0 || q > 2) continue;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { const uint32_t c = hb[j] | (uint32_t)(15 - (r * 3 + q)); key[o][j] = c > key[o][j] ? c : key[o][j]; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const int oy = 2 * A + (o >> 1), ox = 2 * B + (o & 1);
+                if (oy >= s.OH || ox >= s.OW) continue;
+                const int64_t v = (((int64_t)n * s.OH + oy) * s.OW + ox) * s.C8 + cg;
+                rn::u32x4 out;
+                out.x = (key[o][0] >> 16) | (key[o][1] & 0xffff0000u); out.y = (key[o][2] >> 16) | (key[o][3] & 0xffff0000u);
+                out.z = (key[o][4] >> 16) | (key[o][5] & 0xffff0000u); out.w = (key[o][6] >> 16) | (key[o][7] & 0xffff0000u);
+                ((rn::u32x4 *)y)[v] = out;
+                if (idx) {
+                    rn::u32x2 pk;
+                    pk.x = (15u - (key[o][0] & 15u)) | ((15u - (key[o][1] & 15u)) << 8) | ((15u - (key[o][2] & 15u)) << 16) | ((15u - (key[o][3] & 15u)) << 24);
+                    pk.y = (15u - (key[o][4] & 15u)) | ((15u - (key[o][5] & 15u)) << 8) | ((15u - (key[o][6] & 15u)) << 16) | ((15u - (key[o][7] & 15u)) << 24);
+                    ((rn::u32x2 *)idx)[v] = pk;
+                }
+            }
+            continue;
+        }
+        float m[4][8], ca[8], cb[8];
+        int k[4][8];
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { m[o][j] = -INFINITY; k[o][j] = -1; }
         if (AFF) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { ca[j] = coef_a[cg * 8 + j]; cb[j] = coef_b[cg * 8 + j]; }
         }
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int iy = 2 * oy - 1 + r;
+        for (int ri = 0; ri < 5; ++ri) {
+            const int iy = 4 * A - 1 + ri;
             if (iy < 0 || iy >= s.H) continue;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int ix = 2 * ox - 1 + q;
+            for (int ci = 0; ci < 5; ++ci) {
+                const int ix = 4 * B - 1 + ci;
                 if (ix < 0 || ix >= s.W) continue;
                 float f[8];
                 v8<DT>::ld(x, (((int64_t)n * s.H + iy) * s.W + ix) * s.C8 + cg, f);
@@ -97,63 +159,85 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const void *__restrict
                     for (int j = 0; j < 8; ++j) { const float t = fmaf(f[j], ca[j], cb[j]); f[j] = pool_round<DT>(t > 0.0f ? t : 0.0f); }
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (k[j] < 0 || f[j] > m[j] || f[j] != f[j]) { m[j] = f[j]; k[j] = r * 3 + q; }   // PyTorch's scan: first maximum, last NaN
+                for (int o = 0; o < 4; ++o) {
+                    const int oj = o >> 1, ok_ = o & 1, r = ri - 2 * oj, q = ci - 2 * ok_;     // position inside output o's window
+                    if (r < 0 || r > 2 || q < 0 || q > 2) continue;                            // (compile-time after unrolling)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (k[o][j] < 0 || f[j] > m[o][j] || f[j] != f[j]) { m[o][j] = f[j]; k[o][j] = r * 3 + q; }   // PyTorch's scan: first maximum, last NaN
+                }
             }
         }
-        v8<DT>::st(y, i, m);
-        if (idx) {
-            rn::u32x2 pk;
-            pk.x = (uint32_t)k[0] | ((uint32_t)k[1] << 8) | ((uint32_t)k[2] << 16) | ((uint32_t)k[3] << 24);
-            pk.y = (uint32_t)k[4] | ((uint32_t)k[5] << 8) | ((uint32_t)k[6] << 16) | ((uint32_t)k[7] << 24);
-            ((rn::u32x2 *)idx)[i] = pk;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int oy = 2 * A + (o >> 1), ox = 2 * B + (o & 1);
+            if (oy >= s.OH || ox >= s.OW) continue;
+            const int64_t v = (((int64_t)n * s.OH + oy) * s.OW + ox) * s.C8 + cg;
+            v8<DT>::st(y, v, m[o]);
+            if (idx) {
+                rn::u32x2 pk;
+                pk.x = (uint32_t)k[o][0] | ((uint32_t)k[o][1] << 8) | ((uint32_t)k[o][2] << 16) | ((uint32_t)k[o][3] << 24);
+                pk.y = (uint32_t)k[o][4] | ((uint32_t)k[o][5] << 8) | ((uint32_t)k[o][6] << 16) | ((uint32_t)k[o][7] << 24);
+                ((rn::u32x2 *)idx)[v] = pk;
+            }
         }
     }
 }
 
-// dx of an input element = sum of dy over the (<= 4) windows whose arg-max code names it
+// dx of an input element = sum of dy over the (<= 4) windows whose arg-max code names it.  A thread owns the 2 x 2 block of input
+// elements (2a .. 2a+1, 2b .. 2b+1): together they are covered by the SAME four windows (a .. a+1) x (b .. b+1), so their code words
+// and gradient vectors are fetched once for four outputs (a thread per input element fetched them four times: 132 -> 7x us at the
+// stem's shape).  Even rows / columns lie in one window row / column only, odd ones in two.  The sums run over the windows in
+// (oy, ox) order as before: same values bit for bit.
 template <int DT>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t *__restrict__ idx, const void *__restrict__ dy,
                                                           void *__restrict__ dx, const PoolShape s)
 {
-    const int64_t total = (int64_t)s.N * s.H * s.W * s.C8;
+    const int HB = (s.H + 1) >> 1, WB = (s.W + 1) >> 1;
+    const int64_t total = (int64_t)s.N * HB * WB * s.C8;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        int cg, ix, iy, n;
-        split_index(i, total < (1ll << 31), s.C8, s.W, s.H, cg, ix, iy, n);
-        float g[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) g[j] = 0.0f;
-        // windows (oy, ox) that contain (iy, ix): 2*o - 1 <= i <= 2*o + 1, at most 2 x 2 of them.  All four code words and
-        // all four gradient vectors are fetched up front (clamped addresses, masked afterwards): no load waits on a compare
-        const int oy0 = iy >> 1, oy1 = (iy + 1) >> 1, ox0 = ix >> 1, ox1 = (ix + 1) >> 1;
-        int64_t w[4];
+        int cg, b, a, n;
+        split_index(i, total < (1ll << 31), s.C8, WB, HB, cg, b, a, n);
+        // the four windows (clamped addresses, masked afterwards): all loads up front
         bool ok[4];
-        uint32_t rep[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int oy = oy0 + (k >> 1), ox = ox0 + (k & 1);
-            ok[k] = oy <= oy1 && oy < s.OH && ox <= ox1 && ox < s.OW;
-            const int oyc = ok[k] ? oy : oy0 < s.OH ? oy0 : s.OH - 1, oxc = ok[k] ? ox : ox0 < s.OW ? ox0 : s.OW - 1;
-            w[k] = (((int64_t)n * s.OH + oyc) * s.OW + oxc) * s.C8 + cg;
-            rep[k] = (uint32_t)((iy - (2 * oyc - 1)) * 3 + (ix - (2 * oxc - 1))) * 0x01010101u;
-        }
         rn::u32x2 pk[4];
         float gv[4][8];
+        int64_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int oy = a + (k >> 1), ox = b + (k & 1);
+            ok[k] = oy < s.OH && ox < s.OW;
+            const int oyc = oy < s.OH ? oy : s.OH - 1, oxc = ox < s.OW ? ox : s.OW - 1;
+            w[k] = (((int64_t)n * s.OH + oyc) * s.OW + oxc) * s.C8 + cg;
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) pk[k] = ((const rn::u32x2 *)idx)[w[k]];
 #pragma unroll
         for (int k = 0; k < 4; ++k) v8<DT>::ld(dy, w[k], gv[k]);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            // byte-wise compare: zero bytes of (pk ^ rep) are the channels whose arg-max is this element
-            const uint32_t d0 = pk[k].x ^ rep[k], d1 = pk[k].y ^ rep[k];
+        for (int e = 0; e < 4; ++e) {
+            const int ey = e >> 1, ex = e & 1, iy = 2 * a + ey, ix = 2 * b + ex;
+            if (iy >= s.H || ix >= s.W) continue;
+            float g[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                g[j] += (ok[k] && ((d0 >> (8 * j)) & 0xffu) == 0u) ? gv[k][j] : 0.0f;
-                g[j + 4] += (ok[k] && ((d1 >> (8 * j)) & 0xffu) == 0u) ? gv[k][j + 4] : 0.0f;
+            for (int j = 0; j < 8; ++j) g[j] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int ky = k >> 1, kx = k & 1;
+                // window row a + ky covers row iy = 2a + ey  <=>  ky == 0 or (ky == 1 and ey == 1); likewise for columns
+                const bool covers = (ky == 0 || ey == 1) && (kx == 0 || ex == 1);
+                if (!covers) continue;
+                // position of (iy, ix) inside window (a + ky, b + kx): row iy - (2 (a + ky) - 1) = ey + 1 - 2 ky
+                const uint32_t rep = (uint32_t)((ey + 1 - 2 * ky) * 3 + (ex + 1 - 2 * kx)) * 0x01010101u;
+                const uint32_t d0 = pk[k].x ^ rep, d1 = pk[k].y ^ rep;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    g[j] += (ok[k] && ((d0 >> (8 * j)) & 0xffu) == 0u) ? gv[k][j] : 0.0f;
+                    g[j + 4] += (ok[k] && ((d1 >> (8 * j)) & 0xffu) == 0u) ? gv[k][j + 4] : 0.0f;
+                }
             }
+            v8<DT>::st(dx, (((int64_t)n * s.H + iy) * s.W + ix) * s.C8 + cg, g);
         }
-        v8<DT>::st(dx, i, g);
     }
 }
 
@@ -217,7 +301,7 @@ RN_API int rn_maxpool3x3s2_forward(const void *x, void *y, uint8_t *argmax, int 
     if (dtype != RN_F32 && dtype != RN_BF16 && dtype != RN_F16) return RN_EINVAL;
     if (!rn::aligned(x, 16) || !rn::aligned(y, 16) || (argmax && !rn::aligned(argmax, 8))) return RN_EALIGN;
     const PoolShape s{N, H, W, C / 8, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
-    const dim3 g(pool_blocks((int64_t)N * s.OH * s.OW * s.C8)), b(256);
+    const dim3 g(pool_blocks((int64_t)N * ((s.OH + 1) / 2) * ((s.OW + 1) / 2) * s.C8)), b(256);      // a thread per 2 x 2 block of outputs
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
         case RN_F32: hipLaunchKernelGGL((maxpool_fwd_kernel<RN_F32>), g, b, 0, st, x, y, argmax, s, nullptr, nullptr); break;
@@ -236,7 +320,7 @@ RN_API int rn_bn_relu_maxpool3x3s2_forward(const void *x, const float *coef, voi
     if (dtype != RN_F32 && dtype != RN_BF16 && dtype != RN_F16) return RN_EINVAL;
     if (!rn::aligned(x, 16) || !rn::aligned(y, 16) || (argmax && !rn::aligned(argmax, 8))) return RN_EALIGN;
     const PoolShape s{N, H, W, C / 8, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
-    const dim3 g(pool_blocks((int64_t)N * s.OH * s.OW * s.C8)), b(256);
+    const dim3 g(pool_blocks((int64_t)N * ((s.OH + 1) / 2) * ((s.OW + 1) / 2) * s.C8)), b(256);      // a thread per 2 x 2 block of outputs
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
         case RN_F32: hipLaunchKernelGGL((maxpool_fwd_kernel<RN_F32, true>), g, b, 0, st, x, y, argmax, s, coef, coef + C); break;
@@ -255,7 +339,7 @@ RN_API int rn_maxpool3x3s2_backward(const uint8_t *argmax, const void *dy, void 
     if (dtype != RN_F32 && dtype != RN_BF16 && dtype != RN_F16) return RN_EINVAL;
     if (!rn::aligned(argmax, 8) || !rn::aligned(dy, 16) || !rn::aligned(dx, 16)) return RN_EALIGN;
     const PoolShape s{N, H, W, C / 8, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
-    const dim3 g(pool_blocks((int64_t)N * H * W * s.C8)), b(256);
+    const dim3 g(pool_blocks((int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * s.C8)), b(256);        // a thread per 2 x 2 block of input elements
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
         case RN_F32: hipLaunchKernelGGL((maxpool_bwd_kernel<RN_F32>), g, b, 0, st, argmax, dy, dx, s); break;
