@@ -24,6 +24,8 @@
 // ran 5 - 17 % slower on random data -- the part holds a higher clock under the 16x16x32 shape (rocprof: same busy
 // cycles, shorter duration).  The weight-gradient kernel below was tried on 16x16x32 as well and was 5 - 9 % SLOWER
 // there (A/B on one box: towers 380 -> 398 us, class-output 955 -> 1046 us), so it keeps 32x32x16.
+// Staging instruction form: `buffer_load_dwordx4 ... lds` (descriptor + SGPR offset + 32-bit per-thread offset, no 64-bit VALU add per
+// piece) instead of `global_load_lds_dwordx4` was tried in round 3: towers 389 -> 393 us, class-output data gradient 519 -> 571 us.
 // Tile rounds: 1 626 equal tiles on 256 CUs fill 6.35 rounds and take 7; running the last 90 as 180 half tiles (128 rows, 8
 // waves of 64 x 64, one extra launch) was built and tested in round 3 and changed nothing (386 -> 389 us): a half tile takes as
 // long as a full one's share of the round, i.e. the launch is bound chip-wide (power / clock), not by the per-CU tile schedule.
