@@ -24,6 +24,10 @@
 // ran 5 - 17 % slower on random data -- the part holds a higher clock under the 16x16x32 shape (rocprof: same busy
 // cycles, shorter duration).  The weight-gradient kernel below was tried on 16x16x32 as well and was 5 - 9 % SLOWER
 // there (A/B on one box: towers 380 -> 398 us, class-output 955 -> 1046 us), so it keeps 32x32x16.
+// One wave per SIMD instead of ping-pong (4 waves of 128 x 128, 256-register accumulators, fragment reads and LDS-DMA pieces issued
+// between the MFMAs of the previous k-step, one barrier per K-tile) was prototyped in round 3 on the same LDS image: bit-identical
+// results, 555 us against 395 us for the tower pair -- a lone wave pays the ~60-cycle issue cost of each of its 16 LDS-DMA pieces per
+// K-tile inside its own MFMA stream; with two waves per SIMD the partner absorbs it.  Ping-pong stays.
 // Staging instruction form: `buffer_load_dwordx4 ... lds` (descriptor + SGPR offset + 32-bit per-thread offset, no 64-bit VALU add per
 // piece) instead of `global_load_lds_dwordx4` was tried in round 3: towers 389 -> 393 us, class-output data gradient 519 -> 571 us.
 // Tile rounds: 1 626 equal tiles on 256 CUs fill 6.35 rounds and take 7; running the last 90 as 180 half tiles (128 rows, 8
