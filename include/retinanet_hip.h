@@ -271,6 +271,13 @@ int rn_pw_conv_forward(const rn_pw_conv *d, const void *x, const void *w, void *
 size_t rn_pw_wgrad_workspace_bytes(const rn_pw_conv *d);
 int rn_pw_conv_wgrad(const rn_pw_conv *d, const void *g, const void *x, void *dw, const rn_pw_prologue *gpro,
                      const rn_pw_prologue *xpro, void *workspace, size_t workspace_bytes, void *stream);
+/* rn_pw_conv_wgrad in two steps, so that the split reductions of several weight gradients (a bottleneck's three or four) share ONE
+ * launch: _partial runs the position-contraction kernel only (f32 partials of *splits position splits in `workspace`, which must
+ * stay untouched until the reduction), rn_pw_wgrad_reduce_many sums up to 8 of them into their bf16 gradients (n_elems[i] =
+ * N * taps * Cin of gradient i; HOST arrays). */
+int rn_pw_conv_wgrad_partial(const rn_pw_conv *d, const void *g, const void *x, const rn_pw_prologue *gpro, const rn_pw_prologue *xpro,
+                             void *workspace, size_t workspace_bytes, int *splits, void *stream);
+int rn_pw_wgrad_reduce_many(const void *const *partials, const int *splits, const int64_t *n_elems, void *const *dws, int n, void *stream);
 
 
 /* ---- the ResNet stem convolution (7x7 / stride 2 / pad 3, 3 -> 64 channels, bias-free) -------------------------------

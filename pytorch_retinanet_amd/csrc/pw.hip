@@ -548,6 +548,40 @@ __global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float *__res
     }
 }
 
+// The same reduction for up to 8 weight gradients in one launch (blockIdx.y = gradient): a fused bottleneck's three or four
+// weight gradients are summed once at the end of its backward instead of behind each kernel (8 us of launch-bound work each).
+constexpr int RED_MAX = 8;
+struct ReduceTable { const float *partial[RED_MAX]; uint16_t *dw[RED_MAX]; int S[RED_MAX]; int64_t n4[RED_MAX]; };
+__global__ __launch_bounds__(256) void pw_wgrad_reduce_many_kernel(const ReduceTable t)
+{
+    __shared__ rn::f32x4 sh[8][32];
+    const int it = blockIdx.y;
+    const float *__restrict__ partial = t.partial[it];
+    const int S = t.S[it];
+    const int64_t n4 = t.n4[it];
+    const int j = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    for (int64_t i0 = (int64_t)blockIdx.x * 32; i0 < n4; i0 += (int64_t)gridDim.x * 32) {      // (uniform trip count per block)
+        const int64_t i = i0 + j;
+        rn::f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (i < n4)
+            for (int sp = slice; sp < S; sp += 8) {
+                const rn::f32x4 v = ((const rn::f32x4 *)partial)[sp * n4 + i];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        sh[slice][j] = s;
+        __syncthreads();
+        if (slice == 0 && i < n4) {
+            rn::f32x4 u = sh[0][j];
+#pragma unroll
+            for (int l = 1; l < 8; ++l) { const rn::f32x4 v = sh[l][j]; u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w; }
+            rn::u32x2 o;
+            o.x = rn::dt<RN_BF16>::pk(u.x, u.y); o.y = rn::dt<RN_BF16>::pk(u.z, u.w);
+            ((rn::u32x2 *)t.dw[it])[i] = o;
+        }
+        __syncthreads();
+    }
+}
+
 int cu_count()
 {
     int dev = 0, cus = 0;
@@ -717,13 +751,14 @@ RN_API size_t rn_pw_wgrad_workspace_bytes(const rn_pw_conv *d)
     return (size_t)(S0 > S1 ? S0 : S1) * d->N * d->taps * d->Cin * sizeof(float);
 }
 
-RN_API int rn_pw_conv_wgrad(const rn_pw_conv *d, const void *g, const void *x, void *dw, const rn_pw_prologue *gpro,
-                            const rn_pw_prologue *xpro, void *workspace, size_t workspace_bytes, void *stream)
+// splits >= 0: the kernel only (partials in `workspace`), *splits = their number; dw is then produced by rn_pw_wgrad_reduce_many
+static int pw_wgrad_impl(const rn_pw_conv *d, const void *g, const void *x, void *dw, const rn_pw_prologue *gpro, const rn_pw_prologue *xpro,
+                         void *workspace, size_t workspace_bytes, void *stream, int *splits)
 {
     const int rc = check_geometry(d);
     if (rc != RN_OK) return rc;
-    if (!g || !x || !dw || !workspace) return RN_EINVAL;
-    if (!rn::aligned(g, 16) || !rn::aligned(x, 16) || !rn::aligned(dw, 16) || !rn::aligned(workspace, 16)) return RN_EALIGN;
+    if (!g || !x || (!dw && !splits) || !workspace) return RN_EINVAL;
+    if (!rn::aligned(g, 16) || !rn::aligned(x, 16) || (dw && !rn::aligned(dw, 16)) || !rn::aligned(workspace, 16)) return RN_EALIGN;
     if (workspace_bytes < rn_pw_wgrad_workspace_bytes(d)) return RN_EWORKSPACE;
     WgArgs a = {};
     a.G = (const uint16_t *)g; a.X = (const uint16_t *)x; a.partial = (float *)workspace;
@@ -756,8 +791,41 @@ RN_API int rn_pw_conv_wgrad(const rn_pw_conv *d, const void *g, const void *x, v
     else if (TK == 128) r = dispatch_wgrad<64, 128>(a, pg, px, st);
     else r = dispatch_wgrad<64, 64>(a, pg, px, st);
     if (r != RN_OK) return r;
+    if (splits) { *splits = a.S; return RN_OK; }
     const int64_t n4 = (int64_t)d->N * d->taps * d->Cin / 4;
     hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, st, (const float *)workspace, a.S, n4, (uint16_t *)dw);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+RN_API int rn_pw_conv_wgrad(const rn_pw_conv *d, const void *g, const void *x, void *dw, const rn_pw_prologue *gpro,
+                            const rn_pw_prologue *xpro, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return pw_wgrad_impl(d, g, x, dw, gpro, xpro, workspace, workspace_bytes, stream, nullptr);
+}
+
+RN_API int rn_pw_conv_wgrad_partial(const rn_pw_conv *d, const void *g, const void *x, const rn_pw_prologue *gpro, const rn_pw_prologue *xpro,
+                                    void *workspace, size_t workspace_bytes, int *splits, void *stream)
+{
+    if (!splits) return RN_EINVAL;
+    return pw_wgrad_impl(d, g, x, nullptr, gpro, xpro, workspace, workspace_bytes, stream, splits);
+}
+
+RN_API int rn_pw_wgrad_reduce_many(const void *const *partials, const int *splits, const int64_t *n_elems, void *const *dws, int n, void *stream)
+{
+    if (!partials || !splits || !n_elems || !dws || n <= 0 || n > RED_MAX) return RN_EINVAL;
+    ReduceTable t;
+    int64_t most = 1;
+    for (int i = 0; i < RED_MAX; ++i) {
+        const int q = i < n ? i : 0;
+        if (!partials[q] || !dws[q] || splits[q] <= 0 || n_elems[q] <= 0 || (n_elems[q] & 3)) return RN_EINVAL;
+        if (!rn::aligned(partials[q], 16) || !rn::aligned(dws[q], 8)) return RN_EALIGN;
+        t.partial[i] = (const float *)partials[q]; t.dw[i] = (uint16_t *)dws[q]; t.S[i] = splits[q]; t.n4[i] = n_elems[q] / 4;
+        if (t.n4[i] > most) most = t.n4[i];
+    }
+    int64_t bx = (most + 31) / 32;
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(pw_wgrad_reduce_many_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, t);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

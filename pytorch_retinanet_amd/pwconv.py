@@ -38,6 +38,7 @@ FUSED_BOTTLENECK = os.environ.get("RN_FUSED_BOTTLENECK", "1") != "0"      # 0: t
 # fusion; at layer3 / layer4 (256 / 512 mid channels, K up to 2048) the GEMMs are compute-bound and the 128 x 128 register-staged
 # tiles of csrc/pw.hip run at a third of MIOpen's rate (measured: conv3 data gradient 99 us against 36 + 22 us)
 FUSED_MAX_MID = int(os.environ.get("RN_FUSED_MAX_MID", "128"))
+DEFER_WGRAD_REDUCE = True      # a fused block sums the splits of its 1x1 weight gradients in one launch at the end of its backward
 _WG_WS: Dict[tuple, Tensor] = {}
 PW_FLOP: Dict[str, float] = {}        # useful flop per call of the timed pw launches (bench.py)
 
@@ -98,8 +99,10 @@ def stats_epilogue(M: int, n_out: int, dev: torch.device) -> Tuple[RnPwEpilogue,
 
 
 def pw_wgrad(g: Tensor, x: Tensor, w_like: Tensor, stride: int = 1, gpro: Optional[RnPwPrologue] = None,
-             xpro: Optional[RnPwPrologue] = None, tag: str = "pw_wgrad") -> Tensor:
-    """Weight gradient of ``conv2d(xpro(x), w, stride)`` for the output gradient ``gpro(g)``; returns a tensor like ``w_like``."""
+             xpro: Optional[RnPwPrologue] = None, tag: str = "pw_wgrad", defer: Optional[list] = None) -> Tensor:
+    """Weight gradient of ``conv2d(xpro(x), w, stride)`` for the output gradient ``gpro(g)``; returns a tensor like ``w_like``.
+    ``defer``: a list -- only the position-contraction kernel runs now, into a private partial buffer; the returned tensor is filled by
+    ``pw_wgrad_flush(defer)``, which sums the splits of everything on the list in one launch."""
     taps = int(w_like.shape[2] * w_like.shape[3])
     d, oshape = _desc(x, int(w_like.shape[0]), taps, stride)
     assert tuple(g.shape) == oshape, (tuple(g.shape), oshape)
@@ -107,6 +110,16 @@ def pw_wgrad(g: Tensor, x: Tensor, w_like: Tensor, stride: int = 1, gpro: Option
     dev = x.device
     st = _stream(dev)
     need = lib.rn_pw_wgrad_workspace_bytes(C.byref(d))
+    if defer is not None and DEFER_WGRAD_REDUCE and len(defer) < 8:
+        ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        S = C.c_int(0)
+        PW_FLOP[tag] = 2.0 * d.M * d.N * taps * d.Cin
+        with _timed(tag, dev):
+            check(lib.rn_pw_conv_wgrad_partial(C.byref(d), g.data_ptr(), x.data_ptr(), C.byref(gpro) if gpro is not None else None,
+                                               C.byref(xpro) if xpro is not None else None, ws.data_ptr(), ws.numel(), C.byref(S), st),
+                  "rn_pw_conv_wgrad_partial")
+        defer.append((ws, int(S.value), dw.numel(), dw))
+        return dw
     key = (dev.index, st)
     ws = _WG_WS.get(key)
     if ws is None or ws.numel() < need:
@@ -116,6 +129,17 @@ def pw_wgrad(g: Tensor, x: Tensor, w_like: Tensor, stride: int = 1, gpro: Option
         check(lib.rn_pw_conv_wgrad(C.byref(d), g.data_ptr(), x.data_ptr(), dw.data_ptr(), C.byref(gpro) if gpro is not None else None,
                                    C.byref(xpro) if xpro is not None else None, ws.data_ptr(), ws.numel(), st), "rn_pw_conv_wgrad")
     return dw
+
+
+def pw_wgrad_flush(defer: list) -> None:
+    "Sum the splits of every weight gradient ``pw_wgrad(..., defer=defer)`` left on the list (one launch) and clear it."
+    if not defer:
+        return
+    n = len(defer)
+    check(lib.rn_pw_wgrad_reduce_many((C.c_void_p * n)(*[e[0].data_ptr() for e in defer]), (C.c_int * n)(*[e[1] for e in defer]),
+                                      (C.c_int64 * n)(*[e[2] for e in defer]), (C.c_void_p * n)(*[e[3].data_ptr() for e in defer]), n,
+                                      _stream(defer[0][3].device)), "rn_pw_wgrad_reduce_many")
+    defer.clear()
 
 
 # ---- BatchNorm pieces (csrc/norm.hip) --------------------------------------------------------------------------------------
@@ -242,7 +266,8 @@ class _BottleneckFn(torch.autograd.Function):
         w3t, w1t = wts[0], wts[1]
         wdt = wts[2] if wd is not None else None
         dy2 = pw_forward(g_out, w3t, pro=pro3, epi=epi, tag="pw_conv3_dgrad")
-        dw3 = pw_wgrad(g_out, z2, w3, gpro=pro3, xpro=affine_relu(st2[2 * Cm:]), tag="pw_conv3_wgrad")
+        pending: list = []                  # the block's 1x1 weight gradients: kernels now, one reduction of their splits at the end
+        dw3 = pw_wgrad(g_out, z2, w3, gpro=pro3, xpro=affine_relu(st2[2 * Cm:]), tag="pw_conv3_wgrad", defer=pending)
         # bn2: finalize from the epilogue sums, apply (conv2's backward is MIOpen's and wants dz2 in memory)
         gr2 = torch.empty((5 * Cm,), dtype=torch.float32, device=dev)
         check(lib.rn_bn_bwd_finalize(part2.data_ptr(), nb2, M1, Cm, g2.data_ptr(), p2, p2 + 4 * Cm, 1, gr2.data_ptr(), gr2.data_ptr() + 4 * Cm,
@@ -277,7 +302,7 @@ class _BottleneckFn(torch.autograd.Function):
                                          pd + 4 * C4, pd + 8 * C4, 1, 2, grd.data_ptr(), grd.data_ptr() + 4 * C4, grd.data_ptr() + 8 * C4, wp,
                                          wn, st), "rn_bn_act_backward")
             dgd, dbd = grd[:C4], grd[C4:2 * C4]
-            dwd = pw_wgrad(dzd, x, wd, stride=dn[0].stride[0], tag="pw_down_wgrad")
+            dwd = pw_wgrad(dzd, x, wd, stride=dn[0].stride[0], tag="pw_down_wgrad", defer=pending)
             # the downsample branch's data gradient is a GEMM on ITS grid (the stride-2 grid of x for layer2 .. layer4's first
             # blocks) and joins conv1's data gradient in that GEMM's epilogue -- no scatter into a zero-filled tensor (MIOpen's
             # strided data gradient) and no add pass over the block's largest tensor (0.14 + 0.03 ms per step at the bench shape)
@@ -290,7 +315,8 @@ class _BottleneckFn(torch.autograd.Function):
                 full = torch.zeros_like(x)
                 full[:, :, ::sd, ::sd] = dxd
                 dx = pw_forward(dz1, w1t, tag="pw_conv1_dgrad") + full
-        dw1 = pw_wgrad(dz1, x, w1, tag="pw_conv1_wgrad")
+        dw1 = pw_wgrad(dz1, x, w1, tag="pw_conv1_wgrad", defer=pending)
+        pw_wgrad_flush(pending)
         return (None, dx, dw1, gr1[:Cm], gr1[Cm:2 * Cm], dw2, gr2[:Cm], gr2[Cm:2 * Cm], dw3, gr3[:C4], gr3[C4:2 * C4], dwd, dgd, dbd)
 
 
