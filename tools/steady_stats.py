@@ -1,18 +1,21 @@
 #!/usr/bin/env python3
 """Steady-state per-kernel stats from a rocprofv3 kernel_trace.csv: only the dispatches of the last
 N train steps (delimited by the K3 stream kernel) are kept, so MIOpen's find-mode/JIT warm-up
-kernels do not pollute the table.  usage: steady_stats.py <kernel_trace.csv> <out.csv> [steps]"""
+kernels do not pollute the table.  ``skip``: trailing steps to leave out (bench.py's --timing-steps run EAGERLY with an event pair
+around every hand-written launch: same kernels, but 5-6 us of idle time at every pair -- they are not steady-state replays).
+usage: steady_stats.py <kernel_trace.csv> <out.csv> [steps] [skip]"""
 import csv
 import sys
 from collections import defaultdict
 
 src, dst = sys.argv[1], sys.argv[2]
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+skip = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 rows = list(csv.DictReader(open(src)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if "loss_stream_kernel" in r["Kernel_Name"]]
-assert len(marks) > steps, "not enough steps in the trace"
-lo, hi = marks[-steps - 1], marks[-1]          # [K3 of step n-steps-1, K3 of the last step): `steps` whole steps
+assert len(marks) > steps + skip, "not enough steps in the trace"
+lo, hi = marks[-steps - 1 - skip], marks[-1 - skip]          # [K3 of step n-steps-1, K3 of the last kept step): `steps` whole steps
 sel = rows[lo:hi]
 t0, t1 = int(sel[0]["Start_Timestamp"]), int(sel[-1]["End_Timestamp"])
 agg = defaultdict(list)

@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """One steady-state train step as a kernel timeline (start offset, duration, gap before, grid, name) from a rocprofv3
-kernel_trace.csv; the step is delimited by the K3 stream kernel like steady_stats.py.
-usage: step_timeline.py <kernel_trace.csv> <out.csv>"""
+kernel_trace.csv; the step is delimited by the K3 stream kernel like steady_stats.py.  ``skip``: trailing steps to leave out
+(bench.py's eager --timing-steps, whose event pairs open 5-6 us gaps around every hand-written launch).
+usage: step_timeline.py <kernel_trace.csv> <out.csv> [skip]"""
 import csv
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if "loss_stream_kernel" in r["Kernel_Name"]]
-sel = rows[marks[-2]:marks[-1]]
+skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+sel = rows[marks[-2 - skip]:marks[-1 - skip]]
 t0 = int(sel[0]["Start_Timestamp"])
 prev_end = t0
 with open(sys.argv[2], "w", newline="") as f:
