@@ -857,6 +857,7 @@ def dense_conv_group(xs: Sequence[Tensor], convs) -> List[Tensor]:
 # kernel runs it at 1.2 PFLOP/s, a half-empty round of 256 x 256 tiles cannot match that), the two gradients run on the dense
 # MFMA kernels: MIOpen's data gradient 95 us + weight gradient 87 us + 15 us of zero / cast helpers against 62 + 50 us.
 CONV3X3_BWD = True
+CONV3X3_FWD = True      # ... and the forward too (in the step CK's kernel takes 73-76 us on this shape, the dense kernel 59)
 
 
 def conv3x3_bwd_fusable(conv, x: Tensor) -> bool:
@@ -872,7 +873,20 @@ class _Conv3x3MfmaBwd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
-        return F.conv2d(x, w, None, 1, 1)
+        if not CONV3X3_FWD:
+            return F.conv2d(x, w, None, 1, 1)
+        N, _, h, wd = x.shape
+        dev = x.device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        wc = w if _cl(w) else w.contiguous(memory_format=torch.channels_last)
+        y = torch.empty_like(x)
+        _mfma_call("mfma_conv2_fwd", dev, 2.0 * N * h * wd * 256 * 2304,
+                   lambda: lib.rn_conv3x3_dense_batched(_ptr_array([x]), _ptr_array([wc]), None, _ptr_array([y]), 1, RN_BF16, N,
+                                                        _int_array([h]), _int_array([wd]), 256, 256, _zero_page(dev).data_ptr(), stream),
+                   "rn_conv3x3_dense_batched")
+        return y
 
     @staticmethod
     def backward(ctx, dy):
@@ -911,3 +925,59 @@ class _Conv3x3MfmaBwd(torch.autograd.Function):
 
 def conv3x3_mfma_bwd(conv, x: Tensor) -> Tensor:
     return _Conv3x3MfmaBwd.apply(x, conv.weight)
+
+
+# ---------------------------------------------------------------------------------------------------
+# The other 3x3 / stride-1 convolutions that stay on MIOpen (conv2 of layer1 / layer2 / layer4: 64, 128, 512 channels): the data
+# gradient of a stride-1 / pad-1 3x3 convolution IS a 3x3 / pad-1 convolution of the output gradient with the flipped, transposed
+# weights.  MIOpen's forward kernels (CK) beat its backward-data kernels on every one of these shapes and need no zero fill of the
+# result first (step timeline, layer1: 78 us against 93 + 18; layer2: 70 against 77 + 11; layer4: 101 against 119 + 8), so the data
+# gradient is issued as a forward convolution; the weight flip is one launch of the kernel the MFMA data gradients already use.
+DGRAD_AS_FWD = True
+
+
+def dgrad_as_fwd_ok(w: Tensor, stride, x: Tensor) -> bool:
+    return (DGRAD_AS_FWD and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and _cl(x) and w.dim() == 4 and
+            tuple(w.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0)
+
+
+def conv3x3_dgrad_as_fwd(g: Tensor, w: Tensor) -> Tensor:
+    "Data gradient of ``F.conv2d(x, w, None, 1, 1)`` (w [Cout, Cin, 3, 3] bf16) for the output gradient ``g``: a forward convolution."
+    dev = g.device
+    if dev.index != torch.cuda.current_device():
+        torch.cuda.set_device(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    wc = w if _cl(w) else w.contiguous(memory_format=torch.channels_last)
+    Cout, Cin = int(w.shape[0]), int(w.shape[1])
+    wt = torch.empty((Cin, Cout, 3, 3), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+    check(lib.rn_conv3x3_dgrad_weight_batched(_ptr_array([wc]), _ptr_array([wt]), 1, Cout, Cin, stream), "rn_conv3x3_dgrad_weight_batched")
+    gc = g if (g.dtype == torch.bfloat16 and _cl(g)) else g.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    return F.conv2d(gc, wt, None, 1, 1)
+
+
+class _Conv3x3DgradAsFwd(torch.autograd.Function):
+    "``F.conv2d(x, w, None, 1, 1)``; backward: data gradient as a forward convolution, weight gradient MIOpen's."
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return F.conv2d(x, w, None, 1, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        g = dy if (dy.dtype == torch.bfloat16 and _cl(dy)) else dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dx = conv3x3_dgrad_as_fwd(g, w) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        return dx, dw
+
+
+def conv3x3_dgrad_fwd_fusable(conv, x: Tensor) -> bool:
+    return (dgrad_as_fwd_ok(conv.weight, conv.stride, x) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and
+            conv.bias is None and torch.is_grad_enabled())
+
+
+def conv3x3_dgrad_fwd(conv, x: Tensor) -> Tensor:
+    return _Conv3x3DgradAsFwd.apply(x, conv.weight)

@@ -275,8 +275,14 @@ class _BottleneckFn(torch.autograd.Function):
         dz2 = torch.empty_like(z2)
         check(lib.rn_bn_bwd_apply(dy2.data_ptr(), 0, z2.data_ptr(), dz2.data_ptr(), 0, RN_BF16, M1, Cm, gr2.data_ptr() + 8 * Cm, 0, 0, st),
               "rn_bn_bwd_apply")
-        da1, dw2 = torch.ops.aten.convolution_backward(dz2, a1, w2, None, list(blk.conv2.stride), list(blk.conv2.padding), [1, 1], False,
-                                                       [0, 0], 1, [True, True, False])[:2]
+        from . import biasact
+        if biasact.dgrad_as_fwd_ok(w2, blk.conv2.stride, dz2) and tuple(blk.conv2.padding) == (1, 1):
+            # stride 1: the data gradient as a forward convolution with the flipped weights (CK's forward kernel, no zero fill)
+            da1 = biasact.conv3x3_dgrad_as_fwd(dz2, w2)
+            dw2 = torch.ops.aten.convolution_backward(dz2, a1, w2, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        else:
+            da1, dw2 = torch.ops.aten.convolution_backward(dz2, a1, w2, None, list(blk.conv2.stride), list(blk.conv2.padding), [1, 1], False,
+                                                           [0, 0], 1, [True, True, False])[:2]
         if not _cl(da1):
             da1 = da1.contiguous(memory_format=torch.channels_last)
         # bn1 backward (ReLU mask recomputed from z1 and the forward coefficients)
@@ -532,6 +538,8 @@ def conv1x1(conv, x: Tensor) -> Tensor:
     from . import biasact
     if biasact.conv3x3_bwd_fusable(conv, x):        # 3x3 / 256 -> 256 (layer3's conv2): MIOpen forward, gradients on csrc/conv.hip
         return biasact.conv3x3_mfma_bwd(conv, x)
+    if biasact.conv3x3_dgrad_fwd_fusable(conv, x):  # other 3x3 / stride-1 convs (layer4's conv2): data gradient as a forward convolution
+        return biasact.conv3x3_dgrad_fwd(conv, x)
     return conv(x)
 
 

@@ -96,7 +96,7 @@ def test_feature_pyramid_uses_the_dense_group_and_matches_the_per_level_path():
 
 
 def test_conv3x3_gradients_on_the_dense_kernels_match_torch():
-    "Bottleneck conv2 of layer3 (256 -> 256, no bias): MIOpen forward, both gradients on the dense MFMA kernels."
+    "Bottleneck conv2 of layer3 (256 -> 256, no bias): forward and both gradients on the dense MFMA kernels."
     from pytorch_retinanet_amd import biasact
     dev = torch.device("cuda:0")
     torch.manual_seed(11)
@@ -111,3 +111,25 @@ def test_conv3x3_gradients_on_the_dense_kernels_match_torch():
     yf = F.conv2d(xf, wf, None, 1, 1)
     yf.backward(dy.float())
     assert _rel(y, yf) < 4e-3 and _rel(dx, xf.grad) < 4e-3 and _rel(dw, wf.grad) < 4e-3, (_rel(y, yf), _rel(dx, xf.grad), _rel(dw, wf.grad))
+
+
+@pytest.mark.parametrize("cout,cin,hw", [(64, 64, (40, 52)), (128, 128, (25, 34)), (512, 512, (13, 21)), (64, 128, (17, 19))])
+def test_data_gradient_issued_as_a_forward_convolution(cout, cin, hw):
+    "conv2 of layer1 / layer2 / layer4: dx = conv(dy, flipped transposed weights) -- against autograd on fp32 (backbone.py:112,128)."
+    from pytorch_retinanet_amd import biasact
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    conv = nn.Conv2d(cin, cout, 3, 1, 1, bias=False).to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
+    x = torch.randn((2, cin, *hw), device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_()
+    dy = torch.randn((2, cout, *hw), device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert biasact.conv3x3_dgrad_fwd_fusable(conv, x)
+    y = biasact.conv3x3_dgrad_fwd(conv, x)
+    y.backward(dy)
+    dx, dw = x.grad.clone(), conv.weight.grad.clone()
+    xf, wf = x.detach().float().requires_grad_(), conv.weight.detach().float().requires_grad_()
+    yf = F.conv2d(xf, wf, None, 1, 1)
+    yf.backward(dy.float())
+    assert dx.shape == x.shape and dw.shape == conv.weight.shape
+    assert _rel(y, yf) < 4e-3 and _rel(dx, xf.grad) < 4e-3 and _rel(dw, wf.grad) < 4e-3, (_rel(y, yf), _rel(dx, xf.grad), _rel(dw, wf.grad))
+    # strided / dilated / grouped convolutions do not take this path
+    assert not biasact.conv3x3_dgrad_fwd_fusable(nn.Conv2d(cin, cout, 3, 2, 1, bias=False).to(dev).to(torch.bfloat16), x)
