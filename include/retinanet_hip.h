@@ -299,6 +299,16 @@ size_t rn_stem_wgrad_workspace_bytes(int B, int H, int W);
 int rn_stem_conv_wgrad(const void *g, const void *xp, void *dw, int dtype, int B, int H, int W, void *workspace,
                        size_t workspace_bytes, void *stream);
 
+/* Weight gradient of a NARROW 3x3 / stride-1 / pad-1 convolution without bias -- conv2 of the layer1 / layer2 / layer4 bottlenecks
+ * (retinanet/backbone.py:112,128, autograd's weight gradient of F.conv2d there): Cout, Cin multiples of 64, bf16 channels-last.
+ *   g  [N][H][W][Cout] gradient at the conv output,  x [N][H][W][Cin] the conv input,
+ *   dw [Cout][3][3][Cin] bf16 (channels-last memory of a [Cout, Cin, 3, 3] gradient), fp32 accumulation.
+ * All nine taps of a 64 x 64 block of dw are held by one workgroup (csrc/wgrad3x3.hip); zero_page: >= 128 zero bytes on the device
+ * (what pixels outside the image read); workspace: f32 partials, rn_conv3x3_wgrad_narrow_workspace_bytes(Cout, Cin) bytes. */
+size_t rn_conv3x3_wgrad_narrow_workspace_bytes(int Cout, int Cin);
+int rn_conv3x3_wgrad_narrow(const void *g, const void *x, void *dw, int dtype, int N, int H, int W, int Cout, int Cin,
+                            const void *zero_page, void *workspace, size_t workspace_bytes, void *stream);
+
 /* n device-to-device copies (dsts[i] <- srcs[i], nbytes[i] bytes, non-overlapping) in one launch per 64: the inputs of a step
  * into the static buffers of its captured hipGraph (graph.CapturedTrainStep).  srcs / dsts / nbytes are HOST arrays. */
 int rn_copy_many(const void *const *srcs, void *const *dsts, const int64_t *nbytes, int n, void *stream);

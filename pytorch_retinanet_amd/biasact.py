@@ -955,8 +955,48 @@ def conv3x3_dgrad_as_fwd(g: Tensor, w: Tensor) -> Tensor:
     return F.conv2d(gc, wt, None, 1, 1)
 
 
+# Their weight gradient: one team of waves holds all nine taps of a 64 x 64 block of dW (csrc/wgrad3x3.hip) instead of one
+# workgroup per tap re-reading both operands (MIOpen: 123 us + a zero fill + a cast per layer1 block).
+NARROW_WGRAD = True
+_NARROW_WS: Dict[tuple, Tensor] = {}
+
+
+def wgrad_narrow_ok(w: Tensor, stride, x: Tensor) -> bool:
+    return (NARROW_WGRAD and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and _cl(x) and w.dim() == 4 and
+            tuple(w.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0 and
+            w.shape[0] * w.shape[1] <= 512 * 512)
+
+
+def conv3x3_wgrad_narrow(g: Tensor, x: Tensor, w: Tensor) -> Tensor:
+    "Weight gradient of ``F.conv2d(x, w, None, 1, 1)`` (bf16 channels-last, Cout / Cin multiples of 64) -> like ``w``, channels-last."
+    dev = x.device
+    if dev.index != torch.cuda.current_device():
+        torch.cuda.set_device(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    N, Cin, H, W = x.shape
+    Cout = int(w.shape[0])
+    gc = g if (g.dtype == torch.bfloat16 and _cl(g)) else g.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    need = lib.rn_conv3x3_wgrad_narrow_workspace_bytes(Cout, Cin)
+    key = (dev.index, stream)
+    ws = _NARROW_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _NARROW_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
+    dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+    _mfma_call("mfma_conv2_narrow_wgrad", dev, 2.0 * N * H * W * Cout * Cin * 9,
+               lambda: lib.rn_conv3x3_wgrad_narrow(gc.data_ptr(), x.data_ptr(), dw.data_ptr(), RN_BF16, N, H, W, Cout, Cin,
+                                                   _zero_page(dev).data_ptr(), ws.data_ptr(), ws.numel(), stream), "rn_conv3x3_wgrad_narrow")
+    return dw
+
+
+def conv3x3_weight_gradient(g: Tensor, x: Tensor, w: Tensor) -> Tensor:
+    "Weight gradient of a 3x3 / stride-1 / pad-1 convolution: the narrow MFMA kernel where it applies, else MIOpen's."
+    if wgrad_narrow_ok(w, (1, 1), x):
+        return conv3x3_wgrad_narrow(g, x, w)
+    return torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+
+
 class _Conv3x3DgradAsFwd(torch.autograd.Function):
-    "``F.conv2d(x, w, None, 1, 1)``; backward: data gradient as a forward convolution, weight gradient MIOpen's."
+    "``F.conv2d(x, w, None, 1, 1)``; backward: data gradient as a forward convolution, weight gradient on csrc/wgrad3x3.hip."
 
     @staticmethod
     def forward(ctx, x, w):
@@ -970,7 +1010,7 @@ class _Conv3x3DgradAsFwd(torch.autograd.Function):
         dx = conv3x3_dgrad_as_fwd(g, w) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
-            dw = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+            dw = conv3x3_weight_gradient(g, x, w)
         return dx, dw
 
 

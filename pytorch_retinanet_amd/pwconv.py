@@ -279,7 +279,7 @@ class _BottleneckFn(torch.autograd.Function):
         if biasact.dgrad_as_fwd_ok(w2, blk.conv2.stride, dz2) and tuple(blk.conv2.padding) == (1, 1):
             # stride 1: the data gradient as a forward convolution with the flipped weights (CK's forward kernel, no zero fill)
             da1 = biasact.conv3x3_dgrad_as_fwd(dz2, w2)
-            dw2 = torch.ops.aten.convolution_backward(dz2, a1, w2, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+            dw2 = biasact.conv3x3_weight_gradient(dz2, a1, w2)
         else:
             da1, dw2 = torch.ops.aten.convolution_backward(dz2, a1, w2, None, list(blk.conv2.stride), list(blk.conv2.padding), [1, 1], False,
                                                            [0, 0], 1, [True, True, False])[:2]

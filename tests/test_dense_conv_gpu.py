@@ -133,3 +133,55 @@ def test_data_gradient_issued_as_a_forward_convolution(cout, cin, hw):
     assert _rel(y, yf) < 4e-3 and _rel(dx, xf.grad) < 4e-3 and _rel(dw, wf.grad) < 4e-3, (_rel(y, yf), _rel(dx, xf.grad), _rel(dw, wf.grad))
     # strided / dilated / grouped convolutions do not take this path
     assert not biasact.conv3x3_dgrad_fwd_fusable(nn.Conv2d(cin, cout, 3, 2, 1, bias=False).to(dev).to(torch.bfloat16), x)
+
+
+@pytest.mark.parametrize("N,cout,cin,hw", [
+    (2, 64, 64, (40, 52)),        # one sub-problem; a row is one stage of two k-steps (52 > 32)
+    (1, 64, 64, (3, 30)),         # rows shorter than one k-step, three image rows: every vertical tap leaves the image somewhere
+    (2, 64, 64, (9, 97)),         # 97 = 64 + 33: second stage of a row runs both k-steps with 31 zero pixels
+    (1, 64, 64, (5, 96)),         # 96 = 64 + 32: second stage runs ONE k-step
+    (2, 128, 128, (25, 34)),      # four sub-problems
+    (1, 128, 64, (7, 70)),        # rectangular: Cout != Cin
+    (1, 512, 512, (13, 21)),      # layer4: 64 sub-problems, 4 workgroups each
+    (8, 64, 64, (200, 334)),      # layer1 of the 800 x 1333 bucket (full size)
+])
+def test_narrow_weight_gradient_matches_torch(N, cout, cin, hw):
+    "csrc/wgrad3x3.hip against autograd's weight gradient of F.conv2d on fp32 copies of the same bf16 tensors (backbone.py:112,128)."
+    from pytorch_retinanet_amd import biasact
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(17)
+    x = torch.randn((N, cin, *hw), device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn((N, cout, *hw), device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.empty((cout, cin, 3, 3), device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert biasact.wgrad_narrow_ok(w, (1, 1), x)
+    dw = biasact.conv3x3_wgrad_narrow(dy, x, w)
+    assert dw.shape == w.shape and dw.is_contiguous(memory_format=torch.channels_last)
+    if N * hw[0] * hw[1] > 100000:      # the full-size case: fp32 reference by MIOpen in chunks of the batch (memory), same contraction
+        ref = sum(torch.ops.aten.convolution_backward(dy[i:i + 1].float(), x[i:i + 1].float(), w.float(), None, [1, 1], [1, 1], [1, 1], False,
+                                                      [0, 0], 1, [False, True, False])[1] for i in range(N))
+    else:
+        ref = torch.ops.aten.convolution_backward(dy.float(), x.float(), w.float(), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                  [False, True, False])[1]
+    # bf16 rounding of the result only: fp32 accumulation on both sides
+    assert _rel(dw, ref) < 3e-3, _rel(dw, ref)
+    # every tap separately (a swapped or shifted tap would pass a norm test on white noise only by luck -- it would not: checked anyway)
+    for t in range(9):
+        assert _rel(dw[:, :, t // 3, t % 3], ref[:, :, t // 3, t % 3]) < 4e-3, t
+
+
+def test_narrow_weight_gradient_rejects_what_it_cannot_do():
+    from pytorch_retinanet_amd import biasact
+    from pytorch_retinanet_amd._lib import lib, RN_BF16, RN_F16
+    dev = torch.device("cuda:0")
+    x = torch.zeros((1, 64, 4, 4), device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert not biasact.wgrad_narrow_ok(torch.empty((96, 64, 3, 3), dtype=torch.bfloat16), (1, 1), x)
+    assert not biasact.wgrad_narrow_ok(torch.empty((64, 64, 3, 3), dtype=torch.bfloat16), (2, 2), x)
+    assert not biasact.wgrad_narrow_ok(torch.empty((64, 64, 1, 1), dtype=torch.bfloat16), (1, 1), x)
+    ws = torch.empty((lib.rn_conv3x3_wgrad_narrow_workspace_bytes(64, 64),), dtype=torch.uint8, device=dev)
+    dw = torch.empty((64 * 9 * 64,), dtype=torch.bfloat16, device=dev)
+    z = biasact._zero_page(dev).data_ptr()
+    assert lib.rn_conv3x3_wgrad_narrow(x.data_ptr(), x.data_ptr(), dw.data_ptr(), RN_F16, 1, 4, 4, 64, 64, z, ws.data_ptr(), ws.numel(), 0) != 0
+    assert lib.rn_conv3x3_wgrad_narrow(x.data_ptr(), x.data_ptr(), dw.data_ptr(), RN_BF16, 1, 4, 4, 96, 64, z, ws.data_ptr(), ws.numel(), 0) != 0
+    assert lib.rn_conv3x3_wgrad_narrow(x.data_ptr(), x.data_ptr(), dw.data_ptr(), RN_BF16, 1, 4, 4, 64, 64, z, ws.data_ptr(), 16, 0) != 0
+    assert lib.rn_conv3x3_wgrad_narrow(x.data_ptr(), x.data_ptr(), dw.data_ptr(), RN_BF16, 1, 4, 4, 64, 64, 0, ws.data_ptr(), ws.numel(), 0) != 0
+    assert lib.rn_conv3x3_wgrad_narrow_workspace_bytes(96, 64) == 0
