@@ -663,8 +663,13 @@ int wgrad_splits(const rn_pw_conv *d, int *tiles_per_split, const bool g_transfo
     int S = (2 * cu_count() + tiles - 1) / tiles;                // about two workgroups per CU
     const int ktiles = (int)((d->M + 63) / 64);
     const int64_t split_bytes = (int64_t)d->N * d->taps * d->Cin * 4;
-    const int cap = (int)(((int64_t)16 << 20) / split_bytes);    // f32 partials: at most ~16 MiB written and re-read
-    if (S > cap) S = cap < 32 ? 32 : cap;
+    // Split scan on MI355X (kernel + reduction, isolated, us): two workgroups per CU is the optimum at every width of the trunk --
+    //   tiles 8 (134400 x 256 x 512): S = 32 / 64: 71 / 60;   tiles 32 (33600 x 512 x 1024): S = 8 / 16 / 32: 71 / 60 / 96;
+    //   tiles 64 (8400 x 512 x 2048): S = 4 / 8 / 32: 43 / 37 / 71;   tiles 128 (8400 x 2048 x 1024): S = 2 / 4 / 32: 75 / 61 / 134
+    // -- which is always 2 * CUs * 64 KiB = 32 MiB of f32 partials.  (Rounds 2-3 capped the partials at 16 MiB but never went
+    // below 32 splits: layer4's GEMMs wrote and re-read 113 - 256 MB for 43 MB of operands.)
+    const int cap = (int)(((int64_t)32 << 20) / split_bytes);
+    if (S > cap) S = cap;
     if (S > ktiles) S = ktiles;
     if (S > 512) S = 512;
     if (S < 1) S = 1;
