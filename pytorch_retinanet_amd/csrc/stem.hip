@@ -120,7 +120,10 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_fwd_kernel(const StemArgs a
     int t = t_beg + wave;
     const int t_last = t_end - 1;
     int tx = t % a.tiles_x, yo = (t / a.tiles_x) % a.Ho, b = (t / a.tiles_x) / a.Ho;      // once per wave: compute cursor
-    int tl = t, bl = b, yl = yo, xl = tx;                                                 // load cursor
+    // load cursor.  A wave of the last workgroup may own NO tile (t > t_last): its (masked) loads must still hit the buffer -- they
+    // walk the workgroup's last tile; t itself can lie past the last image (found by placing the buffers at the end of their mappings)
+    int tl = t <= t_last ? t : t_last;
+    int xl = tl % a.tiles_x, yl = (tl / a.tiles_x) % a.Ho, bl = (tl / a.tiles_x) / a.Ho;
     // The loop body is straight-line code -- every wave runs the same number of (load, compute) steps, loads past the wave's
     // last tile re-read that tile, stores and statistics past it are masked -- so that the compiler's s_waitcnt counting is exact:
     // with `if (tile exists)` around the loads its vmcnt for a fragment also waited for the loads issued AFTER it.

@@ -1,0 +1,36 @@
+"""Out-of-bounds guard: the hand-written kernels run with every input placed at the very end of its own device mapping
+(tools/guard_probe.py, a child process: a GPU memory access fault aborts the process that caused it)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = [
+    ("stem", "2", "30", "600"),        # 570 tiles over 143 workgroups: the last one has two waves without a tile (the bug this test found)
+    ("stem", "1", "37", "53"),
+    ("stem", "1", "7", "7"),
+    ("stem", "2", "64", "96"),
+    ("w3", "2", "9", "97", "64"),
+    ("w3", "1", "3", "30", "64"),
+    ("w3", "2", "25", "34", "128"),
+    ("w3", "1", "13", "21", "512"),
+    ("dense",),
+    ("pw",),
+    ("pool",),
+    ("bottleneck",),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=["-".join(c) for c in CASES])
+def test_kernels_stay_inside_their_operands(case):
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "guard_probe.py"), *case], capture_output=True, text=True, env=env,
+                       timeout=600, cwd=ROOT)
+    tail = (r.stdout + r.stderr)[-1500:]
+    assert r.returncode == 0, f"probe {case} died (GPU memory access fault?):\n{tail}"
+    assert "ok " + case[0] in r.stdout, tail

@@ -360,8 +360,10 @@ def test_stem_conv_weight_gradient(B, H, W):
     wsb = torch.empty((need,), dtype=torch.uint8, device=DEV)
     dw = torch.full_like(w, float("nan"))
     check(lib.rn_stem_conv_wgrad(g.data_ptr(), xp.data_ptr(), dw.data_ptr(), RN_BF16, B, H, W, wsb.data_ptr(), need, st), "rn_stem_conv_wgrad")
-    ref = torch.ops.aten.convolution_backward(g.float(), x.float(), w.float(), None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
-                                              [False, True, False])[1]
+    # fp32 reference on the CPU (small problems; MIOpen's fp32 weight-gradient search for these odd shapes aborted the process once
+    # in a while when it ran late in a long test session)
+    ref = torch.ops.aten.convolution_backward(g.float().cpu(), x.float().cpu(), w.float().cpu(), None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+                                              [False, True, False])[1].to(DEV)
     assert dw.shape == ref.shape and dw.stride() == w.stride()
     _close(dw, ref, 1e-2, "stem weight gradient")
 

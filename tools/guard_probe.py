@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Out-of-bounds probe for the hand-written kernels: every INPUT tensor is placed at the very END of its own device mapping
+(no caching allocator: one hipMalloc per tensor, 2 MiB granules), so a kernel that reads or writes past an operand runs off the
+mapping and the GPU raises a memory access fault (the process aborts) instead of silently touching a neighbour.  Found this way:
+``stem_fwd_kernel`` -- a wave of the last workgroup that owns no tile loaded at a tile index past the last image.
+
+usage: guard_probe.py stem B H W | w3 N H W C | dense | pw | pool | bottleneck      (driven by tests/test_guard_gpu.py)
+Prints one "ok ..." line per case; a fault kills the process (non-zero exit status, no "ok" line for the case)."""
+import os
+import sys
+
+os.environ["PYTORCH_NO_CUDA_MEMORY_CACHING"] = "1"
+import torch                                                       # noqa: E402
+import torch.nn as nn                                              # noqa: E402
+
+from pytorch_retinanet_amd._lib import RN_BF16, check, lib         # noqa: E402
+
+DEV = torch.device("cuda:0")
+GRAN = 2 << 20
+_KEEP = []
+
+
+def raw_at_end(nbytes: int, fill=None) -> torch.Tensor:
+    tot = (nbytes + GRAN - 1) // GRAN * GRAN
+    base = torch.empty((tot,), dtype=torch.uint8, device=DEV)
+    base.fill_(0x7f if fill is None else fill)                     # bf16 0x7f7f = 3.4e38: a stray read of the padding shows in the results too
+    _KEEP.append(base)
+    off = (tot - nbytes) // 16 * 16
+    return base[off: off + nbytes]
+
+
+def cl_at_end(N: int, C: int, H: int, W: int, scale: float = 1.0, seed: int = 0) -> torch.Tensor:
+    "bf16 channels-last [N, C, H, W] random tensor whose last byte is the last byte (mod 16) of its mapping"
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    src = (torch.randn((N, H, W, C), device=DEV, generator=g) * scale).to(torch.bfloat16)
+    raw = raw_at_end(src.numel() * 2)
+    t = raw.view(torch.bfloat16).view(N, H, W, C)
+    t.copy_(src)
+    return t.permute(0, 3, 1, 2)
+
+
+def main() -> None:
+    which = sys.argv[1]
+    st = torch.cuda.current_stream().cuda_stream
+    if which == "stem":
+        B, H, W = (int(v) for v in sys.argv[2:5])
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        x, w, g = raw_at_end(B * H * W * 3 * 2, 0x3c), raw_at_end(64 * 147 * 2, 0x3c), raw_at_end(B * Ho * Wo * 64 * 2, 0x3c)
+        xp, wk, z = raw_at_end(lib.rn_stem_padded_bytes(B, H, W)), raw_at_end(64 * 7 * 32 * 2), raw_at_end(B * Ho * Wo * 64 * 2)
+        part = raw_at_end(lib.rn_stem_partial_rows(B, H, W) * 2 * 64 * 4)
+        check(lib.rn_stem_conv_forward(x.data_ptr(), w.data_ptr(), xp.data_ptr(), wk.data_ptr(), z.data_ptr(), part.data_ptr(), RN_BF16, B, H, W,
+                                       st), "rn_stem_conv_forward")
+        torch.cuda.synchronize()
+        need = lib.rn_stem_wgrad_workspace_bytes(B, H, W)
+        ws, dw = raw_at_end(need), raw_at_end(64 * 147 * 2)
+        check(lib.rn_stem_conv_wgrad(g.data_ptr(), xp.data_ptr(), dw.data_ptr(), RN_BF16, B, H, W, ws.data_ptr(), need, st), "rn_stem_conv_wgrad")
+        torch.cuda.synchronize()
+        print("ok stem", B, H, W, flush=True)
+    elif which == "w3":
+        N, H, W, Cc = (int(v) for v in sys.argv[2:6])
+        g, x = raw_at_end(N * H * W * Cc * 2, 0x3c), raw_at_end(N * H * W * Cc * 2, 0x3c)
+        need = lib.rn_conv3x3_wgrad_narrow_workspace_bytes(Cc, Cc)
+        dw, ws, zp = raw_at_end(Cc * Cc * 9 * 2), raw_at_end(need), raw_at_end(256, 0)
+        check(lib.rn_conv3x3_wgrad_narrow(g.data_ptr(), x.data_ptr(), dw.data_ptr(), RN_BF16, N, H, W, Cc, Cc, zp.data_ptr(), ws.data_ptr(), need,
+                                          st), "rn_conv3x3_wgrad_narrow")
+        torch.cuda.synchronize()
+        print("ok w3", N, H, W, Cc, flush=True)
+    elif which == "dense":
+        from pytorch_retinanet_amd import biasact
+        for N, shapes in [(2, [(25, 42), (13, 21), (7, 11)]), (1, [(1, 300), (3, 1), (2, 2)]), (3, [(9, 30)])]:
+            convs = [nn.Conv2d(256, 256, 3, 1, 1).to(DEV).to(torch.bfloat16).to(memory_format=torch.channels_last) for _ in shapes]
+            for c in convs:
+                c.bias.data = c.bias.data.float()
+            xs = [cl_at_end(N, 256, h, w, seed=i).requires_grad_() for i, (h, w) in enumerate(shapes)]
+            ys = biasact.dense_conv_group(xs, convs)
+            torch.autograd.backward(ys, [cl_at_end(N, 256, h, w, seed=9 + i) for i, (h, w) in enumerate(shapes)])
+            torch.cuda.synchronize()
+            # layer3's conv2: forward and both gradients, P = 1
+            c2 = nn.Conv2d(256, 256, 3, 1, 1, bias=False).to(DEV).to(torch.bfloat16).to(memory_format=torch.channels_last)
+            x2 = cl_at_end(N, 256, *shapes[0], seed=5).requires_grad_()
+            biasact.conv3x3_mfma_bwd(c2, x2).backward(cl_at_end(N, 256, *shapes[0], seed=6))
+            torch.cuda.synchronize()
+            print("ok dense", N, shapes, flush=True)
+    elif which == "pw":
+        from pytorch_retinanet_amd import pwconv
+        for (N, cin, cout, H, W, k, s) in [(2, 64, 256, 9, 13, 1, 1), (1, 256, 64, 7, 5, 1, 1), (2, 128, 128, 11, 14, 3, 1), (2, 128, 128, 11, 14, 3, 2),
+                                           (1, 512, 1024, 6, 10, 1, 2), (3, 1024, 256, 5, 3, 1, 1)]:
+            x = cl_at_end(N, cin, H, W, seed=1)
+            w = cl_at_end(cout, cin, k, k, 0.05, seed=2)
+            y = pwconv.pw_forward(x, w, stride=s)
+            g = cl_at_end(*y.shape, seed=3)
+            pwconv.pw_wgrad(g, x, w, stride=s)
+            torch.cuda.synchronize()
+            print("ok pw", N, cin, cout, H, W, k, s, flush=True)
+    elif which == "pool":
+        from pytorch_retinanet_amd.pool import FusedMaxPool2d
+        for (N, Cc, H, W) in [(2, 64, 37, 53), (1, 64, 1, 1), (1, 8, 5, 2), (2, 64, 30, 301)]:
+            x = cl_at_end(N, Cc, H, W, seed=1).requires_grad_()
+            y = FusedMaxPool2d(3, 2, 1)(x)
+            y.backward(cl_at_end(*y.shape, seed=2))
+            torch.cuda.synchronize()
+            print("ok pool", N, Cc, H, W, flush=True)
+    elif which == "bottleneck":
+        from pytorch_retinanet_amd import backbone, optim
+        for (inpl, planes, stride, H, W) in [(64, 64, 1, 19, 27), (256, 64, 1, 19, 27), (256, 128, 2, 18, 26), (1024, 512, 2, 7, 9), (2048, 512, 1, 5, 7)]:
+            ds = None
+            if stride != 1 or inpl != planes * 4:
+                ds = nn.Sequential(nn.Conv2d(inpl, planes * 4, 1, stride, bias=False), backbone.FusedBatchNorm2d(planes * 4))
+            blk = backbone.Bottleneck(inpl, planes, stride, ds).to(DEV).to(memory_format=torch.channels_last).train()
+            for m in blk.modules():
+                if isinstance(m, nn.Conv2d):
+                    m.weight.data = m.weight.data.to(torch.bfloat16)
+            x = cl_at_end(2, inpl, H, W, seed=1).requires_grad_()
+            y = blk(x)
+            y.backward(cl_at_end(*y.shape, seed=2))
+            torch.cuda.synchronize()
+            print("ok bottleneck", inpl, planes, stride, H, W, flush=True)
+    else:
+        raise SystemExit(f"unknown probe {which!r}")
+
+
+if __name__ == "__main__":
+    main()
