@@ -22,13 +22,15 @@ CASES = [
     ("pw",),
     ("pool",),
     ("bottleneck",),
+    ("step", "resnet50", "200", "280"),
+    ("step", "resnet18", "131", "173"),
 ]
 
 
 @pytest.mark.parametrize("case", CASES, ids=["-".join(c) for c in CASES])
 def test_kernels_stay_inside_their_operands(case):
     env = dict(os.environ)
-    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "tests"), env.get("PYTHONPATH", "")])      # (tests/synth.py: synthetic GT)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "guard_probe.py"), *case], capture_output=True, text=True, env=env,
                        timeout=600, cwd=ROOT)
     tail = (r.stdout + r.stderr)[-1500:]

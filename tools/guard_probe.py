@@ -4,7 +4,7 @@
 mapping and the GPU raises a memory access fault (the process aborts) instead of silently touching a neighbour.  Found this way:
 ``stem_fwd_kernel`` -- a wave of the last workgroup that owns no tile loaded at a tile index past the last image.
 
-usage: guard_probe.py stem B H W | w3 N H W C | dense | pw | pool | bottleneck      (driven by tests/test_guard_gpu.py)
+usage: guard_probe.py stem B H W | w3 N H W C | dense | pw | pool | bottleneck | step KIND MIN MAX      (driven by tests/test_guard_gpu.py)
 Prints one "ok ..." line per case; a fault kills the process (non-zero exit status, no "ok" line for the case)."""
 import os
 import sys
@@ -115,6 +115,35 @@ def main() -> None:
             y.backward(cl_at_end(*y.shape, seed=2))
             torch.cuda.synchronize()
             print("ok bottleneck", inpl, planes, stride, H, W, flush=True)
+    elif which == "step":
+        # whole train steps + one inference pass with one device allocation per tensor (page-granular mappings: an overrun of more
+        # than a page past ANY tensor of the step faults), R50 trunk, odd image sizes, eager
+        import numpy as np
+        import pytorch_retinanet_amd as P
+        import synth
+        from pytorch_retinanet_amd.graph import CapturedTrainStep
+        from pytorch_retinanet_amd.optim import MasterSGD, use_bf16_conv_weights
+        torch.manual_seed(3)
+        kind, lo, hi = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+        net = P.Retinanet(num_classes=7, backbone_kind=kind, pretrained=False, min_size=lo, max_size=hi).to(DEV)
+        net = net.to(memory_format=torch.channels_last).train()
+        use_bf16_conv_weights(net)
+        opt = MasterSGD(net.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+        step = CapturedTrainStep(net, opt, amp_dtype=torch.bfloat16, enabled=False)
+        rng = np.random.default_rng(1)
+        for hw in [(lo - 3, hi - 7), (lo + 5, hi - 21)]:
+            images = [torch.from_numpy(rng.random((3, *hw), dtype=np.float32)).to(DEV) for _ in range(2)]
+            targets = []
+            for _ in range(2):
+                b, l = synth.gt_boxes(rng, 4, hw[0], hw[1], num_classes=7, wh_lo=20.0, wh_hi=90.0)
+                targets.append({"boxes": torch.from_numpy(b).to(DEV), "labels": torch.from_numpy(l).to(DEV)})
+            loss = float(step(images, targets)["loss"])
+            assert loss == loss, "loss is NaN"
+        net.eval()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            net([torch.from_numpy(rng.random((3, lo - 1, hi - 2), dtype=np.float32)).to(DEV)])
+        torch.cuda.synchronize()
+        print("ok step", kind, lo, hi, flush=True)
     else:
         raise SystemExit(f"unknown probe {which!r}")
 
