@@ -24,6 +24,8 @@ CASES = [
     ("bottleneck",),
     ("step", "resnet50", "200", "280"),
     ("step", "resnet18", "131", "173"),
+    ("step", "resnet50", "333", "517"),
+    ("step", "resnet18", "97", "400"),
 ]
 
 
