@@ -312,6 +312,10 @@ int rn_conv3x3_wgrad_narrow(const void *g, const void *x, void *dw, int dtype, i
 /* n device-to-device copies (dsts[i] <- srcs[i], nbytes[i] bytes, non-overlapping) in one launch per 64: the inputs of a step
  * into the static buffers of its captured hipGraph (graph.CapturedTrainStep).  srcs / dsts / nbytes are HOST arrays. */
 int rn_copy_many(const void *const *srcs, void *const *dsts, const int64_t *nbytes, int n, void *stream);
+/* n widening copies dsts[i] (f32) <- srcs[i] (src_dtype: RN_BF16 or RN_F16), counts[i] elements each, one launch per 64: the
+ * gather of 16-bit parameter gradients into the fp32 buckets of the gradient exchange (no reference analogue: Lightning's DDP
+ * exchanges fp32 gradients of fp32 parameters).  HOST arrays. */
+int rn_cast_many_to_f32(const void *const *srcs, void *const *dsts, const int64_t *counts, int n, int src_dtype, void *stream);
 
 /* dsts[i] [cols[i]][rows[i]] = transpose of srcs[i] [rows[i]][cols[i]], 16-bit elements, n <= 16 matrices in one launch (the
  * data-gradient weights of a bottleneck's 1x1 convolutions).  srcs / dsts / rows / cols are HOST arrays. */

@@ -28,6 +28,46 @@ import torch.distributed as dist
 from torch import nn
 
 
+def _flat_pair(view: torch.Tensor, grad: torch.Tensor) -> bool:
+    "Same shape and strides, both dense: the copy is a walk over numel elements of the two storages."
+    return (grad.is_cuda and grad.device == view.device and grad.shape == view.shape and grad.stride() == view.stride() and
+            (grad.is_contiguous() or (grad.dim() == 4 and grad.is_contiguous(memory_format=torch.channels_last))))
+
+
+def _gather(views, grads) -> None:
+    """``views[i].copy_(grads[i])`` for a whole bucket.  On the GPU, 16-bit gradients going into fp32 views take ONE launch per 64
+    tensors (``rn_cast_many_to_f32``) and same-dtype ones one launch per 64 (``rn_copy_many``): ``torch._foreach_copy_`` across
+    dtypes issues one kernel per tensor -- 161 launches of ~5 us per step for the R50 model, 0.8 ms on the critical path of
+    every bucket's all-reduce."""
+    rest_v, rest_g, cast, same = [], [], [], []
+    for v, g in zip(views, grads):
+        if v.is_cuda and _flat_pair(v, g):
+            if v.dtype == torch.float32 and g.dtype in (torch.bfloat16, torch.float16):
+                cast.append((v, g)); continue
+            if v.dtype == g.dtype:
+                same.append((v, g)); continue
+        rest_v.append(v); rest_g.append(g)
+    if cast or same:
+        import ctypes as C
+        from ._lib import RN_BF16, RN_F16, check, lib
+        dev = (cast or same)[0][0].device
+        if dev.index != torch.cuda.current_device():
+            torch.cuda.set_device(dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        for code, dt in ((RN_BF16, torch.bfloat16), (RN_F16, torch.float16)):
+            grp = [(v, g) for v, g in cast if g.dtype == dt]
+            if grp:
+                n = len(grp)
+                check(lib.rn_cast_many_to_f32((C.c_void_p * n)(*[g.data_ptr() for _, g in grp]), (C.c_void_p * n)(*[v.data_ptr() for v, _ in grp]),
+                                              (C.c_int64 * n)(*[g.numel() for _, g in grp]), n, code, stream), "rn_cast_many_to_f32")
+        if same:
+            n = len(same)
+            check(lib.rn_copy_many((C.c_void_p * n)(*[g.data_ptr() for _, g in same]), (C.c_void_p * n)(*[v.data_ptr() for v, _ in same]),
+                                   (C.c_int64 * n)(*[g.numel() * g.element_size() for _, g in same]), n, stream), "rn_copy_many")
+    if rest_v:
+        torch._foreach_copy_(rest_v, rest_g)
+
+
 class _Bucket:
     __slots__ = ("flat", "params", "pending", "work", "launched")
 
@@ -112,7 +152,7 @@ class BucketedGradAllReduce:
             if view.dtype == p.dtype:
                 p.grad = view              # (a bf16 working copy keeps its bf16 .grad; its exchanged gradient is grad_views()[p])
         if views:
-            torch._foreach_copy_(views, grads)     # also promotes bf16 gradients into fp32 buckets
+            _gather(views, grads)                  # also promotes bf16 gradients into fp32 buckets
         b.launched = True
         if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
             return

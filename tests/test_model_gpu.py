@@ -863,3 +863,27 @@ def test_top_tower_layer_relu_backward_rides_in_the_output_convs_data_gradient()
             torch.testing.assert_close(fused[1][n], plain[1][n], rtol=1e-4, atol=1e-4 * float(plain[1][n].abs().max()))
         else:
             assert torch.equal(fused[1][n], plain[1][n]), n
+
+
+def test_bucket_gather_is_one_widening_launch_and_equals_copy():
+    "parallel._gather == per-tensor copy_ (bf16 / f16 -> fp32 views, same-dtype views, odd sizes, channels-last and strided leftovers)."
+    from pytorch_retinanet_amd import parallel
+    g = torch.Generator(device=DEV).manual_seed(3)
+    shapes = [(64, 3, 7, 7), (256, 64, 1, 1), (90 * 9,), (5,), (64, 64, 3, 3), (1,), (1000, 7)]
+    grads, views, want = [], [], []
+    for i, shp in enumerate(shapes):
+        dt = [torch.bfloat16, torch.float16, torch.float32][i % 3]
+        t = torch.randn(shp, device=DEV, generator=g).to(dt)
+        if len(shp) == 4:
+            t = t.contiguous(memory_format=torch.channels_last)
+        grads.append(t)
+        flat = torch.full((t.numel() + 64,), float("nan"), device=DEV, dtype=torch.float32)
+        views.append(torch.as_strided(flat, t.size(), t.stride(), 64 - (i % 2) * 3 if dt == torch.float32 else 64))
+        want.append(t.float())
+    # a pair whose strides differ (the gradient is a transposed view): must take the fallback
+    t = torch.randn((6, 10), device=DEV, generator=g).to(torch.bfloat16).t()
+    grads.append(t); views.append(torch.empty((10, 6), device=DEV, dtype=torch.float32)); want.append(t.float())
+    parallel._gather(views, grads)
+    torch.cuda.synchronize()
+    for v, w in zip(views, want):
+        assert torch.equal(v, w)
