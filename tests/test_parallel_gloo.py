@@ -139,3 +139,16 @@ def test_bucket_views_stay_aligned_after_odd_sized_parameters():
     ddp.finish()
     for p, v in ddp.grad_views().items():
         assert p.grad.data_ptr() == v.data_ptr() and torch.isfinite(v).all()
+
+
+def test_bucket_gather_falls_back_to_copy_on_the_cpu():
+    "parallel._gather on CPU tensors (no HIP library involved): plain copies, incl. the widening one and mismatched strides."
+    import torch
+    from pytorch_retinanet_amd import parallel
+    g = torch.Generator().manual_seed(1)
+    grads = [torch.randn((4, 3, 2, 2), generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last),
+             torch.randn((7,), generator=g), torch.randn((3, 5), generator=g).t()]
+    views = [torch.empty((4, 3, 2, 2), dtype=torch.float32).contiguous(memory_format=torch.channels_last), torch.empty((7,)), torch.empty((5, 3))]
+    parallel._gather(views, grads)
+    for v, gr in zip(views, grads):
+        assert torch.equal(v, gr.float())
