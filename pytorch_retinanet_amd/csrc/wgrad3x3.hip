@@ -175,8 +175,7 @@ __global__ __launch_bounds__(W3_THREADS) void wgrad3x3_kernel(const W3Args a)
 #undef W3_FRAG
 #undef W3_WAIT
 
-    // team 1 -> LDS -> team 0 adds in place (lane-contiguous: conflict-free), then all 512 threads write the ONE partial of the
-    // workgroup in its final [n][t][c] order as 16-byte stores (the accumulator layout gives 64-byte segments: 12 us -> see DESIGN).
+    // team 1 -> LDS -> team 0 (lane-contiguous: conflict-free), then one partial per workgroup.
     // D lane: column (c) = lane & 15, rows (n) 4 (lane >> 4) + j
     float *xch = (float *)lds;
     if (team == 1) {
@@ -189,19 +188,16 @@ __global__ __launch_bounds__(W3_THREADS) void wgrad3x3_kernel(const W3Args a)
     }
     __syncthreads();
     if (team == 0) {
+        float *out = a.partial + (int64_t)blockIdx.x * W3_OUT;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int t = 0; t < 9; ++t)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xch[(((ct * 4 + i) * 9 + t) * 4 + j) * 64 + lane] += acc[i][t][j];
-    }
-    __syncthreads();
-    rn::f32x4 *out4 = (rn::f32x4 *)(a.partial + (int64_t)blockIdx.x * W3_OUT);
-    for (int f4 = (int)threadIdx.x; f4 < W3_OUT / 4; f4 += W3_THREADS) {
-        const int f = f4 * 4, c = f & 63, t = (f >> 6) % 9, n = f / (9 * 64);
-        const int i = n >> 4, g = (n >> 2) & 3, j = n & 3, cw = c >> 4, ln = 16 * g + (c & 15);
-        out4[f4] = *(const rn::f32x4 *)(xch + ((((cw * 4 + i) * 9 + t) * 4 + j) * 64 + ln));
+                for (int j = 0; j < 4; ++j) {
+                    const int n = i * 16 + 4 * (lane >> 4) + j, c = ct * 16 + (lane & 15);
+                    out[(n * 9 + t) * 64 + c] = acc[i][t][j] + xch[(((ct * 4 + i) * 9 + t) * 4 + j) * 64 + lane];
+                }
     }
 }
 
