@@ -255,3 +255,22 @@ def test_canvas_layout_and_pack_unpack_roundtrip_cpu():
     y = biasact.bias_act(x, torch.arange(8.0), cv.mask, relu=True)
     ref = torch.relu(x + torch.arange(8.0)[None, :, None, None]) * cv.mask.view(1, 1, cv.H, cv.W)
     assert torch.equal(y, ref)
+
+
+def test_weight_gradient_partials_stay_at_two_workgroups_per_cu():
+    """Host logic of csrc/pw.hip and csrc/wgrad3x3.hip (no GPU call): the f32 split partials of a 1x1 weight gradient are two
+    workgroups per CU x one 64 KiB tile = 32 MiB at every trunk width -- rounds 2-3 never went below 32 splits and layer4's
+    GEMMs wrote 113-256 MB --, and the narrow 3x3 weight gradient keeps one partial per CU whatever the sub-problem count."""
+    import ctypes as C
+    from pytorch_retinanet_amd._lib import RnPwConv, lib
+    for (M, N, Cin, H, W) in [(33600, 256, 1024, 50, 84), (33600, 1024, 256, 50, 84), (8400, 512, 2048, 25, 42), (8400, 2048, 512, 25, 42),
+                              (8400, 2048, 1024, 25, 42), (134400, 256, 512, 100, 168), (534400, 64, 256, 200, 334), (534400, 256, 64, 200, 334)]:
+        d = RnPwConv(M, Cin, N, 1, 1, 0, H, W, H, W)
+        need = lib.rn_pw_wgrad_workspace_bytes(C.byref(d))
+        assert 0 < need <= (32 << 20), (M, N, Cin, need)
+        assert need % (N * Cin * 4) == 0                       # whole splits
+    for cout, cin in [(64, 64), (128, 128), (256, 256), (512, 512), (128, 64)]:
+        need = lib.rn_conv3x3_wgrad_narrow_workspace_bytes(cout, cin)
+        subs = (cout // 64) * (cin // 64)
+        assert need % (subs * 64 * 9 * 64 * 4) == 0 and 0 < need <= 256 * 64 * 9 * 64 * 4, (cout, cin, need)
+    assert lib.rn_conv3x3_wgrad_narrow_workspace_bytes(96, 64) == 0 and lib.rn_conv3x3_wgrad_narrow_workspace_bytes(0, 64) == 0
