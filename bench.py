@@ -57,6 +57,111 @@ def parse():
     return ap.parse_args()
 
 
+class ClockSampler:
+    """Shader clock / power / temperature of the GPU while the timed region runs, from the amdgpu sysfs files (no child process, no
+    HIP call): `pp_dpm_sclk` (the level marked `*`), hwmon `freq1_input` (Hz), `power1_average` / `power1_input` (uW), `temp1_input`.
+    A thread samples every `period` seconds; `summary()` gives min / mean / max and the sample count, or says what was missing.
+    Evidence for "the part holds N GHz under MFMA load" statements and for the box-to-box spread of the headline number."""
+
+    def __init__(self, index=0, period=0.05):
+        import glob
+        import threading
+        self.period, self.samples, self._stop, self._thr = period, [], threading.Event(), None
+        cards = []
+        for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            try:
+                if open(os.path.join(d, "vendor")).read().strip() == "0x1002":
+                    cards.append(d)
+            except OSError:
+                pass
+        self.dev = cards[index] if index < len(cards) else (cards[0] if cards else None)
+        self.hwmon = None
+        if self.dev:
+            hm = sorted(glob.glob(os.path.join(self.dev, "hwmon", "hwmon*")))
+            self.hwmon = hm[0] if hm else None
+
+    @staticmethod
+    def _read(path):
+        try:
+            return open(path).read()
+        except OSError:
+            return None
+
+    def _sample(self):
+        rec = {}
+        if self.dev:
+            t = self._read(os.path.join(self.dev, "pp_dpm_sclk"))
+            if t:
+                for ln in t.splitlines():
+                    if ln.rstrip().endswith("*"):
+                        try:
+                            rec["sclk_mhz"] = float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+                        except (IndexError, ValueError):
+                            pass
+        if self.hwmon:
+            f = self._read(os.path.join(self.hwmon, "freq1_input"))
+            if f and "sclk_mhz" not in rec:
+                try:
+                    rec["sclk_mhz"] = float(f) / 1e6
+                except ValueError:
+                    pass
+            for name in ("power1_average", "power1_input"):
+                w = self._read(os.path.join(self.hwmon, name))
+                if w:
+                    try:
+                        rec["power_w"] = float(w) / 1e6
+                        break
+                    except ValueError:
+                        pass
+            c = self._read(os.path.join(self.hwmon, "temp1_input"))
+            if c:
+                try:
+                    rec["temp_c"] = float(c) / 1e3
+                except ValueError:
+                    pass
+        return rec
+
+    def start(self):
+        import threading
+
+        def run():
+            while not self._stop.is_set():
+                r = self._sample()
+                if r:
+                    self.samples.append(r)
+                self._stop.wait(self.period)
+        self._thr = threading.Thread(target=run, daemon=True)
+        self._thr.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self._thr:
+            self._thr.join(timeout=2.0)
+        return self.summary()
+
+    def summary(self):
+        out = {"source": f"sysfs {self.dev}" if self.dev else "no amdgpu sysfs device readable", "samples": len(self.samples),
+               "period_s": self.period}
+        for key in ("sclk_mhz", "power_w", "temp_c"):
+            v = [r[key] for r in self.samples if key in r]
+            if v:
+                out[key] = {"min": round(min(v), 1), "mean": round(sum(v) / len(v), 1), "max": round(max(v), 1)}
+        return out
+
+
+def newest_pmc(root):
+    "profiles/rNN_k3_pmc.json of the highest round (the counter passes are a separate rocprofv3 run; the file says which commit)."
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(root, "profiles", "r*_k3_pmc.json")):
+        m = re.match(r"r(\d+)_k3_pmc\.json$", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    return best[1] if best else None
+
+
 def synth_batch(batch, gt, seed, device):
     import synth
     rng = np.random.default_rng(seed)
@@ -294,6 +399,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    clocks = ClockSampler(local_rank).start() if rank == 0 else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = stepper(images, targets)
@@ -303,6 +409,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gpu_state = clocks.stop() if clocks else None
     final_loss = float(out["loss"])
     graph_replays = stepper.replays
     # per-kernel figures: the same step, enqueued eagerly with a pair of HIP events around every hand-written kernel (events
@@ -331,11 +438,13 @@ def main():
         streamed = k3_bytes(args.batch, A, K_run, args.gt, s)
         k3_ms = kms.get("loss_stream_kernel")             # events recorded by the library right around the streaming kernel
         traffic, traffic_source = None, None
-        pmc = os.path.join(ROOT, "profiles", "r03_k3_pmc.json")
-        if os.path.exists(pmc):
+        pmc = newest_pmc(ROOT)
+        if pmc:
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                traffic_source = "profiles/r03_k3_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)"
+                rec = json.load(open(pmc))
+                traffic = rec.get("hbm_bytes_per_launch")
+                traffic_source = (f"profiles/{os.path.basename(pmc)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at commit "
+                                  f"{rec.get('commit', 'unrecorded')}; not measured in this run)")
             except Exception:          # noqa: BLE001
                 traffic = None
         roof = {"bound": "hbm", "kernel": "loss_stream_kernel<bf16> (K3 focal + smooth-L1 loss, forward + gradients; HIP events right around the kernel)",
@@ -384,6 +493,7 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
             "roofline": roof, "roofline_other": roof_other, "conv_mfma": conv_mfma,
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 0,
+            "gpu_state_during_timed_region": gpu_state,
             "step_launch": {"mode": "hipGraph replay" if graph_replays else "eager", "graph_replays_in_run": graph_replays,
                             "per_kernel_events": f"{timing_steps} eager steps after the timed region"},
         }

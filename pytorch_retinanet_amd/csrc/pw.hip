@@ -602,11 +602,8 @@ template <int BN, int PRO, int EPI> int launch_gemm(const PwArgs &a, hipStream_t
     constexpr int lds_main = 2 * (PW_BM * PW_BK * 2 + BN * PW_BK * 2) > PW_BM * BN * 4 ? 2 * (PW_BM * PW_BK * 2 + BN * PW_BK * 2) : PW_BM * BN * 4;
     const int lds = lds_main + (PRO == PRO_NONE ? 0 : (PRO == PRO_AFFINE_RELU ? 2 : 5) * a.Cin * 4) + ((EPI & EPI_RELU_BWD) ? 4 * BN * 4 : 0);
     if (lds > 160 * 1024) return RN_EUNSUPPORTED;
-    static int attr_max = 0;
-    if (lds > attr_max) {
-        RN_HIP(hipFuncSetAttribute((const void *)pw_gemm_kernel<BN, PRO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_max = lds;
-    }
+    static rn::DynLdsOptIn opt_in = {};
+    { const int rc = opt_in.ensure((const void *)pw_gemm_kernel<BN, PRO, EPI>, lds); if (rc != RN_OK) return rc; }
     hipLaunchKernelGGL((pw_gemm_kernel<BN, PRO, EPI>), dim3((unsigned)a.gx, (unsigned)(a.N / BN)), dim3(PW_THREADS), lds, st, a);
     RN_LAUNCH_CHECK();
     return RN_OK;
@@ -626,11 +623,8 @@ template <int BN, int PRO> int dispatch_epi(const PwArgs &a, const int epi, hipS
 template <int TN, int TK, int PROG, int PROX> int launch_wgrad(const WgArgs &a, hipStream_t st)
 {
     constexpr int lds = 64 * (TN + TK) * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        RN_HIP(hipFuncSetAttribute((const void *)pw_wgrad_kernel<TN, TK, PROG, PROX>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+    static rn::DynLdsOptIn opt_in = {};
+    { const int rc = opt_in.ensure((const void *)pw_wgrad_kernel<TN, TK, PROG, PROX>, lds); if (rc != RN_OK) return rc; }
     const unsigned gy = (unsigned)((a.N / TN) * (a.Cin / TK) * a.taps);
     hipLaunchKernelGGL((pw_wgrad_kernel<TN, TK, PROG, PROX>), dim3((unsigned)a.S, gy), dim3(PW_THREADS), lds, st, a);
     RN_LAUNCH_CHECK();
@@ -653,6 +647,11 @@ void wgrad_tile(const int N, const int Cin, int &TN, int &TK, const bool g_trans
     else if (N >= 128) { TN = (N >= 256 && !g_transform) ? 256 : 128; TK = 64; }    // (BN-backward prologue: 256-wide G staging would spill)
     else if (Cin >= 128) { TN = 64; TK = Cin >= 256 ? 256 : 128; }
     else { TN = 64; TK = 64; }
+    // the grid is (N / TN) x (Cin / TK) tiles: a tile that does not DIVIDE its axis would leave the rest of dW unwritten (N = 192
+    // with TN = 128: rows 128..191).  N and Cin are multiples of 64 (check_geometry), so halving ends at 64 at the latest; every
+    // (TN, TK) this can produce -- (128,128) (256,64) (128,64) (64,256) (64,128) (64,64) -- is instantiated below.
+    while (N % TN) TN >>= 1;
+    while (Cin % TK) TK >>= 1;
 }
 
 int wgrad_splits(const rn_pw_conv *d, int *tiles_per_split, const bool g_transform)
@@ -685,6 +684,7 @@ int check_geometry(const rn_pw_conv *d)
     if (d->taps != 1 && d->taps != 9) return RN_EUNSUPPORTED;
     if (d->stride < 1 || d->pad < 0 || d->Ho <= 0 || d->Wo <= 0 || d->H <= 0 || d->W <= 0) return RN_EINVAL;
     if (d->M % (d->Ho * d->Wo)) return RN_EINVAL;
+    if (d->M >= ((int64_t)1 << 31)) return RN_EUNSUPPORTED;                      // the kernels index rows with 32-bit integers
     if ((int64_t)(d->M / (d->Ho * d->Wo)) * d->H * d->W >= ((int64_t)1 << 31) || (int64_t)d->M * d->N >= ((int64_t)1 << 40)) return RN_EUNSUPPORTED;
     return RN_OK;
 }

@@ -118,4 +118,22 @@ static __device__ __forceinline__ int wave_sum_i(int v) {
 
 static inline bool aligned(const void *p, size_t a) { return (((uintptr_t)p) & (a - 1)) == 0; }
 
+// Opt-in for more than 64 KiB of dynamic LDS.  The attribute lives with the DEVICE's copy of the code object, so the "already
+// done" note is kept per device (a process that drives a second GPU must set it there too) and per kernel (one `DynLdsOptIn`
+// object per kernel instantiation); relaxed atomics: two threads racing here both set the same value, which is harmless.
+struct DynLdsOptIn {
+    int have[64];
+    int ensure(const void *kernel, const int bytes) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return (int)e;
+        const bool slot = dev >= 0 && dev < 64;
+        if (slot && __atomic_load_n(&have[dev], __ATOMIC_RELAXED) >= bytes) return RN_OK;
+        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return (int)e;
+        if (slot) __atomic_store_n(&have[dev], bytes, __ATOMIC_RELAXED);
+        return RN_OK;
+    }
+};
+
 }  // namespace rn

@@ -390,6 +390,7 @@ RN_API int rn_stem_conv_forward(const void *x, const void *w, void *xp, void *wk
     if (dtype != RN_BF16) return RN_EUNSUPPORTED;
     if ((int64_t)B * (H + 6) * (W + 8) >= ((int64_t)1 << 31)) return RN_EUNSUPPORTED;
     if (!rn::aligned(xp, 16) || !rn::aligned(wk, 16) || !rn::aligned(y, 16)) return RN_EALIGN;
+    if (!rn::aligned(x, 2) || !rn::aligned(w, 2)) return RN_EALIGN;              // (read element by element: bf16 alignment is all they need)
     hipStream_t st = (hipStream_t)stream;
     StemPadArgs pa;
     pa.x = (const uint16_t *)x; pa.xp = (uint16_t *)xp; pa.B = B; pa.H = H; pa.W = W; pa.Hp2 = H + 6; pa.Wpp = (W + 6 + 1) & ~1;

@@ -268,11 +268,8 @@ RN_API int rn_conv3x3_wgrad_narrow(const void *g, const void *x, void *dw, int d
     a.wgs_per_sub = w3_workgroups(subs);
     a.tiles_per_team = (a.tiles + 2 * a.wgs_per_sub - 1) / (2 * a.wgs_per_sub);
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
-        RN_HIP(hipFuncSetAttribute((const void *)wgrad3x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS));
-        attr_set = true;
-    }
+    static rn::DynLdsOptIn opt_in = {};
+    { const int rc = opt_in.ensure((const void *)wgrad3x3_kernel, W3_LDS); if (rc != RN_OK) return rc; }
     hipLaunchKernelGGL(wgrad3x3_kernel, dim3((unsigned)(subs * a.wgs_per_sub)), dim3(W3_THREADS), W3_LDS, st, a);
     RN_LAUNCH_CHECK();
     hipLaunchKernelGGL(wgrad3x3_reduce_kernel, dim3(W3_OUT / 4 / 32, (unsigned)subs), dim3(256), 0, st, (const float *)workspace, a.wgs_per_sub,

@@ -186,6 +186,30 @@ def test_weight_gradient_plain(n_out, cin, k, stride):
     _close(dw, ref, 1e-2, "weight gradient")
 
 
+@pytest.mark.parametrize("n_out,cin,k", [(192, 64, 1), (192, 192, 1), (384, 64, 1), (64, 320, 1), (320, 192, 1), (192, 64, 3), (64, 192, 3)])
+def test_weight_gradient_widths_that_are_not_powers_of_two(n_out, cin, k):
+    """The C ABI accepts every multiple of 64: the tile must DIVIDE its axis or part of dW is never written (N = 192
+    picked a 128-wide tile and one tile).  The workspace is poisoned with NaN patterns first, so an unwritten partial shows."""
+    from pytorch_retinanet_amd import pwconv
+    H, W = 13, 17
+    x = _rand((2, cin, H, W), 1.0, 1)
+    w = _rand((n_out, cin, k, k), 0.05, 2)
+    g = _rand((2, n_out, H, W), 1.0, 3)
+    pwconv.pw_wgrad(g, x, w)                                   # (allocates the cached workspace)
+    for ws in pwconv._WG_WS.values():
+        ws.fill_(0xFF)                                         # f32 0xFFFFFFFF = NaN
+    dw = pwconv.pw_wgrad(g, x, w)
+    ref = torch.ops.aten.convolution_backward(g.float(), x.float(), w.float(), None, [1, 1], [k // 2, k // 2], [1, 1], False, [0, 0], 1,
+                                              [False, True, False])[1]
+    assert bool(torch.isfinite(dw.float()).all()), "part of dW was summed from unwritten workspace"
+    _close(dw, ref, 1e-2, "weight gradient")
+    # deferred form (private partial buffer + one reduce launch for several problems): same answer
+    lst = []
+    dw2 = pwconv.pw_wgrad(g, x, w, defer=lst)
+    pwconv.pw_wgrad_flush(lst)
+    assert torch.equal(dw2, dw)
+
+
 @pytest.mark.parametrize("c4,cm", [(256, 64), (512, 128), (1024, 256)])
 def test_weight_gradient_with_both_operand_transforms(c4, cm):
     "conv3's weight gradient of a bottleneck: dz3 from (g, z3, bits) and a2 = relu(bn2(z2)), both formed in the operand loads."
