@@ -53,6 +53,14 @@ def parse():
     ap.add_argument("--no-detect", action="store_true", help="skip the inference-chain (decode + NMS + top-k) roofline line (BASELINE configs[3] shape)")
     ap.add_argument("--ddp-graph", action="store_true", help="capture the step in a hipGraph also when gradients are exchanged (default there: eager steps -- the captured step with RCCL's forked stream branches replays 3.5 %% slower than eager enqueueing, DESIGN.md section 6)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel of every step from Python instead of replaying the captured hipGraph of the step (graph.CapturedTrainStep)")
+    ap.add_argument("--mode", default="train", choices=["train", "predict"], help="predict: only the BASELINE configs[3] end-to-end inference line "
+                    "(R101-FPN, 16 x 3x1333x1333, eval-mode folded BN, conv stack + decode + NMS + top-100 + rescale) as the JSON line")
+    ap.add_argument("--no-predict", action="store_true", help="skip the configs[3] end-to-end predict line (roofline_other.predict_e2e)")
+    ap.add_argument("--predict-backbone", default="resnet101")
+    ap.add_argument("--predict-batch", type=int, default=16)
+    ap.add_argument("--predict-size", type=int, default=1333)
+    ap.add_argument("--predict-dtype", default="bf16", choices=["bf16", "fp16"], help="autocast dtype of the predict line (bf16: the head runs on "
+                    "the hand-written MFMA kernels; fp16: MIOpen convolutions, same detect chain)")
     ap.add_argument("--timing-steps", type=int, default=5, help="eager steps run AFTER the timed region with HIP events around the hand-written kernels (per-kernel figures of the JSON line)")
     return ap.parse_args()
 
@@ -63,7 +71,8 @@ class ClockSampler:
     A thread samples every `period` seconds; `summary()` gives min / mean / max and the sample count, or says what was missing.
     Evidence for "the part holds N GHz under MFMA load" statements and for the box-to-box spread of the headline number."""
 
-    def __init__(self, index=0, period=0.05):
+    def __init__(self, pci=None, period=0.05):
+        """``pci``: "dddd:bb:dd.f" of the GPU (the box shows every GPU of the node in sysfs, HIP only the leased one)."""
         import glob
         import threading
         self.period, self.samples, self._stop, self._thr = period, [], threading.Event(), None
@@ -74,7 +83,12 @@ class ClockSampler:
                     cards.append(d)
             except OSError:
                 pass
-        self.dev = cards[index] if index < len(cards) else (cards[0] if cards else None)
+        self.dev = None
+        if pci:
+            for d in cards:
+                if os.path.basename(os.path.realpath(d)).lower() == pci.lower():
+                    self.dev = d
+        self.pci = pci
         self.hwmon = None
         if self.dev:
             hm = sorted(glob.glob(os.path.join(self.dev, "hwmon", "hwmon*")))
@@ -98,6 +112,13 @@ class ClockSampler:
                             rec["sclk_mhz"] = float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
                         except (IndexError, ValueError):
                             pass
+        if self.dev:
+            t = self._read(os.path.join(self.dev, "gpu_busy_percent"))
+            if t:
+                try:
+                    rec["busy_pct"] = float(t)
+                except ValueError:
+                    pass
         if self.hwmon:
             f = self._read(os.path.join(self.hwmon, "freq1_input"))
             if f and "sclk_mhz" not in rec:
@@ -141,9 +162,9 @@ class ClockSampler:
         return self.summary()
 
     def summary(self):
-        out = {"source": f"sysfs {self.dev}" if self.dev else "no amdgpu sysfs device readable", "samples": len(self.samples),
-               "period_s": self.period}
-        for key in ("sclk_mhz", "power_w", "temp_c"):
+        out = {"source": f"sysfs {self.dev} (pci {self.pci})" if self.dev else f"no amdgpu sysfs device for pci {self.pci}",
+               "samples": len(self.samples), "period_s": self.period}
+        for key in ("sclk_mhz", "power_w", "temp_c", "busy_pct"):
             v = [r[key] for r in self.samples if key in r]
             if v:
                 out[key] = {"min": round(min(v), 1), "mean": round(sum(v) / len(v), 1), "max": round(max(v), 1)}
@@ -311,6 +332,74 @@ def detect_chain_line(device, with_cpu):
     return line, cpu
 
 
+R101_FWD_GFLOP_1344 = 1124.0   # R101-FPN + heads forward @1344x1344 per image
+
+
+def predict_e2e_line(args, device, with_cpu):
+    """BASELINE configs[3] END TO END ("conv stack ... included in an end-to-end figure"; reference path
+    retinanet/models.py:245-272): ``Retinanet.predict`` on B synthetic 3 x S x S images resident in HBM -- fused transform ->
+    R101-FPN + heads in eval mode (frozen BatchNorm folded into the convolutions) under 16-bit autocast -> per-level
+    rn_detect_levels (score scan, decode, per-class NMS, top-100) -> rescale to the original sizes -> the <= 100 rows per image.
+    Random-init weights (prior bias -4.6): the candidate count of the detect chain is whatever those logits give and is stated;
+    the chain under a stated candidate load is `roofline_other.detect_chain`.  CPU leg: the same model's forward on ONE image
+    with PyTorch's CPU kernels (fp32) + the oracle's detect chain on its head outputs."""
+    import pytorch_retinanet_amd as P
+    from pytorch_retinanet_amd.optim import use_bf16_conv_weights
+    B, S = args.predict_batch, args.predict_size
+    dt = torch.bfloat16 if args.predict_dtype == "bf16" else torch.float16
+    torch.manual_seed(0)
+    net = P.Retinanet(num_classes=90, backbone_kind=args.predict_backbone, pretrained=False, min_size=S, max_size=S)
+    net = net.to(device).to(memory_format=torch.channels_last).eval()
+    if dt == torch.bfloat16:
+        use_bf16_conv_weights(net)                       # (no per-forward weight casts)
+    g = torch.Generator().manual_seed(3)
+    images = [torch.rand(3, S, S, generator=g).to(device) for _ in range(B)]
+    with torch.autocast("cuda", dtype=dt):
+        for _ in range(2):
+            dets = net.predict(images)
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            dets = net.predict(images)                   # (ends with the host read of the <= 100 rows per image: synchronous)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+    t = float(np.median(times))
+    Sp = (S + 31) // 32 * 32
+    gflop = R101_FWD_GFLOP_1344 * (Sp * Sp) / (1344.0 * 1344.0) if args.predict_backbone == "resnet101" else None
+    line = {"metric": f"images/sec RetinaNet-{args.predict_backbone.replace('resnet', 'R')}-FPN predict() end to end",
+            "value": round(B / t, 2), "unit": "images/sec", "ms_per_batch": round(t * 1e3, 2),
+            "workload": f"B={B} x 3x{S}x{S} (padded {Sp}x{Sp}), eval-mode folded BN, {args.predict_dtype} autocast, K=90, random-init weights; "
+                        f"{int(np.mean([len(d['scores']) for d in dets]))} detections/image kept",
+            "sample": "median of 5 predict() calls after 2 warm-ups, wall clock incl. the final device-to-host read",
+            "conv_tflops": round(gflop * B / t / 1e3, 1) if gflop else None,
+            "conv_frac_of_mfma_peak": round(gflop * B / t / 1e3 / MFMA_PEAK_TFLOPS, 4) if gflop else None}
+    if with_cpu:
+        import oracle
+        import synth
+        oracle.build()
+        cpu_net = P.Retinanet(num_classes=90, backbone_kind=args.predict_backbone, pretrained=False, min_size=S, max_size=S).eval()
+        img = images[0].cpu()
+        ctimes = []
+        with torch.no_grad():
+            for _ in range(3):
+                t0 = time.perf_counter()
+                il, _ = cpu_net.transform([img], None)
+                fmaps, out = cpu_net._features(il.tensors)
+                anc = oracle.anchors_emit(synth.levels_for(il.tensors.shape[-2], il.tensors.shape[-1]),
+                                          [oracle.cell_anchors(sz, synth.ANCHOR_RATIOS) for sz in synth.ANCHOR_SIZES], 0.0)
+                oracle.detect(out["cls_preds"].numpy(), out["bbox_preds"].numpy(), anc, [tuple(il.image_sizes[0])])
+                ctimes.append(time.perf_counter() - t0)
+        ct = float(np.median(ctimes[1:]))
+        line["cpu"] = {"value": round(1.0 / ct, 4), "unit": "images/sec (PyTorch CPU conv stack fp32 + oracle detect chain, batch 1)",
+                       "cores": torch.get_num_threads(), "kind": "port", "sample": "median of 2 single-image passes after 1 warm-up",
+                       "s_per_image": round(ct, 3)}
+        del cpu_net
+    del net
+    torch.cuda.empty_cache()
+    return line
+
+
 def k3_cold_line(device, B, T, nbytes):
     """K3 at the train shape on COLD logits (the isolated kernel: the in-step figure of `roofline` reads logits the
     class-output conv has just left in the 256 MiB Infinity Cache, walking them back to front).  Per-level bf16 tensors as
@@ -371,6 +460,14 @@ def main():
 
     tuning.use_shipped_miopen_db(rank)        # before the first conv: skip MIOpen's exhaustive search on a cold box
     tuning.enable_conv_autotune()             # channels_last needs find-mode picks (tuning.py has the numbers)
+    if args.mode == "predict":
+        if world != 1:
+            raise SystemExit("bench.py --mode predict is a single-GPU line (images are independent: run N replicas for N GPUs)")
+        line = predict_e2e_line(args, device, not args.no_cpu_baseline)
+        line.update({"n_gpus": 1, "higher_is_better": True, "vs_baseline": None, "dtype": args.predict_dtype, "data": "synthetic",
+                     "config": {"workload": line["workload"]}})
+        print(json.dumps(line), flush=True)
+        return
     torch.manual_seed(0)
     net = P.Retinanet(num_classes=90, backbone_kind=args.backbone, pretrained=False, min_size=800, max_size=1333)
     net = net.to(device).to(memory_format=torch.channels_last).train()
@@ -399,7 +496,11 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    clocks = ClockSampler(local_rank).start() if rank == 0 else None
+    clocks = None
+    if rank == 0:
+        pr = torch.cuda.get_device_properties(local_rank)
+        pci = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+        clocks = ClockSampler(pci).start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = stepper(images, targets)
@@ -508,6 +609,8 @@ def main():
             line["roofline_other"]["detect_chain"] = det_line
             if det_cpu is not None:
                 line["cpu_baseline"]["detect_chain"] = det_cpu
+            if not args.no_predict:
+                line["roofline_other"]["predict_e2e"] = predict_e2e_line(args, device, not args.no_cpu_baseline)
     else:
         line = None
     # The JSON line must be the LAST line of the job's stdout.  RCCL writes a "Librccl path" line to C stdout when it

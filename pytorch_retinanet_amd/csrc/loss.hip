@@ -28,6 +28,7 @@
 #include <cstdlib>
 
 #include "rn_common.hpp"
+#include "rn_match.hpp"
 
 namespace {
 
@@ -67,6 +68,11 @@ struct LossArgs {
     rn_loss_params p;
     float alpha_pos;         // weight of t=1 elements: 1-alpha (Q2)
     float2 *part_stream;     // [blocks] (cls, reg) partial sums
+    // fused matching (loss_stream_kernel<.., FUSED = true>): the IoU matcher of box_utils.py:51-80 runs in this kernel's prologue
+    float fg_thr, bg_thr;
+    int32_t *nfg_acc;        // [B] foreground counts of this launch: zero on entry (the finalize kernel re-zeroes them), device-scope atomics
+    unsigned *bar;           // [1] grid barrier arrival counter: zero on entry (the finalize kernel re-zeroes it)
+    int64_t *matches_out;    // nullable: [B][A] match codes, written by the wave that owns a row's first element
 };
 
 // ---- background element (t = 0) ------------------------------------------------------
@@ -167,11 +173,21 @@ __device__ __forceinline__ float reg_row(const rn::f32x4 g, const rn::f32x4 an, 
     return l;
 }
 
+// num_fg[b]: K2's output, or -- fused matching -- this launch's device-scope counter (complete once the grid barrier has been passed;
+// read with a device-scope atomic load: the adds were performed by other XCDs, whose L2 this one does not snoop)
+template <bool FUSED>
+__device__ __forceinline__ int load_nfg(const LossArgs &a, const int b)
+{
+    if (FUSED) return __hip_atomic_load(&a.nfg_acc[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return a.num_fg[b];
+}
+
 // alpha / (max(num_fg,1) * B) of image b; 0 for an image without GT (every row ignored, Q7)
+template <bool FUSED = false>
 __device__ __forceinline__ float image_gmul(const LossArgs &a, const int b)
 {
     const int T = a.gt_off[b + 1] - a.gt_off[b];
-    const int nf = a.num_fg[b];
+    const int nf = load_nfg<FUSED>(a, b);
     return (T > 0) ? a.p.alpha * ((1.0f / (float)(nf > 1 ? nf : 1)) * a.inv_B) : 0.0f;
 }
 
@@ -184,12 +200,13 @@ __device__ __forceinline__ float image_gmul(const LossArgs &a, const int b)
 constexpr int LIST_CAP = 320;       // rows of a wave's range whose repair goes through the LDS lists (5 chunks of 64; 273 at the train shape)
 constexpr int IGN_U = 4;            // independent element loads per lane per round in the ignored-row repair
 
-template <int DT, bool GAMMA2, bool WRITE_GRAD, int PF, int NT>
+template <int DT, bool GAMMA2, bool WRITE_GRAD, int PF, int NT, bool FUSED = false>
 __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs a)
 {
     typedef rn::dt<DT> D;
     constexpr int VEC = D::VEC;
     __shared__ float s_part[LOSS_WAVES][2];
+    __shared__ signed char s_pmv[FUSED ? LOSS_WAVES : 1][FUSED ? LIST_CAP : 1];   // fused matching: match code of every row of the wave's range
     __shared__ unsigned short s_ign_row[LOSS_WAVES][LIST_CAP];   // ignored rows of the wave's range (offsets from its first row)
     __shared__ float s_ign_gm[LOSS_WAVES][LIST_CAP];            // their alpha/(max(nfg,1)*B)
     __shared__ int s_pos_off[LOSS_WAVES][LIST_CAP];             // positive elements of matched rows: offset from the range's first element
@@ -205,11 +222,107 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
     const int64_t gv_end = min(gv_beg + a.vec_per_wave, a.total_vec);  // (levels laid end to end)
     const int K = a.K;
 
+
+    // ---- Fused matching (FUSED): box_utils.py:51-80 for the rows of THIS wave's range, before anything else.  At the train shape
+    // (T <= 64 GT boxes per image) a row's match is ~T x 25 VALU instructions, while a separate K2 launch is bound by launch latency and
+    // one memory round trip per workgroup (17 us kernel + a memset for 16 MB).  The GT boxes of an image sit one
+    // per LANE (a 16-byte load each, L2 hits) and are broadcast with v_readlane; pair arithmetic and tie / NaN semantics are K2's own
+    // (rn_match.hpp).  The one quantity that is global is num_fg[b] (the normaliser of every gradient of image b, losses.py:107-109):
+    // the waves add their own rows' foreground counts to device-scope counters and meet at a grid barrier -- the grid is the resident
+    // grid (launch_stream), so every workgroup is on the chip.  Match codes wait in LDS (one byte per row) for the repair phase.
+    if (FUSED) {
+        using namespace rn_match;
+        int m_off = 0;
+        for (int li = 0; li < a.L; ++li) {
+            const LossLevel &lv = a.lv[li];
+            const int64_t nvec = lv.nvec;
+            if (gv_end <= lv.voff && nvec > 0) break;
+            const int64_t v_beg = max(gv_beg, lv.voff) - lv.voff;
+            const int64_t v_end = min(gv_end, lv.voff + nvec) - lv.voff;
+            const bool active = (nvec > 0) ? (v_beg < v_end) : (gwave == 0);
+            if (!active) continue;
+            const int64_t e_beg = v_beg * VEC;
+            const int64_t e_end = (nvec == 0 || v_end == nvec) ? lv.N : v_end * VEC;
+            const int64_t row_lo = e_beg / K;
+            const int64_t row_hi = e_end > e_beg ? (e_end - 1) / K : row_lo - 1;
+#pragma unroll 1
+            for (int64_t r0 = row_lo; r0 <= row_hi; r0 += RN_WAVE) {
+                const int n = (int)min((int64_t)RN_WAVE, row_hi - r0 + 1);
+                const bool valid = lane < n;
+                const int64_t r = min(r0 + lane, row_hi);                          // (idle lanes repeat the last row: every lane holds a real anchor)
+                const int b = (int)((uint32_t)r / (uint32_t)lv.A_l);
+                const int64_t ag = lv.base + (r - (int64_t)b * lv.A_l);
+                const rn::f32x4 an = a.anchors[(int64_t)b * a.anchor_bstride4 + ag];
+                const float area_a = (an.z - an.x) * (an.w - an.y);
+                const int b_first = __builtin_amdgcn_readfirstlane(b), b_last = __builtin_amdgcn_readlane(b, RN_WAVE - 1);   // (rows ascend with the lane)
+                const bool a_ok = __all(anchor_is_proper(an, area_a));
+                WaveBox bb = {0.f, 0.f, 0.f, 0.f};
+                if (a_ok) bb = WaveBox{wave_min(an.x), wave_min(an.y), wave_max(an.z), wave_max(an.w)};
+                int pmv = -2;
+#pragma unroll 1
+                for (int bq = b_first; bq <= b_last; ++bq) {                        // one image per chunk, two where a seam crosses it
+                    const int t0 = a.gt_off[bq];
+                    const int T = min(max(a.gt_off[bq + 1] - t0, 0), RN_WAVE);      // (the host promised <= 64 per image)
+                    rn::f32x4 mine = {0.f, 0.f, 0.f, 0.f};
+                    float mine_a = 0.0f;
+                    if (lane < T) { mine = a.gt_boxes[t0 + lane]; mine_a = (mine.z - mine.x) * (mine.w - mine.y); }
+                    float best = 0.0f;
+                    int bi = 0;
+                    if (a_ok && __all(lane >= T || gt_is_proper(mine, mine_a))) {
+                        unsigned long long todo = __ballot(lane < T && may_overlap(bb, mine));   // 64 boxes culled against the wave's strip at once
+                        while (todo) {
+                            const int l = __ffsll((long long)todo) - 1;
+                            todo &= todo - 1;
+                            const GtBox g = gt_of_lane(mine, mine_a, l);
+                            const float inter = inter_fast(g, an);
+                            if (__any(inter != 0.0f)) {
+                                const float v = inter / ((g.area + area_a) - inter);
+                                if (v > best) { best = v; bi = l; }
+                            }
+                        }
+                    } else {
+                        Best bb2 = {0.0f, 0, false};
+                        for (int l = 0; l < T; ++l) {
+                            const GtBox g = gt_of_lane(mine, mine_a, l);
+                            careful_update(bb2, iou_pair(vec(g), g.area, an, area_a), l);
+                        }
+                        best = bb2.v; bi = bb2.i;
+                    }
+                    const int code = (int)classify(best, bi, T, a.fg_thr, a.bg_thr);
+                    if (b == bq) pmv = code;
+                }
+                if (valid) s_pmv[wave][m_off + (int)(r0 - row_lo) + lane] = (signed char)pmv;
+                const bool own = valid && r * K >= e_beg;                          // the row's first element lies in this wave's range: counted / written once
+                if (a.matches_out && own) a.matches_out[(int64_t)b * a.A + ag] = (int64_t)pmv;
+#pragma unroll 1
+                for (int bq = b_first; bq <= b_last; ++bq) {
+                    const unsigned long long fg = __ballot(own && b == bq && pmv >= 0);
+                    if (fg && lane == 0) {
+                        // returning form + a use of the result: the wave waits until the add has been PERFORMED, so it is ordered before
+                        // this workgroup's barrier arrival below without a release fence (an agent-scope release writes the L2 back)
+                        const int old = __hip_atomic_fetch_add(&a.nfg_acc[bq], (int)__popcll(fg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        asm volatile("" ::"v"(old));
+                    }
+                }
+            }
+            m_off += (int)(row_hi - row_lo + 1);
+        }
+        // grid barrier: one arrival per workgroup, polled by one thread per workgroup
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned old = __hip_atomic_fetch_add(a.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" ::"v"(old));
+            while (__hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+    }
+
     // acc is carried in double: phase A adds the background term of rows that phase B later takes out
     // again, and that cancellation must not cost precision when such a row holds large logits.
     // (One DP fma per group per lane: free.)
     double acc = 0.0;                                            // already scaled by alpha*scale
     float reg = 0.0f;
+    int seg_off = 0;                                             // (fused matching) first LDS slot of the current level segment's match codes
 
     for (int li = 0; li < a.L; ++li) {                           // a wave's range rarely spans more than one level
         const LossLevel &lv = a.lv[li];
@@ -258,7 +371,11 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
             for (int64_t r0 = row_lo; r0 <= cap_hi; r0 += RN_WAVE) {                 // wave-uniform
                 const int n = (int)min((int64_t)RN_WAVE, cap_hi - r0 + 1);
                 unsigned long long m = ~0ull;                                      // no words (old entry points): look every row up
-                if (a.special) {
+                int pmv_l = -1;
+                if (FUSED) {
+                    if (lane < n) pmv_l = s_pmv[wave][seg_off + (int)(r0 - row_lo) + lane];
+                    m = __ballot(pmv_l != -1);
+                } else if (a.special) {
                     const int b0 = (int)((uint32_t)r0 / (uint32_t)lv.A_l);
                     const int64_t a0 = r0 - (int64_t)b0 * lv.A_l;
                     if (a0 + n <= lv.A_l) {                                        // the chunk lies inside one image
@@ -279,11 +396,11 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                 if (flagged) {
                     b = (int)((uint32_t)r / (uint32_t)lv.A_l);
                     ag = lv.base + (r - (int64_t)b * lv.A_l);
-                    pmv = (int)a.matches[(int64_t)b * a.A + ag];
+                    pmv = FUSED ? pmv_l : (int)a.matches[(int64_t)b * a.A + ag];
                 }
                 const bool special = flagged && pmv != -1;
                 int t0 = 0, T = 0, nf = 1;
-                if (special) { t0 = a.gt_off[b]; T = a.gt_off[b + 1] - t0; nf = a.num_fg[b]; }
+                if (special) { t0 = a.gt_off[b]; T = a.gt_off[b + 1] - t0; nf = load_nfg<FUSED>(a, b); }
                 const bool live = special && T > 0;                                // images without GT: phase A writes zeros
                 const bool matched = live && pmv >= 0, ign = live && pmv < 0;
                 const float scale = (1.0f / (float)(nf > 1 ? nf : 1)) * a.inv_B;
@@ -364,7 +481,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
         if (v_beg < v_end) {
             int b = (int)(e_beg / lv.per_image);                      // image of the first element
             int64_t img_end_v = ((int64_t)(b + 1) * lv.per_image) / VEC;   // vectors [.., img_end_v) lie entirely in image b
-            float gmul = image_gmul(a, b);
+            float gmul = image_gmul<FUSED>(a, b);
 
             const int64_t last = v_end - 1;
             const int64_t groups = (v_end - v_beg) / (PF * RN_WAVE);      // full groups of PF wave-iterations
@@ -406,7 +523,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                     // is "image b before element e_seam, image b + 1 from it on": two wave-uniform multipliers and a compare.
                     const int64_t e_seam = (int64_t)(b + 1) * lv.per_image;
                     const bool one_seam = lv.per_image >= (int64_t)PF * RN_WAVE * VEC && b + 1 < a.B;
-                    const float gmul_next = one_seam ? image_gmul(a, b + 1) : 0.0f;
+                    const float gmul_next = one_seam ? image_gmul<FUSED>(a, b + 1) : 0.0f;
 #pragma unroll 1
                     for (int u = 0; u < PF; ++u) {
                         const int64_t v = v0 + u * RN_WAVE + lane;
@@ -424,7 +541,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                                 s_hi += j >= k ? wb : 0.0f;
                                 g[j] = gg * (j >= k ? gmul_next : gmul);
                             } else {
-                                const float gm = image_gmul(a, (int)((v * VEC + j) / lv.per_image));
+                                const float gm = image_gmul<FUSED>(a, (int)((v * VEC + j) / lv.per_image));
                                 acc += (double)wb * (double)gm;
                                 g[j] = gg * gm;
                             }
@@ -435,7 +552,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                     b = (int)(((v0 + PF * RN_WAVE) * VEC) / lv.per_image);
                     if (b > a.B - 1) b = a.B - 1;
                     img_end_v = ((int64_t)(b + 1) * lv.per_image) / VEC;
-                    gmul = image_gmul(a, b);
+                    gmul = image_gmul<FUSED>(a, b);
                 }
 #pragma unroll
                 for (int u = 0; u < PF; ++u) q[u] = qn[u];
@@ -447,7 +564,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                 D::unpack(src[v], x);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
-                    const float gm = image_gmul(a, (int)((v * VEC + j) / lv.per_image));
+                    const float gm = image_gmul<FUSED>(a, (int)((v * VEC + j) / lv.per_image));
                     float wb, gg;
                     bg_elem<GAMMA2>(x[j], a.p, wb, gg);
                     acc += (double)wb * (double)gm;
@@ -460,7 +577,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
         if (nvec == 0 || v_end == nvec) {
             const int64_t e = nvec * VEC + lane;
             if (lane < VEC && e < lv.N) {
-                const float gm = image_gmul(a, (int)(e / lv.per_image));
+                const float gm = image_gmul<FUSED>(a, (int)(e / lv.per_image));
                 float wb, gg;
                 bg_elem<GAMMA2>(D::ld(lv.cls, e), a.p, wb, gg);
                 acc += (double)wb * (double)gm;
@@ -483,8 +600,9 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+        if (FUSED) seg_off += (int)(row_hi - row_lo + 1);       // (the host admits the fused form only when every range fits the lists)
         // rows past the lists' capacity (ranges longer than LIST_CAP rows: small K or few waves), chunk by chunk after the stream
-        for (int64_t c0 = row_lo + LIST_CAP; c0 <= row_hi; c0 += RN_WAVE) {
+        for (int64_t c0 = row_lo + LIST_CAP; !FUSED && c0 <= row_hi; c0 += RN_WAVE) {
             const int64_t r = c0 + lane;
             bool ignored = false;
             float ign_gm = 0.0f;
@@ -585,10 +703,17 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
     }
 }
 
+// `bar` != null (fused matching): the launch's foreground counters move to num_fg_out and the state words go back to zero for the
+// next launch on this state buffer (this kernel follows the stream kernel in stream order: plain loads / stores are enough here)
 __global__ __launch_bounds__(1024) void loss_finalize_kernel(const float2 *__restrict__ partials, const int n,
-                                                             float *__restrict__ out)
+                                                             float *__restrict__ out, unsigned *__restrict__ bar,
+                                                             int32_t *__restrict__ nfg_acc, int32_t *__restrict__ num_fg_out, const int B)
 {
     __shared__ double s[2][1024];
+    if (bar) {
+        for (int b = threadIdx.x; b < B; b += 1024) { num_fg_out[b] = nfg_acc[b]; nfg_acc[b] = 0; }
+        if (threadIdx.x == 0) bar[0] = 0u;
+    }
     double c = 0.0, r = 0.0;
     for (int i = threadIdx.x; i < n; i += 1024) { const float2 v = partials[i]; c += (double)v.x; r += (double)v.y; }
     s[0][threadIdx.x] = c; s[1][threadIdx.x] = r;
@@ -670,7 +795,7 @@ struct ProfileEvents { hipEvent_t start, stop; };
 static thread_local ProfileEvents g_prof = {nullptr, nullptr};     // set only for the duration of one rn_loss_fwd_bwd_levels_timed call
 
 template <typename StreamT>
-int launch_stream(StreamT stream_k, LossArgs &a, int vec, hipStream_t st, int *n_stream)
+int launch_stream(StreamT stream_k, LossArgs &a, int vec, hipStream_t st, int *n_stream, const bool fused = false)
 {
     int res = 0;
     int rc = resident_blocks(stream_k, &res);
@@ -690,9 +815,14 @@ int launch_stream(StreamT stream_k, LossArgs &a, int vec, hipStream_t st, int *n
         // reads exactly those first: 131 -> 117 us on one box (round-2 A/B of the two orders); no effect on cold data
         a.reverse = 1;
     }
-    (void)vec;
     int64_t need = ((nvec + vpw - 1) / vpw + LOSS_WAVES - 1) / LOSS_WAVES;
     if (need < 1) need = 1;
+    if (fused) {
+        // every workgroup must be resident (grid barrier), and the match codes of a wave's rows must fit its LDS list: a range of vpw
+        // vectors covers at most vpw * VEC / K rows + 2 partial rows per level segment + the rows of a level's ragged tail
+        if (need > res) return RN_EUNSUPPORTED;
+        if (vpw * vec / a.K + 3 * (int64_t)a.L + 1 > LIST_CAP) return RN_EUNSUPPORTED;
+    }
     if (g_prof.start) RN_HIP(hipEventRecord(g_prof.start, st));
     hipLaunchKernelGGL(stream_k, dim3((unsigned)need), dim3(LOSS_BLOCK), 0, st, a);
     RN_LAUNCH_CHECK();
@@ -702,12 +832,20 @@ int launch_stream(StreamT stream_k, LossArgs &a, int vec, hipStream_t st, int *n
 }
 
 template <int DT>
-int launch_loss(LossArgs &a, bool gamma2, bool wg, hipStream_t st, int *ns)
+int launch_loss(LossArgs &a, bool gamma2, bool wg, hipStream_t st, int *ns, const bool fused = false)
 {
     constexpr int VEC = rn::dt<DT>::VEC;
     // PF = 2 groups of loads in flight, non-temporal loads: the best of the (2|4|8) x (nt|plain) sweep on MI355X
     int n_stream = 0, rc;
-    if (gamma2) {
+    if (fused) {
+        if (gamma2) {
+            if (wg) rc = launch_stream(loss_stream_kernel<DT, true, true, 2, 1, true>, a, VEC, st, &n_stream, true);
+            else rc = launch_stream(loss_stream_kernel<DT, true, false, 2, 1, true>, a, VEC, st, &n_stream, true);
+        } else {
+            if (wg) rc = launch_stream(loss_stream_kernel<DT, false, true, 2, 1, true>, a, VEC, st, &n_stream, true);
+            else rc = launch_stream(loss_stream_kernel<DT, false, false, 2, 1, true>, a, VEC, st, &n_stream, true);
+        }
+    } else if (gamma2) {
         if (wg) rc = launch_stream(loss_stream_kernel<DT, true, true, 2, 1>, a, VEC, st, &n_stream);
         else rc = launch_stream(loss_stream_kernel<DT, true, false, 2, 1>, a, VEC, st, &n_stream);
     } else {
@@ -727,17 +865,19 @@ RN_API size_t rn_loss_workspace_bytes(int B, int64_t A, int K)
     return sizeof(float2) * (size_t)LOSS_MAX_BLOCKS * 2 + 16;
 }
 
+// fused matching: thresholds, optional match codes out, num_fg out, and the state words (zero on entry, zero on exit)
+struct FusedMatch { float fg_thr, bg_thr; int64_t *matches_out; int32_t *num_fg_out; void *state; };
+
 static int loss_levels_core(const void *const *cls_levels, const void *const *box_levels,
                             const int64_t *level_anchors, int L, int dtype, int B, int K,
                             const float *anchors, int64_t anchor_bstride, const float *gt_boxes,
                             const int64_t *gt_labels, const int32_t *gt_off, const int64_t *matches, const uint64_t *special_rows,
                             const int32_t *num_fg, const rn_loss_params *params, float *out_loss,
                             void *const *grad_cls_levels, void *const *grad_box_levels, void *workspace,
-                            size_t workspace_bytes, void *stream)
+                            size_t workspace_bytes, void *stream, const FusedMatch *fm = nullptr)
 {
-    if (!cls_levels || !box_levels || !level_anchors || !anchors || !gt_off || !matches || !num_fg || !params || !out_loss ||
-        !workspace)
-        return RN_EINVAL;
+    if (!cls_levels || !box_levels || !level_anchors || !anchors || !gt_off || !params || !out_loss || !workspace) return RN_EINVAL;
+    if (!fm && (!matches || !num_fg)) return RN_EINVAL;
     if (L <= 0 || L > RN_MAX_LEVELS || B <= 0 || K <= 0) return RN_EINVAL;
     if ((grad_cls_levels == nullptr) != (grad_box_levels == nullptr)) return RN_EINVAL;
     if (dtype != RN_F32 && dtype != RN_BF16 && dtype != RN_F16) return RN_EINVAL;
@@ -784,6 +924,11 @@ static int loss_levels_core(const void *const *cls_levels, const void *const *bo
     a.p = *params;
     a.alpha_pos = (float)(1.0 - (double)params->alpha);
     a.part_stream = (float2 *)workspace;
+    a.fg_thr = a.bg_thr = 0.0f; a.nfg_acc = nullptr; a.bar = nullptr; a.matches_out = nullptr;
+    if (fm) {
+        a.fg_thr = fm->fg_thr; a.bg_thr = fm->bg_thr; a.matches_out = fm->matches_out;
+        a.bar = (unsigned *)fm->state; a.nfg_acc = (int32_t *)fm->state + 16;        // (counters one cache-line half away from the barrier word)
+    }
     if (grad_cls_levels)
         for (int l = 0; l < L; ++l)
             if (grad_cls_levels[l] == cls_levels[l]) return RN_EINVAL;      // the repair phase re-reads logits the stream has passed
@@ -792,12 +937,13 @@ static int loss_levels_core(const void *const *cls_levels, const void *const *bo
     hipStream_t st = (hipStream_t)stream;
     int ns = 0, rc;
     switch (dtype) {
-        case RN_F32: rc = launch_loss<RN_F32>(a, gamma2, wg, st, &ns); break;
-        case RN_BF16: rc = launch_loss<RN_BF16>(a, gamma2, wg, st, &ns); break;
-        default: rc = launch_loss<RN_F16>(a, gamma2, wg, st, &ns); break;
+        case RN_F32: rc = launch_loss<RN_F32>(a, gamma2, wg, st, &ns, fm != nullptr); break;
+        case RN_BF16: rc = launch_loss<RN_BF16>(a, gamma2, wg, st, &ns, fm != nullptr); break;
+        default: rc = launch_loss<RN_F16>(a, gamma2, wg, st, &ns, fm != nullptr); break;
     }
     if (rc != RN_OK) return rc;
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float2 *)a.part_stream, ns, out_loss);
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float2 *)a.part_stream, ns, out_loss, a.bar, a.nfg_acc,
+                       fm ? fm->num_fg_out : nullptr, B);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
@@ -826,6 +972,32 @@ RN_API int rn_loss_fwd_bwd_levels_ex(const void *const *cls_levels, const void *
     const int rc = loss_levels_core(cls_levels, box_levels, level_anchors, L, dtype, B, K, anchors, anchor_bstride, gt_boxes, gt_labels,
                                     gt_off, matches, special_rows, num_fg, params, out_loss, grad_cls_levels, grad_box_levels, workspace,
                                     workspace_bytes, stream);
+    g_prof.start = g_prof.stop = nullptr;
+    return rc;
+}
+
+RN_API size_t rn_loss_match_state_bytes(int B) { return B > 0 ? (size_t)(16 + B) * sizeof(int32_t) : 0; }
+
+RN_API int rn_loss_match_fwd_bwd_levels(const void *const *cls_levels, const void *const *box_levels,
+                                        const int64_t *level_anchors, int L, int dtype, int B, int K,
+                                        const float *anchors, int64_t anchor_bstride, const float *gt_boxes,
+                                        const int64_t *gt_labels, const int32_t *gt_off, int max_gt_per_image,
+                                        float fg_thr, float bg_thr, int64_t *matches_out, int32_t *num_fg_out,
+                                        const rn_loss_params *params, float *out_loss, void *const *grad_cls_levels,
+                                        void *const *grad_box_levels, void *workspace, size_t workspace_bytes, void *state,
+                                        size_t state_bytes, void *stream, void *event_start, void *event_stop)
+{
+    if (!num_fg_out || !state || B <= 0 || max_gt_per_image < 0) return RN_EINVAL;
+    if (!(fg_thr > bg_thr)) return RN_ETHRESH;
+    if (max_gt_per_image > RN_WAVE) return RN_EUNSUPPORTED;            // one GT box per lane: larger sets go through rn_iou_match + rn_loss_fwd_bwd_levels
+    if (max_gt_per_image > 0 && !gt_boxes) return RN_EINVAL;
+    if (state_bytes < rn_loss_match_state_bytes(B)) return RN_EWORKSPACE;
+    if (!rn::aligned(state, 64)) return RN_EALIGN;
+    const FusedMatch fm = {fg_thr, bg_thr, matches_out, num_fg_out, state};
+    g_prof.start = (hipEvent_t)event_start; g_prof.stop = (hipEvent_t)event_stop;
+    const int rc = loss_levels_core(cls_levels, box_levels, level_anchors, L, dtype, B, K, anchors, anchor_bstride, gt_boxes, gt_labels,
+                                    gt_off, nullptr, nullptr, nullptr, params, out_loss, grad_cls_levels, grad_box_levels, workspace,
+                                    workspace_bytes, stream, &fm);
     g_prof.start = g_prof.stop = nullptr;
     return rc;
 }
