@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RN_ABI_VERSION 4
+#define RN_ABI_VERSION 5
 #define RN_MAX_LEVELS 8
 
 enum rn_dtype { RN_F32 = 0, RN_BF16 = 1, RN_F16 = 2 };
@@ -150,6 +150,25 @@ int rn_loss_fwd_bwd_levels_ex(const void *const *cls_levels, const void *const *
                               const uint64_t *special_rows, const int32_t *num_fg, const rn_loss_params *params,
                               float *out_loss, void *const *grad_cls_levels, void *const *grad_box_levels, void *workspace,
                               size_t workspace_bytes, void *stream, void *event_start, void *event_stop);
+/* K2 + K3 in ONE launch (round 4): the matcher of retinanet/box_utils.py:51-80 runs in the loss kernel's prologue -- every wave
+ * matches the anchor rows of its own range against the image's GT boxes (one box per lane, so max_gt_per_image <= 64), the
+ * per-image foreground counts meet in device-scope counters behind a grid barrier (the launch uses the resident grid only), and
+ * the match codes never leave the chip unless `matches_out` (nullable, i64[B][A]) asks for them.  Same results as
+ * rn_iou_match + rn_loss_fwd_bwd_levels bit for bit (match codes, num_fg) / to the last ulp of the same arithmetic (losses,
+ * gradients).  num_fg_out i32[B] is written by the finalize kernel.  `state` (rn_loss_match_state_bytes(B), 64-byte aligned)
+ * holds the barrier word and the counters: the caller zero-fills it ONCE; every completed call leaves it zero-filled; it must
+ * not be shared by calls that can run concurrently (one per stream).  RN_EUNSUPPORTED: more than 64 GT boxes in an image, or a
+ * shape whose per-wave row range does not fit the kernel's lists (then call rn_iou_match_special + rn_loss_fwd_bwd_levels_ex).
+ * event_start / event_stop as in rn_loss_fwd_bwd_levels_ex. */
+size_t rn_loss_match_state_bytes(int B);
+int rn_loss_match_fwd_bwd_levels(const void *const *cls_levels, const void *const *box_levels,
+                                 const int64_t *level_anchors, int L, int dtype, int B, int K,
+                                 const float *anchors, int64_t anchor_bstride, const float *gt_boxes,
+                                 const int64_t *gt_labels, const int32_t *gt_off, int max_gt_per_image,
+                                 float fg_thr, float bg_thr, int64_t *matches_out, int32_t *num_fg_out,
+                                 const rn_loss_params *params, float *out_loss, void *const *grad_cls_levels,
+                                 void *const *grad_box_levels, void *workspace, size_t workspace_bytes, void *state,
+                                 size_t state_bytes, void *stream, void *event_start, void *event_stop);
 int rn_loss_fwd_bwd_levels_timed(const void *const *cls_levels, const void *const *box_levels,
                                  const int64_t *level_anchors, int L, int dtype, int B, int K,
                                  const float *anchors, int64_t anchor_bstride, const float *gt_boxes,

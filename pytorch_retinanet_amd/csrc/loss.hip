@@ -73,6 +73,7 @@ struct LossArgs {
     int32_t *nfg_acc;        // [B] foreground counts of this launch: zero on entry (the finalize kernel re-zeroes them), device-scope atomics
     unsigned *bar;           // [1] grid barrier arrival counter: zero on entry (the finalize kernel re-zeroes it)
     int64_t *matches_out;    // nullable: [B][A] match codes, written by the wave that owns a row's first element
+    int32_t dbg;             // development ablations (RN_K3_FUSED_DEBUG): 1 = no barrier, 2 = no matching pass, 4 = long poll backoff
 };
 
 // ---- background element (t = 0) ------------------------------------------------------
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
     if (FUSED) {
         using namespace rn_match;
         int m_off = 0;
-        for (int li = 0; li < a.L; ++li) {
+        for (int li = 0; li < ((a.dbg & 2) ? 0 : a.L); ++li) {
             const LossLevel &lv = a.lv[li];
             const int64_t nvec = lv.nvec;
             if (gv_end <= lv.voff && nvec > 0) break;
@@ -309,10 +310,17 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
         }
         // grid barrier: one arrival per workgroup, polled by one thread per workgroup
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned old = __hip_atomic_fetch_add(a.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("" ::"v"(old));
-            while (__hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) __builtin_amdgcn_s_sleep(2);
+        if (threadIdx.x == 0 && !(a.dbg & 1)) {
+            // NON-returning add: 1 536 returning adds to one address serialise at ~40 ns each (measured: +57 us per launch), the
+            // fire-and-forget form at ~1.4 ns.  This wave's foreground adds above were waited for, the other waves' before the barrier
+            __hip_atomic_fetch_add(a.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (bounded: were the grid ever not co-resident -- it is sized from the occupancy query -- the launch must fail loudly, not
+            // hang the device: ~4 M polls, seconds, then a sticky flag that makes the finalize kernel return NaN losses)
+            unsigned spins = 0;
+            while (__hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+                if (a.dbg & 4) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); } else __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 21)) { __hip_atomic_store(a.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
         }
         __syncthreads();
     }
@@ -714,6 +722,7 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(const float2 *__res
         for (int b = threadIdx.x; b < B; b += 1024) { num_fg_out[b] = nfg_acc[b]; nfg_acc[b] = 0; }
         if (threadIdx.x == 0) bar[0] = 0u;
     }
+    const bool barrier_failed = bar && bar[1] != 0u;               // (uniform: read before the reset below can matter -- only thread 0 writes it, after the sums)
     double c = 0.0, r = 0.0;
     for (int i = threadIdx.x; i < n; i += 1024) { const float2 v = partials[i]; c += (double)v.x; r += (double)v.y; }
     s[0][threadIdx.x] = c; s[1][threadIdx.x] = r;
@@ -722,7 +731,11 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(const float2 *__res
         if ((int)threadIdx.x < o) { s[0][threadIdx.x] += s[0][threadIdx.x + o]; s[1][threadIdx.x] += s[1][threadIdx.x + o]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { out[0] = (float)s[0][0]; out[1] = (float)s[1][0]; }
+    if (threadIdx.x == 0) {
+        out[0] = barrier_failed ? __builtin_nanf("") : (float)s[0][0];
+        out[1] = barrier_failed ? __builtin_nanf("") : (float)s[1][0];
+        if (barrier_failed) bar[1] = 0u;
+    }
 }
 
 template <int DT>
@@ -777,12 +790,13 @@ __global__ __launch_bounds__(256) void scale_inplace_batched_kernel(const ScaleT
 // Grid = what is co-resident (CUs x blocks/CU from the occupancy query), never more: a second,
 // partially filled round of blocks would idle most of the chip for a whole block lifetime.
 template <typename KernelT>
-int resident_blocks(KernelT kernel, int *out)
+int resident_blocks(KernelT kernel, int *out, const int per_cu_cap = 1 << 30)
 {
     int dev = 0, cus = 0, per_cu = 0;
     RN_HIP(hipGetDevice(&dev));
     RN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     RN_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, LOSS_BLOCK, 0));
+    if (per_cu > per_cu_cap) per_cu = per_cu_cap;
     int n = cus * per_cu;
     if (n < 1) n = 1;
     if (n > LOSS_MAX_BLOCKS) n = LOSS_MAX_BLOCKS;
@@ -798,7 +812,11 @@ template <typename StreamT>
 int launch_stream(StreamT stream_k, LossArgs &a, int vec, hipStream_t st, int *n_stream, const bool fused = false)
 {
     int res = 0;
-    int rc = resident_blocks(stream_k, &res);
+    // fused matching needs EVERY workgroup resident (grid barrier).  The occupancy query is an estimate: the value-only variant (64
+    // VGPRs -> 8 workgroups per CU by registers, 8 x 19 232 B of LDS = 154 KB "fits" 160 KB) was answered 8 and the hardware held
+    // fewer (LDS allocation granularity) -- the barrier timed out.  6 per CU is what the gradient variant (the measured one) runs at
+    // and leaves 45 KB of LDS slack.
+    int rc = resident_blocks(stream_k, &res, fused ? 6 : (1 << 30));
     if (rc != RN_OK) return rc;
     // even split of the vectors over the resident waves, in whole wave-iterations (64 vectors = 1 KiB)
     const int64_t nvec = a.total_vec;
@@ -819,9 +837,9 @@ int launch_stream(StreamT stream_k, LossArgs &a, int vec, hipStream_t st, int *n
     if (need < 1) need = 1;
     if (fused) {
         // every workgroup must be resident (grid barrier), and the match codes of a wave's rows must fit its LDS list: a range of vpw
-        // vectors covers at most vpw * VEC / K rows + 2 partial rows per level segment + the rows of a level's ragged tail
+        // vectors (+ a ragged tail of < VEC elements per level) covers at most elements / K rows + 2 partial rows per level segment
         if (need > res) return RN_EUNSUPPORTED;
-        if (vpw * vec / a.K + 3 * (int64_t)a.L + 1 > LIST_CAP) return RN_EUNSUPPORTED;
+        if ((vpw * vec + (int64_t)a.L * (vec - 1)) / a.K + 2 * (int64_t)a.L + 1 > LIST_CAP) return RN_EUNSUPPORTED;
     }
     if (g_prof.start) RN_HIP(hipEventRecord(g_prof.start, st));
     hipLaunchKernelGGL(stream_k, dim3((unsigned)need), dim3(LOSS_BLOCK), 0, st, a);
@@ -924,7 +942,8 @@ static int loss_levels_core(const void *const *cls_levels, const void *const *bo
     a.p = *params;
     a.alpha_pos = (float)(1.0 - (double)params->alpha);
     a.part_stream = (float2 *)workspace;
-    a.fg_thr = a.bg_thr = 0.0f; a.nfg_acc = nullptr; a.bar = nullptr; a.matches_out = nullptr;
+    a.fg_thr = a.bg_thr = 0.0f; a.nfg_acc = nullptr; a.bar = nullptr; a.matches_out = nullptr; a.dbg = 0;
+    if (const char *e = getenv("RN_K3_FUSED_DEBUG")) a.dbg = atoi(e);
     if (fm) {
         a.fg_thr = fm->fg_thr; a.bg_thr = fm->bg_thr; a.matches_out = fm->matches_out;
         a.bar = (unsigned *)fm->state; a.nfg_acc = (int32_t *)fm->state + 16;        // (counters one cache-line half away from the barrier word)

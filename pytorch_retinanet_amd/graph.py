@@ -29,6 +29,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 from torch import Tensor
 
+from . import ops
 from ._lib import check, lib
 from .norm import note_raw_write
 
@@ -36,10 +37,10 @@ _log = logging.getLogger(__name__)
 
 
 class _Entry:
-    __slots__ = ("graph", "images", "targets", "losses", "calls", "failed")
+    __slots__ = ("graph", "images", "targets", "losses", "calls", "failed", "match_state")
 
     def __init__(self):
-        self.graph, self.images, self.targets, self.losses, self.calls, self.failed = None, None, None, None, 0, False
+        self.graph, self.images, self.targets, self.losses, self.calls, self.failed, self.match_state = None, None, None, None, 0, False, None
 
 
 class CapturedTrainStep:
@@ -81,14 +82,17 @@ class CapturedTrainStep:
         ims = tuple((tuple(im.shape), im.dtype, im.device) for im in images)
         tgs = tuple(tuple(sorted((k, tuple(v.shape), v.dtype) for k, v in t.items() if isinstance(v, Tensor))) for t in targets)
         mode = tuple(m.training for m in self.net.modules())
-        return (ims, tgs, groups, hash(mode), self.amp_dtype)
+        frozen = tuple(p.requires_grad for p in self.net.parameters())       # (freezing / unfreezing layers changes the launch sequence)
+        return (ims, tgs, groups, hash(mode), hash(frozen), self.amp_dtype)
 
     def _capture(self, e: _Entry, images, targets) -> None:
         e.images = [im.clone() for im in images]
         e.targets = [{k: (v.clone() if isinstance(v, Tensor) else v) for k, v in t.items()} for t in targets]
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        # the fused loss kernel's state words: zero-filled here, OUTSIDE the capture, and owned by this entry (ops.use_match_state)
+        e.match_state = ops.new_match_state(e.images[0].device)
+        with ops.use_match_state(e.match_state), torch.cuda.graph(g, capture_error_mode="thread_local"):
             e.losses = self._step(e.images, e.targets)
         e.graph = g
         self.captures += 1

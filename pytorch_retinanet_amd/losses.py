@@ -7,6 +7,7 @@ writes the gradients in the same pass that computes the loss values, so
 ``backward`` only has to apply the upstream scalar (a device-side no-op when it
 is 1, the ``loss.backward()`` case).
 """
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -54,6 +55,12 @@ class MatchAhead:
 
 
 _SIDE_STREAMS = {}
+# K2 inside K3 (rn_loss_match_fwd_bwd_levels) is OPT-IN: bit-identical results, but measured SLOWER than the two launches on MI355X
+# (B = 8, A = 201 600, T = 8, isolated: 201 us against 154 us for K2 + K3).  num_fg[b] normalises every gradient of image b, so the
+# fused kernel needs a grid barrier between its matching prologue and the stream; ablations on one box: the barrier alone +23 us (it
+# exposes the launch ramp of the 1 536 workgroups, which the plain kernel hides under the early workgroups' streaming), the matching
+# pass alone +15 us when other waves' streaming covers it and ~45 us when everything waits behind the barrier.
+FUSE_MATCH = os.environ.get("RN_FUSE_MATCH", "0") == "1"
 
 
 def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
@@ -70,14 +77,24 @@ class _FusedDenseHeadLossLevels(torch.autograd.Function):
     def forward(ctx, anchors, gt_boxes, gt_labels, gt_off, params, fg_thr, bg_thr, L, ahead, *levels):
         cls_levels, box_levels = levels[:L], levels[L:]
         B = cls_levels[0].shape[0]
-        if ahead is not None:
-            torch.cuda.current_stream(cls_levels[0].device).wait_event(ahead.done)        # K2 ran beside the head convolutions
-            matches, num_fg, special = ahead.matches, ahead.num_fg, ahead.special
-        else:
-            matches, num_fg, special = ops.iou_match(anchors, gt_boxes, gt_off, B, fg_thr, bg_thr, want_special=True)
         want_grad = any(ctx.needs_input_grad[9:])
-        loss, gcls, gbox = ops.loss_fwd_bwd_levels(cls_levels, box_levels, anchors, gt_boxes, gt_labels, gt_off, matches,
-                                                   num_fg, params, want_grad, special=special)
+        fused = None
+        if ahead is not None and not isinstance(ahead, MatchAhead):
+            # ``ahead`` = the largest per-image GT count: K2 runs INSIDE the loss kernel (one launch; box_utils.py:51-80 in the
+            # prologue of rn_loss_match_fwd_bwd_levels) unless the library declines the shape
+            fused = ops.loss_match_fwd_bwd_levels(cls_levels, box_levels, anchors, gt_boxes, gt_labels, gt_off, int(ahead), fg_thr,
+                                                  bg_thr, params, want_grad)
+            ahead = None
+        if fused is not None:
+            loss, gcls, gbox = fused[0], fused[1], fused[2]
+        else:
+            if ahead is not None:
+                torch.cuda.current_stream(cls_levels[0].device).wait_event(ahead.done)        # K2 ran beside the head convolutions
+                matches, num_fg, special = ahead.matches, ahead.num_fg, ahead.special
+            else:
+                matches, num_fg, special = ops.iou_match(anchors, gt_boxes, gt_off, B, fg_thr, bg_thr, want_special=True)
+            loss, gcls, gbox = ops.loss_fwd_bwd_levels(cls_levels, box_levels, anchors, gt_boxes, gt_labels, gt_off, matches,
+                                                       num_fg, params, want_grad, special=special)
         ctx.grads = (gcls, gbox)
         ctx.meta = [(c.shape, c.dtype) for c in cls_levels] + [(b.shape, b.dtype) for b in box_levels]
         # two scalar outputs (views of the kernel's f32[2]): backward then receives the two upstream scalars directly, without
@@ -159,6 +176,12 @@ class RetinaNetLosses(nn.Module):
         gt_labels = torch.cat([l.reshape(-1).to(device=dev, dtype=torch.int64) for l in labels])
         return gt_boxes, gt_labels, ops.gt_offsets(counts, dev)
 
+    @staticmethod
+    def fuses_match(targets) -> bool:
+        """``RN_FUSE_MATCH=1``: the matcher runs inside the loss kernel (one launch, ``rn_loss_match_fwd_bwd_levels``) when no image has
+        more than 64 GT boxes.  Off by default: measured slower than K2 + K3 (see ``FUSE_MATCH``)."""
+        return FUSE_MATCH and max([int(t["boxes"].reshape(-1, 4).shape[0]) for t in targets] or [0]) <= 64
+
     def match_ahead(self, targets: List[Dict[str, Tensor]], anchors) -> MatchAhead:
         """Launch K2 (IoU + matcher, box_utils.py:51-80) NOW, on a side stream: it depends only on the anchors and the GT boxes,
         both known as soon as the feature-map shapes are, and then runs beside the head convolutions instead of between the
@@ -178,6 +201,11 @@ class RetinaNetLosses(nn.Module):
                           out=(h.matches, h.num_fg, h.special))
             h.done = torch.cuda.Event()
             h.done.record(side)
+        # the tensors were allocated on the calling stream but are written / read on the side stream: if the head raises before
+        # the loss joins the streams and the handle is dropped, the allocator must not hand the blocks out while K2 still runs
+        for t in (h.matches, h.num_fg, h.special, h.gt_boxes, h.gt_off, anchors):
+            if t is not None:
+                t.record_stream(side)
         return h
 
     def forward_levels(self, targets: List[Dict[str, Tensor]], cls_levels: Sequence[Tensor], box_levels: Sequence[Tensor],
@@ -191,6 +219,8 @@ class RetinaNetLosses(nn.Module):
         else:
             gt_boxes, gt_labels, gt_off = self._gt_arrays(targets, dev)
             anchors_t = _stack_anchors(anchors)
+            if cls_levels[0].is_cuda and self.fuses_match(targets):
+                ahead = max([int(t["boxes"].reshape(-1, 4).shape[0]) for t in targets] or [0])      # (an int: see the Function)
         out = _FusedDenseHeadLossLevels.apply(anchors_t, gt_boxes, gt_labels, gt_off, self._params(),
                                               IOU_THRESHOLDS_FOREGROUND, IOU_THRESHOLDS_BACKGROUND, len(cls_levels), ahead,
                                               *cls_levels, *box_levels)

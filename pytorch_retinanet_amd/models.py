@@ -134,8 +134,8 @@ class Retinanet(nn.Module):
         # hipGraph: a graph with a forked branch costs hipGraphLaunch 20 ms of host time per replay on ROCm 7.0 (0.4 ms for
         # the linear graph of the same step, bench.py host_enqueue_ms_per_step) -- 25 us of GPU time are not worth that.
         ahead = None
-        if batch.is_cuda and not torch.cuda.is_current_stream_capturing():
-            ahead = self.retinanet_head.losses.match_ahead(targets, anchors)
+        if batch.is_cuda and not torch.cuda.is_current_stream_capturing() and not self.retinanet_head.losses.fuses_match(targets):
+            ahead = self.retinanet_head.losses.match_ahead(targets, anchors)      # (<= 64 GT per image: K2 runs inside K3, no launch at all)
         # same losses as compute_loss(targets, retinanet_head(feature_maps), anchors), but the loss kernel
         # reads the five per-level conv outputs in place instead of their torch.cat (layers.py:195, :259)
         outputs = self.retinanet_head.forward_levels(feature_maps)

@@ -262,6 +262,104 @@ def loss_fwd_bwd_levels(cls_levels: Sequence[Tensor], box_levels: Sequence[Tenso
     return out, gcls, gbox
 
 
+# ---- K2 + K3 in one launch -------------------------------------------------------------------------------------------------
+# State words of rn_loss_match_fwd_bwd_levels (grid-barrier counter + per-image foreground counters): zero-filled ONCE, left
+# zero-filled by every completed call, never shared by two streams (one buffer per device and stream).  A hipGraph capture gets
+# its own buffer, allocated BEFORE the capture begins (``new_match_state`` / ``use_match_state``: a buffer allocated inside the
+# capture would come with a zero-fill node that replays every step).
+MATCH_STATE_IMAGES = 4096
+RN_EUNSUPPORTED = -4
+_MATCH_STATE = {}
+_MATCH_STATE_OVERRIDE = None
+
+
+def new_match_state(dev: torch.device) -> Tensor:
+    return torch.zeros((16 + MATCH_STATE_IMAGES,), dtype=torch.int32, device=dev)
+
+
+class use_match_state:
+    "``with use_match_state(buf):`` -- fused loss calls on ``buf.device`` inside the block use ``buf`` (graph capture)."
+
+    def __init__(self, buf: Optional[Tensor]):
+        self.buf = buf
+
+    def __enter__(self):
+        global _MATCH_STATE_OVERRIDE
+        self.prev, _MATCH_STATE_OVERRIDE = _MATCH_STATE_OVERRIDE, self.buf
+        return self
+
+    def __exit__(self, *exc):
+        global _MATCH_STATE_OVERRIDE
+        _MATCH_STATE_OVERRIDE = self.prev
+        return False
+
+
+def _match_state(dev: torch.device) -> Tensor:
+    if _MATCH_STATE_OVERRIDE is not None and _MATCH_STATE_OVERRIDE.device == dev:
+        return _MATCH_STATE_OVERRIDE
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    st = _MATCH_STATE.get(key)
+    if st is None:
+        st = _MATCH_STATE[key] = new_match_state(dev)
+    return st
+
+
+def loss_match_fwd_bwd_levels(cls_levels: Sequence[Tensor], box_levels: Sequence[Tensor], anchors: Tensor, gt_boxes: Tensor,
+                              gt_labels: Tensor, gt_off: Tensor, max_gt: int, fg_thr: float, bg_thr: float, params: RnLossParams,
+                              want_grad: bool = True, want_matches: bool = False):
+    """K2 + K3 in ONE launch (``rn_loss_match_fwd_bwd_levels``): the matcher runs in the loss kernel's prologue, ``matches`` is
+    written only when ``want_matches``.  -> (loss f32[2], [grad_cls_l], [grad_box_l], num_fg i32[B], matches or None), or
+    ``None`` when the library declines the shape (more than 64 GT boxes in an image, ranges that do not fit its lists): the
+    caller then runs ``iou_match`` + ``loss_fwd_bwd_levels``.  ``max_gt``: the largest per-image GT count (host-known)."""
+    L = len(cls_levels)
+    if L == 0 or L > _lib.RN_MAX_LEVELS or len(box_levels) != L:
+        raise ValueError("need 1..8 levels of (cls, box) outputs")
+    dev = _need_dev(*cls_levels, *box_levels, anchors, gt_boxes, gt_labels, gt_off)
+    if not fg_thr > bg_thr:
+        raise AssertionError("match_thr must be greater than back_thr")   # box_utils.py:66
+    B, _, K = cls_levels[0].shape
+    if max_gt > 64 or B > MATCH_STATE_IMAGES:
+        return None
+    dt = cls_levels[0].dtype
+    cls_levels = [_c(c) for c in cls_levels]
+    box_levels = [_c(b if b.dtype == dt else b.to(dt)) for b in box_levels]
+    counts = [int(c.shape[1]) for c in cls_levels]
+    for c, b in zip(cls_levels, box_levels):
+        if c.dim() != 3 or b.shape != (B, c.shape[1], 4) or c.shape[0] != B or c.shape[2] != K or c.dtype != dt:
+            raise ValueError(f"bad level shapes {tuple(c.shape)} / {tuple(b.shape)}")
+    A = sum(counts)
+    anchors, bstride = _anchor_args(anchors, B, A)
+    gt_boxes = _c(gt_boxes.float()).reshape(-1, 4)
+    gt_labels = _c(gt_labels.to(torch.int64)).reshape(-1)
+    out = torch.empty((2,), dtype=torch.float32, device=dev)
+    gcls = [torch.empty_like(c) for c in cls_levels] if want_grad else None
+    gbox = [torch.empty_like(b) for b in box_levels] if want_grad else None
+    num_fg = torch.empty((B,), dtype=torch.int32, device=dev)
+    matches = torch.empty((B, A), dtype=torch.int64, device=dev) if want_matches else None
+    ws_bytes = lib.rn_loss_workspace_bytes(B, A, K)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    state = _match_state(dev)
+    arr = lambda ts: (C.c_void_p * L)(*[t.data_ptr() for t in ts])
+    k0 = k1 = None
+    if _TIMERS is not None:
+        k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k0.record(torch.cuda.current_stream(dev)); k1.record(torch.cuda.current_stream(dev))      # creates the handles
+    with torch.cuda.device(dev), _timed("loss_fwd_bwd" if want_grad else "loss_fwd", dev):
+        rc = lib.rn_loss_match_fwd_bwd_levels(arr(cls_levels), arr(box_levels), (C.c_int64 * L)(*counts), L, _dtype_code(cls_levels[0]),
+                                              B, K, _ptr(anchors), bstride, _ptr(gt_boxes), _ptr(gt_labels), _ptr(gt_off), int(max_gt),
+                                              fg_thr, bg_thr, _ptr(matches), _ptr(num_fg), C.byref(params), _ptr(out),
+                                              arr(gcls) if want_grad else None, arr(gbox) if want_grad else None, _ptr(ws), ws_bytes,
+                                              _ptr(state), state.numel() * 4, _stream(dev), k0.cuda_event if k0 else None,
+                                              k1.cuda_event if k1 else None)
+        if rc == RN_EUNSUPPORTED:
+            return None
+        check(rc, "rn_loss_match_fwd_bwd_levels")
+    if k0 is not None:
+        _TIMERS.setdefault("loss_stream_kernel" if want_grad else "loss_stream_kernel_fwd", []).append((k0, k1))
+        _TIMERS.setdefault("loss_stream_kernel_fused_match", []).append((k0, k1))
+    return out, gcls, gbox, num_fg, matches
+
+
 def scale_inplace(t: Tensor, scale: Tensor) -> Tensor:
     """t *= scale (device scalar, f32); a no-op on the device when scale == 1."""
     dev = _need_dev(t, scale)

@@ -97,6 +97,30 @@ def bench_k3(reps, dtype, B=8, want_grad=True, T=8):
            {"num_fg_per_image": int(nfg.float().mean()), "ignored_rows_per_image": int((m == -2).sum() // B)})
 
 
+def bench_k3_fused(reps, dtype, B=8, T=8):
+    "K2 inside K3 (rn_loss_match_fwd_bwd_levels, one launch) next to K2 + K3 (two launches + the num_fg memset) on the same data."
+    A, K = 201600, 90
+    rng = np.random.default_rng(0)
+    anc = anchors_for(800, 1344)
+    gt, gl, off = gts(rng, B, T, 800, 1333)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    cls = (torch.randn((B, A, K), device=DEV, generator=g) - 4.6).to(dtype)
+    box = (torch.randn((B, A, 4), device=DEV, generator=g) * 0.1).to(dtype)
+    p = ops.make_loss_params(0.25, 2.0, 0.1)
+    s = cls.element_size()
+    nbytes = B * (2 * (A * K * s + A * 4 * s) + A * 8 + T * 24)
+
+    def two():
+        m, nfg, sp = ops.iou_match(anc, gt, off, B, 0.5, 0.4, want_special=True)
+        return ops.loss_fwd_bwd_levels([cls], [box], anc, gt, gl, off, m, nfg, p, True, special=sp)
+    ms2 = timeit(two, reps)
+    report(f"K2 + K3 two launches {str(dtype).split('.')[-1]} B={B} A={A} K={K} T={T}", ms2, nbytes)
+    ms1 = timeit(lambda: ops.loss_match_fwd_bwd_levels([cls], [box], anc, gt, gl, off, T, 0.5, 0.4, p, True), reps)
+    report(f"K2 inside K3 one launch {str(dtype).split('.')[-1]} B={B} A={A} K={K} T={T}", ms1, nbytes)
+    msm = timeit(lambda: ops.loss_match_fwd_bwd_levels([cls], [box], anc, gt, gl, off, T, 0.5, 0.4, p, True, want_matches=True), reps)
+    report(f"K2 inside K3 one launch + matches written {str(dtype).split('.')[-1]} T={T}", msm, nbytes)
+
+
 def bench_detect(reps, mean, std, tag, B=16):
     A, K = 338454, 90
     anc = anchors_for(1344, 1344)
@@ -153,6 +177,11 @@ def main():
             bench_k3(reps, torch.float16, T=500)
         elif w == "k3f32":
             bench_k3(reps, torch.float32)
+        elif w == "k3fused8":
+            bench_k3_fused(reps, torch.bfloat16, T=8)
+        elif w == "k3fused":
+            for T in (0, 8, 32, 64):
+                bench_k3_fused(reps, torch.bfloat16, T=T)
         elif w == "k3fwd":
             bench_k3(reps, torch.bfloat16, want_grad=False)
         elif w == "detect":
