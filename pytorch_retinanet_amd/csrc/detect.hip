@@ -419,7 +419,16 @@ __global__ __launch_bounds__(SEG_THREADS) void seg_count_kernel(const SegArgs a)
         rn::f32x4 an[SEG_UNROLL];
         int64_t slot[SEG_UNROLL];
 #pragma unroll
-        for (int u = 0; u < SEG_UNROLL; ++u) { slot[u] = seg_slot_of(a, s_shard, min(i0 + u * SEG_THREADS + t, sl.hi - 1)); key[u] = cand[slot[u]]; }
+        for (int u = 0; u < SEG_UNROLL; ++u) {
+            slot[u] = seg_slot_of(a, s_shard, min(i0 + u * SEG_THREADS + t, sl.hi - 1));
+            key[u] = cand[slot[u]];
+            // Lanes past the slice re-read its LAST candidate (clamped index) only to keep the loads below unconditional -- but the
+            // lane that OWNS that candidate may belong to another wave of this workgroup, which may already have marked it dead
+            // (DEAD_KEY: "anchor" 2^32 / K) by the time this wave loads it: the delta / anchor loads below then ran 760 MB past their
+            // tensors.  Round 4, found by the end-to-end predict line on a random-init R101 (half of all candidates dead): a lane
+            // without a candidate of its own loads anchor 0.
+            if (i0 + u * SEG_THREADS + t >= sl.hi) key[u] = 0;
+        }
 #pragma unroll
         for (int u = 0; u < SEG_UNROLL; ++u) {
             const uint32_t ak = (uint32_t)key[u];
@@ -845,6 +854,9 @@ RN_API int rn_detect_levels(const void *const *cls_levels, const void *const *bo
     for (int l = 0; l < L; ++l)
         if (!rn::aligned(cls_levels[l], 16) || !rn::aligned(box_levels[l], dtype == RN_F32 ? 16 : 8)) return RN_EALIGN;
     hipStream_t st = (hipStream_t)stream;
+    // RN_DETECT_DEBUG=1: synchronise after every stage and name it on stderr (which kernel of the chain raised a fault)
+    static const bool dbg = getenv("RN_DETECT_DEBUG") != nullptr;
+    auto stage = [&](const char *name) { if (dbg) { const hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[rn_detect] %s: %s\n", name, hipGetErrorString(e)); } };
     DetectWs w = carve(workspace, B, A, K, C);
     const RegW rw = {{params->reg_w[0], params->reg_w[1], params->reg_w[2], params->reg_w[3]}};
 
@@ -864,6 +876,12 @@ RN_API int rn_detect_levels(const void *const *cls_levels, const void *const *bo
         voff += lv.nvec;
     }
     sa.total_vec = voff;
+    if (dbg) {
+        fprintf(stderr, "[rn_detect] B %d A %lld K %d C %lld ws %p..%p boxes %p cand %p seg %p sbox %p supp %p cand_count %p kept %p seg_len %p seg_start %p hist %p anchors %p hw %p\n",
+                B, (long long)A, K, (long long)C, workspace, (void *)((char *)workspace + w.total), (void *)w.boxes, (void *)w.cand, (void *)w.seg, (void *)w.sbox,
+                (void *)w.supp, (void *)w.cand_count, (void *)w.kept_count, (void *)w.seg_len, (void *)w.seg_start, (void *)w.hist, (const void *)anchors, (const void *)image_hw);
+        for (int l = 0; l < L; ++l) fprintf(stderr, "[rn_detect]   level %d cls %p box %p A_l %lld\n", l, cls_levels[l], box_levels[l], (long long)level_anchors[l]);
+    }
     RN_HIP(hipMemsetAsync(w.cand_count, 0, w.zero_bytes, st));
 
     for (int l = L; l < RN_MAX_LEVELS; ++l) fa.lv[l] = fa.lv[L - 1];
@@ -911,16 +929,18 @@ RN_API int rn_detect_levels(const void *const *cls_levels, const void *const *bo
         default: return RN_EINVAL;
     }
     RN_LAUNCH_CHECK();
+    stage("score_scan");
     {
         static_assert(SEG_GROUPS == 16, "carve() sizes the class histograms for 16 workgroups per image");
         const dim3 fg(SEG_GROUPS, (unsigned)B), fb(SEG_THREADS);
         switch (dtype) {
-            case RN_F32: hipLaunchKernelGGL((seg_count_kernel<RN_F32>), fg, fb, 0, st, fa); hipLaunchKernelGGL((seg_scatter_kernel<RN_F32>), fg, fb, 0, st, fa); break;
-            case RN_BF16: hipLaunchKernelGGL((seg_count_kernel<RN_BF16>), fg, fb, 0, st, fa); hipLaunchKernelGGL((seg_scatter_kernel<RN_BF16>), fg, fb, 0, st, fa); break;
-            default: hipLaunchKernelGGL((seg_count_kernel<RN_F16>), fg, fb, 0, st, fa); hipLaunchKernelGGL((seg_scatter_kernel<RN_F16>), fg, fb, 0, st, fa); break;
+            case RN_F32: hipLaunchKernelGGL((seg_count_kernel<RN_F32>), fg, fb, 0, st, fa); stage("seg_count"); hipLaunchKernelGGL((seg_scatter_kernel<RN_F32>), fg, fb, 0, st, fa); break;
+            case RN_BF16: hipLaunchKernelGGL((seg_count_kernel<RN_BF16>), fg, fb, 0, st, fa); stage("seg_count"); hipLaunchKernelGGL((seg_scatter_kernel<RN_BF16>), fg, fb, 0, st, fa); break;
+            default: hipLaunchKernelGGL((seg_count_kernel<RN_F16>), fg, fb, 0, st, fa); stage("seg_count"); hipLaunchKernelGGL((seg_scatter_kernel<RN_F16>), fg, fb, 0, st, fa); break;
         }
         RN_LAUNCH_CHECK();
     }
+    stage("seg_scatter");
     rn::NmsLaunch na;
     na.keys = w.seg; na.kept = w.cand; na.keep_idx = nullptr; na.boxes = w.boxes;
     na.seg_start = w.seg_start; na.seg_len = w.seg_len; na.kept_count = w.kept_count;
@@ -928,9 +948,11 @@ RN_API int rn_detect_levels(const void *const *cls_levels, const void *const *bo
     na.S = B * K; na.box_mode = 1; na.K = K; na.A = A; na.iou_thr = params->nms_thr;
     rc = rn::launch_nms(na, st);
     if (rc != RN_OK) return rc;
+    stage("nms");
     hipLaunchKernelGGL(topk_kernel, dim3((unsigned)B), dim3(TOPK_THREADS), 0, st, w.cand, w.seg_start, w.kept_count, w.boxes,
                        K, A, params->max_det, (rn::f32x4 *)out_boxes, out_scores, out_labels, out_count);
     RN_LAUNCH_CHECK();
+    stage("topk");
     return RN_OK;
 }
 

@@ -198,7 +198,8 @@ __device__ __forceinline__ float image_gmul(const LossArgs &a, const int b)
 // plain background (positive element of a matched row, whole ignored rows) and emits the box
 // gradient / regression term of the rows whose first element it owns.  Both phases write from one
 // wave, so program order gives the right final value without any cross-wave ordering.
-constexpr int LIST_CAP = 320;       // rows of a wave's range whose repair goes through the LDS lists (5 chunks of 64; 273 at the train shape)
+constexpr int LIST_CAP_PLAIN = 320;  // rows of a wave's range whose repair goes through the LDS lists (5 chunks of 64; 273 at the train shape)
+constexpr int LIST_CAP_FUSED = 384;  // fused matching: EVERY row of the range must fit (it runs at 5 workgroups per CU: 319 rows at the train shape)
 constexpr int IGN_U = 4;            // independent element loads per lane per round in the ignored-row repair
 
 template <int DT, bool GAMMA2, bool WRITE_GRAD, int PF, int NT, bool FUSED = false>
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
 {
     typedef rn::dt<DT> D;
     constexpr int VEC = D::VEC;
+    constexpr int LIST_CAP = FUSED ? LIST_CAP_FUSED : LIST_CAP_PLAIN;
     __shared__ float s_part[LOSS_WAVES][2];
     __shared__ signed char s_pmv[FUSED ? LOSS_WAVES : 1][FUSED ? LIST_CAP : 1];   // fused matching: match code of every row of the wave's range
     __shared__ unsigned short s_ign_row[LOSS_WAVES][LIST_CAP];   // ignored rows of the wave's range (offsets from its first row)
@@ -460,25 +462,59 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int total = n_ign * K;
-                for (int t0 = 0; t0 < total; t0 += RN_WAVE * IGN_U) {
-                    float xs[IGN_U], gms[IGN_U];
-                    bool ok[IGN_U];
+                if (VEC == 8 && !(K & 1)) {
+                    // 16-bit logits, even K: a row is K / 2 whole dwords (rows start on 4-byte boundaries, ranges on 16-byte ones), so the
+                    // repair moves two elements per memory instruction -- at 500 GT boxes per image a wave has ~14 ignored rows, and their
+                    // 2-byte loads / stores were as many memory instructions as a fifth of its stream (round 3: 196 us at T = 500)
+                    const int K2 = K >> 1, total2 = n_ign * K2;
+                    const uint32_t *const src32 = (const uint32_t *)lv.cls;
+                    for (int t0 = 0; t0 < total2; t0 += RN_WAVE * IGN_U) {
+                        uint32_t xs[IGN_U];
+                        float gms[IGN_U];
+                        bool ok[IGN_U];
 #pragma unroll
-                    for (int u = 0; u < IGN_U; ++u) {
-                        const int t = min(t0 + u * RN_WAVE + lane, total - 1);
-                        const int j = t / K, k = t - j * K;
-                        const int64_t e = (row_lo + s_ign_row[wave][j]) * K + k;
-                        gms[u] = s_ign_gm[wave][j];
-                        ok[u] = (t0 + u * RN_WAVE + lane < total) && e >= e_beg && e < e_end;
-                        xs[u] = D::ld(lv.cls, e);
+                        for (int u = 0; u < IGN_U; ++u) {
+                            const int t = min(t0 + u * RN_WAVE + lane, total2 - 1);
+                            const int j = t / K2, k2 = t - j * K2;
+                            const int64_t e = (row_lo + s_ign_row[wave][j]) * K + 2 * k2;
+                            gms[u] = s_ign_gm[wave][j];
+                            ok[u] = (t0 + u * RN_WAVE + lane < total2) && e >= e_beg && e < e_end;
+                            xs[u] = src32[e >> 1];
+                        }
+#pragma unroll
+                        for (int u = 0; u < IGN_U; ++u) {
+                            if (ok[u]) {
+                                const float x0 = DT == RN_BF16 ? __uint_as_float(xs[u] << 16) : rn::half_lo(xs[u]);
+                                const float x1 = DT == RN_BF16 ? __uint_as_float(xs[u] & 0xffff0000u) : rn::half_hi(xs[u]);
+                                float wb0, wb1, gbg;
+                                bg_elem<GAMMA2>(x0, a.p, wb0, gbg);
+                                bg_elem<GAMMA2>(x1, a.p, wb1, gbg);
+                                acc -= (double)wb0 * (double)gms[u];
+                                acc -= (double)wb1 * (double)gms[u];
+                            }
+                        }
                     }
+                } else {
+                    const int total = n_ign * K;
+                    for (int t0 = 0; t0 < total; t0 += RN_WAVE * IGN_U) {
+                        float xs[IGN_U], gms[IGN_U];
+                        bool ok[IGN_U];
 #pragma unroll
-                    for (int u = 0; u < IGN_U; ++u) {
-                        if (ok[u]) {
-                            float wb, gbg;
-                            bg_elem<GAMMA2>(xs[u], a.p, wb, gbg);
-                            acc -= (double)wb * (double)gms[u];
+                        for (int u = 0; u < IGN_U; ++u) {
+                            const int t = min(t0 + u * RN_WAVE + lane, total - 1);
+                            const int j = t / K, k = t - j * K;
+                            const int64_t e = (row_lo + s_ign_row[wave][j]) * K + k;
+                            gms[u] = s_ign_gm[wave][j];
+                            ok[u] = (t0 + u * RN_WAVE + lane < total) && e >= e_beg && e < e_end;
+                            xs[u] = D::ld(lv.cls, e);
+                        }
+#pragma unroll
+                        for (int u = 0; u < IGN_U; ++u) {
+                            if (ok[u]) {
+                                float wb, gbg;
+                                bg_elem<GAMMA2>(xs[u], a.p, wb, gbg);
+                                acc -= (double)wb * (double)gms[u];
+                            }
                         }
                     }
                 }
@@ -599,11 +635,20 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             for (int i = lane; i < n_pos; i += RN_WAVE) D::st(lv.gcls, e_beg + s_pos_off[wave][i], s_pos_val[wave][i]);
-            const int total = n_ign * K;
-            for (int t = lane; t < total; t += RN_WAVE) {
-                const int j = t / K, k = t - j * K;
-                const int64_t e = (row_lo + s_ign_row[wave][j]) * K + k;
-                if (e >= e_beg && e < e_end) D::st(lv.gcls, e, 0.0f);
+            if (VEC == 8 && !(K & 1)) {                                            // (two 16-bit zeros per store: see the read side)
+                const int K2 = K >> 1, total2 = n_ign * K2;
+                for (int t = lane; t < total2; t += RN_WAVE) {
+                    const int j = t / K2, k2 = t - j * K2;
+                    const int64_t e = (row_lo + s_ign_row[wave][j]) * K + 2 * k2;
+                    if (e >= e_beg && e < e_end) ((uint32_t *)lv.gcls)[e >> 1] = 0u;
+                }
+            } else {
+                const int total = n_ign * K;
+                for (int t = lane; t < total; t += RN_WAVE) {
+                    const int j = t / K, k = t - j * K;
+                    const int64_t e = (row_lo + s_ign_row[wave][j]) * K + k;
+                    if (e >= e_beg && e < e_end) D::st(lv.gcls, e, 0.0f);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -839,7 +884,7 @@ int launch_stream(StreamT stream_k, LossArgs &a, int vec, hipStream_t st, int *n
         // every workgroup must be resident (grid barrier), and the match codes of a wave's rows must fit its LDS list: a range of vpw
         // vectors (+ a ragged tail of < VEC elements per level) covers at most elements / K rows + 2 partial rows per level segment
         if (need > res) return RN_EUNSUPPORTED;
-        if ((vpw * vec + (int64_t)a.L * (vec - 1)) / a.K + 2 * (int64_t)a.L + 1 > LIST_CAP) return RN_EUNSUPPORTED;
+        if ((vpw * vec + (int64_t)a.L * (vec - 1)) / a.K + 2 * (int64_t)a.L + 1 > LIST_CAP_FUSED) return RN_EUNSUPPORTED;
     }
     if (g_prof.start) RN_HIP(hipEventRecord(g_prof.start, st));
     hipLaunchKernelGGL(stream_k, dim3((unsigned)need), dim3(LOSS_BLOCK), 0, st, a);

@@ -26,6 +26,18 @@ CASES = [
     ("step", "resnet18", "131", "173"),
     ("step", "resnet50", "333", "517"),
     ("step", "resnet18", "97", "400"),
+    # the dense-head kernels themselves (round 4: a bf16 predict at 2 x 1344 x 1344 faulted inside rn_detect_levels)
+    ("detect", "bf16", "2", "1344", "1344", "90"),
+    ("detect", "bf16", "16", "1344", "1344", "90"),
+    ("detect", "f16", "1", "1344", "1344", "90", "-7.0"),
+    ("detect", "bf16", "3", "352", "416", "7", "-3.0"),
+    ("detect", "f32", "2", "224", "160", "5", "-2.0"),
+    ("detect", "bf16", "1", "352", "416", "90", "0", "1000", "500"),     # exploding head outputs (half of the candidates dead): the seg_count race
+    ("detect", "bf16", "4", "1344", "1344", "90", "0", "1000", "500"),
+    ("loss", "bf16", "3", "800", "1344", "90", "8"),
+    ("loss", "f16", "2", "800", "1344", "90", "500"),
+    ("loss", "f32", "3", "224", "160", "5", "3"),
+    ("loss", "bf16", "4", "352", "416", "7", "40"),
 ]
 
 

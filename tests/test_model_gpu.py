@@ -163,6 +163,35 @@ def test_lightning_module_with_simple_trainer():
     assert len(outs) == 2 and all("detections" in o for o in outs)
 
 
+def test_simple_trainer_replays_the_captured_step():
+    """the training path itself (``SimpleTrainer.fit``) runs the step bench.py measures -- ``graph.CapturedTrainStep``:
+    two eager steps per input signature, then hipGraph replays; the weights move as in the eager trainer (same data, same seed)."""
+    import pytorch_retinanet_amd as P
+
+    def run(capture):
+        torch.manual_seed(7)
+        conf = P.load_hparams()
+        conf.model.update(backbone_kind="resnet18", pretrained=False, num_classes=5, min_size=128, max_size=160)
+        conf.dataset.kind = "synthetic"
+        conf.dataset.update(length=12, height=128, width=160, boxes_per_image=3)
+        conf.dataloader.train_bs = 2
+        conf.dataloader.valid_bs = 2
+        conf.dataloader.args.pin_memory = False
+        model = P.RetinaNetModel(conf)                     # (same seed: same weights and the same shuffled order in both runs)
+        trainer = P.SimpleTrainer(max_epochs=1, device=DEV, capture=capture)
+        steps = trainer.fit(model)
+        w = model.net.retinanet_head.classification_head.class_subnet_output.bias.detach().float().cpu()
+        return steps, trainer.captured_steps, w
+
+    steps, replays, w_graph = run(True)
+    assert steps == 6 and replays >= 3, (steps, replays)
+    steps_e, replays_e, w_eager = run(False)
+    assert steps_e == 6 and replays_e == 0
+    assert bool(torch.isfinite(w_graph).all())
+    # same trajectory up to the run-to-run noise of the bf16 conv stack (a captured step IS the eager step: tests/test_graph_gpu.py)
+    assert float((w_graph - w_eager).abs().max()) <= 5e-3 * max(1.0, float(w_eager.abs().max())), float((w_graph - w_eager).abs().max())
+
+
 def test_test_step_through_the_evaluator_equals_bbox_eval_on_the_oracles_detections(oracle_lib):
     """The evaluation path end to end (reference model.py:132-146: test_step -> CocoEvaluator.update -> test_epoch_end ->
     accumulate / summarize -> stats[0]) on GPU detections, against ``BBoxEval`` fed the CPU oracle's detections

@@ -4,7 +4,8 @@
 mapping and the GPU raises a memory access fault (the process aborts) instead of silently touching a neighbour.  Found this way:
 ``stem_fwd_kernel`` -- a wave of the last workgroup that owns no tile loaded at a tile index past the last image.
 
-usage: guard_probe.py stem B H W | w3 N H W C | dense | pw | pool | bottleneck | step KIND MIN MAX      (driven by tests/test_guard_gpu.py)
+usage: guard_probe.py stem B H W | w3 N H W C | dense | pw | pool | bottleneck | step KIND MIN MAX | detect DT B H W K [MEAN] |
+       loss DT B H W K T                                                                    (driven by tests/test_guard_gpu.py)
 Prints one "ok ..." line per case; a fault kills the process (non-zero exit status, no "ok" line for the case)."""
 import os
 import sys
@@ -144,6 +145,74 @@ def main() -> None:
             net([torch.from_numpy(rng.random((3, lo - 1, hi - 2), dtype=np.float32)).to(DEV)])
         torch.cuda.synchronize()
         print("ok step", kind, lo, hi, flush=True)
+    elif which == "detect":
+        # K4-K7 (rn_detect_levels): every per-level logit / delta tensor, the anchors and the image sizes at the end of their own mappings
+        import numpy as np
+        import synth
+        from pytorch_retinanet_amd import ops
+        from pytorch_retinanet_amd.anchors import AnchorGenerator
+        dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[sys.argv[2]]
+        B, H, W, K = (int(v) for v in sys.argv[3:7])
+        mean = float(sys.argv[7]) if len(sys.argv) > 7 else -4.6
+        std, dstd = (float(sys.argv[8]), float(sys.argv[9])) if len(sys.argv) > 9 else (1.2, 0.1)
+        levels = synth.levels_for(H, W)
+        ag = AnchorGenerator().to(DEV)
+        anc_src = ops.anchors_emit(levels, list(ag.cell_anchors), 0.0)
+        anc = raw_at_end(anc_src.numel() * 4).view(torch.float32).view(-1, 4)
+        anc.copy_(anc_src)
+        g = torch.Generator(device=DEV).manual_seed(1)
+        cl, bl = [], []
+        for (h, w, _) in levels:
+            n = h * w * 9
+            c = raw_at_end(B * n * K * dt.itemsize).view(dt).view(B, n, K)
+            c.copy_((torch.randn((B, n, K), device=DEV, generator=g) * std + mean).to(dt))
+            d = raw_at_end(B * n * 4 * dt.itemsize).view(dt).view(B, n, 4)
+            d.copy_((torch.randn((B, n, 4), device=DEV, generator=g) * dstd).to(dt))
+            cl.append(c); bl.append(d)
+        dets = ops.detect_levels(cl, bl, anc, [(H - 5, W - 3)] * B, 0.05, 1e-2, 0.5, 100)
+        torch.cuda.synchronize()
+        print("ok detect", sys.argv[2], B, H, W, K, mean, [int(d["scores"].numel()) for d in dets], flush=True)
+    elif which == "loss":
+        # K2 + K3 (rn_iou_match_special + rn_loss_fwd_bwd_levels_ex, and the one-launch form): per-level logits / deltas, anchors, GT
+        # boxes / labels / offsets at the end of their own mappings; ragged GT counts incl. an image without GT
+        import numpy as np
+        import synth
+        from pytorch_retinanet_amd import ops
+        from pytorch_retinanet_amd.anchors import AnchorGenerator
+        dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[sys.argv[2]]
+        B, H, W, K, T = (int(v) for v in sys.argv[3:8])
+        levels = synth.levels_for(H, W)
+        ag = AnchorGenerator().to(DEV)
+        anc_src = ops.anchors_emit(levels, list(ag.cell_anchors), 0.0)
+        anc = raw_at_end(anc_src.numel() * 4).view(torch.float32).view(-1, 4)
+        anc.copy_(anc_src)
+        rng = np.random.default_rng(2)
+        Ts = [T if i != 1 else 0 for i in range(B)]
+        gtb, gtl = zip(*[synth.gt_boxes(rng, t, H, W, num_classes=K, wh_lo=20.0, wh_hi=min(H, W) * 0.6) for t in Ts])
+        gb = np.concatenate(gtb).astype(np.float32); gl = np.concatenate(gtl).astype(np.int64)
+        gt_t = raw_at_end(max(gb.size, 4) * 4).view(torch.float32)[:gb.size].view(-1, 4); gt_t.copy_(torch.from_numpy(gb))
+        gl_t = raw_at_end(max(gl.size, 1) * 8).view(torch.int64)[:gl.size]; gl_t.copy_(torch.from_numpy(gl))
+        off_src = ops.gt_offsets(Ts, DEV)
+        off = raw_at_end(off_src.numel() * 4).view(torch.int32); off.copy_(off_src)
+        g = torch.Generator(device=DEV).manual_seed(1)
+        cl, bl = [], []
+        for (h, w, _) in levels:
+            n = h * w * 9
+            c = raw_at_end(B * n * K * dt.itemsize).view(dt).view(B, n, K)
+            c.copy_((torch.randn((B, n, K), device=DEV, generator=g) - 4.6).to(dt))
+            d = raw_at_end(B * n * 4 * dt.itemsize).view(dt).view(B, n, 4)
+            d.copy_((torch.randn((B, n, 4), device=DEV, generator=g) * 0.1).to(dt))
+            cl.append(c); bl.append(d)
+        p = ops.make_loss_params(0.25, 2.0, 0.1)
+        m, nfg, sp = ops.iou_match(anc, gt_t, off, B, 0.5, 0.4, want_special=True)
+        loss, gc, gbx = ops.loss_fwd_bwd_levels(cl, bl, anc, gt_t, gl_t, off, m, nfg, p, True, special=sp)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(loss).all())
+        if max(Ts) <= 64:
+            out = ops.loss_match_fwd_bwd_levels(cl, bl, anc, gt_t, gl_t, off, max(Ts), 0.5, 0.4, p, True, want_matches=True)
+            torch.cuda.synchronize()
+            assert out is None or (torch.equal(out[0], loss) and torch.equal(out[4], m))
+        print("ok loss", sys.argv[2], B, H, W, K, T, [float(x) for x in loss], flush=True)
     else:
         raise SystemExit(f"unknown probe {which!r}")
 
