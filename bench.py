@@ -51,7 +51,11 @@ def parse():
     ap.add_argument("--torch-sgd", action="store_true", help="fp32 parameters + torch.optim.SGD instead of fp32 masters + bf16 conv weights (optim.MasterSGD); same arithmetic")
     ap.add_argument("--cpu-baseline-reps", type=int, default=30, help="batches of the dense-head workload timed on the host (about 10 s of CPU work)")
     ap.add_argument("--no-detect", action="store_true", help="skip the inference-chain (decode + NMS + top-k) roofline line (BASELINE configs[3] shape)")
-    ap.add_argument("--ddp-graph", action="store_true", help="capture the step in a hipGraph also when gradients are exchanged (default there: eager steps -- the captured step with RCCL's forked stream branches replays 3.5 %% slower than eager enqueueing, DESIGN.md section 6)")
+    ap.add_argument("--ddp-mode", default="segmented", choices=["segmented", "eager", "onegraph"],
+                    help="how the step is launched when gradients are exchanged: segmented (default) = four linear hipGraphs with the buckets' "
+                         "all-reduces issued eagerly between the replays (graph.CapturedTrainStep); eager = every kernel enqueued from Python; "
+                         "onegraph = one capture incl. the collectives (forked stream branches: replays slower than eager on ROCm 7, DESIGN.md section 6)")
+    ap.add_argument("--ddp-graph", action="store_true", help="same as --ddp-mode onegraph (round-3 spelling)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel of every step from Python instead of replaying the captured hipGraph of the step (graph.CapturedTrainStep)")
     ap.add_argument("--mode", default="train", choices=["train", "predict"], help="predict: only the BASELINE configs[3] end-to-end inference line "
                     "(R101-FPN, 16 x 3x1333x1333, eval-mode folded BN, conv stack + decode + NMS + top-100 + rescale) as the JSON line")
@@ -507,18 +511,21 @@ def main():
         from pytorch_retinanet_amd.optim import MasterSGD, use_bf16_conv_weights
         use_bf16_conv_weights(net)
         optimizer = MasterSGD(net.parameters(), lr=1e-3, weight_decay=1e-3, momentum=0.9)
-    ddp = P.BucketedGradAllReduce(net) if (world > 1 or args.force_ddp) else None
+    from pytorch_retinanet_amd.graph import CapturedTrainStep, retinanet_stage_of
+    ddp_mode = "onegraph" if args.ddp_graph else args.ddp_mode
+    ddp = P.BucketedGradAllReduce(net, stage_of=retinanet_stage_of if ddp_mode == "segmented" else None) if (world > 1 or args.force_ddp) else None
     images, targets = synth_batch(args.batch, args.gt, seed=rank, device=device)
 
     # One step = graph.CapturedTrainStep: zero_grad -> autocast forward -> backward -> (bucketed all-reduce) -> SGD.  The first
     # two calls run eagerly (MIOpen find, caches, optimizer state), the third captures the step in a hipGraph, and every
     # later call is one graph replay (--no-graph: every call enqueues its ~700 kernels from Python).
-    from pytorch_retinanet_amd.graph import CapturedTrainStep
-    # With a gradient exchange the step is NOT captured by default: torch's process group runs the all-reduces on its own stream, the
-    # capture turns that into forked graph branches, and ROCm replays such a graph slower than Python enqueues the same kernels
-    # (world 1, same box: 279 captured / 289 eager / 302 without the exchange); eager keeps the overlap of exchange and backward.
-    use_graph = not args.no_graph and (ddp is None or args.ddp_graph)
-    stepper = CapturedTrainStep(net, optimizer, ddp, amp_dtype=torch.bfloat16, eager_steps=2, enabled=use_graph)
+    # With a gradient exchange the step is captured as FOUR linear graphs (forward + head / FPN backward | layer4, layer3 | layer2 .. stem |
+    # optimizer) and the buckets' all-reduces are issued eagerly on the process group's stream between the replays: ONE capture would
+    # turn the collectives into forked graph branches, which ROCm replays slower than Python enqueues the same kernels (world 1, same
+    # box, round 3: 279 captured / 289 eager / 302 without the exchange), and eager steps cost ~20 ms of host time each.
+    use_graph = not args.no_graph and (ddp is None or ddp_mode != "eager")
+    stepper = CapturedTrainStep(net, optimizer, ddp, amp_dtype=torch.bfloat16, eager_steps=2, enabled=use_graph,
+                                segmented=(ddp is not None and ddp_mode == "segmented"))
     n_warm = max(args.warmup, 3)               # (MIOpen's find, the caches and -- when capturing -- the capture itself stay out of the timed region)
     for _ in range(n_warm):
         stepper(images, targets)
@@ -527,13 +534,16 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     clocks = None
-    if rank == 0:
+    if rank == 0 and not os.environ.get("RN_BENCH_NO_GPU_STATE"):
         pr = torch.cuda.get_device_properties(local_rank)
         pci = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
         clocks = ClockSampler(pci).start()
     t0 = time.perf_counter()
+    trace = [] if os.environ.get("RN_BENCH_TRACE_LOSS") else None
     for _ in range(args.steps):
         out = stepper(images, targets)
+        if trace is not None:
+            trace.append(out["loss"].clone())
     host_enqueue = time.perf_counter() - t0      # (diagnostic: the host is done enqueueing here; the GPU usually is not)
     torch.cuda.synchronize()
     if world > 1:
@@ -542,6 +552,8 @@ def main():
     elapsed = time.perf_counter() - t0
     gpu_state = clocks.stop() if clocks else None
     final_loss = float(out["loss"])
+    if trace is not None:
+        print("loss trace:", [round(float(x), 4) for x in trace], file=sys.stderr)
     graph_replays = stepper.replays
     # per-kernel figures: the same step, enqueued eagerly with a pair of HIP events around every hand-written kernel (events
     # recorded inside a captured graph are dependency markers, not timestamps), right after the timed region, same data
@@ -625,7 +637,9 @@ def main():
             "roofline": roof, "roofline_other": roof_other, "conv_mfma": conv_mfma,
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 0,
             "gpu_state_during_timed_region": gpu_state,
-            "step_launch": {"mode": "hipGraph replay" if graph_replays else "eager", "graph_replays_in_run": graph_replays,
+            "step_launch": {"mode": ("4 linear hipGraph segments + eager all-reduces between them" if stepper.segmented else "hipGraph replay") if graph_replays else "eager",
+                            "graph_replays_in_run": graph_replays, "buckets": ddp.num_buckets if ddp is not None else 0,
+                            "graph_nodes": dict(__import__("pytorch_retinanet_amd.graph", fromlist=["LAST_CENSUS"]).LAST_CENSUS),
                             "per_kernel_events": f"{timing_steps} eager steps after the timed region"},
         }
         if world == 1 and not args.no_cpu_baseline:

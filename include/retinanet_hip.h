@@ -68,6 +68,17 @@ typedef struct rn_detect_params {
 int rn_version(void);
 const char *rn_status_string(int status);
 
+/* Node census of a captured hipGraph (`graph`: hipGraph_t): counts[0] kernel, [1] memset, [2] memcpy, [3] other node types.
+ * Why it exists: memset NODES of a replayed hipGraph misbehave on ROCm 7.0 -- after the process has synchronised with the device
+ * and enqueued other blit work (fills, small copies) a replayed memset writes garbage (round 4: a 32-byte hipMemsetAsync in front
+ * of the matcher scaled every later loss by 1 / garbage).  This library issues no hipMemsetAsync; a host that captures its calls
+ * together with other work (MIOpen's split-K weight gradients clear their output with one at some shapes) can check its graph. */
+int rn_hipgraph_node_census(void *graph, int64_t counts[4]);
+/* The repair: every memset node of `graph` (not yet instantiated) is replaced by a kernel node with the same destination, value,
+ * element size, width, height and pitch, the same dependencies and the same dependents; *replaced (nullable) = their number.
+ * graph.CapturedTrainStep calls it between capture_end and instantiate (torch.cuda.CUDAGraph(keep_graph=True)). */
+int rn_hipgraph_replace_memset_nodes(void *graph, int64_t *replaced);
+
 /* ---- K1 anchors_emit --------------------------------------------------------
  * Replaces AnchorGenerator._compute_grid_offsets / grid_anchors / forward's cat,
  * retinanet/anchors.py:151-170, :172-197, :228.  Bit-exact with the CPU path.

@@ -52,6 +52,8 @@ _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_si
 # name -> (restype, argtypes); mirrors include/retinanet_hip.h one to one
 SIGNATURES = {
     "rn_version": (C.c_int, []),
+    "rn_hipgraph_node_census": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "rn_hipgraph_replace_memset_nodes": (C.c_int, [_vp, C.POINTER(_i64)]),
     "rn_status_string": (C.c_char_p, [C.c_int]),
     "rn_anchors_count": (_i64, [C.POINTER(RnLevel), C.c_int]),
     "rn_anchors_emit": (C.c_int, [C.POINTER(RnLevel), C.c_int, C.POINTER(_vp), C.c_double, _vp, _vp]),

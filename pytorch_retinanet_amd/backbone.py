@@ -243,6 +243,11 @@ class ResNetBackbone(nn.Module):
         stack += [block(self.inplanes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*stack)
 
+    # Stage cuts (graph.CapturedTrainStep with a gradient exchange): C3 / C4 / C5 are replaced by detached leaves, so that the backward
+    # pass can run as separate autograd calls -- head + FPN | layer4, layer3 | layer2 .. stem -- each captured in its own linear hipGraph,
+    # with the finished buckets' all-reduces issued eagerly between the replays (``StageCuts.pairs``: (producer output, leaf)).
+    stage_cuts: Optional["StageCuts"] = None
+
     def _forward_impl(self, x: Tensor) -> Dict[str, Tensor]:
         if pwconv.stem_fusable(self.conv1, self.bn1, x):     # training, bf16: the MFMA stem kernel with bn1's statistics in its epilogue
             x = pwconv.stem(self.conv1, self.bn1, x, pool=self.maxpool)      # ... and bn1's apply + ReLU inside the max pooling
@@ -250,13 +255,39 @@ class ResNetBackbone(nn.Module):
             x = self.maxpool(conv_bn(self.conv1, self.bn1, x, relu=True))
         x = self.layer1(x)
         # C3 / C4 feed the next layer's conv1 + stride-2 downsample conv and an FPN lateral: their data gradients join in one GEMM
-        c3 = pwconv.share_gradients(self.layer2(x))
-        c4 = pwconv.share_gradients(self.layer3(c3))
+        cuts = self.stage_cuts if (self.stage_cuts is not None and torch.is_grad_enabled()) else None
+        c3 = self.layer2(x)
+        if cuts is not None:
+            c3 = cuts.cut(c3)
+        c3 = pwconv.share_gradients(c3)       # (across a cut the consumers run in different backward passes: donors notice and return their own)
+        c4 = self.layer3(c3)
+        if cuts is not None:
+            c4 = cuts.cut(c4)
+        c4 = pwconv.share_gradients(c4)
         c5 = self.layer4(c4)
+        if cuts is not None:
+            c5 = cuts.cut(c5)
         return {"layer_2": c3, "layer_3": c4, "layer_4": c5}
 
     def forward(self, x: Tensor) -> Dict[str, Tensor]:
         return self._forward_impl(x)
+
+
+class StageCuts:
+    """Collector of the cut points of one forward pass: ``cut(t)`` returns a detached leaf that stands in for ``t`` downstream."""
+
+    def __init__(self):
+        self.pairs: List[Tuple[Tensor, Tensor]] = []
+
+    def cut(self, t: Tensor) -> Tensor:
+        if not t.requires_grad:
+            return t
+        leaf = t.detach().requires_grad_(True)
+        self.pairs.append((t, leaf))
+        return leaf
+
+    def clear(self) -> None:
+        self.pairs = []
 
 
 _SPECS = {

@@ -435,7 +435,7 @@ class _Pack(torch.autograd.Function):
         out = torch.empty((canvas.sheets(N), f0.shape[1], canvas.H, canvas.W), dtype=f0.dtype, device=f0.device,
                           memory_format=torch.channels_last)
         if not _pack_native(canvas, feats, out, N, True):
-            out.zero_()
+            out.fill_(0)            # (a fill KERNEL: zero_() is a hipMemsetAsync, a memset node under capture -- layers._conv_own_bias)
             for l, s_, r, c, h, w in canvas.regions:
                 src = feats[l][s_::S]
                 if src.shape[0]:
@@ -486,7 +486,7 @@ def _scatter_levels(cv: "Canvas", grads, shape, dt, dev, n_images: int) -> Tenso
         lv = [gl if (gl.dtype == dt and _cl(gl)) else gl.to(dt).contiguous(memory_format=torch.channels_last) for gl in grads]
         if _pack_native(cv, lv, g, n_images, True):
             return g
-    g.zero_()
+    g.fill_(0)
     for l, s_, r, c, h, w in cv.regions:
         gl = grads[l]
         if gl is not None:
@@ -513,7 +513,7 @@ _ZEROS: Dict[int, Tensor] = {}
 def _zero_page(dev: torch.device) -> Tensor:
     z = _ZEROS.get(dev.index)
     if z is None:
-        z = _ZEROS[dev.index] = torch.zeros((256,), dtype=torch.uint8, device=dev)
+        z = _ZEROS[dev.index] = torch.empty((256,), dtype=torch.uint8, device=dev).fill_(0)
     return z
 
 
@@ -543,7 +543,7 @@ def _dgrad_weight(w: Tensor) -> Tensor:
               "rn_conv3x3_levels_dgrad_weight")
         return out
     wt = w.flip(2, 3).transpose(0, 1)                                   # [Cin, Cout, 3, 3]
-    out = torch.zeros((Cin, Kpad, 3, 3), dtype=w.dtype, device=w.device).contiguous(memory_format=torch.channels_last)
+    out = torch.empty((Cin, Kpad, 3, 3), dtype=w.dtype, device=w.device).fill_(0).contiguous(memory_format=torch.channels_last)
     e = Cout - Cout % 8
     out[:, :e] = wt[:, :e]
     if Cout % 8:
@@ -594,7 +594,7 @@ class _ClsOutputConv(torch.autograd.Function):
         gs = []
         for dy, (h, wd) in zip(dys, cv.shapes):
             if dy is None:
-                dy = torch.zeros((N, h * wd * Cout), dtype=x.dtype, device=dev)
+                dy = torch.empty((N, h * wd * Cout), dtype=x.dtype, device=dev).fill_(0)
             gs.append(dy.to(x.dtype).contiguous())
         lv = _layout(cv, N)
         real = N * sum(h * wd for h, wd in cv.shapes)
@@ -683,7 +683,7 @@ class _BoxOutputConv(torch.autograd.Function):
         gs = []
         for dy, (h, wd) in zip(dys, cv.shapes):
             if dy is None:
-                dy = torch.zeros((N, h * wd * Cout), dtype=x.dtype, device=dev)
+                dy = torch.empty((N, h * wd * Cout), dtype=x.dtype, device=dev).fill_(0)
             gs.append(dy.to(x.dtype).contiguous())
         dx = dw = db = None
         if ctx.needs_input_grad[0]:

@@ -774,6 +774,11 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const uint64_t *__re
     if (t == 0) out_count[b] = nout;
 }
 
+__global__ void zero_bytes4_kernel(uint32_t *__restrict__ p, const int64_t n)
+{
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0u;
+}
+
 size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct DetectWs {
@@ -882,7 +887,8 @@ RN_API int rn_detect_levels(const void *const *cls_levels, const void *const *bo
                 (void *)w.supp, (void *)w.cand_count, (void *)w.kept_count, (void *)w.seg_len, (void *)w.seg_start, (void *)w.hist, (const void *)anchors, (const void *)image_hw);
         for (int l = 0; l < L; ++l) fprintf(stderr, "[rn_detect]   level %d cls %p box %p A_l %lld\n", l, cls_levels[l], box_levels[l], (long long)level_anchors[l]);
     }
-    RN_HIP(hipMemsetAsync(w.cand_count, 0, w.zero_bytes, st));
+    hipLaunchKernelGGL(zero_bytes4_kernel, dim3(1), dim3(256), 0, st, (uint32_t *)w.cand_count, (int64_t)(w.zero_bytes / 4));   // (no hipMemsetAsync: match.hip, zero_i32_kernel)
+    RN_LAUNCH_CHECK();
 
     for (int l = L; l < RN_MAX_LEVELS; ++l) fa.lv[l] = fa.lv[L - 1];
     fa.anchors = (const rn::f32x4 *)anchors; fa.anchor_bstride4 = anchor_bstride / 4; fa.image_hw = image_hw; fa.rw = rw;

@@ -73,7 +73,7 @@ struct LossArgs {
     int32_t *nfg_acc;        // [B] foreground counts of this launch: zero on entry (the finalize kernel re-zeroes them), device-scope atomics
     unsigned *bar;           // [1] grid barrier arrival counter: zero on entry (the finalize kernel re-zeroes it)
     int64_t *matches_out;    // nullable: [B][A] match codes, written by the wave that owns a row's first element
-    int32_t dbg;             // development ablations (RN_K3_FUSED_DEBUG): 1 = no barrier, 2 = no matching pass, 4 = long poll backoff
+    int32_t dbg;             // development ablations (RN_K3_FUSED_DEBUG): 1 = no barrier, 2 = no matching pass, 4 = long poll backoff, 8 = ignored rows element by element
 };
 
 // ---- background element (t = 0) ------------------------------------------------------
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (VEC == 8 && !(K & 1)) {
+                if (VEC == 8 && !(K & 1) && !(a.dbg & 8)) {
                     // 16-bit logits, even K: a row is K / 2 whole dwords (rows start on 4-byte boundaries, ranges on 16-byte ones), so the
                     // repair moves two elements per memory instruction -- at 500 GT boxes per image a wave has ~14 ignored rows, and their
                     // 2-byte loads / stores were as many memory instructions as a fifth of its stream (round 3: 196 us at T = 500)
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             for (int i = lane; i < n_pos; i += RN_WAVE) D::st(lv.gcls, e_beg + s_pos_off[wave][i], s_pos_val[wave][i]);
-            if (VEC == 8 && !(K & 1)) {                                            // (two 16-bit zeros per store: see the read side)
+            if (VEC == 8 && !(K & 1) && !(a.dbg & 8)) {                                            // (two 16-bit zeros per store: see the read side)
                 const int K2 = K >> 1, total2 = n_ign * K2;
                 for (int t = lane; t < total2; t += RN_WAVE) {
                     const int j = t / K2, k2 = t - j * K2;

@@ -24,6 +24,8 @@
 // (area_t + area_a) - inter, IEEE divide, no FMA contraction (this file is
 // compiled with -ffp-contract=off), first index wins ties, NaN propagates as in
 // torch.max (first NaN wins, and a NaN max is neither < bg nor > fg -> -2).
+#include <cstdlib>
+
 #include "rn_common.hpp"
 #include "rn_match.hpp"
 
@@ -439,6 +441,19 @@ __global__ __launch_bounds__(FIN_BLOCK) void iou_match_finalize_kernel(
     }
 }
 
+// num_fg[0..B) = 0 as a KERNEL.  A hipMemsetAsync becomes a MEMSET NODE when the step is captured in a hipGraph, and on ROCm 7.0 the
+// memset nodes of a replayed graph write garbage once the process has synchronised with the device and enqueued other work (round 4:
+// every replay after the first torch.cuda.synchronize() scaled both losses by 1 / garbage -- num_fg; the same graph with this kernel
+// is exact; RN_DBG_MEMSET_NODE=1 restores the memset for the regression experiment).  The library issues no hipMemsetAsync at all.
+__global__ void zero_i32_kernel(int32_t *__restrict__ p, const int n)
+{
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
+}
+__global__ __launch_bounds__(256) void zero_u64_kernel(unsigned long long *__restrict__ p, const int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0ull;
+}
+
 }  // namespace
 
 RN_API int rn_iou_match(const float *anchors, int64_t anchor_bstride, const float *gt_boxes, const int32_t *gt_off,
@@ -466,7 +481,11 @@ RN_API int rn_iou_match_special(const float *anchors, int64_t anchor_bstride, co
     if (!(fg_thr > bg_thr)) return RN_ETHRESH;
     if (!rn::aligned(anchors, 16) || (gt_boxes && !rn::aligned(gt_boxes, 16)) || (anchor_bstride & 3)) return RN_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-    if (num_fg) RN_HIP(hipMemsetAsync(num_fg, 0, sizeof(int32_t) * (size_t)B, st));
+    if (num_fg) {
+        static const bool memset_node = getenv("RN_DBG_MEMSET_NODE") != nullptr;
+        if (memset_node) RN_HIP(hipMemsetAsync(num_fg, 0, sizeof(int32_t) * (size_t)B, st));
+        else { hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(64), 0, st, num_fg, B); RN_LAUNCH_CHECK(); }
+    }
     // The batch kernel needs host knowledge of sum(T) (gt_off lives on the device and this call never syncs):
     // callers that know it pass total_gt >= 0; -1 means unknown -> the general kernel.
     if (anchor_bstride == 0 && B <= 64 && total_gt >= 0 && total_gt <= BATCH_GT_MAX && total_gt <= 32 * (int64_t)B) {
@@ -482,7 +501,13 @@ RN_API int rn_iou_match_special(const float *anchors, int64_t anchor_bstride, co
         // hundreds of GT boxes per image: split the GT axis too (see iou_match_chunk_kernel); z workgroups per anchor strip
         int z = (int)((total_gt / B + CHUNK_TILE - 1) / CHUNK_TILE);
         z = z < 2 ? 2 : (z > 16 ? 16 : z);
-        RN_HIP(hipMemsetAsync(matches, 0, sizeof(int64_t) * (size_t)B * (size_t)A, st));
+        {   // (a kernel, not hipMemsetAsync: see zero_i32_kernel)
+            const int64_t n = (int64_t)B * A;
+            int64_t blocks = (n + 255) / 256;
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(zero_u64_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned long long *)matches, n);
+            RN_LAUNCH_CHECK();
+        }
         const dim3 grid((unsigned)((A + MATCH_BLOCK * 4 - 1) / (MATCH_BLOCK * 4)), (unsigned)B, (unsigned)z);
         hipLaunchKernelGGL(iou_match_chunk_kernel<4>, grid, dim3(MATCH_BLOCK), 0, st, (const rn::f32x4 *)anchors, anchor_bstride / 4,
                            (const rn::f32x4 *)gt_boxes, gt_off, A, (unsigned long long *)matches);

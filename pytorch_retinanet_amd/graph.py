@@ -22,6 +22,7 @@ MIOpen's find, the caches and the optimizer state); the next one captures and re
 are kept (least recently used goes first); a capture that fails falls back to eager for that signature.
 """
 import ctypes as C
+import os
 import logging
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -37,16 +38,81 @@ _log = logging.getLogger(__name__)
 
 
 class _Entry:
-    __slots__ = ("graph", "images", "targets", "losses", "calls", "failed", "match_state")
+    __slots__ = ("graph", "images", "targets", "losses", "calls", "failed", "match_state", "segments", "bucket_ids", "pool")
 
     def __init__(self):
         self.graph, self.images, self.targets, self.losses, self.calls, self.failed, self.match_state = None, None, None, None, 0, False, None
+        self.segments, self.bucket_ids, self.pool = None, None, None
+
+
+class MemsetNodeInGraph(RuntimeError):
+    pass
+
+
+LAST_CENSUS: Dict[str, int] = {}          # node counts of the graphs captured so far in this process (bench.py reports them)
+
+
+def _new_graph() -> "torch.cuda.CUDAGraph":
+    try:
+        return torch.cuda.CUDAGraph(keep_graph=True)          # (keeps the hipGraph_t for the node census below)
+    except TypeError:
+        return torch.cuda.CUDAGraph()
+
+
+def _refuse_memset_nodes(g) -> None:
+    """(Repairs, then refuses what is left.)  A captured step must not hold a MEMSET node: on ROCm 7.0 the memset nodes of a replayed hipGraph write garbage once the
+    process has synchronised with the device and enqueued other blit work (round 4: K2's 32-byte ``num_fg`` clear scaled every loss
+    after bench.py's warm-up synchronisation by 1 / garbage).  This package issues no memset (kernels clear what needs clearing,
+    ``layers.FeaturePyramid._conv_own_bias``); MIOpen still does for some weight-gradient algorithms at some shapes -- such a step
+    is refused here and runs eagerly (``CapturedTrainStep.__call__`` catches the exception)."""
+    raw = getattr(g, "raw_cuda_graph", None)
+    try:
+        handle = raw() if raw is not None else None
+    except Exception:                    # noqa: BLE001 -- graph not kept (older torch): nothing to inspect
+        handle = None
+    if handle:
+        counts = (C.c_int64 * 4)()
+        check(lib.rn_hipgraph_node_census(C.c_void_p(int(handle)), counts), "rn_hipgraph_node_census")
+        LAST_CENSUS.update(kernel=LAST_CENSUS.get("kernel", 0) + int(counts[0]), memset=LAST_CENSUS.get("memset", 0) + int(counts[1]),
+                           memcpy=LAST_CENSUS.get("memcpy", 0) + int(counts[2]), other=LAST_CENSUS.get("other", 0) + int(counts[3]))
+        if counts[1] and not os.environ.get("RN_GRAPH_KEEP_MEMSET_NODES"):
+            # the repair: each memset node becomes a kernel node with the same parameters, dependencies and dependents
+            n = C.c_int64(0)
+            check(lib.rn_hipgraph_replace_memset_nodes(C.c_void_p(int(handle)), C.byref(n)), "rn_hipgraph_replace_memset_nodes")
+            LAST_CENSUS["memset_replaced"] = LAST_CENSUS.get("memset_replaced", 0) + int(n.value)
+            check(lib.rn_hipgraph_node_census(C.c_void_p(int(handle)), counts), "rn_hipgraph_node_census")
+        if counts[1]:
+            raise MemsetNodeInGraph(f"the captured step holds {counts[1]} memset node(s) next to {counts[0]} kernels (a third-party "
+                                    f"library cleared a buffer with hipMemsetAsync); replays of such a graph are not trusted on this ROCm")
+    inst = getattr(g, "instantiate", None)
+    if handle and inst is not None:
+        inst()
+
+
+def retinanet_stage_of(name: str) -> int:
+    """Backward stage of a ``Retinanet`` parameter (``BucketedGradAllReduce(stage_of=...)``): 0 = head + FPN, 1 = layer4 + layer3,
+    2 = layer2 .. stem -- the order in which the staged backward pass finishes their gradients."""
+    if name.startswith("backbone.backbone.layer4") or name.startswith("backbone.backbone.layer3"):
+        return 1
+    if name.startswith("backbone."):
+        return 2
+    return 0
 
 
 class CapturedTrainStep:
     def __init__(self, net, optimizer, ddp=None, amp_dtype: Optional[torch.dtype] = torch.bfloat16, eager_steps: int = 2,
-                 max_graphs: int = 4, enabled: bool = True):
+                 max_graphs: int = 4, enabled: bool = True, segmented: Optional[bool] = None):
+        """``segmented`` (default: on whenever gradients are exchanged): the step with a gradient exchange as FOUR linear hipGraphs --
+        forward + head / FPN backward | layer4, layer3 backward | layer2 .. stem backward | optimizer -- with the finished buckets'
+        all-reduces issued EAGERLY on the process group's communication stream between the replays and the wait for them in
+        front of the last segment.  Why not one graph: torch's process group runs the collectives on its own stream, a capture
+        turns that into forked graph branches, and ROCm replays such a graph slower than Python enqueues the same kernels
+        (DESIGN.md section 6); why not eager: ~20 ms of host time per 25 ms step.  The backward pass is cut at C3 / C4 / C5
+        (``backbone.StageCuts``) and run as separate autograd calls, so each segment's capture begins and ends on this thread."""
         self.net, self.optimizer, self.ddp = net, optimizer, ddp
+        self.segmented = (ddp is not None) if segmented is None else (bool(segmented) and ddp is not None)
+        if self.segmented:
+            ddp.deferred = True
         self.amp_dtype = amp_dtype
         self.eager_steps, self.max_graphs, self.enabled = max(int(eager_steps), 1), int(max_graphs), enabled
         self._entries: "OrderedDict[tuple, _Entry]" = OrderedDict()
@@ -54,8 +120,47 @@ class CapturedTrainStep:
         self.captures = 0
 
     # -- the step itself (identical in eager mode and under capture) -------------------------------------------------
+    def _staged(self, images, targets, mark) -> Dict[str, Tensor]:
+        """The step with the backward pass in stages; ``mark(i)`` runs after stage i's kernels have been enqueued (i = 0, 1, 2: the
+        buckets completed so far may be exchanged; 3: after the optimizer).  ``ddp.finish()`` -- the wait for the exchange -- runs
+        between mark(2) and the optimizer, outside any capture."""
+        from .backbone import StageCuts
+        net, opt, ddp = self.net, self.optimizer, self.ddp
+        trunk = net.backbone.backbone
+        cuts = StageCuts()
+        ddp.zero_grad()
+        trunk.stage_cuts = cuts
+        try:
+            with torch.autocast(images[0].device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None, cache_enabled=False):
+                losses = net(list(images), [dict(t) for t in targets])
+                total = losses["classification_loss"] + losses["regression_loss"]
+        finally:
+            trunk.stage_cuts = None
+        total.backward()                                          # stage 0: head + FPN; gradients of the cut leaves
+        mark(0)
+        pairs = cuts.pairs                                        # [(C3, leaf), (C4, leaf), (C5, leaf)] in forward order
+        for out, leaf in reversed(pairs[1:]):                     # stage 1: layer4, then layer3 (each adds to the leaf below it)
+            if leaf.grad is not None:
+                out.backward(leaf.grad)
+                leaf.grad = None
+        mark(1)
+        if pairs and pairs[0][1].grad is not None:                # stage 2: layer2 .. stem
+            pairs[0][0].backward(pairs[0][1].grad)
+            pairs[0][1].grad = None
+        mark(2)
+        ddp.finish()
+        if type(opt).__name__ == "MasterSGD":
+            opt.step(grads=ddp.grad_views())
+        else:
+            opt.step()
+        mark(3)
+        return {"classification_loss": losses["classification_loss"].detach(), "regression_loss": losses["regression_loss"].detach(),
+                "loss": total.detach()}
+
     def _step(self, images: Sequence[Tensor], targets: Sequence[Dict[str, Tensor]]) -> Dict[str, Tensor]:
         net, opt, ddp = self.net, self.optimizer, self.ddp
+        if self.segmented:
+            return self._staged(images, targets, lambda i: ddp.issue_ready() if i < 3 else None)
         if ddp is not None:
             ddp.zero_grad()
         else:
@@ -85,15 +190,69 @@ class CapturedTrainStep:
         frozen = tuple(p.requires_grad for p in self.net.parameters())       # (freezing / unfreezing layers changes the launch sequence)
         return (ims, tgs, groups, hash(mode), hash(frozen), self.amp_dtype)
 
+    def _capture_segments(self, e: _Entry, images, targets) -> None:
+        "Four linear graphs sharing one memory pool; the exchange calls between them run eagerly, here as at every replay."
+        dev = images[0].device
+        e.images = [im.clone() for im in images]
+        e.targets = [{k: (v.clone() if isinstance(v, Tensor) else v) for k, v in t.items()} for t in targets]
+        e.match_state = ops.new_match_state(dev)
+        e.pool = torch.cuda.graph_pool_handle()
+        e.segments, e.bucket_ids = [], []
+        ddp = self.ddp
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        state = {"g": None}
+
+        def begin():
+            state["g"] = _new_graph()
+            state["g"].capture_begin(pool=e.pool, capture_error_mode="thread_local")
+
+        def mark(i):
+            state["g"].capture_end()
+            _refuse_memset_nodes(state["g"])
+            e.segments.append(state["g"])
+            e.bucket_ids.append(ddp.issue_ready() if i < 3 else [])       # eager: the collectives of the buckets this segment completed
+            if i < 2:
+                begin()
+            # (i == 2: ddp.finish() runs next -- eager: the compute stream waits for the communication stream -- and begins the
+            # optimizer's segment, see finish_then_begin below)
+
+        with ops.use_match_state(e.match_state), torch.cuda.stream(side):
+            orig_finish = ddp.finish
+
+            def finish_then_begin():
+                orig_finish()
+                begin()
+            ddp.finish = finish_then_begin
+            try:
+                begin()
+                e.losses = self._staged(e.images, e.targets, mark)
+            finally:
+                ddp.finish = orig_finish
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.captures += 1
+
+    def _replay_segments(self, e: _Entry) -> None:
+        ddp = self.ddp
+        for i in range(3):
+            e.segments[i].replay()
+            ddp.issue(e.bucket_ids[i])
+        ddp.finish()
+        e.segments[3].replay()
+
     def _capture(self, e: _Entry, images, targets) -> None:
+        if self.segmented:
+            return self._capture_segments(e, images, targets)
         e.images = [im.clone() for im in images]
         e.targets = [{k: (v.clone() if isinstance(v, Tensor) else v) for k, v in t.items()} for t in targets]
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
+        g = _new_graph()
         # the fused loss kernel's state words: zero-filled here, OUTSIDE the capture, and owned by this entry (ops.use_match_state)
         e.match_state = ops.new_match_state(e.images[0].device)
         with ops.use_match_state(e.match_state), torch.cuda.graph(g, capture_error_mode="thread_local"):
             e.losses = self._step(e.images, e.targets)
+        _refuse_memset_nodes(g)
         e.graph = g
         self.captures += 1
 
@@ -111,12 +270,14 @@ class CapturedTrainStep:
         e.calls += 1
         if e.failed or e.calls <= self.eager_steps:
             return self._step(images, targets)
-        if e.graph is None:
+        if e.graph is None and e.segments is None:
             try:
                 self._capture(e, images, targets)
             except Exception as exc:                          # noqa: BLE001 -- a step that cannot be captured still has to run
                 _log.warning("train-step capture failed (%s: %s); this input signature runs eagerly", type(exc).__name__, exc)
-                e.failed, e.graph, e.images, e.targets, e.losses = True, None, None, None, None
+                e.failed, e.graph, e.images, e.targets, e.losses, e.segments = True, None, None, None, None, None
+                if self.ddp is not None:
+                    self.ddp.reset()
                 torch.cuda.synchronize()
                 return self._step(images, targets)
         else:
@@ -135,7 +296,10 @@ class CapturedTrainStep:
                 check(lib.rn_copy_many((C.c_void_p * n)(*[t.data_ptr() for t in srcs]), (C.c_void_p * n)(*[t.data_ptr() for t in dsts]),
                                        (C.c_int64 * n)(*[t.numel() * t.element_size() for t in dsts]), n,
                                        torch.cuda.current_stream(dsts[0].device).cuda_stream), "rn_copy_many")
-        e.graph.replay()
+        if e.segments is not None:
+            self._replay_segments(e)
+        else:
+            e.graph.replay()
         note_raw_write()                                      # parameters and BN statistics changed behind torch's back
         self.replays += 1
         return e.losses

@@ -60,14 +60,29 @@ class FeaturePyramid(nn.Module):
                 return out
         return lat + self._up(top)
 
+    @staticmethod
+    def _conv_own_bias(conv: nn.Conv2d, x: Tensor) -> Tensor:
+        """``conv(x)`` with the bias added -- and its gradient summed -- by the library's kernels (``biasact.bias_act``).  Why: autograd's
+        ``convolution_backward`` forms a bias gradient with ``aten::sum``, which clears its accumulator with ``hipMemsetAsync``; in a
+        captured step that is a MEMSET NODE, and on ROCm 7.0 the memset nodes of a replayed hipGraph write garbage once the process has
+        synchronised with the device and done other work (round 4: K2's 32-byte ``num_fg`` memset made every replay after the first
+        ``torch.cuda.synchronize()`` scale the losses by 1 / garbage; ``tests/test_graph_gpu.py``).  The captured step holds no memset
+        node any more."""
+        if x.is_cuda and conv.bias is not None and conv.bias.dtype == torch.float32 and torch.is_grad_enabled() and conv.bias.requires_grad:
+            y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+            if biasact.fusable(y, conv.bias):
+                return biasact.bias_act(y, conv.bias, None, relu=False)
+            return y + conv.bias.to(y.dtype)[None, :, None, None]
+        return conv(x)
+
     def forward(self, inps: List[Tensor]) -> List[Tensor]:
         c3, c4, c5 = inps
         from .pwconv import conv1x1            # laterals: 1x1 GEMMs on the fastest of MIOpen / hipBLASLt / csrc/pw.hip per product
         p5 = conv1x1(self.conv_c5_1x1, c5)
         p4 = self._lateral_plus_up(conv1x1(self.conv_c4_1x1, c4), p5)
         p3 = self._lateral_plus_up(conv1x1(self.conv_c3_1x1, c3), p4)
-        p6 = self.conv_c6_3x3(c5)
-        p7 = self.conv_c7_3x3(F.relu(p6))
+        p6 = self._conv_own_bias(self.conv_c6_3x3, c5)
+        p7 = self._conv_own_bias(self.conv_c7_3x3, F.relu(p6))
         outs, convs = [p3, p4, p5], [self.conv_c3_3x3, self.conv_c4_3x3, self.conv_c5_3x3]
         if biasact.dense_group_fusable(outs, convs):       # one MFMA launch each way for the three levels (csrc/conv.hip, MODE_DENSE)
             return biasact.dense_conv_group(outs, convs) + [p6, p7]

@@ -109,8 +109,8 @@ class _FusedDenseHeadLossLevels(torch.autograd.Function):
         gcls, gbox = ctx.grads
         ctx.grads = None
         dev = gcls[0].device
-        g0 = torch.zeros((1,), device=dev) if g0 is None else g0.reshape(1)
-        g1 = torch.zeros((1,), device=dev) if g1 is None else g1.reshape(1)
+        g0 = torch.full((1,), 0.0, device=dev) if g0 is None else g0.reshape(1)
+        g1 = torch.full((1,), 0.0, device=dev) if g1 is None else g1.reshape(1)
         ops.scale_inplace_batched(list(gcls) + list(gbox), [g0] * len(gcls) + [g1] * len(gbox))      # one launch
         outs = [t.view(shape) if t.dtype == dt else t.to(dt).view(shape) for t, (shape, dt) in zip(list(gcls) + list(gbox), ctx.meta)]
         return (None,) * 9 + tuple(outs)
@@ -204,7 +204,7 @@ class RetinaNetLosses(nn.Module):
         # the tensors were allocated on the calling stream but are written / read on the side stream: if the head raises before
         # the loss joins the streams and the handle is dropped, the allocator must not hand the blocks out while K2 still runs
         for t in (h.matches, h.num_fg, h.special, h.gt_boxes, h.gt_off, anchors):
-            if t is not None:
+            if t is not None and not os.environ.get("RN_DBG_NO_RECORD_STREAM"):
                 t.record_stream(side)
         return h
 

@@ -78,21 +78,31 @@ class _Bucket:
 
 class BucketedGradAllReduce:
     def __init__(self, module: nn.Module, bucket_mb: float = 32.0, process_group=None, average: bool = True,
-                 sync_params: bool = True):
+                 sync_params: bool = True, stage_of=None):
+        """``stage_of(parameter_name) -> int`` (optional): buckets never span two stages -- ``graph.CapturedTrainStep`` runs the backward
+        pass stage by stage (head + FPN | layer4, layer3 | layer2 .. stem) and issues a stage's buckets when its graph segment has
+        been enqueued (``stage_index`` below; see ``deferred``)."""
         self.module = module
+        # deferred = True: a completed bucket is gathered (kernels: capturable) but NOT exchanged from the autograd hook; it waits in
+        # ``ready`` until the caller -- outside any stream capture -- calls ``issue_ready()``
+        self.deferred = False
+        self.ready: List["_Bucket"] = []
         self.group = process_group
         self.average = average
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.backend = dist.get_backend(process_group) if dist.is_initialized() else None
-        params = [p for p in module.parameters() if p.requires_grad]
-        params.reverse()                                     # ~ reverse forward order
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        named.reverse()                                      # ~ reverse forward order
+        params = [p for _, p in named]
+        stage = {id(p): (int(stage_of(n)) if stage_of is not None else 0) for n, p in named}
         self.buckets: List[_Bucket] = []
         self._owner = {}
         cap = int(bucket_mb * (1 << 20))
         group, size = [], 0
         for p in params:
             nbytes = self._padded(p.numel()) * self._grad_dtype(p).itemsize
-            if group and (size + nbytes > cap or self._grad_dtype(p) != self._grad_dtype(group[0]) or p.device != group[0].device):
+            if group and (size + nbytes > cap or self._grad_dtype(p) != self._grad_dtype(group[0]) or p.device != group[0].device
+                          or stage[id(p)] != stage[id(group[0])]):
                 self._make_bucket(group)
                 group, size = [], 0
             group.append(p)
@@ -145,7 +155,7 @@ class BucketedGradAllReduce:
         for p in b.params:
             view = self._owner[p][1]
             if p.grad is None:
-                view.zero_()                   # parameter without a gradient this step
+                view.fill_(0)                  # parameter without a gradient this step (a fill kernel, not a memset: graph.py)
             elif p.grad.data_ptr() != view.data_ptr():
                 views.append(view)
                 grads.append(p.grad)
@@ -154,6 +164,12 @@ class BucketedGradAllReduce:
         if views:
             _gather(views, grads)                  # also promotes bf16 gradients into fp32 buckets
         b.launched = True
+        if self.deferred:
+            self.ready.append(b)
+            return
+        self._exchange(b)
+
+    def _exchange(self, b: _Bucket) -> None:
         if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
             return
         if self.average and self.backend == "nccl":
@@ -161,11 +177,34 @@ class BucketedGradAllReduce:
         else:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def reset(self) -> None:
+        "Forget a half-finished step (a capture that was abandoned): no bucket is pending, ready or in flight."
+        self.ready = []
+        for b in self.buckets:
+            b.pending, b.launched, b.work = len(b.params), False, None
+
+    def issue_ready(self) -> List[int]:
+        "Deferred mode: exchange the buckets completed since the last call (NOT under stream capture); -> their indices."
+        done = [self.buckets.index(b) for b in self.ready]
+        for b in self.ready:
+            self._exchange(b)
+        self.ready = []
+        return done
+
+    def issue(self, indices) -> None:
+        "Exchange the given buckets -- the replay of a captured step: the gather kernels ran inside the graph segment just enqueued."
+        for i in indices:
+            b = self.buckets[i]
+            b.launched = True
+            self._exchange(b)
+
     # -- call after backward, before optimizer.step ------------------------------------------
     def finish(self) -> None:
         for b in self.buckets:
             if not b.launched:                 # parameters that received no gradient this step
                 self._launch(b)
+        if self.deferred and self.ready:
+            self.issue_ready()
         for b in self.buckets:
             if b.work is not None:
                 b.work.wait()                  # compute stream waits for the communication stream

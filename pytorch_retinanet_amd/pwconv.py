@@ -318,7 +318,7 @@ class _BottleneckFn(torch.autograd.Function):
                 epi1 = RnPwEpilogue(RN_PW_EPI_RESID, 0, dxd.data_ptr(), 0, 0, 0, 0, 0, 0, sd, x.shape[2], x.shape[3])
                 dx = pw_forward(dz1, w1t, epi=epi1, tag="pw_conv1_dgrad")
             else:
-                full = torch.zeros_like(x)
+                full = torch.empty_like(x).fill_(0)
                 full[:, :, ::sd, ::sd] = dxd
                 dx = pw_forward(dz1, w1t, tag="pw_conv1_dgrad") + full
         dw1 = pw_wgrad(dz1, x, w1, tag="pw_conv1_wgrad", defer=pending)
@@ -511,7 +511,7 @@ class _Conv1x1S2(torch.autograd.Function):
                 join.compact.append((comp, 2))
                 JOIN_STATS["compact"] += 1
             else:
-                dx = torch.zeros_like(x)
+                dx = torch.empty_like(x).fill_(0)
                 dx[:, :, ::2, ::2] = comp
         if ctx.needs_input_grad[1]:
             dw = torch.ops.aten.convolution_backward(g, x, w, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]

@@ -124,3 +124,23 @@ def test_two_ranks_with_live_batchnorm_match_the_emulated_ranks(tmp_path):
     for s in range(len(single["losses"])):
         noise = abs(single["losses"][s] - single2["losses"][s])
         assert abs(single["losses"][s] - 0.5 * (r[0]["losses"][s] + r[1]["losses"][s])) <= NOISE_X * noise + 1e-3 * abs(single["losses"][s])
+
+
+def test_two_ranks_through_the_segmented_graphs_equal_the_global_batch(tmp_path):
+    """the step under a gradient exchange as four linear hipGraph segments (staged backward: head + FPN | layer4,
+    layer3 | layer2 .. stem | optimizer) with the buckets' all-reduces issued between the replays.  Five steps: two eager staged
+    ones, the capture, two replays.  Ranks bit-equal; equal to the single-process global batch within the measured noise."""
+    out = str(tmp_path)
+    _launch_ranks(out, "--precision", "bf16", "--segmented", "--steps", "5")
+    single, single2 = _single_twice(tmp_path, "--precision", "bf16", "--steps", "5")
+    r0 = torch.load(os.path.join(out, "rank0.pt"))
+    r1 = torch.load(os.path.join(out, "rank1.pt"))
+    assert r0["replays"] >= 2 and r1["replays"] >= 2, (r0["replays"], r1["replays"])
+    assert len(r0["buckets"]) >= 3
+    for k, a in r0["params"].items():
+        assert torch.equal(a, r1["params"][k]), f"ranks diverged at {k}"
+        ok, err, bound, spread = _close(a, single["params"][k], single2["params"][k], 3e-3)
+        assert ok, (k, err, bound, spread)
+    for s in range(len(single["losses"])):
+        noise = abs(single["losses"][s] - single2["losses"][s])
+        assert abs(single["losses"][s] - 0.5 * (r0["losses"][s] + r1["losses"][s])) <= NOISE_X * noise + 2e-2 * abs(single["losses"][s])

@@ -6,6 +6,8 @@ is equality with this package's own eager step: same loss trajectory and same pa
 non-determinism of MIOpen's atomically accumulated weight gradients (the tolerance ``test_model_gpu`` uses for two eager
 runs), BN running statistics advancing once per replay, and derived caches (frozen-BN fold) seeing the replayed updates.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -105,3 +107,87 @@ def test_a_new_input_signature_gets_its_own_graph_and_folds_see_replayed_updates
     n = step.replays
     step(*a[1])
     assert step.replays == n
+
+
+def test_replays_survive_a_device_sync_and_unrelated_eager_work():
+    """Round 4: with a hipMemsetAsync inside the captured step (K2's 32-byte ``num_fg`` clear; ``aten::sum``'s accumulator clear in
+    autograd's conv bias gradient) every replay that followed a ``torch.cuda.synchronize()`` + other eager work computed garbage --
+    memset NODES of a replayed hipGraph misbehave on ROCm 7.0 (``bench.py`` synchronises between warm-up and the timed steps: its
+    loss read 0.0099 / 320 / NaN instead of 3.58).  The package issues no memset any more, and a step whose graph still holds a
+    memset node (MIOpen clears some weight gradients with one at some shapes) is refused and runs eagerly.  Either way: replays
+    interleaved with synchronisations, allocations and fills follow the un-interrupted trajectory."""
+    from pytorch_retinanet_amd.graph import CapturedTrainStep
+    data = _batches(10)
+    res = {}
+    for disturb in (False, True):
+        net, opt = _setup()
+        step = CapturedTrainStep(net, opt, amp_dtype=torch.bfloat16, eager_steps=2, enabled=True)
+        losses = []
+        for i, (im, tg) in enumerate(data):
+            if disturb and i >= 4:
+                torch.cuda.synchronize()
+                junk = [torch.full((n,), float("nan"), device=DEV) for n in (64, 256, 4096, 1 << 16, 1 << 20) for _ in range(16)]
+                torch.cuda.synchronize()
+                del junk
+            losses.append(step(im, tg)["loss"].clone())
+        torch.cuda.synchronize()
+        res[disturb] = np.array([float(x) for x in losses])
+        assert step.replays == len(data) - 2                   # (MIOpen's memset nodes at these shapes were replaced by kernel nodes)
+    assert np.all(np.isfinite(res[True]))
+    np.testing.assert_allclose(res[True], res[False], rtol=2e-2)
+
+
+def test_a_graph_with_a_memset_node_is_refused_and_the_librarys_own_calls_capture_without_one(oracle_lib):
+    "``rn_hipgraph_node_census`` / ``graph._refuse_memset_nodes``: a captured ``zero_()`` is a memset node; K2 + K3 + detect capture as kernels only."
+    import ctypes as C
+    from pytorch_retinanet_amd import graph, ops
+    from pytorch_retinanet_amd._lib import lib
+    x = torch.ones((1024,), device=DEV)
+    torch.cuda.synchronize()
+    g = graph._new_graph()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemsetAsync.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        y = x * 2.0
+        st = torch.cuda.current_stream().cuda_stream
+        assert hip.hipMemsetAsync(x.data_ptr(), 0, x.numel() * 4, C.c_void_p(st)) == 0      # -> a memset node
+        z = x + 1.0
+    counts = (C.c_int64 * 4)()
+    assert lib.rn_hipgraph_node_census(C.c_void_p(int(g.raw_cuda_graph())), counts) == 0
+    assert counts[0] >= 1 and counts[1] == 1, list(counts)
+    os.environ["RN_GRAPH_KEEP_MEMSET_NODES"] = "1"
+    try:
+        with pytest.raises(graph.MemsetNodeInGraph):
+            graph._refuse_memset_nodes(g)
+    finally:
+        del os.environ["RN_GRAPH_KEEP_MEMSET_NODES"]
+    # the repair: the memset node becomes a kernel node with the same effect, dependencies and dependents
+    graph._refuse_memset_nodes(g)
+    assert lib.rn_hipgraph_node_census(C.c_void_p(int(g.raw_cuda_graph())), counts) == 0 and counts[1] == 0 and counts[0] >= 2
+    x.fill_(3.0)
+    g.replay(); torch.cuda.synchronize()
+    assert float(y[0]) == 6.0 and float(x.abs().max()) == 0.0 and float(z.min()) == 1.0 == float(z.max())
+    # the library's own dense-head calls: K2 (its num_fg clear is a kernel now), K3, the detect chain (candidate counters)
+    rng = np.random.default_rng(3)
+    A, K, B = 6759, 5, 2
+    levels = synth.levels_for(224, 160)
+    anc = ops.anchors_emit(levels, [torch.from_numpy(oracle_lib.cell_anchors(s_, synth.ANCHOR_RATIOS)).to(DEV) for s_ in synth.ANCHOR_SIZES], 0.0)
+    cls, box = synth.head_outputs(rng, B, A, K)
+    cls_t, box_t = torch.from_numpy(cls).to(DEV), torch.from_numpy(box).to(DEV)
+    gtb, gtl = zip(*[synth.gt_boxes(rng, 3, 224, 160, num_classes=K) for _ in range(B)])
+    gt_t, gl_t = torch.from_numpy(np.concatenate(gtb)).to(DEV), torch.from_numpy(np.concatenate(gtl)).to(DEV)
+    off = ops.gt_offsets([3] * B, torch.device(DEV))
+    p = ops.make_loss_params(0.25, 2.0, 0.1)
+    m, nfg, sp = ops.iou_match(anc, gt_t, off, B, 0.5, 0.4, want_special=True)          # (warm: allocations, function attributes)
+    ops.loss_fwd_bwd_levels([cls_t], [box_t], anc, gt_t, gl_t, off, m, nfg, p, True, special=sp)
+    torch.cuda.synchronize()
+    g2 = graph._new_graph()
+    with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+        m, nfg, sp = ops.iou_match(anc, gt_t, off, B, 0.5, 0.4, want_special=True)
+        loss, gc, gb = ops.loss_fwd_bwd_levels([cls_t], [box_t], anc, gt_t, gl_t, off, m, nfg, p, True, special=sp)
+    assert lib.rn_hipgraph_node_census(C.c_void_p(int(g2.raw_cuda_graph())), counts) == 0
+    assert counts[0] >= 3 and counts[1] == 0, list(counts)
+    graph._refuse_memset_nodes(g2)                               # (also instantiates)
+    g2.replay(); torch.cuda.synchronize()
+    ref = oracle_lib.loss_fwd_bwd(cls, box, anc.cpu().numpy(), list(gtb), list(gtl), oracle_lib.iou_match(anc.cpu().numpy(), list(gtb))[0])
+    np.testing.assert_allclose(loss.cpu().numpy(), ref["loss"], rtol=1e-4)

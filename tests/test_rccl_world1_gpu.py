@@ -29,22 +29,27 @@ def _bench(*extra):
 
 
 def test_world1_rccl_step_matches_the_plain_step():
-    ddp = _bench("--force-ddp")
-    ddp_graph = _bench("--force-ddp", "--ddp-graph")
+    seg = _bench("--force-ddp")                               # default: four linear graph segments, all-reduces eager between them
+    eager = _bench("--force-ddp", "--ddp-mode", "eager")
     plain = _bench()
-    assert ddp["rccl_ranks"] == 1 and ddp_graph["rccl_ranks"] == 1 and plain["rccl_ranks"] == 0
-    assert ddp["n_gpus"] == 1 and ddp["config"]["parallelism"] == "dp1"
-    for line in (ddp, ddp_graph, plain):
+    assert seg["rccl_ranks"] == 1 and eager["rccl_ranks"] == 1 and plain["rccl_ranks"] == 0
+    assert seg["n_gpus"] == 1 and seg["config"]["parallelism"] == "dp1"
+    for line in (seg, eager, plain):
         assert line["value"] > 0 and line["config"]["final_loss"] == line["config"]["final_loss"]      # finite (not NaN)
         assert 0 < line["config"]["final_loss"] < 100
-    # one rank: the exchange is an identity, but the bucket gather and the 153 MB single-rank all-reduce are extra work, and
-    # the eager step pays Python's enqueue: measured 4 % (eager) / 7.5 % (captured) below the plain captured step
-    assert plain["value"] * 0.88 <= ddp["value"] <= plain["value"] * 1.03, (ddp["value"], plain["value"])
-    assert plain["value"] * 0.85 <= ddp_graph["value"] <= plain["value"] * 1.03, (ddp_graph["value"], plain["value"])
-    assert ddp["step_launch"]["mode"] == "eager" and ddp_graph["step_launch"]["mode"] == "hipGraph replay"
-    assert plain["step_launch"]["mode"] == "hipGraph replay"
-    for line in (ddp, ddp_graph):
-        assert abs(line["config"]["final_loss"] - plain["config"]["final_loss"]) <= 0.05 * plain["config"]["final_loss"]
+    # one rank: the exchange is an identity, but the bucket gather and the 153 MB single-rank all-reduce are extra work; the eager
+    # step also pays Python's enqueue (~20 ms of host time per step), the segmented one four graph launches and a few collective calls
+    assert plain["value"] * 0.88 <= eager["value"] <= plain["value"] * 1.03, (eager["value"], plain["value"])
+    assert plain["value"] * 0.93 <= seg["value"] <= plain["value"] * 1.03, (seg["value"], plain["value"])
+    assert eager["step_launch"]["mode"] == "eager" and plain["step_launch"]["mode"] == "hipGraph replay"
+    assert seg["step_launch"]["mode"].startswith("4 linear hipGraph segments") and seg["step_launch"]["graph_replays_in_run"] >= 6
+    assert seg["step_launch"]["buckets"] >= 4
+    assert seg["host_enqueue_ms_per_step"] <= 3.0, seg["host_enqueue_ms_per_step"]                       # 
+    # (the eager run is the yardstick: a replayed graph that goes wrong after bench.py's warm-up synchronisation -- round 4, memset
+    # nodes -- shows as a final loss far from the eager one)
+    for line in (seg, plain):
+        assert abs(line["config"]["final_loss"] - eager["config"]["final_loss"]) <= 0.02 * eager["config"]["final_loss"], (line["config"]["final_loss"], eager["config"]["final_loss"])
+    assert plain["step_launch"].get("graph_nodes", {}).get("memset", 0) == 0
     if os.environ.get("RN_KEEP_PROFILES"):
-        with open(os.path.join(ROOT, "gpurun_out", "r03_rccl_world1.json"), "w") as f:
-            json.dump({"force_ddp": ddp, "force_ddp_graph": ddp_graph, "plain": plain}, f, indent=1)
+        with open(os.path.join(ROOT, "gpurun_out", "r04_rccl_world1.json"), "w") as f:
+            json.dump({"force_ddp_segmented": seg, "force_ddp_eager": eager, "plain": plain}, f, indent=1)

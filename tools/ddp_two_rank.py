@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--global-batch", type=int, default=4)
     ap.add_argument("--bn", default="frozen", choices=["frozen", "train"])
     ap.add_argument("--ranks", type=int, default=2, help="--single --bn train: number of ranks to emulate")
+    ap.add_argument("--segmented", action="store_true", help="ranks: run the steps through graph.CapturedTrainStep's segmented form (staged "
+                    "backward, four hipGraph segments from the third step on, all-reduces issued between the replays)")
     args = ap.parse_args()
     world = 1 if args.single else int(os.environ["WORLD_SIZE"])
     rank = 0 if args.single else int(os.environ["RANK"])
@@ -68,7 +70,9 @@ def main():
         use_bf16_conv_weights(net)
     opt = MasterSGD(net.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-3)
     emulate = args.ranks if (args.single and live_bn) else 0
-    ddp = None if emulate else P.BucketedGradAllReduce(net, bucket_mb=8.0)           # several buckets for a 20 M-parameter model
+    from pytorch_retinanet_amd.graph import CapturedTrainStep, retinanet_stage_of
+    ddp = None if emulate else P.BucketedGradAllReduce(net, bucket_mb=8.0, stage_of=retinanet_stage_of if args.segmented else None)   # several buckets for a 20 M-parameter model
+    stepper = CapturedTrainStep(net, opt, ddp, amp_dtype=torch.bfloat16 if bf16 else None, eager_steps=2) if (args.segmented and ddp is not None) else None
     assert emulate or ddp.num_buckets >= 3
 
     def bn_buffers():
@@ -111,6 +115,9 @@ def main():
         mine = slice(rank * per, (rank + 1) * per)
         imgs = [i.to(dev) for i in images[mine]]
         tgts = [{k: v.to(dev) for k, v in t.items()} for t in targets[mine]]
+        if stepper is not None:
+            losses.append(float(stepper(imgs, tgts)["loss"]))
+            continue
         ddp.zero_grad()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
             out = net(imgs, tgts)
@@ -123,12 +130,14 @@ def main():
     state = {n: (p.master if hasattr(p, "master") else p.data).detach().float().cpu() for n, p in net.named_parameters()}
     os.makedirs(args.out, exist_ok=True)
     bufs = [{n: b.float().cpu() for n, b in rb.items()} for rb in rank_bufs] if emulate else [{n: b.float().cpu() for n, b in bn_buffers().items()}]
-    torch.save({"params": state, "losses": losses, "buckets": ddp.bucket_bytes() if ddp else [], "bn_buffers": bufs},
+    torch.save({"params": state, "losses": losses, "buckets": ddp.bucket_bytes() if ddp else [], "bn_buffers": bufs,
+                "replays": stepper.replays if stepper is not None else 0},
                os.path.join(args.out, "single.pt" if args.single else f"rank{rank}.pt"))
     if not args.single:
         dist.barrier()
         dist.destroy_process_group()
-    print(f"rank {rank}/{world}: losses {['%.5f' % x for x in losses]} buckets {ddp.num_buckets if ddp else 0}", flush=True)
+    print(f"rank {rank}/{world}: losses {['%.5f' % x for x in losses]} buckets {ddp.num_buckets if ddp else 0} "
+          f"graph replays {stepper.replays if stepper is not None else 0}", flush=True)
 
 
 if __name__ == "__main__":
