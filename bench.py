@@ -534,16 +534,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     clocks = None
-    if rank == 0 and not os.environ.get("RN_BENCH_NO_GPU_STATE"):
+    if rank == 0:
         pr = torch.cuda.get_device_properties(local_rank)
         pci = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
         clocks = ClockSampler(pci).start()
     t0 = time.perf_counter()
-    trace = [] if os.environ.get("RN_BENCH_TRACE_LOSS") else None
     for _ in range(args.steps):
         out = stepper(images, targets)
-        if trace is not None:
-            trace.append(out["loss"].clone())
     host_enqueue = time.perf_counter() - t0      # (diagnostic: the host is done enqueueing here; the GPU usually is not)
     torch.cuda.synchronize()
     if world > 1:
@@ -552,8 +549,6 @@ def main():
     elapsed = time.perf_counter() - t0
     gpu_state = clocks.stop() if clocks else None
     final_loss = float(out["loss"])
-    if trace is not None:
-        print("loss trace:", [round(float(x), 4) for x in trace], file=sys.stderr)
     graph_replays = stepper.replays
     # per-kernel figures: the same step, enqueued eagerly with a pair of HIP events around every hand-written kernel (events
     # recorded inside a captured graph are dependency markers, not timestamps), right after the timed region, same data

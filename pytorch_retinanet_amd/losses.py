@@ -204,7 +204,7 @@ class RetinaNetLosses(nn.Module):
         # the tensors were allocated on the calling stream but are written / read on the side stream: if the head raises before
         # the loss joins the streams and the handle is dropped, the allocator must not hand the blocks out while K2 still runs
         for t in (h.matches, h.num_fg, h.special, h.gt_boxes, h.gt_off, anchors):
-            if t is not None and not os.environ.get("RN_DBG_NO_RECORD_STREAM"):
+            if t is not None:
                 t.record_stream(side)
         return h
 
