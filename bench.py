@@ -667,7 +667,7 @@ def main():
         except Exception:          # noqa: BLE001
             pass
         print(json.dumps(line), flush=True)
-        if world > 1 or args.force_ddp:
+        if (world > 1 or args.force_ddp) and not os.environ.get("RN_BENCH_NORMAL_EXIT"):      # (a profiler needs the normal exit to write its files)
             os._exit(0)
 
 

@@ -139,6 +139,13 @@ class CapturedTrainStep:
         total.backward()                                          # stage 0: head + FPN; gradients of the cut leaves
         mark(0)
         pairs = cuts.pairs                                        # [(C3, leaf), (C4, leaf), (C5, leaf)] in forward order
+        # C3 / C4 join the data gradients of their consumers in the receiver's GEMM (pwconv._GradJoin); the FPN lateral's gradient was
+        # produced in ANOTHER autograd pass (stage 0), so it is handed to the join here: the receiver accumulates into it (addmm_) and
+        # autograd ASSIGNS the result to the leaf -- no 137 / 69 MB add per cut
+        for _, leaf in pairs:
+            j = getattr(leaf, "_rn_join", None)
+            if j is not None and j._has_receiver and not j.recv_done and j.full is None and leaf.grad is not None:
+                j.full, leaf.grad = leaf.grad, None
         for out, leaf in reversed(pairs[1:]):                     # stage 1: layer4, then layer3 (each adds to the leaf below it)
             if leaf.grad is not None:
                 out.backward(leaf.grad)
