@@ -59,7 +59,7 @@ def _new_graph() -> "torch.cuda.CUDAGraph":
         return torch.cuda.CUDAGraph()
 
 
-def _refuse_memset_nodes(g) -> None:
+def _repair_memset_nodes(g) -> None:
     """(Repairs, then refuses what is left.)  A captured step must not hold a MEMSET node: on ROCm 7.0 the memset nodes of a replayed hipGraph write garbage once the
     process has synchronised with the device and enqueued other blit work (round 4: K2's 32-byte ``num_fg`` clear scaled every loss
     after bench.py's warm-up synchronisation by 1 / garbage).  This package issues no memset (kernels clear what needs clearing,
@@ -217,7 +217,7 @@ class CapturedTrainStep:
 
         def mark(i):
             state["g"].capture_end()
-            _refuse_memset_nodes(state["g"])
+            _repair_memset_nodes(state["g"])
             e.segments.append(state["g"])
             e.bucket_ids.append(ddp.issue_ready() if i < 3 else [])       # eager: the collectives of the buckets this segment completed
             if i < 2:
@@ -259,7 +259,7 @@ class CapturedTrainStep:
         e.match_state = ops.new_match_state(e.images[0].device)
         with ops.use_match_state(e.match_state), torch.cuda.graph(g, capture_error_mode="thread_local"):
             e.losses = self._step(e.images, e.targets)
-        _refuse_memset_nodes(g)
+        _repair_memset_nodes(g)
         e.graph = g
         self.captures += 1
 

@@ -138,7 +138,7 @@ def test_replays_survive_a_device_sync_and_unrelated_eager_work():
 
 
 def test_a_graph_with_a_memset_node_is_refused_and_the_librarys_own_calls_capture_without_one(oracle_lib):
-    "``rn_hipgraph_node_census`` / ``graph._refuse_memset_nodes``: a captured ``zero_()`` is a memset node; K2 + K3 + detect capture as kernels only."
+    "``rn_hipgraph_node_census`` / ``graph._repair_memset_nodes``: a captured ``zero_()`` is a memset node; K2 + K3 + detect capture as kernels only."
     import ctypes as C
     from pytorch_retinanet_amd import graph, ops
     from pytorch_retinanet_amd._lib import lib
@@ -158,11 +158,11 @@ def test_a_graph_with_a_memset_node_is_refused_and_the_librarys_own_calls_captur
     os.environ["RN_GRAPH_KEEP_MEMSET_NODES"] = "1"
     try:
         with pytest.raises(graph.MemsetNodeInGraph):
-            graph._refuse_memset_nodes(g)
+            graph._repair_memset_nodes(g)
     finally:
         del os.environ["RN_GRAPH_KEEP_MEMSET_NODES"]
     # the repair: the memset node becomes a kernel node with the same effect, dependencies and dependents
-    graph._refuse_memset_nodes(g)
+    graph._repair_memset_nodes(g)
     assert lib.rn_hipgraph_node_census(C.c_void_p(int(g.raw_cuda_graph())), counts) == 0 and counts[1] == 0 and counts[0] >= 2
     x.fill_(3.0)
     g.replay(); torch.cuda.synchronize()
@@ -187,7 +187,7 @@ def test_a_graph_with_a_memset_node_is_refused_and_the_librarys_own_calls_captur
         loss, gc, gb = ops.loss_fwd_bwd_levels([cls_t], [box_t], anc, gt_t, gl_t, off, m, nfg, p, True, special=sp)
     assert lib.rn_hipgraph_node_census(C.c_void_p(int(g2.raw_cuda_graph())), counts) == 0
     assert counts[0] >= 3 and counts[1] == 0, list(counts)
-    graph._refuse_memset_nodes(g2)                               # (also instantiates)
+    graph._repair_memset_nodes(g2)                               # (also instantiates)
     g2.replay(); torch.cuda.synchronize()
     ref = oracle_lib.loss_fwd_bwd(cls, box, anc.cpu().numpy(), list(gtb), list(gtl), oracle_lib.iou_match(anc.cpu().numpy(), list(gtb))[0])
     np.testing.assert_allclose(loss.cpu().numpy(), ref["loss"], rtol=1e-4)
