@@ -339,6 +339,13 @@ size_t rn_conv3x3_wgrad_narrow_workspace_bytes(int Cout, int Cin);
 int rn_conv3x3_wgrad_narrow(const void *g, const void *x, void *dw, int dtype, int N, int H, int W, int Cout, int Cin,
                             const void *zero_page, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The forward product of the same NARROW 3x3 / stride-1 / pad-1 convolution at C = 64 input and output channels (conv2 of the layer1
+ * bottlenecks, retinanet/backbone.py:112,128 -- what F.conv2d(x, w, None, 1, 1) returns there), bf16 channels-last, fp32 accumulation:
+ *   x, y [N][H][W][64],  w [64][3][3][64] (channels-last memory of a [64, 64, 3, 3] weight).
+ * Issued with the tap-reversed, role-swapped weight (rn_conv3x3_levels_dgrad_weight's layout) it is the data gradient of that
+ * convolution.  Weights in registers, input rows in an LDS ring (csrc/narrow3x3.hip).  RN_EUNSUPPORTED for other C or dtypes. */
+int rn_conv3x3_narrow_forward(const void *x, const void *w, void *y, int dtype, int N, int H, int W, int C, void *stream);
+
 /* n device-to-device copies (dsts[i] <- srcs[i], nbytes[i] bytes, non-overlapping) in one launch per 64: the inputs of a step
  * into the static buffers of its captured hipGraph (graph.CapturedTrainStep).  srcs / dsts / nbytes are HOST arrays. */
 int rn_copy_many(const void *const *srcs, void *const *dsts, const int64_t *nbytes, int n, void *stream);

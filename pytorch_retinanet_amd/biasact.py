@@ -935,6 +935,36 @@ def conv3x3_mfma_bwd(conv, x: Tensor) -> Tensor:
 # gradient is issued as a forward convolution; the weight flip is one launch of the kernel the MFMA data gradients already use.
 DGRAD_AS_FWD = True
 
+# The forward product at 64 channels on this library's own kernel (csrc/narrow3x3.hip: weights in registers, input rows in an LDS ring)
+# instead of the CK grouped-convolution kernel MIOpen picks for it; RN_NARROW_FWD=0 keeps MIOpen's.
+NARROW_FWD = os.environ.get("RN_NARROW_FWD", "1") == "1"
+
+
+def narrow_fwd_ok(x: Tensor, w: Tensor) -> bool:
+    return (NARROW_FWD and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 4 and _cl(x) and
+            tuple(w.shape) == (64, 64, 3, 3) and x.shape[1] == 64 and x.numel() // 64 < (1 << 31))
+
+
+def conv3x3_narrow_forward(x: Tensor, w: Tensor) -> Tensor:
+    "``F.conv2d(x, w, None, 1, 1)`` for bf16 channels-last x [N, 64, H, W] and w [64, 64, 3, 3] on ``rn_conv3x3_narrow_forward``."
+    dev = x.device
+    if dev.index != torch.cuda.current_device():
+        torch.cuda.set_device(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    wc = w if _cl(w) else w.contiguous(memory_format=torch.channels_last)
+    N, C, H, W = x.shape
+    y = torch.empty_like(x, memory_format=torch.channels_last)
+    _mfma_call("mfma_conv2_narrow_fwd", dev, 2.0 * N * H * W * C * C * 9,
+               lambda: lib.rn_conv3x3_narrow_forward(x.data_ptr(), wc.data_ptr(), y.data_ptr(), RN_BF16, N, H, W, C, stream), "rn_conv3x3_narrow_forward")
+    return y
+
+
+def conv3x3_same(x: Tensor, w: Tensor) -> Tensor:
+    "``F.conv2d(x, w, None, 1, 1)`` (no autograd): the narrow kernel where it applies, else MIOpen."
+    if narrow_fwd_ok(x, w):
+        return conv3x3_narrow_forward(x, w)
+    return F.conv2d(x, w, None, 1, 1)
+
 
 def dgrad_as_fwd_ok(w: Tensor, stride, x: Tensor) -> bool:
     return (DGRAD_AS_FWD and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and _cl(x) and w.dim() == 4 and
@@ -952,7 +982,7 @@ def conv3x3_dgrad_as_fwd(g: Tensor, w: Tensor) -> Tensor:
     wt = torch.empty((Cin, Cout, 3, 3), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
     check(lib.rn_conv3x3_dgrad_weight_batched(_ptr_array([wc]), _ptr_array([wt]), 1, Cout, Cin, stream), "rn_conv3x3_dgrad_weight_batched")
     gc = g if (g.dtype == torch.bfloat16 and _cl(g)) else g.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    return F.conv2d(gc, wt, None, 1, 1)
+    return conv3x3_same(gc, wt)
 
 
 # Their weight gradient: one team of waves holds all nine taps of a 64 x 64 block of dW (csrc/wgrad3x3.hip) instead of one
@@ -1001,7 +1031,7 @@ class _Conv3x3DgradAsFwd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
-        return F.conv2d(x, w, None, 1, 1)
+        return conv3x3_same(x, w)
 
     @staticmethod
     def backward(ctx, dy):

@@ -209,7 +209,11 @@ class _BottleneckFn(torch.autograd.Function):
         z1 = pw_forward(x, w1, epi=e1, tag="pw_conv1_fwd")
         st1 = bn_finalize(p1, nb1, M0, blk.bn1)
         a1, _ = bn_apply(z1, st1, relu=True)                                 # conv2 is MIOpen's: it needs the activation
-        z2 = F.conv2d(a1, w2, None, blk.conv2.stride, blk.conv2.padding)
+        from . import biasact
+        if s == 1 and tuple(blk.conv2.padding) == (1, 1) and biasact.narrow_fwd_ok(a1, w2):
+            z2 = biasact.conv3x3_narrow_forward(a1, w2)                      # 64 channels: csrc/narrow3x3.hip
+        else:
+            z2 = F.conv2d(a1, w2, None, blk.conv2.stride, blk.conv2.padding)
         if not _cl(z2):
             z2 = z2.contiguous(memory_format=torch.channels_last)
         st2 = bn_stats(z2, blk.bn2)

@@ -187,3 +187,38 @@ def test_narrow_weight_gradient_rejects_what_it_cannot_do():
     assert lib.rn_conv3x3_wgrad_narrow(x.data_ptr(), x.data_ptr(), dw.data_ptr(), RN_BF16, 1, 4, 4, 64, 64, z, ws.data_ptr(), 16, 0) != 0
     assert lib.rn_conv3x3_wgrad_narrow(x.data_ptr(), x.data_ptr(), dw.data_ptr(), RN_BF16, 1, 4, 4, 64, 64, 0, ws.data_ptr(), ws.numel(), 0) != 0
     assert lib.rn_conv3x3_wgrad_narrow_workspace_bytes(96, 64) == 0
+
+
+@pytest.mark.parametrize("N,hw", [
+    (2, (40, 52)),         # one strip, masked tail (52 < 128)
+    (1, (1, 1)),           # a single pixel: every tap but the centre leaves the image
+    (1, (3, 130)),         # two strips, the second holds two pixels; three rows: bands of one row on a 256-CU part
+    (2, (9, 128)),         # exactly one full strip: the right halo pixel is outside the image
+    (3, (5, 257)),         # three strips, one pixel in the last
+    (1, (300, 129)),       # bands of several rows with a short last band
+    (8, (200, 336)),       # layer1 of the 800 x 1333 bucket (full size)
+])
+def test_narrow_forward_matches_torch(N, hw):
+    "csrc/narrow3x3.hip against F.conv2d on fp32 copies of the same bf16 tensors (conv2 of a layer1 bottleneck, backbone.py:112,128)."
+    from pytorch_retinanet_amd import biasact
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(23)
+    x = torch.randn((N, 64, *hw), device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((64, 64, 3, 3), device=dev, generator=g) * 0.06).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert biasact.narrow_fwd_ok(x, w)
+    y = biasact.conv3x3_narrow_forward(x, w)
+    assert y.shape == x.shape and y.is_contiguous(memory_format=torch.channels_last)
+    ref = F.conv2d(x.float(), w.float(), None, 1, 1)
+    # bf16 rounding of an fp32 sum of 576 products: half an ulp of the result
+    assert _rel(y, ref) < 4e-3, _rel(y, ref)
+    assert float((y.float() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()) + 1e-6
+    # a different weight per output channel and per tap: a transposed or mirrored tap order cannot pass
+    w2 = torch.zeros_like(w)
+    w2[5, 9, 0, 2] = 1.0                                   # y[:, 5, h, w] = x[:, 9, h - 1, w + 1]
+    y2 = biasact.conv3x3_narrow_forward(x, w2)
+    want = torch.zeros_like(x)
+    if hw[0] > 1 and hw[1] > 1:
+        want[:, 5, 1:, :-1] = x[:, 9, :-1, 1:]
+    assert torch.equal(y2, want)
+    # other channel counts and dtypes are declined, not mis-computed
+    assert not biasact.narrow_fwd_ok(x[:, :32], w[:, :32]) and not biasact.narrow_fwd_ok(x.float(), w.float())

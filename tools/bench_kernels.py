@@ -157,6 +157,25 @@ def bench_detect(reps, mean, std, tag, B=16):
     report(f"torch.cat of the 5 levels (avoided) B={B}", cat_ms, 2 * B * (A * K * 2 + A * 4 * 2))
 
 
+def bench_narrow3x3(reps, N=8, H=200, W=336):
+    "conv2 of a layer1 bottleneck (64 -> 64, 3x3, stride 1): csrc/narrow3x3.hip next to the kernel MIOpen picks, same tensors."
+    import torch.nn.functional as F
+    from pytorch_retinanet_amd import biasact
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn((N, 64, H, W), generator=g).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((64, 64, 3, 3), generator=g) * 0.05).to(DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = biasact.conv3x3_narrow_forward(x, w)
+    ref = F.conv2d(x.float(), w.float(), None, 1, 1)
+    err = float((y.float() - ref).abs().max())
+    err_lib = float((F.conv2d(x, w, None, 1, 1).float() - ref).abs().max())
+    flop = 2.0 * N * H * W * 64 * 64 * 9
+    nbytes = 2 * N * H * W * 64 * 2 + 64 * 64 * 9 * 2
+    for name, fn in (("rn_conv3x3_narrow_forward", lambda: biasact.conv3x3_narrow_forward(x, w)), ("MIOpen F.conv2d", lambda: F.conv2d(x, w, None, 1, 1))):
+        med, mn, mean = timeit(fn, reps)
+        print(json.dumps({"kernel": f"{name} {N}x{H}x{W}x64 bf16", "ms_median": round(med, 4), "ms_min": round(mn, 4), "TFLOP/s": round(flop / med / 1e9, 1),
+                          "GB/s": round(nbytes / med / 1e6, 1), "max_abs_err_vs_fp32": err if name.startswith("rn_") else err_lib}), flush=True)
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     reps = 30
@@ -190,6 +209,9 @@ def main():
             bench_detect(6, -20.0, 0.5, "empty")
         elif w == "detect_stress":
             bench_detect(3, -6.0, 1.5, "stress")
+        elif w == "narrow3x3":
+            bench_narrow3x3(reps)
+            bench_narrow3x3(reps, 2, 37, 131)
 
 
 if __name__ == "__main__":
