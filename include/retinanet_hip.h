@@ -343,8 +343,10 @@ int rn_conv3x3_wgrad_narrow(const void *g, const void *x, void *dw, int dtype, i
  * bottlenecks, retinanet/backbone.py:112,128 -- what F.conv2d(x, w, None, 1, 1) returns there), bf16 channels-last, fp32 accumulation:
  *   x, y [N][H][W][64],  w [64][3][3][64] (channels-last memory of a [64, 64, 3, 3] weight).
  * Issued with the tap-reversed, role-swapped weight (rn_conv3x3_levels_dgrad_weight's layout) it is the data gradient of that
- * convolution.  Weights in registers, input rows in an LDS ring (csrc/narrow3x3.hip).  RN_EUNSUPPORTED for other C or dtypes. */
-int rn_conv3x3_narrow_forward(const void *x, const void *w, void *y, int dtype, int N, int H, int W, int C, void *stream);
+ * convolution.  Weights in registers, input rows in an LDS ring (csrc/narrow3x3.hip); zero_page: >= 128 zero bytes on the device (what
+ * pixels outside the image read).  RN_EUNSUPPORTED for other C or dtypes. */
+int rn_conv3x3_narrow_forward(const void *x, const void *w, void *y, int dtype, int N, int H, int W, int C, const void *zero_page,
+                              void *stream);
 
 /* n device-to-device copies (dsts[i] <- srcs[i], nbytes[i] bytes, non-overlapping) in one launch per 64: the inputs of a step
  * into the static buffers of its captured hipGraph (graph.CapturedTrainStep).  srcs / dsts / nbytes are HOST arrays. */

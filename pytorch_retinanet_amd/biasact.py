@@ -955,7 +955,7 @@ def conv3x3_narrow_forward(x: Tensor, w: Tensor) -> Tensor:
     N, C, H, W = x.shape
     y = torch.empty_like(x, memory_format=torch.channels_last)
     _mfma_call("mfma_conv2_narrow_fwd", dev, 2.0 * N * H * W * C * C * 9,
-               lambda: lib.rn_conv3x3_narrow_forward(x.data_ptr(), wc.data_ptr(), y.data_ptr(), RN_BF16, N, H, W, C, stream), "rn_conv3x3_narrow_forward")
+               lambda: lib.rn_conv3x3_narrow_forward(x.data_ptr(), wc.data_ptr(), y.data_ptr(), RN_BF16, N, H, W, C, _zero_page(dev).data_ptr(), stream), "rn_conv3x3_narrow_forward")
     return y
 
 

@@ -11,34 +11,43 @@
 //     v_mfma_f32_32x32x16_bf16 = 144 registers, loaded once per workgroup (rows = output channels, so D is [channel][pixel] and a lane ends
 //     up with 4 CONSECUTIVE channels of a pixel: 8-byte stores, no LDS transpose);
 //   * a workgroup (4 waves: 2 channel halves x 2 pixel halves) walks a band of output rows of one 128-pixel column strip; every input row
-//     is staged ONCE per band (130 pixels x 128 bytes, 16-byte chunks XOR-swizzled by pixel pair: conflict-free ds_read_b128) into a ring
+//     is staged ONCE per band (130 pixels x 128 bytes by LDS-DMA, 16-byte chunks XOR-swizzled by pixel pair: conflict-free ds_read_b128) into a ring
 //     of four rows, the three vertical taps read three ring rows, the three horizontal taps the same row one pixel further;
-//   * per output row a wave issues 72 MFMAs and 72 fragment reads; the next input row is in flight (global -> registers) under them and goes
-//     into the free ring slot before the single barrier of the step.  Two workgroups per CU (66.5 KB of LDS each) overlap each other.
+//   * per output row a wave issues 72 MFMAs and 72 fragment reads (issued two K-steps ahead); the next input row is in flight (LDS-DMA into
+//     the free ring slot) under them; one barrier per row.  Two workgroups per CU (68 KB of LDS each) overlap each other.
 #include "rn_common.hpp"
 
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((address_space(3))) void *lds_void_ptr;
 
 constexpr int N3_THREADS = 256;
 constexpr int N3_TW = 128;                       // output pixels of a strip
-constexpr int N3_SPX = N3_TW + 2;                // staged pixels of an input row (one halo pixel each side)
-constexpr int N3_ROWBYTES = N3_SPX * 128;        // 64 channels x 2 bytes per pixel
-constexpr int N3_LDS = 4 * N3_ROWBYTES;          // ring of four input rows: 66 560 bytes
-constexpr int N3_CHUNKS = N3_SPX * 8;            // 16-byte chunks of a staged row
-constexpr int N3_ST = (N3_CHUNKS + N3_THREADS - 1) / N3_THREADS;     // chunks per thread (5)
+constexpr int N3_PIECES = 17;                    // LDS-DMA pieces of a staged row: 8 pixels x 128 bytes each (130 pixels are read)
+constexpr int N3_ROWBYTES = N3_PIECES * 1024;    // 136 staged pixels x (64 channels x 2 bytes)
+constexpr int N3_LDS = 4 * N3_ROWBYTES;          // ring of four input rows: 69 632 bytes -> two workgroups per CU
+#ifndef N3_AHEAD
+#define N3_AHEAD 2                               // K-steps between a fragment read and its MFMAs (<= 5)
+#endif
 
 struct N3Args {
     const uint16_t *x;      // [N][H][W][64]
     const uint16_t *w;      // [64][9][64]  (channels-last memory of a [64, 64, 3, 3] weight)
     uint16_t *y;            // [N][H][W][64]
+    const void *zeros;      // >= 128 zero bytes: what the staged pixels outside the image read
     int N, H, W;
     int strips, bands, rows_per_band;
+    int dbg;                // RN_N3_DEBUG ablations (timing only, results wrong): 1 no stores, 2 no staging in the loop, 4 no barrier in the loop
 };
 
 __device__ __forceinline__ int n3_swz(const int sp) { return (sp >> 1) & 7; }
+
+// The fragment reads are inline asm, their waits counted by hand: the compiler would order every LDS read it knows of behind the LDS-DMA in
+// flight (vmcnt(0)) and so serialise the fetch of the next input row with this row's MFMAs (same reason as csrc/wgrad3x3.hip).
+#define N3_DS_READ(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+#define N3_WAIT_LGKM(N) asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
 
 __global__ __launch_bounds__(N3_THREADS, 2) void conv3x3_narrow64_kernel(const N3Args a)
 {
@@ -46,134 +55,162 @@ __global__ __launch_bounds__(N3_THREADS, 2) void conv3x3_narrow64_kernel(const N
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cw = wave & 1, pw = wave >> 1;                     // channel half, pixel half
-    int u = blockIdx.x;
-    const int band = u % a.bands; u /= a.bands;
-    const int strip = u % a.strips;
-    const int n = u / a.strips;
+    int u_ = blockIdx.x;
+    const int band = u_ % a.bands; u_ /= a.bands;
+    const int strip = u_ % a.strips;
+    const int n = u_ / a.strips;
     const int x0 = strip * N3_TW;
     const int y0 = band * a.rows_per_band, y1 = min(y0 + a.rows_per_band, a.H);
     if (y0 >= y1) return;
 
+    // ---- staging of one input row (image row yy, pixels x0 - 1 .. x0 + 128): LDS-DMA, 16 bytes per lane; a piece lands as 1 KiB of
+    // consecutive lanes, so the XOR swizzle of the 16-byte chunks (by pixel pair) is applied on the SOURCE side
+    const int lpx = lane >> 3, lch = lane & 7;
+    uint32_t src_off[2];                                          // byte offset inside the 8 pixels of a piece, by piece parity
+#pragma unroll
+    for (int par = 0; par < 2; ++par) src_off[par] = (uint32_t)(lpx * 128 + ((lch ^ ((par * 4 + (lane >> 4)) & 7)) << 4));
+    const unsigned char *const zsrc = (const unsigned char *)a.zeros + lch * 16;
+    auto stage = [&](const int yy) {
+        const bool row_ok = (unsigned)yy < (unsigned)a.H;
+        unsigned char *const rb = lds + ((yy + 4) & 3) * N3_ROWBYTES;
+        const int64_t row_byte = (((int64_t)n * a.H + (row_ok ? yy : 0)) * a.W + (x0 - 1)) * 128;        // of staged pixel 0 (may be one pixel before the row)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int u = wave + 4 * i;                           // wave-uniform
+            if (u < N3_PIECES) {
+                const int sp = 8 * u + lpx, xx = x0 - 1 + sp;
+                const bool ok = row_ok && sp < N3_TW + 2 && (unsigned)xx < (unsigned)a.W;
+                const unsigned char *const src = ok ? (const unsigned char *)a.x + (row_byte + u * 1024 + src_off[u & 1]) : zsrc;
+                __builtin_amdgcn_global_load_lds((const void *)src, (lds_void_ptr)(rb + u * 1024), 16, 0, 0);
+            }
+        }
+    };
+    stage(y0 - 1); stage(y0); stage(y0 + 1);
+
     // ---- weights: this wave's 32 output channels x (9 taps x 64 input channels), as MFMA A-fragments (row = output channel)
     bf16x8 wf[9][4];
+    const int kh = lane >> 5;
     {
-        const int co = cw * 32 + (lane & 31), kh = lane >> 5;
+        const int co = cw * 32 + (lane & 31);
         const uint16_t *wp = a.w + (int64_t)co * 9 * 64 + kh * 8;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int kc = 0; kc < 4; ++kc) wf[t][kc] = *(const bf16x8 *)(wp + t * 64 + kc * 16);
     }
-
-    // ---- staging of one input row (image row yy, pixels x0 - 1 .. x0 + 128) : global -> registers -> ring slot
-    rn::u32x4 st[N3_ST];
-    auto load_row = [&](const int yy) {
-        const bool row_ok = yy >= 0 && yy < a.H;
+    // fragment addresses of pixel block 0 (block 1: + 32 pixels = + 4096 bytes, same swizzle): horizontal tap dx reads staged pixel
+    // p + dx (staged pixel 0 is x0 - 1), 16-channel chunk kc
+    uint32_t col[3][4];
 #pragma unroll
-        for (int i = 0; i < N3_ST; ++i) {
-            const int q = tid + i * N3_THREADS;
-            const int sp = q >> 3, c = q & 7;
-            const int xx = x0 - 1 + sp;
-            const bool ok = row_ok && q < N3_CHUNKS && xx >= 0 && xx < a.W;
-            const int64_t e = (((int64_t)n * a.H + (ok ? yy : 0)) * a.W + (ok ? xx : 0)) * 64 + c * 8;      // (clamped: always a valid address)
-            st[i] = *(const rn::u32x4 *)(a.x + e);               // (zeroed in store_row: the select must not make the MFMAs wait for the load)
-        }
-    };
-    auto store_row = [&](const int yy) {
-        unsigned char *const rb = lds + ((yy + 4) & 3) * N3_ROWBYTES;
-        const bool row_ok = yy >= 0 && yy < a.H;
+    for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-        for (int i = 0; i < N3_ST; ++i) {
-            const int q = tid + i * N3_THREADS;
-            if (q < N3_CHUNKS) {
-                const int sp = q >> 3, c = q & 7;
-                const int xx = x0 - 1 + sp;
-                const bool ok = row_ok && xx >= 0 && xx < a.W;
-                *(rn::u32x4 *)(rb + sp * 128 + ((c ^ n3_swz(sp)) << 4)) = ok ? st[i] : rn::u32x4{0u, 0u, 0u, 0u};
-            }
+        for (int kc = 0; kc < 4; ++kc) {
+            const int sp = pw * 64 + (lane & 31) + dx;
+            col[dx][kc] = (uint32_t)(sp * 128 + (((kc * 2 + kh) ^ n3_swz(sp)) << 4));
         }
-    };
-    load_row(y0 - 1); store_row(y0 - 1);
-    load_row(y0);     store_row(y0);
-    load_row(y0 + 1); store_row(y0 + 1);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // fragment addresses: pixel block pb, horizontal tap dx -> staged pixel sp = p + dx (staged pixel 0 is x0 - 1)
-    const int kh = lane >> 5;
-    int sp_off[2][3], sp_swz[2][3];
-#pragma unroll
-    for (int pb = 0; pb < 2; ++pb)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            const int sp = pw * 64 + pb * 32 + (lane & 31) + dx;
-            sp_off[pb][dx] = sp * 128;
-            sp_swz[pb][dx] = n3_swz(sp);
-        }
-
     for (int y = y0; y < y1; ++y) {
-        if (y + 2 <= y1) load_row(y + 2);                        // the row the NEXT step needs last (y + 2 = (y + 1) + 1), in flight under the MFMAs
+        const bool stage_next = (y + 2 <= y1) && !(a.dbg & 2);
+        if (stage_next) stage(y + 2);                            // the row the NEXT step needs last; slot (y + 2) & 3 held row y - 2: nobody reads it now
         f32x16 acc[2];
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[pb][r] = 0.0f;
-        // 36 K-steps (tap, 16-channel chunk) x 2 pixel blocks; the fragments of step s + 1 are read before the MFMAs of step s issue
-        const unsigned char *rb3[3];
+        uint32_t rbase[3];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) rb3[dy] = lds + ((y + dy - 1 + 4) & 3) * N3_ROWBYTES;
-        auto frag = [&](const int s, const int pb) -> bf16x8 {
-            const int t = s >> 2, kc = s & 3, dy = t / 3, dx = t % 3;
-            return *(const bf16x8 *)(rb3[dy] + sp_off[pb][dx] + (((kc * 2 + kh) ^ sp_swz[pb][dx]) << 4));
-        };
-        bf16x8 cur[2] = {frag(0, 0), frag(0, 1)}, nxt[2];
+        for (int dy = 0; dy < 3; ++dy) rbase[dy] = lds_base + (uint32_t)(((y + dy - 1 + 4) & 3) * N3_ROWBYTES);
+        // 36 K-steps (tap, 16-channel chunk) x 2 pixel blocks; the two fragments of step s are read N3_AHEAD steps (2 N3_AHEAD MFMAs) ahead
+        bf16x8 f[N3_AHEAD + 1][2];
+#define N3_READ(S) { const uint32_t ad_ = rbase[((S) >> 2) / 3] + col[((S) >> 2) % 3][(S) & 3]; \
+                     N3_DS_READ(f[(S) % (N3_AHEAD + 1)][0], ad_, 0); N3_DS_READ(f[(S) % (N3_AHEAD + 1)][1], ad_, 4096); }
+#pragma unroll
+        for (int s = 0; s < N3_AHEAD; ++s) N3_READ(s)
 #pragma unroll
         for (int s = 0; s < 36; ++s) {
-            if (s + 1 < 36) { nxt[0] = frag(s + 1, 0); nxt[1] = frag(s + 1, 1); }
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s >> 2][s & 3], cur[0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s >> 2][s & 3], cur[1], acc[1], 0, 0, 0);
-            cur[0] = nxt[0]; cur[1] = nxt[1];
+            if (s + N3_AHEAD < 36) { N3_READ(s + N3_AHEAD) }
+            // outstanding after this step's issue: steps s .. min(s + N3_AHEAD, 35), two reads each; all but step s's may stay in flight
+            constexpr int LAST = 35;
+            const int later = (s + N3_AHEAD < LAST ? s + N3_AHEAD : LAST) - s;
+            switch (later) {
+                case 0: N3_WAIT_LGKM(0) break;
+                case 1: N3_WAIT_LGKM(2) break;
+                case 2: N3_WAIT_LGKM(4) break;
+                case 3: N3_WAIT_LGKM(6) break;
+                case 4: N3_WAIT_LGKM(8) break;
+                default: N3_WAIT_LGKM(10) break;
+            }
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s >> 2][s & 3], f[s % (N3_AHEAD + 1)][0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s >> 2][s & 3], f[s % (N3_AHEAD + 1)][1], acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // D[channel][pixel]: lane = pixel (lane & 31), channels 8 g + 4 (lane >> 5) + j in acc[4 g + j]
+#undef N3_READ
+        // D[channel][pixel]: lane = pixel (lane & 31), channels 8 g + 4 (lane >> 5) + j in acc[4 g + j].  v_permlane32_swap trades the
+        // halves of two channel groups between lanes l and l + 32, so that a lane stores 8 consecutive channels (16 bytes) of its pixel:
+        // lanes 0..31 the even group of the pair, lanes 32..63 the odd one -- 32 contiguous bytes per pixel and instruction.
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb) {
             const int px = x0 + pw * 64 + pb * 32 + (lane & 31);
-            if (px < a.W) {
-                uint16_t *const yp = a.y + (((int64_t)n * a.H + y) * a.W + px) * 64 + cw * 32 + 4 * kh;
+            if (x0 + pw * 64 + pb * 32 >= a.W) continue;          // (wave-uniform: the tile lies right of the image -- the count below relies on it)
+            uint16_t *const yp = a.y + (((int64_t)n * a.H + y) * a.W + px) * 64 + cw * 32 + 8 * kh;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    rn::u32x2 o;
-                    o.x = rn::dt<RN_BF16>::pk(acc[pb][4 * g + 0], acc[pb][4 * g + 1]);
-                    o.y = rn::dt<RN_BF16>::pk(acc[pb][4 * g + 2], acc[pb][4 * g + 3]);
-                    *(rn::u32x2 *)(yp + 8 * g) = o;
-                }
+            for (int gp = 0; gp < 2; ++gp) {
+                const uint32_t ax = rn::dt<RN_BF16>::pk(acc[pb][8 * gp + 0], acc[pb][8 * gp + 1]), ay = rn::dt<RN_BF16>::pk(acc[pb][8 * gp + 2], acc[pb][8 * gp + 3]);
+                const uint32_t bx = rn::dt<RN_BF16>::pk(acc[pb][8 * gp + 4], acc[pb][8 * gp + 5]), by = rn::dt<RN_BF16>::pk(acc[pb][8 * gp + 6], acc[pb][8 * gp + 7]);
+                const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                if (px < a.W && (!(a.dbg & 1) || acc[pb][0] == 12345.678f))
+                    *(rn::u32x4 *)(yp + 16 * gp) = rn::u32x4{sx[0], sy[0], sx[1], sy[1]};
             }
         }
-        if (y + 2 <= y1) store_row(y + 2);                       // slot (y + 2) & 3 held row y - 2: nobody reads it in this step
-        __syncthreads();
+        // The staged row has landed: vmcnt counts loads and stores in issue order on gfx9, so everything but the stores just issued
+        // (two per tile that has a pixel inside the image) must have retired -- not the stores themselves, whose acknowledgement
+        // from the L2 takes longer than the step's MFMAs leave to hide.
+        {
+            const int tiles = (x0 + pw * 64 < a.W ? 1 : 0) + (x0 + pw * 64 + 32 < a.W ? 1 : 0);
+            if ((a.dbg & 1) || (a.dbg & 8)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            else if (tiles == 2) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else if (tiles == 1) { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+            else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        }
+        // (a bare s_barrier: __syncthreads() carries a workgroup release fence = vmcnt(0), which would wait for the stores after all;
+        // the ring is written by the DMA waited for above and read by the asm reads, all retired at the last K-step's lgkmcnt(0))
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(a.dbg & 4)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 }  // namespace
 
 // x, y [N][H][W][C] bf16 channels-last; w [C][3][3][C] (channels-last memory of [C, C, 3, 3]); C = 64.
-RN_API int rn_conv3x3_narrow_forward(const void *x, const void *w, void *y, int dtype, int N, int H, int W, int C, void *stream)
+RN_API int rn_conv3x3_narrow_forward(const void *x, const void *w, void *y, int dtype, int N, int H, int W, int C, const void *zero_page,
+                                     void *stream)
 {
-    if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0) return RN_EINVAL;
+    if (!x || !w || !y || !zero_page || N <= 0 || H <= 0 || W <= 0) return RN_EINVAL;
     if (dtype != RN_BF16 || C != 64) return RN_EUNSUPPORTED;
     if ((int64_t)N * H * W >= ((int64_t)1 << 31)) return RN_EUNSUPPORTED;
     if (!rn::aligned(x, 16) || !rn::aligned(w, 16) || !rn::aligned(y, 16)) return RN_EALIGN;
     N3Args a;
     a.x = (const uint16_t *)x; a.w = (const uint16_t *)w; a.y = (uint16_t *)y;
+    a.zeros = zero_page;
     a.N = N; a.H = H; a.W = W;
     a.strips = (W + N3_TW - 1) / N3_TW;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     // two workgroups per CU: bands so that (images x strips x bands) fills them once (a band re-stages two halo rows)
     int bands = (2 * cus) / (N * a.strips);
+    static const int bands_env = getenv("RN_N3_BANDS") ? atoi(getenv("RN_N3_BANDS")) : 0;      // (experiments)
+    if (bands_env > 0) bands = bands_env;
     if (bands < 1) bands = 1;
     if (bands > H) bands = H;
     a.rows_per_band = (H + bands - 1) / bands;
     a.bands = (H + a.rows_per_band - 1) / a.rows_per_band;
+    static const int dbg = getenv("RN_N3_DEBUG") ? atoi(getenv("RN_N3_DEBUG")) : 0;
+    a.dbg = dbg;
     static rn::DynLdsOptIn opt_in = {};
     { const int rc = opt_in.ensure((const void *)conv3x3_narrow64_kernel, N3_LDS); if (rc != RN_OK) return rc; }
     hipLaunchKernelGGL(conv3x3_narrow64_kernel, dim3((unsigned)(N * a.strips * a.bands)), dim3(N3_THREADS), N3_LDS, (hipStream_t)stream, a);

@@ -212,6 +212,8 @@ def main():
         elif w == "narrow3x3":
             bench_narrow3x3(reps)
             bench_narrow3x3(reps, 2, 37, 131)
+        elif w == "narrow3x3_tall":
+            bench_narrow3x3(reps, 8, 400, 336)
 
 
 if __name__ == "__main__":
