@@ -18,6 +18,10 @@ CASES = [
     ("w3", "1", "3", "30", "64"),
     ("w3", "2", "25", "34", "128"),
     ("w3", "1", "13", "21", "512"),
+    ("n3", "2", "9", "97"),            # csrc/narrow3x3.hip: one strip with a masked tail
+    ("n3", "1", "3", "130"),           # two strips, two pixels in the second
+    ("n3", "3", "37", "257"),
+    ("n3", "1", "1", "1"),
     ("dense",),
     ("pw",),
     ("pool",),

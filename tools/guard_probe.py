@@ -4,7 +4,7 @@
 mapping and the GPU raises a memory access fault (the process aborts) instead of silently touching a neighbour.  Found this way:
 ``stem_fwd_kernel`` -- a wave of the last workgroup that owns no tile loaded at a tile index past the last image.
 
-usage: guard_probe.py stem B H W | w3 N H W C | dense | pw | pool | bottleneck | step KIND MIN MAX | detect DT B H W K [MEAN] |
+usage: guard_probe.py stem B H W | w3 N H W C | n3 N H W | dense | pw | pool | bottleneck | step KIND MIN MAX | detect DT B H W K [MEAN] |
        loss DT B H W K T                                                                    (driven by tests/test_guard_gpu.py)
 Prints one "ok ..." line per case; a fault kills the process (non-zero exit status, no "ok" line for the case)."""
 import os
@@ -66,6 +66,15 @@ def main() -> None:
                                           st), "rn_conv3x3_wgrad_narrow")
         torch.cuda.synchronize()
         print("ok w3", N, H, W, Cc, flush=True)
+    elif which == "n3":
+        # forward product of the 64-channel 3x3 convolution (csrc/narrow3x3.hip): LDS-DMA row staging with a zero page for the halo
+        N, H, W = (int(v) for v in sys.argv[2:5])
+        x, w = raw_at_end(N * H * W * 64 * 2, 0x3c), raw_at_end(64 * 64 * 9 * 2, 0x3c)
+        y, zp = raw_at_end(N * H * W * 64 * 2), raw_at_end(256, 0)
+        check(lib.rn_conv3x3_narrow_forward(x.data_ptr(), w.data_ptr(), y.data_ptr(), RN_BF16, N, H, W, 64, zp.data_ptr(), st), "rn_conv3x3_narrow_forward")
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(y.view(torch.bfloat16).float()).all()), "a pixel outside the image was read"       # (padding is 3.4e38: 9 * 64 of them overflow)
+        print("ok n3", N, H, W, flush=True)
     elif which == "dense":
         from pytorch_retinanet_amd import biasact
         for N, shapes in [(2, [(25, 42), (13, 21), (7, 11)]), (1, [(1, 300), (3, 1), (2, 2)]), (3, [(9, 30)])]:
