@@ -24,7 +24,9 @@ constexpr int BN_BLOCK = 256;
 constexpr int BN_RBLOCK_MAX = 1024;       // threads per block of the two BN reduction kernels (runtime: reduce_grid)
 constexpr int BN_MAX_BLOCKS = 512;
 constexpr int FIN_CH = 8;                 // channels per block of the per-channel kernels
-constexpr int FIN_LANES = 256 / FIN_CH;    // threads that split the partial sums of one channel
+constexpr int FIN_THREADS = 1024;         // threads per block of the per-channel kernels: with 512 partials every thread has ONE batch of loads in flight
+constexpr int FIN_LANES = FIN_THREADS / FIN_CH;    // threads that split the partial sums of one channel (thread = channel + FIN_CH * lane)
+constexpr int FIN_WAVES = FIN_THREADS / 64;
 
 template <int DT> struct vec8;          // 8 consecutive channels <-> float[8]
 template <> struct vec8<RN_BF16> {
@@ -175,15 +177,18 @@ __global__ __launch_bounds__(BN_RBLOCK_MAX) void bn_stats_partial_kernel(const v
     }
 }
 
-// Sum of the per-block partials of one channel pair, split over FIN_LANES threads and combined in
-// double through LDS (fixed order: deterministic).  Returns the totals to the lane-0 thread of each channel.
+// Sum of the per-block partials of one channel pair, split over FIN_LANES threads and combined in double: a wave holds 8 lanes of
+// each of its 8 channels (butterfly over lane bits 3..5), the 16 waves meet in LDS.  Fixed order: deterministic.  Returns the
+// totals to the lane-0 thread of each channel.  These kernels are latency chains (a launch, one round of loads that miss --
+// the partials were written on other XCDs -- and the combine): 1024 threads so that the round is ONE batch of loads per thread
+// (256 threads: four dependent batches, 5.9 us per call; 106 calls per R50 step).
 __device__ __forceinline__ void channel_totals(const float *__restrict__ partial, const int nblocks, const int C, const int c,
-                                               const int ln, double (*sh)[FIN_LANES][FIN_CH], double &s, double &q)
+                                               const int ln, double (*sh)[FIN_WAVES][FIN_CH], double &s, double &q)
 {
     double ls = 0.0, lq = 0.0;
     if (c < C) {
         int b = ln;
-        for (; b + 3 * FIN_LANES < nblocks; b += 4 * FIN_LANES) {        // 8 independent loads in flight (the partials come from other XCDs' writes: misses)
+        for (; b + 3 * FIN_LANES < nblocks; b += 4 * FIN_LANES) {        // 8 independent loads in flight
             float ps[4], pq[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) { ps[u] = partial[(int64_t)(b + u * FIN_LANES) * 2 * C + c]; pq[u] = partial[(int64_t)(b + u * FIN_LANES) * 2 * C + C + c]; }
@@ -192,23 +197,25 @@ __device__ __forceinline__ void channel_totals(const float *__restrict__ partial
         }
         for (; b < nblocks; b += FIN_LANES) { ls += (double)partial[(int64_t)b * 2 * C + c]; lq += (double)partial[(int64_t)b * 2 * C + C + c]; }
     }
-    const int ch = threadIdx.x % FIN_CH;
-    sh[0][ln][ch] = ls; sh[1][ln][ch] = lq;
+#pragma unroll
+    for (int m = FIN_CH; m < 64; m <<= 1) { ls += __shfl_xor(ls, m); lq += __shfl_xor(lq, m); }
+    const int ch = threadIdx.x % FIN_CH, wv = threadIdx.x / 64;
+    if ((threadIdx.x & 63) < FIN_CH) { sh[0][wv][ch] = ls; sh[1][wv][ch] = lq; }
     __syncthreads();
     s = 0.0; q = 0.0;
     if (ln == 0)
-        for (int l = 0; l < FIN_LANES; ++l) { s += sh[0][l][ch]; q += sh[1][l][ch]; }
+        for (int l = 0; l < FIN_WAVES; ++l) { s += sh[0][l][ch]; q += sh[1][l][ch]; }
 }
 
 // per channel: mean / inverse std of the batch, the affine coefficients y = x*a + b, running-stat update
-__global__ __launch_bounds__(256) void bn_stats_final_kernel(const float *__restrict__ partial, const int nblocks, const int64_t M,
+__global__ __launch_bounds__(FIN_THREADS) void bn_stats_final_kernel(const float *__restrict__ partial, const int nblocks, const int64_t M,
                                                              const int C, const float *__restrict__ gamma, const float *__restrict__ beta,
                                                              float *__restrict__ running_mean, float *__restrict__ running_var,
                                                              int64_t *__restrict__ num_batches_tracked, const float momentum,
                                                              const float eps, float *__restrict__ save_mean, float *__restrict__ save_invstd,
                                                              float *__restrict__ coef_a, float *__restrict__ coef_b)
 {
-    __shared__ double sh[2][FIN_LANES][FIN_CH];
+    __shared__ double sh[2][FIN_WAVES][FIN_CH];
     const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, ln = threadIdx.x / FIN_CH;
     if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
     double s, q;
@@ -377,13 +384,13 @@ __global__ __launch_bounds__(BN_RBLOCK_MAX) void bn_bwd_partial_kernel(const voi
 
 // per channel: dgamma, dbeta and the coefficients of dx = a*g + k0 + k1*x
 //   training: dx = a*(g - mean(g) - xhat*mean(g*xhat));  eval (frozen statistics): dx = a*g
-__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float *__restrict__ partial, const int nblocks, const int64_t M, const int C,
+__global__ __launch_bounds__(FIN_THREADS) void bn_bwd_final_kernel(const float *__restrict__ partial, const int nblocks, const int64_t M, const int C,
                                                            const float *__restrict__ gamma, const float *__restrict__ save_mean,
                                                            const float *__restrict__ save_invstd, const int training,
                                                            float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                            float *__restrict__ coef_a, float *__restrict__ coef_k0, float *__restrict__ coef_k1)
 {
-    __shared__ double sh[2][FIN_LANES][FIN_CH];
+    __shared__ double sh[2][FIN_WAVES][FIN_CH];
     const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, ln = threadIdx.x / FIN_CH;
     double s, q;
     channel_totals(partial, nblocks, C, c, ln, sh, s, q);
@@ -510,7 +517,7 @@ int stats_final_launch(const float *partial, int nb, int64_t M, int C, const flo
                        float *running_var, int64_t *num_batches_tracked, float momentum, float eps, float *save_mean,
                        float *save_invstd, float *ca, float *cb, hipStream_t st)
 {
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, st, partial, nb, M, C, gamma, beta, running_mean,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_THREADS), 0, st, partial, nb, M, C, gamma, beta, running_mean,
                        running_var, num_batches_tracked, momentum, eps, save_mean, save_invstd, ca, cb);
     RN_LAUNCH_CHECK();
     return RN_OK;
@@ -575,7 +582,7 @@ int bwd_partial_launch(const void *dy, const void *y, const void *x, int dtype, 
 int bwd_final_launch(const float *partial, int nb, int64_t M, int C, const float *gamma, const float *save_mean, const float *save_invstd,
                      int training, float *dgamma, float *dbeta, float *ca, float *k0, float *k1, hipStream_t st)
 {
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, st, partial, nb, M, C, gamma, save_mean, save_invstd,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_THREADS), 0, st, partial, nb, M, C, gamma, save_mean, save_invstd,
                        training, dgamma, dbeta, ca, k0, k1);
     RN_LAUNCH_CHECK();
     return RN_OK;
@@ -876,17 +883,18 @@ __global__ __launch_bounds__(BN_BLOCK) void bias_act_bwd_kernel(const void *__re
 __global__ __launch_bounds__(256) void bias_grad_final_kernel(const float *__restrict__ partial, const int nblocks, const int C,
                                                               float *__restrict__ dbias)
 {
-    __shared__ double sh[FIN_LANES][FIN_CH];
+    constexpr int LANES = 256 / FIN_CH;                             // (256-thread blocks: few partials, few calls)
+    __shared__ double sh[LANES][FIN_CH];
     const int ch = threadIdx.x % FIN_CH, ln = threadIdx.x / FIN_CH;
     const int c = blockIdx.x * FIN_CH + ch;
     double ls = 0.0;
     if (c < C)
-        for (int b = ln; b < nblocks; b += FIN_LANES) ls += (double)partial[(int64_t)b * C + c];
+        for (int b = ln; b < nblocks; b += LANES) ls += (double)partial[(int64_t)b * C + c];
     sh[ln][ch] = ls;
     __syncthreads();
     if (ln == 0 && c < C) {
         double s = 0.0;
-        for (int l = 0; l < FIN_LANES; ++l) s += sh[l][ch];
+        for (int l = 0; l < LANES; ++l) s += sh[l][ch];
         dbias[c] = (float)s;
     }
 }
