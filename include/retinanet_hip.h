@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RN_ABI_VERSION 5
+#define RN_ABI_VERSION 6
 #define RN_MAX_LEVELS 8
 
 enum rn_dtype { RN_F32 = 0, RN_BF16 = 1, RN_F16 = 2 };
@@ -458,6 +458,9 @@ int rn_conv3x3_canvas_dgrad_relu_batched(const void *const *gs, const void *cons
 /* The data gradient's weights of P convs: outs[p] [Cin][3][3][Cout] = ws[p] [Cout][3][3][Cin] with taps reversed and channel
  * roles swapped (16-bit elements, Cout % 32 == Cin % 32 == 0); one launch. */
 int rn_conv3x3_dgrad_weight_batched(const void *const *ws, void *const *outs, int P, int Cout, int Cin, void *stream);
+/* The same for n convolutions of different widths (couts[i], cins[i], multiples of 32) in one launch per 48: a training step
+ * flips the weights of all its 3x3 convolutions at once (pytorch_retinanet_amd/biasact.py: refresh_dgrad_weights). */
+int rn_conv3x3_dgrad_weight_many(const void *const *ws, void *const *outs, const int *couts, const int *cins, int n, void *stream);
 /* out[c] = sum over l and rows of xs[l][row][c] for L <= 6 dense row-major bf16 / f16 tensors [rows[l]][C] (C even: the
  * 810-channel logit gradients, the 36-channel box-delta gradients): the bias gradient of the class- / box-output conv.
  * f32 out[C], deterministic. */

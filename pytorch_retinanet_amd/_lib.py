@@ -115,6 +115,7 @@ SIGNATURES = {
                                           _sz, _vp]),
     "rn_conv3x3_canvas_batched_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _i64, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "rn_conv3x3_dgrad_weight_batched": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "rn_conv3x3_dgrad_weight_many": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp]),
     "rn_fpn_add_upsample2x": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "rn_fpn_upsample2x_backward": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "rn_canvas_pack": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),

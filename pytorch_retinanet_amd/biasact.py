@@ -13,6 +13,7 @@ after every layer.
 """
 import ctypes as C
 import os
+import weakref
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -269,9 +270,7 @@ class _TowerConvPair(torch.autograd.Function):
             link.ptrs, link.dbias, link.half = None, None, [None, None]
         dxs = [None, None]
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            wts = [torch.empty((Cin, Cout, 3, 3), dtype=w0.dtype, device=dev, memory_format=torch.channels_last) for _ in range(2)]
-            check(lib.rn_conv3x3_dgrad_weight_batched(_ptr_array([w0, w1]), _ptr_array(wts), 2, Cout, Cin, stream),
-                  "rn_conv3x3_dgrad_weight_batched")                   # [Cin, Cout, 3, 3], taps reversed: one launch for both
+            wts = dgrad_weights([w0, w1], stream)                      # [Cin, Cout, 3, 3], taps reversed (the step's table, or one launch for both)
             dxs = [torch.empty_like(x0), torch.empty_like(x1)]
             if prev is not None and prev.relu_masks is not None and Cin == Cout:
                 need = lib.rn_conv3x3_colsum_workspace_bytes(2, M, Cin)
@@ -527,6 +526,88 @@ def _layout(cv: "Canvas", n_images: int):
     for i, (h, w) in enumerate(cv.shapes):
         lay.hw[i] = h * w
     return C.byref(lay)
+
+
+# ---- the data-gradient weights of all 3x3 convolutions of a step in ONE launch -------------------------------------------------
+# A data gradient issued as a forward convolution needs the weight with its taps reversed and its channel roles swapped.  Flipping it
+# where it is needed costs a launch per convolution (18 per R50 step, ~4.7 us each on the step's critical path).  Instead every site
+# asks ``dgrad_weights``: a weight seen once is REGISTERED, and ``refresh_dgrad_weights()`` -- called by the model at the start of a
+# training forward -- flips all registered weights in one launch into persistent buffers.  An entry is used only while it is provably
+# current: same tensor object, same ``_version`` as when it was flipped, and no ``invalidate_dgrad_weights()`` since (this package's
+# optimizer writes parameters through raw pointers and calls it).
+DGRAD_WEIGHT_TABLE = os.environ.get("RN_DGRAD_WEIGHT_TABLE", "1") == "1"
+
+
+class _FlippedWeight:
+    __slots__ = ("ref", "flipped", "version", "epoch")
+
+    def __init__(self, w: Tensor):
+        self.ref = weakref.ref(w)
+        self.flipped = torch.empty((int(w.shape[1]), int(w.shape[0]), 3, 3), dtype=w.dtype, device=w.device, memory_format=torch.channels_last)
+        self.version, self.epoch = -1, -1
+
+
+_DW_TABLE: Dict[int, _FlippedWeight] = {}
+_DW_EPOCH = 0          # bumped by invalidate_dgrad_weights(): entries stamped with an older epoch are stale
+
+
+def invalidate_dgrad_weights() -> None:
+    "The parameters changed behind autograd's back (an optimizer that writes through raw pointers): nothing flipped so far is current."
+    global _DW_EPOCH
+    _DW_EPOCH += 1
+
+
+def _dw_eligible(w: Tensor) -> bool:
+    return (DGRAD_WEIGHT_TABLE and w.is_cuda and w.dtype in (torch.bfloat16, torch.float16) and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3)
+            and _cl(w) and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0)
+
+
+def refresh_dgrad_weights(device=None) -> int:
+    "Flip every registered weight (that still exists, on ``device`` if given) in one launch; -> how many."
+    live = []
+    for key in list(_DW_TABLE):
+        e = _DW_TABLE[key]
+        w = e.ref()
+        if w is None or not _dw_eligible(w) or w.device != e.flipped.device or tuple(e.flipped.shape[:2]) != (w.shape[1], w.shape[0]):
+            del _DW_TABLE[key]
+            continue
+        if device is None or w.device == torch.device(device):
+            live.append((w, e))
+    if not live:
+        return 0
+    dev = live[0][0].device
+    live = [(w, e) for w, e in live if w.device == dev]
+    if dev.index != torch.cuda.current_device():
+        torch.cuda.set_device(dev)
+    n = len(live)
+    check(lib.rn_conv3x3_dgrad_weight_many(_ptr_array([w for w, _ in live]), _ptr_array([e.flipped for _, e in live]),
+                                           _int_array([int(w.shape[0]) for w, _ in live]), _int_array([int(w.shape[1]) for w, _ in live]), n,
+                                           torch.cuda.current_stream(dev).cuda_stream), "rn_conv3x3_dgrad_weight_many")
+    for w, e in live:
+        e.version, e.epoch = w._version, _DW_EPOCH
+    return n
+
+
+def dgrad_weights(ws: Sequence[Tensor], stream: int) -> List[Tensor]:
+    """[Cin, Cout, 3, 3] data-gradient weights (taps reversed, roles swapped) of ``ws`` (all the same [Cout, Cin, 3, 3]): the step's table
+    where it is current, else flipped here in one launch (and registered for the next ``refresh_dgrad_weights``)."""
+    out: List[Optional[Tensor]] = []
+    for w in ws:
+        e = _DW_TABLE.get(id(w)) if DGRAD_WEIGHT_TABLE else None
+        ok = e is not None and e.ref() is w and e.version == w._version and e.epoch == _DW_EPOCH
+        out.append(e.flipped if ok else None)
+    todo = [i for i, t in enumerate(out) if t is None]
+    if todo:
+        Cout, Cin = int(ws[0].shape[0]), int(ws[0].shape[1])
+        srcs = [ws[i] if _cl(ws[i]) else ws[i].contiguous(memory_format=torch.channels_last) for i in todo]
+        dsts = [torch.empty((Cin, Cout, 3, 3), dtype=ws[i].dtype, device=ws[i].device, memory_format=torch.channels_last) for i in todo]
+        check(lib.rn_conv3x3_dgrad_weight_batched(_ptr_array(srcs), _ptr_array(dsts), len(todo), Cout, Cin, stream), "rn_conv3x3_dgrad_weight_batched")
+        for i, d in zip(todo, dsts):
+            out[i] = d
+            w = ws[i]
+            if _dw_eligible(w) and w.is_leaf and id(w) not in _DW_TABLE:
+                _DW_TABLE[id(w)] = _FlippedWeight(w)              # (a parameter: flipped with the others from the next step on)
+    return out
 
 
 def _dgrad_weight(w: Tensor) -> Tensor:
@@ -823,8 +904,7 @@ class _DenseConvGroup(torch.autograd.Function):
         gs = [dy if (dy.dtype == torch.bfloat16 and _cl(dy)) else dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for dy in dys]
         dxs = [None] * P
         if any(ctx.needs_input_grad[:P]):
-            wts = [torch.empty((256, 256, 3, 3), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last) for _ in range(P)]
-            check(lib.rn_conv3x3_dgrad_weight_batched(_ptr_array(ws), _ptr_array(wts), P, 256, 256, stream), "rn_conv3x3_dgrad_weight_batched")
+            wts = dgrad_weights(list(ws), stream)
             dxs = [torch.empty_like(x) for x in xs]
             _mfma_call(f"mfma_fpn_output_dgrad_x{P}", dev, flop,
                        lambda: lib.rn_conv3x3_dense_batched(_ptr_array(gs), _ptr_array(wts), None, _ptr_array(dxs), P, RN_BF16, N,
@@ -901,8 +981,7 @@ class _Conv3x3MfmaBwd(torch.autograd.Function):
         flop = 2.0 * N * h * wd * 256 * 2304
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            wt = torch.empty((256, 256, 3, 3), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
-            check(lib.rn_conv3x3_dgrad_weight_batched(_ptr_array([wc]), _ptr_array([wt]), 1, 256, 256, stream), "rn_conv3x3_dgrad_weight_batched")
+            wt = dgrad_weights([w], stream)[0]
             dx = torch.empty_like(x)
             _mfma_call("mfma_conv2_dgrad", dev, flop,
                        lambda: lib.rn_conv3x3_dense_batched(_ptr_array([g]), _ptr_array([wt]), None, _ptr_array([dx]), 1, RN_BF16, N,
@@ -977,10 +1056,7 @@ def conv3x3_dgrad_as_fwd(g: Tensor, w: Tensor) -> Tensor:
     if dev.index != torch.cuda.current_device():
         torch.cuda.set_device(dev)
     stream = torch.cuda.current_stream().cuda_stream
-    wc = w if _cl(w) else w.contiguous(memory_format=torch.channels_last)
-    Cout, Cin = int(w.shape[0]), int(w.shape[1])
-    wt = torch.empty((Cin, Cout, 3, 3), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
-    check(lib.rn_conv3x3_dgrad_weight_batched(_ptr_array([wc]), _ptr_array([wt]), 1, Cout, Cin, stream), "rn_conv3x3_dgrad_weight_batched")
+    wt = dgrad_weights([w], stream)[0]
     gc = g if (g.dtype == torch.bfloat16 and _cl(g)) else g.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
     return conv3x3_same(gc, wt)
 

@@ -901,6 +901,35 @@ __global__ __launch_bounds__(256) void dgrad_weight_kernel(const WeightPrep a)
     }
 }
 
+// The same for a whole model's 3x3 convolutions of DIFFERENT widths in one launch (every dependent launch costs ~4.7 us of the
+// step's timeline, and a step flipped its weights in 18 of them): 1-D grid over the (entry, tap, 32 x 32 tile) units.
+constexpr int DW_MANY_MAX = 48;
+struct WeightPrepMany { const uint16_t *w[DW_MANY_MAX]; uint16_t *out[DW_MANY_MAX]; int cout[DW_MANY_MAX], cin[DW_MANY_MAX], first[DW_MANY_MAX + 1]; int n; };
+__global__ __launch_bounds__(256) void dgrad_weight_many_kernel(const WeightPrepMany a)
+{
+    __shared__ uint16_t tile[32][34];
+    int e = 0;
+    while (e + 1 < a.n && (int)blockIdx.x >= a.first[e + 1]) ++e;     // (block-uniform)
+    const int Cout = a.cout[e], Cin = a.cin[e];
+    int u = (int)blockIdx.x - a.first[e];
+    const int t = u % 9; u /= 9;
+    const int co0 = (u % (Cout / 32)) * 32, ci0 = (u / (Cout / 32)) * 32;
+    const uint16_t *__restrict__ w = a.w[e];
+    uint16_t *__restrict__ out = a.out[e];
+    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + 8 * k;                                  // co offset
+        tile[r][c] = w[((int64_t)(co0 + r) * 9 + t) * Cin + ci0 + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + 8 * k;                                  // ci offset
+        out[((int64_t)(ci0 + r) * 9 + (8 - t)) * Cout + co0 + c] = tile[c][r];
+    }
+}
+
 // Pack the per-level tensors [n_images][h][w][C] onto the canvas sheets [N][Hp][Wp][C] (gaps zeroed) or unpack them, through
 // the position map: one launch instead of a zero fill plus one strided copy per (level, slot) -- 11 launches for five levels on
 // two-image sheets, four times per step.  UNIT = bytes per thread item (16, 8 or 4: C * 2 must be a multiple).
@@ -1101,6 +1130,28 @@ RN_API int rn_conv3x3_dgrad_weight_batched(const void *const *ws, void *const *o
     hipLaunchKernelGGL(dgrad_weight_kernel, dim3((unsigned)(9 * P), (unsigned)(Cout / 32), (unsigned)(Cin / 32)), dim3(256), 0,
                        (hipStream_t)stream, a);
     RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+RN_API int rn_conv3x3_dgrad_weight_many(const void *const *ws, void *const *outs, const int *couts, const int *cins, int n, void *stream)
+{
+    if (!ws || !outs || !couts || !cins || n <= 0) return RN_EINVAL;
+    for (int i0 = 0; i0 < n; i0 += DW_MANY_MAX) {
+        WeightPrepMany a = {};
+        a.n = n - i0 < DW_MANY_MAX ? n - i0 : DW_MANY_MAX;
+        int blocks = 0;
+        for (int i = 0; i < a.n; ++i) {
+            const int q = i0 + i;
+            if (!ws[q] || !outs[q] || ws[q] == outs[q] || couts[q] <= 0 || cins[q] <= 0) return RN_EINVAL;
+            if (couts[q] % 32 || cins[q] % 32) return RN_EUNSUPPORTED;
+            a.w[i] = (const uint16_t *)ws[q]; a.out[i] = (uint16_t *)outs[q]; a.cout[i] = couts[q]; a.cin[i] = cins[q];
+            a.first[i] = blocks;
+            blocks += 9 * (couts[q] / 32) * (cins[q] / 32);
+        }
+        a.first[a.n] = blocks;
+        hipLaunchKernelGGL(dgrad_weight_many_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+        RN_LAUNCH_CHECK();
+    }
     return RN_OK;
 }
 

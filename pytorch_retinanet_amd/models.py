@@ -127,6 +127,9 @@ class Retinanet(nn.Module):
         batch = images.tensors
         if self.backbone.backbone.conv1.weight.is_contiguous(memory_format=torch.channels_last):
             batch = batch.contiguous(memory_format=torch.channels_last)        # no-op after the fused transform
+        if batch.is_cuda and self.training and torch.is_grad_enabled():
+            from . import biasact
+            biasact.refresh_dgrad_weights(batch.device)            # the backward pass's flipped 3x3 weights: one launch for the whole model
         feature_maps = self.fpn(self.backbone(batch))
         anchors = self.anchor_generator(images, feature_maps)
         # K2 (IoU + matcher) needs only the anchors and the GT boxes: it goes out on a side stream here and runs beside the

@@ -123,4 +123,6 @@ class MasterSGD(torch.optim.Optimizer):
                                              float(group["momentum"]), float(group["dampening"]), float(group["weight_decay"]),
                                              int(group["nesterov"]), int(bool(first)), torch.cuda.current_stream().cuda_stream),
                       "rn_sgd_master_step")
+        from . import biasact
+        biasact.invalidate_dgrad_weights()           # (the kernel wrote the parameters through raw pointers: no version counter moved)
         return loss

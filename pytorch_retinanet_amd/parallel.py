@@ -233,6 +233,11 @@ class BucketedGradAllReduce:
                     t.data.copy_(t.master)
                 else:
                     dist.broadcast(t.data, src=src, group=self.group)
+        try:
+            from . import biasact
+            biasact.invalidate_dgrad_weights()       # (.data writes do not move the parameters' version counters)
+        except (ImportError, OSError, RuntimeError):              # CPU-only host (gloo tests): no HIP library, nothing cached
+            pass
 
     @property
     def num_buckets(self) -> int:

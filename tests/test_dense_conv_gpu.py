@@ -222,3 +222,51 @@ def test_narrow_forward_matches_torch(N, hw):
     assert torch.equal(y2, want)
     # other channel counts and dtypes are declined, not mis-computed
     assert not biasact.narrow_fwd_ok(x[:, :32], w[:, :32]) and not biasact.narrow_fwd_ok(x.float(), w.float())
+
+
+def test_step_table_of_flipped_weights_is_used_only_while_current():
+    "biasact.refresh_dgrad_weights: one launch flips every registered 3x3 weight; an entry serves a backward pass only while it is current."
+    from pytorch_retinanet_amd import biasact
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    convs = [nn.Conv2d(c, c, 3, 1, 1, bias=False).to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last) for c in (64, 128, 64)]
+    xs = [torch.randn((2, c.in_channels, 9, 13), device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for c in convs]
+
+    def dx_of(conv, x):
+        x = x.detach().requires_grad_()
+        biasact.conv3x3_dgrad_fwd(conv, x).sum().backward()
+        return x.grad
+
+    def want(conv, x):
+        xf = x.detach().float().requires_grad_()
+        F.conv2d(xf, conv.weight.detach().float(), None, 1, 1).sum().backward()
+        return xf.grad
+
+    st = torch.cuda.current_stream().cuda_stream
+    for c, x in zip(convs, xs):                            # first use: flipped on the spot, registered
+        assert _rel(dx_of(c, x), want(c, x)) < 4e-3
+    assert all(id(c.weight) in biasact._DW_TABLE for c in convs)
+    assert biasact.refresh_dgrad_weights(dev) >= 3
+    for c in convs:                                        # the table's entries are the flipped weights, bit for bit
+        e = biasact._DW_TABLE[id(c.weight)]
+        assert biasact.dgrad_weights([c.weight], st)[0] is e.flipped
+        assert torch.equal(e.flipped, c.weight.detach().flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last))
+    for c, x in zip(convs, xs):
+        assert _rel(dx_of(c, x), want(c, x)) < 4e-3
+    # an in-place update autograd sees (version counter) retires the entry without a refresh ...
+    with torch.no_grad():
+        convs[0].weight.mul_(-2.0)
+    assert biasact.dgrad_weights([convs[0].weight], st)[0] is not biasact._DW_TABLE[id(convs[0].weight)].flipped
+    assert _rel(dx_of(convs[0], xs[0]), want(convs[0], xs[0])) < 4e-3
+    # ... a write behind its back (raw pointers: this package's optimizer) needs invalidate_dgrad_weights()
+    biasact.refresh_dgrad_weights(dev)
+    convs[1].weight.data.mul_(3.0)
+    biasact.invalidate_dgrad_weights()
+    assert _rel(dx_of(convs[1], xs[1]), want(convs[1], xs[1])) < 4e-3
+    # a weight that no longer exists leaves the table at the next refresh
+    key = id(convs[2].weight)
+    del convs[2:], c, e
+    import gc
+    gc.collect()
+    biasact.refresh_dgrad_weights(dev)
+    assert key not in biasact._DW_TABLE
