@@ -203,8 +203,6 @@ RN_API int rn_conv3x3_narrow_forward(const void *x, const void *w, void *y, int 
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     // two workgroups per CU: bands so that (images x strips x bands) fills them once (a band re-stages two halo rows)
     int bands = (2 * cus) / (N * a.strips);
-    static const int bands_env = getenv("RN_N3_BANDS") ? atoi(getenv("RN_N3_BANDS")) : 0;      // (experiments)
-    if (bands_env > 0) bands = bands_env;
     if (bands < 1) bands = 1;
     if (bands > H) bands = H;
     a.rows_per_band = (H + bands - 1) / bands;
