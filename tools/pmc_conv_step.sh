@@ -15,7 +15,7 @@ agg = defaultdict(lambda: defaultdict(list))
 for f in glob.glob("/tmp/pc/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if any(k in n for k in ("conv3x3_canvas_kernel", "conv3x3_wgrad_kernel", "stem_fwd_kernel", "stem_wgrad_kernel", "wgrad3x3_kernel", "pw_gemm_kernel<128, 1, 1>")):
+        if any(k in n for k in ("conv3x3_canvas_kernel", "conv3x3_wgrad_kernel", "stem_fwd_kernel", "stem_wgrad_kernel", "wgrad3x3_kernel", "conv3x3_narrow64_kernel", "pw_gemm_kernel<128, 1, 1>")):
             agg[n[:95]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in sorted(agg.items()):
     print(k)
