@@ -71,7 +71,13 @@ def conv_bn(conv: nn.Conv2d, bn: FusedBatchNorm2d, x: Tensor, relu: bool = False
     if FOLD_FROZEN_BN and not bn.training and not torch.is_grad_enabled() and x.is_cuda and bn.track_running_stats:
         dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
         w, b, ones, zeros, var1 = _folded(conv, bn, dt)
-        y = F.conv2d(x.to(dt), w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        from . import biasact
+        xd = x.to(dt)
+        if (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+                and biasact.narrow_fwd_ok(xd, w)):
+            y = biasact.conv3x3_narrow_forward(xd, w)              # 64 channels: csrc/narrow3x3.hip (conv2 of the layer1 bottlenecks)
+        else:
+            y = F.conv2d(xd, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
         if bn._fusable(y, residual):
             return _BNAct.apply(y, residual, ones, b, zeros, var1, None, False, 0.0, bn.eps, relu)
         y = y + b.to(y.dtype)[None, :, None, None]

@@ -148,22 +148,40 @@ __global__ __launch_bounds__(N3_THREADS, 2) void conv3x3_narrow64_kernel(const N
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef N3_READ
-        // D[channel][pixel]: lane = pixel (lane & 31), channels 8 g + 4 (lane >> 5) + j in acc[4 g + j].  v_permlane32_swap trades the
-        // halves of two channel groups between lanes l and l + 32, so that a lane stores 8 consecutive channels (16 bytes) of its pixel:
-        // lanes 0..31 the even group of the pair, lanes 32..63 the odd one -- 32 contiguous bytes per pixel and instruction.
+        // D[channel][pixel]: lane = pixel (lane & 31), channels 8 g + 4 (lane >> 5) + j in acc[4 g + j].  Three rounds of lane swaps turn
+        // that into full 16-byte chunks laid out for the store: (1) v_permlane32_swap between the two halves of a channel-group pair
+        // gives a lane 8 consecutive channels of its pixel (lanes 0..31 the even group, 32..63 the odd one); (2) the same swap between
+        // the two pairs and (3) v_permlane16_swap regroup the four 16-lane rows so that ONE store instruction carries all four chunks
+        // (64 contiguous bytes = this wave's 32 channels) of 16 pixels: row k of the wave writes chunk k.  (8-byte stores straight from
+        // the accumulators: +4 us per launch; 32-byte pieces, rounds 1 only: +1.)
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb) {
-            const int px = x0 + pw * 64 + pb * 32 + (lane & 31);
             if (x0 + pw * 64 + pb * 32 >= a.W) continue;          // (wave-uniform: the tile lies right of the image -- the count below relies on it)
-            uint16_t *const yp = a.y + (((int64_t)n * a.H + y) * a.W + px) * 64 + cw * 32 + 8 * kh;
+            uint32_t v[2][4];
 #pragma unroll
             for (int gp = 0; gp < 2; ++gp) {
                 const uint32_t ax = rn::dt<RN_BF16>::pk(acc[pb][8 * gp + 0], acc[pb][8 * gp + 1]), ay = rn::dt<RN_BF16>::pk(acc[pb][8 * gp + 2], acc[pb][8 * gp + 3]);
                 const uint32_t bx = rn::dt<RN_BF16>::pk(acc[pb][8 * gp + 4], acc[pb][8 * gp + 5]), by = rn::dt<RN_BF16>::pk(acc[pb][8 * gp + 6], acc[pb][8 * gp + 7]);
                 const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
                 const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-                if (px < a.W && (!(a.dbg & 1) || acc[pb][0] == 12345.678f))
-                    *(rn::u32x4 *)(yp + 16 * gp) = rn::u32x4{sx[0], sy[0], sx[1], sy[1]};
+                v[gp][0] = sx[0]; v[gp][1] = sy[0]; v[gp][2] = sx[1]; v[gp][3] = sy[1];
+            }
+            // rows of 16 lanes: v[0] = [px 0-15 chunk 0 | px 16-31 chunk 0 | px 0-15 chunk 1 | px 16-31 chunk 1], v[1] the same for chunks 2, 3
+            uint32_t lo[4], hi[4];                                  // lo: pixels 0..15 of the tile, hi: pixels 16..31; row k = chunk k
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const auto t = __builtin_amdgcn_permlane32_swap(v[0][d], v[1][d], false, false);
+                const auto u = __builtin_amdgcn_permlane16_swap(t[0], t[1], false, false);
+                lo[d] = u[0]; hi[d] = u[1];
+            }
+            const int chunk = lane >> 4;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int px = x0 + pw * 64 + pb * 32 + 16 * h + (lane & 15);
+                if (px < a.W && (!(a.dbg & 1) || acc[pb][0] == 12345.678f)) {
+                    uint16_t *const yp = a.y + (((int64_t)n * a.H + y) * a.W + px) * 64 + cw * 32 + 8 * chunk;
+                    *(rn::u32x4 *)yp = h ? rn::u32x4{hi[0], hi[1], hi[2], hi[3]} : rn::u32x4{lo[0], lo[1], lo[2], lo[3]};
+                }
             }
         }
         // The staged row has landed: vmcnt counts loads and stores in issue order on gfx9, so everything but the stores just issued
