@@ -605,7 +605,8 @@ def dgrad_weights(ws: Sequence[Tensor], stream: int) -> List[Tensor]:
         for i, d in zip(todo, dsts):
             out[i] = d
             w = ws[i]
-            if _dw_eligible(w) and w.is_leaf and id(w) not in _DW_TABLE:
+            stale = _DW_TABLE.get(id(w))                         # (an id is reused once its tensor is gone: replace such an entry)
+            if _dw_eligible(w) and w.is_leaf and (stale is None or stale.ref() is not w):
                 _DW_TABLE[id(w)] = _FlippedWeight(w)              # (a parameter: flipped with the others from the next step on)
     return out
 

@@ -245,7 +245,7 @@ def test_step_table_of_flipped_weights_is_used_only_while_current():
     st = torch.cuda.current_stream().cuda_stream
     for c, x in zip(convs, xs):                            # first use: flipped on the spot, registered
         assert _rel(dx_of(c, x), want(c, x)) < 4e-3
-    assert all(id(c.weight) in biasact._DW_TABLE for c in convs)
+    assert all(biasact._DW_TABLE[id(c.weight)].ref() is c.weight for c in convs)
     assert biasact.refresh_dgrad_weights(dev) >= 3
     for c in convs:                                        # the table's entries are the flipped weights, bit for bit
         e = biasact._DW_TABLE[id(c.weight)]
