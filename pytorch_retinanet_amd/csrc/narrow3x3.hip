@@ -3,13 +3,13 @@
 //
 //   y[n][h][w][co] = sum over (dy, dx, ci) of x[n][h + dy - 1][w + dx - 1][ci] * w[co][dy][dx][ci]        (fp32 accumulation)
 //
-// Why a kernel of its own (VERDICT r3 item 3): the 256-channel implicit-GEMM kernels of conv.hip would idle 3/4 of every MFMA at 64 output
+// Why a kernel of its own: the 256-channel implicit-GEMM kernels of conv.hip would idle 3/4 of every MFMA at 64 output
 // channels, and a GEMM formulation re-reads every input pixel once per tap (pw_gemm's 3x3 mode: 42 flop per byte of L2 -> LDS traffic).
 // CK's grouped-conv kernel, which MIOpen picks, runs the layer1 shape (8 x 200 x 336 x 64: 39.6 GFLOP, 69 MB in, 69 MB out) in 76 us.
 // Here the WEIGHTS live in registers and the pixels in a ring of input rows:
 //   * a wave owns 32 output channels x 64 pixels of an image row: its 32 x 576 weight block is 36 A-fragments of
 //     v_mfma_f32_32x32x16_bf16 = 144 registers, loaded once per workgroup (rows = output channels, so D is [channel][pixel] and a lane ends
-//     up with 4 CONSECUTIVE channels of a pixel: 8-byte stores, no LDS transpose);
+//     up with 4 CONSECUTIVE channels of a pixel; three lane swaps make that 16-byte chunks in store order, no LDS transpose);
 //   * a workgroup (4 waves: 2 channel halves x 2 pixel halves) walks a band of output rows of one 128-pixel column strip; every input row
 //     is staged ONCE per band (130 pixels x 128 bytes by LDS-DMA, 16-byte chunks XOR-swizzled by pixel pair: conflict-free ds_read_b128) into a ring
 //     of four rows, the three vertical taps read three ring rows, the three horizontal taps the same row one pixel further;
