@@ -73,6 +73,9 @@ def conv_bn(conv: nn.Conv2d, bn: FusedBatchNorm2d, x: Tensor, relu: bool = False
         w, b, ones, zeros, var1 = _folded(conv, bn, dt)
         from . import biasact
         xd = x.to(dt)
+        if pwconv.eval_conv1x1_ok(conv, xd, w, residual):
+            # 1x1: the folded bias, the identity branch and the ReLU ride in the GEMM's epilogue -- no pass over the output at all
+            return pwconv.eval_conv1x1(conv, xd, w, b, relu, residual)
         if (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
                 and biasact.narrow_fwd_ok(xd, w)):
             y = biasact.conv3x3_narrow_forward(xd, w)              # 64 channels: csrc/narrow3x3.hip (conv2 of the layer1 bottlenecks)

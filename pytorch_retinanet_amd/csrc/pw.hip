@@ -32,7 +32,7 @@ constexpr int PW_MAX_GX = 512;                  // persistent row-tile walkers =
 #define PW_SWZ(row) (((row) >> 1) & 7)
 
 enum { PRO_NONE = 0, PRO_AFFINE_RELU = 1, PRO_BN_BWD = 2 };
-enum { EPI_STATS = 1, EPI_RESID = 2, EPI_RELU_BWD = 4 };
+enum { EPI_STATS = 1, EPI_RESID = 2, EPI_RELU_BWD = 4, EPI_BIAS = 8 };
 
 __device__ __forceinline__ float alive_bf16() { return __uint_as_float(0x00004000u); }   // norm.hip: relu_alive_threshold<RN_BF16>
 
@@ -50,6 +50,8 @@ struct PwArgs {
                                     //          joins the rows with even (y, x) only (the data gradient of a 1x1 / stride-2 convolution)
     const uint16_t *Zp;             // EPI_RELU_BWD: Y = Y * [fma(Zp, ea, eb) > alive]; sums of Y and Y * (Zp - emean) * einv
     const float *ea, *eb, *emean, *einv;
+    const float *bias;              // EPI_BIAS: Y = act(acc + bias[n] (+ R)), act = ReLU when relu_out (inference: a folded BatchNorm + residual + ReLU)
+    int relu_out;
     int M, Cin, N, taps;            // M output rows; K = taps * Cin
     int relu_mode;                  // PRO_BN_BWD: 0 none, 2 recomputed from X2, 3 bits
     int stride, pad, Ho, Wo, H, W_; // position decode of output row m = (n, ho, wo) -> input (n, ho * stride - pad + dy, ...)
@@ -223,6 +225,8 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
     }
     const float alive = alive_bf16();
 
+    float ebias[8];                                             // EPI_BIAS: this thread's 8 fixed columns of the bias
+    if (EPI & EPI_BIAS) ld8f(a.bias + n0 + ecg * 8, ebias);
     int mt = blockIdx.x;
     if (mt < MT) {
 #pragma unroll
@@ -314,11 +318,19 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
                 float v[8];
                 ld8f(tile + row * BN + ecg * 8, v);
                 const int64_t e = (int64_t)m * a.N + n0 + ecg * 8;
+                if (EPI & EPI_BIAS) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += ebias[j];
+                }
                 if (EPI & EPI_RESID) {
                     float r[8];
                     rn::dt<RN_BF16>::unpack(er[i], r);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] += ((ebits[i] >> j) & 1u) ? r[j] : 0.0f;
+                }
+                if ((EPI & EPI_BIAS) && a.relu_out) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
                 }
                 rn::u32x4 o = rn::dt<RN_BF16>::pack(v);
                 if (EPI & (EPI_STATS | EPI_RELU_BWD)) {
@@ -616,6 +628,8 @@ template <int BN, int PRO> int dispatch_epi(const PwArgs &a, const int epi, hipS
         case EPI_STATS: return launch_gemm<BN, PRO, EPI_STATS>(a, st);
         case EPI_RESID: return launch_gemm<BN, PRO, EPI_RESID>(a, st);
         case EPI_RELU_BWD: return launch_gemm<BN, PRO, EPI_RELU_BWD>(a, st);
+        case EPI_BIAS: if (PRO == PRO_NONE) return launch_gemm<BN, PRO_NONE, EPI_BIAS>(a, st); return RN_EUNSUPPORTED;
+        case EPI_BIAS | EPI_RESID: if (PRO == PRO_NONE) return launch_gemm<BN, PRO_NONE, EPI_BIAS | EPI_RESID>(a, st); return RN_EUNSUPPORTED;
         default: return RN_EUNSUPPORTED;
     }
 }
@@ -722,8 +736,13 @@ RN_API int rn_pw_conv_forward(const rn_pw_conv *d, const void *x, const void *w,
     }
     if (epi && epi->kind != 0) {
         e = epi->kind;
-        if (e == EPI_STATS) { if (!epi->partial) return RN_EINVAL; a.partial = epi->partial; }
-        else if (e == EPI_RESID) {
+        if (e & EPI_BIAS) {                                       // (inference epilogue: alone or with an unmasked residual)
+            if (!epi->bias || (e & ~(EPI_BIAS | EPI_RESID)) || !rn::aligned(epi->bias, 16)) return RN_EINVAL;
+            a.bias = epi->bias; a.relu_out = epi->relu ? 1 : 0;
+        }
+        if (e == EPI_BIAS) { }
+        else if (e == EPI_STATS) { if (!epi->partial) return RN_EINVAL; a.partial = epi->partial; }
+        else if ((e & ~EPI_BIAS) == EPI_RESID) {
             if (!epi->resid) return RN_EINVAL;
             if (epi->res_stride != 0 && epi->res_stride != 1 && epi->res_stride != 2) return RN_EUNSUPPORTED;
             a.R = (const uint16_t *)epi->resid; a.rbits = epi->rbits; a.rs = epi->res_stride == 2 ? 2 : 1;

@@ -29,7 +29,7 @@ import torch.nn.functional as F
 from torch import Tensor
 
 from . import norm
-from ._lib import (RN_BF16, RN_PW_EPI_RELU_BWD, RN_PW_EPI_RESID, RN_PW_EPI_STATS, RN_PW_PRO_AFFINE_RELU, RN_PW_PRO_BN_BWD,
+from ._lib import (RN_BF16, RN_PW_EPI_BIAS, RN_PW_EPI_RELU_BWD, RN_PW_EPI_RESID, RN_PW_EPI_STATS, RN_PW_PRO_AFFINE_RELU, RN_PW_PRO_BN_BWD,
                    RnPwConv, RnPwEpilogue, RnPwPrologue, check, lib)
 from .ops import _timed
 
@@ -90,6 +90,44 @@ def pw_forward(x: Tensor, w: Tensor, stride: int = 1, pro: Optional[RnPwPrologue
         check(lib.rn_pw_conv_forward(C.byref(d), x.data_ptr(), w.data_ptr(), y.data_ptr(), C.byref(pro) if pro is not None else None,
                                      C.byref(epi) if epi is not None else None, st), "rn_pw_conv_forward")
     return y
+
+
+def bias_act_epilogue(bias: Tensor, relu: bool, residual: Optional[Tensor] = None) -> RnPwEpilogue:
+    "y = act(conv + bias[n] (+ residual)), act = ReLU when ``relu`` -- the GEMM's epilogue (inference: folded BatchNorm + identity + ReLU)."
+    e = RnPwEpilogue(RN_PW_EPI_BIAS | (RN_PW_EPI_RESID if residual is not None else 0), 0, residual.data_ptr() if residual is not None else 0)
+    e.relu, e.bias = int(bool(relu)), bias.data_ptr()
+    return e
+
+
+# Inference with frozen BatchNorm (backbone.conv_bn): a 1x1 convolution with its folded bias, the identity branch and the ReLU as ONE
+# GEMM -- csrc/pw.hip where its contraction is short, hipBLASLt's bias / bias + ReLU epilogue where it is long (pw_gemm is 2 x behind
+# hipBLASLt at 1024 - 2048 input channels, tools/pw_gemm_probe.py) -- instead of MIOpen's convolution + an epilogue pass over its output
+# (R101 predict at 16 x 1344^2: 9 ms of 37 in those passes, 6.5 of them behind conv3).
+EVAL_1X1_FUSED = True
+
+
+def eval_conv1x1_ok(conv, x: Tensor, w: Tensor, residual: Optional[Tensor]) -> bool:
+    if not (EVAL_1X1_FUSED and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 4 and _cl(x) and _cl(w)):
+        return False
+    if conv.kernel_size != (1, 1) or conv.padding != (0, 0) or conv.dilation != (1, 1) or conv.groups != 1 or conv.stride not in ((1, 1), (2, 2)):
+        return False
+    Cout, Cin = int(w.shape[0]), int(w.shape[1])
+    if Cin % 64 or Cout % 64 or x.shape[0] * x.shape[2] * x.shape[3] >= (1 << 31):
+        return False
+    return residual is None or (residual.dtype == torch.bfloat16 and _cl(residual))
+
+
+def eval_conv1x1(conv, x: Tensor, w: Tensor, bias: Tensor, relu: bool, residual: Optional[Tensor]) -> Tensor:
+    "``act(conv2d(x, w, stride) + bias (+ residual))`` for a 1x1 convolution: one GEMM with the rest in its epilogue."
+    s = int(conv.stride[0])
+    N, Cin, H, W = x.shape
+    Cout = int(w.shape[0])
+    if s == 1 and residual is None and MM_1X1 and _fwd_by_mm(N * H * W, Cin, Cout):
+        x2, w2 = x.permute(0, 2, 3, 1).reshape(-1, Cin), w.reshape(Cout, Cin)
+        b16 = bias.to(x.dtype)
+        y2 = torch._addmm_activation(b16, x2, w2.t()) if relu else torch.addmm(b16, x2, w2.t())
+        return y2.view(N, H, W, Cout).permute(0, 3, 1, 2)
+    return pw_forward(x, w, stride=s, epi=bias_act_epilogue(bias, relu, residual), tag="pw_eval_1x1")
 
 
 def stats_epilogue(M: int, n_out: int, dev: torch.device) -> Tuple[RnPwEpilogue, Tensor, int]:

@@ -413,3 +413,70 @@ def test_bn_relu_inside_maxpool_equals_the_two_pass_form():
             check(lib.rn_maxpool3x3s2_forward(a.data_ptr(), y.data_ptr(), arg.data_ptr(), RN_BF16, N, H, W, Cc, st), "pool")
         outs.append((y, arg))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("shape,cout,stride,relu,with_res", [
+    ((2, 64, 37, 45), 256, 1, True, True),        # conv3 of a layer1 block: + identity, ReLU
+    ((2, 256, 37, 45), 64, 1, True, False),       # conv1: bias + ReLU
+    ((2, 256, 38, 46), 512, 2, False, False),     # the downsample branch: stride 2, no ReLU
+    ((1, 512, 9, 11), 2048, 1, True, True),       # layer4 conv3 (two column tiles of 128 per 256 ... sixteen)
+    ((3, 128, 5, 7), 192, 1, False, True),        # 64-wide column tiles, residual without ReLU
+])
+def test_forward_with_bias_residual_relu_epilogue(shape, cout, stride, relu, with_res):
+    "Inference epilogue (folded BatchNorm + identity + ReLU, backbone.py:118-136 under eval()): act(conv + bias (+ residual)), one rounding."
+    from pytorch_retinanet_amd import pwconv
+    x = _rand(shape, 1.0, 1)
+    w = _rand((cout, shape[1], 1, 1), 0.05, 2)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    bias = torch.randn(cout, device=DEV, generator=gen)
+    ref = F.conv2d(x.float(), w.float(), bias, stride)
+    res = _rand(tuple(ref.shape), 1.0, 4) if with_res else None
+    if res is not None:
+        ref = ref + res.float()
+    if relu:
+        ref = F.relu(ref)
+    y = pwconv.pw_forward(x, w, stride=stride, epi=pwconv.bias_act_epilogue(bias, relu, res))
+    assert y.shape == ref.shape and y.dtype == torch.bfloat16
+    _close(y, ref, 6e-3, "bias / residual / ReLU epilogue")
+    if relu:
+        assert float(y.float().min()) >= 0.0
+    # the epilogue is exclusive with the training epilogues and prologues
+    from pytorch_retinanet_amd._lib import RN_PW_EPI_BIAS, RN_PW_EPI_STATS, RnPwEpilogue, lib
+    bad = RnPwEpilogue(RN_PW_EPI_BIAS | RN_PW_EPI_STATS, 0)
+    bad.bias = bias.data_ptr()
+    with pytest.raises(RuntimeError):
+        pwconv.pw_forward(x, w, stride=stride, epi=bad)
+
+
+def test_frozen_bn_bottleneck_runs_its_1x1_convs_with_fused_epilogues():
+    "backbone.conv_bn under eval(): the GEMM-epilogue path == the convolution + epilogue-pass path == the fp32 block (backbone.py:118-136)."
+    from pytorch_retinanet_amd import backbone, pwconv
+    torch.manual_seed(5)
+    for inpl, planes, stride, hw in ((256, 64, 1, (19, 27)), (256, 128, 2, (18, 26)), (1024, 256, 1, (9, 13)), (2048, 512, 1, (5, 7))):
+        ds = None
+        if stride != 1 or inpl != planes * 4:
+            ds = torch.nn.Sequential(torch.nn.Conv2d(inpl, planes * 4, 1, stride, bias=False), backbone.FusedBatchNorm2d(planes * 4))
+        blk = backbone.Bottleneck(inpl, planes, stride, ds).to(DEV).to(memory_format=torch.channels_last)
+        for m in blk.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0.0, 0.2); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0.0, 0.2)
+        blk.eval()
+        x = _rand((2, inpl, *hw), 1.0, 6)
+        with torch.no_grad():
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                pwconv.EVAL_1X1_FUSED = True
+                y1 = blk(x)
+                pwconv.EVAL_1X1_FUSED = False
+                try:
+                    y0 = blk(x)
+                finally:
+                    pwconv.EVAL_1X1_FUSED = True
+            backbone.FOLD_FROZEN_BN = False
+            try:
+                yf = blk(x.float())                                  # fp32, BatchNorm applied layer by layer
+            finally:
+                backbone.FOLD_FROZEN_BN = True
+        assert y1.dtype == torch.bfloat16 and y1.shape == y0.shape == yf.shape
+        e1 = float((y1.float() - yf).norm() / yf.norm())
+        e0 = float((y0.float() - yf).norm() / yf.norm())
+        assert e1 <= max(1.15 * e0, 6e-3), (inpl, planes, stride, e1, e0)   # one rounding less per convolution: not further from fp32 than the two-pass path
