@@ -24,8 +24,10 @@ namespace {
 
 using rn::f32x4;
 
-constexpr int MED_CAP = 2048;      // 256 threads, 58 KiB LDS
+constexpr int MED_CAP = 2048;      // sorted and suppressed in LDS (nms_lds_body)
 constexpr int BIG_THREADS = 1024;
+constexpr int MASK_CAP = 256;      // boxes per suppression-matrix tile
+constexpr int MASK_WORDS = MASK_CAP / 64;
 
 __device__ __forceinline__ bool overlaps(const f32x4 bi, const float ai, const f32x4 bj, const float aj, const float thr)
 {
@@ -101,6 +103,93 @@ __device__ __forceinline__ int block_excl_scan(int *s_scan, const int mine, int 
     return s_scan[threadIdx.x];
 }
 
+// Steps 2 and 3 of the blocked greedy scan (nms_lds_body, nms_big_body) on one tile of m <= MASK_CAP sorted boxes in LDS.
+// tile_matrix: bit j of mask[i][w] (j = 64 w + bit) <=> j > i and IoU(i, j) > thr; a wave takes every NW-th row, its lanes keep column
+// j = 64 w + lane of every word in registers, the row's box is one LDS broadcast, lane w collects word w (as nms_mask_kernel).
+template <int NW>
+__device__ __forceinline__ void tile_matrix(const f32x4 *s_box, const float *s_area, const int m, uint64_t (*s_mask)[MASK_WORDS], const float thr)
+{
+    const int lane = threadIdx.x & (RN_WAVE - 1), wave = threadIdx.x / RN_WAVE;
+    const int nw = (m + 63) >> 6;
+    f32x4 bj[MASK_WORDS];
+    float aj[MASK_WORDS];
+#pragma unroll
+    for (int w = 0; w < MASK_WORDS; ++w) {
+        const int j = min(w * 64 + lane, m - 1);
+        bj[w] = s_box[j]; aj[w] = s_area[j];
+    }
+    for (int i = wave; i < m; i += NW) {
+        const f32x4 bi = s_box[i];
+        const float ai = s_area[i];
+        const int w0 = (i + 1) >> 6;
+        uint64_t mine = 0ull;
+#pragma unroll
+        for (int w = 0; w < MASK_WORDS; ++w) {
+            if (w >= w0 && w < nw) {                                      // wave-uniform
+                const int j = w * 64 + lane;
+                const bool live = j > i && j < m;
+                const bool sup = overlaps_wave(bi, ai, bj[w], aj[w], thr, live) && live;
+                const unsigned long long mm = __ballot(sup);
+                if (lane == w) mine = mm;
+            }
+        }
+        if (lane < MASK_WORDS) s_mask[i][lane] = mine;
+    }
+}
+
+// tile_scan (wave 0; call after a barrier): the greedy scan over the tile's matrix with the "removed" set in SGPRs, starting from
+// the boxes already removed (supp[i] != 0: suppressed by a box kept in an earlier tile), visiting only rows that suppress something;
+// keepw[w] = the tile's kept boxes as bits.
+__device__ __forceinline__ void tile_scan(uint64_t (*s_mask)[MASK_WORDS], const uint8_t *s_supp, const int m, uint64_t *s_keepw)
+{
+    const int lane = threadIdx.x & (RN_WAVE - 1), wave = threadIdx.x / RN_WAVE;
+    if (wave != 0) return;
+    const int nw = (m + 63) >> 6;
+    uint64_t row[MASK_WORDS][MASK_WORDS];
+#pragma unroll
+    for (int wb = 0; wb < MASK_WORDS; ++wb)
+#pragma unroll
+        for (int ww = 0; ww < MASK_WORDS; ++ww) row[wb][ww] = (wb * 64 + lane < m && ww < nw) ? s_mask[wb * 64 + lane][ww] : 0ull;
+    uint64_t rem[MASK_WORDS];
+#pragma unroll
+    for (int w = 0; w < MASK_WORDS; ++w) rem[w] = __ballot(w * 64 + lane < m && s_supp[min(w * 64 + lane, m - 1)] != 0);
+#pragma unroll
+    for (int w = 0; w < MASK_WORDS; ++w) {
+        if (w * 64 < m) {
+            uint64_t any = 0;
+#pragma unroll
+            for (int ww = 0; ww < MASK_WORDS; ++ww) if (ww >= w) any |= row[w][ww];
+            uint64_t todo = __ballot(any != 0ull);
+            while (true) {
+                const uint64_t live = todo & ~rem[w];
+                if (!live) break;
+                const int bit = __builtin_ctzll(live);
+#pragma unroll
+                for (int ww = 0; ww < MASK_WORDS; ++ww)
+                    if (ww >= w) {
+                        const unsigned lo32 = __builtin_amdgcn_readlane((unsigned)row[w][ww], bit);
+                        const unsigned hi32 = __builtin_amdgcn_readlane((unsigned)(row[w][ww] >> 32), bit);
+                        rem[ww] |= ((uint64_t)hi32 << 32) | lo32;
+                    }
+                todo &= ~((2ull << bit) - 1ull);
+            }
+        }
+    }
+    if (lane < MASK_WORDS) {
+        uint64_t r = 0;
+#pragma unroll
+        for (int w = 0; w < MASK_WORDS; ++w) if (lane == w) r = rem[w];
+        const int lo64 = lane * 64;
+        const uint64_t valid = (m - lo64 >= 64) ? ~0ull : ((m - lo64 > 0) ? ((1ull << (m - lo64)) - 1ull) : 0ull);
+        s_keepw[lane] = ~r & valid;
+    }
+}
+
+// LDS image of nms_lds_body: box f32x4 | key u64 | area f32 | supp u8 (29 bytes per entry), scan i32[THREADS + 1], then (8-byte aligned) the
+// tile's suppression matrix u64[MASK_CAP][MASK_WORDS], the kept list u16[CAP] and the tile's keep words u64[MASK_WORDS].
+__host__ __device__ constexpr size_t nms_lds_mask_offset(const int cap, const int threads) { return (((size_t)cap * 29 + sizeof(int) * (threads + 1)) + 7) / 8 * 8; }
+__host__ __device__ constexpr size_t nms_lds_bytes(const int cap, const int threads) { return nms_lds_mask_offset(cap, threads) + (size_t)MASK_CAP * MASK_WORDS * 8 + (size_t)cap * 2 + MASK_WORDS * 8; }
+
 template <int THREADS, int CAP>
 __device__ __forceinline__ void nms_lds_body(const rn::NmsLaunch &a, unsigned char *smem)
 {
@@ -129,12 +218,57 @@ __device__ __forceinline__ void nms_lds_body(const rn::NmsLaunch &a, unsigned ch
     }
     __syncthreads();
 
-    for (int i = 0; i < n; ++i) {
-        if (s_supp[i]) continue;                       // same value in every thread: no writes since the last barrier
-        const f32x4 bi = s_box[i];
-        const float ai = s_area[i];
-        for (int j = i + 1 + threadIdx.x; j < n; j += THREADS)
-            if (!s_supp[j] && overlaps(bi, ai, s_box[j], s_area[j], a.iou_thr)) s_supp[j] = 1;
+    // Blocked greedy scan, tiles of MASK_CAP sorted boxes (the box-by-box loop it replaces paid one workgroup barrier per KEPT box:
+    // 2.5 ms for a 2 000-box segment of barely overlapping boxes -- an untrained head, or a crowded class):
+    //   1. every box of the tile against the boxes KEPT in earlier tiles (all threads, no serial step);
+    //   2. the tile's own pairwise suppression matrix as ballot words (a wave takes every NW-th row), as in nms_mask_kernel;
+    //   3. wave 0 scans the matrix with the "removed" set in SGPRs, starting from the boxes step 1 removed, visiting only rows that
+    //      suppress something;
+    //   4. the kept boxes join the list step 1 of the later tiles reads.
+    // Same predicate, same order: the keep set is the greedy one bit for bit.
+    constexpr int NW = THREADS / RN_WAVE;
+    uint64_t (*s_mask)[MASK_WORDS] = (uint64_t (*)[MASK_WORDS])(smem + nms_lds_mask_offset(CAP, THREADS));
+    uint16_t *s_kept = (uint16_t *)(smem + nms_lds_mask_offset(CAP, THREADS) + (size_t)MASK_CAP * MASK_WORDS * 8);   // sorted positions of the kept boxes
+    uint64_t *s_keepw = (uint64_t *)(smem + nms_lds_mask_offset(CAP, THREADS) + (size_t)MASK_CAP * MASK_WORDS * 8 + (size_t)CAP * 2);
+    const int lane = threadIdx.x & (RN_WAVE - 1);
+    int nkept = 0;
+    for (int t0 = 0; t0 < n; t0 += MASK_CAP) {
+        const int m = min(MASK_CAP, n - t0);
+        if (nkept > 0) {                                                          // 1. (uniform)
+            constexpr int G = THREADS / MASK_CAP;                                  // threads per tile box, striding the kept list
+            const int j = threadIdx.x % MASK_CAP, g = threadIdx.x / MASK_CAP;      // (a wave shares g: its loop below is wave-uniform)
+            const bool in = j < m;
+            const f32x4 bj = s_box[t0 + (in ? j : 0)];
+            const float aj = s_area[t0 + (in ? j : 0)];
+            bool dead = false;
+            for (int k = g; k < nkept; k += G) {
+                const int p = s_kept[k];
+                const bool live = in && !dead;
+                if (overlaps_wave(s_box[p], s_area[p], bj, aj, a.iou_thr, live) && live) dead = true;
+            }
+            if (dead) s_supp[t0 + j] = 1;
+            __syncthreads();
+        }
+        tile_matrix<NW>(s_box + t0, s_area + t0, m, s_mask, a.iou_thr);                // 2.
+        __syncthreads();
+        tile_scan(s_mask, s_supp + t0, m, s_keepw);                                    // 3.
+        __syncthreads();
+        {                                                                         // 4.
+            int before = 0, total = 0;
+            const int tw = (threadIdx.x % MASK_CAP) >> 6;
+#pragma unroll
+            for (int w = 0; w < MASK_WORDS; ++w) {
+                const int c = __popcll(s_keepw[w]);
+                if (w < tw) before += c;
+                total += c;
+            }
+            if ((int)threadIdx.x < MASK_CAP && (int)threadIdx.x < m) {
+                const uint64_t mine = s_keepw[tw];
+                if ((mine >> lane) & 1ull) s_kept[nkept + before + __popcll(mine & ((1ull << lane) - 1ull))] = (uint16_t)(t0 + threadIdx.x);
+                else s_supp[t0 + threadIdx.x] = 1;
+            }
+            nkept += total;
+        }
         __syncthreads();
     }
 
@@ -157,9 +291,6 @@ __device__ __forceinline__ void nms_lds_body(const rn::NmsLaunch &a, unsigned ch
 // Segments of up to MASK_CAP entries (the common case: ~100 candidates per (image, class) at the
 // reference's prior): rank sort, the full pairwise suppression matrix as 64-bit ballot words, then
 // a register-resident scan.  Nothing in it is serial except the n-step scan of 4 words.
-constexpr int MASK_CAP = 256;
-constexpr int MASK_WORDS = MASK_CAP / 64;
-
 __global__ __launch_bounds__(MASK_CAP) void nms_mask_kernel(const rn::NmsLaunch a)
 {
     __shared__ uint64_t s_in[MASK_CAP];
@@ -289,7 +420,7 @@ __global__ __launch_bounds__(MASK_CAP) void nms_mask_kernel(const rn::NmsLaunch 
 }
 
 // Segments longer than MED_CAP: chunk sort in LDS, merge passes and NMS state in HBM.
-__device__ __forceinline__ void nms_big_body(const rn::NmsLaunch &a)
+__device__ __forceinline__ void nms_big_body(const rn::NmsLaunch &a, unsigned char *smem)
 {
     __shared__ uint64_t s_key[MED_CAP];
     __shared__ int s_scan[BIG_THREADS + 1];
@@ -344,16 +475,69 @@ __device__ __forceinline__ void nms_big_body(const rn::NmsLaunch &a)
         g_supp[i] = 0;
     }
     __syncthreads();
-    for (int i = 0; i < n; ++i) {
-        if (g_supp[i]) continue;
-        const f32x4 bi = g_box[i];
-        const float ai = (bi.z - bi.x) * (bi.w - bi.y);
-        for (int j = i + 1 + threadIdx.x; j < n; j += BIG_THREADS) {
-            if (g_supp[j]) continue;
-            const f32x4 bj = g_box[j];
-            if (overlaps(bi, ai, bj, (bj.z - bj.x) * (bj.w - bj.y), a.iou_thr)) g_supp[j] = 1;
+    // The blocked greedy scan of nms_lds_body with the sorted boxes in HBM: a tile of MASK_CAP boxes at a time in LDS; the boxes kept so
+    // far are COMPACTED IN PLACE at the front of g_box (a kept box moves to a position at or below its own, and tiles are read front to
+    // back, so nothing unread is overwritten) and pass through LDS 1 024 at a time for step 1.  (The box-by-box loop this replaces: one
+    // barrier and an HBM round trip per kept box, 2.5 ms for a 3 000-box segment of barely overlapping boxes.)
+    {
+        constexpr int NW = BIG_THREADS / RN_WAVE, G = BIG_THREADS / MASK_CAP;
+        f32x4 *s_tbox = (f32x4 *)smem;                                                      // [MASK_CAP]
+        f32x4 *s_kbox = (f32x4 *)(smem + (size_t)MASK_CAP * 16);                            // [BIG_THREADS] kept boxes of the current chunk
+        float *s_tarea = (float *)(smem + (size_t)(MASK_CAP + BIG_THREADS) * 16);           // [MASK_CAP]
+        uint64_t (*s_mask)[MASK_WORDS] = (uint64_t (*)[MASK_WORDS])(smem + (size_t)(MASK_CAP + BIG_THREADS) * 16 + (size_t)MASK_CAP * 4);
+        uint64_t *s_keepw = (uint64_t *)(smem + (size_t)(MASK_CAP + BIG_THREADS) * 16 + (size_t)MASK_CAP * 4 + (size_t)MASK_CAP * MASK_WORDS * 8);
+        uint8_t *s_tsupp = smem + (size_t)(MASK_CAP + BIG_THREADS) * 16 + (size_t)MASK_CAP * 4 + (size_t)MASK_CAP * MASK_WORDS * 8 + MASK_WORDS * 8;
+        const int lane = threadIdx.x & (RN_WAVE - 1);
+        const int j = threadIdx.x % MASK_CAP, g = threadIdx.x / MASK_CAP;
+        int nkept = 0;
+        for (int t0 = 0; t0 < n; t0 += MASK_CAP) {
+            const int m = min(MASK_CAP, n - t0);
+            if ((int)threadIdx.x < m) {
+                const f32x4 b = g_box[t0 + threadIdx.x];
+                s_tbox[threadIdx.x] = b;
+                s_tarea[threadIdx.x] = (b.z - b.x) * (b.w - b.y);
+                s_tsupp[threadIdx.x] = 0;
+            }
+            __syncthreads();
+            const bool in = j < m;
+            const f32x4 bj = s_tbox[in ? j : 0];
+            const float aj = s_tarea[in ? j : 0];
+            bool dead = false;
+            for (int c0 = 0; c0 < nkept; c0 += BIG_THREADS) {                                // 1. (uniform trip count)
+                const int kc = min(BIG_THREADS, nkept - c0);
+                if ((int)threadIdx.x < kc) s_kbox[threadIdx.x] = g_box[c0 + threadIdx.x];
+                __syncthreads();
+                for (int k = g; k < kc; k += G) {
+                    const f32x4 bk = s_kbox[k];
+                    const bool live = in && !dead;
+                    if (overlaps_wave(bk, (bk.z - bk.x) * (bk.w - bk.y), bj, aj, a.iou_thr, live) && live) dead = true;
+                }
+                __syncthreads();                                                             // the chunk is overwritten next
+            }
+            if (dead) s_tsupp[j] = 1;
+            __syncthreads();
+            tile_matrix<NW>(s_tbox, s_tarea, m, s_mask, a.iou_thr);                          // 2.
+            __syncthreads();
+            tile_scan(s_mask, s_tsupp, m, s_keepw);                                          // 3.
+            __syncthreads();
+            {                                                                                // 4.
+                int before = 0, total = 0;
+                const int tw = j >> 6;
+#pragma unroll
+                for (int w = 0; w < MASK_WORDS; ++w) {
+                    const int c = __popcll(s_keepw[w]);
+                    if (w < tw) before += c;
+                    total += c;
+                }
+                if ((int)threadIdx.x < m) {
+                    const uint64_t mine = s_keepw[tw];
+                    if ((mine >> lane) & 1ull) g_box[nkept + before + __popcll(mine & ((1ull << lane) - 1ull))] = s_tbox[threadIdx.x];
+                    else g_supp[t0 + threadIdx.x] = 1;
+                }
+                nkept += total;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     const int per = (n + BIG_THREADS - 1) / BIG_THREADS;
     const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
@@ -395,7 +579,7 @@ __global__ __launch_bounds__(BIG_THREADS) void nms_large_kernel(const rn::NmsLau
     const int n = a.seg_len[blockIdx.x];
     if (n <= MASK_CAP) return;
     if (n <= MED_CAP) nms_lds_body<BIG_THREADS, MED_CAP>(a, smem);
-    else nms_big_body(a);
+    else nms_big_body(a, smem);
 }
 
 }  // namespace
@@ -403,7 +587,7 @@ __global__ __launch_bounds__(BIG_THREADS) void nms_large_kernel(const rn::NmsLau
 int rn::launch_nms(const rn::NmsLaunch &a, hipStream_t st)
 {
     if (a.S <= 0) return RN_OK;
-    const size_t lds_med = (size_t)MED_CAP * 29 + sizeof(int) * (BIG_THREADS + 1);
+    const size_t lds_med = nms_lds_bytes(MED_CAP, BIG_THREADS);
     {   // > 64 KiB of LDS in one workgroup (static + dynamic) needs the opt-in once per device
         static bool attr_set[64] = {};
         int dev = 0;
