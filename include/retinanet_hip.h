@@ -348,10 +348,11 @@ int rn_conv3x3_wgrad_narrow(const void *g, const void *x, void *dw, int dtype, i
  * bottlenecks, retinanet/backbone.py:112,128 -- what F.conv2d(x, w, None, 1, 1) returns there), bf16 channels-last, fp32 accumulation:
  *   x, y [N][H][W][64],  w [64][3][3][64] (channels-last memory of a [64, 64, 3, 3] weight).
  * Issued with the tap-reversed, role-swapped weight (rn_conv3x3_levels_dgrad_weight's layout) it is the data gradient of that
- * convolution.  Weights in registers, input rows in an LDS ring (csrc/narrow3x3.hip); zero_page: >= 128 zero bytes on the device (what
+ * convolution.  bias (f32 [64], may be NULL) and relu: y = act(conv + bias) in the epilogue -- inference with the BatchNorm folded in.
+ * Weights in registers, input rows in an LDS ring (csrc/narrow3x3.hip); zero_page: >= 128 zero bytes on the device (what
  * pixels outside the image read).  RN_EUNSUPPORTED for other C or dtypes. */
-int rn_conv3x3_narrow_forward(const void *x, const void *w, void *y, int dtype, int N, int H, int W, int C, const void *zero_page,
-                              void *stream);
+int rn_conv3x3_narrow_forward(const void *x, const void *w, const float *bias, void *y, int dtype, int N, int H, int W, int C, int relu,
+                              const void *zero_page, void *stream);
 
 /* n device-to-device copies (dsts[i] <- srcs[i], nbytes[i] bytes, non-overlapping) in one launch per 64: the inputs of a step
  * into the static buffers of its captured hipGraph (graph.CapturedTrainStep).  srcs / dsts / nbytes are HOST arrays. */
@@ -432,6 +433,11 @@ int rn_conv3x3_canvas_wgrad_batched(const void *const *gs, const void *const *xs
 int rn_conv3x3_dense_batched(const void *const *xs, const void *const *ws, const float *const *biases, void *const *ys, int P,
                              int dtype, int N, const int *hs, const int *wds, int Cin, int Cout, const void *zeros,
                              void *stream);
+/* The same with ys[p] = relu(...) when `relu` (inference: conv2 of the layer3 bottlenecks with the folded BatchNorm as bias and the
+ * ReLU of retinanet/backbone.py:132 in the epilogue). */
+int rn_conv3x3_dense_batched_act(const void *const *xs, const void *const *ws, const float *const *biases, void *const *ys, int P,
+                                 int dtype, int N, const int *hs, const int *wds, int Cin, int Cout, const void *zeros, int relu,
+                                 void *stream);
 /* Its weight gradient (256 -> 256): dws[p][co][3][3][ci] = sum over positions of gs[p][pos][co] * xs[p][pos + tap][ci];
  * every problem gets a number of position splits proportional to its size (one round of workgroups in total), a second
  * kernel sums the f32 partials.  workspace: rn_conv3x3_dense_wgrad_workspace_bytes(P); zeros: >= 256 bytes of zeros. */

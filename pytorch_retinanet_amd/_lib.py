@@ -127,6 +127,7 @@ SIGNATURES = {
     "rn_conv3x3_wgrad_workspace_bytes": (_sz, [C.c_int, _i64]),
     "rn_conv3x3_canvas_wgrad_batched": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _sz, _vp]),
     "rn_conv3x3_dense_batched": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "rn_conv3x3_dense_batched_act": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp]),
     "rn_conv3x3_dense_wgrad_workspace_bytes": (_sz, [C.c_int]),
     "rn_conv3x3_dense_wgrad_batched": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _sz, _vp]),
     "rn_stem_padded_bytes": (_sz, [C.c_int, C.c_int, C.c_int]),
@@ -136,7 +137,7 @@ SIGNATURES = {
     "rn_stem_conv_wgrad": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _sz, _vp]),
     "rn_conv3x3_wgrad_narrow_workspace_bytes": (_sz, [C.c_int, C.c_int]),
     "rn_conv3x3_wgrad_narrow": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _sz, _vp]),
-    "rn_conv3x3_narrow_forward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "rn_conv3x3_narrow_forward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rn_copy_many": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp]),
     "rn_cast_many_to_f32": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "rn_transpose_many": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp]),

@@ -76,9 +76,14 @@ def conv_bn(conv: nn.Conv2d, bn: FusedBatchNorm2d, x: Tensor, relu: bool = False
         if pwconv.eval_conv1x1_ok(conv, xd, w, residual):
             # 1x1: the folded bias, the identity branch and the ReLU ride in the GEMM's epilogue -- no pass over the output at all
             return pwconv.eval_conv1x1(conv, xd, w, b, relu, residual)
-        if (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
-                and biasact.narrow_fwd_ok(xd, w)):
-            y = biasact.conv3x3_narrow_forward(xd, w)              # 64 channels: csrc/narrow3x3.hip (conv2 of the layer1 bottlenecks)
+        plain3x3 = conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+        if plain3x3 and residual is None and biasact.dense_eval_ok(xd, w):
+            # 256 / 512 channels (conv2 of layer3 / layer4): bias + ReLU in the epilogue of the head's dense MFMA kernel
+            return biasact.conv3x3_dense_bias_act(xd, w, b, relu)
+        if plain3x3 and residual is None and biasact.narrow_fwd_ok(xd, w):
+            return biasact.conv3x3_narrow_forward(xd, w, b, relu)  # 64 channels (conv2 of layer1): csrc/narrow3x3.hip, bias + ReLU in its epilogue
+        if plain3x3 and biasact.narrow_fwd_ok(xd, w):
+            y = biasact.conv3x3_narrow_forward(xd, w)
         else:
             y = F.conv2d(xd, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
         if bn._fusable(y, residual):

@@ -1025,8 +1025,9 @@ def narrow_fwd_ok(x: Tensor, w: Tensor) -> bool:
             tuple(w.shape) == (64, 64, 3, 3) and x.shape[1] == 64 and x.numel() // 64 < (1 << 31))
 
 
-def conv3x3_narrow_forward(x: Tensor, w: Tensor) -> Tensor:
-    "``F.conv2d(x, w, None, 1, 1)`` for bf16 channels-last x [N, 64, H, W] and w [64, 64, 3, 3] on ``rn_conv3x3_narrow_forward``."
+def conv3x3_narrow_forward(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, relu: bool = False) -> Tensor:
+    """``F.conv2d(x, w, None, 1, 1)`` for bf16 channels-last x [N, 64, H, W] and w [64, 64, 3, 3] on ``rn_conv3x3_narrow_forward``;
+    with ``bias`` (f32 [64]): ``act(conv + bias)``, act = ReLU when ``relu`` (the folded-BatchNorm inference path)."""
     dev = x.device
     if dev.index != torch.cuda.current_device():
         torch.cuda.set_device(dev)
@@ -1035,7 +1036,36 @@ def conv3x3_narrow_forward(x: Tensor, w: Tensor) -> Tensor:
     N, C, H, W = x.shape
     y = torch.empty_like(x, memory_format=torch.channels_last)
     _mfma_call("mfma_conv2_narrow_fwd", dev, 2.0 * N * H * W * C * C * 9,
-               lambda: lib.rn_conv3x3_narrow_forward(x.data_ptr(), wc.data_ptr(), y.data_ptr(), RN_BF16, N, H, W, C, _zero_page(dev).data_ptr(), stream), "rn_conv3x3_narrow_forward")
+               lambda: lib.rn_conv3x3_narrow_forward(x.data_ptr(), wc.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(), RN_BF16, N, H, W, C,
+                                                     int(bool(relu)), _zero_page(dev).data_ptr(), stream), "rn_conv3x3_narrow_forward")
+    return y
+
+
+# Inference (frozen BatchNorm folded into weight + bias): conv2 of the layer3 / layer4 bottlenecks on the dense mode of the head's MFMA
+# kernel with the bias and the ReLU in its epilogue, instead of CK's kernel + an epilogue pass over the output.
+DENSE_EVAL = True
+
+
+def dense_eval_ok(x: Tensor, w: Tensor) -> bool:
+    return (DENSE_EVAL and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 4 and _cl(x) and _cl(w) and
+            tuple(w.shape[2:]) == (3, 3) and w.shape[1] == x.shape[1] and w.shape[1] % 64 == 0 and w.shape[0] % 256 == 0 and
+            x.shape[0] * x.shape[2] * x.shape[3] < (1 << 22))
+
+
+def conv3x3_dense_bias_act(x: Tensor, w: Tensor, bias: Optional[Tensor], relu: bool) -> Tensor:
+    "``act(F.conv2d(x, w, bias, 1, 1))`` (bf16 channels-last, Cin % 64 == 0, Cout % 256 == 0; bias f32) on ``rn_conv3x3_dense_batched_act``."
+    dev = x.device
+    if dev.index != torch.cuda.current_device():
+        torch.cuda.set_device(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    N, Cin, h, wd = x.shape
+    Cout = int(w.shape[0])
+    y = torch.empty((N, Cout, h, wd), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+    bs = (C.c_void_p * 1)(bias.data_ptr()) if bias is not None else None
+    _mfma_call("mfma_conv2_eval", dev, 2.0 * N * h * wd * Cout * 9 * Cin,
+               lambda: lib.rn_conv3x3_dense_batched_act(_ptr_array([x]), _ptr_array([w]), bs, _ptr_array([y]), 1, RN_BF16, N, _int_array([h]),
+                                                        _int_array([wd]), Cin, Cout, _zero_page(dev).data_ptr(), int(bool(relu)), stream),
+               "rn_conv3x3_dense_batched_act")
     return y
 
 

@@ -1462,8 +1462,9 @@ static int dense_geom(DenseGeom &g, int P, int N, const int *hs, const int *wds)
     return RN_OK;
 }
 
-RN_API int rn_conv3x3_dense_batched(const void *const *xs, const void *const *ws, const float *const *biases, void *const *ys, int P,
-                                    int dtype, int N, const int *hs, const int *wds, int Cin, int Cout, const void *zeros, void *stream)
+RN_API int rn_conv3x3_dense_batched_act(const void *const *xs, const void *const *ws, const float *const *biases, void *const *ys, int P,
+                                        int dtype, int N, const int *hs, const int *wds, int Cin, int Cout, const void *zeros, int relu,
+                                        void *stream)
 {
     if (!xs || !ws || !ys || !zeros || Cin <= 0 || Cout <= 0) return RN_EINVAL;
     if (dtype != RN_BF16 || Cin % CONV_BK || Cout % CONV_BN) return RN_EUNSUPPORTED;
@@ -1482,8 +1483,14 @@ RN_API int rn_conv3x3_dense_batched(const void *const *xs, const void *const *ws
         if (p < P) tiles += (int)((a.dn.M[p] + CONV_BM - 1) / CONV_BM);
     }
     a.dn.tile_beg[CONV_MAX_PROBLEMS] = 0x7fffffff;
-    a.mask = nullptr; a.M = 0; a.HWp = 1; a.Wp = 1; a.Cin = Cin; a.Cout = Cout; a.relu = 0; a.zeros = (const uint16_t *)zeros;
+    a.mask = nullptr; a.M = 0; a.HWp = 1; a.Wp = 1; a.Cin = Cin; a.Cout = Cout; a.relu = relu ? 1 : 0; a.zeros = (const uint16_t *)zeros;
     return conv_launch_mode<MODE_DENSE>(a, dim3((unsigned)tiles, (unsigned)(Cout / CONV_BN), 1), (hipStream_t)stream);
+}
+
+RN_API int rn_conv3x3_dense_batched(const void *const *xs, const void *const *ws, const float *const *biases, void *const *ys, int P,
+                                    int dtype, int N, const int *hs, const int *wds, int Cin, int Cout, const void *zeros, void *stream)
+{
+    return rn_conv3x3_dense_batched_act(xs, ws, biases, ys, P, dtype, N, hs, wds, Cin, Cout, zeros, 0, stream);
 }
 
 // splits of the DENSE weight gradient: every split walks `tps` K-tiles (the last one of a problem fewer), as many splits in

@@ -37,6 +37,8 @@ struct N3Args {
     const uint16_t *w;      // [64][9][64]  (channels-last memory of a [64, 64, 3, 3] weight)
     uint16_t *y;            // [N][H][W][64]
     const void *zeros;      // >= 128 zero bytes: what the staged pixels outside the image read
+    const float *bias;      // [64] or null: y = act(conv + bias), act = ReLU when relu (inference: the folded BatchNorm of the layer)
+    int relu;
     int N, H, W;
     int strips, bands, rows_per_band;
     int dbg;                // RN_N3_DEBUG ablations (timing only, results wrong): 1 no stores, 2 no staging in the loop, 4 no barrier in the loop
@@ -109,6 +111,12 @@ __global__ __launch_bounds__(N3_THREADS, 2) void conv3x3_narrow64_kernel(const N
             col[dx][kc] = (uint32_t)(sp * 128 + (((kc * 2 + kh) ^ n3_swz(sp)) << 4));
         }
     const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+    // epilogue constants: the bias of this lane's 16 output channels (acc[.][4 g + j] is channel 32 cw + 8 g + 4 kh + j)
+    float eb[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) eb[4 * g + j] = a.bias ? a.bias[cw * 32 + 8 * g + 4 * kh + j] : 0.0f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -157,6 +165,10 @@ __global__ __launch_bounds__(N3_THREADS, 2) void conv3x3_narrow64_kernel(const N
 #pragma unroll
         for (int pb = 0; pb < 2; ++pb) {
             if (x0 + pw * 64 + pb * 32 >= a.W) continue;          // (wave-uniform: the tile lies right of the image -- the count below relies on it)
+            if (a.bias) {                                          // (uniform)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float t = acc[pb][r] + eb[r]; acc[pb][r] = (a.relu && !(t > 0.0f)) ? 0.0f : t; }
+            }
             uint32_t v[2][4];
 #pragma unroll
             for (int gp = 0; gp < 2; ++gp) {
@@ -205,8 +217,8 @@ __global__ __launch_bounds__(N3_THREADS, 2) void conv3x3_narrow64_kernel(const N
 }  // namespace
 
 // x, y [N][H][W][C] bf16 channels-last; w [C][3][3][C] (channels-last memory of [C, C, 3, 3]); C = 64.
-RN_API int rn_conv3x3_narrow_forward(const void *x, const void *w, void *y, int dtype, int N, int H, int W, int C, const void *zero_page,
-                                     void *stream)
+RN_API int rn_conv3x3_narrow_forward(const void *x, const void *w, const float *bias, void *y, int dtype, int N, int H, int W, int C, int relu,
+                                     const void *zero_page, void *stream)
 {
     if (!x || !w || !y || !zero_page || N <= 0 || H <= 0 || W <= 0) return RN_EINVAL;
     if (dtype != RN_BF16 || C != 64) return RN_EUNSUPPORTED;
@@ -214,7 +226,7 @@ RN_API int rn_conv3x3_narrow_forward(const void *x, const void *w, void *y, int 
     if (!rn::aligned(x, 16) || !rn::aligned(w, 16) || !rn::aligned(y, 16)) return RN_EALIGN;
     N3Args a;
     a.x = (const uint16_t *)x; a.w = (const uint16_t *)w; a.y = (uint16_t *)y;
-    a.zeros = zero_page;
+    a.zeros = zero_page; a.bias = bias; a.relu = (bias && relu) ? 1 : 0;
     a.N = N; a.H = H; a.W = W;
     a.strips = (W + N3_TW - 1) / N3_TW;
     int dev = 0, cus = 0;

@@ -220,6 +220,13 @@ def test_narrow_forward_matches_torch(N, hw):
     if hw[0] > 1 and hw[1] > 1:
         want[:, 5, 1:, :-1] = x[:, 9, :-1, 1:]
     assert torch.equal(y2, want)
+    # bias + ReLU in the epilogue (the folded-BatchNorm inference path): act(conv + bias), one rounding
+    bias = torch.randn(64, device=dev, generator=g)
+    yb = biasact.conv3x3_narrow_forward(x, w, bias, True)
+    refb = F.relu(ref + bias[None, :, None, None])
+    assert float((yb.float() - refb).abs().max()) <= 2.0 ** -8 * float(refb.abs().max()) + 1e-6 and float(yb.float().min()) >= 0.0
+    yn = biasact.conv3x3_narrow_forward(x, w, bias, False)
+    assert float((yn.float() - (ref + bias[None, :, None, None])).abs().max()) <= 2.0 ** -8 * float((ref + bias[None, :, None, None]).abs().max()) + 1e-6
     # other channel counts and dtypes are declined, not mis-computed
     assert not biasact.narrow_fwd_ok(x[:, :32], w[:, :32]) and not biasact.narrow_fwd_ok(x.float(), w.float())
 

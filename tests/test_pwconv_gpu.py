@@ -448,7 +448,7 @@ def test_forward_with_bias_residual_relu_epilogue(shape, cout, stride, relu, wit
         pwconv.pw_forward(x, w, stride=stride, epi=bad)
 
 
-def test_frozen_bn_bottleneck_runs_its_1x1_convs_with_fused_epilogues():
+def test_frozen_bn_bottleneck_runs_its_convs_with_fused_epilogues():
     "backbone.conv_bn under eval(): the GEMM-epilogue path == the convolution + epilogue-pass path == the fp32 block (backbone.py:118-136)."
     from pytorch_retinanet_amd import backbone, pwconv
     torch.manual_seed(5)
@@ -463,14 +463,15 @@ def test_frozen_bn_bottleneck_runs_its_1x1_convs_with_fused_epilogues():
         blk.eval()
         x = _rand((2, inpl, *hw), 1.0, 6)
         with torch.no_grad():
+            from pytorch_retinanet_amd import biasact
             with torch.autocast("cuda", dtype=torch.bfloat16):
-                pwconv.EVAL_1X1_FUSED = True
+                pwconv.EVAL_1X1_FUSED = biasact.DENSE_EVAL = True      # GEMM epilogues for the 1x1 convs, the dense MFMA kernel for a 256 / 512-channel conv2
                 y1 = blk(x)
-                pwconv.EVAL_1X1_FUSED = False
+                pwconv.EVAL_1X1_FUSED = biasact.DENSE_EVAL = False     # library convolutions + one epilogue pass each
                 try:
                     y0 = blk(x)
                 finally:
-                    pwconv.EVAL_1X1_FUSED = True
+                    pwconv.EVAL_1X1_FUSED = biasact.DENSE_EVAL = True
             backbone.FOLD_FROZEN_BN = False
             try:
                 yf = blk(x.float())                                  # fp32, BatchNorm applied layer by layer

@@ -71,7 +71,7 @@ def main() -> None:
         N, H, W = (int(v) for v in sys.argv[2:5])
         x, w = raw_at_end(N * H * W * 64 * 2, 0x3c), raw_at_end(64 * 64 * 9 * 2, 0x3c)
         y, zp = raw_at_end(N * H * W * 64 * 2), raw_at_end(256, 0)
-        check(lib.rn_conv3x3_narrow_forward(x.data_ptr(), w.data_ptr(), y.data_ptr(), RN_BF16, N, H, W, 64, zp.data_ptr(), st), "rn_conv3x3_narrow_forward")
+        check(lib.rn_conv3x3_narrow_forward(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), RN_BF16, N, H, W, 64, 0, zp.data_ptr(), st), "rn_conv3x3_narrow_forward")
         torch.cuda.synchronize()
         assert bool(torch.isfinite(y.view(torch.bfloat16).float()).all()), "a pixel outside the image was read"       # (padding is 3.4e38: 9 * 64 of them overflow)
         print("ok n3", N, H, W, flush=True)
