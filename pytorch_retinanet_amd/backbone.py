@@ -262,11 +262,22 @@ class ResNetBackbone(nn.Module):
     # with the finished buckets' all-reduces issued eagerly between the replays (``StageCuts.pairs``: (producer output, leaf)).
     stage_cuts: Optional["StageCuts"] = None
 
+    def _stem_inference(self, x: Tensor) -> Tensor:
+        "``maxpool(relu(bn1(conv1(x))))`` outside training: frozen BatchNorm folded, on the MFMA stem kernel where it applies."
+        bn = self.bn1
+        if FOLD_FROZEN_BN and not bn.training and not torch.is_grad_enabled() and x.is_cuda and bn.track_running_stats:
+            dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+            w, b = _folded(self.conv1, bn, dt)[:2]
+            xd = x.to(dt)
+            if pwconv.stem_eval_ok(self.conv1, self.maxpool, xd, w):
+                return pwconv.stem_eval(xd, w, b)
+        return self.maxpool(conv_bn(self.conv1, self.bn1, x, relu=True))
+
     def _forward_impl(self, x: Tensor) -> Dict[str, Tensor]:
         if pwconv.stem_fusable(self.conv1, self.bn1, x):     # training, bf16: the MFMA stem kernel with bn1's statistics in its epilogue
             x = pwconv.stem(self.conv1, self.bn1, x, pool=self.maxpool)      # ... and bn1's apply + ReLU inside the max pooling
         else:
-            x = self.maxpool(conv_bn(self.conv1, self.bn1, x, relu=True))
+            x = self._stem_inference(x)
         x = self.layer1(x)
         # C3 / C4 feed the next layer's conv1 + stride-2 downsample conv and an FPN lateral: their data gradients join in one GEMM
         cuts = self.stage_cuts if (self.stage_cuts is not None and torch.is_grad_enabled()) else None

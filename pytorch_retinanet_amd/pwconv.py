@@ -673,6 +673,44 @@ class _StemFn(torch.autograd.Function):
         return None, None, None, dw, gr[:Cc], gr[Cc:2 * Cc]
 
 
+# Inference: the same stem kernel with the BatchNorm folded into its weights; the folded bias and the ReLU are applied inside the max
+# pooling (coefficients a = 1, b = bias), so the 925 MB activation of a 16 x 1344^2 batch between them is written once and read once
+# (MIOpen's implicit GEMM + an epilogue pass + the pooling pass before).
+STEM_EVAL = True
+
+
+def stem_eval_ok(conv, pool, x: Tensor, w: Tensor) -> bool:
+    return (STEM_EVAL and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 4 and _cl(x) and x.shape[1] == 3 and
+            conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.dilation == (1, 1) and conv.groups == 1 and
+            conv.out_channels == 64 and pool is not None and pool.kernel_size == 3 and pool.stride == 2 and pool.padding == 1 and
+            pool.dilation == 1 and not pool.ceil_mode and not pool.return_indices and
+            x.shape[0] * (x.shape[2] + 6) * (x.shape[3] + 8) < (1 << 31))
+
+
+def stem_eval(x: Tensor, w: Tensor, bias: Tensor) -> Tensor:
+    "``maxpool3x3s2(relu(conv7x7s2(x, w) + bias))`` on csrc/stem.hip + the pooling kernel (w: the folded bf16 weight, bias f32 [64])."
+    B, _, H, W = x.shape
+    dev = x.device
+    st = _stream(dev)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    xp = torch.empty((lib.rn_stem_padded_bytes(B, H, W),), dtype=torch.uint8, device=dev)
+    wk = torch.empty((64 * 7 * 32,), dtype=torch.bfloat16, device=dev)
+    wc = w if _cl(w) else w.contiguous(memory_format=torch.channels_last)
+    z = torch.empty((B, 64, Ho, Wo), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+    partial = torch.empty((lib.rn_stem_partial_rows(B, H, W) * 2 * 64,), dtype=torch.float32, device=dev)      # (the kernel's statistics: unused here)
+    PW_FLOP["stem_fwd"] = 2.0 * B * Ho * Wo * 64 * 147
+    with _timed("stem_fwd", dev):
+        check(lib.rn_stem_conv_forward(x.data_ptr(), wc.data_ptr(), xp.data_ptr(), wk.data_ptr(), z.data_ptr(), partial.data_ptr(), RN_BF16, B, H, W, st),
+              "rn_stem_conv_forward")
+    coef = torch.cat([torch.ones(64, dtype=torch.float32, device=dev), bias.float()])
+    Hq, Wq = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+    out = torch.empty((B, 64, Hq, Wq), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+    arg = torch.empty(out.shape, dtype=torch.uint8, device=dev, memory_format=torch.channels_last)
+    check(lib.rn_bn_relu_maxpool3x3s2_forward(z.data_ptr(), coef.data_ptr(), out.data_ptr(), arg.data_ptr(), RN_BF16, B, Ho, Wo, 64, st),
+          "rn_bn_relu_maxpool3x3s2_forward")
+    return out
+
+
 def stem(conv, bn, x: Tensor, pool=None) -> Tensor:
     "``relu(bn(conv(x)))``, or ``pool(relu(bn(conv(x))))`` when ``pool`` is the stem's 3x3 / stride-2 / pad-1 max pooling module."
     fuse = (pool is not None and pool.kernel_size == 3 and pool.stride == 2 and pool.padding == 1 and pool.dilation == 1

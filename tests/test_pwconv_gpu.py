@@ -481,3 +481,27 @@ def test_frozen_bn_bottleneck_runs_its_convs_with_fused_epilogues():
         e1 = float((y1.float() - yf).norm() / yf.norm())
         e0 = float((y0.float() - yf).norm() / yf.norm())
         assert e1 <= max(1.15 * e0, 6e-3), (inpl, planes, stride, e1, e0)   # one rounding less per convolution: not further from fp32 than the two-pass path
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 37, 53), (2, 131, 173)])
+def test_stem_inference_on_the_mfma_kernel_equals_the_folded_library_path(B, H, W):
+    "ResNet._stem_inference: conv7x7 with the folded BatchNorm on csrc/stem.hip + bias / ReLU inside the pooling == conv + epilogue pass + pooling."
+    from pytorch_retinanet_amd import backbone, pwconv
+    torch.manual_seed(3)
+    net = backbone.resnet18(pretrained=False).to(DEV).to(memory_format=torch.channels_last).eval()
+    with torch.no_grad():
+        net.bn1.running_mean.normal_(0.0, 0.3); net.bn1.running_var.uniform_(0.5, 1.5); net.bn1.weight.uniform_(0.5, 1.5); net.bn1.bias.normal_(0.0, 0.3)
+        x = _rand((B, 3, H, W), 1.0, 9)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pwconv.STEM_EVAL = True
+            y1 = net._stem_inference(x)
+            pwconv.STEM_EVAL = False
+            try:
+                y0 = net._stem_inference(x)
+            finally:
+                pwconv.STEM_EVAL = True
+        ref = F.max_pool2d(F.relu(F.batch_norm(F.conv2d(x.float(), net.conv1.weight.float(), None, 2, 3), net.bn1.running_mean, net.bn1.running_var,
+                                               net.bn1.weight, net.bn1.bias, False, 0.0, net.bn1.eps)), 3, 2, 1)
+    assert y1.shape == y0.shape == ref.shape and y1.dtype == torch.bfloat16
+    e1, e0 = float((y1.float() - ref).norm() / ref.norm()), float((y0.float() - ref).norm() / ref.norm())
+    assert e1 <= max(1.2 * e0, 6e-3), (e1, e0)
