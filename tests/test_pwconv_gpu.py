@@ -421,15 +421,18 @@ def test_bn_relu_inside_maxpool_equals_the_two_pass_form():
     ((2, 256, 38, 46), 512, 2, False, False),     # the downsample branch: stride 2, no ReLU
     ((1, 512, 9, 11), 2048, 1, True, True),       # layer4 conv3 (two column tiles of 128 per 256 ... sixteen)
     ((3, 128, 5, 7), 192, 1, False, True),        # 64-wide column tiles, residual without ReLU
-])
+    ((2, 128, 21, 25), 128, 1, True, False),      # 3x3 (conv2 of a layer2 block)
+    ((2, 256, 22, 26), 256, 2, True, False),      # 3x3 / stride 2 (conv2 of the first block of layer3)
+], ids=lambda v: str(v))
 def test_forward_with_bias_residual_relu_epilogue(shape, cout, stride, relu, with_res):
     "Inference epilogue (folded BatchNorm + identity + ReLU, backbone.py:118-136 under eval()): act(conv + bias (+ residual)), one rounding."
     from pytorch_retinanet_amd import pwconv
+    k = 3 if (shape[1] == cout and shape[2] in (21, 22)) else 1
     x = _rand(shape, 1.0, 1)
-    w = _rand((cout, shape[1], 1, 1), 0.05, 2)
+    w = _rand((cout, shape[1], k, k), 0.05 if k == 1 else 0.02, 2)
     gen = torch.Generator(device=DEV).manual_seed(3)
     bias = torch.randn(cout, device=DEV, generator=gen)
-    ref = F.conv2d(x.float(), w.float(), bias, stride)
+    ref = F.conv2d(x.float(), w.float(), bias, stride, k // 2)
     res = _rand(tuple(ref.shape), 1.0, 4) if with_res else None
     if res is not None:
         ref = ref + res.float()
@@ -465,7 +468,7 @@ def test_frozen_bn_bottleneck_runs_its_convs_with_fused_epilogues():
         with torch.no_grad():
             from pytorch_retinanet_amd import biasact
             with torch.autocast("cuda", dtype=torch.bfloat16):
-                pwconv.EVAL_1X1_FUSED = biasact.DENSE_EVAL = True      # GEMM epilogues for the 1x1 convs, the dense MFMA kernel for a 256 / 512-channel conv2
+                pwconv.EVAL_1X1_FUSED = biasact.DENSE_EVAL = True      # GEMM epilogues for the 1x1 convs, own kernels for conv2
                 y1 = blk(x)
                 pwconv.EVAL_1X1_FUSED = biasact.DENSE_EVAL = False     # library convolutions + one epilogue pass each
                 try:
