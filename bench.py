@@ -56,6 +56,9 @@ def parse():
                          "all-reduces issued eagerly between the replays (graph.CapturedTrainStep); eager = every kernel enqueued from Python; "
                          "onegraph = one capture incl. the collectives (forked stream branches: replays slower than eager on ROCm 7, DESIGN.md section 6)")
     ap.add_argument("--ddp-graph", action="store_true", help="same as --ddp-mode onegraph (round-3 spelling)")
+    ap.add_argument("--set", default="", metavar="MODULE.NAME=VALUE[,...]",
+                    help="A/B runs: set module-level switches of the package after import, e.g. --set biasact.NARROW_FWD=False,pwconv.EVAL_1X1_FUSED=False "
+                         "(the switches README.md lists; the JSON line records what was set)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every kernel of every step from Python instead of replaying the captured hipGraph of the step (graph.CapturedTrainStep)")
     ap.add_argument("--mode", default="train", choices=["train", "predict"], help="predict: only the BASELINE configs[3] end-to-end inference line "
                     "(R101-FPN, 16 x 3x1333x1333, eval-mode folded BN, conv stack + decode + NMS + top-100 + rescale) as the JSON line")
@@ -492,6 +495,16 @@ def main():
     import pytorch_retinanet_amd as P
     from pytorch_retinanet_amd import ops, tuning
 
+    if args.set:
+        import ast
+        import importlib
+        for item in args.set.split(","):
+            path, value = item.split("=", 1)
+            mod, name = path.strip().rsplit(".", 1)
+            m = importlib.import_module("pytorch_retinanet_amd." + mod)
+            if not hasattr(m, name):
+                raise SystemExit(f"bench.py --set: pytorch_retinanet_amd.{mod} has no switch {name}")
+            setattr(m, name, ast.literal_eval(value.strip()))
     tuning.use_shipped_miopen_db(rank)        # before the first conv: skip MIOpen's exhaustive search on a cold box
     tuning.enable_conv_autotune()             # channels_last needs find-mode picks (tuning.py has the numbers)
     if args.mode == "predict":
@@ -628,7 +641,8 @@ def main():
             "config": {"workload": f"RetinaNet-{args.backbone.replace('resnet', 'R')}-FPN bf16 train step, per-GPU batch "
                                    f"{args.batch} x 3x800x1333 (padded 800x1344), A=201600 anchors, K=90, T={args.gt} GT/img, "
                                    f"SGD(momentum{'' if args.torch_sgd else ', fp32 masters + bf16 conv weights'}); random-init weights",
-                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4),
+                       **({"switches_set": args.set} if args.set else {})},
             "roofline": roof, "roofline_other": roof_other, "conv_mfma": conv_mfma,
             "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 0,
             "gpu_state_during_timed_region": gpu_state,
