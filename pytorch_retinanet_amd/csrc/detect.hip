@@ -859,9 +859,6 @@ RN_API int rn_detect_levels(const void *const *cls_levels, const void *const *bo
     for (int l = 0; l < L; ++l)
         if (!rn::aligned(cls_levels[l], 16) || !rn::aligned(box_levels[l], dtype == RN_F32 ? 16 : 8)) return RN_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-    // RN_DETECT_DEBUG=1: synchronise after every stage and name it on stderr (which kernel of the chain raised a fault)
-    static const bool dbg = getenv("RN_DETECT_DEBUG") != nullptr;
-    auto stage = [&](const char *name) { if (dbg) { const hipError_t e = hipStreamSynchronize(st); fprintf(stderr, "[rn_detect] %s: %s\n", name, hipGetErrorString(e)); } };
     DetectWs w = carve(workspace, B, A, K, C);
     const RegW rw = {{params->reg_w[0], params->reg_w[1], params->reg_w[2], params->reg_w[3]}};
 
@@ -881,12 +878,6 @@ RN_API int rn_detect_levels(const void *const *cls_levels, const void *const *bo
         voff += lv.nvec;
     }
     sa.total_vec = voff;
-    if (dbg) {
-        fprintf(stderr, "[rn_detect] B %d A %lld K %d C %lld ws %p..%p boxes %p cand %p seg %p sbox %p supp %p cand_count %p kept %p seg_len %p seg_start %p hist %p anchors %p hw %p\n",
-                B, (long long)A, K, (long long)C, workspace, (void *)((char *)workspace + w.total), (void *)w.boxes, (void *)w.cand, (void *)w.seg, (void *)w.sbox,
-                (void *)w.supp, (void *)w.cand_count, (void *)w.kept_count, (void *)w.seg_len, (void *)w.seg_start, (void *)w.hist, (const void *)anchors, (const void *)image_hw);
-        for (int l = 0; l < L; ++l) fprintf(stderr, "[rn_detect]   level %d cls %p box %p A_l %lld\n", l, cls_levels[l], box_levels[l], (long long)level_anchors[l]);
-    }
     hipLaunchKernelGGL(zero_bytes4_kernel, dim3(1), dim3(256), 0, st, (uint32_t *)w.cand_count, (int64_t)(w.zero_bytes / 4));   // (no hipMemsetAsync: match.hip, zero_i32_kernel)
     RN_LAUNCH_CHECK();
 
@@ -935,18 +926,16 @@ RN_API int rn_detect_levels(const void *const *cls_levels, const void *const *bo
         default: return RN_EINVAL;
     }
     RN_LAUNCH_CHECK();
-    stage("score_scan");
     {
         static_assert(SEG_GROUPS == 16, "carve() sizes the class histograms for 16 workgroups per image");
         const dim3 fg(SEG_GROUPS, (unsigned)B), fb(SEG_THREADS);
         switch (dtype) {
-            case RN_F32: hipLaunchKernelGGL((seg_count_kernel<RN_F32>), fg, fb, 0, st, fa); stage("seg_count"); hipLaunchKernelGGL((seg_scatter_kernel<RN_F32>), fg, fb, 0, st, fa); break;
-            case RN_BF16: hipLaunchKernelGGL((seg_count_kernel<RN_BF16>), fg, fb, 0, st, fa); stage("seg_count"); hipLaunchKernelGGL((seg_scatter_kernel<RN_BF16>), fg, fb, 0, st, fa); break;
-            default: hipLaunchKernelGGL((seg_count_kernel<RN_F16>), fg, fb, 0, st, fa); stage("seg_count"); hipLaunchKernelGGL((seg_scatter_kernel<RN_F16>), fg, fb, 0, st, fa); break;
+            case RN_F32: hipLaunchKernelGGL((seg_count_kernel<RN_F32>), fg, fb, 0, st, fa); hipLaunchKernelGGL((seg_scatter_kernel<RN_F32>), fg, fb, 0, st, fa); break;
+            case RN_BF16: hipLaunchKernelGGL((seg_count_kernel<RN_BF16>), fg, fb, 0, st, fa); hipLaunchKernelGGL((seg_scatter_kernel<RN_BF16>), fg, fb, 0, st, fa); break;
+            default: hipLaunchKernelGGL((seg_count_kernel<RN_F16>), fg, fb, 0, st, fa); hipLaunchKernelGGL((seg_scatter_kernel<RN_F16>), fg, fb, 0, st, fa); break;
         }
         RN_LAUNCH_CHECK();
     }
-    stage("seg_scatter");
     rn::NmsLaunch na;
     na.keys = w.seg; na.kept = w.cand; na.keep_idx = nullptr; na.boxes = w.boxes;
     na.seg_start = w.seg_start; na.seg_len = w.seg_len; na.kept_count = w.kept_count;
@@ -954,11 +943,9 @@ RN_API int rn_detect_levels(const void *const *cls_levels, const void *const *bo
     na.S = B * K; na.box_mode = 1; na.K = K; na.A = A; na.iou_thr = params->nms_thr;
     rc = rn::launch_nms(na, st);
     if (rc != RN_OK) return rc;
-    stage("nms");
     hipLaunchKernelGGL(topk_kernel, dim3((unsigned)B), dim3(TOPK_THREADS), 0, st, w.cand, w.seg_start, w.kept_count, w.boxes,
                        K, A, params->max_det, (rn::f32x4 *)out_boxes, out_scores, out_labels, out_count);
     RN_LAUNCH_CHECK();
-    stage("topk");
     return RN_OK;
 }
 

@@ -73,7 +73,6 @@ struct LossArgs {
     int32_t *nfg_acc;        // [B] foreground counts of this launch: zero on entry (the finalize kernel re-zeroes them), device-scope atomics
     unsigned *bar;           // [1] grid barrier arrival counter: zero on entry (the finalize kernel re-zeroes it)
     int64_t *matches_out;    // nullable: [B][A] match codes, written by the wave that owns a row's first element
-    int32_t dbg;             // development ablations (RN_K3_FUSED_DEBUG): 1 = no barrier, 2 = no matching pass, 4 = long poll backoff, 8 = ignored rows element by element
 };
 
 // ---- background element (t = 0) ------------------------------------------------------
@@ -236,7 +235,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
     if (FUSED) {
         using namespace rn_match;
         int m_off = 0;
-        for (int li = 0; li < ((a.dbg & 2) ? 0 : a.L); ++li) {
+        for (int li = 0; li < a.L; ++li) {
             const LossLevel &lv = a.lv[li];
             const int64_t nvec = lv.nvec;
             if (gv_end <= lv.voff && nvec > 0) break;
@@ -312,7 +311,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
         }
         // grid barrier: one arrival per workgroup, polled by one thread per workgroup
         __syncthreads();
-        if (threadIdx.x == 0 && !(a.dbg & 1)) {
+        if (threadIdx.x == 0) {
             // NON-returning add: 1 536 returning adds to one address serialise at ~40 ns each (measured: +57 us per launch), the
             // fire-and-forget form at ~1.4 ns.  This wave's foreground adds above were waited for, the other waves' before the barrier
             __hip_atomic_fetch_add(a.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -320,7 +319,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
             // hang the device: ~4 M polls, seconds, then a sticky flag that makes the finalize kernel return NaN losses)
             unsigned spins = 0;
             while (__hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-                if (a.dbg & 4) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); } else __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(8);
                 if (++spins > (1u << 21)) { __hip_atomic_store(a.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
             }
         }
@@ -462,7 +461,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (VEC == 8 && !(K & 1) && !(a.dbg & 8)) {
+                if (VEC == 8 && !(K & 1)) {
                     // 16-bit logits, even K: a row is K / 2 whole dwords (rows start on 4-byte boundaries, ranges on 16-byte ones), so the
                     // repair moves two elements per memory instruction -- at 500 GT boxes per image a wave has ~14 ignored rows, and their
                     // 2-byte loads / stores were as many memory instructions as a fifth of its stream (round 3: 196 us at T = 500)
@@ -635,7 +634,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             for (int i = lane; i < n_pos; i += RN_WAVE) D::st(lv.gcls, e_beg + s_pos_off[wave][i], s_pos_val[wave][i]);
-            if (VEC == 8 && !(K & 1) && !(a.dbg & 8)) {                                            // (two 16-bit zeros per store: see the read side)
+            if (VEC == 8 && !(K & 1)) {                                            // (two 16-bit zeros per store: see the read side)
                 const int K2 = K >> 1, total2 = n_ign * K2;
                 for (int t = lane; t < total2; t += RN_WAVE) {
                     const int j = t / K2, k2 = t - j * K2;
@@ -987,8 +986,7 @@ static int loss_levels_core(const void *const *cls_levels, const void *const *bo
     a.p = *params;
     a.alpha_pos = (float)(1.0 - (double)params->alpha);
     a.part_stream = (float2 *)workspace;
-    a.fg_thr = a.bg_thr = 0.0f; a.nfg_acc = nullptr; a.bar = nullptr; a.matches_out = nullptr; a.dbg = 0;
-    if (const char *e = getenv("RN_K3_FUSED_DEBUG")) a.dbg = atoi(e);
+    a.fg_thr = a.bg_thr = 0.0f; a.nfg_acc = nullptr; a.bar = nullptr; a.matches_out = nullptr;
     if (fm) {
         a.fg_thr = fm->fg_thr; a.bg_thr = fm->bg_thr; a.matches_out = fm->matches_out;
         a.bar = (unsigned *)fm->state; a.nfg_acc = (int32_t *)fm->state + 16;        // (counters one cache-line half away from the barrier word)

@@ -444,7 +444,7 @@ __global__ __launch_bounds__(FIN_BLOCK) void iou_match_finalize_kernel(
 // num_fg[0..B) = 0 as a KERNEL.  A hipMemsetAsync becomes a MEMSET NODE when the step is captured in a hipGraph, and on ROCm 7.0 the
 // memset nodes of a replayed graph write garbage once the process has synchronised with the device and enqueued other work (round 4:
 // every replay after the first torch.cuda.synchronize() scaled both losses by 1 / garbage -- num_fg; the same graph with this kernel
-// is exact; RN_DBG_MEMSET_NODE=1 restores the memset for the regression experiment).  The library issues no hipMemsetAsync at all.
+// is exact).  The library issues no hipMemsetAsync at all.
 __global__ void zero_i32_kernel(int32_t *__restrict__ p, const int n)
 {
     for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
@@ -481,11 +481,7 @@ RN_API int rn_iou_match_special(const float *anchors, int64_t anchor_bstride, co
     if (!(fg_thr > bg_thr)) return RN_ETHRESH;
     if (!rn::aligned(anchors, 16) || (gt_boxes && !rn::aligned(gt_boxes, 16)) || (anchor_bstride & 3)) return RN_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-    if (num_fg) {
-        static const bool memset_node = getenv("RN_DBG_MEMSET_NODE") != nullptr;
-        if (memset_node) RN_HIP(hipMemsetAsync(num_fg, 0, sizeof(int32_t) * (size_t)B, st));
-        else { hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(64), 0, st, num_fg, B); RN_LAUNCH_CHECK(); }
-    }
+    if (num_fg) { hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(64), 0, st, num_fg, B); RN_LAUNCH_CHECK(); }   // (a kernel, never hipMemsetAsync: DESIGN.md, memset nodes)
     // The batch kernel needs host knowledge of sum(T) (gt_off lives on the device and this call never syncs):
     // callers that know it pass total_gt >= 0; -1 means unknown -> the general kernel.
     if (anchor_bstride == 0 && B <= 64 && total_gt >= 0 && total_gt <= BATCH_GT_MAX && total_gt <= 32 * (int64_t)B) {

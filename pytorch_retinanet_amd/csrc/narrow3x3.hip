@@ -41,7 +41,6 @@ struct N3Args {
     int relu;
     int N, H, W;
     int strips, bands, rows_per_band;
-    int dbg;                // RN_N3_DEBUG ablations (timing only, results wrong): 1 no stores, 2 no staging in the loop, 4 no barrier in the loop
 };
 
 __device__ __forceinline__ int n3_swz(const int sp) { return (sp >> 1) & 7; }
@@ -121,7 +120,7 @@ __global__ __launch_bounds__(N3_THREADS, 2) void conv3x3_narrow64_kernel(const N
     __syncthreads();
 
     for (int y = y0; y < y1; ++y) {
-        const bool stage_next = (y + 2 <= y1) && !(a.dbg & 2);
+        const bool stage_next = (y + 2 <= y1);
         if (stage_next) stage(y + 2);                            // the row the NEXT step needs last; slot (y + 2) & 3 held row y - 2: nobody reads it now
         f32x16 acc[2];
 #pragma unroll
@@ -189,27 +188,34 @@ __global__ __launch_bounds__(N3_THREADS, 2) void conv3x3_narrow64_kernel(const N
             const int chunk = lane >> 4;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int px = x0 + pw * 64 + pb * 32 + 16 * h + (lane & 15);
-                if (px < a.W && (!(a.dbg & 1) || acc[pb][0] == 12345.678f)) {
+                const int pxb = x0 + pw * 64 + pb * 32 + 16 * h;                // (wave-uniform)
+                if (pxb >= a.W) continue;                                       // uniform branch: a half tile right of the image issues NO store (counted below)
+                const int px = pxb + (lane & 15);
+                if (px < a.W) {
                     uint16_t *const yp = a.y + (((int64_t)n * a.H + y) * a.W + px) * 64 + cw * 32 + 8 * chunk;
                     *(rn::u32x4 *)yp = h ? rn::u32x4{hi[0], hi[1], hi[2], hi[3]} : rn::u32x4{lo[0], lo[1], lo[2], lo[3]};
                 }
             }
         }
         // The staged row has landed: vmcnt counts loads and stores in issue order on gfx9, so everything but the stores just issued
-        // (two per tile that has a pixel inside the image) must have retired -- not the stores themselves, whose acknowledgement
-        // from the L2 takes longer than the step's MFMAs leave to hide.
+        // must have retired -- not the stores themselves, whose acknowledgement from the L2 takes longer than the step's MFMAs leave
+        // to hide.  The count is the number of 16-pixel half tiles that START inside the image (each issues exactly one store
+        // instruction: the uniform branch above skips the others, and a half tile that starts inside has lane 0 active), 0..4.
         {
-            const int tiles = (x0 + pw * 64 < a.W ? 1 : 0) + (x0 + pw * 64 + 32 < a.W ? 1 : 0);
-            if ((a.dbg & 1) || (a.dbg & 8)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-            else if (tiles == 2) { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-            else if (tiles == 1) { asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
-            else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            const int xb = x0 + pw * 64;
+            const int stores = (xb < a.W ? 1 : 0) + (xb + 16 < a.W ? 1 : 0) + (xb + 32 < a.W ? 1 : 0) + (xb + 48 < a.W ? 1 : 0);
+            switch (stores) {
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
         }
         // (a bare s_barrier: __syncthreads() carries a workgroup release fence = vmcnt(0), which would wait for the stores after all;
         // the ring is written by the DMA waited for above and read by the asm reads, all retired at the last K-step's lgkmcnt(0))
         __builtin_amdgcn_sched_barrier(0);
-        if (!(a.dbg & 4)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -237,8 +243,6 @@ RN_API int rn_conv3x3_narrow_forward(const void *x, const void *w, const float *
     if (bands > H) bands = H;
     a.rows_per_band = (H + bands - 1) / bands;
     a.bands = (H + a.rows_per_band - 1) / a.rows_per_band;
-    static const int dbg = getenv("RN_N3_DEBUG") ? atoi(getenv("RN_N3_DEBUG")) : 0;
-    a.dbg = dbg;
     static rn::DynLdsOptIn opt_in = {};
     { const int rc = opt_in.ensure((const void *)conv3x3_narrow64_kernel, N3_LDS); if (rc != RN_OK) return rc; }
     hipLaunchKernelGGL(conv3x3_narrow64_kernel, dim3((unsigned)(N * a.strips * a.bands)), dim3(N3_THREADS), N3_LDS, (hipStream_t)stream, a);

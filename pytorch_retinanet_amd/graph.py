@@ -52,11 +52,27 @@ class MemsetNodeInGraph(RuntimeError):
 LAST_CENSUS: Dict[str, int] = {}          # node counts of the graphs captured so far in this process (bench.py reports them)
 
 
+_WARNED_NO_HANDLE = False
+
+
 def _new_graph() -> "torch.cuda.CUDAGraph":
     try:
         return torch.cuda.CUDAGraph(keep_graph=True)          # (keeps the hipGraph_t for the node census below)
     except TypeError:
         return torch.cuda.CUDAGraph()
+
+
+def _uninspectable(g) -> None:
+    """The raw hipGraph_t is not available (a torch without ``CUDAGraph(keep_graph=True)``): no node census, no memset repair.  On ROCm
+    that is exactly the case the repair exists for, so the capture is REFUSED there (the step runs eagerly: slower, never wrong);
+    elsewhere it is logged once."""
+    global _WARNED_NO_HANDLE
+    if getattr(torch.version, "hip", None):
+        raise MemsetNodeInGraph("this torch cannot hand out the captured hipGraph_t (CUDAGraph(keep_graph=True) is missing): memset nodes "
+                                "of third-party libraries can be neither counted nor replaced, and their replays are not trusted on ROCm")
+    if not _WARNED_NO_HANDLE:
+        _WARNED_NO_HANDLE = True
+        _log.warning("captured graph cannot be inspected (no raw graph handle): node census and memset-node repair skipped")
 
 
 def _repair_memset_nodes(g) -> None:
@@ -84,6 +100,8 @@ def _repair_memset_nodes(g) -> None:
         if counts[1]:
             raise MemsetNodeInGraph(f"the captured step holds {counts[1]} memset node(s) next to {counts[0]} kernels (a third-party "
                                     f"library cleared a buffer with hipMemsetAsync); replays of such a graph are not trusted on this ROCm")
+    else:
+        _uninspectable(g)
     inst = getattr(g, "instantiate", None)
     if handle and inst is not None:
         inst()
@@ -209,14 +227,16 @@ class CapturedTrainStep:
         torch.cuda.synchronize()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        state = {"g": None}
+        state = {"g": None, "open": False}
 
         def begin():
             state["g"] = _new_graph()
             state["g"].capture_begin(pool=e.pool, capture_error_mode="thread_local")
+            state["open"] = True
 
         def mark(i):
             state["g"].capture_end()
+            state["open"] = False
             _repair_memset_nodes(state["g"])
             e.segments.append(state["g"])
             e.bucket_ids.append(ddp.issue_ready() if i < 3 else [])       # eager: the collectives of the buckets this segment completed
@@ -235,9 +255,28 @@ class CapturedTrainStep:
             try:
                 begin()
                 e.losses = self._staged(e.images, e.targets, mark)
+            except BaseException:
+                # a failure inside an open segment (a MIOpen / check() error in forward or backward) must END that capture before
+                # anything else touches the device from this thread: torch.cuda.graph.__exit__ does this for the one-graph path, the
+                # hand-driven begin / mark pair has to do it itself.  Then the half-built segments and their pool are dropped.
+                if state["open"]:
+                    try:
+                        state["g"].capture_end()
+                    except Exception:                # noqa: BLE001 -- the capture is already invalid: ending it may raise again
+                        pass
+                    state["open"] = False
+                for g in e.segments + [state["g"]]:
+                    try:
+                        if g is not None:
+                            g.reset()
+                    except Exception:                # noqa: BLE001
+                        pass
+                state["g"] = None
+                e.segments, e.bucket_ids, e.pool, e.losses = None, None, None, None
+                raise
             finally:
                 ddp.finish = orig_finish
-        torch.cuda.current_stream(dev).wait_stream(side)
+                torch.cuda.current_stream(dev).wait_stream(side)
         self.captures += 1
 
     def _replay_segments(self, e: _Entry) -> None:
@@ -283,9 +322,10 @@ class CapturedTrainStep:
             except Exception as exc:                          # noqa: BLE001 -- a step that cannot be captured still has to run
                 _log.warning("train-step capture failed (%s: %s); this input signature runs eagerly", type(exc).__name__, exc)
                 e.failed, e.graph, e.images, e.targets, e.losses, e.segments = True, None, None, None, None, None
+                e.bucket_ids, e.pool, e.match_state = None, None, None
+                torch.cuda.synchronize()                      # (the capture's side stream has been joined by _capture_segments' finally)
                 if self.ddp is not None:
                     self.ddp.reset()
-                torch.cuda.synchronize()
                 return self._step(images, targets)
         else:
             # the step's inputs into the graph's static buffers: one multi-tensor launch per dtype for what already lives on the

@@ -197,6 +197,12 @@ def test_narrow_weight_gradient_rejects_what_it_cannot_do():
     (3, (5, 257)),         # three strips, one pixel in the last
     (1, (300, 129)),       # bands of several rows with a short last band
     (8, (200, 336)),       # layer1 of the 800 x 1333 bucket (full size)
+    (2, (40, 112)),        # W % 128 == 112: wave 2's last half tile starts inside the image, the DMA piece behind it holds pixel W - 1
+    (2, (40, 240)),        # the same in the second strip
+    (2, (24, 144)),        # second strip with exactly 16 valid pixels: ONE store per row (the counted vmcnt follows the stores issued)
+    (2, (24, 137)),        # ... 9 valid pixels
+    (2, (24, 176)),        # 48 valid pixels: three stores
+    (4, (64, 80)),         # wave 1 of the only strip: 16 valid pixels of its 64
 ])
 def test_narrow_forward_matches_torch(N, hw):
     "csrc/narrow3x3.hip against F.conv2d on fp32 copies of the same bf16 tensors (conv2 of a layer1 bottleneck, backbone.py:112,128)."

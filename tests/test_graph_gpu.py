@@ -191,3 +191,48 @@ def test_a_graph_with_a_memset_node_is_refused_and_the_librarys_own_calls_captur
     g2.replay(); torch.cuda.synchronize()
     ref = oracle_lib.loss_fwd_bwd(cls, box, anc.cpu().numpy(), list(gtb), list(gtl), oracle_lib.iou_match(anc.cpu().numpy(), list(gtb))[0])
     np.testing.assert_allclose(loss.cpu().numpy(), ref["loss"], rtol=1e-4)
+
+
+def test_a_failure_inside_an_open_segment_ends_the_capture_and_the_step_runs_eagerly():
+    """the segmented capture drives capture_begin / capture_end by hand; an exception raised while a segment is
+    open (a MIOpen / check() failure in forward or backward) must end that capture, drop the half-built segments and leave the device
+    usable -- the step of that call runs eagerly, later calls of that signature stay eager, other signatures still capture."""
+    from pytorch_retinanet_amd.graph import CapturedTrainStep, retinanet_stage_of
+    from pytorch_retinanet_amd.parallel import BucketedGradAllReduce
+    net, opt = _setup()
+    ddp = BucketedGradAllReduce(net, stage_of=retinanet_stage_of)          # world 1, no process group: gathers only
+    step = CapturedTrainStep(net, opt, ddp=ddp, amp_dtype=torch.bfloat16, eager_steps=1)
+    assert step.segmented
+    boom = {"on": True}
+
+    def hook(_m, _inp, _out):
+        if boom["on"] and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("injected failure inside an open capture segment")
+    h = net.fpn.register_forward_hook(hook)
+    data = _batches(4)
+    losses = [float(step(im, tg)["loss"]) for im, tg in data]                 # call 2 tries to capture, fails inside segment 0
+    torch.cuda.synchronize()
+    assert not torch.cuda.is_current_stream_capturing()
+    assert step.captures == 0 and step.replays == 0 and np.all(np.isfinite(losses))
+    assert all(b.pending == len(b.params) or b.launched for b in ddp.buckets)
+    # a failure in a LATER segment (stage 1's backward): segments already built are dropped too
+    boom["on"] = False
+    h.remove()
+    fired = {"n": 0}
+
+    def bhook(_m, _gin, _gout):
+        if boom["on"] and torch.cuda.is_current_stream_capturing():
+            fired["n"] += 1
+            raise RuntimeError("injected failure in the second segment")
+    hb = net.backbone.backbone.layer4.register_full_backward_hook(bhook)
+    boom["on"] = True
+    data2 = _batches(3, T=2, seed=9)                                           # a new signature (other GT count)
+    l2 = [float(step(im, tg)["loss"]) for im, tg in data2]
+    torch.cuda.synchronize()
+    assert fired["n"] == 1 and step.captures == 0 and np.all(np.isfinite(l2))
+    hb.remove()
+    boom["on"] = False
+    data3 = _batches(4, T=4, seed=3)                                           # a third signature captures and replays normally
+    l3 = [float(step(im, tg)["loss"]) for im, tg in data3]
+    torch.cuda.synchronize()
+    assert step.captures == 1 and step.replays == 3 and np.all(np.isfinite(l3))
