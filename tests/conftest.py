@@ -29,8 +29,8 @@ _ORDER = [
     "test_oracle_golden.py", "test_host_surface.py", "test_properties.py", "test_coco_eval.py", "test_parallel_gloo.py",
     "test_hip_parity.py", "test_e2e_gpu.py", "test_model_gpu.py",
     "test_norm_gpu.py", "test_pwconv_gpu.py", "test_dense_conv_gpu.py", "test_narrow_conv_gpu.py",
-    "test_graph_gpu.py", "test_guard_gpu.py",
-    "test_rccl_world1_gpu.py", "test_ddp_two_rank_gpu.py",
+    "test_graph_gpu.py", "test_guard_gpu.py", "test_traj_gpu.py",
+    "test_rccl_world1_gpu.py", "test_ddp_two_rank_gpu.py", "test_bench_launch_gpu.py",
 ]
 
 

@@ -476,9 +476,71 @@ def gen_e2e():
     save("e2e.npz", **out)
 
 
+def gen_traj():
+    """FIVE optimisation steps of the REFERENCE model: ``training_step`` (model.py:112-119: loss = sum of the loss dict) under the
+    optimizer hparams.yaml:63-68 configures (``torch.optim.SGD`` on ``net.parameters()``, lr 1e-3, weight decay 1e-3, momentum 0.9,
+    model.py:76-78).  Two trajectories from the seed-reproducible state dict of the e2e fixture:
+      live    the module in train() -- BatchNorm on batch statistics with running-stat updates (Q18) -- on two images per step;
+      frozen  the module as constructed (backbone.py:347-351: BatchNorm layers in eval(), everything else in training mode) on four
+              images per step of one size: the run a 2 x 2 data-parallel split reproduces exactly (per-image normaliser, Q8).
+    Recorded: the loss dict of every step, and for every parameter (and, live, every BatchNorm buffer) a fingerprint of
+    final - initial: norm, projection on a seeded direction, 16 seeded elements."""
+    print("[traj]  model.py:76-78,112-119 + hparams.yaml:63-68 (5 SGD steps of the reference model)")
+    out = {"opt": np.array([synth.TRAJ_OPT["lr"], synth.TRAJ_OPT["weight_decay"], synth.TRAJ_OPT["momentum"]], np.float64),
+           "steps": np.array(synth.TRAJ_STEPS)}
+    for kind in ("live", "frozen"):
+        torch.manual_seed(0)
+        ref = R.Retinanet(**synth.TRAJ)
+        spec = [(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in ref.state_dict().items()]
+        vals = synth.state_dict_values(spec, seed=4242)
+        sd = ref.state_dict()
+        for k, v in vals.items():
+            sd[k] = torch.from_numpy(v)
+        ref.load_state_dict(sd)
+        if kind == "live":
+            ref.train()
+        else:
+            assert ref.training and not ref.backbone.backbone.bn1.training          # as constructed: freeze_bn=True
+        opt = torch.optim.SGD(ref.parameters(), **synth.TRAJ_OPT)
+        initial = {k: v.detach().clone() for k, v in ref.state_dict().items()}
+        losses = []
+        for step in range(synth.TRAJ_STEPS):
+            images, targets = synth.traj_inputs(kind, step)
+            timgs = [torch.from_numpy(i) for i in images]
+            ttgts = [{"boxes": torch.from_numpy(b), "labels": torch.from_numpy(l)} for b, l in targets]
+            loss_dict = ref(timgs, ttgts)
+            total = sum(l for l in loss_dict.values())
+            opt.zero_grad()
+            total.backward()
+            opt.step()
+            losses.append([float(loss_dict["classification_loss"].detach()), float(loss_dict["regression_loss"].detach())])
+            print(f"  {kind} step {step}: cls={losses[-1][0]:.6f} reg={losses[-1][1]:.6f}")
+        out[f"{kind}_losses"] = np.array(losses, np.float64)
+        final = ref.state_dict()
+        pkeys = [k for k, _ in ref.named_parameters()]
+        bkeys = [k for k, _ in ref.named_buffers() if "running_" in k] if kind == "live" else []
+        for tag, keys in (("param", pkeys), ("buf", bkeys)):
+            if not keys:
+                continue
+            fps = [synth.fingerprint(k, (final[k].double() - initial[k].double()).numpy()) for k in keys]
+            out[f"{kind}_{tag}_keys"] = np.array(keys)
+            out[f"{kind}_{tag}_norm"] = np.array([f[0] for f in fps])
+            out[f"{kind}_{tag}_proj"] = np.array([f[1] for f in fps])
+            out[f"{kind}_{tag}_pos"] = np.stack([f[2] for f in fps])
+            out[f"{kind}_{tag}_samples"] = np.stack([f[3] for f in fps])
+            out[f"{kind}_{tag}_scale"] = np.array([float(initial[k].double().norm()) for k in keys])     # |initial|: what "moved" is relative to
+        if kind == "live":
+            assert int(final["backbone.backbone.bn1.num_batches_tracked"]) == synth.TRAJ_STEPS
+        else:
+            assert torch.equal(final["backbone.backbone.bn1.running_mean"], initial["backbone.backbone.bn1.running_mean"])
+        moved = np.array([f for f in out[f"{kind}_param_norm"]])
+        print(f"  {kind}: {len(pkeys)} parameters, |delta| median {np.median(moved):.3e} max {moved.max():.3e}")
+    save("traj.npz", **out)
+
+
 if __name__ == "__main__":
     oracle.build()
-    which = sys.argv[1:] or ["anchors", "match", "loss", "decode", "detect", "nms", "transform", "e2e"]
+    which = sys.argv[1:] or ["anchors", "match", "loss", "decode", "detect", "nms", "transform", "e2e", "traj"]
     for w in which:
         globals()["gen_" + w]()
     print("done")

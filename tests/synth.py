@@ -135,3 +135,36 @@ def e2e_inputs(seed: int = 31):
         b, l = gt_boxes(rng, T, h, w, num_classes=5, wh_lo=20.0, wh_hi=90.0)
         targets.append((b, l))
     return images, targets
+
+
+TRAJ = dict(num_classes=5, backbone_kind="resnet18", pretrained=False, min_size=128, max_size=160)
+# The reference's optimizer (hparams.yaml:63-68: SGD, weight decay 1e-3, momentum 0.9) at a learning rate of 2e-5 instead of its 1e-3:
+# on this synthetic state dict 1e-3 diverges (total loss 3.2 -> 18.9 / 212.9 at step 1) and the 5-step map amplifies a 1e-6 relative
+# perturbation of the initial weights to 9e-4 in the losses -- no tolerance could tell a wrong step from rounding.  At 2e-5 the
+# losses fall (3.23 -> 3.01, 3.89 -> 3.55) and the same perturbation stays at 2e-6 (scratch-measured with the reference itself,
+# tests/golden/gen_golden.py gen_traj prints the trajectory).
+TRAJ_OPT = dict(lr=2e-5, weight_decay=1e-3, momentum=0.9)
+TRAJ_STEPS = 5
+
+
+def traj_inputs(kind: str, step: int):
+    """Batch ``step`` of the training-trajectory fixture (tests/golden/traj.npz).
+    ``live``: two images of different sizes (the transform resizes and pads them), 3 and 2 GT boxes -- the same shapes at every
+    step, so a captured step serves all of them.  ``frozen``: four images of exactly 3 x 128 x 160 (no resize, no padding: a rank
+    that holds images [2r, 2r + 1] sees the same feature maps as the global batch), 3 GT boxes each."""
+    rng = np.random.default_rng(7000 + 31 * step + (0 if kind == "live" else 500))
+    sizes = [(120, 150), (140, 128)] if kind == "live" else [(128, 160)] * 4
+    counts = (3, 2) if kind == "live" else (3, 3, 3, 3)
+    images = [rng.random((3, h, w), dtype=np.float32) for h, w in sizes]
+    targets = [gt_boxes(rng, T, h, w, num_classes=5, wh_lo=20.0, wh_hi=90.0) for (h, w), T in zip(sizes, counts)]
+    return images, targets
+
+
+def fingerprint(key: str, delta: np.ndarray, nsample: int = 16):
+    "(norm, projection on a direction seeded by the key, positions, samples) of a tensor -- the trajectory fixture's record of one parameter's movement"
+    import zlib
+    flat = np.asarray(delta, dtype=np.float64).reshape(-1)
+    seed = zlib.crc32(key.encode())
+    r = np.random.default_rng(seed).standard_normal(flat.size)
+    pos = np.random.default_rng(seed ^ 0x5A5A5A5A).integers(0, flat.size, nsample)
+    return float(np.linalg.norm(flat)), float(flat @ r), pos.astype(np.int64), flat[pos]

@@ -1,0 +1,206 @@
+"""The TRAINING LOOP against the reference's: five optimisation steps (``/root/reference/model.py:112-119`` ``training_step`` = sum of the
+loss dict, ``model.py:76-78`` + ``hparams.yaml:63-68`` = ``torch.optim.SGD`` with momentum 0.9 and weight decay 1e-3 over
+``net.parameters()``) of the reference's own ``Retinanet`` on a seed-reproducible state dict, recorded by ``tests/golden/gen_golden.py traj``
+into ``tests/golden/traj.npz``: per-step loss dicts, and for every parameter / BatchNorm buffer a fingerprint of final - initial (norm,
+projection on a seeded direction, 16 seeded elements).  Two recorded runs: ``live`` (module in train(): BatchNorm on batch statistics,
+Q18) and ``frozen`` (the module as constructed, ``backbone.py:347-351``: BatchNorm in eval()) on four same-size images, which a 2 x 2
+data-parallel split reproduces exactly (per-image normaliser, Q8).  The learning rate of the fixture is 2e-5, not hparams' 1e-3
+(``synth.TRAJ_OPT``: 1e-3 diverges on the synthetic weights and makes the 5-step map chaotic).
+
+Held to it: (a) this package's eager step, (b) ``graph.CapturedTrainStep`` (2 eager steps + capture + 2 replays),
+fp32 and bf16 autocast on bf16 working copies under ``MasterSGD``, (c) two ranks on the split batch through the segmented graphs
+(``tools/ddp_two_rank.py --fixture traj``).  Tolerances: fp32 per-step losses rel <= 1e-3, bf16 <= 2e-2; parameter
+movement: see ``_BOUNDS`` (measured on MI355X, then fixed with margin).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# worst-parameter bounds on (|norm - ref| / ref, |proj - ref| / ref norm, |sample - ref| / rms of the reference delta)
+_BOUNDS = {"32": (1e-2, 2e-2, 1e-1), "bf16": (0.25, 0.25, 1.5)}
+_LOSS_RTOL = {"32": 1e-3, "bf16": 2e-2}
+
+
+def _fixture():
+    return np.load(os.path.join(ROOT, "tests", "golden", "traj.npz"), allow_pickle=False)
+
+
+def build_model(device, kind):
+    "This package's Retinanet with the fixture's state dict, in the fixture's mode (live: train(); frozen: BatchNorm in eval())."
+    import pytorch_retinanet_amd as P
+    net = P.Retinanet(**synth.TRAJ)
+    sd = net.state_dict()
+    spec = [(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in sd.items()]
+    for k, v in synth.state_dict_values(spec, seed=4242).items():
+        sd[k] = torch.from_numpy(v)
+    net.load_state_dict(sd)
+    net = net.to(device).to(memory_format=torch.channels_last).train()
+    if kind == "frozen":
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.eval()
+    return net
+
+
+def masters(net):
+    return {n: (p.master if hasattr(p, "master") else p.data).detach().double().cpu().numpy().copy() for n, p in net.named_parameters()}
+
+
+def buffers(net):
+    return {n: b.detach().double().cpu().numpy().copy() for n, b in net.named_buffers() if "running_" in n}
+
+
+def batch(kind, step, device, lo=0, hi=None):
+    images, targets = synth.traj_inputs(kind, step)
+    hi = len(images) if hi is None else hi
+    timgs = [torch.from_numpy(i).to(device) for i in images[lo:hi]]
+    ttgts = [{"boxes": torch.from_numpy(b).to(device), "labels": torch.from_numpy(l).to(device)} for b, l in targets[lo:hi]]
+    return timgs, ttgts
+
+
+def movement_errors(g, kind, tag, initial, final):
+    "Worst (norm, projection, sample) errors of final - initial against the fixture's fingerprints, and the keys that hold them."
+    worst, where = [0.0, 0.0, 0.0], ["", "", ""]
+    keys = [str(k) for k in g[f"{kind}_{tag}_keys"]]
+    assert keys == [k for k in initial if k in set(keys)] and len(keys) == len(initial), "parameter / buffer names differ from the reference's"
+    for i, k in enumerate(keys):
+        norm, proj, pos, samp = float(g[f"{kind}_{tag}_norm"][i]), float(g[f"{kind}_{tag}_proj"][i]), g[f"{kind}_{tag}_pos"][i], g[f"{kind}_{tag}_samples"][i]
+        d = (final[k] - initial[k]).reshape(-1)
+        gn, gp, _, gs = synth.fingerprint(k, d)
+        assert norm > 0, k
+        rms = norm / np.sqrt(d.size)
+        errs = (abs(gn - norm) / norm, abs(gp - proj) / norm, float(np.max(np.abs(gs - samp))) / rms)
+        for j in range(3):
+            if errs[j] > worst[j]:
+                worst[j], where[j] = errs[j], k
+    return worst, where
+
+
+def check_run(g, kind, precision, losses, initial, final, buf0=None, buf1=None):
+    ref = g[f"{kind}_losses"]
+    got = np.array(losses, np.float64)
+    assert got.shape == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=_LOSS_RTOL[precision], err_msg=f"{kind} {precision}: per-step loss dict")
+    worst, where = movement_errors(g, kind, "param", initial, final)
+    print(f"[traj] {kind} {precision}: loss rel err {np.max(np.abs(got - ref) / np.abs(ref)):.2e}; parameter movement worst (norm, proj, sample) "
+          f"= {worst[0]:.3e} {worst[1]:.3e} {worst[2]:.3e} at {where}")
+    for w, b, k in zip(worst, _BOUNDS[precision], where):
+        assert w <= b, (kind, precision, worst, where)
+    if buf0 is not None:
+        wb, whb = movement_errors(g, kind, "buf", buf0, buf1)
+        print(f"[traj] {kind} {precision}: BN running statistics worst = {wb[0]:.3e} {wb[1]:.3e} {wb[2]:.3e} at {whb}")
+        for w, b in zip(wb, _BOUNDS[precision]):
+            assert w <= b, (kind, precision, "running statistics", wb, whb)
+
+
+def test_fixture_is_the_reference_optimizer_and_covers_every_parameter():
+    "CPU: the fixture carries hparams' momentum / weight decay, five steps, and one fingerprint per parameter of this package's model."
+    g = _fixture()
+    assert int(g["steps"]) == synth.TRAJ_STEPS == 5 and g["opt"].tolist() == [synth.TRAJ_OPT["lr"], 1e-3, 0.9]
+    import yaml
+    hp = yaml.safe_load(open(os.path.join(ROOT, "pytorch_retinanet_amd", "hparams.yaml")))["optimizer"]["params"]
+    assert hp["weight_decay"] == synth.TRAJ_OPT["weight_decay"] and hp["momentum"] == synth.TRAJ_OPT["momentum"]
+    import pytorch_retinanet_amd as P
+    net = P.Retinanet(**synth.TRAJ)
+    for kind in ("live", "frozen"):
+        assert [str(k) for k in g[f"{kind}_param_keys"]] == [n for n, _ in net.named_parameters()]
+        assert g[f"{kind}_losses"].shape == (5, 2) and np.all(g[f"{kind}_param_norm"] > 0)
+        assert g[f"{kind}_losses"][:, 0].min() > 1.0 and g[f"{kind}_losses"].sum(1)[-1] < g[f"{kind}_losses"].sum(1)[0]      # it trains
+    assert [str(k) for k in g["live_buf_keys"]] == [n for n, _ in net.named_buffers() if "running_" in n]
+
+
+@pytest.mark.reference
+def test_fixture_is_current_with_the_reference():
+    "Build container: the first two steps of the live trajectory, re-run with the reference itself, equal the committed fixture."
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import _tv_standin
+    R = _tv_standin.import_reference()
+    g = _fixture()
+    torch.manual_seed(0)
+    ref = R.Retinanet(**synth.TRAJ)
+    sd = ref.state_dict()
+    spec = [(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in sd.items()]
+    for k, v in synth.state_dict_values(spec, seed=4242).items():
+        sd[k] = torch.from_numpy(v)
+    ref.load_state_dict(sd)
+    ref.train()
+    opt = torch.optim.SGD(ref.parameters(), **synth.TRAJ_OPT)
+    for step in range(2):
+        images, targets = synth.traj_inputs("live", step)
+        out = ref([torch.from_numpy(i) for i in images], [{"boxes": torch.from_numpy(b), "labels": torch.from_numpy(l)} for b, l in targets])
+        total = sum(out.values())
+        opt.zero_grad()
+        total.backward()
+        opt.step()
+        np.testing.assert_allclose([float(out["classification_loss"]), float(out["regression_loss"])], g["live_losses"][step], rtol=1e-5)
+
+
+def _run_single(kind, precision, captured):
+    from pytorch_retinanet_amd.graph import CapturedTrainStep
+    from pytorch_retinanet_amd.optim import MasterSGD, use_bf16_conv_weights
+    net = build_model(DEV, kind)
+    bf16 = precision == "bf16"
+    if bf16:
+        use_bf16_conv_weights(net)
+    opt = MasterSGD(net.parameters(), **synth.TRAJ_OPT)
+    initial, buf0 = masters(net), buffers(net)
+    step = CapturedTrainStep(net, opt, amp_dtype=torch.bfloat16 if bf16 else None, eager_steps=2, enabled=captured)
+    losses = []
+    for s in range(synth.TRAJ_STEPS):
+        out = step(*batch(kind, s, DEV))
+        losses.append([float(out["classification_loss"]), float(out["regression_loss"])])
+    torch.cuda.synchronize()
+    assert step.replays == (synth.TRAJ_STEPS - 2 if captured else 0) and step.captures == int(captured)
+    return losses, initial, masters(net), buf0, buffers(net)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["live", "frozen"])
+@pytest.mark.parametrize("precision", ["32", "bf16"])
+@pytest.mark.parametrize("captured", [False, True], ids=["eager", "captured"])
+def test_five_steps_reproduce_the_reference_trajectory(kind, precision, captured):
+    g = _fixture()
+    losses, p0, p1, b0, b1 = _run_single(kind, precision, captured)
+    check_run(g, kind, precision, losses, p0, p1, *((b0, b1) if kind == "live" else ()))
+    if kind == "frozen":
+        for k in b0:
+            assert np.array_equal(b0[k], b1[k]), k                        # BatchNorm in eval(): running statistics untouched
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["32", "bf16"])
+def test_two_ranks_on_the_split_batch_reproduce_the_reference_trajectory(tmp_path, precision):
+    """(c): the frozen-BatchNorm trajectory of the reference on four images per step == two ranks with two images each through
+    ``BucketedGradAllReduce`` + the segmented ``CapturedTrainStep`` (2 eager staged steps + capture + 2 replays), ranks bit-equal."""
+    g = _fixture()
+    out = str(tmp_path)
+    env = dict(os.environ, MIOPEN_LOG_LEVEL="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "ddp_two_rank.py"), "--out", out, "--precision", precision,
+           "--segmented", "--fixture", "traj", "--steps", str(synth.TRAJ_STEPS)]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    r0, r1 = torch.load(os.path.join(out, "rank0.pt")), torch.load(os.path.join(out, "rank1.pt"))
+    assert r0["replays"] >= 2 and r1["replays"] >= 2
+    for k, a in r0["params"].items():
+        assert torch.equal(a, r1["params"][k]), f"ranks diverged at {k}"
+    # the reference's loss at a step = the mean over the four images = the mean of the two ranks' losses (each the mean of its two)
+    losses = 0.5 * (np.array(r0["loss_dicts"]) + np.array(r1["loss_dicts"]))
+    initial = {k: v.double().numpy() for k, v in r0["initial"].items()}
+    final = {k: v.double().numpy() for k, v in r0["params"].items()}
+    check_run(g, "frozen", precision, losses, initial, final)

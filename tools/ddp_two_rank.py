@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--ranks", type=int, default=2, help="--single --bn train: number of ranks to emulate")
     ap.add_argument("--segmented", action="store_true", help="ranks: run the steps through graph.CapturedTrainStep's segmented form (staged "
                     "backward, four hipGraph segments from the third step on, all-reduces issued between the replays)")
+    ap.add_argument("--fixture", default=None, choices=[None, "traj"], help="traj: the reference's recorded training trajectory "
+                    "(tests/golden/traj.npz, frozen BatchNorm, four images per step): its state dict, inputs and optimizer settings")
     args = ap.parse_args()
     world = 1 if args.single else int(os.environ["WORLD_SIZE"])
     rank = 0 if args.single else int(os.environ["RANK"])
@@ -59,6 +61,17 @@ def main():
         with torch.no_grad():
             for p in net.parameters():
                 p.add_(0.01)
+    if args.fixture == "traj":
+        sd = net.state_dict()
+        spec = [(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in sd.items()]
+        for k, v in synth.state_dict_values(spec, seed=4242).items():
+            sd[k] = torch.from_numpy(v)
+        net.load_state_dict(sd)
+        initial = {n: p.detach().clone() for n, p in net.named_parameters()}
+        if rank == 1:
+            with torch.no_grad():
+                for p in net.parameters():
+                    p.add_(0.01)
     net = net.to(dev).to(memory_format=torch.channels_last).train()
     live_bn = args.bn == "train"
     if not live_bn:
@@ -68,7 +81,7 @@ def main():
     bf16 = args.precision == "bf16"
     if bf16:
         use_bf16_conv_weights(net)
-    opt = MasterSGD(net.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    opt = MasterSGD(net.parameters(), **(synth.TRAJ_OPT if args.fixture == "traj" else dict(lr=1e-2, momentum=0.9, weight_decay=1e-3)))
     emulate = args.ranks if (args.single and live_bn) else 0
     from pytorch_retinanet_amd.graph import CapturedTrainStep, retinanet_stage_of
     ddp = None if emulate else P.BucketedGradAllReduce(net, bucket_mb=8.0, stage_of=retinanet_stage_of if args.segmented else None)   # several buckets for a 20 M-parameter model
@@ -88,13 +101,19 @@ def main():
     rng = np.random.default_rng(99)
     G = args.global_batch
     per = G // (emulate or world)
-    losses = []
+    losses, loss_dicts = [], []
     for step in range(args.steps):
-        images = [torch.from_numpy(rng.random((3, 128, 160), dtype=np.float32)) for _ in range(G)]
-        targets = []
-        for _ in range(G):
-            b, l = synth.gt_boxes(rng, 3, 128, 160, num_classes=5, wh_lo=20.0, wh_hi=90.0)
-            targets.append({"boxes": torch.from_numpy(b), "labels": torch.from_numpy(l)})
+        if args.fixture == "traj":
+            ims, tgs = synth.traj_inputs("frozen", step)
+            assert len(ims) == G
+            images = [torch.from_numpy(i) for i in ims]
+            targets = [{"boxes": torch.from_numpy(b), "labels": torch.from_numpy(l)} for b, l in tgs]
+        else:
+            images = [torch.from_numpy(rng.random((3, 128, 160), dtype=np.float32)) for _ in range(G)]
+            targets = []
+            for _ in range(G):
+                b, l = synth.gt_boxes(rng, 3, 128, 160, num_classes=5, wh_lo=20.0, wh_hi=90.0)
+                targets.append({"boxes": torch.from_numpy(b), "labels": torch.from_numpy(l)})
         if emulate:
             opt.zero_grad(set_to_none=True)
             tot = 0.0
@@ -116,7 +135,9 @@ def main():
         imgs = [i.to(dev) for i in images[mine]]
         tgts = [{k: v.to(dev) for k, v in t.items()} for t in targets[mine]]
         if stepper is not None:
-            losses.append(float(stepper(imgs, tgts)["loss"]))
+            o = stepper(imgs, tgts)
+            losses.append(float(o["loss"]))
+            loss_dicts.append([float(o["classification_loss"]), float(o["regression_loss"])])
             continue
         ddp.zero_grad()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
@@ -126,11 +147,13 @@ def main():
         ddp.finish()
         opt.step(grads=ddp.grad_views())
         losses.append(float(loss.detach()))
+        loss_dicts.append([float(out["classification_loss"].detach()), float(out["regression_loss"].detach())])
     torch.cuda.synchronize()
     state = {n: (p.master if hasattr(p, "master") else p.data).detach().float().cpu() for n, p in net.named_parameters()}
     os.makedirs(args.out, exist_ok=True)
     bufs = [{n: b.float().cpu() for n, b in rb.items()} for rb in rank_bufs] if emulate else [{n: b.float().cpu() for n, b in bn_buffers().items()}]
-    torch.save({"params": state, "losses": losses, "buckets": ddp.bucket_bytes() if ddp else [], "bn_buffers": bufs,
+    torch.save({"params": state, "losses": losses, "buckets": ddp.bucket_bytes() if ddp else [], "bn_buffers": bufs, "loss_dicts": loss_dicts,
+                "initial": {n: v.float().cpu() for n, v in initial.items()} if args.fixture == "traj" else {},
                 "replays": stepper.replays if stepper is not None else 0},
                os.path.join(args.out, "single.pt" if args.single else f"rank{rank}.pt"))
     if not args.single:
