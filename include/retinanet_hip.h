@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RN_ABI_VERSION 7
+#define RN_ABI_VERSION 8
 #define RN_MAX_LEVELS 8
 
 enum rn_dtype { RN_F32 = 0, RN_BF16 = 1, RN_F16 = 2 };
@@ -277,7 +277,9 @@ int rn_bn_bwd_apply(const void *dy, const void *y, const void *x, void *dx, void
  * workspace rn_pw_wgrad_workspace_bytes(d) (f32 partials of the position splits, summed in a fixed order). */
 enum { RN_PW_PRO_NONE = 0, RN_PW_PRO_AFFINE_RELU = 1, RN_PW_PRO_BN_BWD = 2 };
 enum { RN_PW_EPI_NONE = 0, RN_PW_EPI_STATS = 1, RN_PW_EPI_RESID = 2, RN_PW_EPI_RELU_BWD = 4, RN_PW_EPI_BIAS = 8 };
-typedef struct rn_pw_conv { int64_t M; int32_t Cin, N, taps, stride, pad, Ho, Wo, H, W; } rn_pw_conv;
+/* dtype: element type of x / w / y / g / dw -- RN_BF16 or RN_F16 (0, what a caller from before ABI version 8 leaves in the struct's
+ * tail padding, means RN_BF16); the struct's size did not change. */
+typedef struct rn_pw_conv { int64_t M; int32_t Cin, N, taps, stride, pad, Ho, Wo, H, W, dtype; } rn_pw_conv;
 typedef struct rn_pw_prologue {
     int32_t kind, relu_mode;
     const float *a, *b, *c, *fa, *fb;
@@ -310,6 +312,8 @@ int rn_pw_conv_wgrad(const rn_pw_conv *d, const void *g, const void *x, void *dw
  * launch: _partial runs the position-contraction kernel only (f32 partials of *splits position splits in `workspace`, which must
  * stay untouched until the reduction), rn_pw_wgrad_reduce_many sums up to 8 of them into their bf16 gradients (n_elems[i] =
  * N * taps * Cin of gradient i; HOST arrays). */
+int rn_pw_wgrad_reduce_many_dt(const void *const *partials, const int *splits, const int64_t *n_elems, void *const *dws, int n, int dtype,
+                               void *stream);
 int rn_pw_conv_wgrad_partial(const rn_pw_conv *d, const void *g, const void *x, const rn_pw_prologue *gpro, const rn_pw_prologue *xpro,
                              void *workspace, size_t workspace_bytes, int *splits, void *stream);
 int rn_pw_wgrad_reduce_many(const void *const *partials, const int *splits, const int64_t *n_elems, void *const *dws, int n, void *stream);
@@ -398,7 +402,7 @@ int rn_bias_act_backward(const void *dy, const void *y, const uint8_t *mask, voi
  * x, y: [M = N*Hp*Wp][C] bf16 (channels-last [N, C, Hp, Wp]); w: [Cout][3][3][Cin] bf16 (the channels-last
  * memory of a [Cout, Cin, 3, 3] weight); bias f32[Cout] or NULL; mask u8[HWp = Hp*Wp] or NULL -- it must be 0 on
  * the border (border outputs are computed from wrapped neighbours and are only correct as zeros).  Wp = row
- * pitch in positions.  dtype: RN_BF16 only; Cin % 64 == 0, Cout % 256 == 0 (else RN_EUNSUPPORTED: the caller
+ * pitch in positions.  dtype: RN_BF16 or RN_F16 (every conv3x3 / stem / narrow entry point of this library: the same kernels instantiated on v_mfma_..._bf16 / _f16); Cin % 64 == 0, Cout % 256 == 0 (else RN_EUNSUPPORTED: the caller
  * keeps its MIOpen path).  The data gradient is the same call with the taps reversed and the channel roles
  * swapped (w' = w.flip(2, 3).transpose(0, 1)), relu = 0, bias = NULL. */
 int rn_conv3x3_canvas(const void *x, const void *w, const float *bias, const uint8_t *mask, void *y, int dtype,
@@ -555,6 +559,13 @@ int rn_fpn_upsample2x_backward(const void *g, void *dtop, int dtype, int N, int 
 int rn_sgd_master_step(float *const *masters, float *const *momenta, const void *const *grads, void *const *params16,
                        const int64_t *numels, int n_tensors, int grads16, float lr, float momentum, float dampening,
                        float weight_decay, int nesterov, int first_step, void *stream);
+/* The same step for fp16 working copies and for fp16 autocast under a loss scale (ABI 8): dtype16 = RN_BF16 or RN_F16 is the type of
+ * params16[i] (and of the 16-bit gradients); grad_scale / found_inf (nullable DEVICE scalars, f32) are what torch.amp.GradScaler hands
+ * an optimizer with `_step_supports_amp_scaling`: every gradient is divided by grad_scale[0] first, and when found_inf[0] != 0 the
+ * launch changes nothing (no parameter, no momentum buffer) -- no host synchronisation, so the step stays capturable. */
+int rn_sgd_master_step_ex(float *const *masters, float *const *momenta, const void *const *grads, void *const *params16,
+                          const int64_t *numels, int n_tensors, int grads16, int dtype16, float lr, float momentum, float dampening,
+                          float weight_decay, int nesterov, int first_step, const float *grad_scale, const float *found_inf, void *stream);
 
 /* ---- T1 transform (normalise + resize + pad + batch) -------------------------------------------
  * Replaces torchvision's GeneralizedRCNNTransform as the reference runs it at

@@ -30,7 +30,8 @@ class RnDetectParams(C.Structure):
 
 class RnPwConv(C.Structure):
     _fields_ = [("M", C.c_int64), ("Cin", C.c_int32), ("N", C.c_int32), ("taps", C.c_int32), ("stride", C.c_int32),
-                ("pad", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("H", C.c_int32), ("W", C.c_int32)]
+                ("pad", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("dtype", C.c_int32)]            # RN_BF16 / RN_F16 (0 = RN_BF16: older callers)
 
 
 class RnPwPrologue(C.Structure):
@@ -105,6 +106,7 @@ SIGNATURES = {
     "rn_bn_relu_maxpool3x3s2_forward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "rn_maxpool3x3s2_backward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "rn_sgd_master_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32, _f32, _f32, C.c_int, C.c_int, _vp]),
+    "rn_sgd_master_step_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _f32, _f32, _f32, C.c_int, C.c_int, _vp, _vp, _vp]),
     "rn_conv3x3_canvas_to_levels": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                               _vp, _vp]),
     "rn_conv3x3_levels_to_canvas": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -144,6 +146,7 @@ SIGNATURES = {
     "rn_conv3x3_levels_dgrad_weight": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "rn_pw_conv_wgrad_partial": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "rn_pw_wgrad_reduce_many": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "rn_pw_wgrad_reduce_many_dt": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]),
     "rn_transform_batch": (C.c_int, [_vp, _vp, _vp, C.c_int, C.POINTER(_f32), C.POINTER(_f32), C.c_int, C.c_int, _vp,
                                      C.c_int, C.c_int, _vp]),
     "rn_nms_workspace_bytes": (_sz, [_i64, C.c_int]),

@@ -15,6 +15,7 @@ from torch import Tensor, nn
 
 from . import pwconv
 from .norm import RAW_WRITES, FusedBatchNorm2d, _BNAct
+from .pwconv import H16
 from .pool import FusedMaxPool2d
 
 __all__ = ["resnet18", "resnet34", "resnet50", "resnet101", "resnet152"]
@@ -142,7 +143,7 @@ class _Conv1x1Skip(torch.autograd.Function):
         ctx.link = link
         N, Cin, H, W = x.shape
         Cmid = w.shape[0]
-        if pwconv.MM_1X1 and x.dtype == torch.bfloat16 and pwconv._fwd_by_mm(N * H * W, Cin, Cmid):       # (hipBLASLt: pwconv._Conv1x1)
+        if pwconv.MM_1X1 and x.dtype in H16 and pwconv._fwd_by_mm(N * H * W, Cin, Cmid):       # (hipBLASLt: pwconv._Conv1x1)
             return (x.permute(0, 2, 3, 1).reshape(-1, Cin) @ w.reshape(Cmid, Cin).t()).view(N, H, W, Cmid).permute(0, 3, 1, 2)
         return F.conv2d(x, w)
 
@@ -169,7 +170,7 @@ class _Conv1x1Skip(torch.autograd.Function):
                 dx2 = g2 @ w2
             dx = dx2.view(N, H, W, Cin).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[1]:
-            if pwconv.MM_1X1 and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and Cin % 64 == 0 and Cmid % 64 == 0:
+            if pwconv.MM_1X1 and x.dtype in H16 and w.dtype == x.dtype and Cin % 64 == 0 and Cmid % 64 == 0:
                 dw = pwconv.pw_wgrad(g, x, w, tag="pw_1x1_wgrad")                # position-contraction kernel of csrc/pw.hip
             else:
                 dw = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]

@@ -25,6 +25,7 @@ from ._lib import RN_BF16, RN_F16, RN_F32, check, lib
 from .ops import _timed          # event pairs around the MFMA conv launches when ops.enable_timing(True) (bench.py)
 
 _DT = {torch.float32: RN_F32, torch.bfloat16: RN_BF16, torch.float16: RN_F16}
+H16 = (torch.bfloat16, torch.float16)          # the element types of the MFMA conv kernels (v_mfma_*_bf16 / _f16: same rate, same kernels)
 _WS: Dict[tuple, Tensor] = {}
 PAIR_SHEETS = True     # two images per canvas sheet (Canvas.of) when that takes fewer positions
 MFMA_FLOP: Dict[str, float] = {}      # USEFUL flop per call of every timed MFMA launch (bench.py: achieved TFLOP/s of the own conv kernels)
@@ -104,7 +105,7 @@ def _canvas_wgrad(gs, xs, ws, Wp: int, stream: int):
     """Weight gradients of P canvas convs (256 -> 256, bf16) by ``rn_conv3x3_canvas_wgrad_batched``; None when the
     shapes are outside the kernel's range (the caller then asks MIOpen)."""
     x0, w0 = xs[0], ws[0]
-    if not (MFMA_WGRAD and x0.dtype == torch.bfloat16 and tuple(w0.shape) == (256, 256, 3, 3)):
+    if not (MFMA_WGRAD and x0.dtype in H16 and tuple(w0.shape) == (256, 256, 3, 3)):
         return None
     dev = x0.device
     N, _, Hp, _ = x0.shape
@@ -307,7 +308,7 @@ def tower_conv_pair(x0: Tensor, x1: Tensor, w0: Tensor, w1: Tensor, b0: Tensor, 
 def tower_conv_fusable(x: Tensor, conv) -> bool:
     "The MFMA canvas conv covers bf16, 3x3 / stride 1 / pad 1, Cin % 64 == 0 and Cout % 256 == 0 (head towers: 256 -> 256)."
     # (its data gradient runs on the same kernel when Cin % 256 == 0 as well, else on MIOpen)
-    return (x.is_cuda and x.dtype == torch.bfloat16 and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and
+    return (x.is_cuda and x.dtype in H16 and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and
             conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is not None and
             conv.in_channels % 64 == 0 and conv.out_channels % 256 == 0)
 
@@ -411,7 +412,7 @@ class Canvas:
 def _pack_native(cv: "Canvas", levels: Sequence[Tensor], canvas_t: Tensor, n_images: int, to_canvas: bool) -> bool:
     """``rn_canvas_pack``: all levels <-> the canvas sheets in one launch (False: shapes / dtypes the kernel does not take)."""
     x = canvas_t
-    if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 4 and _cl(x) and x.shape[1] % 2 == 0
+    if not (x.is_cuda and x.dtype in H16 and x.dim() == 4 and _cl(x) and x.shape[1] % 2 == 0
             and len(levels) <= 6 and x.shape[0] * cv.H * cv.W < (1 << 22)):
         return False
     for t in levels:
@@ -558,7 +559,7 @@ def invalidate_dgrad_weights() -> None:
 
 
 def _dw_eligible(w: Tensor) -> bool:
-    return (DGRAD_WEIGHT_TABLE and w.is_cuda and w.dtype in (torch.bfloat16, torch.float16) and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3)
+    return (DGRAD_WEIGHT_TABLE and w.is_cuda and w.dtype in H16 and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3)
             and _cl(w) and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0)
 
 
@@ -618,7 +619,7 @@ def _dgrad_weight(w: Tensor) -> Tensor:
     e .. e+7 carry channels Cout-8 .. Cout-1 with zero weight on the repeated ones; zeros up to Kpad."""
     Cout, Cin = w.shape[0], w.shape[1]
     Kpad = (Cout + 63) // 64 * 64
-    if w.is_cuda and w.dtype in (torch.bfloat16, torch.float16) and _cl(w) and Cout >= 8:
+    if w.is_cuda and w.dtype in H16 and _cl(w) and Cout >= 8:
         # one launch (the torch form below is a flip, a fill and two or three strided copies: ~35 us of 5-us kernels per conv)
         out = torch.empty((Cin, Kpad, 3, 3), dtype=w.dtype, device=w.device, memory_format=torch.channels_last)
         check(lib.rn_conv3x3_levels_dgrad_weight(w.data_ptr(), out.data_ptr(), Cout, Cin, Kpad, torch.cuda.current_stream(w.device).cuda_stream),
@@ -706,7 +707,7 @@ class _ClsOutputConv(torch.autograd.Function):
 def _colsum_levels(gs: Sequence[Tensor], C_: int) -> Tensor:
     "f32[C] = column sums over all rows of the dense per-level tensors ``[N, rows * C]`` (bias gradient): one read, two launches."
     dev = gs[0].device
-    if gs[0].dtype not in (torch.bfloat16, torch.float16) or C_ % 2 or len(gs) > 6:
+    if gs[0].dtype not in H16 or C_ % 2 or len(gs) > 6:
         return sum(g.reshape(-1, C_).sum(0, dtype=torch.float32) for g in gs)
     stream = torch.cuda.current_stream().cuda_stream
     need = lib.rn_colsum_rows_workspace_bytes(len(gs), C_)
@@ -829,7 +830,7 @@ def box_output_conv(x: Tensor, conv, canvas: "Canvas", n_images: int, relu_link=
 
 def cls_output_conv_fusable(x: Tensor, conv, canvas: "Canvas") -> bool:
     "bf16 canvas with a zero border, 3x3 / stride 1 / pad 1, Cin == 256, an even number of output channels (>= 8), <= 6 levels."
-    return (x.is_cuda and x.dtype == torch.bfloat16 and _cl(x) and canvas.pad == 1 and conv.kernel_size == (3, 3)
+    return (x.is_cuda and x.dtype in H16 and _cl(x) and canvas.pad == 1 and conv.kernel_size == (3, 3)
             and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
             and conv.in_channels == 256 and conv.out_channels % 2 == 0 and 8 <= conv.out_channels <= 1024
             and len(canvas.shapes) <= 6 and canvas.slots <= 8 and x.shape[0] * canvas.H * canvas.W < (1 << 22)
@@ -855,7 +856,7 @@ def dense_group_fusable(xs: Sequence[Tensor], convs) -> bool:
         return False
     N = xs[0].shape[0]
     for x, conv in zip(xs, convs):
-        if not (x.is_cuda and x.dtype == torch.bfloat16 and _cl(x) and x.shape[0] == N and x.shape[1] == 256 and
+        if not (x.is_cuda and x.dtype in H16 and _cl(x) and x.shape[0] == N and x.shape[1] == 256 and
                 N * x.shape[2] * x.shape[3] < (1 << 22) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and
                 conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is not None and
                 conv.in_channels == 256 and conv.out_channels == 256 and conv.bias.dtype == torch.float32):
@@ -887,7 +888,7 @@ class _DenseConvGroup(torch.autograd.Function):
         ys = [torch.empty_like(x) for x in xs]
         flop = sum(2.0 * N * h * w * 256 * 2304 for h, w in zip(hs, wds))
         _mfma_call(f"mfma_fpn_output_fwd_x{P}", dev, flop,
-                   lambda: lib.rn_conv3x3_dense_batched(_ptr_array(xs), _ptr_array(ws), _ptr_array(bs), _ptr_array(ys), P, RN_BF16, N,
+                   lambda: lib.rn_conv3x3_dense_batched(_ptr_array(xs), _ptr_array(ws), _ptr_array(bs), _ptr_array(ys), P, _DT[xs[0].dtype], N,
                                                         _int_array(hs), _int_array(wds), 256, 256, _zero_page(dev).data_ptr(), stream),
                    "rn_conv3x3_dense_batched")
         ctx.save_for_backward(*xs, *ws)
@@ -902,13 +903,13 @@ class _DenseConvGroup(torch.autograd.Function):
         if dev.index != torch.cuda.current_device():
             torch.cuda.set_device(dev)
         stream = torch.cuda.current_stream().cuda_stream
-        gs = [dy if (dy.dtype == torch.bfloat16 and _cl(dy)) else dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for dy in dys]
+        gs = [dy if (dy.dtype == xs[0].dtype and _cl(dy)) else dy.to(xs[0].dtype).contiguous(memory_format=torch.channels_last) for dy in dys]
         dxs = [None] * P
         if any(ctx.needs_input_grad[:P]):
             wts = dgrad_weights(list(ws), stream)
             dxs = [torch.empty_like(x) for x in xs]
             _mfma_call(f"mfma_fpn_output_dgrad_x{P}", dev, flop,
-                       lambda: lib.rn_conv3x3_dense_batched(_ptr_array(gs), _ptr_array(wts), None, _ptr_array(dxs), P, RN_BF16, N,
+                       lambda: lib.rn_conv3x3_dense_batched(_ptr_array(gs), _ptr_array(wts), None, _ptr_array(dxs), P, _DT[xs[0].dtype], N,
                                                             _int_array(hs), _int_array(wds), 256, 256, _zero_page(dev).data_ptr(), stream),
                        "rn_conv3x3_dense_batched")
         dws = [None] * P
@@ -918,9 +919,9 @@ class _DenseConvGroup(torch.autograd.Function):
             wsb = _DENSE_WS.get(key)
             if wsb is None or wsb.numel() < need:
                 wsb = _DENSE_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
-            dws = [torch.empty((256, 256, 3, 3), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last) for _ in range(P)]
+            dws = [torch.empty((256, 256, 3, 3), dtype=xs[0].dtype, device=dev, memory_format=torch.channels_last) for _ in range(P)]
             _mfma_call(f"mfma_fpn_output_wgrad_x{P}", dev, flop,
-                       lambda: lib.rn_conv3x3_dense_wgrad_batched(_ptr_array(gs), _ptr_array(xs), _ptr_array(dws), P, RN_BF16, N, _int_array(hs),
+                       lambda: lib.rn_conv3x3_dense_wgrad_batched(_ptr_array(gs), _ptr_array(xs), _ptr_array(dws), P, _DT[xs[0].dtype], N, _int_array(hs),
                                                                   _int_array(wds), 256, 256, _zero_page(dev).data_ptr(), wsb.data_ptr(),
                                                                   wsb.numel(), stream),
                        "rn_conv3x3_dense_wgrad_batched")
@@ -929,8 +930,8 @@ class _DenseConvGroup(torch.autograd.Function):
 
 
 def dense_conv_group(xs: Sequence[Tensor], convs) -> List[Tensor]:
-    "``[conv(x) for x, conv in zip(xs, convs)]`` for ``dense_group_fusable`` inputs; weights are cast to bf16 here (autocast's cast)."
-    return list(_DenseConvGroup.apply(*xs, *[c.weight.to(torch.bfloat16) for c in convs], *[c.bias for c in convs]))
+    "``[conv(x) for x, conv in zip(xs, convs)]`` for ``dense_group_fusable`` inputs; weights are cast to the activations' dtype here (autocast's cast)."
+    return list(_DenseConvGroup.apply(*xs, *[c.weight.to(xs[0].dtype) for c in convs], *[c.bias for c in convs]))
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -942,7 +943,7 @@ CONV3X3_FWD = True      # ... and the forward too (in the step CK's kernel takes
 
 
 def conv3x3_bwd_fusable(conv, x: Tensor) -> bool:
-    return (CONV3X3_BWD and x.is_cuda and x.dtype == torch.bfloat16 and conv.weight.dtype == torch.bfloat16 and _cl(x) and
+    return (CONV3X3_BWD and x.is_cuda and x.dtype in H16 and conv.weight.dtype == x.dtype and _cl(x) and
             conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1) and
             conv.groups == 1 and conv.bias is None and conv.in_channels == 256 and conv.out_channels == 256 and
             torch.is_grad_enabled() and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 22))
@@ -964,7 +965,7 @@ class _Conv3x3MfmaBwd(torch.autograd.Function):
         wc = w if _cl(w) else w.contiguous(memory_format=torch.channels_last)
         y = torch.empty_like(x)
         _mfma_call("mfma_conv2_fwd", dev, 2.0 * N * h * wd * 256 * 2304,
-                   lambda: lib.rn_conv3x3_dense_batched(_ptr_array([x]), _ptr_array([wc]), None, _ptr_array([y]), 1, RN_BF16, N,
+                   lambda: lib.rn_conv3x3_dense_batched(_ptr_array([x]), _ptr_array([wc]), None, _ptr_array([y]), 1, _DT[x.dtype], N,
                                                         _int_array([h]), _int_array([wd]), 256, 256, _zero_page(dev).data_ptr(), stream),
                    "rn_conv3x3_dense_batched")
         return y
@@ -977,7 +978,7 @@ class _Conv3x3MfmaBwd(torch.autograd.Function):
         if dev.index != torch.cuda.current_device():
             torch.cuda.set_device(dev)
         stream = torch.cuda.current_stream().cuda_stream
-        g = dy if (dy.dtype == torch.bfloat16 and _cl(dy)) else dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        g = dy if (dy.dtype == x.dtype and _cl(dy)) else dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
         wc = w if _cl(w) else w.contiguous(memory_format=torch.channels_last)
         flop = 2.0 * N * h * wd * 256 * 2304
         dx = dw = None
@@ -985,7 +986,7 @@ class _Conv3x3MfmaBwd(torch.autograd.Function):
             wt = dgrad_weights([w], stream)[0]
             dx = torch.empty_like(x)
             _mfma_call("mfma_conv2_dgrad", dev, flop,
-                       lambda: lib.rn_conv3x3_dense_batched(_ptr_array([g]), _ptr_array([wt]), None, _ptr_array([dx]), 1, RN_BF16, N,
+                       lambda: lib.rn_conv3x3_dense_batched(_ptr_array([g]), _ptr_array([wt]), None, _ptr_array([dx]), 1, _DT[x.dtype], N,
                                                             _int_array([h]), _int_array([wd]), 256, 256, _zero_page(dev).data_ptr(), stream),
                        "rn_conv3x3_dense_batched")
         if ctx.needs_input_grad[1]:
@@ -994,9 +995,9 @@ class _Conv3x3MfmaBwd(torch.autograd.Function):
             wsb = _DENSE_WS.get(key)
             if wsb is None or wsb.numel() < need:
                 wsb = _DENSE_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
-            dw = torch.empty((256, 256, 3, 3), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+            dw = torch.empty((256, 256, 3, 3), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
             _mfma_call("mfma_conv2_wgrad", dev, flop,
-                       lambda: lib.rn_conv3x3_dense_wgrad_batched(_ptr_array([g]), _ptr_array([x]), _ptr_array([dw]), 1, RN_BF16, N, _int_array([h]),
+                       lambda: lib.rn_conv3x3_dense_wgrad_batched(_ptr_array([g]), _ptr_array([x]), _ptr_array([dw]), 1, _DT[x.dtype], N, _int_array([h]),
                                                                   _int_array([wd]), 256, 256, _zero_page(dev).data_ptr(), wsb.data_ptr(),
                                                                   wsb.numel(), stream),
                        "rn_conv3x3_dense_wgrad_batched")
@@ -1021,7 +1022,7 @@ NARROW_FWD = True
 
 
 def narrow_fwd_ok(x: Tensor, w: Tensor) -> bool:
-    return (NARROW_FWD and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 4 and _cl(x) and
+    return (NARROW_FWD and x.is_cuda and x.dtype in H16 and w.dtype == x.dtype and x.dim() == 4 and _cl(x) and
             tuple(w.shape) == (64, 64, 3, 3) and x.shape[1] == 64 and x.numel() // 64 < (1 << 31))
 
 
@@ -1036,7 +1037,7 @@ def conv3x3_narrow_forward(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, 
     N, C, H, W = x.shape
     y = torch.empty_like(x, memory_format=torch.channels_last)
     _mfma_call("mfma_conv2_narrow_fwd", dev, 2.0 * N * H * W * C * C * 9,
-               lambda: lib.rn_conv3x3_narrow_forward(x.data_ptr(), wc.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(), RN_BF16, N, H, W, C,
+               lambda: lib.rn_conv3x3_narrow_forward(x.data_ptr(), wc.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(), _DT[x.dtype], N, H, W, C,
                                                      int(bool(relu)), _zero_page(dev).data_ptr(), stream), "rn_conv3x3_narrow_forward")
     return y
 
@@ -1047,7 +1048,7 @@ DENSE_EVAL = True
 
 
 def dense_eval_ok(x: Tensor, w: Tensor) -> bool:
-    return (DENSE_EVAL and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 4 and _cl(x) and _cl(w) and
+    return (DENSE_EVAL and x.is_cuda and x.dtype in H16 and w.dtype == x.dtype and x.dim() == 4 and _cl(x) and _cl(w) and
             tuple(w.shape[2:]) == (3, 3) and w.shape[1] == x.shape[1] and w.shape[1] % 64 == 0 and w.shape[0] % 256 == 0 and
             x.shape[0] * x.shape[2] * x.shape[3] < (1 << 22))
 
@@ -1063,7 +1064,7 @@ def conv3x3_dense_bias_act(x: Tensor, w: Tensor, bias: Optional[Tensor], relu: b
     y = torch.empty((N, Cout, h, wd), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
     bs = (C.c_void_p * 1)(bias.data_ptr()) if bias is not None else None
     _mfma_call("mfma_conv2_eval", dev, 2.0 * N * h * wd * Cout * 9 * Cin,
-               lambda: lib.rn_conv3x3_dense_batched_act(_ptr_array([x]), _ptr_array([w]), bs, _ptr_array([y]), 1, RN_BF16, N, _int_array([h]),
+               lambda: lib.rn_conv3x3_dense_batched_act(_ptr_array([x]), _ptr_array([w]), bs, _ptr_array([y]), 1, _DT[x.dtype], N, _int_array([h]),
                                                         _int_array([wd]), Cin, Cout, _zero_page(dev).data_ptr(), int(bool(relu)), stream),
                "rn_conv3x3_dense_batched_act")
     return y
@@ -1077,7 +1078,7 @@ def conv3x3_same(x: Tensor, w: Tensor) -> Tensor:
 
 
 def dgrad_as_fwd_ok(w: Tensor, stride, x: Tensor) -> bool:
-    return (DGRAD_AS_FWD and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and _cl(x) and w.dim() == 4 and
+    return (DGRAD_AS_FWD and x.is_cuda and x.dtype in H16 and w.dtype == x.dtype and _cl(x) and w.dim() == 4 and
             tuple(w.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and w.shape[0] % 32 == 0 and w.shape[1] % 32 == 0)
 
 
@@ -1088,7 +1089,7 @@ def conv3x3_dgrad_as_fwd(g: Tensor, w: Tensor) -> Tensor:
         torch.cuda.set_device(dev)
     stream = torch.cuda.current_stream().cuda_stream
     wt = dgrad_weights([w], stream)[0]
-    gc = g if (g.dtype == torch.bfloat16 and _cl(g)) else g.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gc = g if (g.dtype == w.dtype and _cl(g)) else g.to(w.dtype).contiguous(memory_format=torch.channels_last)
     return conv3x3_same(gc, wt)
 
 
@@ -1099,7 +1100,7 @@ _NARROW_WS: Dict[tuple, Tensor] = {}
 
 
 def wgrad_narrow_ok(w: Tensor, stride, x: Tensor) -> bool:
-    return (NARROW_WGRAD and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and _cl(x) and w.dim() == 4 and
+    return (NARROW_WGRAD and x.is_cuda and x.dtype in H16 and w.dtype == x.dtype and _cl(x) and w.dim() == 4 and
             tuple(w.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0 and
             w.shape[0] * w.shape[1] <= 512 * 512)
 
@@ -1112,15 +1113,15 @@ def conv3x3_wgrad_narrow(g: Tensor, x: Tensor, w: Tensor) -> Tensor:
     stream = torch.cuda.current_stream().cuda_stream
     N, Cin, H, W = x.shape
     Cout = int(w.shape[0])
-    gc = g if (g.dtype == torch.bfloat16 and _cl(g)) else g.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gc = g if (g.dtype == x.dtype and _cl(g)) else g.to(x.dtype).contiguous(memory_format=torch.channels_last)
     need = lib.rn_conv3x3_wgrad_narrow_workspace_bytes(Cout, Cin)
     key = (dev.index, stream)
     ws = _NARROW_WS.get(key)
     if ws is None or ws.numel() < need:
         ws = _NARROW_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
-    dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+    dw = torch.empty((Cout, Cin, 3, 3), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
     _mfma_call("mfma_conv2_narrow_wgrad", dev, 2.0 * N * H * W * Cout * Cin * 9,
-               lambda: lib.rn_conv3x3_wgrad_narrow(gc.data_ptr(), x.data_ptr(), dw.data_ptr(), RN_BF16, N, H, W, Cout, Cin,
+               lambda: lib.rn_conv3x3_wgrad_narrow(gc.data_ptr(), x.data_ptr(), dw.data_ptr(), _DT[x.dtype], N, H, W, Cout, Cin,
                                                    _zero_page(dev).data_ptr(), ws.data_ptr(), ws.numel(), stream), "rn_conv3x3_wgrad_narrow")
     return dw
 
@@ -1143,7 +1144,7 @@ class _Conv3x3DgradAsFwd(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        g = dy if (dy.dtype == torch.bfloat16 and _cl(dy)) else dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        g = dy if (dy.dtype == x.dtype and _cl(dy)) else dy.to(x.dtype).contiguous(memory_format=torch.channels_last)
         dx = conv3x3_dgrad_as_fwd(g, w) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:

@@ -42,8 +42,7 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
+using rn::f32x16;
 typedef __attribute__((address_space(3))) void *lds_void_ptr;
 
 constexpr int CONV_BM = 256, CONV_BN = 256, CONV_BK = 64, CONV_THREADS = 512;
@@ -174,19 +173,18 @@ struct ConvArgs {
     int64_t M, HWp;
     int Cin, Cout, Wp, relu;    // Cin = channels walked per tap (FROM_LEVELS: the padded row length, a multiple of 64)
     int n_base;                 // first output channel of blockIdx.y = 0 (the NARROW launch of the last column tile)
+    int f16;                    // host side only: element type fp16 instead of bf16 (selects the kernel instantiation)
     LevelSet lv;
     DenseGeom dn;               // MODE_DENSE only (M, HWp, Wp, mask unused there)
 };
 struct ConvProblem { const uint16_t *X, *W; const float *bias; uint16_t *Y; };
-
-__device__ __forceinline__ uint16_t f2bf(const float f) { return (uint16_t)(rn::dt<RN_BF16>::pk(f, 0.0f) & 0xffffu); }
 
 struct Walk { int tap, chunk; };      // position of the K walk
 
 // NARROW (TO_LEVELS only): a column tile of at most 64 output channels -- the last, ragged tile of the 810-channel
 // class-output conv (42 columns).  All 8 waves split the ROWS (32 each) and compute 32 x 64: a quarter of the MFMAs and a
 // quarter of the weight staging of a full tile whose other 192 columns would be zeros.
-template <int MODE, bool NARROW = false>
+template <int DT, int MODE, bool NARROW = false>
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const ConvArgs args)
 {
     constexpr int MI = NARROW ? 1 : 4;                            // 32-row accumulator tiles per wave
@@ -230,8 +228,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     // 2 x (4 + 2) of two 16-deep ones) -- but under load the chip holds a higher clock on this shape (MI355X_MICROARCH.md, DVFS
     // give-back item 7: +12 .. 15 % FLOP/s at equal cycles on random data).
     constexpr int MT = 2 * MI, NT = 4;                            // 16 x 16 accumulator tiles per wave: rows x columns
-    typedef __attribute__((ext_vector_type(4))) float f32x4v;
-    f32x4v acc[MT][NT];
+    rn::f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -355,7 +352,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
             __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
         }
     };
-    bf16x8 fa[MT], fb[NT];
+    typename rn::mma<DT>::frag fa[MT], fb[NT];
 #define RN_DS_READ(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
 #define RN_LOAD_FRAGS_AT(AA, KS)                                                   \
     { const uint32_t ba = bbase + b_off[KS], aa = (AA);                            \
@@ -367,7 +364,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
 #define RN_MFMA_ALL()                                                              \
     _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                              \
         _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)                          \
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = rn::mma<DT>::m16(fa[mi], fb[ni], acc[mi][ni]);
 #define RN_MFMA_PHASE()                                                            \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);          \
     __builtin_amdgcn_s_setprio(1);                                                 \
@@ -462,7 +459,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
                 const int row = wm * (32 * MI) + mi * 16 + 4 * (lane >> 4) + r;
                 float v = acc[mi][ni][r] + b;
                 if (args.relu & 1) v = v > 0.0f ? v : 0.0f;
-                Ys[row * CONV_BN + col] = f2bf(v);
+                Ys[row * CONV_BN + col] = rn::mma<DT>::dn(v);
             }
         }
     if (MODE == MODE_TO_LEVELS && tid < CONV_BM) {
@@ -519,8 +516,8 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {                    // two bf16 per word
                         vw[j] &= ((bits >> (2 * j)) & 1u ? 0x0000ffffu : 0u) | ((bits >> (2 * j + 1)) & 1u ? 0xffff0000u : 0u);
-                        cs[2 * j] += __uint_as_float(vw[j] << 16);
-                        cs[2 * j + 1] += __uint_as_float(vw[j] & 0xffff0000u);
+                        cs[2 * j] += rn::mma<DT>::lo(vw[j]);
+                        cs[2 * j + 1] += rn::mma<DT>::hi(vw[j]);
                     }
                     v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
                 }
@@ -529,8 +526,8 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
                     uint32_t bits = 0;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        bits |= (__uint_as_float(vw[j] << 16) > 0.0f ? 1u : 0u) << (2 * j);
-                        bits |= (__uint_as_float(vw[j] & 0xffff0000u) > 0.0f ? 1u : 0u) << (2 * j + 1);
+                        bits |= (rn::mma<DT>::lo(vw[j]) > 0.0f ? 1u : 0u) << (2 * j);
+                        bits |= (rn::mma<DT>::hi(vw[j]) > 0.0f ? 1u : 0u) << (2 * j + 1);
                     }
                     rmask_out[m * (args.Cout >> 3) + (n0 >> 3) + piece] = (uint8_t)bits;
                 }
@@ -576,6 +573,7 @@ struct WgradArgs {
     int64_t M, HWp;
     int Wp, S, tiles_per_split;                 // K-tiles (64 positions) per split
     int ch_base;                                // GATHER: first output channel of problem 0 (the NARROW launch of the last row tile)
+    int f16;                                    // host side only: fp16 elements (kernel instantiation)
     LevelSet lv;                                // GATHER: dense per-level gradient tensors [N][h][w][row_elems]; problem p = output channels 256 p ..
     DenseGeom dn;                               // DENSE: per-problem geometry; tile_beg = first split of the problem (blockIdx.x walks them all)
     int dn_tps[CONV_MAX_PROBLEMS];              //        K-tiles per split of problem p
@@ -591,7 +589,7 @@ struct WgradArgs {
 // the forward kernel); every problem has its own number of splits -- proportional to its positions, so that all workgroups
 // walk about the same number of K-tiles -- and an X row whose tap leaves the image reads the zero page: row / column of the
 // 4 rows a thread stages are recomputed per K-tile (two reciprocal multiplications each, sheet_coords).
-template <bool GATHER, bool NARROW = false, bool DENSE = false>
+template <int DT, bool GATHER, bool NARROW = false, bool DENSE = false>
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const WgradArgs a)
 {
     constexpr int MI = NARROW ? 2 : 4, NI = NARROW ? 1 : 2;
@@ -756,11 +754,11 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
         RN_TR_READ(fa[SET][MI - 2][0], abase + a_off[MI - 2], KOFF0); RN_TR_READ(fa[SET][MI - 2][1], abase + a_off[MI - 2], KOFF1);   \
         RN_TR_READ(fa[SET][MI - 1][0], abase + a_off[MI - 1], KOFF0); RN_TR_READ(fa[SET][MI - 1][1], abase + a_off[MI - 1], KOFF1); }
     struct U2 { unsigned long long lo, hi; };
-#define RN_FRAG(v) __builtin_bit_cast(bf16x8, U2{v[0], v[1]})
+#define RN_FRAG(v) __builtin_bit_cast(typename rn::mma<DT>::frag, U2{v[0], v[1]})
 #define RN_MFMA8(SET)                                                              \
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                              \
         _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                          \
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(RN_FRAG(fa[SET][mi]), RN_FRAG(fb[SET][ni]), acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = rn::mma<DT>::m32(RN_FRAG(fa[SET][mi]), RN_FRAG(fb[SET][ni]), acc[mi][ni]);
 #define RN_MFMA_PHASE()                                                            \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0);          \
     __builtin_amdgcn_s_setprio(1);                                                 \
@@ -823,6 +821,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
 
 // dW[p][n][t][c] (bf16) = sum over the splits of partial[p][s][t][n][c]
 // (rows: output channels of problem p that exist -- 256 except for the last channel tile of the class-output conv)
+template <int DT>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial, const int S, uint16_t *dw0, uint16_t *dw1,
                                                            uint16_t *dw2, uint16_t *dw3, const int rows0, const int rows1,
                                                            const int rows2, const int rows3, const int shift_from, const int shift)
@@ -849,13 +848,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
         n_out = n - shift;
     } else if (n >= rows) return;
     rn::u32x2 o;
-    o.x = rn::dt<RN_BF16>::pk(s.x, s.y); o.y = rn::dt<RN_BF16>::pk(s.z, s.w);
+    o.x = rn::dt<DT>::pk(s.x, s.y); o.y = rn::dt<DT>::pk(s.z, s.w);
     *(rn::u32x2 *)(dw + ((int64_t)n_out * 9 + t) * 256 + c) = o;
 }
 
 // The same sum for the DENSE launch, whose problems own different numbers of splits: partial[split][t][n][c], splits
 // beg[p] .. beg[p + 1] belong to problem p.
 struct DenseSplits { int beg[CONV_MAX_PROBLEMS + 1]; };
+template <int DT>
 __global__ __launch_bounds__(256) void wgrad_reduce_dense_kernel(const float *__restrict__ partial, const DenseSplits sp, uint16_t *dw0,
                                                                  uint16_t *dw1, uint16_t *dw2, uint16_t *dw3)
 {
@@ -871,7 +871,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_dense_kernel(const float *__
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     rn::u32x2 o;
-    o.x = rn::dt<RN_BF16>::pk(s.x, s.y); o.y = rn::dt<RN_BF16>::pk(s.z, s.w);
+    o.x = rn::dt<DT>::pk(s.x, s.y); o.y = rn::dt<DT>::pk(s.z, s.w);
     *(rn::u32x2 *)(dw + ((int64_t)n * 9 + t) * 256 + c) = o;
 }
 
@@ -1039,22 +1039,22 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restr
 
 }  // namespace
 
-template <int MODE, bool NARROW = false>
-static int conv_launch_mode(const ConvArgs &a, const dim3 grid, hipStream_t st)
+template <int DT, int MODE, bool NARROW>
+static int conv_launch_dt(const ConvArgs &a, const dim3 grid, hipStream_t st)
 {
-    {   // 160 KiB of dynamic LDS needs the opt-in once per device (the attribute lives with the device's code object)
-        static bool attr_set[64] = {};
-        int dev = 0;
-        RN_HIP(hipGetDevice(&dev));
-        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-            RN_HIP(hipFuncSetAttribute((const void *)conv3x3_canvas_kernel<MODE, NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES));
-            if (dev >= 0 && dev < 64) attr_set[dev] = true;
-        }
-    }
-    hipLaunchKernelGGL((conv3x3_canvas_kernel<MODE, NARROW>), grid, dim3(CONV_THREADS), CONV_LDS_BYTES, st, a);
+    // 160 KiB of dynamic LDS needs the opt-in once per device (the attribute lives with the device's code object)
+    static rn::DynLdsOptIn opt_in = {};
+    { const int rc = opt_in.ensure((const void *)conv3x3_canvas_kernel<DT, MODE, NARROW>, CONV_LDS_BYTES); if (rc != RN_OK) return rc; }
+    hipLaunchKernelGGL((conv3x3_canvas_kernel<DT, MODE, NARROW>), grid, dim3(CONV_THREADS), CONV_LDS_BYTES, st, a);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
+template <int MODE, bool NARROW = false>
+static int conv_launch_mode(const ConvArgs &a, const dim3 grid, hipStream_t st)
+{
+    return a.f16 ? conv_launch_dt<RN_F16, MODE, NARROW>(a, grid, st) : conv_launch_dt<RN_BF16, MODE, NARROW>(a, grid, st);
+}
+static inline bool conv_dtype_ok(const int dtype) { return dtype == RN_BF16 || dtype == RN_F16; }
 
 static int fill_levels(LevelSet &ls, const rn_canvas_layout *lay, int row_elems, void *const *ptrs, int N, int Hp, int Wp)
 {
@@ -1090,8 +1090,9 @@ RN_API int rn_conv3x3_canvas_batched_ex(const void *const *xs, const void *const
 {
     if (relu_mask_outs && !relu) return RN_EINVAL;
     if (!xs || !ws || !ys || P <= 0 || P > CONV_MAX_PROBLEMS || M <= 0 || HWp <= 0 || Wp <= 0 || Cin <= 0 || Cout <= 0) return RN_EINVAL;
-    if (dtype != RN_BF16 || Cin % CONV_BK || Cout % CONV_BN) return RN_EUNSUPPORTED;
+    if (!conv_dtype_ok(dtype) || Cin % CONV_BK || Cout % CONV_BN) return RN_EUNSUPPORTED;
     ConvArgs a = {};
+    a.f16 = dtype == RN_F16;
     for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) {
         const int q = p < P ? p : 0;
         if (!xs[q] || !ws[q] || !ys[q]) return RN_EINVAL;
@@ -1231,9 +1232,10 @@ RN_API int rn_conv3x3_canvas_dgrad_relu_batched(const void *const *gs, const voi
     if (!gs || !ws || !relu_masks || !ys || !dbiases || !workspace || P <= 0 || P > CONV_MAX_PROBLEMS || M <= 0 || HWp <= 0 || Wp <= 0 ||
         Cin <= 0 || Cout <= 0)
         return RN_EINVAL;
-    if (dtype != RN_BF16 || Cin % CONV_BK || Cout % CONV_BN) return RN_EUNSUPPORTED;
+    if (!conv_dtype_ok(dtype) || Cin % CONV_BK || Cout % CONV_BN) return RN_EUNSUPPORTED;
     if (workspace_bytes < rn_conv3x3_colsum_workspace_bytes(P, M, Cout)) return RN_EWORKSPACE;
     ConvArgs a = {};
+    a.f16 = dtype == RN_F16;
     const int64_t tiles = (M + CONV_BM - 1) / CONV_BM;
     float *outs[CONV_MAX_PROBLEMS] = {nullptr, nullptr, nullptr, nullptr};
     for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) {
@@ -1261,9 +1263,10 @@ RN_API int rn_conv3x3_canvas_to_levels(const void *x, const void *w, const float
                                        void *stream)
 {
     if (!x || !w || !zeros || N <= 0 || Hp <= 2 || Wp <= 2 || Cin <= 0 || Cout <= 0) return RN_EINVAL;
-    if (dtype != RN_BF16 || Cin % CONV_BK || (Cout & 1) || (int64_t)N * Hp * Wp >= (1 << 22)) return RN_EUNSUPPORTED;
+    if (!conv_dtype_ok(dtype) || Cin % CONV_BK || (Cout & 1) || (int64_t)N * Hp * Wp >= (1 << 22)) return RN_EUNSUPPORTED;
     if (!rn::aligned(x, 16) || !rn::aligned(w, 16) || !rn::aligned(zeros, 16)) return RN_EALIGN;
     ConvArgs a = {};
+    a.f16 = dtype == RN_F16;
     const int rc = fill_levels(a.lv, layout, Cout, ys, N, Hp, Wp);
     if (rc != RN_OK) return rc;
     for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) { a.Xs[p] = (const uint16_t *)x; a.Ws[p] = (const uint16_t *)w; a.biases[p] = bias; a.Ys[p] = nullptr; }
@@ -1290,11 +1293,12 @@ RN_API int rn_conv3x3_levels_to_canvas(const void *const *gs, const rn_canvas_la
                                        const void *zeros, void *stream)
 {
     if (!gs || !w || !y || !zeros || N <= 0 || Hp <= 2 || Wp <= 2 || Kpad <= 0 || Cout <= 0) return RN_EINVAL;
-    if (dtype != RN_BF16 || Kpad % CONV_BK || Cout % CONV_BN || Kpad < row_elems || Kpad - row_elems >= CONV_BK ||
+    if (!conv_dtype_ok(dtype) || Kpad % CONV_BK || Cout % CONV_BN || Kpad < row_elems || Kpad - row_elems >= CONV_BK ||
         (int64_t)N * Hp * Wp >= (1 << 22) || row_elems < 8)
         return RN_EUNSUPPORTED;
     if (!rn::aligned(w, 16) || !rn::aligned(y, 16) || !rn::aligned(zeros, 16)) return RN_EALIGN;
     ConvArgs a = {};
+    a.f16 = dtype == RN_F16;
     const int rc = fill_levels(a.lv, layout, row_elems, const_cast<void *const *>(gs), N, Hp, Wp);
     if (rc != RN_OK) return rc;
     for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) { a.Xs[p] = nullptr; a.Ws[p] = (const uint16_t *)w; a.biases[p] = nullptr; a.Ys[p] = (uint16_t *)y; }
@@ -1313,13 +1317,14 @@ RN_API int rn_conv3x3_levels_to_canvas_relu(const void *const *gs, const rn_canv
                                             void *stream)
 {
     if (!gs || !w || !y || !zeros || !relu_mask || !dbias || !workspace || N <= 0 || Hp <= 2 || Wp <= 2 || Kpad <= 0 || Cout <= 0) return RN_EINVAL;
-    if (dtype != RN_BF16 || Kpad % CONV_BK || Cout % CONV_BN || Kpad < row_elems || Kpad - row_elems >= CONV_BK ||
+    if (!conv_dtype_ok(dtype) || Kpad % CONV_BK || Cout % CONV_BN || Kpad < row_elems || Kpad - row_elems >= CONV_BK ||
         (int64_t)N * Hp * Wp >= (1 << 22) || row_elems < 8)
         return RN_EUNSUPPORTED;
     if (!rn::aligned(w, 16) || !rn::aligned(y, 16) || !rn::aligned(zeros, 16) || !rn::aligned(relu_mask, 16)) return RN_EALIGN;
     const int64_t M = (int64_t)N * Hp * Wp;
     if (workspace_bytes < rn_conv3x3_colsum_workspace_bytes(1, M, Cout)) return RN_EWORKSPACE;
     ConvArgs a = {};
+    a.f16 = dtype == RN_F16;
     const int rc = fill_levels(a.lv, layout, row_elems, const_cast<void *const *>(gs), N, Hp, Wp);
     if (rc != RN_OK) return rc;
     for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) {
@@ -1361,29 +1366,29 @@ RN_API size_t rn_conv3x3_wgrad_workspace_bytes(int P, int64_t M)
     return ((size_t)P * S + (size_t)S1) * 9 * 65536 * sizeof(float);
 }
 
-template <bool GATHER, bool NARROW = false>
-static int wgrad_launch(WgradArgs &a, uint16_t *const (&dw)[CONV_MAX_PROBLEMS], const int (&rows)[CONV_MAX_PROBLEMS], int P, int64_t M,
-                        void *workspace, hipStream_t st, int shift_from = 0, int shift = 0, size_t *used_floats = nullptr)
+template <int DT, bool GATHER, bool NARROW>
+static int wgrad_launch_dt(WgradArgs &a, uint16_t *const (&dw)[CONV_MAX_PROBLEMS], const int (&rows)[CONV_MAX_PROBLEMS], int P, int64_t M,
+                           void *workspace, hipStream_t st, int shift_from, int shift, size_t *used_floats)
 {
-    int dev = 0;
-    RN_HIP(hipGetDevice(&dev));
-    {
-        static bool attr_set[64] = {};
-        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-            RN_HIP(hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<GATHER, NARROW>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES));
-            if (dev >= 0 && dev < 64) attr_set[dev] = true;
-        }
-    }
+    static rn::DynLdsOptIn opt_in = {};
+    { const int rc = opt_in.ensure((const void *)conv3x3_wgrad_kernel<DT, GATHER, NARROW>, CONV_LDS_BYTES); if (rc != RN_OK) return rc; }
     // one workgroup per (split, tap, problem): choose the split count so that the grid is about one wave of the chip
     const int S = wgrad_splits(P, M, &a.tiles_per_split);
     a.S = S; a.M = M; a.partial = (float *)workspace;
     if (used_floats) *used_floats = (size_t)P * S * 9 * 65536;
-    hipLaunchKernelGGL((conv3x3_wgrad_kernel<GATHER, NARROW>), dim3((unsigned)S, 9, (unsigned)P), dim3(CONV_THREADS), CONV_LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<DT, GATHER, NARROW>), dim3((unsigned)S, 9, (unsigned)P), dim3(CONV_THREADS), CONV_LDS_BYTES, st, a);
     RN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(9 * 65536 / 4 / 256, (unsigned)P), dim3(256), 0, st, (const float *)workspace, S, dw[0], dw[1],
+    hipLaunchKernelGGL(wgrad_reduce_kernel<DT>, dim3(9 * 65536 / 4 / 256, (unsigned)P), dim3(256), 0, st, (const float *)workspace, S, dw[0], dw[1],
                        dw[2], dw[3], rows[0], rows[1], rows[2], rows[3], shift_from, shift);
     RN_LAUNCH_CHECK();
     return RN_OK;
+}
+template <bool GATHER, bool NARROW = false>
+static int wgrad_launch(WgradArgs &a, uint16_t *const (&dw)[CONV_MAX_PROBLEMS], const int (&rows)[CONV_MAX_PROBLEMS], int P, int64_t M,
+                        void *workspace, hipStream_t st, int shift_from = 0, int shift = 0, size_t *used_floats = nullptr)
+{
+    return a.f16 ? wgrad_launch_dt<RN_F16, GATHER, NARROW>(a, dw, rows, P, M, workspace, st, shift_from, shift, used_floats)
+                 : wgrad_launch_dt<RN_BF16, GATHER, NARROW>(a, dw, rows, P, M, workspace, st, shift_from, shift, used_floats);
 }
 
 RN_API int rn_conv3x3_canvas_wgrad_batched(const void *const *gs, const void *const *xs, void *const *dws, int P, int dtype,
@@ -1391,9 +1396,10 @@ RN_API int rn_conv3x3_canvas_wgrad_batched(const void *const *gs, const void *co
                                            size_t workspace_bytes, void *stream)
 {
     if (!gs || !xs || !dws || !zeros || !workspace || P <= 0 || P > CONV_MAX_PROBLEMS || M <= 0 || Wp <= 0) return RN_EINVAL;
-    if (dtype != RN_BF16 || Cin != 256 || Cout != 256) return RN_EUNSUPPORTED;
+    if (!conv_dtype_ok(dtype) || Cin != 256 || Cout != 256) return RN_EUNSUPPORTED;
     if (workspace_bytes < rn_conv3x3_wgrad_workspace_bytes(P, M)) return RN_EWORKSPACE;
     WgradArgs a = {};
+    a.f16 = dtype == RN_F16;
     uint16_t *dw[CONV_MAX_PROBLEMS] = {nullptr, nullptr, nullptr, nullptr};
     const int rows[CONV_MAX_PROBLEMS] = {256, 256, 256, 256};
     for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) {
@@ -1414,10 +1420,11 @@ RN_API int rn_conv3x3_levels_wgrad(const void *const *gs, const rn_canvas_layout
     if (!gs || !x || !dw || !zeros || !workspace || N <= 0 || Hp <= 2 || Wp <= 2) return RN_EINVAL;
     const int P = (row_elems + 255) / 256;
     const int64_t M = (int64_t)N * Hp * Wp;
-    if (dtype != RN_BF16 || Cin != 256 || P > CONV_MAX_PROBLEMS || M >= (1 << 22) || row_elems < 8) return RN_EUNSUPPORTED;
+    if (!conv_dtype_ok(dtype) || Cin != 256 || P > CONV_MAX_PROBLEMS || M >= (1 << 22) || row_elems < 8) return RN_EUNSUPPORTED;
     if (workspace_bytes < rn_conv3x3_wgrad_workspace_bytes(P, M)) return RN_EWORKSPACE;
     if (!rn::aligned(x, 16) || !rn::aligned(dw, 16) || !rn::aligned(zeros, 16)) return RN_EALIGN;
     WgradArgs a = {};
+    a.f16 = dtype == RN_F16;
     const int rc = fill_levels(a.lv, layout, row_elems, const_cast<void *const *>(gs), N, Hp, Wp);
     if (rc != RN_OK) return rc;
     uint16_t *dws[CONV_MAX_PROBLEMS];
@@ -1467,8 +1474,9 @@ RN_API int rn_conv3x3_dense_batched_act(const void *const *xs, const void *const
                                         void *stream)
 {
     if (!xs || !ws || !ys || !zeros || Cin <= 0 || Cout <= 0) return RN_EINVAL;
-    if (dtype != RN_BF16 || Cin % CONV_BK || Cout % CONV_BN) return RN_EUNSUPPORTED;
+    if (!conv_dtype_ok(dtype) || Cin % CONV_BK || Cout % CONV_BN) return RN_EUNSUPPORTED;
     ConvArgs a = {};
+    a.f16 = dtype == RN_F16;
     int rc = dense_geom(a.dn, P, N, hs, wds);
     if (rc != RN_OK) return rc;
     if (!rn::aligned(zeros, 16)) return RN_EALIGN;
@@ -1535,8 +1543,9 @@ RN_API int rn_conv3x3_dense_wgrad_batched(const void *const *gs, const void *con
                                           size_t workspace_bytes, void *stream)
 {
     if (!gs || !xs || !dws || !zeros || !workspace) return RN_EINVAL;
-    if (dtype != RN_BF16 || Cin != 256 || Cout != 256) return RN_EUNSUPPORTED;
+    if (!conv_dtype_ok(dtype) || Cin != 256 || Cout != 256) return RN_EUNSUPPORTED;
     WgradArgs a = {};
+    a.f16 = dtype == RN_F16;
     int rc = dense_geom(a.dn, P, N, hs, wds);
     if (rc != RN_OK) return rc;
     if (workspace_bytes < rn_conv3x3_dense_wgrad_workspace_bytes(P)) return RN_EWORKSPACE;
@@ -1557,19 +1566,17 @@ RN_API int rn_conv3x3_dense_wgrad_batched(const void *const *gs, const void *con
     sp.beg[P] = total;                                              // end of the last problem for the reduction
     a.zeros = (const uint16_t *)zeros; a.partial = (float *)workspace; a.S = total; a.M = 0; a.Wp = 1; a.HWp = 1; a.tiles_per_split = tps;
     hipStream_t st = (hipStream_t)stream;
-    int dev = 0;
-    RN_HIP(hipGetDevice(&dev));
-    {
-        static bool attr_set[64] = {};
-        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-            RN_HIP(hipFuncSetAttribute((const void *)conv3x3_wgrad_kernel<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES));
-            if (dev >= 0 && dev < 64) attr_set[dev] = true;
-        }
-    }
-    hipLaunchKernelGGL((conv3x3_wgrad_kernel<false, false, true>), dim3((unsigned)total, 9, 1), dim3(CONV_THREADS), CONV_LDS_BYTES, st, a);
-    RN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad_reduce_dense_kernel, dim3(9 * 65536 / 4 / 256, (unsigned)P), dim3(256), 0, st, (const float *)workspace, sp, dw[0],
-                       dw[1], dw[2], dw[3]);
-    RN_LAUNCH_CHECK();
+    a.f16 = dtype == RN_F16;
+#define RN_DENSE_WGRAD(DT)                                                                                                                    \
+    {   static rn::DynLdsOptIn opt_in = {};                                                                                                   \
+        const int rc2 = opt_in.ensure((const void *)conv3x3_wgrad_kernel<DT, false, false, true>, CONV_LDS_BYTES);                            \
+        if (rc2 != RN_OK) return rc2;                                                                                                         \
+        hipLaunchKernelGGL((conv3x3_wgrad_kernel<DT, false, false, true>), dim3((unsigned)total, 9, 1), dim3(CONV_THREADS), CONV_LDS_BYTES, st, a); \
+        RN_LAUNCH_CHECK();                                                                                                                    \
+        hipLaunchKernelGGL(wgrad_reduce_dense_kernel<DT>, dim3(9 * 65536 / 4 / 256, (unsigned)P), dim3(256), 0, st, (const float *)workspace, sp, dw[0], \
+                           dw[1], dw[2], dw[3]);                                                                                              \
+        RN_LAUNCH_CHECK(); }
+    if (a.f16) RN_DENSE_WGRAD(RN_F16) else RN_DENSE_WGRAD(RN_BF16)
+#undef RN_DENSE_WGRAD
     return RN_OK;
 }

@@ -19,8 +19,7 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
+using rn::f32x16;
 typedef __attribute__((address_space(3))) void *lds_void_ptr;
 
 constexpr int N3_THREADS = 256;
@@ -50,6 +49,7 @@ __device__ __forceinline__ int n3_swz(const int sp) { return (sp >> 1) & 7; }
 #define N3_DS_READ(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
 #define N3_WAIT_LGKM(N) asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
 
+template <int DT>
 __global__ __launch_bounds__(N3_THREADS, 2) void conv3x3_narrow64_kernel(const N3Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -89,7 +89,8 @@ __global__ __launch_bounds__(N3_THREADS, 2) void conv3x3_narrow64_kernel(const N
     stage(y0 - 1); stage(y0); stage(y0 + 1);
 
     // ---- weights: this wave's 32 output channels x (9 taps x 64 input channels), as MFMA A-fragments (row = output channel)
-    bf16x8 wf[9][4];
+    typedef typename rn::mma<DT>::frag frag8;
+    frag8 wf[9][4];
     const int kh = lane >> 5;
     {
         const int co = cw * 32 + (lane & 31);
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(N3_THREADS, 2) void conv3x3_narrow64_kernel(const N
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int kc = 0; kc < 4; ++kc) wf[t][kc] = *(const bf16x8 *)(wp + t * 64 + kc * 16);
+            for (int kc = 0; kc < 4; ++kc) wf[t][kc] = *(const frag8 *)(wp + t * 64 + kc * 16);
     }
     // fragment addresses of pixel block 0 (block 1: + 32 pixels = + 4096 bytes, same swizzle): horizontal tap dx reads staged pixel
     // p + dx (staged pixel 0 is x0 - 1), 16-channel chunk kc
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(N3_THREADS, 2) void conv3x3_narrow64_kernel(const N
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) rbase[dy] = lds_base + (uint32_t)(((y + dy - 1 + 4) & 3) * N3_ROWBYTES);
         // 36 K-steps (tap, 16-channel chunk) x 2 pixel blocks; the two fragments of step s are read N3_AHEAD steps (2 N3_AHEAD MFMAs) ahead
-        bf16x8 f[N3_AHEAD + 1][2];
+        frag8 f[N3_AHEAD + 1][2];
 #define N3_READ(S) { const uint32_t ad_ = rbase[((S) >> 2) / 3] + col[((S) >> 2) % 3][(S) & 3]; \
                      N3_DS_READ(f[(S) % (N3_AHEAD + 1)][0], ad_, 0); N3_DS_READ(f[(S) % (N3_AHEAD + 1)][1], ad_, 4096); }
 #pragma unroll
@@ -150,8 +151,8 @@ __global__ __launch_bounds__(N3_THREADS, 2) void conv3x3_narrow64_kernel(const N
                 case 4: N3_WAIT_LGKM(8) break;
                 default: N3_WAIT_LGKM(10) break;
             }
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s >> 2][s & 3], f[s % (N3_AHEAD + 1)][0], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s >> 2][s & 3], f[s % (N3_AHEAD + 1)][1], acc[1], 0, 0, 0);
+            acc[0] = rn::mma<DT>::m32(wf[s >> 2][s & 3], f[s % (N3_AHEAD + 1)][0], acc[0]);
+            acc[1] = rn::mma<DT>::m32(wf[s >> 2][s & 3], f[s % (N3_AHEAD + 1)][1], acc[1]);
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef N3_READ
@@ -171,8 +172,8 @@ __global__ __launch_bounds__(N3_THREADS, 2) void conv3x3_narrow64_kernel(const N
             uint32_t v[2][4];
 #pragma unroll
             for (int gp = 0; gp < 2; ++gp) {
-                const uint32_t ax = rn::dt<RN_BF16>::pk(acc[pb][8 * gp + 0], acc[pb][8 * gp + 1]), ay = rn::dt<RN_BF16>::pk(acc[pb][8 * gp + 2], acc[pb][8 * gp + 3]);
-                const uint32_t bx = rn::dt<RN_BF16>::pk(acc[pb][8 * gp + 4], acc[pb][8 * gp + 5]), by = rn::dt<RN_BF16>::pk(acc[pb][8 * gp + 6], acc[pb][8 * gp + 7]);
+                const uint32_t ax = rn::dt<DT>::pk(acc[pb][8 * gp + 0], acc[pb][8 * gp + 1]), ay = rn::dt<DT>::pk(acc[pb][8 * gp + 2], acc[pb][8 * gp + 3]);
+                const uint32_t bx = rn::dt<DT>::pk(acc[pb][8 * gp + 4], acc[pb][8 * gp + 5]), by = rn::dt<DT>::pk(acc[pb][8 * gp + 6], acc[pb][8 * gp + 7]);
                 const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
                 const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
                 v[gp][0] = sx[0]; v[gp][1] = sy[0]; v[gp][2] = sx[1]; v[gp][3] = sy[1];
@@ -227,7 +228,7 @@ RN_API int rn_conv3x3_narrow_forward(const void *x, const void *w, const float *
                                      const void *zero_page, void *stream)
 {
     if (!x || !w || !y || !zero_page || N <= 0 || H <= 0 || W <= 0) return RN_EINVAL;
-    if (dtype != RN_BF16 || C != 64) return RN_EUNSUPPORTED;
+    if ((dtype != RN_BF16 && dtype != RN_F16) || C != 64) return RN_EUNSUPPORTED;
     if ((int64_t)N * H * W >= ((int64_t)1 << 31)) return RN_EUNSUPPORTED;
     if (!rn::aligned(x, 16) || !rn::aligned(w, 16) || !rn::aligned(y, 16)) return RN_EALIGN;
     N3Args a;
@@ -243,9 +244,13 @@ RN_API int rn_conv3x3_narrow_forward(const void *x, const void *w, const float *
     if (bands > H) bands = H;
     a.rows_per_band = (H + bands - 1) / bands;
     a.bands = (H + a.rows_per_band - 1) / a.rows_per_band;
-    static rn::DynLdsOptIn opt_in = {};
-    { const int rc = opt_in.ensure((const void *)conv3x3_narrow64_kernel, N3_LDS); if (rc != RN_OK) return rc; }
-    hipLaunchKernelGGL(conv3x3_narrow64_kernel, dim3((unsigned)(N * a.strips * a.bands)), dim3(N3_THREADS), N3_LDS, (hipStream_t)stream, a);
+#define N3_LAUNCH(DT)                                                                                                                  \
+    {   static rn::DynLdsOptIn opt_in = {};                                                                                            \
+        const int rc = opt_in.ensure((const void *)conv3x3_narrow64_kernel<DT>, N3_LDS);                                               \
+        if (rc != RN_OK) return rc;                                                                                                    \
+        hipLaunchKernelGGL(conv3x3_narrow64_kernel<DT>, dim3((unsigned)(N * a.strips * a.bands)), dim3(N3_THREADS), N3_LDS, (hipStream_t)stream, a); }
+    if (dtype == RN_F16) N3_LAUNCH(RN_F16) else N3_LAUNCH(RN_BF16)
+#undef N3_LAUNCH
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

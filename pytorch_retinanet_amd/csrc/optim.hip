@@ -22,7 +22,11 @@ struct SgdTable {
     void *p16[SGD_MAX_TENSORS];
     int64_t n[SGD_MAX_TENSORS];
     float lr, momentum, dampening, weight_decay;
-    int nesterov, first, grad16;            // grad16: gradients of tensors WITH a 16-bit copy are bf16 (else f32)
+    int nesterov, first, grad16;            // grad16: gradients of tensors WITH a 16-bit copy are 16-bit as well (else f32)
+    int f16;                                // the 16-bit copies (and 16-bit gradients) are fp16 instead of bf16
+    // fp16 autocast with torch.amp.GradScaler (an optimizer with _step_supports_amp_scaling): the gradients are grad_scale[0] times
+    // too large, and the whole step is skipped when found_inf[0] != 0 -- both device scalars, so nothing synchronises (null: 1 / 0)
+    const float *grad_scale, *found_inf;
 };
 
 __device__ __forceinline__ float sgd_one(const SgdTable &t, const float gin, float &wi, float &mi)
@@ -38,8 +42,12 @@ __device__ __forceinline__ float sgd_one(const SgdTable &t, const float gin, flo
     return wi;
 }
 
+template <bool F16>
 __global__ __launch_bounds__(256) void sgd_master_kernel(const SgdTable t)
 {
+    constexpr int DT = F16 ? RN_F16 : RN_BF16;
+    if (t.found_inf && *t.found_inf != 0.0f) return;             // (GradScaler: a non-finite gradient somewhere -> no parameter moves)
+    const float inv_scale = t.grad_scale ? 1.0f / *t.grad_scale : 1.0f;
     const int ti = blockIdx.y;
     float *__restrict__ w = t.master[ti];
     float *__restrict__ m = t.mom[ti];
@@ -57,22 +65,22 @@ __global__ __launch_bounds__(256) void sgd_master_kernel(const SgdTable t)
         float g[4];
         if (g16) {
             const rn::u32x2 gv = ((const rn::u32x2 *)t.grad[ti])[v];
-            g[0] = __uint_as_float(gv.x << 16); g[1] = __uint_as_float(gv.x & 0xffff0000u);
-            g[2] = __uint_as_float(gv.y << 16); g[3] = __uint_as_float(gv.y & 0xffff0000u);
+            g[0] = rn::mma<DT>::lo(gv.x); g[1] = rn::mma<DT>::hi(gv.x);
+            g[2] = rn::mma<DT>::lo(gv.y); g[3] = rn::mma<DT>::hi(gv.y);
         } else {
             const rn::f32x4 gv = ((const rn::f32x4 *)t.grad[ti])[v];
             g[0] = gv.x; g[1] = gv.y; g[2] = gv.z; g[3] = gv.w;
         }
         float ww[4] = {wv.x, wv.y, wv.z, wv.w}, mm[4] = {mv.x, mv.y, mv.z, mv.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sgd_one(t, g[j], ww[j], mm[j]);
+        for (int j = 0; j < 4; ++j) sgd_one(t, t.grad_scale ? g[j] * inv_scale : g[j], ww[j], mm[j]);
         wv.x = ww[0]; wv.y = ww[1]; wv.z = ww[2]; wv.w = ww[3];
         mv.x = mm[0]; mv.y = mm[1]; mv.z = mm[2]; mv.w = mm[3];
         ((rn::f32x4 *)w)[v] = wv;
         if (has_m) ((rn::f32x4 *)m)[v] = mv;
         if (p16) {
             rn::u32x2 o;
-            o.x = rn::dt<RN_BF16>::pk(ww[0], ww[1]); o.y = rn::dt<RN_BF16>::pk(ww[2], ww[3]);
+            o.x = rn::dt<DT>::pk(ww[0], ww[1]); o.y = rn::dt<DT>::pk(ww[2], ww[3]);
             ((rn::u32x2 *)p16)[v] = o;
         }
     }
@@ -80,21 +88,24 @@ __global__ __launch_bounds__(256) void sgd_master_kernel(const SgdTable t)
         const int64_t i = n4 * 4 + threadIdx.x;
         if (threadIdx.x < 4 && i < n) {
             float wi = w[i], mi = (has_m && !t.first) ? m[i] : 0.0f;
-            const float g = g16 ? __uint_as_float((uint32_t)((const uint16_t *)t.grad[ti])[i] << 16) : ((const float *)t.grad[ti])[i];
+            float g = g16 ? rn::mma<DT>::lo((uint32_t)((const uint16_t *)t.grad[ti])[i]) : ((const float *)t.grad[ti])[i];
+            if (t.grad_scale) g *= inv_scale;
             sgd_one(t, g, wi, mi);
             w[i] = wi;
             if (has_m) m[i] = mi;
-            if (p16) p16[i] = (uint16_t)(rn::dt<RN_BF16>::pk(wi, 0.0f) & 0xffffu);
+            if (p16) p16[i] = rn::mma<DT>::dn(wi);
         }
     }
 }
 
 }  // namespace
 
-RN_API int rn_sgd_master_step(float *const *masters, float *const *momenta, const void *const *grads, void *const *params16,
-                              const int64_t *numels, int n_tensors, int grads16, float lr, float momentum, float dampening,
-                              float weight_decay, int nesterov, int first_step, void *stream)
+RN_API int rn_sgd_master_step_ex(float *const *masters, float *const *momenta, const void *const *grads, void *const *params16,
+                                 const int64_t *numels, int n_tensors, int grads16, int dtype16, float lr, float momentum, float dampening,
+                                 float weight_decay, int nesterov, int first_step, const float *grad_scale, const float *found_inf,
+                                 void *stream)
 {
+    if (dtype16 != RN_BF16 && dtype16 != RN_F16) return RN_EUNSUPPORTED;
     if (!masters || !momenta || !grads || !params16 || !numels || n_tensors < 0) return RN_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     for (int base = 0; base < n_tensors; base += SGD_MAX_TENSORS) {
@@ -110,15 +121,25 @@ RN_API int rn_sgd_master_step(float *const *masters, float *const *momenta, cons
         }
         t.lr = lr; t.momentum = momentum; t.dampening = dampening; t.weight_decay = weight_decay;
         t.nesterov = nesterov; t.first = first_step; t.grad16 = grads16;
+        t.f16 = dtype16 == RN_F16; t.grad_scale = grad_scale; t.found_inf = found_inf;
         int64_t max_n = 1;
         for (int i = 0; i < cnt; ++i) max_n = t.n[i] > max_n ? t.n[i] : max_n;
         int64_t bx = (max_n / 4 + 255) / 256;                    // one pass over the largest tensor, capped
         if (bx > SGD_BLOCKS_X) bx = SGD_BLOCKS_X;
         if (bx < 1) bx = 1;
-        hipLaunchKernelGGL(sgd_master_kernel, dim3((unsigned)bx, (unsigned)cnt), dim3(256), 0, st, t);
+        if (t.f16) hipLaunchKernelGGL(sgd_master_kernel<true>, dim3((unsigned)bx, (unsigned)cnt), dim3(256), 0, st, t);
+        else hipLaunchKernelGGL(sgd_master_kernel<false>, dim3((unsigned)bx, (unsigned)cnt), dim3(256), 0, st, t);
         RN_LAUNCH_CHECK();
     }
     return RN_OK;
+}
+
+RN_API int rn_sgd_master_step(float *const *masters, float *const *momenta, const void *const *grads, void *const *params16,
+                              const int64_t *numels, int n_tensors, int grads16, float lr, float momentum, float dampening,
+                              float weight_decay, int nesterov, int first_step, void *stream)
+{
+    return rn_sgd_master_step_ex(masters, momenta, grads, params16, numels, n_tensors, grads16, RN_BF16, lr, momentum, dampening, weight_decay,
+                                 nesterov, first_step, nullptr, nullptr, stream);
 }
 
 // ---- many small device-to-device copies in one launch ---------------------------------------------------------------------------

@@ -24,8 +24,7 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
+using rn::f32x16;
 
 constexpr int PW_BM = 128, PW_BK = 64, PW_THREADS = 256;
 constexpr int PW_MAX_GX = 512;                  // persistent row-tile walkers = BN partial rows (norm.hip: BN_MAX_BLOCKS)
@@ -34,7 +33,8 @@ constexpr int PW_MAX_GX = 512;                  // persistent row-tile walkers =
 enum { PRO_NONE = 0, PRO_AFFINE_RELU = 1, PRO_BN_BWD = 2 };
 enum { EPI_STATS = 1, EPI_RESID = 2, EPI_RELU_BWD = 4, EPI_BIAS = 8 };
 
-__device__ __forceinline__ float alive_bf16() { return __uint_as_float(0x00004000u); }   // norm.hip: relu_alive_threshold<RN_BF16>
+// norm.hip: relu_alive_threshold<DT> -- half the smallest subnormal of the element type (ties to even -> 0)
+template <int DT> __device__ __forceinline__ float alive_dt() { return __uint_as_float(DT == RN_F16 ? 0x33000000u : 0x00004000u); }
 
 struct PwArgs {
     const uint16_t *X, *X2;         // X: [rows][Cin];  PRO_BN_BWD: X = upstream gradient g, X2 = the BN input z (same shape)
@@ -56,6 +56,7 @@ struct PwArgs {
     int relu_mode;                  // PRO_BN_BWD: 0 none, 2 recomputed from X2, 3 bits
     int stride, pad, Ho, Wo, H, W_; // position decode of output row m = (n, ho, wo) -> input (n, ho * stride - pad + dy, ...)
     int gx;                         // row-tile walkers per column tile
+    int f16;                        // host side: fp16 elements instead of bf16 (kernel instantiation)
 };
 
 // one output row of the tile as this thread sees it: image base (in rows) and the top-left input coordinate
@@ -94,19 +95,19 @@ __device__ __forceinline__ void load_coef(ProCoef &k, const float *pa, const flo
         if (relu_mode == 2) { ld8f(fa + ch, k.fa); ld8f(fb + ch, k.fb); }
     }
 }
-template <int PRO>
+template <int DT, int PRO>
 __device__ __forceinline__ rn::u32x4 transform(const rn::u32x4 x, const rn::u32x4 z, const uint32_t bits, const ProCoef &k, const int relu_mode,
                                                const bool valid)
 {
     if (PRO == PRO_NONE) return valid ? x : rn::u32x4{0u, 0u, 0u, 0u};
     float f[8], g[8];
-    rn::dt<RN_BF16>::unpack(x, f);
+    rn::dt<DT>::unpack(x, f);
     if (PRO == PRO_AFFINE_RELU) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float t = fmaf(f[j], k.a[j], k.b[j]); f[j] = t > 0.0f ? t : 0.0f; }
     } else {
-        rn::dt<RN_BF16>::unpack(z, g);
-        const float alive = alive_bf16();
+        rn::dt<DT>::unpack(z, g);
+        const float alive = alive_dt<DT>();
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float gj = f[j];
@@ -115,12 +116,12 @@ __device__ __forceinline__ rn::u32x4 transform(const rn::u32x4 x, const rn::u32x
             f[j] = fmaf(k.a[j], gj, fmaf(k.c[j], g[j], k.b[j]));
         }
     }
-    const rn::u32x4 o = rn::dt<RN_BF16>::pack(f);
+    const rn::u32x4 o = rn::dt<DT>::pack(f);
     return valid ? o : rn::u32x4{0u, 0u, 0u, 0u};
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-template <int BN, int PRO, int EPI>
+template <int DT, int BN, int PRO, int EPI>
 __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
 {
     constexpr int MI = 2, NI = BN / 64;                         // 2 x 2 waves of 64 x (BN / 2)
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *(rn::u32x4 *)(sb + wa_off[i]) = transform<PRO>(sx[i], sz[i], sbits[i], coef, a.relu_mode, sval[i]);
+        for (int i = 0; i < 4; ++i) *(rn::u32x4 *)(sb + wa_off[i]) = transform<DT, PRO>(sx[i], sz[i], sbits[i], coef, a.relu_mode, sval[i]);
 #pragma unroll
         for (int i = 0; i < BROWS; ++i) *(rn::u32x4 *)(sb + wb_off[i]) = sw[i];
     };
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
         }
         __syncthreads();
     }
-    const float alive = alive_bf16();
+    const float alive = alive_dt<DT>();
 
     float ebias[8];                                             // EPI_BIAS: this thread's 8 fixed columns of the bias
     if (EPI & EPI_BIAS) ld8f(a.bias + n0 + ecg * 8, ebias);
@@ -280,16 +281,17 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
             const unsigned char *const sb = lds + (kt & 1) * STAGE;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                bf16x8 fa[MI], fb[NI];
+                typedef typename rn::mma<DT>::frag frag8;
+                frag8 fa[MI], fb[NI];
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) fa[mi] = *(const bf16x8 *)(sb + a_off[kk] + mi * 4096);
+                for (int mi = 0; mi < MI; ++mi) fa[mi] = *(const frag8 *)(sb + a_off[kk] + mi * 4096);
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) fb[ni] = *(const bf16x8 *)(sb + b_off[kk] + ni * 4096);
+                for (int ni = 0; ni < NI; ++ni) fb[ni] = *(const frag8 *)(sb + b_off[kk] + ni * 4096);
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = rn::mma<DT>::m32(fa[mi], fb[ni], acc[mi][ni]);
             }
             if (kt + 1 < KT) commit((kt + 1) & 1);
             __syncthreads();
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
                 }
                 if (EPI & EPI_RESID) {
                     float r[8];
-                    rn::dt<RN_BF16>::unpack(er[i], r);
+                    rn::dt<DT>::unpack(er[i], r);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] += ((ebits[i] >> j) & 1u) ? r[j] : 0.0f;
                 }
@@ -332,21 +334,21 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
                 }
-                rn::u32x4 o = rn::dt<RN_BF16>::pack(v);
+                rn::u32x4 o = rn::dt<DT>::pack(v);
                 if (EPI & (EPI_STATS | EPI_RELU_BWD)) {
-                    rn::dt<RN_BF16>::unpack(o, v);              // the statistics are those of the stored (rounded) tensor
+                    rn::dt<DT>::unpack(o, v);              // the statistics are those of the stored (rounded) tensor
                     if (EPI & EPI_RELU_BWD) {
                         float z[8], ea[8], eb[8], emu[8], eis[8];
                         ld8f(s_epi + ecg * 8, ea); ld8f(s_epi + BN + ecg * 8, eb);
                         ld8f(s_epi + 2 * BN + ecg * 8, emu); ld8f(s_epi + 3 * BN + ecg * 8, eis);
-                        rn::dt<RN_BF16>::unpack(er[i], z);
+                        rn::dt<DT>::unpack(er[i], z);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             if (!(fmaf(z[j], ea[j], eb[j]) > alive)) v[j] = 0.0f;
                             ssum[j] += v[j];
                             qsum[j] = fmaf(v[j], (z[j] - emu[j]) * eis[j], qsum[j]);
                         }
-                        o = rn::dt<RN_BF16>::pack(v);          // exact: v is a bf16 value or zero
+                        o = rn::dt<DT>::pack(v);          // exact: v is a bf16 value or zero
                     } else {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; qsum[j] = fmaf(v[j], v[j], qsum[j]); }
@@ -387,11 +389,12 @@ struct WgArgs {
     float *partial;                 // [S][N][taps * Cin] f32
     int M, N, Cin, taps, stride, pad, Ho, Wo, H, W_;
     int S, tiles_per_split;         // K-tiles of 64 positions per split
+    int f16;                        // host side: fp16 elements (kernel instantiation)
 };
 
 template <int W> __device__ __forceinline__ int tr_swz(const int row) { return W >= 128 ? ((row & 3) << 2) : (((row >> 1) & 1) << 2); }
 
-template <int TN, int TK, int PROG, int PROX>
+template <int DT, int TN, int TK, int PROG, int PROX>
 __global__ __launch_bounds__(PW_THREADS, 2) void pw_wgrad_kernel(const WgArgs a)
 {
     constexpr int MI = TN / 64, NI = TK / 64;                   // 2 x 2 waves of (TN / 2) x (TK / 2)
@@ -480,12 +483,12 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_wgrad_kernel(const WgArgs a)
 #pragma unroll
         for (int i = 0; i < GV; ++i) {
             const int row = gr0 + i * GRS;
-            *(rn::u32x4 *)(lds + row * G_ROWB + ((gc_ ^ tr_swz<TN>(row)) << 4)) = transform<PROG>(sg[i], sg2[i], sgb[i], gcoef, a.g_relu_mode, gval[i]);
+            *(rn::u32x4 *)(lds + row * G_ROWB + ((gc_ ^ tr_swz<TN>(row)) << 4)) = transform<DT, PROG>(sg[i], sg2[i], sgb[i], gcoef, a.g_relu_mode, gval[i]);
         }
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
             const int row = xr0 + i * XRS;
-            *(rn::u32x4 *)(lds + G_TILE + row * X_ROWB + ((xc_ ^ tr_swz<TK>(row)) << 4)) = transform<PROX>(sx[i], sx[i], 0xffu, xcoef, 0, xval[i]);
+            *(rn::u32x4 *)(lds + G_TILE + row * X_ROWB + ((xc_ ^ tr_swz<TK>(row)) << 4)) = transform<DT, PROX>(sx[i], sx[i], 0xffu, xcoef, 0, xval[i]);
         }
     };
     // transposing fragment reads through the compiler's builtin (it then tracks their lgkmcnt itself; an inline-asm read is
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_wgrad_kernel(const WgArgs a)
     auto tr_frag = [&](const uint32_t off, const uint32_t rowb) {     // 8-deep k fragment = positions +0..3 and +4..7
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(lds + off));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(lds + off + 4 * rowb));
-        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        return __builtin_bit_cast(typename rn::mma<DT>::frag, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
     if (m_begin < a.M) {
         issue(0);
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_wgrad_kernel(const WgArgs a)
             if (kt + 1 < KT && m_begin + (kt + 1) * 64 < a.M) issue(kt + 1);      // in flight under the MFMAs
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                bf16x8 fg[MI], fx[NI];
+                typename rn::mma<DT>::frag fg[MI], fx[NI];
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) fg[mi] = tr_frag(g_off[mi] + kk * 16 * G_ROWB, G_ROWB);
 #pragma unroll
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_wgrad_kernel(const WgArgs a)
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fg[mi], fx[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = rn::mma<DT>::m32(fg[mi], fx[ni], acc[mi][ni]);
             }
             __syncthreads();
         }
@@ -537,6 +540,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_wgrad_kernel(const WgArgs a)
 
 // dW (bf16) = sum over the splits of partial (f32).  A block owns 32 float4 outputs; its 8 thread rows each sum every 8th
 // split (8 loads in flight per output instead of one serial chain over S), then the 8 sums are combined in a fixed order.
+template <int DT>
 __global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float *__restrict__ partial, const int S, const int64_t n4, uint16_t *__restrict__ dw)
 {
     __shared__ rn::f32x4 sh[8][32];
@@ -555,7 +559,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float *__res
 #pragma unroll
         for (int l = 1; l < 8; ++l) { const rn::f32x4 v = sh[l][j]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
         rn::u32x2 o;
-        o.x = rn::dt<RN_BF16>::pk(t.x, t.y); o.y = rn::dt<RN_BF16>::pk(t.z, t.w);
+        o.x = rn::dt<DT>::pk(t.x, t.y); o.y = rn::dt<DT>::pk(t.z, t.w);
         ((rn::u32x2 *)dw)[i] = o;
     }
 }
@@ -564,6 +568,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_reduce_kernel(const float *__res
 // weight gradients are summed once at the end of its backward instead of behind each kernel (8 us of launch-bound work each).
 constexpr int RED_MAX = 8;
 struct ReduceTable { const float *partial[RED_MAX]; uint16_t *dw[RED_MAX]; int S[RED_MAX]; int64_t n4[RED_MAX]; };
+template <int DT>
 __global__ __launch_bounds__(256) void pw_wgrad_reduce_many_kernel(const ReduceTable t)
 {
     __shared__ rn::f32x4 sh[8][32];
@@ -587,7 +592,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_reduce_many_kernel(const ReduceT
 #pragma unroll
             for (int l = 1; l < 8; ++l) { const rn::f32x4 v = sh[l][j]; u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w; }
             rn::u32x2 o;
-            o.x = rn::dt<RN_BF16>::pk(u.x, u.y); o.y = rn::dt<RN_BF16>::pk(u.z, u.w);
+            o.x = rn::dt<DT>::pk(u.x, u.y); o.y = rn::dt<DT>::pk(u.z, u.w);
             ((rn::u32x2 *)t.dw[it])[i] = o;
         }
         __syncthreads();
@@ -609,16 +614,20 @@ int walkers(const int M)
     return (MT + rounds - 1) / rounds;
 }
 
-template <int BN, int PRO, int EPI> int launch_gemm(const PwArgs &a, hipStream_t st)
+template <int DT, int BN, int PRO, int EPI> int launch_gemm_dt(const PwArgs &a, hipStream_t st)
 {
     constexpr int lds_main = 2 * (PW_BM * PW_BK * 2 + BN * PW_BK * 2) > PW_BM * BN * 4 ? 2 * (PW_BM * PW_BK * 2 + BN * PW_BK * 2) : PW_BM * BN * 4;
     const int lds = lds_main + (PRO == PRO_NONE ? 0 : (PRO == PRO_AFFINE_RELU ? 2 : 5) * a.Cin * 4) + ((EPI & EPI_RELU_BWD) ? 4 * BN * 4 : 0);
     if (lds > 160 * 1024) return RN_EUNSUPPORTED;
     static rn::DynLdsOptIn opt_in = {};
-    { const int rc = opt_in.ensure((const void *)pw_gemm_kernel<BN, PRO, EPI>, lds); if (rc != RN_OK) return rc; }
-    hipLaunchKernelGGL((pw_gemm_kernel<BN, PRO, EPI>), dim3((unsigned)a.gx, (unsigned)(a.N / BN)), dim3(PW_THREADS), lds, st, a);
+    { const int rc = opt_in.ensure((const void *)pw_gemm_kernel<DT, BN, PRO, EPI>, lds); if (rc != RN_OK) return rc; }
+    hipLaunchKernelGGL((pw_gemm_kernel<DT, BN, PRO, EPI>), dim3((unsigned)a.gx, (unsigned)(a.N / BN)), dim3(PW_THREADS), lds, st, a);
     RN_LAUNCH_CHECK();
     return RN_OK;
+}
+template <int BN, int PRO, int EPI> int launch_gemm(const PwArgs &a, hipStream_t st)
+{
+    return a.f16 ? launch_gemm_dt<RN_F16, BN, PRO, EPI>(a, st) : launch_gemm_dt<RN_BF16, BN, PRO, EPI>(a, st);
 }
 
 template <int BN, int PRO> int dispatch_epi(const PwArgs &a, const int epi, hipStream_t st)
@@ -634,15 +643,19 @@ template <int BN, int PRO> int dispatch_epi(const PwArgs &a, const int epi, hipS
     }
 }
 
-template <int TN, int TK, int PROG, int PROX> int launch_wgrad(const WgArgs &a, hipStream_t st)
+template <int DT, int TN, int TK, int PROG, int PROX> int launch_wgrad_dt(const WgArgs &a, hipStream_t st)
 {
     constexpr int lds = 64 * (TN + TK) * 2;
     static rn::DynLdsOptIn opt_in = {};
-    { const int rc = opt_in.ensure((const void *)pw_wgrad_kernel<TN, TK, PROG, PROX>, lds); if (rc != RN_OK) return rc; }
+    { const int rc = opt_in.ensure((const void *)pw_wgrad_kernel<DT, TN, TK, PROG, PROX>, lds); if (rc != RN_OK) return rc; }
     const unsigned gy = (unsigned)((a.N / TN) * (a.Cin / TK) * a.taps);
-    hipLaunchKernelGGL((pw_wgrad_kernel<TN, TK, PROG, PROX>), dim3((unsigned)a.S, gy), dim3(PW_THREADS), lds, st, a);
+    hipLaunchKernelGGL((pw_wgrad_kernel<DT, TN, TK, PROG, PROX>), dim3((unsigned)a.S, gy), dim3(PW_THREADS), lds, st, a);
     RN_LAUNCH_CHECK();
     return RN_OK;
+}
+template <int TN, int TK, int PROG, int PROX> int launch_wgrad(const WgArgs &a, hipStream_t st)
+{
+    return a.f16 ? launch_wgrad_dt<RN_F16, TN, TK, PROG, PROX>(a, st) : launch_wgrad_dt<RN_BF16, TN, TK, PROG, PROX>(a, st);
 }
 
 template <int TN, int TK> int dispatch_wgrad(const WgArgs &a, const int prog, const int prox, hipStream_t st)
@@ -696,6 +709,7 @@ int check_geometry(const rn_pw_conv *d)
     if (!d || d->M <= 0 || d->Cin <= 0 || d->N <= 0) return RN_EINVAL;
     if (d->Cin % 64 || d->N % 64) return RN_EUNSUPPORTED;
     if (d->taps != 1 && d->taps != 9) return RN_EUNSUPPORTED;
+    if (d->dtype != 0 && d->dtype != RN_BF16 && d->dtype != RN_F16) return RN_EUNSUPPORTED;          // (0: a caller from before the field existed = bf16)
     if (d->stride < 1 || d->pad < 0 || d->Ho <= 0 || d->Wo <= 0 || d->H <= 0 || d->W <= 0) return RN_EINVAL;
     if (d->M % (d->Ho * d->Wo)) return RN_EINVAL;
     if (d->M >= ((int64_t)1 << 31)) return RN_EUNSUPPORTED;                      // the kernels index rows with 32-bit integers
@@ -719,6 +733,7 @@ RN_API int rn_pw_conv_forward(const rn_pw_conv *d, const void *x, const void *w,
     a.M = (int)d->M; a.Cin = d->Cin; a.N = d->N; a.taps = d->taps; a.stride = d->stride; a.pad = d->pad;
     a.Ho = d->Ho; a.Wo = d->Wo; a.H = d->H; a.W_ = d->W;
     a.gx = walkers(a.M);
+    a.f16 = d->dtype == RN_F16;
     int p = PRO_NONE, e = 0;
     if (pro && pro->kind != PRO_NONE) {
         p = pro->kind;
@@ -789,6 +804,7 @@ static int pw_wgrad_impl(const rn_pw_conv *d, const void *g, const void *x, void
     a.M = (int)d->M; a.N = d->N; a.Cin = d->Cin; a.taps = d->taps; a.stride = d->stride; a.pad = d->pad;
     a.Ho = d->Ho; a.Wo = d->Wo; a.H = d->H; a.W_ = d->W;
     const bool g_transform = gpro && gpro->kind != PRO_NONE;
+    a.f16 = d->dtype == RN_F16;
     a.S = wgrad_splits(d, &a.tiles_per_split, g_transform);
     int pg = PRO_NONE, px = PRO_NONE;
     if (gpro && gpro->kind != PRO_NONE) {
@@ -817,7 +833,8 @@ static int pw_wgrad_impl(const rn_pw_conv *d, const void *g, const void *x, void
     if (r != RN_OK) return r;
     if (splits) { *splits = a.S; return RN_OK; }
     const int64_t n4 = (int64_t)d->N * d->taps * d->Cin / 4;
-    hipLaunchKernelGGL(pw_wgrad_reduce_kernel, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, st, (const float *)workspace, a.S, n4, (uint16_t *)dw);
+    if (a.f16) hipLaunchKernelGGL(pw_wgrad_reduce_kernel<RN_F16>, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, st, (const float *)workspace, a.S, n4, (uint16_t *)dw);
+    else hipLaunchKernelGGL(pw_wgrad_reduce_kernel<RN_BF16>, dim3((unsigned)((n4 + 31) / 32)), dim3(256), 0, st, (const float *)workspace, a.S, n4, (uint16_t *)dw);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
@@ -835,8 +852,10 @@ RN_API int rn_pw_conv_wgrad_partial(const rn_pw_conv *d, const void *g, const vo
     return pw_wgrad_impl(d, g, x, nullptr, gpro, xpro, workspace, workspace_bytes, stream, splits);
 }
 
-RN_API int rn_pw_wgrad_reduce_many(const void *const *partials, const int *splits, const int64_t *n_elems, void *const *dws, int n, void *stream)
+RN_API int rn_pw_wgrad_reduce_many_dt(const void *const *partials, const int *splits, const int64_t *n_elems, void *const *dws, int n, int dtype,
+                                      void *stream)
 {
+    if (dtype != RN_BF16 && dtype != RN_F16) return RN_EUNSUPPORTED;
     if (!partials || !splits || !n_elems || !dws || n <= 0 || n > RED_MAX) return RN_EINVAL;
     ReduceTable t;
     int64_t most = 1;
@@ -849,7 +868,13 @@ RN_API int rn_pw_wgrad_reduce_many(const void *const *partials, const int *split
     }
     int64_t bx = (most + 31) / 32;
     if (bx > 2048) bx = 2048;
-    hipLaunchKernelGGL(pw_wgrad_reduce_many_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, t);
+    if (dtype == RN_F16) hipLaunchKernelGGL(pw_wgrad_reduce_many_kernel<RN_F16>, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, t);
+    else hipLaunchKernelGGL(pw_wgrad_reduce_many_kernel<RN_BF16>, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, t);
     RN_LAUNCH_CHECK();
     return RN_OK;
+}
+
+RN_API int rn_pw_wgrad_reduce_many(const void *const *partials, const int *splits, const int64_t *n_elems, void *const *dws, int n, void *stream)
+{
+    return rn_pw_wgrad_reduce_many_dt(partials, splits, n_elems, dws, n, RN_BF16, stream);
 }

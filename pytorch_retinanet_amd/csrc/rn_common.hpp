@@ -95,6 +95,28 @@ template <> struct dt<RN_F16> {
     static __device__ __forceinline__ void st(void *p, int64_t i, float v) { ((_Float16 *)p)[i] = (_Float16)v; }
 };
 
+// ---- matrix-instruction traits of the two 16-bit element types (same rate on gfx950: v_mfma_f32_{16x16x32,32x32x16}_{bf16,f16}) ----
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+template <int DT> struct mma;
+template <> struct mma<RN_BF16> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x4 m16(const frag a, const frag b, const f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x16 m32(const frag a, const frag b, const f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ uint16_t dn(const float f) { return (uint16_t)(dt<RN_BF16>::pk(f, 0.0f) & 0xffffu); }      // f32 -> element bits (RNE)
+    static __device__ __forceinline__ float lo(const uint32_t w) { return __uint_as_float(w << 16); }                            // halves of a packed dword
+    static __device__ __forceinline__ float hi(const uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+};
+template <> struct mma<RN_F16> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x4 m16(const frag a, const frag b, const f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x16 m32(const frag a, const frag b, const f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ uint16_t dn(const float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+    static __device__ __forceinline__ float lo(const uint32_t w) { return half_lo(w); }
+    static __device__ __forceinline__ float hi(const uint32_t w) { return half_hi(w); }
+};
+
 // ---- wave64 reductions -------------------------------------------------------
 static __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

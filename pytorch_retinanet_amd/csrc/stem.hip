@@ -17,7 +17,6 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4v;
 
 constexpr int STEM_THREADS = 256, STEM_WAVES = 4;
@@ -72,6 +71,7 @@ struct StemArgs {
 };
 
 
+template <int DT>
 __global__ __launch_bounds__(STEM_THREADS) void stem_fwd_kernel(const StemArgs a)
 {
     __shared__ uint32_t s_strip[STEM_WAVES][16 * 34];             // per wave: 16 pixels x (32 dwords of 64 bf16 channels + 2 pad)
@@ -81,11 +81,12 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_fwd_kernel(const StemArgs a
     const int p = lane & 15, g = lane >> 4;                          // pixel of the tile / k-group (as operand), channel group (as result)
 
     // the weights: 4 channel tiles x 7 kernel rows, lane = (channel p of the tile, k-group g)
-    bf16x8 wf[4][7];
+    typedef typename rn::mma<DT>::frag el16x8;             // (8 consecutive 16-bit elements: bf16 or fp16)
+    el16x8 wf[4][7];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int r = 0; r < 7; ++r) wf[mt][r] = *(const bf16x8 *)(a.wk + ((mt * 16 + p) * 7 + r) * STEM_KROW + 8 * g);
+        for (int r = 0; r < 7; ++r) wf[mt][r] = *(const el16x8 *)(a.wk + ((mt * 16 + p) * 7 + r) * STEM_KROW + 8 * g);
 
     float ssum[4][4], ssq[4][4];
 #pragma unroll
@@ -103,9 +104,9 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_fwd_kernel(const StemArgs a
     auto tile_base = [&](const int b, const int yo, const int tx) {
         return a.xp + (((int64_t)b * a.Hp2 + 2 * yo) * a.Wpp + 32 * tx) * 4;
     };
-    auto load_tile = [&](const uint16_t *base, bf16x8 (&af)[7]) {
+    auto load_tile = [&](const uint16_t *base, el16x8 (&af)[7]) {
 #pragma unroll
-        for (int r = 0; r < 7; ++r) af[r] = *(const bf16x8 *)(base + r * row_elems + lane_off);
+        for (int r = 0; r < 7; ++r) af[r] = *(const el16x8 *)(base + r * row_elems + lane_off);
     };
     auto advance = [&](int &b, int &yo, int &tx) {                   // + STEM_WAVES tiles (tiles_x >= 1: wraps handled in a loop)
         tx += STEM_WAVES;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_fwd_kernel(const StemArgs a
     // the bench shape (134 400 tiles): 2 sets x 2 waves per SIMD 100 us; 3 sets 111; 4 / 6 sets at one wave per SIMD 101 / 103 --
     // not latency-bound.  Ablations: no output stores 64 us, no statistics 94, one load per tile instead of seven 85; non-temporal
     // output stores 81 (and the BatchNorm apply pass that reads the output next 108 -> 98 us).  MIOpen: 240 us + 46 us statistics.
-    bf16x8 ring[STEM_NB][7];
+    el16x8 ring[STEM_NB][7];
     int t = t_beg + wave;
     const int t_last = t_end - 1;
     int tx = t % a.tiles_x, yo = (t / a.tiles_x) % a.Ho, b = (t / a.tiles_x) / a.Ho;      // once per wave: compute cursor
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_fwd_kernel(const StemArgs a
     // The loop body is straight-line code -- every wave runs the same number of (load, compute) steps, loads past the wave's
     // last tile re-read that tile, stores and statistics past it are masked -- so that the compiler's s_waitcnt counting is exact:
     // with `if (tile exists)` around the loads its vmcnt for a fragment also waited for the loads issued AFTER it.
-    auto load_next = [&](bf16x8 (&dst)[7]) {
+    auto load_next = [&](el16x8 (&dst)[7]) {
         load_tile(tile_base(bl, yl, xl), dst);
         if (tl + STEM_WAVES <= t_last) { tl += STEM_WAVES; advance(bl, yl, xl); }        // scalar; stays on the last tile at the end
     };
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_fwd_kernel(const StemArgs a
 #pragma unroll
         for (int j = 0; j < STEM_NB; ++j) {
             load_next(ring[(j + STEM_NB - 1) % STEM_NB]);
-            bf16x8 (&af)[7] = ring[j];
+            el16x8 (&af)[7] = ring[j];
             const bool valid = done < n_tiles;                                            // wave-uniform
             const int xo0 = tx * 16;
             f32x4v acc[4];
@@ -149,16 +150,16 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_fwd_kernel(const StemArgs a
 #pragma unroll
             for (int r = 0; r < 7; ++r)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[mt][r], af[r], acc[mt], 0, 0, 0);
+                for (int mt = 0; mt < 4; ++mt) acc[mt] = rn::mma<DT>::m16(wf[mt][r], af[r], acc[mt]);
             // result lane (pixel p, group g): channels mt * 16 + 4 g + 0..3 of pixel xo0 + p
             const bool live = valid && xo0 + p < a.Wo;                                    // (lanes past the row end hold garbage, possibly NaN)
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const uint32_t lo = rn::dt<RN_BF16>::pk(acc[mt][0], acc[mt][1]), hi = rn::dt<RN_BF16>::pk(acc[mt][2], acc[mt][3]);
+                const uint32_t lo = rn::dt<DT>::pk(acc[mt][0], acc[mt][1]), hi = rn::dt<DT>::pk(acc[mt][2], acc[mt][3]);
                 *(rn::u32x2 *)(strip + p * 34 + mt * 8 + g * 2) = rn::u32x2{lo, hi};
                 const uint32_t lo_l = live ? lo : 0u, hi_l = live ? hi : 0u;
-                const float v0 = __uint_as_float(lo_l << 16), v1 = __uint_as_float(lo_l & 0xffff0000u);
-                const float v2 = __uint_as_float(hi_l << 16), v3 = __uint_as_float(hi_l & 0xffff0000u);
+                const float v0 = rn::mma<DT>::lo(lo_l), v1 = rn::mma<DT>::hi(lo_l);
+                const float v2 = rn::mma<DT>::lo(hi_l), v3 = rn::mma<DT>::hi(hi_l);
                 ssum[mt][0] += v0; ssq[mt][0] = fmaf(v0, v0, ssq[mt][0]);
                 ssum[mt][1] += v1; ssq[mt][1] = fmaf(v1, v1, ssq[mt][1]);
                 ssum[mt][2] += v2; ssq[mt][2] = fmaf(v2, v2, ssq[mt][2]);
@@ -227,8 +228,10 @@ struct StemWgradArgs {
     int tiles_x, total_stages, stages_per_wg;
 };
 
+template <int DT>
 __global__ __launch_bounds__(STEM_THREADS) void stem_wgrad_kernel(const StemWgradArgs a)
 {
+    typedef typename rn::mma<DT>::frag el16x8;             // (8 consecutive 16-bit elements: bf16 or fp16)
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * SW_BUF];
     typedef __attribute__((ext_vector_type(4))) short s16x4;
     typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_wgrad_kernel(const StemWgra
     auto tr_frag = [&](const unsigned char *base, const int rowb) {      // pixels +0..3 and +4..7 of this lane group's 8
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base + 4 * rowb));
-        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        return __builtin_bit_cast(el16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
 
     if (s_beg < s_end) { fetch(s_beg); commit(lds); }
@@ -290,14 +293,14 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_wgrad_kernel(const StemWgra
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int px = ks * 32 + 8 * grp + q;                           // this lane's row of the transposing reads
-            bf16x8 gf[2];
+            el16x8 gf[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) gf[i] = tr_frag(cur + px * SW_GPITCH + ((2 * mp + i) * 16 + 4 * p4) * 2, SW_GPITCH);
 #pragma unroll
             for (int r = 0; r < 7; ++r) {
-                const bf16x8 xf = tr_frag(cur + SW_GBYTES + r * SW_SPITCH + px * 16 + (kp * 16 + 4 * p4) * 2, 16);
+                const el16x8 xf = tr_frag(cur + SW_GBYTES + r * SW_SPITCH + px * 16 + (kp * 16 + 4 * p4) * 2, 16);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc[i][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[i], xf, acc[i][r], 0, 0, 0);
+                for (int i = 0; i < 2; ++i) acc[i][r] = rn::mma<DT>::m16(gf[i], xf, acc[i][r]);
             }
         }
         if (s + 1 < s_end) commit(nxt);
@@ -318,6 +321,7 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_wgrad_kernel(const StemWgra
 
 // dw [64][7][7][3] bf16 = sum of the partials (k = 4 * px + c; the pad columns are dropped).  Block = 16 outputs x 16 slices of
 // the partials, combined through LDS in a fixed order (a thread per output summing 512 partials alone took 45 us).
+template <int DT>
 __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float *__restrict__ partial, const int n, uint16_t *__restrict__ dw)
 {
     __shared__ float sh[16][17];
@@ -336,7 +340,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float *__r
 #pragma unroll
         for (int j = 0; j < 16; ++j) t += sh[j][o];
         const int k = i % STEM_KROW, r = (i / STEM_KROW) % 7, ch = i / (7 * STEM_KROW), px = k >> 2, c = k & 3;
-        if (px < 7 && c < 3) dw[((ch * 7 + r) * 7 + px) * 3 + c] = (uint16_t)(rn::dt<RN_BF16>::pk(t, 0.0f) & 0xffffu);
+        if (px < 7 && c < 3) dw[((ch * 7 + r) * 7 + px) * 3 + c] = rn::mma<DT>::dn(t);
     }
 }
 
@@ -387,7 +391,7 @@ RN_API int rn_stem_conv_forward(const void *x, const void *w, void *xp, void *wk
                                 void *stream)
 {
     if (!x || !w || !xp || !wk || !y || B <= 0 || H <= 0 || W <= 0) return RN_EINVAL;
-    if (dtype != RN_BF16) return RN_EUNSUPPORTED;
+    if (dtype != RN_BF16 && dtype != RN_F16) return RN_EUNSUPPORTED;
     if ((int64_t)B * (H + 6) * (W + 8) >= ((int64_t)1 << 31)) return RN_EUNSUPPORTED;
     if (!rn::aligned(xp, 16) || !rn::aligned(wk, 16) || !rn::aligned(y, 16)) return RN_EALIGN;
     if (!rn::aligned(x, 2) || !rn::aligned(w, 2)) return RN_EALIGN;              // (read element by element: bf16 alignment is all they need)
@@ -406,7 +410,8 @@ RN_API int rn_stem_conv_forward(const void *x, const void *w, void *xp, void *wk
     a.B = B; a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1; a.Hp2 = pa.Hp2; a.Wpp = pa.Wpp;
     a.tiles_x = (a.Wo + 15) / 16; a.total_tiles = B * a.Ho * a.tiles_x;
     const int wgs = stem_grid(a.total_tiles, &a.tiles_per_wg);
-    hipLaunchKernelGGL(stem_fwd_kernel, dim3((unsigned)wgs), dim3(STEM_THREADS), 0, st, a);
+    if (dtype == RN_F16) hipLaunchKernelGGL(stem_fwd_kernel<RN_F16>, dim3((unsigned)wgs), dim3(STEM_THREADS), 0, st, a);
+    else hipLaunchKernelGGL(stem_fwd_kernel<RN_BF16>, dim3((unsigned)wgs), dim3(STEM_THREADS), 0, st, a);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
@@ -424,7 +429,7 @@ RN_API int rn_stem_conv_wgrad(const void *g, const void *xp, void *dw, int dtype
                               size_t workspace_bytes, void *stream)
 {
     if (!g || !xp || !dw || !workspace || B <= 0 || H <= 0 || W <= 0) return RN_EINVAL;
-    if (dtype != RN_BF16) return RN_EUNSUPPORTED;
+    if (dtype != RN_BF16 && dtype != RN_F16) return RN_EUNSUPPORTED;
     if (workspace_bytes < rn_stem_wgrad_workspace_bytes(B, H, W)) return RN_EWORKSPACE;
     if (!rn::aligned(g, 16) || !rn::aligned(xp, 16) || !rn::aligned(workspace, 16)) return RN_EALIGN;
     StemWgradArgs a;
@@ -433,10 +438,11 @@ RN_API int rn_stem_conv_wgrad(const void *g, const void *xp, void *dw, int dtype
     a.tiles_x = (a.Wo + SW_STAGE - 1) / SW_STAGE; a.total_stages = B * a.Ho * a.tiles_x;
     const int wgs = stem_wgrad_grid(a.total_stages, &a.stages_per_wg);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)wgs), dim3(STEM_THREADS), 0, st, a);
+    if (dtype == RN_F16) hipLaunchKernelGGL(stem_wgrad_kernel<RN_F16>, dim3((unsigned)wgs), dim3(STEM_THREADS), 0, st, a);
+    else hipLaunchKernelGGL(stem_wgrad_kernel<RN_BF16>, dim3((unsigned)wgs), dim3(STEM_THREADS), 0, st, a);
     RN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3((64 * 7 * STEM_KROW + 15) / 16), dim3(256), 0, st, (const float *)workspace, wgs,
-                       (uint16_t *)dw);
+    if (dtype == RN_F16) hipLaunchKernelGGL(stem_wgrad_reduce_kernel<RN_F16>, dim3((64 * 7 * STEM_KROW + 15) / 16), dim3(256), 0, st, (const float *)workspace, wgs, (uint16_t *)dw);
+    else hipLaunchKernelGGL(stem_wgrad_reduce_kernel<RN_BF16>, dim3((64 * 7 * STEM_KROW + 15) / 16), dim3(256), 0, st, (const float *)workspace, wgs, (uint16_t *)dw);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

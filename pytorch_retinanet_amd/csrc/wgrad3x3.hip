@@ -19,7 +19,6 @@
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4v;
 
 constexpr int W3_THREADS = 512, W3_TEAM = 256;
@@ -44,6 +43,7 @@ struct W3Args {
     int tiles_x, tiles, subs_c, wgs_per_sub, tiles_per_team;
 };
 
+template <int DT>
 __global__ __launch_bounds__(W3_THREADS) void wgrad3x3_kernel(const W3Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(W3_THREADS) void wgrad3x3_kernel(const W3Args a)
     // two reads are issued one tap ahead of the four MFMAs that consume them.
     struct U2 { unsigned long long lo, hi; };
 #define W3_TR(dst, addr) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr))
-#define W3_FRAG(v) __builtin_bit_cast(bf16x8, U2{v[0], v[1]})
+#define W3_FRAG(v) __builtin_bit_cast(typename rn::mma<DT>::frag, U2{v[0], v[1]})
 #define W3_WAIT(N) asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); __builtin_amdgcn_sched_barrier(0);
 
     // Phases: the teams alternate -- in phase ph team (ph & 1) runs the MFMAs of its tile ph >> 1 while the other team issues the
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(W3_THREADS) void wgrad3x3_kernel(const W3Args a)
                 else { W3_WAIT(0) }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W3_FRAG(gf[i]), W3_FRAG(xf[t & 3]), acc[i][t], 0, 0, 0);
+                    acc[i][t] = rn::mma<DT>::m16(W3_FRAG(gf[i]), W3_FRAG(xf[t & 3]), acc[i][t]);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #undef W3_XREAD
@@ -203,6 +203,7 @@ __global__ __launch_bounds__(W3_THREADS) void wgrad3x3_kernel(const W3Args a)
 
 // dw[(n0 + n)][t][c0 + c] (bf16, [Cn][3][3][Cc]) = sum over the sub-problem's workgroups of partial[..][n][t][c].
 // Block = 32 float4 columns x 8 slices of the partials, combined through LDS in a fixed order.
+template <int DT>
 __global__ __launch_bounds__(256) void wgrad3x3_reduce_kernel(const float *__restrict__ partial, const int wgs_per_sub, const int subs_c,
                                                               const int Cc, uint16_t *__restrict__ dw)
 {
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_reduce_kernel(const float *__res
         const int e = i4 * 4, c = e & 63, tp = (e >> 6) % 9, n = e / (9 * 64);
         const int n0 = (sub / subs_c) * 64, c0 = (sub % subs_c) * 64;
         rn::u32x2 o;
-        o.x = rn::dt<RN_BF16>::pk(t.x, t.y); o.y = rn::dt<RN_BF16>::pk(t.z, t.w);
+        o.x = rn::dt<DT>::pk(t.x, t.y); o.y = rn::dt<DT>::pk(t.z, t.w);
         *(rn::u32x2 *)(dw + ((int64_t)(n0 + n) * 9 + tp) * Cc + c0 + c) = o;
     }
 }
@@ -256,7 +257,7 @@ RN_API int rn_conv3x3_wgrad_narrow(const void *g, const void *x, void *dw, int d
                                    const void *zero_page, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!g || !x || !dw || !workspace || !zero_page || N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cin <= 0) return RN_EINVAL;
-    if (dtype != RN_BF16 || Cout % 64 || Cin % 64) return RN_EUNSUPPORTED;
+    if ((dtype != RN_BF16 && dtype != RN_F16) || Cout % 64 || Cin % 64) return RN_EUNSUPPORTED;
     const int subs = (Cout / 64) * (Cin / 64);
     if (subs > 4096 || (int64_t)N * H * ((W + W3_PX - 1) / W3_PX) >= ((int64_t)1 << 30)) return RN_EUNSUPPORTED;
     if (workspace_bytes < rn_conv3x3_wgrad_narrow_workspace_bytes(Cout, Cin)) return RN_EWORKSPACE;
@@ -268,12 +269,16 @@ RN_API int rn_conv3x3_wgrad_narrow(const void *g, const void *x, void *dw, int d
     a.wgs_per_sub = w3_workgroups(subs);
     a.tiles_per_team = (a.tiles + 2 * a.wgs_per_sub - 1) / (2 * a.wgs_per_sub);
     hipStream_t st = (hipStream_t)stream;
-    static rn::DynLdsOptIn opt_in = {};
-    { const int rc = opt_in.ensure((const void *)wgrad3x3_kernel, W3_LDS); if (rc != RN_OK) return rc; }
-    hipLaunchKernelGGL(wgrad3x3_kernel, dim3((unsigned)(subs * a.wgs_per_sub)), dim3(W3_THREADS), W3_LDS, st, a);
-    RN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(wgrad3x3_reduce_kernel, dim3(W3_OUT / 4 / 32, (unsigned)subs), dim3(256), 0, st, (const float *)workspace, a.wgs_per_sub,
-                       a.subs_c, Cin, (uint16_t *)dw);
-    RN_LAUNCH_CHECK();
+#define W3_LAUNCH(DT)                                                                                                                  \
+    {   static rn::DynLdsOptIn opt_in = {};                                                                                            \
+        const int rc = opt_in.ensure((const void *)wgrad3x3_kernel<DT>, W3_LDS);                                                       \
+        if (rc != RN_OK) return rc;                                                                                                    \
+        hipLaunchKernelGGL(wgrad3x3_kernel<DT>, dim3((unsigned)(subs * a.wgs_per_sub)), dim3(W3_THREADS), W3_LDS, st, a);              \
+        RN_LAUNCH_CHECK();                                                                                                             \
+        hipLaunchKernelGGL(wgrad3x3_reduce_kernel<DT>, dim3(W3_OUT / 4 / 32, (unsigned)subs), dim3(256), 0, st, (const float *)workspace, \
+                           a.wgs_per_sub, a.subs_c, Cin, (uint16_t *)dw);                                                              \
+        RN_LAUNCH_CHECK(); }
+    if (dtype == RN_F16) W3_LAUNCH(RN_F16) else W3_LAUNCH(RN_BF16)
+#undef W3_LAUNCH
     return RN_OK;
 }

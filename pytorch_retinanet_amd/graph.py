@@ -119,7 +119,7 @@ def retinanet_stage_of(name: str) -> int:
 
 class CapturedTrainStep:
     def __init__(self, net, optimizer, ddp=None, amp_dtype: Optional[torch.dtype] = torch.bfloat16, eager_steps: int = 2,
-                 max_graphs: int = 4, enabled: bool = True, segmented: Optional[bool] = None):
+                 max_graphs: int = 4, enabled: bool = True, segmented: Optional[bool] = None, scaler=None):
         """``segmented`` (default: on whenever gradients are exchanged): the step with a gradient exchange as FOUR linear hipGraphs --
         forward + head / FPN backward | layer4, layer3 backward | layer2 .. stem backward | optimizer -- with the finished buckets'
         all-reduces issued EAGERLY on the process group's communication stream between the replays and the wait for them in
@@ -128,6 +128,12 @@ class CapturedTrainStep:
         (DESIGN.md section 6); why not eager: ~20 ms of host time per 25 ms step.  The backward pass is cut at C3 / C4 / C5
         (``backbone.StageCuts``) and run as separate autograd calls, so each segment's capture begins and ends on this thread."""
         self.net, self.optimizer, self.ddp = net, optimizer, ddp
+        # fp16 autocast: a torch.amp.GradScaler (the reference's precision=16 run is native AMP, demo.ipynb).  Its scale / growth
+        # tracker are device tensors and optim.MasterSGD takes grad_scale / found_inf on the device, so scale -> backward -> step ->
+        # update records into the graph like the rest of the step.  Single-process steps only.
+        self.scaler = scaler
+        if scaler is not None and ddp is not None:
+            raise ValueError("loss scaling is wired for the single-process step only")
         self.segmented = (ddp is not None) if segmented is None else (bool(segmented) and ddp is not None)
         if self.segmented:
             ddp.deferred = True
@@ -194,6 +200,12 @@ class CapturedTrainStep:
         with torch.autocast(dev_type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None, cache_enabled=False):
             losses = net(list(images), [dict(t) for t in targets])
             total = losses["classification_loss"] + losses["regression_loss"]
+        if self.scaler is not None:
+            self.scaler.scale(total).backward()
+            self.scaler.step(opt)
+            self.scaler.update()
+            return {"classification_loss": losses["classification_loss"].detach(), "regression_loss": losses["regression_loss"].detach(),
+                    "loss": total.detach()}
         total.backward()
         if ddp is not None:
             ddp.finish()
@@ -260,6 +272,15 @@ class CapturedTrainStep:
                 # anything else touches the device from this thread: torch.cuda.graph.__exit__ does this for the one-graph path, the
                 # hand-driven begin / mark pair has to do it itself.  Then the half-built segments and their pool are dropped.
                 if state["open"]:
+                    # the autograd engine may have pulled OTHER streams into the capture (an AccumulateGrad node created by an eager
+                    # step lives on the stream of that step: the engine makes that stream wait for the capturing one and joins it
+                    # back at the end of the pass -- which a failure in the middle of the pass skips).  Join what can be joined, or
+                    # the capture ends "unjoined" and that stream stays in capture mode.
+                    for other in {torch.cuda.default_stream(dev), torch.cuda.current_stream(dev)} - {side}:
+                        try:
+                            side.wait_stream(other)
+                        except Exception:            # noqa: BLE001
+                            pass
                     try:
                         state["g"].capture_end()
                     except Exception:                # noqa: BLE001 -- the capture is already invalid: ending it may raise again

@@ -130,8 +130,8 @@ class RetinaNetModel(_Base):
         opt_cls = load_obj(self.conf.optimizer.class_name)
         if getattr(opt_cls, "__name__", "") == "MasterSGD" and next(self.net.parameters()).is_cuda:
             # optimizer.class_name: pytorch_retinanet_amd.optim.MasterSGD -- SGD on fp32 masters, conv weights held in bf16
-            from .optim import use_bf16_conv_weights
-            use_bf16_conv_weights(self.net)
+            from .optim import use_16bit_conv_weights
+            use_16bit_conv_weights(self.net, getattr(self, "working_dtype", None) or torch.bfloat16)     # (SimpleTrainer sets it from its precision)
         self.optimizer = opt_cls(self.net.parameters(), **dict(self.conf.optimizer.params))
         sched = self.conf.scheduler
         if sched.class_name is None:
@@ -220,15 +220,21 @@ class SimpleTrainer:
         model.to(self.device)
         if self.channels_last:
             model.to(memory_format=torch.channels_last)
+        model.working_dtype = self.amp_dtype
         opt = model.configure_optimizers()
         optimizers, schedulers = (opt if isinstance(opt, tuple) else (opt, []))
         optimizer = optimizers[0]
         ddp = BucketedGradAllReduce(model.net) if dist.is_available() and dist.is_initialized() else None
+        # precision "16" = fp16 autocast WITH dynamic loss scaling, like the reference's native-AMP run (Lightning precision=16):
+        # fp16 gradients of a focal loss normalised by num_fg underflow without it
+        scaler = torch.amp.GradScaler("cuda") if (self.amp_dtype == torch.float16 and self.device.type == "cuda") else None
+        if scaler is not None and ddp is not None:
+            raise NotImplementedError("precision='16' (loss scaling) is single-process; use precision='bf16' under torch.distributed")
         stepper = None
         if (self.capture and self.device.type == "cuda" and ddp is None and type(model).training_step is RetinaNetModel.training_step
                 and not any(s["interval"] == "step" and "monitor" not in s for s in schedulers)):
             from .graph import CapturedTrainStep
-            stepper = CapturedTrainStep(model.net, optimizer, None, amp_dtype=self.amp_dtype)
+            stepper = CapturedTrainStep(model.net, optimizer, None, amp_dtype=self.amp_dtype, scaler=scaler)
         step = 0
         for epoch in range(self.max_epochs):
             model.train()
@@ -247,13 +253,18 @@ class SimpleTrainer:
                     with self._autocast():
                         out = model.training_step(batch, i)
                     ddp.zero_grad() if ddp else optimizer.zero_grad(set_to_none=False)
-                    out["loss"].backward()
-                    if ddp:
-                        ddp.finish()
-                    if ddp and type(optimizer).__name__ == "MasterSGD":
-                        optimizer.step(grads=ddp.grad_views())       # fp32 bucket views of the bf16 working copies
+                    if scaler is not None:
+                        scaler.scale(out["loss"]).backward()
+                        scaler.step(optimizer)
+                        scaler.update()
                     else:
-                        optimizer.step()
+                        out["loss"].backward()
+                        if ddp:
+                            ddp.finish()
+                        if ddp and type(optimizer).__name__ == "MasterSGD":
+                            optimizer.step(grads=ddp.grad_views())       # fp32 bucket views of the bf16 working copies
+                        else:
+                            optimizer.step()
                 step += 1
                 if step % self.log_every == 0:
                     self.log.info("epoch %d step %d loss %.4f", epoch, step, float(out["loss"]))

@@ -17,23 +17,29 @@ from typing import Dict, Iterable, List, Optional
 import torch
 from torch import Tensor, nn
 
-from ._lib import check, lib
+from ._lib import RN_BF16, RN_F16, check, lib
 from .norm import note_raw_write
 
 
-def use_bf16_conv_weights(model: nn.Module) -> int:
-    """Convert every 4-D fp32 parameter (conv weights) to bf16 in place, keeping the fp32 values as ``p.master``.
-    Returns the number of converted parameters.  BatchNorm parameters and biases stay fp32."""
+def use_16bit_conv_weights(model: nn.Module, dtype: torch.dtype = torch.bfloat16) -> int:
+    """Convert every 4-D fp32 parameter (conv weights) to ``dtype`` (bf16 or fp16: the autocast dtype of the run) in place, keeping the
+    fp32 values as ``p.master``.  Returns the number of converted parameters.  BatchNorm parameters and biases stay fp32."""
+    if dtype not in (torch.bfloat16, torch.float16):
+        raise TypeError(f"working copies are bf16 or fp16, not {dtype}")
     n = 0
     for p in model.parameters():
         if p.dim() == 4 and p.dtype == torch.float32 and p.is_cuda:
             master = p.data
-            p.data = master.to(torch.bfloat16)            # preserves the memory format (channels_last stays)
+            p.data = master.to(dtype)                     # preserves the memory format (channels_last stays)
             p.master = master
             if p.grad is not None:
                 p.grad = None
             n += 1
     return n
+
+
+def use_bf16_conv_weights(model: nn.Module) -> int:
+    return use_16bit_conv_weights(model, torch.bfloat16)
 
 
 def master_state_dict(model: nn.Module) -> Dict[str, Tensor]:
@@ -57,6 +63,10 @@ def load_master_state_dict(model: nn.Module, state: Dict[str, Tensor], strict: b
 
 
 class MasterSGD(torch.optim.Optimizer):
+    # torch.amp.GradScaler.step() hands such an optimizer `grad_scale` / `found_inf` (device scalars) instead of unscaling the gradients
+    # and reading found_inf back on the host: the kernel divides and skips on the device (rn_sgd_master_step_ex), nothing synchronises
+    _step_supports_amp_scaling = True
+
     def __init__(self, params: Iterable, lr: float = 1e-3, momentum: float = 0.0, dampening: float = 0.0,
                  weight_decay: float = 0.0, nesterov: bool = False):
         if nesterov and (momentum <= 0 or dampening != 0):
@@ -75,6 +85,7 @@ class MasterSGD(torch.optim.Optimizer):
         for group in self.param_groups:
             masters, moms, gptrs, p16s, ns = [], [], [], [], []
             grads16 = None
+            dt16 = None
             first = None
             keep: List[Tensor] = []
             for p in group["params"]:
@@ -89,7 +100,10 @@ class MasterSGD(torch.optim.Optimizer):
                     raise TypeError("MasterSGD handles CUDA fp32 parameters and bf16 parameters converted by use_bf16_conv_weights")
                 st = self.state[p]
                 if "momentum_buffer" not in st:
-                    st["momentum_buffer"] = torch.empty_like(w) if group["momentum"] != 0 else None
+                    # (under a GradScaler the very first step may be SKIPPED by found_inf: the buffer then has to hold zeros, with
+                    # which the next step's momentum * buf + g is torch's first-step buf = g; a fill kernel, not a memset: graph.py)
+                    amp = getattr(self, "found_inf", None) is not None
+                    st["momentum_buffer"] = (torch.empty_like(w).fill_(0) if amp else torch.empty_like(w)) if group["momentum"] != 0 else None
                     st["steps"] = 0
                 if first is None:
                     first = st["steps"] == 0
@@ -97,13 +111,17 @@ class MasterSGD(torch.optim.Optimizer):
                     raise RuntimeError("parameters of one group must have taken the same number of steps")
                 st["steps"] += 1
                 if has16:
-                    is16 = g.dtype == torch.bfloat16
+                    if dt16 is None:
+                        dt16 = p.dtype
+                    elif dt16 != p.dtype:
+                        raise RuntimeError("the 16-bit working copies of one group must share a dtype")
+                    is16 = g.dtype == p.dtype
                     if not is16 and g.dtype != torch.float32:
-                        raise TypeError(f"unsupported gradient dtype {g.dtype}")
+                        raise TypeError(f"unsupported gradient dtype {g.dtype} for a {p.dtype} working copy")
                     if grads16 is None:
                         grads16 = is16
                     elif grads16 != is16:
-                        raise RuntimeError("gradients of the bf16 parameters must be all bf16 or all fp32")
+                        raise RuntimeError("gradients of the 16-bit parameters must be all 16-bit or all fp32")
                 elif g.dtype != torch.float32:
                     raise TypeError("fp32 parameters need fp32 gradients")
                 # same memory order for master / momentum / gradient / bf16 copy: all carry the parameter's strides
@@ -117,12 +135,18 @@ class MasterSGD(torch.optim.Optimizer):
             if n == 0:
                 continue
             dev = group["params"][0].device
+            scale, found = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)       # (set by GradScaler.step around this call)
+            for t in (scale, found):
+                if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.numel() == 1):
+                    raise TypeError("grad_scale / found_inf must be CUDA fp32 scalars (torch.amp.GradScaler)")
             with torch.cuda.device(dev):
-                check(lib.rn_sgd_master_step((C.c_void_p * n)(*masters), (C.c_void_p * n)(*moms), (C.c_void_p * n)(*gptrs),
-                                             (C.c_void_p * n)(*p16s), (C.c_int64 * n)(*ns), n, int(bool(grads16)), float(group["lr"]),
-                                             float(group["momentum"]), float(group["dampening"]), float(group["weight_decay"]),
-                                             int(group["nesterov"]), int(bool(first)), torch.cuda.current_stream().cuda_stream),
-                      "rn_sgd_master_step")
+                check(lib.rn_sgd_master_step_ex((C.c_void_p * n)(*masters), (C.c_void_p * n)(*moms), (C.c_void_p * n)(*gptrs),
+                                                (C.c_void_p * n)(*p16s), (C.c_int64 * n)(*ns), n, int(bool(grads16)),
+                                                RN_F16 if dt16 == torch.float16 else RN_BF16, float(group["lr"]),
+                                                float(group["momentum"]), float(group["dampening"]), float(group["weight_decay"]),
+                                                int(group["nesterov"]), int(bool(first)), scale.data_ptr() if scale is not None else None,
+                                                found.data_ptr() if found is not None else None, torch.cuda.current_stream().cuda_stream),
+                      "rn_sgd_master_step_ex")
         from . import biasact
         biasact.invalidate_dgrad_weights()           # (the kernel wrote the parameters through raw pointers: no version counter moved)
         return loss

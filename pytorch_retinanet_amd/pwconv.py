@@ -29,7 +29,7 @@ import torch.nn.functional as F
 from torch import Tensor
 
 from . import norm
-from ._lib import (RN_BF16, RN_PW_EPI_BIAS, RN_PW_EPI_RELU_BWD, RN_PW_EPI_RESID, RN_PW_EPI_STATS, RN_PW_PRO_AFFINE_RELU, RN_PW_PRO_BN_BWD,
+from ._lib import (RN_BF16, RN_F16, RN_PW_EPI_BIAS, RN_PW_EPI_RELU_BWD, RN_PW_EPI_RESID, RN_PW_EPI_STATS, RN_PW_PRO_AFFINE_RELU, RN_PW_PRO_BN_BWD,
                    RnPwConv, RnPwEpilogue, RnPwPrologue, check, lib)
 from .ops import _timed
 
@@ -40,6 +40,8 @@ FUSED_BOTTLENECK = os.environ.get("RN_FUSED_BOTTLENECK", "1") != "0"      # 0: t
 FUSED_MAX_MID = int(os.environ.get("RN_FUSED_MAX_MID", "128"))
 DEFER_WGRAD_REDUCE = True      # a fused block sums the splits of its 1x1 weight gradients in one launch at the end of its backward
 _WG_WS: Dict[tuple, Tensor] = {}
+H16 = (torch.bfloat16, torch.float16)          # element types of csrc/pw.hip / stem.hip (the same kernels on v_mfma_*_bf16 / _f16)
+_DT16 = {torch.bfloat16: RN_BF16, torch.float16: RN_F16}
 PW_FLOP: Dict[str, float] = {}        # useful flop per call of the timed pw launches (bench.py)
 
 
@@ -53,7 +55,7 @@ def _desc(x: Tensor, n_out: int, taps: int, stride: int) -> Tuple[RnPwConv, Tupl
     pad = 1 if taps == 9 else 0
     k = 3 if taps == 9 else 1
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    return RnPwConv(Nimg * Ho * Wo, Cin, n_out, taps, stride, pad, Ho, Wo, H, W), (Nimg, n_out, Ho, Wo)
+    return RnPwConv(Nimg * Ho * Wo, Cin, n_out, taps, stride, pad, Ho, Wo, H, W, _DT16[x.dtype]), (Nimg, n_out, Ho, Wo)
 
 
 def _stream(dev: torch.device) -> int:
@@ -107,14 +109,14 @@ EVAL_1X1_FUSED = True
 
 
 def eval_conv1x1_ok(conv, x: Tensor, w: Tensor, residual: Optional[Tensor]) -> bool:
-    if not (EVAL_1X1_FUSED and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 4 and _cl(x) and _cl(w)):
+    if not (EVAL_1X1_FUSED and x.is_cuda and x.dtype in H16 and w.dtype == x.dtype and x.dim() == 4 and _cl(x) and _cl(w)):
         return False
     if conv.kernel_size != (1, 1) or conv.padding != (0, 0) or conv.dilation != (1, 1) or conv.groups != 1 or conv.stride not in ((1, 1), (2, 2)):
         return False
     Cout, Cin = int(w.shape[0]), int(w.shape[1])
     if Cin % 64 or Cout % 64 or x.shape[0] * x.shape[2] * x.shape[3] >= (1 << 31):
         return False
-    return residual is None or (residual.dtype == torch.bfloat16 and _cl(residual))
+    return residual is None or (residual.dtype in H16 and _cl(residual))
 
 
 def eval_conv1x1(conv, x: Tensor, w: Tensor, bias: Tensor, relu: bool, residual: Optional[Tensor]) -> Tensor:
@@ -174,9 +176,10 @@ def pw_wgrad_flush(defer: list) -> None:
     if not defer:
         return
     n = len(defer)
-    check(lib.rn_pw_wgrad_reduce_many((C.c_void_p * n)(*[e[0].data_ptr() for e in defer]), (C.c_int * n)(*[e[1] for e in defer]),
-                                      (C.c_int64 * n)(*[e[2] for e in defer]), (C.c_void_p * n)(*[e[3].data_ptr() for e in defer]), n,
-                                      _stream(defer[0][3].device)), "rn_pw_wgrad_reduce_many")
+    assert all(e[3].dtype == defer[0][3].dtype for e in defer)
+    check(lib.rn_pw_wgrad_reduce_many_dt((C.c_void_p * n)(*[e[0].data_ptr() for e in defer]), (C.c_int * n)(*[e[1] for e in defer]),
+                                         (C.c_int64 * n)(*[e[2] for e in defer]), (C.c_void_p * n)(*[e[3].data_ptr() for e in defer]), n,
+                                         _DT16[defer[0][3].dtype], _stream(defer[0][3].device)), "rn_pw_wgrad_reduce_many_dt")
     defer.clear()
 
 
@@ -207,7 +210,7 @@ def bn_stats(x: Tensor, bn) -> Tensor:
     sp = stats.data_ptr()
     wp, wn = norm._workspace(dev, st, Cc)
     rm, rv, nbt = _bn_buffers(bn)
-    check(lib.rn_bn_stats(x.data_ptr(), RN_BF16, M, Cc, bn.weight.data_ptr(), bn.bias.data_ptr(), rm, rv, nbt, bn.momentum, bn.eps,
+    check(lib.rn_bn_stats(x.data_ptr(), _DT16[x.dtype], M, Cc, bn.weight.data_ptr(), bn.bias.data_ptr(), rm, rv, nbt, bn.momentum, bn.eps,
                           sp, sp + 4 * Cc, sp + 8 * Cc, wp, wn, st), "rn_bn_stats")
     norm.note_raw_write()
     return stats
@@ -222,11 +225,11 @@ def bn_apply(x: Tensor, stats: Tensor, relu: bool, residual: Optional[Tensor] = 
     bits = torch.empty((M * Cc // 8,), dtype=torch.uint8, device=x.device) if want_bits else None
     if res_stats is not None:
         assert relu and residual is not None
-        check(lib.rn_bn_apply_res_affine(x.data_ptr(), residual.data_ptr(), res_stats.data_ptr() + 8 * Cc, y.data_ptr(), RN_BF16, M, Cc,
+        check(lib.rn_bn_apply_res_affine(x.data_ptr(), residual.data_ptr(), res_stats.data_ptr() + 8 * Cc, y.data_ptr(), _DT16[x.dtype], M, Cc,
                                          stats.data_ptr() + 8 * Cc, bits.data_ptr() if bits is not None else 0, _stream(x.device)),
               "rn_bn_apply_res_affine")
         return y, bits
-    check(lib.rn_bn_apply(x.data_ptr(), residual.data_ptr() if residual is not None else 0, y.data_ptr(), RN_BF16, M, Cc,
+    check(lib.rn_bn_apply(x.data_ptr(), residual.data_ptr() if residual is not None else 0, y.data_ptr(), _DT16[x.dtype], M, Cc,
                           stats.data_ptr() + 8 * Cc, int(relu), bits.data_ptr() if bits is not None else 0, _stream(x.device)), "rn_bn_apply")
     return y, bits
 
@@ -289,7 +292,7 @@ class _BottleneckFn(torch.autograd.Function):
         gr3 = torch.empty((5 * C4,), dtype=torch.float32, device=dev)            # dgamma | dbeta | a | k0 | k1
         wp, wn = norm._workspace(dev, st, C4)
         p3 = st3.data_ptr()
-        check(lib.rn_bn_bwd_reduce(g_out.data_ptr(), bits.data_ptr(), z3.data_ptr(), RN_BF16, M1, C4, g3.data_ptr(), p3, p3 + 4 * C4, 0, 1, 2,
+        check(lib.rn_bn_bwd_reduce(g_out.data_ptr(), bits.data_ptr(), z3.data_ptr(), _DT16[x.dtype], M1, C4, g3.data_ptr(), p3, p3 + 4 * C4, 0, 1, 2,
                                    gr3.data_ptr(), gr3.data_ptr() + 4 * C4, gr3.data_ptr() + 8 * C4, wp, wn, st), "rn_bn_bwd_reduce")
         pro3 = bn_bwd(gr3[2 * C4:], z3, relu_mode=3, bits=bits)
         # conv3 data gradient with bn3-backward in the operand load; epilogue: ReLU mask of a2 + the two bn2-backward sums
@@ -315,7 +318,7 @@ class _BottleneckFn(torch.autograd.Function):
         check(lib.rn_bn_bwd_finalize(part2.data_ptr(), nb2, M1, Cm, g2.data_ptr(), p2, p2 + 4 * Cm, 1, gr2.data_ptr(), gr2.data_ptr() + 4 * Cm,
                                      gr2.data_ptr() + 8 * Cm, st), "rn_bn_bwd_finalize")
         dz2 = torch.empty_like(z2)
-        check(lib.rn_bn_bwd_apply(dy2.data_ptr(), 0, z2.data_ptr(), dz2.data_ptr(), 0, RN_BF16, M1, Cm, gr2.data_ptr() + 8 * Cm, 0, 0, st),
+        check(lib.rn_bn_bwd_apply(dy2.data_ptr(), 0, z2.data_ptr(), dz2.data_ptr(), 0, _DT16[x.dtype], M1, Cm, gr2.data_ptr() + 8 * Cm, 0, 0, st),
               "rn_bn_bwd_apply")
         from . import biasact
         if biasact.dgrad_as_fwd_ok(w2, blk.conv2.stride, dz2) and tuple(blk.conv2.padding) == (1, 1):
@@ -332,7 +335,7 @@ class _BottleneckFn(torch.autograd.Function):
         dz1 = torch.empty_like(z1)
         p1 = st1.data_ptr()
         wp, wn = norm._workspace(dev, st, Cm)
-        check(lib.rn_bn_act_backward(da1.data_ptr(), 0, z1.data_ptr(), dz1.data_ptr(), 0, RN_BF16, M0, Cm, g1.data_ptr(), p1, p1 + 4 * Cm,
+        check(lib.rn_bn_act_backward(da1.data_ptr(), 0, z1.data_ptr(), dz1.data_ptr(), 0, _DT16[x.dtype], M0, Cm, g1.data_ptr(), p1, p1 + 4 * Cm,
                                      p1 + 8 * Cm, 1, 1, gr1.data_ptr(), gr1.data_ptr() + 4 * Cm, gr1.data_ptr() + 8 * Cm, wp, wn, st),
               "rn_bn_act_backward")
         dwd = dgd = dbd = None
@@ -346,7 +349,7 @@ class _BottleneckFn(torch.autograd.Function):
             dzd = torch.empty_like(zd)
             pd = std.data_ptr()
             wp, wn = norm._workspace(dev, st, C4)
-            check(lib.rn_bn_act_backward(g_out.data_ptr(), bits.data_ptr(), zd.data_ptr(), dzd.data_ptr(), 0, RN_BF16, M1, C4, gd.data_ptr(), pd,
+            check(lib.rn_bn_act_backward(g_out.data_ptr(), bits.data_ptr(), zd.data_ptr(), dzd.data_ptr(), 0, _DT16[x.dtype], M1, C4, gd.data_ptr(), pd,
                                          pd + 4 * C4, pd + 8 * C4, 1, 2, grd.data_ptr(), grd.data_ptr() + 4 * C4, grd.data_ptr() + 8 * C4, wp,
                                          wn, st), "rn_bn_act_backward")
             dgd, dbd = grd[:C4], grd[C4:2 * C4]
@@ -369,7 +372,7 @@ class _BottleneckFn(torch.autograd.Function):
 
 
 def bottleneck_fusable(blk, x: Tensor) -> bool:
-    if not (FUSED_BOTTLENECK and x.is_cuda and x.dtype == torch.bfloat16 and _cl(x) and torch.is_grad_enabled()):
+    if not (FUSED_BOTTLENECK and x.is_cuda and x.dtype in H16 and _cl(x) and torch.is_grad_enabled()):
         return False
     bns = [blk.bn1, blk.bn2, blk.bn3] + ([blk.downsample[1]] if blk.downsample is not None else [])
     convs = [blk.conv1, blk.conv2, blk.conv3] + ([blk.downsample[0]] if blk.downsample is not None else [])
@@ -377,7 +380,7 @@ def bottleneck_fusable(blk, x: Tensor) -> bool:
         if not (bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None and bn.weight.dtype == torch.float32):
             return False
     for cv in convs:
-        if not (cv.weight.dtype == torch.bfloat16 and cv.bias is None and cv.groups == 1 and cv.in_channels % 64 == 0
+        if not (cv.weight.dtype in H16 and cv.bias is None and cv.groups == 1 and cv.in_channels % 64 == 0
                 and cv.out_channels % 64 == 0 and cv.dilation == (1, 1)):
             return False
     if blk.conv2.out_channels > FUSED_MAX_MID:
@@ -564,7 +567,7 @@ def conv1x1(conv, x: Tensor) -> Tensor:
     """``conv(x)`` for a 1x1 / stride-1 ``nn.Conv2d`` on bf16 channels-last activations with every product on the fastest of
     MIOpen / hipBLASLt / csrc/pw.hip (``_Conv1x1``); anything else is ``conv(x)``."""
     w = conv.weight
-    if (MM_1X1 and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and _cl(x) and conv.kernel_size == (1, 1)
+    if (MM_1X1 and x.is_cuda and x.dtype in H16 and w.dtype == x.dtype and _cl(x) and conv.kernel_size == (1, 1)
             and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and conv.in_channels % 64 == 0
             and conv.out_channels % 64 == 0 and torch.is_grad_enabled() and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 24)):
         join, receiver = _join_of(x)
@@ -572,7 +575,7 @@ def conv1x1(conv, x: Tensor) -> Tensor:
         if receiver:
             join.recv_node = y.grad_fn
         return y
-    if (MM_1X1 and JOIN_GRADS and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and _cl(x) and conv.kernel_size == (1, 1)
+    if (MM_1X1 and JOIN_GRADS and x.is_cuda and x.dtype in H16 and w.dtype == x.dtype and _cl(x) and conv.kernel_size == (1, 1)
             and conv.stride == (2, 2) and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is None and conv.in_channels % 64 == 0
             and conv.out_channels % 64 == 0 and torch.is_grad_enabled() and x.requires_grad and getattr(x, "_rn_join", None) is not None
             and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 24)):
@@ -592,9 +595,9 @@ _STEM_WS: Dict[tuple, Tensor] = {}
 
 
 def stem_fusable(conv, bn, x: Tensor) -> bool:
-    return (FUSED_STEM and x.is_cuda and x.dtype == torch.bfloat16 and _cl(x) and torch.is_grad_enabled() and x.shape[1] == 3 and
+    return (FUSED_STEM and x.is_cuda and x.dtype in H16 and _cl(x) and torch.is_grad_enabled() and x.shape[1] == 3 and
             conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.dilation == (1, 1) and
-            conv.groups == 1 and conv.bias is None and conv.out_channels == 64 and conv.weight.dtype == torch.bfloat16 and
+            conv.groups == 1 and conv.bias is None and conv.out_channels == 64 and conv.weight.dtype in H16 and
             bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None and bn.weight.dtype == torch.float32 and
             x.shape[0] * (x.shape[2] + 6) * (x.shape[3] + 8) < (1 << 31))
 
@@ -612,22 +615,22 @@ class _StemFn(torch.autograd.Function):
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         # xp: the zero-bordered NHWC4 copy of the image; the weight gradient reads it again, so it belongs to this call
         ws = (torch.empty((lib.rn_stem_padded_bytes(B, H, W),), dtype=torch.uint8, device=dev),
-              torch.empty((64 * 7 * 32,), dtype=torch.bfloat16, device=dev))
+              torch.empty((64 * 7 * 32,), dtype=x.dtype, device=dev))
         wc = w if _cl(w) else w.contiguous(memory_format=torch.channels_last)
-        z = torch.empty((B, 64, Ho, Wo), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+        z = torch.empty((B, 64, Ho, Wo), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
         nb = lib.rn_stem_partial_rows(B, H, W)
         partial = torch.empty((nb * 2 * 64,), dtype=torch.float32, device=dev)
         PW_FLOP["stem_fwd"] = 2.0 * B * Ho * Wo * 64 * 147
         with _timed("stem_fwd", dev):
             check(lib.rn_stem_conv_forward(x.data_ptr(), wc.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), z.data_ptr(), partial.data_ptr(),
-                                           RN_BF16, B, H, W, st), "rn_stem_conv_forward")
+                                           _DT16[x.dtype], B, H, W, st), "rn_stem_conv_forward")
         stats = bn_finalize(partial, nb, B * Ho * Wo, bn)
         if pool:
             # BatchNorm apply + ReLU inside the 3x3 / stride-2 max pooling: the 275 MB activation between them is never written
             Hq, Wq = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
-            out = torch.empty((B, 64, Hq, Wq), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+            out = torch.empty((B, 64, Hq, Wq), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
             arg = torch.empty(out.shape, dtype=torch.uint8, device=dev, memory_format=torch.channels_last)
-            check(lib.rn_bn_relu_maxpool3x3s2_forward(z.data_ptr(), stats.data_ptr() + 8 * 64, out.data_ptr(), arg.data_ptr(), RN_BF16, B, Ho, Wo,
+            check(lib.rn_bn_relu_maxpool3x3s2_forward(z.data_ptr(), stats.data_ptr() + 8 * 64, out.data_ptr(), arg.data_ptr(), _DT16[x.dtype], B, Ho, Wo,
                                                       64, st), "rn_bn_relu_maxpool3x3s2_forward")
         else:
             out, _ = bn_apply(z, stats, relu=True)
@@ -643,17 +646,17 @@ class _StemFn(torch.autograd.Function):
         st = _stream(dev)
         Cc = 64
         M = z.shape[0] * z.shape[2] * z.shape[3]
-        if not (da.dtype == torch.bfloat16 and _cl(da)):
-            da = da.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        if not (da.dtype == z.dtype and _cl(da)):
+            da = da.to(z.dtype).contiguous(memory_format=torch.channels_last)
         if ctx.pool:                                                 # `da` is the pooled gradient: back through the arg-max codes first
             dpool, da = da, torch.empty_like(z)
-            check(lib.rn_maxpool3x3s2_backward(arg.data_ptr(), dpool.data_ptr(), da.data_ptr(), RN_BF16, z.shape[0], z.shape[2], z.shape[3], Cc, st),
+            check(lib.rn_maxpool3x3s2_backward(arg.data_ptr(), dpool.data_ptr(), da.data_ptr(), _DT16[z.dtype], z.shape[0], z.shape[2], z.shape[3], Cc, st),
                   "rn_maxpool3x3s2_backward")
         gr = torch.empty((5 * Cc,), dtype=torch.float32, device=dev)
         dz = torch.empty_like(z)
         sp = stats.data_ptr()
         wp, wn = norm._workspace(dev, st, Cc)
-        check(lib.rn_bn_act_backward(da.data_ptr(), 0, z.data_ptr(), dz.data_ptr(), 0, RN_BF16, M, Cc, gamma.data_ptr(), sp, sp + 4 * Cc,
+        check(lib.rn_bn_act_backward(da.data_ptr(), 0, z.data_ptr(), dz.data_ptr(), 0, _DT16[z.dtype], M, Cc, gamma.data_ptr(), sp, sp + 4 * Cc,
                                      sp + 8 * Cc, 1, 1, gr.data_ptr(), gr.data_ptr() + 4 * Cc, gr.data_ptr() + 8 * Cc, wp, wn, st),
               "rn_bn_act_backward")
         B, _, H, W = x.shape
@@ -666,7 +669,7 @@ class _StemFn(torch.autograd.Function):
             dw = torch.empty_like(w)
             PW_FLOP["stem_wgrad"] = 2.0 * M * 64 * 147
             with _timed("stem_wgrad", dev):
-                check(lib.rn_stem_conv_wgrad(dz.data_ptr(), xp.data_ptr(), dw.data_ptr(), RN_BF16, B, H, W, wsb.data_ptr(), wsb.numel(), st),
+                check(lib.rn_stem_conv_wgrad(dz.data_ptr(), xp.data_ptr(), dw.data_ptr(), _DT16[z.dtype], B, H, W, wsb.data_ptr(), wsb.numel(), st),
                       "rn_stem_conv_wgrad")
         else:
             dw = torch.ops.aten.convolution_backward(dz, x, w, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False])[1]
@@ -680,7 +683,7 @@ STEM_EVAL = True
 
 
 def stem_eval_ok(conv, pool, x: Tensor, w: Tensor) -> bool:
-    return (STEM_EVAL and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 4 and _cl(x) and x.shape[1] == 3 and
+    return (STEM_EVAL and x.is_cuda and x.dtype in H16 and w.dtype == x.dtype and x.dim() == 4 and _cl(x) and x.shape[1] == 3 and
             conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.dilation == (1, 1) and conv.groups == 1 and
             conv.out_channels == 64 and pool is not None and pool.kernel_size == 3 and pool.stride == 2 and pool.padding == 1 and
             pool.dilation == 1 and not pool.ceil_mode and not pool.return_indices and
@@ -694,19 +697,19 @@ def stem_eval(x: Tensor, w: Tensor, bias: Tensor) -> Tensor:
     st = _stream(dev)
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     xp = torch.empty((lib.rn_stem_padded_bytes(B, H, W),), dtype=torch.uint8, device=dev)
-    wk = torch.empty((64 * 7 * 32,), dtype=torch.bfloat16, device=dev)
+    wk = torch.empty((64 * 7 * 32,), dtype=x.dtype, device=dev)
     wc = w if _cl(w) else w.contiguous(memory_format=torch.channels_last)
-    z = torch.empty((B, 64, Ho, Wo), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+    z = torch.empty((B, 64, Ho, Wo), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
     partial = torch.empty((lib.rn_stem_partial_rows(B, H, W) * 2 * 64,), dtype=torch.float32, device=dev)      # (the kernel's statistics: unused here)
     PW_FLOP["stem_fwd"] = 2.0 * B * Ho * Wo * 64 * 147
     with _timed("stem_fwd", dev):
-        check(lib.rn_stem_conv_forward(x.data_ptr(), wc.data_ptr(), xp.data_ptr(), wk.data_ptr(), z.data_ptr(), partial.data_ptr(), RN_BF16, B, H, W, st),
+        check(lib.rn_stem_conv_forward(x.data_ptr(), wc.data_ptr(), xp.data_ptr(), wk.data_ptr(), z.data_ptr(), partial.data_ptr(), _DT16[x.dtype], B, H, W, st),
               "rn_stem_conv_forward")
     coef = torch.cat([torch.ones(64, dtype=torch.float32, device=dev), bias.float()])
     Hq, Wq = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
-    out = torch.empty((B, 64, Hq, Wq), dtype=torch.bfloat16, device=dev, memory_format=torch.channels_last)
+    out = torch.empty((B, 64, Hq, Wq), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
     arg = torch.empty(out.shape, dtype=torch.uint8, device=dev, memory_format=torch.channels_last)
-    check(lib.rn_bn_relu_maxpool3x3s2_forward(z.data_ptr(), coef.data_ptr(), out.data_ptr(), arg.data_ptr(), RN_BF16, B, Ho, Wo, 64, st),
+    check(lib.rn_bn_relu_maxpool3x3s2_forward(z.data_ptr(), coef.data_ptr(), out.data_ptr(), arg.data_ptr(), _DT16[x.dtype], B, Ho, Wo, 64, st),
           "rn_bn_relu_maxpool3x3s2_forward")
     return out
 

@@ -159,6 +159,53 @@ def test_predict_matches_the_reference_fp32(golden):
 
 
 @pytest.mark.gpu
+def test_forward_and_predict_fp16_autocast(golden):
+    """BASELINE configs[4] / the reference's own published run (native fp16 AMP, demo.ipynb precision=16): fp16 autocast takes the SAME
+    hand-written MFMA kernels as bf16 (csrc/conv.hip, pw.hip, stem.hip, narrow3x3.hip, wgrad3x3.hip instantiated on
+    v_mfma_f32_*_f16) -- asserted through the launch tags -- and holds the fp32 reference: losses within 2e-2 (measured far
+    inside: fp16 carries 3 more mantissa bits than bf16), detections at the bf16 test's bar or better, gradients finite."""
+    from pytorch_retinanet_amd import biasact, pwconv
+    from pytorch_retinanet_amd.optim import use_16bit_conv_weights
+    g = golden("e2e.npz")
+    net = _model(g, DEV).train()
+    assert use_16bit_conv_weights(net, torch.float16) > 0
+    images, targets = _inputs(g, DEV)
+    biasact.MFMA_FLOP.clear(); pwconv.PW_FLOP.clear()
+    with torch.autocast("cuda", dtype=torch.float16):
+        out = net(images, targets)
+        total = out["classification_loss"] + out["regression_loss"]
+    got = np.array([float(out["classification_loss"].detach()), float(out["regression_loss"].detach())])
+    np.testing.assert_allclose(got, g["train_losses"], rtol=2e-2)
+    (total * 1024.0).backward()                                            # (a static loss scale: what GradScaler does, without its bookkeeping)
+    ran = set(biasact.MFMA_FLOP) | set(pwconv.PW_FLOP)
+    for tag in ("mfma_tower_fwd_x2", "mfma_cls_output_fwd", "mfma_box_output_fwd", "mfma_tower_dgrad_x2", "mfma_cls_output_wgrad", "stem_fwd", "stem_wgrad"):
+        assert tag in ran, (tag, sorted(ran))
+    named = dict(net.named_parameters())
+    bad = [k for k, p in named.items() if p.grad is None or not bool(torch.isfinite(p.grad.float()).all())]
+    assert not bad, bad[:5]
+    # gradient norms against the reference's (fp32) at 5e-2: fp16 activations + fp16 weight gradients
+    for k, norm in zip(g["grad_all_keys"], g["grad_all_norms"]):
+        gr = named[str(k)].grad.double() / 1024.0
+        assert abs(float(gr.norm()) - norm) <= 5e-2 * norm + 1e-7, (str(k), float(gr.norm()), float(norm))
+    net = _model(g, DEV).eval()
+    with torch.autocast("cuda", dtype=torch.float16):
+        dets = net.predict(images)
+    n_top = 0
+    for b, d in enumerate(dets):
+        ref = {"boxes": g[f"det_boxes{b}"], "scores": g[f"det_scores{b}"], "labels": g[f"det_labels{b}"]}
+        got = {k: v.float().cpu().numpy() if v.dtype != torch.int64 else v.cpu().numpy() for k, v in d.items()}
+        top = ref["scores"] >= 0.06
+        n_top += int(top.sum())
+        if top.any():
+            iou = _iou(ref["boxes"][top], got["boxes"])
+            same = ref["labels"][top][:, None] == got["labels"][None, :]
+            near = np.abs(ref["scores"][top][:, None] - got["scores"][None, :]) <= 5e-3
+            assert ((iou >= 0.9) & same & near).any(1).mean() >= 0.85, b
+            assert np.median(np.where(same, iou, 0.0).max(1)) >= 0.97, b
+    assert n_top > 0
+
+
+@pytest.mark.gpu
 def test_forward_and_predict_bf16_autocast(golden):
     """The headline numeric configuration (bf16 autocast, MFMA towers, fp32 masters): losses within 2e-2 of the fp32
     reference; detections: >= 85 % of the reference's confident boxes have a same-label partner at IoU >= 0.9 with a score

@@ -25,8 +25,8 @@ import synth
 DEV = "cuda:0"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # worst-parameter bounds on (|norm - ref| / ref, |proj - ref| / ref norm, |sample - ref| / rms of the reference delta)
-_BOUNDS = {"32": (1e-2, 2e-2, 1e-1), "bf16": (0.25, 0.25, 1.5)}
-_LOSS_RTOL = {"32": 1e-3, "bf16": 2e-2}
+_BOUNDS = {"32": (1e-2, 2e-2, 1e-1), "bf16": (0.25, 0.25, 1.5), "16": (0.25, 0.25, 1.5)}
+_LOSS_RTOL = {"32": 1e-3, "bf16": 2e-2, "16": 2e-2}
 
 
 def _fixture():
@@ -145,26 +145,31 @@ def test_fixture_is_current_with_the_reference():
 
 def _run_single(kind, precision, captured):
     from pytorch_retinanet_amd.graph import CapturedTrainStep
-    from pytorch_retinanet_amd.optim import MasterSGD, use_bf16_conv_weights
+    from pytorch_retinanet_amd.optim import MasterSGD, use_16bit_conv_weights
     net = build_model(DEV, kind)
-    bf16 = precision == "bf16"
-    if bf16:
-        use_bf16_conv_weights(net)
+    amp = {"32": None, "bf16": torch.bfloat16, "16": torch.float16}[precision]
+    if amp is not None:
+        use_16bit_conv_weights(net, amp)
     opt = MasterSGD(net.parameters(), **synth.TRAJ_OPT)
     initial, buf0 = masters(net), buffers(net)
-    step = CapturedTrainStep(net, opt, amp_dtype=torch.bfloat16 if bf16 else None, eager_steps=2, enabled=captured)
+    # fp16: dynamic loss scaling like the reference's precision=16 run; a start value that needs no back-off on this model, so that
+    # all five steps are real steps (a skipped step would be a different trajectory) -- checked below
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=10 ** 6) if precision == "16" else None
+    step = CapturedTrainStep(net, opt, amp_dtype=amp, eager_steps=2, enabled=captured, scaler=scaler)
     losses = []
     for s in range(synth.TRAJ_STEPS):
         out = step(*batch(kind, s, DEV))
         losses.append([float(out["classification_loss"]), float(out["regression_loss"])])
     torch.cuda.synchronize()
     assert step.replays == (synth.TRAJ_STEPS - 2 if captured else 0) and step.captures == int(captured)
+    if scaler is not None:
+        assert float(scaler.get_scale()) == 1024.0, "a step was skipped (found_inf): the loss scale backed off"
     return losses, initial, masters(net), buf0, buffers(net)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["live", "frozen"])
-@pytest.mark.parametrize("precision", ["32", "bf16"])
+@pytest.mark.parametrize("precision", ["32", "bf16", "16"])
 @pytest.mark.parametrize("captured", [False, True], ids=["eager", "captured"])
 def test_five_steps_reproduce_the_reference_trajectory(kind, precision, captured):
     g = _fixture()
