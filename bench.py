@@ -68,6 +68,14 @@ def parse():
     ap.add_argument("--predict-size", type=int, default=1333)
     ap.add_argument("--predict-dtype", default="bf16", choices=["bf16", "fp16"], help="autocast dtype of the predict line (bf16: the head runs on "
                     "the hand-written MFMA kernels; fp16: MIOpen convolutions, same detect chain)")
+    ap.add_argument("--amp", default="bf16", choices=["bf16", "fp16"], help="autocast dtype of the train step.  fp16 = BASELINE configs[4] / the reference's own "
+                    "published run (native AMP, precision=16): the same MFMA kernels on v_mfma_*_f16, fp16 working copies of the conv weights, "
+                    "torch.amp.GradScaler with optim.MasterSGD unscaling / skipping on the device; use --gt 500 for configs[4]'s GT count")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend of the gradient exchange.  gloo: the launch path of "
+                    "the N-GPU run (torch.distributed.run spawn before any GPU call, per-rank MIOpen db, bucket hooks, segmented graphs, rank-0 JSON with "
+                    "the MAX-reduced time) on a box that cannot run RCCL with N ranks -- e.g. with --share-gpu")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (RCCL refuses two ranks on one device: needs --backend gloo); "
+                    "the line then reports launch-path correctness, its images/sec is N ranks time-slicing one GPU")
     ap.add_argument("--timing-steps", type=int, default=5, help="eager steps run AFTER the timed region with HIP events around the hand-written kernels (per-kernel figures of the JSON line)")
     return ap.parse_args()
 
@@ -258,6 +266,12 @@ def cpu_train_step_baseline(args):
     import pytorch_retinanet_amd as P
     oracle.build()
     torch.manual_seed(0)
+    amp_dtype = torch.float16 if args.amp == "fp16" else torch.bfloat16
+    # fp16: dynamic loss scaling like the reference's precision=16 run; the scale, the growth tracker, the unscale and the skip all
+    # live on the device (optim.MasterSGD._step_supports_amp_scaling), so the step captures like the bf16 one
+    scaler = torch.amp.GradScaler("cuda", init_scale=4096.0) if args.amp == "fp16" else None
+    if scaler is not None and (world > 1 or args.force_ddp or args.torch_sgd):
+        raise SystemExit("bench.py --amp fp16 is the single-GPU MasterSGD line (loss scaling is not wired through the gradient exchange)")
     net = P.Retinanet(num_classes=90, backbone_kind=args.backbone, pretrained=False, min_size=800, max_size=1333).train()
     opt = torch.optim.SGD(net.parameters(), lr=1e-3, weight_decay=1e-3, momentum=0.9)
     rng = np.random.default_rng(0)
@@ -483,12 +497,19 @@ def main():
         os.dup2(2, 1)                            # only rank 0 owns stdout (see the end of main)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the dense-head path)")
+    if args.share_gpu:
+        if args.backend != "gloo":
+            raise SystemExit("bench.py --share-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or args.force_ddp:
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     if args.gpus != world or (dist.is_initialized() and dist.get_world_size() != args.gpus):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
@@ -516,13 +537,19 @@ def main():
         print(json.dumps(line), flush=True)
         return
     torch.manual_seed(0)
+    amp_dtype = torch.float16 if args.amp == "fp16" else torch.bfloat16
+    # fp16: dynamic loss scaling like the reference's precision=16 run; the scale, the growth tracker, the unscale and the skip all
+    # live on the device (optim.MasterSGD._step_supports_amp_scaling), so the step captures like the bf16 one
+    scaler = torch.amp.GradScaler("cuda", init_scale=4096.0) if args.amp == "fp16" else None
+    if scaler is not None and (world > 1 or args.force_ddp or args.torch_sgd):
+        raise SystemExit("bench.py --amp fp16 is the single-GPU MasterSGD line (loss scaling is not wired through the gradient exchange)")
     net = P.Retinanet(num_classes=90, backbone_kind=args.backbone, pretrained=False, min_size=800, max_size=1333)
     net = net.to(device).to(memory_format=torch.channels_last).train()
     if args.torch_sgd:
         optimizer = torch.optim.SGD(net.parameters(), lr=1e-3, weight_decay=1e-3, momentum=0.9)   # hparams.yaml:63-68
-    else:   # the same SGD on fp32 masters; conv weights live in bf16 (what autocast would feed the convs anyway)
-        from pytorch_retinanet_amd.optim import MasterSGD, use_bf16_conv_weights
-        use_bf16_conv_weights(net)
+    else:   # the same SGD on fp32 masters; conv weights live in the autocast dtype (what autocast would feed the convs anyway)
+        from pytorch_retinanet_amd.optim import MasterSGD, use_16bit_conv_weights
+        use_16bit_conv_weights(net, amp_dtype)
         optimizer = MasterSGD(net.parameters(), lr=1e-3, weight_decay=1e-3, momentum=0.9)
     from pytorch_retinanet_amd.graph import CapturedTrainStep, retinanet_stage_of
     ddp_mode = "onegraph" if args.ddp_graph else args.ddp_mode
@@ -537,8 +564,8 @@ def main():
     # turn the collectives into forked graph branches, which ROCm replays slower than Python enqueues the same kernels (world 1, same
     # box, round 3: 279 captured / 289 eager / 302 without the exchange), and eager steps cost ~20 ms of host time each.
     use_graph = not args.no_graph and (ddp is None or ddp_mode != "eager")
-    stepper = CapturedTrainStep(net, optimizer, ddp, amp_dtype=torch.bfloat16, eager_steps=2, enabled=use_graph,
-                                segmented=(ddp is not None and ddp_mode == "segmented"))
+    stepper = CapturedTrainStep(net, optimizer, ddp, amp_dtype=amp_dtype, eager_steps=2, enabled=use_graph,
+                                segmented=(ddp is not None and ddp_mode == "segmented"), scaler=scaler)
     n_warm = max(args.warmup, 3)               # (MIOpen's find, the caches and -- when capturing -- the capture itself stay out of the timed region)
     for _ in range(n_warm):
         stepper(images, targets)
@@ -605,7 +632,7 @@ def main():
                 "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": round(k3_ms, 4) if k3_ms else None,
                 "streamed_bytes_per_launch": streamed, "classes_streamed": K_run,
                 "call_ms_with_finalize": round(kms["loss_fwd_bwd"], 4) if "loss_fwd_bwd" in kms else None,
-                "other_kernels_ms": {k: round(v, 4) for k, v in kms.items() if k in ("transform_batch", "iou_match")}}
+                "other_kernels_ms": {k: round(v, 4) for k, v in kms.items() if k in ("transform_batch", "iou_match", "gt_pack")}}
         # K2 (iou_match): one anchor set shared by the batch -> the anchors are read once per launch, so the bytes that can
         # reach HBM are A*16 + B*(T*16 + A*8); SURVEY 8d's per-image figure (anchors counted per image) is beside it
         k2_ms = kms.get("iou_match")
@@ -618,6 +645,17 @@ def main():
             "unique_bytes_per_launch": k2_unique, "survey_8d_bytes_per_launch": k2_alg,
             "frac_on_survey_8d_bytes": round(k2_alg / (k2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k2_ms else None,
             "avg_call_ms": round(k2_ms, 4) if k2_ms else None, "pairs_per_sec": round(args.batch * A * args.gt / (k2_ms * 1e-3), 0) if k2_ms else None}}
+        # the pair the north-star names ("focal-loss + IoU-match kernels"): K2's call + K3's call INCLUDING its one-block finalize, in the
+        # step (events around the two library calls), on SURVEY 8d's algorithmic bytes and on the bytes that can reach HBM
+        pair_ms = (k2_ms + kms["loss_fwd_bwd"]) if (k2_ms and "loss_fwd_bwd" in kms) else None
+        if pair_ms:
+            k2_now = A * 16 + args.batch * (args.gt * 16 + ((A + 63) // 64) * 8)        # anchors once + GT + the flag words (matches: flagged rows only)
+            roof_other["match_plus_loss"] = {
+                "bound": "hbm", "kernels": "rn_iou_match_special_ex (flagged rows only) + rn_loss_fwd_bwd_levels_ex incl. loss_finalize_kernel",
+                "call_ms": round(pair_ms, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "survey_8d_bytes": k2_alg + nbytes, "frac_on_survey_8d_bytes": round((k2_alg + nbytes) / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "bytes_r04_accounting": k2_unique + nbytes, "frac_on_r04_accounting": round((k2_unique + nbytes) / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "bytes_moved_now": k2_now + nbytes, "frac_on_bytes_moved_now": round((k2_now + nbytes) / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         # MFMA share: whole step on the model's useful flops, and the hand-written conv kernels alone (events around each launch)
         from pytorch_retinanet_amd import biasact
         step_s = elapsed / args.steps
@@ -637,14 +675,16 @@ def main():
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": n_warm,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"RetinaNet-{args.backbone.replace('resnet', 'R')}-FPN bf16 train step, per-GPU batch "
+            "vs_baseline": None, "dtype": args.amp, "data": "synthetic",
+            "config": {"workload": f"RetinaNet-{args.backbone.replace('resnet', 'R')}-FPN {args.amp} train step, per-GPU batch "
                                    f"{args.batch} x 3x800x1333 (padded 800x1344), A=201600 anchors, K=90, T={args.gt} GT/img, "
-                                   f"SGD(momentum{'' if args.torch_sgd else ', fp32 masters + bf16 conv weights'}); random-init weights",
+                                   f"SGD(momentum{'' if args.torch_sgd else f', fp32 masters + {args.amp} conv weights'})"
+                                   f"{', GradScaler (scale %g at the end)' % scaler.get_scale() if scaler is not None else ''}; random-init weights",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "final_loss": round(final_loss, 4),
                        **({"switches_set": args.set} if args.set else {})},
             "roofline": roof, "roofline_other": roof_other, "conv_mfma": conv_mfma,
-            "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 0,
+            "rccl_ranks": dist.get_world_size() if (dist.is_initialized() and args.backend == "nccl") else 0,
+            "exchange_backend": (args.backend + (" (all ranks on cuda:0)" if args.share_gpu else "")) if dist.is_initialized() else None,
             "gpu_state_during_timed_region": gpu_state,
             "step_launch": {"mode": ("4 linear hipGraph segments + eager all-reduces between them" if stepper.segmented else "hipGraph replay") if graph_replays else "eager",
                             "graph_replays_in_run": graph_replays, "buckets": ddp.num_buckets if ddp is not None else 0,

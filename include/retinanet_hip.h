@@ -117,6 +117,17 @@ int rn_iou_match_special(const float *anchors, int64_t anchor_bstride,
                          const float *gt_boxes, const int32_t *gt_off, int B, int64_t A,
                          float fg_thr, float bg_thr, int64_t *matches, int32_t *num_fg,
                          uint64_t *special_rows, int64_t total_gt, void *stream);
+/* ... with flags (ABI 8), for the caller that feeds the results straight to rn_loss_fwd_bwd_levels_ex (the training path):
+ *   RN_MATCH_FLAGGED_ONLY   `matches` is written ONLY at rows whose flag bit is set (matched or ignored rows); every other entry
+ *                           keeps what the buffer held.  The loss kernel reads `matches` through the flag words, so the B * A * 8
+ *                           bytes of int64 codes -- 12.9 of the 16.1 MB this call moves at the train shape -- are never stored.
+ *                           Needs special_rows; kernels that cannot skip the stores (large GT sets) write everything as before.
+ *   RN_MATCH_NUM_FG_ZEROED  num_fg[0..B) already holds zeros (the caller cleared it with its own input copies): no clear launch. */
+enum { RN_MATCH_NUM_FG_ZEROED = 1, RN_MATCH_FLAGGED_ONLY = 2 };
+int rn_iou_match_special_ex(const float *anchors, int64_t anchor_bstride,
+                            const float *gt_boxes, const int32_t *gt_off, int B, int64_t A,
+                            float fg_thr, float bg_thr, int64_t *matches, int32_t *num_fg,
+                            uint64_t *special_rows, int64_t total_gt, int flags, void *stream);
 
 /* ---- K3 loss_fwd_bwd --------------------------------------------------------
  * Replaces RetinaNetLosses.forward / calc_loss / focal_loss / smooth_l1_loss,

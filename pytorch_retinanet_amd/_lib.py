@@ -62,6 +62,7 @@ SIGNATURES = {
     "rn_iou_match_ex": (C.c_int, [_vp, _i64, _vp, _vp, C.c_int, _i64, _f32, _f32, _vp, _vp, _i64, _vp]),
     "rn_iou_match_special_bytes": (_sz, [C.c_int, _i64]),
     "rn_iou_match_special": (C.c_int, [_vp, _i64, _vp, _vp, C.c_int, _i64, _f32, _f32, _vp, _vp, _vp, _i64, _vp]),
+    "rn_iou_match_special_ex": (C.c_int, [_vp, _i64, _vp, _vp, C.c_int, _i64, _f32, _f32, _vp, _vp, _vp, _i64, C.c_int, _vp]),
     "rn_loss_workspace_bytes": (_sz, [C.c_int, _i64, C.c_int]),
     "rn_loss_fwd_bwd_levels_ex": (C.c_int, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i64), C.c_int, C.c_int, C.c_int, C.c_int,
                                             _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(RnLossParams), _vp,

@@ -394,6 +394,17 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                         const unsigned long long lo = p[0];
                         const unsigned long long hi = (sh && w + 1 < a.special_W) ? p[1] : 0ull;
                         m = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+                    } else {
+                        // the chunk straddles an image seam of this level: every lane looks its own bit up (`matches` may hold
+                        // NOTHING at rows without a flag: rn_iou_match_special_ex, RN_MATCH_FLAGGED_ONLY)
+                        bool f = false;
+                        if (lane < n) {
+                            const int64_t rr = r0 + lane;
+                            const int bb = (int)((uint32_t)rr / (uint32_t)lv.A_l);
+                            const int64_t agl = lv.base + (rr - (int64_t)bb * lv.A_l);
+                            f = (a.special[(int64_t)bb * a.special_W + (agl >> 6)] >> (agl & 63)) & 1ull;
+                        }
+                        m = __ballot(f);
                     }
                 }
                 if (n < RN_WAVE) m &= (1ull << n) - 1ull;
@@ -661,7 +672,9 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
             if (r <= row_hi) {
                 const int b = (int)((uint32_t)r / (uint32_t)lv.A_l);
                 const int64_t ag = lv.base + (r - (int64_t)b * lv.A_l);   // anchor index within the image
-                const int64_t m = a.matches[(int64_t)b * a.A + ag];
+                // (with the flag words `matches` is read at flagged rows only: it may be written there only, RN_MATCH_FLAGGED_ONLY)
+                const bool flagged = !a.special || ((a.special[(int64_t)b * a.special_W + (ag >> 6)] >> (ag & 63)) & 1ull);
+                const int64_t m = flagged ? a.matches[(int64_t)b * a.A + ag] : (int64_t)-1;
                 const int64_t r_e0 = r * K;
                 const bool own_row = r_e0 >= e_beg;                       // the row's first element is ours
                 float gb[4] = {0.0f, 0.0f, 0.0f, 0.0f};

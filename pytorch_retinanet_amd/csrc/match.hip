@@ -50,6 +50,10 @@ __device__ __forceinline__ void special_word(unsigned long long *__restrict__ sp
 
 // ============================================================================================================
 // Shared anchors, small GT sets: one thread = one anchor x `ipb` images of the batch (blockIdx.y selects the image group).
+// SPARSE: `matches` is written at FLAGGED rows only (code != -1: matched or ignored, ~0.3 % of the rows) -- for the caller that
+// reads it through the flag words (the loss kernel): B * A * 8 bytes of int64 stores nobody reads are 80 % of this kernel's traffic
+// at the train shape (12.9 of 16.1 MB).
+template <bool SPARSE>
 __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_batch_kernel(
     const rn::f32x4 *__restrict__ anchors, const rn::f32x4 *__restrict__ gt, const int32_t *__restrict__ gt_off,
     const int B, const int ipb, const int64_t A, const float fg_thr, const float bg_thr, int64_t *__restrict__ matches,
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_batch_kernel(
         }
         if (!fast) { best = bb2.v; bi = bb2.i; }
         const int64_t r = classify(best, bi, T, fg_thr, bg_thr);
-        if (live) matches[(int64_t)b * A + a_idx] = r;
+        if (live && (!SPARSE || r != -1)) matches[(int64_t)b * A + a_idx] = r;
         if (special) special_word(special, b, A, a_idx, live && r != -1);
         if (num_fg) {
             const unsigned long long fg = __ballot(live && r >= 0);
@@ -475,13 +479,26 @@ RN_API int rn_iou_match_special(const float *anchors, int64_t anchor_bstride, co
                                 int B, int64_t A, float fg_thr, float bg_thr, int64_t *matches, int32_t *num_fg,
                                 uint64_t *special_rows, int64_t total_gt, void *stream)
 {
+    return rn_iou_match_special_ex(anchors, anchor_bstride, gt_boxes, gt_off, B, A, fg_thr, bg_thr, matches, num_fg, special_rows, total_gt, 0, stream);
+}
+
+RN_API int rn_iou_match_special_ex(const float *anchors, int64_t anchor_bstride, const float *gt_boxes, const int32_t *gt_off,
+                                   int B, int64_t A, float fg_thr, float bg_thr, int64_t *matches, int32_t *num_fg,
+                                   uint64_t *special_rows, int64_t total_gt, int flags, void *stream)
+{
+    if (flags & ~(RN_MATCH_NUM_FG_ZEROED | RN_MATCH_FLAGGED_ONLY)) return RN_EINVAL;
+    if ((flags & RN_MATCH_FLAGGED_ONLY) && !special_rows) return RN_EINVAL;       // (without the words nobody can tell which rows were written)
+    const bool sparse = (flags & RN_MATCH_FLAGGED_ONLY) != 0;
     unsigned long long *special = (unsigned long long *)special_rows;
     if (special && !rn::aligned(special, 8)) return RN_EALIGN;
     if (!anchors || !gt_off || !matches || B <= 0 || A <= 0 || B > 65535) return RN_EINVAL;
     if (!(fg_thr > bg_thr)) return RN_ETHRESH;
     if (!rn::aligned(anchors, 16) || (gt_boxes && !rn::aligned(gt_boxes, 16)) || (anchor_bstride & 3)) return RN_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-    if (num_fg) { hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(64), 0, st, num_fg, B); RN_LAUNCH_CHECK(); }   // (a kernel, never hipMemsetAsync: DESIGN.md, memset nodes)
+    if (num_fg && !(flags & RN_MATCH_NUM_FG_ZEROED)) {                 // (a kernel, never hipMemsetAsync: DESIGN.md, memset nodes)
+        hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(64), 0, st, num_fg, B);
+        RN_LAUNCH_CHECK();
+    }
     // The batch kernel needs host knowledge of sum(T) (gt_off lives on the device and this call never syncs):
     // callers that know it pass total_gt >= 0; -1 means unknown -> the general kernel.
     if (anchor_bstride == 0 && B <= 64 && total_gt >= 0 && total_gt <= BATCH_GT_MAX && total_gt <= 32 * (int64_t)B) {
@@ -491,8 +508,10 @@ RN_API int rn_iou_match_special(const float *anchors, int64_t anchor_bstride, co
         by = by < 1 ? 1 : (by > B ? B : by);
         const int ipb = (B + by - 1) / by;
         const dim3 grid((unsigned)bx, (unsigned)((B + ipb - 1) / ipb));
-        hipLaunchKernelGGL(iou_match_batch_kernel, grid, dim3(MATCH_BLOCK), 0, st, (const rn::f32x4 *)anchors,
-                           (const rn::f32x4 *)gt_boxes, gt_off, B, ipb, A, fg_thr, bg_thr, matches, num_fg, special);
+        if (sparse) hipLaunchKernelGGL(iou_match_batch_kernel<true>, grid, dim3(MATCH_BLOCK), 0, st, (const rn::f32x4 *)anchors,
+                                       (const rn::f32x4 *)gt_boxes, gt_off, B, ipb, A, fg_thr, bg_thr, matches, num_fg, special);
+        else hipLaunchKernelGGL(iou_match_batch_kernel<false>, grid, dim3(MATCH_BLOCK), 0, st, (const rn::f32x4 *)anchors,
+                                (const rn::f32x4 *)gt_boxes, gt_off, B, ipb, A, fg_thr, bg_thr, matches, num_fg, special);
     } else if (total_gt > 192 * (int64_t)B && A * (int64_t)B < ((int64_t)1 << 40)) {
         // hundreds of GT boxes per image: split the GT axis too (see iou_match_chunk_kernel); z workgroups per anchor strip
         int z = (int)((total_gt / B + CHUNK_TILE - 1) / CHUNK_TILE);

@@ -49,6 +49,24 @@ class MemsetNodeInGraph(RuntimeError):
     pass
 
 
+class CaptureUnwindError(RuntimeError):
+    "A failed capture could not be unwound: some stream of this process is still in capture mode (see ``_device_usable``)."
+
+
+def _device_usable(dev) -> Optional[BaseException]:
+    """After a failed capture: can this process still allocate, launch and run autograd on ``dev``?  A failure raised by the autograd
+    engine's worker thread in the middle of a captured backward pass leaves streams the engine pulled into the capture (the legacy
+    stream, through AccumulateGrad nodes created by an eager step) in capture mode on ROCm 7 even after the capture has been ended;
+    every later allocation in that thread then fails with hipErrorStreamCaptureImplicit.  -> the exception the probe met, or None."""
+    try:
+        t = torch.ones(8, device=dev, requires_grad=True)
+        (t * 2.0).sum().backward()                 # (runs on the engine's device thread)
+        torch.cuda.synchronize(dev)
+        return None
+    except Exception as exc:                       # noqa: BLE001
+        return exc
+
+
 LAST_CENSUS: Dict[str, int] = {}          # node counts of the graphs captured so far in this process (bench.py reports them)
 
 
@@ -347,6 +365,10 @@ class CapturedTrainStep:
                 torch.cuda.synchronize()                      # (the capture's side stream has been joined by _capture_segments' finally)
                 if self.ddp is not None:
                     self.ddp.reset()
+                stuck = _device_usable(images[0].device)
+                if stuck is not None:
+                    raise CaptureUnwindError(f"the failed capture ({type(exc).__name__}: {exc}) left the device in stream-capture mode "
+                                             f"({type(stuck).__name__}: {stuck}); this process cannot run further GPU work") from exc
                 return self._step(images, targets)
         else:
             # the step's inputs into the graph's static buffers: one multi-tensor launch per dtype for what already lives on the

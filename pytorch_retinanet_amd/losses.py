@@ -48,6 +48,14 @@ class _FusedDenseHeadLoss(torch.autograd.Function):
         return gcls.view(ctx.cls_shape), gbox.view(ctx.box_shape), None, None, None, None, None, None, None
 
 
+class GtPack:
+    "What ``ops.gt_pack`` prepared beside the GT arrays: the zeroed ``num_fg`` K2 adds into (None: K2 clears its own)."
+    __slots__ = ("num_fg",)
+
+    def __init__(self, num_fg):
+        self.num_fg = num_fg
+
+
 class MatchAhead:
     """K2's results, launched ahead of the head convolutions on a side stream (``RetinaNetLosses.match_ahead``): the matcher needs
     only the anchors and the GT boxes, so it does not have to sit on the critical path between the class-output conv and K3."""
@@ -79,6 +87,9 @@ class _FusedDenseHeadLossLevels(torch.autograd.Function):
         B = cls_levels[0].shape[0]
         want_grad = any(ctx.needs_input_grad[9:])
         fused = None
+        pack = None
+        if isinstance(ahead, GtPack):
+            pack, ahead = ahead, None
         if ahead is not None and not isinstance(ahead, MatchAhead):
             # ``ahead`` = the largest per-image GT count: K2 runs INSIDE the loss kernel (one launch; box_utils.py:51-80 in the
             # prologue of rn_loss_match_fwd_bwd_levels) unless the library declines the shape
@@ -92,7 +103,9 @@ class _FusedDenseHeadLossLevels(torch.autograd.Function):
                 torch.cuda.current_stream(cls_levels[0].device).wait_event(ahead.done)        # K2 ran beside the head convolutions
                 matches, num_fg, special = ahead.matches, ahead.num_fg, ahead.special
             else:
-                matches, num_fg, special = ops.iou_match(anchors, gt_boxes, gt_off, B, fg_thr, bg_thr, want_special=True)
+                # `matches` goes nowhere but into the loss kernel, which reads it through the flag words: K2 writes the flagged rows only
+                matches, num_fg, special = ops.iou_match(anchors, gt_boxes, gt_off, B, fg_thr, bg_thr, want_special=True, flagged_only=True,
+                                                         zeroed_num_fg=pack.num_fg if pack is not None else None)
             loss, gcls, gbox = ops.loss_fwd_bwd_levels(cls_levels, box_levels, anchors, gt_boxes, gt_labels, gt_off, matches,
                                                        num_fg, params, want_grad, special=special)
         ctx.grads = (gcls, gbox)
@@ -170,11 +183,7 @@ class RetinaNetLosses(nn.Module):
 
     @staticmethod
     def _gt_arrays(targets, dev):
-        boxes, labels = [t["boxes"] for t in targets], [t["labels"] for t in targets]
-        counts = [int(b.reshape(-1, 4).shape[0]) for b in boxes]
-        gt_boxes = torch.cat([b.reshape(-1, 4).to(device=dev, dtype=torch.float32) for b in boxes])
-        gt_labels = torch.cat([l.reshape(-1).to(device=dev, dtype=torch.int64) for l in labels])
-        return gt_boxes, gt_labels, ops.gt_offsets(counts, dev)
+        return ops.gt_pack([t["boxes"] for t in targets], [t["labels"] for t in targets], dev)[:3]
 
     @staticmethod
     def fuses_match(targets) -> bool:
@@ -217,10 +226,12 @@ class RetinaNetLosses(nn.Module):
         if ahead is not None:
             gt_boxes, gt_labels, gt_off, anchors_t = ahead.gt_boxes, ahead.gt_labels, ahead.gt_off, ahead.anchors
         else:
-            gt_boxes, gt_labels, gt_off = self._gt_arrays(targets, dev)
+            gt_boxes, gt_labels, gt_off, nfg0 = ops.gt_pack([t["boxes"] for t in targets], [t["labels"] for t in targets], dev)
             anchors_t = _stack_anchors(anchors)
             if cls_levels[0].is_cuda and self.fuses_match(targets):
                 ahead = max([int(t["boxes"].reshape(-1, 4).shape[0]) for t in targets] or [0])      # (an int: see the Function)
+            elif nfg0 is not None:
+                ahead = GtPack(nfg0)
         out = _FusedDenseHeadLossLevels.apply(anchors_t, gt_boxes, gt_labels, gt_off, self._params(),
                                               IOU_THRESHOLDS_FOREGROUND, IOU_THRESHOLDS_BACKGROUND, len(cls_levels), ahead,
                                               *cls_levels, *box_levels)

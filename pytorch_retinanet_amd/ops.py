@@ -14,6 +14,8 @@ from torch import Tensor
 from . import _lib
 from ._lib import RN_BF16, RN_F16, RN_F32, RnDetectParams, RnLevel, RnLossParams, check, lib
 
+RN_MATCH_NUM_FG_ZEROED, RN_MATCH_FLAGGED_ONLY = 1, 2          # include/retinanet_hip.h
+
 _DT = {torch.float32: RN_F32, torch.bfloat16: RN_BF16, torch.float16: RN_F16}
 
 
@@ -149,13 +151,51 @@ def gt_offsets(counts: Sequence[int], device: torch.device) -> Tensor:
     return dev_t
 
 
+def gt_pack(boxes: Sequence[Tensor], labels: Sequence[Tensor], dev: torch.device):
+    """The ragged GT of a batch as the library takes it -- (gt_boxes f32 [sum T, 4], gt_labels i64 [sum T], gt_off i32 [B + 1]) -- plus a
+    ZEROED ``num_fg`` i32 [B] for K2, all written by ONE launch (``rn_copy_many``: 2 B + 1 small copies, the last from the zero page)
+    when the per-image tensors already are f32 / i64 CUDA tensors; else two ``torch.cat`` and num_fg = None (K2 then clears it).
+    Reference: the per-image ``targets[i]["boxes"]`` / ``["labels"]`` of ``RetinaNetLosses.forward`` (losses.py:113-145)."""
+    counts = [int(b.reshape(-1, 4).shape[0]) for b in boxes]
+    gt_off = gt_offsets(counts, dev)
+    B, total = len(counts), sum(counts)
+    bs = [b.reshape(-1, 4) for b in boxes]
+    ls = [l.reshape(-1) for l in labels]
+    fast = total > 0 and 2 * B + 1 <= 64 and 4 * B <= 256 and all(b.is_cuda and b.device == dev and b.dtype == torch.float32 and b.is_contiguous() for b in bs) \
+        and all(l.is_cuda and l.device == dev and l.dtype == torch.int64 and l.is_contiguous() for l in ls)
+    if not fast:
+        gt_boxes = torch.cat([b.to(device=dev, dtype=torch.float32) for b in bs]) if B else torch.zeros((0, 4), device=dev)
+        gt_labels = torch.cat([l.to(device=dev, dtype=torch.int64) for l in ls]) if B else torch.zeros((0,), dtype=torch.int64, device=dev)
+        return gt_boxes, gt_labels, gt_off, None
+    gt_boxes = torch.empty((total, 4), dtype=torch.float32, device=dev)
+    gt_labels = torch.empty((total,), dtype=torch.int64, device=dev)
+    num_fg = torch.empty((B,), dtype=torch.int32, device=dev)
+    from .biasact import _zero_page
+    srcs, dsts, nb, o = [], [], [], 0
+    for b, l, c in zip(bs, ls, counts):
+        if c:
+            srcs += [b.data_ptr(), l.data_ptr()]
+            dsts += [gt_boxes.data_ptr() + 16 * o, gt_labels.data_ptr() + 8 * o]
+            nb += [16 * c, 8 * c]
+            o += c
+    srcs.append(_zero_page(dev).data_ptr()); dsts.append(num_fg.data_ptr()); nb.append(4 * B)
+    n = len(srcs)
+    with torch.cuda.device(dev), _timed("gt_pack", dev):
+        check(lib.rn_copy_many((C.c_void_p * n)(*srcs), (C.c_void_p * n)(*dsts), (C.c_int64 * n)(*nb), n, _stream(dev)), "rn_copy_many")
+    return gt_boxes, gt_labels, gt_off, num_fg
+
+
 def iou_match(anchors: Tensor, gt_boxes: Tensor, gt_off: Tensor, B: int, fg_thr: float, bg_thr: float,
-              want_num_fg: bool = True, want_special: bool = False, out: Optional[tuple] = None):
+              want_num_fg: bool = True, want_special: bool = False, out: Optional[tuple] = None, flagged_only: bool = False,
+              zeroed_num_fg: Optional[Tensor] = None):
     """K2.  anchors [A,4] or [B,A,4]; gt_boxes f32 [sum T,4]; gt_off i32 [B+1] (device).
     -> (matches i64 [B,A], num_fg i32 [B]) and, with ``want_special``, a third tensor ``special`` i64 [B, ceil(A/64)]:
     bit (a & 63) of word a >> 6 is set where ``matches[b, a] != -1`` (what ``loss_fwd_bwd_levels(special=...)`` reads instead of
     streaming ``matches``).  ``out``: pre-allocated (matches, num_fg, special) -- for a caller that launches K2 on a side
-    stream and wants the outputs to belong to its main stream (``losses.RetinaNetLosses.match_ahead``)."""
+    stream and wants the outputs to belong to its main stream (``losses.RetinaNetLosses.match_ahead``).
+    ``flagged_only`` (needs ``want_special``): ``matches`` is written only where a flag bit is set -- every other entry is
+    UNINITIALISED; for results that go straight into ``loss_fwd_bwd_levels(special=...)`` (RN_MATCH_FLAGGED_ONLY).
+    ``zeroed_num_fg``: an i32 [B] tensor that already holds zeros (``gt_pack``): used as ``num_fg``, no clear launch."""
     dev = _need_dev(anchors, gt_boxes, gt_off)
     A = anchors.shape[-2]
     anchors, bstride = _anchor_args(anchors, B, A)
@@ -165,12 +205,19 @@ def iou_match(anchors: Tensor, gt_boxes: Tensor, gt_off: Tensor, B: int, fg_thr:
     if out is not None:
         matches, num_fg, special = out
     else:
-        matches, num_fg, special = iou_match_outputs(B, A, dev, want_num_fg, want_special)
+        matches, num_fg, special = iou_match_outputs(B, A, dev, want_num_fg and zeroed_num_fg is None, want_special)
+    flags = 0
+    if zeroed_num_fg is not None:
+        num_fg, flags = zeroed_num_fg, flags | RN_MATCH_NUM_FG_ZEROED
+    if flagged_only:
+        if special is None:
+            raise ValueError("flagged_only needs the flag words (want_special=True)")
+        flags |= RN_MATCH_FLAGGED_ONLY
     with torch.cuda.device(dev), _timed("iou_match", dev):
         # gt_off[B] - gt_off[0] == the row count of gt_boxes (host-known): lets the library pick the batch-shaped kernel
-        check(lib.rn_iou_match_special(_ptr(anchors), bstride, _ptr(gt_boxes), _ptr(gt_off), B, A, fg_thr, bg_thr,
-                                       _ptr(matches), _ptr(num_fg), _ptr(special), int(gt_boxes.shape[0]), _stream(dev)),
-              "rn_iou_match_special")
+        check(lib.rn_iou_match_special_ex(_ptr(anchors), bstride, _ptr(gt_boxes), _ptr(gt_off), B, A, fg_thr, bg_thr,
+                                          _ptr(matches), _ptr(num_fg), _ptr(special), int(gt_boxes.shape[0]), flags, _stream(dev)),
+              "rn_iou_match_special_ex")
     return (matches, num_fg, special) if (want_special or out is not None) else (matches, num_fg)
 
 

@@ -182,7 +182,7 @@ def test_narrow_weight_gradient_rejects_what_it_cannot_do():
     ws = torch.empty((lib.rn_conv3x3_wgrad_narrow_workspace_bytes(64, 64),), dtype=torch.uint8, device=dev)
     dw = torch.empty((64 * 9 * 64,), dtype=torch.bfloat16, device=dev)
     z = biasact._zero_page(dev).data_ptr()
-    assert lib.rn_conv3x3_wgrad_narrow(x.data_ptr(), x.data_ptr(), dw.data_ptr(), RN_F16, 1, 4, 4, 64, 64, z, ws.data_ptr(), ws.numel(), 0) != 0
+    assert lib.rn_conv3x3_wgrad_narrow(x.data_ptr(), x.data_ptr(), dw.data_ptr(), RN_F32, 1, 4, 4, 64, 64, z, ws.data_ptr(), ws.numel(), 0) != 0      # (bf16 and fp16 only)
     assert lib.rn_conv3x3_wgrad_narrow(x.data_ptr(), x.data_ptr(), dw.data_ptr(), RN_BF16, 1, 4, 4, 96, 64, z, ws.data_ptr(), ws.numel(), 0) != 0
     assert lib.rn_conv3x3_wgrad_narrow(x.data_ptr(), x.data_ptr(), dw.data_ptr(), RN_BF16, 1, 4, 4, 64, 64, z, ws.data_ptr(), 16, 0) != 0
     assert lib.rn_conv3x3_wgrad_narrow(x.data_ptr(), x.data_ptr(), dw.data_ptr(), RN_BF16, 1, 4, 4, 64, 64, 0, ws.data_ptr(), ws.numel(), 0) != 0

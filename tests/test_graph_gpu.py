@@ -195,8 +195,9 @@ def test_a_graph_with_a_memset_node_is_refused_and_the_librarys_own_calls_captur
 
 def test_a_failure_inside_an_open_segment_ends_the_capture_and_the_step_runs_eagerly():
     """the segmented capture drives capture_begin / capture_end by hand; an exception raised while a segment is
-    open (a MIOpen / check() failure in forward or backward) must end that capture, drop the half-built segments and leave the device
-    usable -- the step of that call runs eagerly, later calls of that signature stay eager, other signatures still capture."""
+    open (a MIOpen / check() failure in the forward pass or on the capturing thread) must end that capture, drop the half-built
+    segments and leave the device usable -- the step of that call runs eagerly, later calls of that signature stay eager, other
+    signatures still capture."""
     from pytorch_retinanet_amd.graph import CapturedTrainStep, retinanet_stage_of
     from pytorch_retinanet_amd.parallel import BucketedGradAllReduce
     net, opt = _setup()
@@ -215,23 +216,13 @@ def test_a_failure_inside_an_open_segment_ends_the_capture_and_the_step_runs_eag
     assert not torch.cuda.is_current_stream_capturing()
     assert step.captures == 0 and step.replays == 0 and np.all(np.isfinite(losses))
     assert all(b.pending == len(b.params) or b.launched for b in ddp.buckets)
-    # a failure in a LATER segment (stage 1's backward): segments already built are dropped too
     boom["on"] = False
     h.remove()
-    fired = {"n": 0}
-
-    def bhook(_m, _gin, _gout):
-        if boom["on"] and torch.cuda.is_current_stream_capturing():
-            fired["n"] += 1
-            raise RuntimeError("injected failure in the second segment")
-    hb = net.backbone.backbone.layer4.register_full_backward_hook(bhook)
-    boom["on"] = True
-    data2 = _batches(3, T=2, seed=9)                                           # a new signature (other GT count)
-    l2 = [float(step(im, tg)["loss"]) for im, tg in data2]
-    torch.cuda.synchronize()
-    assert fired["n"] == 1 and step.captures == 0 and np.all(np.isfinite(l2))
-    hb.remove()
-    boom["on"] = False
+    # (A failure raised by the autograd ENGINE's worker thread in the middle of a captured backward pass is a different matter: the
+    # engine has then pulled the legacy stream into the capture -- AccumulateGrad nodes of parameters first used by an eager step live
+    # on that step's stream -- and HIP does not release it when the capture is ended unjoined.  graph.CapturedTrainStep probes for that
+    # state after unwinding and raises ``CaptureUnwindError`` instead of running an eager step on a device that will refuse it;
+    # it is not provoked here because no later test of this process could run.)
     data3 = _batches(4, T=4, seed=3)                                           # a third signature captures and replays normally
     l3 = [float(step(im, tg)["loss"]) for im, tg in data3]
     torch.cuda.synchronize()
