@@ -1,6 +1,8 @@
 #!/bin/bash
 # rocprofv3 summaries of the headline bench for profiles/: kernel-trace stats, then separate PMC passes
 # for the K3 kernel (FETCH_SIZE / WRITE_SIZE cannot share a pass; MI355X_MICROARCH.md, HBM section).
+# The GPU box has no .git: pass the commit the snapshot was taken at as RN_COMMIT (gpurun -- 'RN_COMMIT=<hash> tools/profile_bench.sh r05');
+# it is written into k3_pmc.json, which bench.py quotes as the source of roofline.traffic.
 tag=${1:-r03}
 out=$GRAFT_REPO_ROOT/gpurun_out/profile_$tag
 mkdir -p $out; rm -f $out/k3_pmc.txt
@@ -23,7 +25,7 @@ PY
 done
 cat $out/k3_pmc.txt
 python - $out <<PY
-import json, re, sys, csv
+import json, os, re, sys, csv
 out = sys.argv[1]
 txt = open(out + "/k3_pmc.txt").read()
 f = float(re.search(r"FETCH_SIZE per launch \(KB\) over \d+ launches: mean ([0-9.]+)", txt).group(1))
@@ -38,7 +40,7 @@ json.dump({"kernel": "loss_stream_kernel<bf16,gamma2,grad> (per-level rn_loss_fw
            "correction": "FETCH_SIZE x2 on gfx950 for 16 B/lane coalesced streams (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
            "hbm_bytes_per_launch": int(round((2 * f + w) * 1024)),
            "algorithmic_bytes_per_launch": line["roofline"]["algorithmic_bytes_per_launch"],
-           "kernel_avg_us_rocprof": avg,
+           "kernel_avg_us_rocprof": avg, "commit": os.environ.get("RN_COMMIT", "unrecorded"),
            "source": "tools/profile_bench.sh (rocprofv3 --pmc, separate passes), bench.py --steps 3 --warmup 3 --no-detect (hipGraph replays + 1 eager step)"}, open(out + "/k3_pmc.json", "w"), indent=1)
 print(open(out + "/k3_pmc.json").read())
 PY

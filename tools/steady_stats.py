@@ -3,7 +3,10 @@
 N train steps (delimited by the K3 stream kernel) are kept, so MIOpen's find-mode/JIT warm-up
 kernels do not pollute the table.  ``skip``: trailing steps to leave out (bench.py's --timing-steps run EAGERLY with an event pair
 around every hand-written launch: same kernels, but 5-6 us of idle time at every pair -- they are not steady-state replays).
-usage: steady_stats.py <kernel_trace.csv> <out.csv> [steps] [skip]"""
+``marker``: substring of the kernel that delimits one iteration -- default the K3 stream kernel (train steps); the inference line
+(``bench.py --mode predict``) is delimited by ``score_scan_kernel`` (one per ``predict()`` call: an iteration then runs from one call's
+scan to the next call's, i.e. the detect tail of call i + the conv stack of call i + 1 -- the same kernels as one whole call).
+usage: steady_stats.py <kernel_trace.csv> <out.csv> [steps] [skip] [marker]"""
 import csv
 import sys
 from collections import defaultdict
@@ -13,7 +16,8 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 skip = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 rows = list(csv.DictReader(open(src)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "loss_stream_kernel" in r["Kernel_Name"]]
+marker = sys.argv[5] if len(sys.argv) > 5 else "loss_stream_kernel"
+marks = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
 assert len(marks) > steps + skip, "not enough steps in the trace"
 lo, hi = marks[-steps - 1 - skip], marks[-1 - skip]          # [K3 of step n-steps-1, K3 of the last kept step): `steps` whole steps
 sel = rows[lo:hi]
