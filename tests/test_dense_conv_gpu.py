@@ -173,7 +173,7 @@ def test_narrow_weight_gradient_matches_torch(N, cout, cin, hw):
 
 def test_narrow_weight_gradient_rejects_what_it_cannot_do():
     from pytorch_retinanet_amd import biasact
-    from pytorch_retinanet_amd._lib import lib, RN_BF16, RN_F16
+    from pytorch_retinanet_amd._lib import lib, RN_BF16, RN_F16, RN_F32
     dev = torch.device("cuda:0")
     x = torch.zeros((1, 64, 4, 4), device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
     assert not biasact.wgrad_narrow_ok(torch.empty((96, 64, 3, 3), dtype=torch.bfloat16), (1, 1), x)
