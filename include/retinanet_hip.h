@@ -172,6 +172,21 @@ int rn_loss_fwd_bwd_levels_ex(const void *const *cls_levels, const void *const *
                               const uint64_t *special_rows, const int32_t *num_fg, const rn_loss_params *params,
                               float *out_loss, void *const *grad_cls_levels, void *const *grad_box_levels, void *workspace,
                               size_t workspace_bytes, void *stream, void *event_start, void *event_stop);
+/* rn_loss_fwd_bwd_levels_ex WITHOUT the one-block finalize launch (ABI 8): every workgroup of the streaming kernel adds its two
+ * partial sums -- as 2^-32 fixed point, so that the total is an integer sum and therefore the same bits in any order -- to two words
+ * of `state` with relaxed device-scope atomics and bumps an arrival counter in the same cache line; workgroup 0 waits for the last
+ * arrival, writes out_loss and leaves the words zeroed.  The finalize KERNEL of the other entry points uses the same arithmetic, so
+ * both give the same bits.  `state`: >= 64 bytes, 64-byte aligned (the first line of a rn_loss_match_state_bytes buffer serves: this
+ * form uses words 8..13, the fused form words 0, 1); the caller zero-fills it ONCE, every completed call leaves it zero-filled, and
+ * it must not be shared by calls that can run concurrently (one per stream).  A workgroup that never arrives (a faulted launch) makes
+ * out_loss NaN after a bounded wait instead of hanging the stream. */
+int rn_loss_fwd_bwd_levels_fin(const void *const *cls_levels, const void *const *box_levels,
+                               const int64_t *level_anchors, int L, int dtype, int B, int K,
+                               const float *anchors, int64_t anchor_bstride, const float *gt_boxes,
+                               const int64_t *gt_labels, const int32_t *gt_off, const int64_t *matches,
+                               const uint64_t *special_rows, const int32_t *num_fg, const rn_loss_params *params,
+                               float *out_loss, void *const *grad_cls_levels, void *const *grad_box_levels, void *workspace,
+                               size_t workspace_bytes, void *state, void *stream, void *event_start, void *event_stop);
 /* K2 + K3 in ONE launch (round 4): the matcher of retinanet/box_utils.py:51-80 runs in the loss kernel's prologue -- every wave
  * matches the anchor rows of its own range against the image's GT boxes (one box per lane, so max_gt_per_image <= 64), the
  * per-image foreground counts meet in device-scope counters behind a grid barrier (the launch uses the resident grid only), and
@@ -179,7 +194,9 @@ int rn_loss_fwd_bwd_levels_ex(const void *const *cls_levels, const void *const *
  * rn_iou_match + rn_loss_fwd_bwd_levels bit for bit (match codes, num_fg) / to the last ulp of the same arithmetic (losses,
  * gradients).  num_fg_out i32[B] is written by the finalize kernel.  `state` (rn_loss_match_state_bytes(B), 64-byte aligned)
  * holds the barrier word and the counters: the caller zero-fills it ONCE; every completed call leaves it zero-filled; it must
- * not be shared by calls that can run concurrently (one per stream).  RN_EUNSUPPORTED: more than 64 GT boxes in an image, or a
+ * not be shared by calls that can run concurrently (one per stream) NOR overlap kernels of other streams that occupy wave slots:
+ * the grid barrier needs every workgroup co-resident (the grid is sized from an occupancy estimate); a barrier that is not
+ * complete after a bounded wait poisons out_loss with NaN instead of hanging.  RN_EUNSUPPORTED: more than 64 GT boxes in an image, or a
  * shape whose per-wave row range does not fit the kernel's lists (then call rn_iou_match_special + rn_loss_fwd_bwd_levels_ex).
  * event_start / event_stop as in rn_loss_fwd_bwd_levels_ex. */
 size_t rn_loss_match_state_bytes(int B);

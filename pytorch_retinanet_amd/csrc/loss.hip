@@ -68,6 +68,8 @@ struct LossArgs {
     rn_loss_params p;
     float alpha_pos;         // weight of t=1 elements: 1-alpha (Q2)
     float2 *part_stream;     // [blocks] (cls, reg) partial sums
+    unsigned *fin;           // nullable: state words of the in-kernel finalize (rn_loss_fwd_bwd_levels_fin): [0] arrivals, [2..5] two int64 sums
+    float *out_loss;         // f32[2], written by workgroup 0 when `fin` is set
     // fused matching (loss_stream_kernel<.., FUSED = true>): the IoU matcher of box_utils.py:51-80 runs in this kernel's prologue
     float fg_thr, bg_thr;
     int32_t *nfg_acc;        // [B] foreground counts of this launch: zero on entry (the finalize kernel re-zeroes them), device-scope atomics
@@ -201,6 +203,26 @@ constexpr int LIST_CAP_PLAIN = 320;  // rows of a wave's range whose repair goes
 constexpr int LIST_CAP_FUSED = 384;  // fused matching: EVERY row of the range must fit (it runs at 5 workgroups per CU: 319 rows at the train shape)
 constexpr int IGN_U = 4;            // independent element loads per lane per round in the ignored-row repair
 
+// Per-workgroup loss partials as 2^-32 fixed point (|partial| < 2^31: a workgroup sums at most a few 10^5 elements of O(10) each):
+// the sum over the workgroups is then an INTEGER sum -- the same bits in any order -- so neither the finalize kernel nor the
+// in-kernel finalize needs a fixed summation order to be deterministic.  Resolution 2.3e-10 per partial against losses of O(1).
+// Non-finite partials (NaN / Inf logits) must stay visible: they add nothing and raise a flag instead (1 NaN, 2 +Inf, 4 -Inf);
+// loss_unfix gives the value IEEE summation would have given: NaN, or the infinity when only one sign was seen.
+__device__ __forceinline__ long long loss_fix(const float v, unsigned &flags)
+{
+    if (!(fabsf(v) < 2147483648.0f)) {                            // NaN, Inf, or a partial beyond the fixed-point range (treated as Inf)
+        flags |= (v != v) ? 1u : (v > 0.0f ? 2u : 4u);
+        return 0;
+    }
+    return __double2ll_rn((double)v * 4294967296.0);
+}
+__device__ __forceinline__ float loss_unfix(const long long s, const unsigned flags)
+{
+    if (flags & 1u || (flags & 6u) == 6u) return __builtin_nanf("");
+    if (flags & 2u) return __builtin_inff();
+    if (flags & 4u) return -__builtin_inff();
+    return (float)((double)s * (1.0 / 4294967296.0));
+}
 template <int DT, bool GAMMA2, bool WRITE_GRAD, int PF, int NT, bool FUSED = false>
 __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs a)
 {
@@ -764,7 +786,39 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
         float c = 0.0f, rg = 0.0f;
 #pragma unroll
         for (int w = 0; w < LOSS_WAVES; ++w) { c += s_part[w][0]; rg += s_part[w][1]; }
-        a.part_stream[blockIdx.x] = make_float2(c, rg);
+        if (a.fin) {
+            // The batch sums WITHOUT a finalize launch: every workgroup adds its two partials, as 2^-32 fixed point, to two 64-bit
+            // words and then bumps the arrival counter -- relaxed device-scope atomics that return nothing (1 536 of them arriving on
+            // one line cost nothing measurable) and live in ONE cache line, so that they are performed in program order
+            // at the same L2 channel; integer addition is order-independent, so the result is the same whoever adds first.
+            // Workgroup 0 waits for the last arrival, converts, and leaves the words zeroed for the next launch on this state buffer.
+            unsigned long long *const sums = (unsigned long long *)(a.fin + 2);
+            unsigned fl_c = 0u, fl_r = 0u;
+            const long long fc = loss_fix(c, fl_c), fr = loss_fix(rg, fl_r);
+            __hip_atomic_fetch_add(sums + 0, (unsigned long long)fc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(sums + 1, (unsigned long long)fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (fl_c | fl_r) __hip_atomic_fetch_or(a.fin + 1, fl_c | (fl_r << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (rare: non-finite logits)
+            __hip_atomic_fetch_add(a.fin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (blockIdx.x == 0) {
+                unsigned spins = 0;
+                bool ok = true;
+                while (__hip_atomic_load(a.fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > (1u << 22)) { ok = false; break; }          // (a workgroup that never arrives = a faulted launch: poison, do not hang)
+                }
+                const long long sc = (long long)__hip_atomic_load(sums + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const long long sr = (long long)__hip_atomic_load(sums + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned fl = __hip_atomic_load(a.fin + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a.out_loss[0] = ok ? loss_unfix(sc, fl & 0xffu) : __builtin_nanf("");
+                a.out_loss[1] = ok ? loss_unfix(sr, (fl >> 8) & 0xffu) : __builtin_nanf("");
+                __hip_atomic_store(sums + 0, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sums + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.fin + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.fin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            a.part_stream[blockIdx.x] = make_float2(c, rg);
+        }
     }
 }
 
@@ -774,14 +828,19 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(const float2 *__res
                                                              float *__restrict__ out, unsigned *__restrict__ bar,
                                                              int32_t *__restrict__ nfg_acc, int32_t *__restrict__ num_fg_out, const int B)
 {
-    __shared__ double s[2][1024];
+    __shared__ long long s[2][1024];                 // the sums in 2^-32 fixed point, like the in-kernel finalize: bit-identical results
     if (bar) {
         for (int b = threadIdx.x; b < B; b += 1024) { num_fg_out[b] = nfg_acc[b]; nfg_acc[b] = 0; }
         if (threadIdx.x == 0) bar[0] = 0u;
     }
     const bool barrier_failed = bar && bar[1] != 0u;               // (uniform: read before the reset below can matter -- only thread 0 writes it, after the sums)
-    double c = 0.0, r = 0.0;
-    for (int i = threadIdx.x; i < n; i += 1024) { const float2 v = partials[i]; c += (double)v.x; r += (double)v.y; }
+    __shared__ unsigned s_flags;
+    if (threadIdx.x == 0) s_flags = 0u;
+    __syncthreads();
+    long long c = 0, r = 0;
+    unsigned fl_c = 0u, fl_r = 0u;
+    for (int i = threadIdx.x; i < n; i += 1024) { const float2 v = partials[i]; c += loss_fix(v.x, fl_c); r += loss_fix(v.y, fl_r); }
+    if (fl_c | fl_r) atomicOr(&s_flags, fl_c | (fl_r << 8));
     s[0][threadIdx.x] = c; s[1][threadIdx.x] = r;
     __syncthreads();
     for (int o = 512; o > 0; o >>= 1) {
@@ -789,8 +848,8 @@ __global__ __launch_bounds__(1024) void loss_finalize_kernel(const float2 *__res
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        out[0] = barrier_failed ? __builtin_nanf("") : (float)s[0][0];
-        out[1] = barrier_failed ? __builtin_nanf("") : (float)s[1][0];
+        out[0] = barrier_failed ? __builtin_nanf("") : loss_unfix(s[0][0], s_flags & 0xffu);
+        out[1] = barrier_failed ? __builtin_nanf("") : loss_unfix(s[1][0], (s_flags >> 8) & 0xffu);
         if (barrier_failed) bar[1] = 0u;
     }
 }
@@ -949,8 +1008,9 @@ static int loss_levels_core(const void *const *cls_levels, const void *const *bo
                             const int64_t *gt_labels, const int32_t *gt_off, const int64_t *matches, const uint64_t *special_rows,
                             const int32_t *num_fg, const rn_loss_params *params, float *out_loss,
                             void *const *grad_cls_levels, void *const *grad_box_levels, void *workspace,
-                            size_t workspace_bytes, void *stream, const FusedMatch *fm = nullptr)
+                            size_t workspace_bytes, void *stream, const FusedMatch *fm = nullptr, void *fin_state = nullptr)
 {
+    if (fin_state && (fm || !rn::aligned(fin_state, 64))) return fm ? RN_EINVAL : RN_EALIGN;
     if (!cls_levels || !box_levels || !level_anchors || !anchors || !gt_off || !params || !out_loss || !workspace) return RN_EINVAL;
     if (!fm && (!matches || !num_fg)) return RN_EINVAL;
     if (L <= 0 || L > RN_MAX_LEVELS || B <= 0 || K <= 0) return RN_EINVAL;
@@ -999,6 +1059,8 @@ static int loss_levels_core(const void *const *cls_levels, const void *const *bo
     a.p = *params;
     a.alpha_pos = (float)(1.0 - (double)params->alpha);
     a.part_stream = (float2 *)workspace;
+    a.fin = fin_state ? (unsigned *)fin_state + 8 : nullptr;            // words 8..13 of the state line (0, 1: the fused form's barrier words)
+    a.out_loss = out_loss;
     a.fg_thr = a.bg_thr = 0.0f; a.nfg_acc = nullptr; a.bar = nullptr; a.matches_out = nullptr;
     if (fm) {
         a.fg_thr = fm->fg_thr; a.bg_thr = fm->bg_thr; a.matches_out = fm->matches_out;
@@ -1017,6 +1079,7 @@ static int loss_levels_core(const void *const *cls_levels, const void *const *bo
         default: rc = launch_loss<RN_F16>(a, gamma2, wg, st, &ns, fm != nullptr); break;
     }
     if (rc != RN_OK) return rc;
+    if (a.fin) return RN_OK;                                            // (workgroup 0 of the stream kernel has written out_loss)
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1024), 0, st, (const float2 *)a.part_stream, ns, out_loss, a.bar, a.nfg_acc,
                        fm ? fm->num_fg_out : nullptr, B);
     RN_LAUNCH_CHECK();
@@ -1047,6 +1110,23 @@ RN_API int rn_loss_fwd_bwd_levels_ex(const void *const *cls_levels, const void *
     const int rc = loss_levels_core(cls_levels, box_levels, level_anchors, L, dtype, B, K, anchors, anchor_bstride, gt_boxes, gt_labels,
                                     gt_off, matches, special_rows, num_fg, params, out_loss, grad_cls_levels, grad_box_levels, workspace,
                                     workspace_bytes, stream);
+    g_prof.start = g_prof.stop = nullptr;
+    return rc;
+}
+
+RN_API int rn_loss_fwd_bwd_levels_fin(const void *const *cls_levels, const void *const *box_levels,
+                                      const int64_t *level_anchors, int L, int dtype, int B, int K,
+                                      const float *anchors, int64_t anchor_bstride, const float *gt_boxes,
+                                      const int64_t *gt_labels, const int32_t *gt_off, const int64_t *matches,
+                                      const uint64_t *special_rows, const int32_t *num_fg, const rn_loss_params *params,
+                                      float *out_loss, void *const *grad_cls_levels, void *const *grad_box_levels, void *workspace,
+                                      size_t workspace_bytes, void *state, void *stream, void *event_start, void *event_stop)
+{
+    if (!state) return RN_EINVAL;
+    g_prof.start = (hipEvent_t)event_start; g_prof.stop = (hipEvent_t)event_stop;
+    const int rc = loss_levels_core(cls_levels, box_levels, level_anchors, L, dtype, B, K, anchors, anchor_bstride, gt_boxes, gt_labels,
+                                    gt_off, matches, special_rows, num_fg, params, out_loss, grad_cls_levels, grad_box_levels, workspace,
+                                    workspace_bytes, stream, nullptr, state);
     g_prof.start = g_prof.stop = nullptr;
     return rc;
 }

@@ -69,6 +69,9 @@ _SIDE_STREAMS = {}
 # exposes the launch ramp of the 1 536 workgroups, which the plain kernel hides under the early workgroups' streaming), the matching
 # pass alone +15 us when other waves' streaming covers it and ~45 us when everything waits behind the barrier.
 FUSE_MATCH = os.environ.get("RN_FUSE_MATCH", "0") == "1"
+# The two batch losses from the streaming kernel itself instead of a one-block finalize launch behind it (rn_loss_fwd_bwd_levels_fin:
+# fixed-point partial sums through device-scope atomics, workgroup 0 waits for the last arrival): same bits, one dependent launch less
+IN_KERNEL_FINALIZE = True
 
 
 def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
@@ -107,7 +110,7 @@ class _FusedDenseHeadLossLevels(torch.autograd.Function):
                 matches, num_fg, special = ops.iou_match(anchors, gt_boxes, gt_off, B, fg_thr, bg_thr, want_special=True, flagged_only=True,
                                                          zeroed_num_fg=pack.num_fg if pack is not None else None)
             loss, gcls, gbox = ops.loss_fwd_bwd_levels(cls_levels, box_levels, anchors, gt_boxes, gt_labels, gt_off, matches,
-                                                       num_fg, params, want_grad, special=special)
+                                                       num_fg, params, want_grad, special=special, in_kernel_finalize=IN_KERNEL_FINALIZE)
         ctx.grads = (gcls, gbox)
         ctx.meta = [(c.shape, c.dtype) for c in cls_levels] + [(b.shape, b.dtype) for b in box_levels]
         # two scalar outputs (views of the kernel's f32[2]): backward then receives the two upstream scalars directly, without

@@ -8,8 +8,8 @@ data-parallel split reproduces exactly (per-image normaliser, Q8).  The learning
 (``synth.TRAJ_OPT``: 1e-3 diverges on the synthetic weights and makes the 5-step map chaotic).
 
 Held to it: (a) this package's eager step, (b) ``graph.CapturedTrainStep`` (2 eager steps + capture + 2 replays),
-fp32 and bf16 autocast on bf16 working copies under ``MasterSGD``, (c) two ranks on the split batch through the segmented graphs
-(``tools/ddp_two_rank.py --fixture traj``).  Tolerances: fp32 per-step losses rel <= 1e-3, bf16 <= 2e-2; parameter
+fp32, bf16 autocast on bf16 working copies and fp16 autocast on fp16 working copies under a GradScaler, all with ``MasterSGD``, (c) two ranks on the split batch through the segmented graphs
+(``tools/ddp_two_rank.py --fixture traj``).  Tolerances: per-step losses fp32 rel <= 1e-4, 16-bit <= 2e-2; parameter
 movement: see ``_BOUNDS`` (measured on MI355X, then fixed with margin).
 """
 import os
@@ -33,11 +33,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 #           element error / rms(d_ref).
 # With live BatchNorm the deep layers see 4 x 5 positions x 2 images: their batch statistics amplify rounding differences (MIOpen's fp32
 # algorithm choice, 16-bit activations) in a handful of BN parameters, which the per-parameter projections of small tensors show at once.
-_BOUNDS = {("32", "frozen"): dict(total=1e-2, norm=1e-2, proj=2e-2, sample=1e-1),
-           ("32", "live"): dict(total=3e-2, norm=2e-2),
-           ("bf16", "frozen"): dict(total=0.25, norm=0.25), ("bf16", "live"): dict(total=0.5, norm=0.3),
-           ("16", "frozen"): dict(total=0.25, norm=0.25), ("16", "live"): dict(total=0.5, norm=0.3)}
-_LOSS_RTOL = {"32": 1e-3, "bf16": 2e-2, "16": 2e-2}
+_BOUNDS = {("32", "frozen"): dict(total=2e-4, norm=1e-3, proj=1e-2, sample=5e-2),       # measured 1.3e-5 / 6.4e-5 / 1.1e-3 / 4.9e-3
+           ("32", "live"): dict(total=5e-3, norm=2e-2),                                  # measured 4.0e-4 / 6.3e-3
+           ("bf16", "frozen"): dict(total=5e-2, norm=5e-2), ("bf16", "live"): dict(total=0.12, norm=0.3),      # 1.4e-2 / 1.3e-2; 4.0e-2 / 0.12
+           ("16", "frozen"): dict(total=4e-2, norm=5e-2), ("16", "live"): dict(total=5e-2, norm=0.15)}         # 1.2e-2 / 1.3e-2; 1.3e-2 / 5.0e-2
+_LOSS_RTOL = {"32": 1e-4, "bf16": 2e-2, "16": 2e-2}              # measured 1.4e-6 / 5.9e-3 / 4.7e-3 (VERDICT r4 asked 1e-3 / 2e-2)
 
 
 def _fixture():
