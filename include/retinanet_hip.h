@@ -174,10 +174,11 @@ int rn_loss_fwd_bwd_levels_ex(const void *const *cls_levels, const void *const *
                               size_t workspace_bytes, void *stream, void *event_start, void *event_stop);
 /* rn_loss_fwd_bwd_levels_ex WITHOUT the one-block finalize launch (ABI 8): every workgroup of the streaming kernel adds its two
  * partial sums -- as 2^-32 fixed point, so that the total is an integer sum and therefore the same bits in any order -- to two words
- * of `state` with relaxed device-scope atomics and bumps an arrival counter in the same cache line; workgroup 0 waits for the last
- * arrival, writes out_loss and leaves the words zeroed.  The finalize KERNEL of the other entry points uses the same arithmetic, so
- * both give the same bits.  `state`: >= 64 bytes, 64-byte aligned (the first line of a rn_loss_match_state_bytes buffer serves: this
- * form uses words 8..13, the fused form words 0, 1); the caller zero-fills it ONCE, every completed call leaves it zero-filled, and
+ * of one of 64 cache lines of `state` with relaxed device-scope atomics and bumps that line's arrival counter; one wave of workgroup 0
+ * polls the 64 counters, sums the lines when everybody has arrived, writes out_loss and leaves the words zeroed.  The finalize KERNEL
+ * of the other entry points uses the same arithmetic, so both give the same bits.  `state`: >= 256 + 64 * 64 = 4 352 bytes, 64-byte
+ * aligned (a rn_loss_match_state_bytes(>= 1 072) buffer serves: this form uses bytes 256 .. 4 351, the fused form words 0, 1 and its
+ * counters, all zero between calls); the caller zero-fills it ONCE, every completed call leaves it zero-filled, and
  * it must not be shared by calls that can run concurrently (one per stream).  A workgroup that never arrives (a faulted launch) makes
  * out_loss NaN after a bounded wait instead of hanging the stream. */
 int rn_loss_fwd_bwd_levels_fin(const void *const *cls_levels, const void *const *box_levels,

@@ -216,6 +216,13 @@ __device__ __forceinline__ long long loss_fix(const float v, unsigned &flags)
     }
     return __double2ll_rn((double)v * 4294967296.0);
 }
+constexpr int FIN_LINES = 64;                                    // cache lines of the in-kernel finalize (one per lane of the polling wave)
+__device__ __forceinline__ long long shfl_xor_ll(const long long v, const int o)
+{
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)((unsigned long long)v & 0xffffffffull), o, RN_WAVE);
+    const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)((unsigned long long)v >> 32), o, RN_WAVE);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ float loss_unfix(const long long s, const unsigned flags)
 {
     if (flags & 1u || (flags & 6u) == 6u) return __builtin_nanf("");
@@ -787,36 +794,56 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
 #pragma unroll
         for (int w = 0; w < LOSS_WAVES; ++w) { c += s_part[w][0]; rg += s_part[w][1]; }
         if (a.fin) {
-            // The batch sums WITHOUT a finalize launch: every workgroup adds its two partials, as 2^-32 fixed point, to two 64-bit
-            // words and then bumps the arrival counter -- relaxed device-scope atomics that return nothing (1 536 of them arriving on
-            // one line cost nothing measurable) and live in ONE cache line, so that they are performed in program order
-            // at the same L2 channel; integer addition is order-independent, so the result is the same whoever adds first.
-            // Workgroup 0 waits for the last arrival, converts, and leaves the words zeroed for the next launch on this state buffer.
-            unsigned long long *const sums = (unsigned long long *)(a.fin + 2);
+            // The batch sums WITHOUT a finalize launch: every workgroup adds its two partials, as 2^-32 fixed point, to the two 64-bit
+            // words of ONE OF 64 cache lines (line = workgroup index mod 64: 1 536 workgroups adding to one line serialise at its L2
+            // channel -- measured +15 us --, 24 per line do not) and then bumps that line's arrival counter -- relaxed device-scope
+            // atomics that return nothing; a line's three words are performed in program order at its channel.  Integer addition is
+            // order-independent, so the result is the same whoever adds first.  Wave 0 of workgroup 0 polls the 64 counters (one per
+            // lane), sums the lines when all workgroups have arrived, converts, and leaves every word zeroed for the next launch.
+            unsigned *const line = a.fin + (blockIdx.x & (FIN_LINES - 1)) * 16;
+            unsigned long long *const sums = (unsigned long long *)(line + 2);
             unsigned fl_c = 0u, fl_r = 0u;
             const long long fc = loss_fix(c, fl_c), fr = loss_fix(rg, fl_r);
             __hip_atomic_fetch_add(sums + 0, (unsigned long long)fc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_add(sums + 1, (unsigned long long)fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (fl_c | fl_r) __hip_atomic_fetch_or(a.fin + 1, fl_c | (fl_r << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (rare: non-finite logits)
-            __hip_atomic_fetch_add(a.fin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (blockIdx.x == 0) {
-                unsigned spins = 0;
-                bool ok = true;
-                while (__hip_atomic_load(a.fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > (1u << 22)) { ok = false; break; }          // (a workgroup that never arrives = a faulted launch: poison, do not hang)
-                }
-                const long long sc = (long long)__hip_atomic_load(sums + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const long long sr = (long long)__hip_atomic_load(sums + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned fl = __hip_atomic_load(a.fin + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                a.out_loss[0] = ok ? loss_unfix(sc, fl & 0xffu) : __builtin_nanf("");
-                a.out_loss[1] = ok ? loss_unfix(sr, (fl >> 8) & 0xffu) : __builtin_nanf("");
-                __hip_atomic_store(sums + 0, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(sums + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(a.fin + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(a.fin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        } else {
+            if (fl_c | fl_r) __hip_atomic_fetch_or(line + 1, fl_c | (fl_r << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (rare: non-finite logits)
+            __hip_atomic_fetch_add(line, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (a.fin && blockIdx.x == 0 && wave == 0) {                 // (thread 0's own arrival above precedes this in program order: same wave)
+        static_assert(FIN_LINES == RN_WAVE, "one line per lane");
+        unsigned *const mine = a.fin + lane * 16;
+        unsigned long long *const msum = (unsigned long long *)(mine + 2);
+        unsigned spins = 0;
+        bool ok = true;
+        while (true) {
+            const int arrived = rn::wave_sum_i((int)__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (arrived >= (int)gridDim.x) break;
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 22)) { ok = false; break; }      // (a workgroup that never arrives = a faulted launch: poison, do not hang)
+        }
+        long long sc = (long long)__hip_atomic_load(msum + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long long sr = (long long)__hip_atomic_load(msum + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned fl = __hip_atomic_load(mine + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            sc += shfl_xor_ll(sc, o); sr += shfl_xor_ll(sr, o);
+            fl |= (unsigned)__shfl_xor((int)fl, o, RN_WAVE);
+        }
+        __hip_atomic_store(msum + 0, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(msum + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+            a.out_loss[0] = ok ? loss_unfix(sc, fl & 0xffu) : __builtin_nanf("");
+            a.out_loss[1] = ok ? loss_unfix(sr, (fl >> 8) & 0xffu) : __builtin_nanf("");
+        }
+    }
+    if (!a.fin && threadIdx.x == 0) {
+        {
+            float c = 0.0f, rg = 0.0f;
+#pragma unroll
+            for (int w = 0; w < LOSS_WAVES; ++w) { c += s_part[w][0]; rg += s_part[w][1]; }
             a.part_stream[blockIdx.x] = make_float2(c, rg);
         }
     }
@@ -1059,7 +1086,7 @@ static int loss_levels_core(const void *const *cls_levels, const void *const *bo
     a.p = *params;
     a.alpha_pos = (float)(1.0 - (double)params->alpha);
     a.part_stream = (float2 *)workspace;
-    a.fin = fin_state ? (unsigned *)fin_state + 8 : nullptr;            // words 8..13 of the state line (0, 1: the fused form's barrier words)
+    a.fin = fin_state ? (unsigned *)fin_state + 64 : nullptr;           // 64 cache lines from byte 256 on (words 0, 1: the fused form's barrier words)
     a.out_loss = out_loss;
     a.fg_thr = a.bg_thr = 0.0f; a.nfg_acc = nullptr; a.bar = nullptr; a.matches_out = nullptr;
     if (fm) {

@@ -132,6 +132,71 @@ __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_batch_kernel(
 }
 
 // ============================================================================================================
+// The train shape proper (round 5): shared anchors and at most 128 GT boxes in the WHOLE batch (B = 8 x T = 8 = 64).  No LDS and no
+// workgroup barrier: lane j of every wave loads GT rows j and j + 64 of the batch itself (one coalesced 16-byte load each: the rows
+// are L2 hits after the first wave), computes their areas, and the pair loop fetches a box with v_readlane exactly as the batch
+// kernel does after its LDS staging.  One thread = one anchor x ALL images, so the grid is A / 256 workgroups (788 instead of the
+// batch kernel's 1 576 at B = 8) and a wave's dependent chain is gt_off (scalar) -> GT rows -> pairs -> stores: the batch kernel's
+// two __syncthreads and its LDS round trip are gone.  This kernel is launch-latency-bound whatever it does; what is
+// left is the shortest chain that still produces the codes, the flag words and num_fg.
+constexpr int SMALL_GT_MAX = 2 * RN_WAVE;
+template <bool SPARSE>
+__global__ __launch_bounds__(MATCH_BLOCK) void iou_match_small_kernel(
+    const rn::f32x4 *__restrict__ anchors, const rn::f32x4 *__restrict__ gt, const int32_t *__restrict__ gt_off,
+    const int B, const int64_t A, const float fg_thr, const float bg_thr, int64_t *__restrict__ matches,
+    int32_t *__restrict__ num_fg, unsigned long long *__restrict__ special)
+{
+    const int tid = threadIdx.x, lane = tid & (RN_WAVE - 1);
+    const int64_t a_idx = (int64_t)blockIdx.x * MATCH_BLOCK + tid;
+    const bool live = a_idx < A;
+    rn::f32x4 an = {0.f, 0.f, 0.f, 0.f};
+    if (live) an = anchors[a_idx];
+    const int g0 = gt_off[0];
+    const int total = min(max(gt_off[B] - g0, 0), SMALL_GT_MAX);        // (the host promised <= SMALL_GT_MAX)
+    rn::f32x4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = {0.f, 0.f, 0.f, 0.f};
+    if (lane < total) m0 = gt[g0 + lane];
+    if (lane + RN_WAVE < total) m1 = gt[g0 + RN_WAVE + lane];
+    const float ar0 = (m0.z - m0.x) * (m0.w - m0.y), ar1 = (m1.z - m1.x) * (m1.w - m1.y);
+    const bool gt_ok = (lane >= total || gt_is_proper(m0, ar0)) && (lane + RN_WAVE >= total || gt_is_proper(m1, ar1));
+    const float area_a = (an.z - an.x) * (an.w - an.y);
+    const bool fast = __all(gt_ok) && __all(anchor_is_proper(an, area_a));
+    WaveBox bb = {0.f, 0.f, 0.f, 0.f};
+    if (fast) bb = WaveBox{wave_min(an.x), wave_min(an.y), wave_max(an.z), wave_max(an.w)};
+
+    for (int b = 0; b < B; ++b) {
+        // clamped against what was loaded: an inconsistent gt_off matches against a truncated GT set instead of reading other rows
+        const int j0 = min(max(gt_off[b] - g0, 0), total);
+        const int T = min(max(gt_off[b + 1] - gt_off[b], 0), total - j0);
+        float best = 0.0f;
+        int bi = 0;
+        Best bb2 = {0.0f, 0, false};
+        for (int l = 0; l < T; ++l) {
+            const int j = j0 + l;                                        // wave-uniform
+            const GtBox g = j < RN_WAVE ? gt_of_lane(m0, ar0, j) : gt_of_lane(m1, ar1, j - RN_WAVE);
+            if (fast) {
+                if (may_overlap(bb, g)) {
+                    const float inter = inter_fast(g, an);
+                    if (__any(inter != 0.0f)) {
+                        const float v = inter / ((g.area + area_a) - inter);
+                        if (v > best) { best = v; bi = l; }
+                    }
+                }
+            } else {
+                careful_update(bb2, iou_pair(vec(g), g.area, an, area_a), l);
+            }
+        }
+        if (!fast) { best = bb2.v; bi = bb2.i; }
+        const int64_t r = classify(best, bi, T, fg_thr, bg_thr);
+        if (live && (!SPARSE || r != -1)) matches[(int64_t)b * A + a_idx] = r;
+        if (special) special_word(special, b, A, a_idx, live && r != -1);
+        if (num_fg) {
+            const unsigned long long fg = __ballot(live && r >= 0);
+            if (lane == 0 && fg) atomicAdd(&num_fg[b], __popcll(fg));
+        }
+    }
+}
+
+// ============================================================================================================
 // General shape: R anchors per thread, GT tiles in LDS.
 template <int R>
 __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_tile_kernel(
@@ -501,7 +566,14 @@ RN_API int rn_iou_match_special_ex(const float *anchors, int64_t anchor_bstride,
     }
     // The batch kernel needs host knowledge of sum(T) (gt_off lives on the device and this call never syncs):
     // callers that know it pass total_gt >= 0; -1 means unknown -> the general kernel.
-    if (anchor_bstride == 0 && B <= 64 && total_gt >= 0 && total_gt <= BATCH_GT_MAX && total_gt <= 32 * (int64_t)B) {
+    if (anchor_bstride == 0 && B <= 64 && total_gt >= 0 && total_gt <= SMALL_GT_MAX && A >= 32 * MATCH_BLOCK) {
+        // a few GT boxes in the whole batch and enough anchors to fill the chip with one thread per anchor: no LDS, no barrier
+        const dim3 grid((unsigned)((A + MATCH_BLOCK - 1) / MATCH_BLOCK));
+        if (sparse) hipLaunchKernelGGL(iou_match_small_kernel<true>, grid, dim3(MATCH_BLOCK), 0, st, (const rn::f32x4 *)anchors,
+                                       (const rn::f32x4 *)gt_boxes, gt_off, B, A, fg_thr, bg_thr, matches, num_fg, special);
+        else hipLaunchKernelGGL(iou_match_small_kernel<false>, grid, dim3(MATCH_BLOCK), 0, st, (const rn::f32x4 *)anchors,
+                                (const rn::f32x4 *)gt_boxes, gt_off, B, A, fg_thr, bg_thr, matches, num_fg, special);
+    } else if (anchor_bstride == 0 && B <= 64 && total_gt >= 0 && total_gt <= BATCH_GT_MAX && total_gt <= 32 * (int64_t)B) {
         // images per workgroup: all of them when the anchors alone give >= 1024 workgroups, else split the batch
         const int64_t bx = (A + MATCH_BLOCK - 1) / MATCH_BLOCK;
         int by = (int)((1024 + bx - 1) / bx);
