@@ -70,8 +70,10 @@ __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_batch_kernel(
     const bool live = a_idx < A;
     rn::f32x4 an = {0.f, 0.f, 0.f, 0.f};
     if (live) an = anchors[a_idx];
-    const int g0 = gt_off[b0];                                          // scalar loads (uniform addresses)
-    const int total = min(gt_off[b1] - g0, BATCH_GT_MAX);               // (the host promised <= BATCH_GT_MAX)
+    // the group's offsets in one vector load (lane l holds gt_off[b0 + l], ipb <= 64 - 1 lanes; see iou_match_small_kernel)
+    const int goff = gt_off[b0 + min(lane, b1 - b0)];
+    const int g0 = __builtin_amdgcn_readlane(goff, 0);
+    const int total = min(__builtin_amdgcn_readlane(goff, b1 - b0) - g0, BATCH_GT_MAX);      // (the host promised <= BATCH_GT_MAX)
     if (tid == 0) s_bad = 0;
     __syncthreads();
     bool ok = true;
@@ -93,8 +95,9 @@ __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_batch_kernel(
     for (int b = b0; b < b1; ++b) {
         // clamped against what was staged: an inconsistent gt_off (rows beyond the host-supplied total / beyond BATCH_GT_MAX)
         // then matches against a truncated GT set instead of indexing past the LDS arrays
-        const int j0 = min(max(gt_off[b] - g0, 0), total);
-        const int T = min(max(gt_off[b + 1] - gt_off[b], 0), total - j0);
+        const int ob = __builtin_amdgcn_readlane(goff, b - b0), oe = __builtin_amdgcn_readlane(goff, b - b0 + 1);
+        const int j0 = min(max(ob - g0, 0), total);
+        const int T = min(max(oe - ob, 0), total - j0);
         float best = 0.0f;
         int bi = 0;
         Best bb2 = {0.0f, 0, false};
@@ -151,8 +154,12 @@ __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_small_kernel(
     const bool live = a_idx < A;
     rn::f32x4 an = {0.f, 0.f, 0.f, 0.f};
     if (live) an = anchors[a_idx];
-    const int g0 = gt_off[0];
-    const int total = min(max(gt_off[B] - g0, 0), SMALL_GT_MAX);        // (the host promised <= SMALL_GT_MAX)
+    // all B + 1 offsets in ONE vector load (lane l holds gt_off[l]; B <= 63): a scalar load of gt_off[b] inside the image loop costs a
+    // memory round trip per image, and eight of those in a row are most of this kernel's time (round 5: 16.9 us for the batch kernel,
+    // whose loop was 8 x (two dependent scalar loads -> LDS read -> ~300 ALU instructions))
+    const int goff = gt_off[lane <= B ? lane : B];
+    const int g0 = __builtin_amdgcn_readlane(goff, 0);
+    const int total = min(max(__builtin_amdgcn_readlane(goff, B) - g0, 0), SMALL_GT_MAX);        // (the host promised <= SMALL_GT_MAX)
     rn::f32x4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = {0.f, 0.f, 0.f, 0.f};
     if (lane < total) m0 = gt[g0 + lane];
     if (lane + RN_WAVE < total) m1 = gt[g0 + RN_WAVE + lane];
@@ -165,8 +172,9 @@ __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_small_kernel(
 
     for (int b = 0; b < B; ++b) {
         // clamped against what was loaded: an inconsistent gt_off matches against a truncated GT set instead of reading other rows
-        const int j0 = min(max(gt_off[b] - g0, 0), total);
-        const int T = min(max(gt_off[b + 1] - gt_off[b], 0), total - j0);
+        const int ob = __builtin_amdgcn_readlane(goff, b), oe = __builtin_amdgcn_readlane(goff, b + 1);
+        const int j0 = min(max(ob - g0, 0), total);
+        const int T = min(max(oe - ob, 0), total - j0);
         float best = 0.0f;
         int bi = 0;
         Best bb2 = {0.0f, 0, false};
@@ -566,7 +574,7 @@ RN_API int rn_iou_match_special_ex(const float *anchors, int64_t anchor_bstride,
     }
     // The batch kernel needs host knowledge of sum(T) (gt_off lives on the device and this call never syncs):
     // callers that know it pass total_gt >= 0; -1 means unknown -> the general kernel.
-    if (anchor_bstride == 0 && B <= 64 && total_gt >= 0 && total_gt <= SMALL_GT_MAX && A >= 32 * MATCH_BLOCK) {
+    if (anchor_bstride == 0 && B <= 63 && total_gt >= 0 && total_gt <= SMALL_GT_MAX && A >= 32 * MATCH_BLOCK) {
         // a few GT boxes in the whole batch and enough anchors to fill the chip with one thread per anchor: no LDS, no barrier
         const dim3 grid((unsigned)((A + MATCH_BLOCK - 1) / MATCH_BLOCK));
         if (sparse) hipLaunchKernelGGL(iou_match_small_kernel<true>, grid, dim3(MATCH_BLOCK), 0, st, (const rn::f32x4 *)anchors,
@@ -578,6 +586,7 @@ RN_API int rn_iou_match_special_ex(const float *anchors, int64_t anchor_bstride,
         const int64_t bx = (A + MATCH_BLOCK - 1) / MATCH_BLOCK;
         int by = (int)((1024 + bx - 1) / bx);
         by = by < 1 ? 1 : (by > B ? B : by);
+        if ((B + by - 1) / by > RN_WAVE - 1) by = 2;                    // (a workgroup's offsets live one per lane: at most 63 images + 1)
         const int ipb = (B + by - 1) / by;
         const dim3 grid((unsigned)bx, (unsigned)((B + ipb - 1) / ipb));
         if (sparse) hipLaunchKernelGGL(iou_match_batch_kernel<true>, grid, dim3(MATCH_BLOCK), 0, st, (const rn::f32x4 *)anchors,
