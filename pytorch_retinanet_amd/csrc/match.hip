@@ -106,14 +106,16 @@ __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_batch_kernel(
             const float mine_a = s_area[j0 + c + lane];
             const int m = min(RN_WAVE, T - c);
             if (fast) {
-                for (int l = 0; l < m; ++l) {
+                // 64 boxes culled by one ballot against the wave's bounding box (see iou_match_small_kernel); survivors in ascending order
+                unsigned long long ov = __ballot(lane < m && may_overlap(bb, mine));
+                while (ov) {                                // wave-uniform
+                    const int l = __builtin_ctzll(ov);
+                    ov &= ov - 1ull;
                     const GtBox g = gt_of_lane(mine, mine_a, l);
-                    if (may_overlap(bb, g)) {               // wave-uniform
-                        const float inter = inter_fast(g, an);
-                        if (__any(inter != 0.0f)) {
-                            const float v = inter / ((g.area + area_a) - inter);
-                            if (v > best) { best = v; bi = c + l; }
-                        }
+                    const float inter = inter_fast(g, an);
+                    if (__any(inter != 0.0f)) {
+                        const float v = inter / ((g.area + area_a) - inter);
+                        if (v > best) { best = v; bi = c + l; }
                     }
                 }
             } else {
@@ -143,6 +145,13 @@ __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_batch_kernel(
 // two __syncthreads and its LDS round trip are gone.  This kernel is launch-latency-bound whatever it does; what is
 // left is the shortest chain that still produces the codes, the flag words and num_fg.
 constexpr int SMALL_GT_MAX = 2 * RN_WAVE;
+// bits [lo, hi) of a 64-bit word, 0 <= lo <= hi <= 64
+__device__ __forceinline__ unsigned long long bits64(const int lo, const int hi)
+{
+    const unsigned long long upto_hi = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
+    const unsigned long long upto_lo = lo >= 64 ? ~0ull : ((1ull << lo) - 1ull);
+    return upto_hi & ~upto_lo;
+}
 template <bool SPARSE>
 __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_small_kernel(
     const rn::f32x4 *__restrict__ anchors, const rn::f32x4 *__restrict__ gt, const int32_t *__restrict__ gt_off,
@@ -170,6 +179,17 @@ __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_small_kernel(
     WaveBox bb = {0.f, 0.f, 0.f, 0.f};
     if (fast) bb = WaveBox{wave_min(an.x), wave_min(an.y), wave_max(an.z), wave_max(an.w)};
 
+    // Fast path: ALL the batch's GT boxes are tested against the wave's bounding box at once -- the boxes are lane-resident, the
+    // bounding box is wave-uniform: four compares and a ballot per register cull up to 128 boxes, where a per-box test (v_readlane x 5,
+    // four compares, a branch) cost ~50 issue cycles for each of the 64 boxes of the train shape: 16 of this kernel's 23 us (round-5
+    // ablation, profiles/r05_k2_ablation.txt: 23.1 us, 7.1 without the pair loop).  A box that misses the bounding box has inter == 0
+    // with every anchor of the wave and cannot change (max, first arg-max); the survivors (~6 % at the train shape) are visited in
+    // ascending order, so the first index still wins ties.
+    unsigned long long ov0 = 0ull, ov1 = 0ull;
+    if (fast) {
+        ov0 = __ballot(lane < total && may_overlap(bb, m0));
+        ov1 = __ballot(lane + RN_WAVE < total && may_overlap(bb, m1));
+    }
     for (int b = 0; b < B; ++b) {
         // clamped against what was loaded: an inconsistent gt_off matches against a truncated GT set instead of reading other rows
         const int ob = __builtin_amdgcn_readlane(goff, b), oe = __builtin_amdgcn_readlane(goff, b + 1);
@@ -178,18 +198,26 @@ __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_small_kernel(
         float best = 0.0f;
         int bi = 0;
         Best bb2 = {0.0f, 0, false};
-        for (int l = 0; l < T; ++l) {
-            const int j = j0 + l;                                        // wave-uniform
-            const GtBox g = j < RN_WAVE ? gt_of_lane(m0, ar0, j) : gt_of_lane(m1, ar1, j - RN_WAVE);
-            if (fast) {
-                if (may_overlap(bb, g)) {
-                    const float inter = inter_fast(g, an);
-                    if (__any(inter != 0.0f)) {
-                        const float v = inter / ((g.area + area_a) - inter);
-                        if (v > best) { best = v; bi = l; }
-                    }
+        if (fast) {
+            // the image's rows [j0, j0 + T) of the two 64-bit survivor masks
+            const int j1 = j0 + T;
+            unsigned long long p0 = ov0 & bits64(min(j0, 64), min(j1, 64));
+            unsigned long long p1 = ov1 & bits64(max(j0, 64) - 64, max(j1, 64) - 64);
+            while (p0 | p1) {                                           // wave-uniform
+                int j;
+                if (p0) { j = __builtin_ctzll(p0); p0 &= p0 - 1ull; }
+                else { j = 64 + __builtin_ctzll(p1); p1 &= p1 - 1ull; }
+                const GtBox g = j < RN_WAVE ? gt_of_lane(m0, ar0, j) : gt_of_lane(m1, ar1, j - RN_WAVE);
+                const float inter = inter_fast(g, an);
+                if (__any(inter != 0.0f)) {
+                    const float v = inter / ((g.area + area_a) - inter);
+                    if (v > best) { best = v; bi = j - j0; }
                 }
-            } else {
+            }
+        } else {
+            for (int l = 0; l < T; ++l) {
+                const int j = j0 + l;                                    // wave-uniform
+                const GtBox g = j < RN_WAVE ? gt_of_lane(m0, ar0, j) : gt_of_lane(m1, ar1, j - RN_WAVE);
                 careful_update(bb2, iou_pair(vec(g), g.area, an, area_a), l);
             }
         }
