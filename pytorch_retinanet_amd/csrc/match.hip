@@ -156,10 +156,24 @@ template <bool SPARSE>
 __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_small_kernel(
     const rn::f32x4 *__restrict__ anchors, const rn::f32x4 *__restrict__ gt, const int32_t *__restrict__ gt_off,
     const int B, const int64_t A, const float fg_thr, const float bg_thr, int64_t *__restrict__ matches,
-    int32_t *__restrict__ num_fg, unsigned long long *__restrict__ special)
+    int32_t *__restrict__ num_fg, unsigned long long *__restrict__ special, const int n_plain, const int nsplit)
 {
     const int tid = threadIdx.x, lane = tid & (RN_WAVE - 1);
-    const int64_t a_idx = (int64_t)blockIdx.x * MATCH_BLOCK + tid;
+    // Load balance.  A wave's time is its number of cull survivors: 4.7 of the batch's 64 boxes on P3, 39 on P6, 63 on P7 (big anchors
+    // overlap everything) -- the eleven P7 waves alone ran a 9 us chain at the END of the launch.  So (1) the workgroups walk the anchor
+    // list BACK TO FRONT (an FPN anchor list ends with its coarsest level), and (2) the last 1/16 of the anchor blocks is split over the
+    // images as well: anchor block n_plain + t / nsplit, image t % nsplit -- `nsplit` short waves instead of one long one.  Both are
+    // pure scheduling: every (anchor, image) pair is still computed by exactly one lane.
+    const int blk = (int)gridDim.x - 1 - (int)blockIdx.x;
+    int ablock = blk, b_lo = 0, b_hi = B;
+    if (blk >= n_plain) {
+        const int t = blk - n_plain;
+        ablock = n_plain + t / nsplit;
+        const int ipp = (B + nsplit - 1) / nsplit;
+        b_lo = (t % nsplit) * ipp;
+        b_hi = min(B, b_lo + ipp);
+    }
+    const int64_t a_idx = (int64_t)ablock * MATCH_BLOCK + tid;
     const bool live = a_idx < A;
     rn::f32x4 an = {0.f, 0.f, 0.f, 0.f};
     if (live) an = anchors[a_idx];
@@ -190,7 +204,7 @@ __global__ __launch_bounds__(MATCH_BLOCK) void iou_match_small_kernel(
         ov0 = __ballot(lane < total && may_overlap(bb, m0));
         ov1 = __ballot(lane + RN_WAVE < total && may_overlap(bb, m1));
     }
-    for (int b = 0; b < B; ++b) {
+    for (int b = b_lo; b < b_hi; ++b) {
         // clamped against what was loaded: an inconsistent gt_off matches against a truncated GT set instead of reading other rows
         const int ob = __builtin_amdgcn_readlane(goff, b), oe = __builtin_amdgcn_readlane(goff, b + 1);
         const int j0 = min(max(ob - g0, 0), total);
@@ -604,11 +618,15 @@ RN_API int rn_iou_match_special_ex(const float *anchors, int64_t anchor_bstride,
     // callers that know it pass total_gt >= 0; -1 means unknown -> the general kernel.
     if (anchor_bstride == 0 && B <= 63 && total_gt >= 0 && total_gt <= SMALL_GT_MAX && A >= 32 * MATCH_BLOCK) {
         // a few GT boxes in the whole batch and enough anchors to fill the chip with one thread per anchor: no LDS, no barrier
-        const dim3 grid((unsigned)((A + MATCH_BLOCK - 1) / MATCH_BLOCK));
+        const int nblk = (int)((A + MATCH_BLOCK - 1) / MATCH_BLOCK);
+        const int tail = nblk / 16 > 0 ? nblk / 16 : 1;                 // anchor blocks that are split over the images too (see the kernel)
+        const int nsplit = B < 8 ? B : 8;
+        const int n_plain = nblk - tail;
+        const dim3 grid((unsigned)(n_plain + tail * nsplit));
         if (sparse) hipLaunchKernelGGL(iou_match_small_kernel<true>, grid, dim3(MATCH_BLOCK), 0, st, (const rn::f32x4 *)anchors,
-                                       (const rn::f32x4 *)gt_boxes, gt_off, B, A, fg_thr, bg_thr, matches, num_fg, special);
+                                       (const rn::f32x4 *)gt_boxes, gt_off, B, A, fg_thr, bg_thr, matches, num_fg, special, n_plain, nsplit);
         else hipLaunchKernelGGL(iou_match_small_kernel<false>, grid, dim3(MATCH_BLOCK), 0, st, (const rn::f32x4 *)anchors,
-                                (const rn::f32x4 *)gt_boxes, gt_off, B, A, fg_thr, bg_thr, matches, num_fg, special);
+                                (const rn::f32x4 *)gt_boxes, gt_off, B, A, fg_thr, bg_thr, matches, num_fg, special, n_plain, nsplit);
     } else if (anchor_bstride == 0 && B <= 64 && total_gt >= 0 && total_gt <= BATCH_GT_MAX && total_gt <= 32 * (int64_t)B) {
         // images per workgroup: all of them when the anchors alone give >= 1024 workgroups, else split the batch
         const int64_t bx = (A + MATCH_BLOCK - 1) / MATCH_BLOCK;
