@@ -299,17 +299,13 @@ int rn_bn_bwd_apply(const void *dy, const void *y, const void *x, void *dx, void
  *   RN_PW_EPI_RESID        y += resid * rbits  (the identity branch's gradient: resid [M][N], rbits [M][N / 8])
  *   RN_PW_EPI_RELU_BWD     y = y * [fma(zprev, ea, eb) > 0 in bf16]; partial f32[walkers][2][N] = (sum y, sum y * (zprev - emean) * einv)
  *                          -- ReLU backward + the two sums of the BatchNorm backward of the layer BELOW this data gradient
- *   RN_PW_EPI_NEXT_BN      (OR-ed with RN_PW_EPI_RESID, no prologue; ABI 8) y -- a bottleneck's input gradient -- is the OUTPUT gradient of the
- *                          block below: partial f32[walkers][2][N] = (sum y', sum y' * (zprev - emean) * einv), y' = y masked by zbits
- *                          [M][N / 8] (that block's output-ReLU bits): the backward sums of its last BatchNorm (retinanet/backbone.py:131-134),
- *                          which would otherwise re-read y in a pass of their own.  y itself is stored unmasked.
  *   RN_PW_EPI_BIAS         y = act(y + bias[n] (+ resid)), act = ReLU when `relu`: alone or OR-ed with RN_PW_EPI_RESID (unmasked, no prologue) --
  *                          inference: bn(conv(x)) with the BatchNorm folded into w and bias, + identity, + ReLU in the GEMM's epilogue
  *                          (retinanet/backbone.py:118-136 under eval(): one pass over the block's largest tensor less per convolution)
  * rn_pw_conv_wgrad: dw [N][taps][Cin] = sum_m gpro(g)[m][N] x xpro(x)[pos(m, tap)][Cin]; gpro: none / BN_BWD, xpro: none / AFFINE_RELU;
  * workspace rn_pw_wgrad_workspace_bytes(d) (f32 partials of the position splits, summed in a fixed order). */
 enum { RN_PW_PRO_NONE = 0, RN_PW_PRO_AFFINE_RELU = 1, RN_PW_PRO_BN_BWD = 2 };
-enum { RN_PW_EPI_NONE = 0, RN_PW_EPI_STATS = 1, RN_PW_EPI_RESID = 2, RN_PW_EPI_RELU_BWD = 4, RN_PW_EPI_BIAS = 8, RN_PW_EPI_NEXT_BN = 16 };
+enum { RN_PW_EPI_NONE = 0, RN_PW_EPI_STATS = 1, RN_PW_EPI_RESID = 2, RN_PW_EPI_RELU_BWD = 4, RN_PW_EPI_BIAS = 8 };
 /* dtype: element type of x / w / y / g / dw -- RN_BF16 or RN_F16 (0, what a caller from before ABI version 8 leaves in the struct's
  * tail padding, means RN_BF16); the struct's size did not change. */
 typedef struct rn_pw_conv { int64_t M; int32_t Cin, N, taps, stride, pad, Ho, Wo, H, W, dtype; } rn_pw_conv;
@@ -334,7 +330,6 @@ typedef struct rn_pw_epilogue {
     int32_t res_stride, res_h, res_w;
     int32_t relu;           /* RN_PW_EPI_BIAS: ReLU after the bias (and the residual) */
     const float *bias;      /* RN_PW_EPI_BIAS: f32 [N], 16-byte aligned */
-    const uint8_t *zbits;   /* RN_PW_EPI_NEXT_BN: [M][N / 8] (zprev, emean, einv as for RN_PW_EPI_RELU_BWD) */
 } rn_pw_epilogue;
 int rn_pw_walkers(int64_t M);
 int rn_pw_conv_forward(const rn_pw_conv *d, const void *x, const void *w, void *y, const rn_pw_prologue *pro,

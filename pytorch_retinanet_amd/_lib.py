@@ -42,12 +42,11 @@ class RnPwPrologue(C.Structure):
 class RnPwEpilogue(C.Structure):
     _fields_ = [("kind", C.c_int32), ("partial", C.c_void_p), ("resid", C.c_void_p), ("rbits", C.c_void_p), ("zprev", C.c_void_p),
                 ("ea", C.c_void_p), ("eb", C.c_void_p), ("emean", C.c_void_p), ("einv", C.c_void_p),
-                ("res_stride", C.c_int32), ("res_h", C.c_int32), ("res_w", C.c_int32), ("relu", C.c_int32), ("bias", C.c_void_p),
-                ("zbits", C.c_void_p)]
+                ("res_stride", C.c_int32), ("res_h", C.c_int32), ("res_w", C.c_int32), ("relu", C.c_int32), ("bias", C.c_void_p)]
 
 
 RN_PW_PRO_NONE, RN_PW_PRO_AFFINE_RELU, RN_PW_PRO_BN_BWD = 0, 1, 2
-RN_PW_EPI_NONE, RN_PW_EPI_STATS, RN_PW_EPI_RESID, RN_PW_EPI_RELU_BWD, RN_PW_EPI_BIAS, RN_PW_EPI_NEXT_BN = 0, 1, 2, 4, 8, 16
+RN_PW_EPI_NONE, RN_PW_EPI_STATS, RN_PW_EPI_RESID, RN_PW_EPI_RELU_BWD, RN_PW_EPI_BIAS = 0, 1, 2, 4, 8
 
 _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_size_t
 

@@ -31,7 +31,7 @@ constexpr int PW_MAX_GX = 512;                  // persistent row-tile walkers =
 #define PW_SWZ(row) (((row) >> 1) & 7)
 
 enum { PRO_NONE = 0, PRO_AFFINE_RELU = 1, PRO_BN_BWD = 2 };
-enum { EPI_STATS = 1, EPI_RESID = 2, EPI_RELU_BWD = 4, EPI_BIAS = 8, EPI_NEXT_BN = 16 };
+enum { EPI_STATS = 1, EPI_RESID = 2, EPI_RELU_BWD = 4, EPI_BIAS = 8 };
 
 // norm.hip: relu_alive_threshold<DT> -- half the smallest subnormal of the element type (ties to even -> 0)
 template <int DT> __device__ __forceinline__ float alive_dt() { return __uint_as_float(DT == RN_F16 ? 0x33000000u : 0x00004000u); }
@@ -49,9 +49,6 @@ struct PwArgs {
     int rs, rH, rW;                 // rs == 2: R lives on the stride-2 grid [n][ceil(rH / 2)][ceil(rW / 2)] of the output grid [n][rH][rW] and
                                     //          joins the rows with even (y, x) only (the data gradient of a 1x1 / stride-2 convolution)
     const uint16_t *Zp;             // EPI_RELU_BWD: Y = Y * [fma(Zp, ea, eb) > alive]; sums of Y and Y * (Zp - emean) * einv
-    const uint8_t *zbits;           // EPI_NEXT_BN (with EPI_RESID): Y is the output gradient of the block BELOW, whose block-output ReLU kept the
-                                    //   elements flagged in zbits [M][N / 8] and whose last BatchNorm had the input Zp [M][N]: partial =
-                                    //   (sum Y', sum Y' (Zp - emean) einv) with Y' = Y * zbits -- that BatchNorm's backward sums; Y is stored unmasked
     const float *ea, *eb, *emean, *einv;
     const float *bias;              // EPI_BIAS: Y = act(acc + bias[n] (+ R)), act = ReLU when relu_out (inference: a folded BatchNorm + residual + ReLU)
     int relu_out;
@@ -219,11 +216,11 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
     };
     // EPI_RELU_BWD: the four per-column vectors of the epilogue, in LDS behind the prologue coefficients: [ea | eb | emean | einv][BN]
     float *const s_epi = s_coef + (PRO == PRO_NONE ? 0 : (PRO == PRO_AFFINE_RELU ? 2 : 5) * a.Cin);
-    if (EPI & (EPI_RELU_BWD | EPI_NEXT_BN)) {                    // (EPI_NEXT_BN uses the last two only)
+    if (EPI & EPI_RELU_BWD) {
         for (int q = tid; q < 4 * BN; q += PW_THREADS) {
             const int which = q / BN, col = q - which * BN;
             const float *src = which == 0 ? a.ea : (which == 1 ? a.eb : (which == 2 ? a.emean : a.einv));
-            s_epi[q] = src ? src[n0 + col] : 0.0f;
+            s_epi[q] = src[n0 + col];
         }
         __syncthreads();
     }
@@ -244,7 +241,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
         uint32_t ebits[EROWS];
         // (the widest variant -- BatchNorm-backward prologue, 128 columns -- has no registers left for this prefetch across its
         // K loop: it spilled 41 VGPRs and ran 12 % slower; there the loads go out right after the last MFMA instead)
-        constexpr bool EPI_EARLY = !(PRO == PRO_BN_BWD && BN == 128) && !((EPI & EPI_NEXT_BN) && BN == 128);      // (EPI_NEXT_BN at 128 columns: 17 dwords spilled with the early prefetch)
+        constexpr bool EPI_EARLY = !(PRO == PRO_BN_BWD && BN == 128);
         auto load_epi = [&]() {
             if (EPI & (EPI_RESID | EPI_RELU_BWD)) {
 #pragma unroll
@@ -302,17 +299,6 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
 
         // ---- epilogue: accumulators -> f32 tile in LDS -> rows of 8-channel vectors
         if (!EPI_EARLY) load_epi();
-        rn::u32x4 ez[(EPI & EPI_NEXT_BN) ? EROWS : 1];           // EPI_NEXT_BN: the lower block's BatchNorm input and ReLU bits of this thread's rows,
-        uint32_t ezb[(EPI & EPI_NEXT_BN) ? EROWS : 1];           //   in flight under the accumulators' trip through LDS
-        if (EPI & EPI_NEXT_BN) {
-#pragma unroll
-            for (int i = 0; i < EROWS; ++i) {
-                const int m = m0 + erl + i * RL, mc = m < a.M ? m : a.M - 1;
-                const int64_t e = (int64_t)mc * a.N + n0 + ecg * 8;
-                ez[i] = *(const rn::u32x4 *)(a.Zp + e);
-                ezb[i] = (uint32_t)a.zbits[e >> 3];
-            }
-        }
         float *const tile = (float *)lds;                       // [128][BN]
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -349,18 +335,6 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
                     for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
                 }
                 rn::u32x4 o = rn::dt<DT>::pack(v);
-                if (EPI & EPI_NEXT_BN) {
-                    float z[8], emu[8], eis[8];
-                    rn::dt<DT>::unpack(o, v);                  // the sums are those of the stored (rounded) gradient, as a separate reduce pass would see it
-                    ld8f(s_epi + 2 * BN + ecg * 8, emu); ld8f(s_epi + 3 * BN + ecg * 8, eis);
-                    rn::dt<DT>::unpack(ez[i], z);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float vm = ((ezb[i] >> j) & 1u) ? v[j] : 0.0f;
-                        ssum[j] += vm;
-                        qsum[j] = fmaf(vm, (z[j] - emu[j]) * eis[j], qsum[j]);
-                    }
-                }
                 if (EPI & (EPI_STATS | EPI_RELU_BWD)) {
                     rn::dt<DT>::unpack(o, v);              // the statistics are those of the stored (rounded) tensor
                     if (EPI & EPI_RELU_BWD) {
@@ -386,7 +360,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
         __syncthreads();                                        // the tile is the next row tile's staging area
     }
 
-    if (EPI & (EPI_STATS | EPI_RELU_BWD | EPI_NEXT_BN)) {
+    if (EPI & (EPI_STATS | EPI_RELU_BWD)) {
         float *const red = (float *)lds;                        // [RL][2][BN]
 #pragma unroll
         for (int j = 0; j < 8; ++j) { red[(erl * 2 + 0) * BN + ecg * 8 + j] = ssum[j]; red[(erl * 2 + 1) * BN + ecg * 8 + j] = qsum[j]; }
@@ -643,7 +617,7 @@ int walkers(const int M)
 template <int DT, int BN, int PRO, int EPI> int launch_gemm_dt(const PwArgs &a, hipStream_t st)
 {
     constexpr int lds_main = 2 * (PW_BM * PW_BK * 2 + BN * PW_BK * 2) > PW_BM * BN * 4 ? 2 * (PW_BM * PW_BK * 2 + BN * PW_BK * 2) : PW_BM * BN * 4;
-    const int lds = lds_main + (PRO == PRO_NONE ? 0 : (PRO == PRO_AFFINE_RELU ? 2 : 5) * a.Cin * 4) + ((EPI & (EPI_RELU_BWD | EPI_NEXT_BN)) ? 4 * BN * 4 : 0);
+    const int lds = lds_main + (PRO == PRO_NONE ? 0 : (PRO == PRO_AFFINE_RELU ? 2 : 5) * a.Cin * 4) + ((EPI & EPI_RELU_BWD) ? 4 * BN * 4 : 0);
     if (lds > 160 * 1024) return RN_EUNSUPPORTED;
     static rn::DynLdsOptIn opt_in = {};
     { const int rc = opt_in.ensure((const void *)pw_gemm_kernel<DT, BN, PRO, EPI>, lds); if (rc != RN_OK) return rc; }
@@ -663,7 +637,6 @@ template <int BN, int PRO> int dispatch_epi(const PwArgs &a, const int epi, hipS
         case EPI_STATS: return launch_gemm<BN, PRO, EPI_STATS>(a, st);
         case EPI_RESID: return launch_gemm<BN, PRO, EPI_RESID>(a, st);
         case EPI_RELU_BWD: return launch_gemm<BN, PRO, EPI_RELU_BWD>(a, st);
-        case EPI_RESID | EPI_NEXT_BN: if (PRO == PRO_NONE) return launch_gemm<BN, PRO_NONE, EPI_RESID | EPI_NEXT_BN>(a, st); return RN_EUNSUPPORTED;
         case EPI_BIAS: if (PRO == PRO_NONE) return launch_gemm<BN, PRO_NONE, EPI_BIAS>(a, st); return RN_EUNSUPPORTED;
         case EPI_BIAS | EPI_RESID: if (PRO == PRO_NONE) return launch_gemm<BN, PRO_NONE, EPI_BIAS | EPI_RESID>(a, st); return RN_EUNSUPPORTED;
         default: return RN_EUNSUPPORTED;
@@ -784,12 +757,8 @@ RN_API int rn_pw_conv_forward(const rn_pw_conv *d, const void *x, const void *w,
         }
         if (e == EPI_BIAS) { }
         else if (e == EPI_STATS) { if (!epi->partial) return RN_EINVAL; a.partial = epi->partial; }
-        else if ((e & ~(EPI_BIAS | EPI_NEXT_BN)) == EPI_RESID && !((e & EPI_BIAS) && (e & EPI_NEXT_BN))) {
+        else if ((e & ~EPI_BIAS) == EPI_RESID) {
             if (!epi->resid) return RN_EINVAL;
-            if (e & EPI_NEXT_BN) {
-                if (!epi->partial || !epi->zprev || !epi->zbits || !epi->emean || !epi->einv) return RN_EINVAL;
-                a.partial = epi->partial; a.Zp = (const uint16_t *)epi->zprev; a.zbits = epi->zbits; a.emean = epi->emean; a.einv = epi->einv;
-            }
             if (epi->res_stride != 0 && epi->res_stride != 1 && epi->res_stride != 2) return RN_EUNSUPPORTED;
             a.R = (const uint16_t *)epi->resid; a.rbits = epi->rbits; a.rs = epi->res_stride == 2 ? 2 : 1;
             if (a.rs == 2) {

@@ -29,8 +29,7 @@ import torch.nn.functional as F
 from torch import Tensor
 
 from . import norm
-from ._lib import (RN_BF16, RN_F16, RN_PW_EPI_BIAS, RN_PW_EPI_NEXT_BN, RN_PW_EPI_RELU_BWD, RN_PW_EPI_RESID, RN_PW_EPI_STATS, RN_PW_PRO_AFFINE_RELU,
-                   RN_PW_PRO_BN_BWD,
+from ._lib import (RN_BF16, RN_F16, RN_PW_EPI_BIAS, RN_PW_EPI_RELU_BWD, RN_PW_EPI_RESID, RN_PW_EPI_STATS, RN_PW_PRO_AFFINE_RELU, RN_PW_PRO_BN_BWD,
                    RnPwConv, RnPwEpilogue, RnPwPrologue, check, lib)
 from .ops import _timed
 
@@ -235,26 +234,6 @@ def bn_apply(x: Tensor, stats: Tensor, relu: bool, residual: Optional[Tensor] = 
     return y, bits
 
 
-# ---- the BatchNorm-backward sums of a block's LAST BatchNorm in the epilogue of the data-gradient GEMM that produces its input --------
-# A fused block starts its backward pass with a reduction over (g_out * bits, z3): two sums per channel, a pass over the block's largest
-# tensors (layer1: 567 MB, ~110 us).  When the block's output feeds ONE consumer and that consumer is the next fused block, g_out is
-# exactly what that block's conv1 data-gradient GEMM writes -- so that GEMM's epilogue forms the sums while the tile is in registers
-# (RN_PW_EPI_NEXT_BN: + z3 and the bits of the block below as extra operands; g_out is not read again: -275 MB and a launch per block).
-# The hand-over: the producing block hangs a `_NextBN` on its output tensor, the consuming block's forward picks it up, its backward
-# deposits the partial sums and the identity of the tensor they belong to, and the producing block's backward uses them only if the
-# gradient it receives IS that tensor, unmodified (same storage, same version counter) -- otherwise it reduces as before.
-NEXT_BN_SUMS = True
-NEXT_BN_STATS = {"used": 0}          # reductions replaced since import (tests)
-
-
-class _NextBN:
-    __slots__ = ("z3", "bits", "stats", "partial", "nb", "stamp")
-
-    def __init__(self, z3, bits, stats):
-        self.z3, self.bits, self.stats = z3, bits, stats
-        self.partial, self.nb, self.stamp = None, 0, None
-
-
 class _BottleneckFn(torch.autograd.Function):
     """One ResNet bottleneck, BatchNorm in training mode, bf16 channels-last.  Tensor arguments (all receive gradients):
     x, conv1.weight, bn1.weight, bn1.bias, conv2.weight, bn2.weight, bn2.bias, conv3.weight, bn3.weight, bn3.bias and, for a
@@ -296,10 +275,6 @@ class _BottleneckFn(torch.autograd.Function):
             out, bits = bn_apply(z3, st3, relu=True, residual=x, want_bits=True)
         ctx.save_for_backward(x, w1, g1, w2, g2, w3, g3, wd, gd, z1, a1, z2, z3, zd, bits, st1, st2, st3, std)
         ctx.blk = blk
-        # (the record of the block BELOW, if x is a fused block's output that feeds only this block; and this block's own record)
-        below = getattr(x, "_rn_next_bn", None) if NEXT_BN_SUMS else None
-        ctx.below = below if (below is not None and below.z3.shape == x.shape and below.z3.dtype == x.dtype) else None
-        ctx.mine = _NextBN(z3, bits, st3) if NEXT_BN_SUMS else None
         return out
 
     @staticmethod
@@ -315,19 +290,10 @@ class _BottleneckFn(torch.autograd.Function):
         M0 = x.shape[0] * x.shape[2] * x.shape[3]
         # bn3 backward sums over (g_out * bits, z3) -> coefficients of dz3 = a g' + k1 z3 + k0
         gr3 = torch.empty((5 * C4,), dtype=torch.float32, device=dev)            # dgamma | dbeta | a | k0 | k1
+        wp, wn = norm._workspace(dev, st, C4)
         p3 = st3.data_ptr()
-        mine = ctx.mine
-        if mine is not None and mine.partial is not None and mine.stamp == (g_out.data_ptr(), g_out._version, tuple(g_out.shape)):
-            # the block above formed the two sums in its conv1 data-gradient epilogue, over exactly this tensor
-            check(lib.rn_bn_bwd_finalize(mine.partial.data_ptr(), mine.nb, M1, C4, g3.data_ptr(), p3, p3 + 4 * C4, 1, gr3.data_ptr(),
-                                         gr3.data_ptr() + 4 * C4, gr3.data_ptr() + 8 * C4, st), "rn_bn_bwd_finalize")
-            NEXT_BN_STATS["used"] += 1
-        else:
-            wp, wn = norm._workspace(dev, st, C4)
-            check(lib.rn_bn_bwd_reduce(g_out.data_ptr(), bits.data_ptr(), z3.data_ptr(), _DT16[x.dtype], M1, C4, g3.data_ptr(), p3, p3 + 4 * C4, 0, 1, 2,
-                                       gr3.data_ptr(), gr3.data_ptr() + 4 * C4, gr3.data_ptr() + 8 * C4, wp, wn, st), "rn_bn_bwd_reduce")
-        if mine is not None:
-            mine.partial, mine.stamp = None, None
+        check(lib.rn_bn_bwd_reduce(g_out.data_ptr(), bits.data_ptr(), z3.data_ptr(), _DT16[x.dtype], M1, C4, g3.data_ptr(), p3, p3 + 4 * C4, 0, 1, 2,
+                                   gr3.data_ptr(), gr3.data_ptr() + 4 * C4, gr3.data_ptr() + 8 * C4, wp, wn, st), "rn_bn_bwd_reduce")
         pro3 = bn_bwd(gr3[2 * C4:], z3, relu_mode=3, bits=bits)
         # conv3 data gradient with bn3-backward in the operand load; epilogue: ReLU mask of a2 + the two bn2-backward sums
         nb2 = lib.rn_pw_walkers(M1)
@@ -373,26 +339,9 @@ class _BottleneckFn(torch.autograd.Function):
                                      p1 + 8 * Cm, 1, 1, gr1.data_ptr(), gr1.data_ptr() + 4 * Cm, gr1.data_ptr() + 8 * Cm, wp, wn, st),
               "rn_bn_act_backward")
         dwd = dgd = dbd = None
-        below = ctx.below
-        nbp = None
-
-        def with_next_bn(epi1):
-            "dx is the output gradient of the fused block below: its bn3-backward sums ride in this GEMM's epilogue"
-            nonlocal nbp
-            if below is None:
-                return epi1
-            Cb = x.shape[1]
-            nbw = lib.rn_pw_walkers(M0)
-            nbp = torch.empty((nbw * 2 * Cb,), dtype=torch.float32, device=dev)
-            pb = below.stats.data_ptr()
-            epi1.kind |= RN_PW_EPI_NEXT_BN
-            epi1.partial, epi1.zprev, epi1.zbits = nbp.data_ptr(), below.z3.data_ptr(), below.bits.data_ptr()
-            epi1.emean, epi1.einv = pb, pb + 4 * Cb
-            below.nb = nbw
-            return epi1
         if wd is None:
             # the identity branch's gradient g_out * bits joins in the data-gradient GEMM's epilogue
-            epi1 = with_next_bn(RnPwEpilogue(RN_PW_EPI_RESID, 0, g_out.data_ptr(), bits.data_ptr(), 0, 0, 0, 0, 0))
+            epi1 = RnPwEpilogue(RN_PW_EPI_RESID, 0, g_out.data_ptr(), bits.data_ptr(), 0, 0, 0, 0, 0)
             dx = pw_forward(dz1, w1t, epi=epi1, tag="pw_conv1_dgrad")
         else:
             dn = blk.downsample
@@ -411,14 +360,12 @@ class _BottleneckFn(torch.autograd.Function):
             sd = dn[0].stride[0]
             dxd = pw_forward(dzd, wdt, tag="pw_down_dgrad")
             if sd in (1, 2):
-                epi1 = with_next_bn(RnPwEpilogue(RN_PW_EPI_RESID, 0, dxd.data_ptr(), 0, 0, 0, 0, 0, 0, sd, x.shape[2], x.shape[3]))
+                epi1 = RnPwEpilogue(RN_PW_EPI_RESID, 0, dxd.data_ptr(), 0, 0, 0, 0, 0, 0, sd, x.shape[2], x.shape[3])
                 dx = pw_forward(dz1, w1t, epi=epi1, tag="pw_conv1_dgrad")
             else:
                 full = torch.empty_like(x).fill_(0)
                 full[:, :, ::sd, ::sd] = dxd
                 dx = pw_forward(dz1, w1t, tag="pw_conv1_dgrad") + full
-        if nbp is not None:
-            below.partial, below.stamp = nbp, (dx.data_ptr(), dx._version, tuple(dx.shape))
         dw1 = pw_wgrad(dz1, x, w1, tag="pw_conv1_wgrad", defer=pending)
         pw_wgrad_flush(pending)
         return (None, dx, dw1, gr1[:Cm], gr1[Cm:2 * Cm], dw2, gr2[:Cm], gr2[Cm:2 * Cm], dw3, gr3[:C4], gr3[C4:2 * C4], dwd, dgd, dbd)
@@ -449,14 +396,10 @@ def bottleneck_fusable(blk, x: Tensor) -> bool:
 
 def bottleneck(blk, x: Tensor) -> Tensor:
     dn = blk.downsample
-    out = _BottleneckFn.apply(blk, x, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias,
-                              blk.conv3.weight, blk.bn3.weight, blk.bn3.bias,
-                              dn[0].weight if dn is not None else None, dn[1].weight if dn is not None else None,
-                              dn[1].bias if dn is not None else None)
-    fn = out.grad_fn
-    if NEXT_BN_SUMS and fn is not None and getattr(fn, "mine", None) is not None:
-        out._rn_next_bn = fn.mine          # (an attribute of THIS tensor object: views, copies and other tensors do not carry it)
-    return out
+    return _BottleneckFn.apply(blk, x, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias,
+                               blk.conv3.weight, blk.bn3.weight, blk.bn3.bias,
+                               dn[0].weight if dn is not None else None, dn[1].weight if dn is not None else None,
+                               dn[1].bias if dn is not None else None)
 
 
 # ---- 1x1 convolutions outside the fused blocks (layer3 / layer4, downsample branches, FPN laterals): the fastest of three ----------

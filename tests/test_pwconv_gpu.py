@@ -508,70 +508,3 @@ def test_stem_inference_on_the_mfma_kernel_equals_the_folded_library_path(B, H, 
     assert y1.shape == y0.shape == ref.shape and y1.dtype == torch.bfloat16
     e1, e0 = float((y1.float() - ref).norm() / ref.norm()), float((y0.float() - ref).norm() / ref.norm())
     assert e1 <= max(1.2 * e0, 6e-3), (e1, e0)
-
-
-@pytest.mark.parametrize("planes,stride_second", [(64, 1), (128, 1), (64, 2)])
-def test_bn_backward_sums_of_the_block_below_ride_in_conv1s_data_gradient(planes, stride_second):
-    """``pwconv.NEXT_BN_SUMS`` (RN_PW_EPI_NEXT_BN): in a chain of fused bottlenecks the bn3-backward reduction of a block whose output
-    feeds only the next fused block is formed in that block's conv1 data-gradient epilogue instead of a pass of its own
-    (retinanet/backbone.py:118-136 + autograd).  Same stored gradient, same two sums up to fp32 summation order: every gradient of the
-    chain equals the separate-reduction run to 1e-3 of its scale, the reductions really were replaced, and a block whose output has a
-    SECOND consumer falls back to its own reduction (the gradient it receives is then a sum, not the GEMM's tensor)."""
-    from pytorch_retinanet_amd import backbone as bb
-    from pytorch_retinanet_amd import pwconv
-    torch.manual_seed(3)
-    inpl = planes * 4
-    ds = None
-    if stride_second == 2:
-        ds = torch.nn.Sequential(bb._conv1x1(inpl, planes * 8, 2), bb.FusedBatchNorm2d(planes * 8))
-    blocks = [bb.Bottleneck(inpl, planes), bb.Bottleneck(inpl, planes),
-              bb.Bottleneck(inpl, planes * 2, 2, ds) if stride_second == 2 else bb.Bottleneck(inpl, planes)]
-    net = torch.nn.Sequential(*blocks).to(DEV).to(memory_format=torch.channels_last).train()
-    with torch.no_grad():
-        for m in net.modules():
-            if isinstance(m, torch.nn.BatchNorm2d):
-                m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
-    for p in net.parameters():
-        if p.dim() == 4:
-            p.data = p.data.to(torch.bfloat16)
-    old_mid = pwconv.FUSED_MAX_MID
-    pwconv.FUSED_MAX_MID = 256
-    x0 = _rand((2, inpl, 24, 28), 1.0, 1)
-    res = {}
-    try:
-        for on in (False, True):
-            pwconv.NEXT_BN_SUMS = on
-            used0 = pwconv.NEXT_BN_STATS["used"]
-            x = x0.clone().requires_grad_(True)
-            net.zero_grad()
-            y = net(x)
-            g = _rand(tuple(y.shape), 1.0, 2)
-            y.backward(g)
-            torch.cuda.synchronize()
-            res[on] = (y.detach().float(), x.grad.float(), {n: p.grad.float().clone() for n, p in net.named_parameters()},
-                       pwconv.NEXT_BN_STATS["used"] - used0)
-        assert res[False][3] == 0 and res[True][3] == 2            # blocks 0 and 1 took their sums from blocks 1 and 2
-        assert torch.equal(res[True][0], res[False][0])
-        _close(res[True][1], res[False][1], 1e-3, "input gradient")
-        for n in res[False][2]:
-            _close(res[True][2][n], res[False][2][n], 2e-3, f"gradient of {n}")
-        # a second consumer of block 0's output: autograd hands block 0 the SUM of two gradients -> its own reduction
-        pwconv.NEXT_BN_SUMS = True
-        used0 = pwconv.NEXT_BN_STATS["used"]
-        x = x0.clone().requires_grad_(True)
-        net.zero_grad()
-        h = blocks[0](x)
-        y = blocks[2](blocks[1](h))
-        (y.float().mean() + 0.5 * h.float().mean()).backward()
-        torch.cuda.synchronize()
-        assert pwconv.NEXT_BN_STATS["used"] - used0 == 1             # only block 1 (fed by block 2 alone)
-        gx_two = x.grad.float().clone()
-        pwconv.NEXT_BN_SUMS = False
-        x = x0.clone().requires_grad_(True)
-        net.zero_grad()
-        h = blocks[0](x)
-        y = blocks[2](blocks[1](h))
-        (y.float().mean() + 0.5 * h.float().mean()).backward()
-        _close(gx_two, x.grad.float(), 1e-3, "input gradient with a second consumer")
-    finally:
-        pwconv.NEXT_BN_SUMS, pwconv.FUSED_MAX_MID = True, old_mid
