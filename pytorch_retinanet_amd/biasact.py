@@ -205,6 +205,7 @@ class TowerLink:
 _CS_WS: Dict[tuple, Tensor] = {}
 FUSE_TOWER_RELU_BWD = True
 BOX_OUTPUT_WGRAD_MFMA = True   # ... and its weight gradient on the narrow gathering kernel
+BOX_OUTPUT_WGRAD_NARROW = True  # ... or (round 5, preferred) on csrc/wgrad3x3.hip over the 64-channel canvas gradient
 BOX_OUTPUT_FWD_MFMA = True     # box-output conv forward on the narrow MFMA level-mode kernel
 
 
@@ -775,7 +776,20 @@ class _BoxOutputConv(torch.autograd.Function):
             _mfma_call("mfma_box_output_dgrad", dev, 2.0 * N * sum(h * wd for h, wd in cv.shapes) * Cout * 9 * Cin,
                        lambda: _levels_dgrad(ctx.relu_link, gs, _layout(cv, N), Cout, wt, cv, dx, x, sheets, Hp, Wp, Cin, stream),
                        "rn_conv3x3_levels_to_canvas")
-        if ctx.needs_input_grad[1] and BOX_OUTPUT_WGRAD_MFMA and Cin == 256:
+        if (ctx.needs_input_grad[1] and BOX_OUTPUT_WGRAD_NARROW and Cout <= 64 and Cin % 64 == 0 and x.dtype in H16
+                and wgrad_narrow_ok(torch.empty((64, Cin, 3, 3), dtype=x.dtype, device="meta"), (1, 1), x)):
+            # Round 5: the canvas IS a zero-bordered channels-last tensor and the gradient is zero on its gaps, so the weight gradient of
+            # the conv on the canvas is the weight gradient of a plain 3x3 / pad-1 conv over the sheets: csrc/wgrad3x3.hip (all nine
+            # taps of a 64 x 64 block of dW per team of waves: x is read once per 64 output channels instead of once per tap) on the
+            # per-level gradients scattered into a 64-channel canvas (Cout = 36 padded with zero channels).  110 us against 198 for the
+            # narrow gathering variant of the position-contraction kernel (which stages the 256-channel x nine times).
+            g36 = _scatter_levels(cv, [gl.view(N, h, wd, Cout).permute(0, 3, 1, 2) for gl, (h, wd) in zip(gs, cv.shapes)],
+                                  (sheets, Cout, Hp, Wp), x.dtype, dev, N)
+            g64 = F.pad(g36, (0, 0, 0, 0, 0, 64 - Cout)).contiguous(memory_format=torch.channels_last)
+            dw64 = conv3x3_wgrad_narrow(g64, x, torch.empty((64, Cin, 3, 3), dtype=x.dtype, device="meta"), tag="mfma_box_output_wgrad",
+                                        flop=2.0 * N * sum(h * wd for h, wd in cv.shapes) * Cout * 9 * Cin)
+            dw = dw64[:Cout].contiguous(memory_format=torch.channels_last)
+        elif ctx.needs_input_grad[1] and BOX_OUTPUT_WGRAD_MFMA and Cin == 256:
             # the narrow (<= 64 rows) variant of the gathering MFMA weight-gradient kernel
             need = lib.rn_conv3x3_wgrad_workspace_bytes(1, sheets * Hp * Wp)
             key = (dev.index, stream)
@@ -1105,7 +1119,7 @@ def wgrad_narrow_ok(w: Tensor, stride, x: Tensor) -> bool:
             w.shape[0] * w.shape[1] <= 512 * 512)
 
 
-def conv3x3_wgrad_narrow(g: Tensor, x: Tensor, w: Tensor) -> Tensor:
+def conv3x3_wgrad_narrow(g: Tensor, x: Tensor, w: Tensor, tag: str = "mfma_conv2_narrow_wgrad", flop: Optional[float] = None) -> Tensor:
     "Weight gradient of ``F.conv2d(x, w, None, 1, 1)`` (bf16 channels-last, Cout / Cin multiples of 64) -> like ``w``, channels-last."
     dev = x.device
     if dev.index != torch.cuda.current_device():
@@ -1120,7 +1134,7 @@ def conv3x3_wgrad_narrow(g: Tensor, x: Tensor, w: Tensor) -> Tensor:
     if ws is None or ws.numel() < need:
         ws = _NARROW_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
     dw = torch.empty((Cout, Cin, 3, 3), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
-    _mfma_call("mfma_conv2_narrow_wgrad", dev, 2.0 * N * H * W * Cout * Cin * 9,
+    _mfma_call(tag, dev, flop if flop is not None else 2.0 * N * H * W * Cout * Cin * 9,
                lambda: lib.rn_conv3x3_wgrad_narrow(gc.data_ptr(), x.data_ptr(), dw.data_ptr(), _DT[x.dtype], N, H, W, Cout, Cin,
                                                    _zero_page(dev).data_ptr(), ws.data_ptr(), ws.numel(), stream), "rn_conv3x3_wgrad_narrow")
     return dw
