@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RN_ABI_VERSION 8
+#define RN_ABI_VERSION 9
 #define RN_MAX_LEVELS 8
 
 enum rn_dtype { RN_F32 = 0, RN_BF16 = 1, RN_F16 = 2 };
@@ -346,6 +346,24 @@ int rn_pw_wgrad_reduce_many_dt(const void *const *partials, const int *splits, c
 int rn_pw_conv_wgrad_partial(const rn_pw_conv *d, const void *g, const void *x, const rn_pw_prologue *gpro, const rn_pw_prologue *xpro,
                              void *workspace, size_t workspace_bytes, int *splits, void *stream);
 int rn_pw_wgrad_reduce_many(const void *const *partials, const int *splits, const int64_t *n_elems, void *const *dws, int n, void *stream);
+/* conv3 of a bottleneck (1x1 / stride 1, Cm -> C4 channels; /root/reference/retinanet/backbone.py:114, applied at :131-132), BOTH
+ * gradients of its autograd backward in one pass over the block-output gradient (ABI 9).  Equivalent to
+ *   rn_pw_conv_forward(g, w3t; prologue RN_PW_PRO_BN_BWD(a3, k0, k1, x2 = z3, bits, relu_mode 3); epilogue RN_PW_EPI_RELU_BWD(partial_bn,
+ *                      zprev = z2, ea, eb, emean, einv)) -> dy2       and
+ *   rn_pw_conv_wgrad_partial(g, z2; gpro = the same prologue, xpro = RN_PW_PRO_AFFINE_RELU(ea, eb)) -> f32 partials in `workspace`,
+ * which each stream g, z3 and the ReLU bits -- the block's largest tensors -- once; here they are read once for both.
+ *   g, z3 [M][C4], bits [M][C4 / 8], w3t [Cm][C4] (w3 transposed), z2, dy2 [M][Cm], 16-bit elements of `dtype`; a3 / k0 / k1 f32 [C4],
+ *   ea / eb / emean / einv f32 [Cm] (16-byte aligned); partial_bn f32 [walkers][2][Cm] with walkers = rn_pw_conv3_backward_walkers(M, Cm, C4)
+ *   (the row count rn_bn_bwd_finalize is given); workspace: rn_pw_conv3_backward_workspace_bytes(M, Cm, C4) bytes = [walkers][C4][Cm] f32,
+ *   *splits = walkers: the (partials, splits) pair rn_pw_wgrad_reduce_many_dt sums into dW3 [C4][Cm].
+ * Shapes: (Cm, C4) = (64, 256) and (128, 512) -- layer1 / layer2 of the ResNet-50 trunk; walkers() returns 0 and the call
+ * RN_EUNSUPPORTED for anything else (the caller keeps the two separate launches).  dy2 is bit-identical to the separate launch. */
+int rn_pw_conv3_backward_walkers(int64_t M, int Cm, int C4);
+size_t rn_pw_conv3_backward_workspace_bytes(int64_t M, int Cm, int C4);
+int rn_pw_conv3_backward(int64_t M, int Cm, int C4, int dtype, const void *g, const void *z3, const uint8_t *bits, const float *a3,
+                         const float *k0, const float *k1, const void *w3t, const void *z2, const float *ea, const float *eb,
+                         const float *emean, const float *einv, void *dy2, float *partial_bn, void *workspace, size_t workspace_bytes,
+                         int *splits, void *stream);
 
 
 /* ---- the ResNet stem convolution (7x7 / stride 2 / pad 3, 3 -> 64 channels, bias-free) -------------------------------

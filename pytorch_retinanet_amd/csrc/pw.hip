@@ -494,7 +494,6 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_wgrad_kernel(const WgArgs a)
     // transposing fragment reads through the compiler's builtin (it then tracks their lgkmcnt itself; an inline-asm read is
     // invisible to the register allocator's copies, which may run before a hand-placed wait)
     typedef __attribute__((ext_vector_type(4))) short s16x4;
-    typedef __attribute__((ext_vector_type(8))) short s16x8;
     typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
     auto tr_frag = [&](const uint32_t off, const uint32_t rowb) {     // 8-deep k fragment = positions +0..3 and +4..7
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(lds + off));
@@ -536,6 +535,276 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_wgrad_kernel(const WgArgs a)
                 out[(int64_t)row * Ktot + tap * a.Cin + col] = acc[mi][ni][r];
             }
         }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// conv3 of a bottleneck (1x1, Cm -> C4 = 4 Cm channels; retinanet/backbone.py:114,131-132), BOTH of its gradients in one
+// pass over the block-output gradient.  pw_gemm_kernel<.., PRO_BN_BWD, EPI_RELU_BWD> (data gradient) and
+// pw_wgrad_kernel<.., PRO_BN_BWD, PRO_AFFINE_RELU> (weight gradient) each stream g_out, z3 and the ReLU bits -- the block's
+// largest tensors -- through the same bn3-backward transform; the two launches are HBM-bound on exactly those bytes (layer1:
+// 142 + 117 us for 722 + 620 MB).  Here a workgroup forms each transformed tile dz3 [128 positions][64 channels] ONCE in LDS
+// and uses it twice: row-major fragments for  dy2[m][cm] += dz3[m][c4] . W3[c4][cm]  and transposing reads of the same tile
+// for  dW3[c4][cm] += dz3[m][c4] . a2[m][cm]  (a2 = relu(bn2(z2)), formed once per row tile from the z2 rows the ReLU-backward
+// epilogue needs anyway).  The dW3 accumulators (C4 x Cm f32 per workgroup) stay in registers across all the row tiles a
+// workgroup walks; one partial per workgroup, summed by pw_wgrad_reduce_many_kernel.
+// Tile: 128 positions, all Cm output columns; 4 waves.  Cm = 64: 96 accumulator registers, two workgroups per CU.  Cm = 128: the
+// C4 x Cm = 512 x 128 weight-gradient accumulators alone are 256 registers per lane, so the kernel runs ONE wave per SIMD on the
+// full 512-register budget (accumulators in AGPRs); it is bandwidth-bound and issues its loads a K-chunk ahead, the matrix pipe
+// has a 4 x margin.  LDS image of the dz3 tile: 128-byte rows, 16-byte chunks XOR-swizzled with PW_SWZ2(row) -- bits (1, 2, 3) of
+// the row as bits (2, 0, 1): a bijection of (row >> 1) & 7 (ds_read_b128 fragments conflict-free, as PW_SWZ) whose bit 2
+// separates rows q and q + 2 (the 4-row blocks of ds_read_b64_tr_b16 conflict-free, as tr_swz).
+struct PairArgs {
+    const uint16_t *G, *Z3;         // [M][C4]: block-output gradient, bn3 input
+    const uint8_t *gbits;           // [M][C4 / 8]: ReLU bits of the block output
+    const float *pa, *pb, *pc;      // [C4]: dz3 = pa * g' + pc * z3 + pb
+    const uint16_t *Wt;             // [Cm][C4]: the data-gradient weight (w3 transposed)
+    const uint16_t *Z2;             // [M][Cm]: bn2 input
+    const float *ea, *eb, *emean, *einv;    // [Cm]: bn2's forward coefficients and statistics
+    uint16_t *Y;                    // [M][Cm]: dy2 * [a2 alive]
+    float *partial_bn;              // [gx][2][Cm]: sums of Y and Y * xhat2
+    float *partial_w;               // [gx][C4][Cm]
+    int M, gx, f16;
+};
+#define PW_SWZ2(row) (((((row) >> 1) & 1) << 2) | (((row) >> 2) & 3))
+
+template <int DT, int CM, int KT, int T>
+__global__ __launch_bounds__(T, 2) void pw_conv3_bwd_kernel(const PairArgs a)
+{
+    constexpr int NW = T / 64, C4 = KT * 64;
+    constexpr int WM = NW / 2, MI = 4 / WM, NI = CM / 64;        // data gradient: WM x 2 waves of (32 MI) x (CM / 2)
+    // weight gradient: a K-chunk's [64 c4][CM] block is NTILES tiles of 32 x 32, one per wave; with twice as many waves as tiles the
+    // two wave groups take the even / the odd chunks (accumulators: KT / GROUPS tiles per wave, nothing held twice)
+    constexpr int NTILES = CM / 16, GROUPS = NW / NTILES, KW = KT / GROUPS;
+    static_assert(NW == NTILES * GROUPS && KT == KW * GROUPS && MI * WM == 4, "wave roles");
+    constexpr int A_TILE = 128 * 128, W_TILE = CM * 128, STAGE = A_TILE + W_TILE;
+    constexpr int AV = 1024 / T, ARS = T / 8, WV = CM * 8 / T;   // staged 16-byte vectors per thread (rows r0 + ARS i)
+    constexpr int CG = CM / 8, RL = T / CG, EROWS = 128 / RL;    // epilogue: thread = 8 fixed columns, rows erl + RL i
+    constexpr int LDS_MAIN = (2 * STAGE > 128 * CM * 4) ? 2 * STAGE : 128 * CM * 4;
+    constexpr int XROWB = CM * 2, X2_OFF = LDS_MAIN, COEF_OFF = X2_OFF + 128 * XROWB;
+    static_assert(WV * ARS == CM && EROWS * RL == 128 && AV * ARS == 128, "tile split");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = tid & 7, r0 = tid >> 3;
+    const int MT = (a.M + 127) / 128;
+    float *const s_coef = (float *)(lds + COEF_OFF);             // [pa | pb | pc][C4], then [ea | eb | emean | einv][CM]
+    float *const s_epi = s_coef + 3 * C4;
+    for (int q = tid; q < 3 * C4; q += T) {
+        const int which = q / C4, ch = q - which * C4;
+        s_coef[q] = (which == 0 ? a.pa : (which == 1 ? a.pb : a.pc))[ch];
+    }
+    for (int q = tid; q < 4 * CM; q += T) {
+        const int which = q / CM, col = q - which * CM;
+        s_epi[q] = (which == 0 ? a.ea : (which == 1 ? a.eb : (which == 2 ? a.emean : a.einv)))[col];
+    }
+    __syncthreads();
+
+    // staging slots
+    uint32_t wa_off[AV], ww_off[WV];
+#pragma unroll
+    for (int i = 0; i < AV; ++i) { const int row = r0 + ARS * i; wa_off[i] = row * 128 + ((c ^ PW_SWZ2(row)) << 4); }
+#pragma unroll
+    for (int i = 0; i < WV; ++i) { const int row = r0 + ARS * i; ww_off[i] = A_TILE + row * 128 + ((c ^ PW_SWZ(row)) << 4); }
+    // data-gradient fragments (row-major ds_read_b128)
+    const int wm = wave >> 1, wn = wave & 1;
+    uint32_t a_off[4], b_off[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int chunk = kk * 2 + (lane >> 5);
+        { const int row = wm * (32 * MI) + (lane & 31); a_off[kk] = row * 128 + ((chunk ^ PW_SWZ2(row)) << 4); }
+        { const int row = wn * (CM / 2) + (lane & 31); b_off[kk] = A_TILE + row * 128 + ((chunk ^ PW_SWZ(row)) << 4); }
+    }
+    // weight-gradient fragments (transposing reads; lane = 16 grp + 4 q + p as in pw_wgrad_kernel): wave = one 32 x 32 tile of the
+    // [64 c4][CM] block of a K-chunk -- rows wr * 32 .., columns wc * 32 ..
+    const int wk = wave / NTILES, wtile = wave % NTILES, wr = wtile & 1, wc = wtile >> 1;    // rows wr * 32 .., columns wc * 32 ..
+    const int grp = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+    uint32_t ga_lo, ga_hi, gx_lo;
+    {
+        const int rl = 8 * (grp >> 1) + q4, ch = wr * 4 + 2 * (grp & 1) + (p4 >> 1), chx = wc * 4 + 2 * (grp & 1) + (p4 >> 1);
+        ga_lo = (uint32_t)(rl * 128 + ((ch ^ PW_SWZ2(rl)) << 4) + (p4 & 1) * 8);
+        ga_hi = (uint32_t)((rl + 4) * 128 + ((ch ^ PW_SWZ2(rl + 4)) << 4) + (p4 & 1) * 8);
+        gx_lo = (uint32_t)(X2_OFF + rl * XROWB + ((chx ^ tr_swz<CM>(q4)) << 4) + (p4 & 1) * 8);
+    }
+    const int ecg = tid % CG, erl = tid / CG;
+    float ssum[8], qsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ssum[j] = 0.0f; qsum[j] = 0.0f; }
+    f32x16 accw[KW];
+#pragma unroll
+    for (int k = 0; k < KW; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accw[k][r] = 0.0f;
+
+    rn::u32x4 sx[AV], sz[AV], sw[WV], er[EROWS];
+    uint32_t sbits[AV];
+    bool sval[AV];
+    int skt = 0;
+    auto issue = [&](const int m0, const int kt) {
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int m = m0 + r0 + ARS * i;
+            sval[i] = m < a.M;
+            const int64_t e = (int64_t)(sval[i] ? m : 0) * C4 + kt * 64 + c * 8;
+            sx[i] = *(const rn::u32x4 *)(a.G + e);
+            sz[i] = *(const rn::u32x4 *)(a.Z3 + e);
+            sbits[i] = a.gbits[e >> 3];
+        }
+#pragma unroll
+        for (int i = 0; i < WV; ++i) sw[i] = *(const rn::u32x4 *)(a.Wt + (int64_t)(r0 + ARS * i) * C4 + kt * 64 + c * 8);
+        skt = kt;
+    };
+    auto commit = [&](const int stage) {
+        unsigned char *const sb = lds + stage * STAGE;
+        ProCoef coef;
+        const int ch = skt * 64 + c * 8;
+        ld8f(s_coef + ch, coef.a); ld8f(s_coef + C4 + ch, coef.b); ld8f(s_coef + 2 * C4 + ch, coef.c);
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            *(rn::u32x4 *)(sb + wa_off[i]) = transform<DT, PRO_BN_BWD>(sx[i], sz[i], sbits[i], coef, 3, sval[i]);
+            __builtin_amdgcn_sched_barrier(0);                      // one vector's 16 floats live at a time (registers)
+        }
+#pragma unroll
+        for (int i = 0; i < WV; ++i) *(rn::u32x4 *)(sb + ww_off[i]) = sw[i];
+    };
+    auto load_z2 = [&](const int m0) {
+#pragma unroll
+        for (int i = 0; i < EROWS; ++i) {
+            const int m = m0 + erl + i * RL, mc = m < a.M ? m : a.M - 1;
+            er[i] = *(const rn::u32x4 *)(a.Z2 + (int64_t)mc * CM + ecg * 8);
+        }
+    };
+    auto commit_a2 = [&]() {                                        // a2 = relu(fma(z2, ea, eb)) rounded to DT: the X operand of the weight gradient
+        ProCoef k;
+        ld8f(s_epi + ecg * 8, k.a); ld8f(s_epi + CM + ecg * 8, k.b);
+#pragma unroll
+        for (int i = 0; i < EROWS; ++i) {
+            const int row = erl + i * RL;
+            *(rn::u32x4 *)(lds + X2_OFF + row * XROWB + ((ecg ^ tr_swz<CM>(row)) << 4)) = transform<DT, PRO_AFFINE_RELU>(er[i], er[i], 0xffu, k, 0, true);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
+    auto tr_pair = [&](const uint32_t lo_off, const uint32_t hi_off) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(lds + lo_off));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(lds + hi_off));
+        return __builtin_bit_cast(typename rn::mma<DT>::frag, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    const float alive = alive_dt<DT>();
+
+    int mt = blockIdx.x;
+    if (mt < MT) { issue(mt * 128, 0); load_z2(mt * 128); }
+    for (; mt < MT; mt += a.gx) {
+        const int m0 = mt * 128;
+        f32x16 accd[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accd[i][j][r] = 0.0f;
+        commit(0);
+        __syncthreads();
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt + 1 < KT) issue(m0, kt + 1);
+            else if (mt + a.gx < MT) issue((mt + a.gx) * 128, 0);  // the next row tile's first chunk, in flight under the epilogue
+            const uint32_t sb = (uint32_t)((kt & 1) * STAGE);
+            typedef typename rn::mma<DT>::frag frag8;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                frag8 fa[MI], fb[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) fa[mi] = *(const frag8 *)(lds + sb + a_off[kk] + mi * 4096);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) fb[ni] = *(const frag8 *)(lds + sb + b_off[kk] + ni * 4096);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        accd[mi][ni] = rn::mma<DT>::m32(fa[mi], fb[ni], accd[mi][ni]);
+            }
+            if (kt == 0) {                                          // z2 rows (loaded behind the previous epilogue) -> a2 tile, under the MFMAs above
+                commit_a2();
+                __syncthreads();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (GROUPS == 1 || (kt % GROUPS) == wk) {              // (wave-uniform)
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {                   // contraction over the tile's 128 positions, 16 per step
+                    const frag8 fg = tr_pair(sb + ga_lo + kk * 2048, sb + ga_hi + kk * 2048);
+                    const frag8 fx = tr_pair(gx_lo + kk * 16 * XROWB, gx_lo + kk * 16 * XROWB + 4 * XROWB);
+                    accw[kt / GROUPS] = rn::mma<DT>::m32(fg, fx, accw[kt / GROUPS]);
+                    if (kk & 1) __builtin_amdgcn_sched_barrier(0); // (keeps the fragment reads of all 8 steps from being hoisted: registers)
+                }
+            }
+            if (kt + 1 < KT) commit((kt + 1) & 1);
+            __syncthreads();
+        }
+
+        // ---- epilogue (pw_gemm_kernel's EPI_RELU_BWD): dy2 = acc * [a2 alive], its two bn2-backward sums
+        float *const tile = (float *)lds;                           // [128][CM]
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int col = wn * (CM / 2) + ni * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * (32 * MI) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    tile[row * CM + col] = accd[mi][ni][r];
+                }
+            }
+        __syncthreads();
+        {
+            float ea[8], eb[8], emu[8], eis[8];
+            ld8f(s_epi + ecg * 8, ea); ld8f(s_epi + CM + ecg * 8, eb);
+            ld8f(s_epi + 2 * CM + ecg * 8, emu); ld8f(s_epi + 3 * CM + ecg * 8, eis);
+#pragma unroll
+            for (int i = 0; i < EROWS; ++i) {
+                const int row = erl + i * RL, m = m0 + row;
+                if (m < a.M) {
+                    float v[8], z[8];
+                    ld8f(tile + row * CM + ecg * 8, v);
+                    rn::u32x4 o = rn::dt<DT>::pack(v);
+                    rn::dt<DT>::unpack(o, v);                      // the statistics are those of the stored (rounded) tensor
+                    rn::dt<DT>::unpack(er[i], z);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (!(fmaf(z[j], ea[j], eb[j]) > alive)) v[j] = 0.0f;
+                        ssum[j] += v[j];
+                        qsum[j] = fmaf(v[j], (z[j] - emu[j]) * eis[j], qsum[j]);
+                    }
+                    o = rn::dt<DT>::pack(v);
+                    *(rn::u32x4 *)(a.Y + (int64_t)m * CM + ecg * 8) = o;
+                }
+            }
+        }
+        if (mt + a.gx < MT) load_z2((mt + a.gx) * 128);            // consumed by the next tile's commit_a2 and epilogue
+        __syncthreads();                                            // the tile is the next row tile's staging area
+    }
+
+    {   // bn2-backward partial sums of the rows this workgroup walked
+        float *const red = (float *)lds;                            // [RL][2][CM]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[(erl * 2 + 0) * CM + ecg * 8 + j] = ssum[j]; red[(erl * 2 + 1) * CM + ecg * 8 + j] = qsum[j]; }
+        __syncthreads();
+        for (int q = tid; q < 2 * CM; q += T) {
+            float t = 0.0f;
+            for (int l = 0; l < RL; ++l) t += red[l * 2 * CM + q];
+            const int which = q >= CM ? 1 : 0;
+            a.partial_bn[((int64_t)blockIdx.x * 2 + which) * CM + (q - which * CM)] = t;
+        }
+    }
+    float *__restrict__ outw = a.partial_w + (int64_t)blockIdx.x * C4 * CM;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) {
+        const int col = wc * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (k * GROUPS + wk) * 64 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            outw[row * CM + col] = accw[k][r];
+        }
+    }
 }
 
 // dW (bf16) = sum over the splits of partial (f32).  A block owns 32 float4 outputs; its 8 thread rows each sum every 8th
@@ -718,6 +987,62 @@ int check_geometry(const rn_pw_conv *d)
 }
 
 }  // namespace
+
+constexpr int PAIR_THREADS = 512, PAIR_WGS_PER_CU = 1;
+static int pair_walkers(const int64_t M, const int Cm)
+{
+    const int MT = (int)((M + 127) / 128), cap = PAIR_WGS_PER_CU * cu_count();
+    if (MT <= cap) return MT;
+    const int rounds = (MT + cap - 1) / cap;
+    return (MT + rounds - 1) / rounds;
+}
+static bool pair_shape_ok(const int64_t M, const int Cm, const int C4)
+{
+    // (Cm, C4) = (128, 512) is not offered: its 512 x 128 f32 accumulators (256 KB per workgroup) leave the
+    // transforms no registers -- 134 - 192 VGPRs spilled, 216 us against 105 + 72 for the two separate launches at the layer2 shape.
+    return M > 0 && M < ((int64_t)1 << 31) / (C4 > 0 ? C4 : 1) * 8 && Cm == 64 && C4 == 256;
+}
+template <int DT, int CM, int KT> static int launch_pair(const PairArgs &a, hipStream_t st)
+{
+    constexpr int stage = 128 * 128 + CM * 128, main_b = (2 * stage > 128 * CM * 4) ? 2 * stage : 128 * CM * 4;
+    constexpr int lds = main_b + 128 * CM * 2 + 3 * KT * 64 * 4 + 4 * CM * 4;
+    static rn::DynLdsOptIn opt_in = {};
+    { const int rc = opt_in.ensure((const void *)pw_conv3_bwd_kernel<DT, CM, KT, PAIR_THREADS>, lds); if (rc != RN_OK) return rc; }
+    hipLaunchKernelGGL((pw_conv3_bwd_kernel<DT, CM, KT, PAIR_THREADS>), dim3((unsigned)a.gx), dim3(PAIR_THREADS), lds, st, a);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+RN_API int rn_pw_conv3_backward_walkers(int64_t M, int Cm, int C4) { return pair_shape_ok(M, Cm, C4) ? pair_walkers(M, Cm) : 0; }
+
+RN_API size_t rn_pw_conv3_backward_workspace_bytes(int64_t M, int Cm, int C4)
+{
+    return pair_shape_ok(M, Cm, C4) ? (size_t)pair_walkers(M, Cm) * C4 * Cm * sizeof(float) : 0;
+}
+
+RN_API int rn_pw_conv3_backward(int64_t M, int Cm, int C4, int dtype, const void *g, const void *z3, const uint8_t *bits, const float *a3,
+                                const float *k0, const float *k1, const void *w3t, const void *z2, const float *ea, const float *eb,
+                                const float *emean, const float *einv, void *dy2, float *partial_bn, void *workspace,
+                                size_t workspace_bytes, int *splits, void *stream)
+{
+    if (!g || !z3 || !bits || !a3 || !k0 || !k1 || !w3t || !z2 || !ea || !eb || !emean || !einv || !dy2 || !partial_bn || !workspace || !splits)
+        return RN_EINVAL;
+    if (dtype != RN_BF16 && dtype != RN_F16) return RN_EUNSUPPORTED;
+    if (!pair_shape_ok(M, Cm, C4)) return RN_EUNSUPPORTED;
+    if (!rn::aligned(g, 16) || !rn::aligned(z3, 16) || !rn::aligned(w3t, 16) || !rn::aligned(z2, 16) || !rn::aligned(dy2, 16) ||
+        !rn::aligned(workspace, 16) || !rn::aligned(a3, 16) || !rn::aligned(k0, 16) || !rn::aligned(k1, 16) || !rn::aligned(ea, 16) ||
+        !rn::aligned(eb, 16) || !rn::aligned(emean, 16) || !rn::aligned(einv, 16))
+        return RN_EALIGN;
+    if (workspace_bytes < rn_pw_conv3_backward_workspace_bytes(M, Cm, C4)) return RN_EWORKSPACE;
+    PairArgs a = {};
+    a.G = (const uint16_t *)g; a.Z3 = (const uint16_t *)z3; a.gbits = bits; a.pa = a3; a.pb = k0; a.pc = k1;
+    a.Wt = (const uint16_t *)w3t; a.Z2 = (const uint16_t *)z2; a.ea = ea; a.eb = eb; a.emean = emean; a.einv = einv;
+    a.Y = (uint16_t *)dy2; a.partial_bn = partial_bn; a.partial_w = (float *)workspace;
+    a.M = (int)M; a.gx = pair_walkers(M, Cm); a.f16 = dtype == RN_F16;
+    *splits = a.gx;
+    hipStream_t st = (hipStream_t)stream;
+    return a.f16 ? launch_pair<RN_F16, 64, 4>(a, st) : launch_pair<RN_BF16, 64, 4>(a, st);
+}
 
 RN_API int rn_pw_walkers(int64_t M) { return M > 0 && M < ((int64_t)1 << 31) ? walkers((int)M) : 0; }
 

@@ -38,6 +38,7 @@ FUSED_BOTTLENECK = os.environ.get("RN_FUSED_BOTTLENECK", "1") != "0"      # 0: t
 # fusion; at layer3 / layer4 (256 / 512 mid channels, K up to 2048) the GEMMs are compute-bound and the 128 x 128 register-staged
 # tiles of csrc/pw.hip run at a third of MIOpen's rate (measured: conv3 data gradient 99 us against 36 + 22 us)
 FUSED_MAX_MID = int(os.environ.get("RN_FUSED_MAX_MID", "128"))
+FUSE_CONV3_BWD = True          # conv3's data and weight gradients in one pass over the block-output gradient (layer1 / layer2 shapes)
 DEFER_WGRAD_REDUCE = True      # a fused block sums the splits of its 1x1 weight gradients in one launch at the end of its backward
 _WG_WS: Dict[tuple, Tensor] = {}
 H16 = (torch.bfloat16, torch.float16)          # element types of csrc/pw.hip / stem.hip (the same kernels on v_mfma_*_bf16 / _f16)
@@ -310,9 +311,27 @@ class _BottleneckFn(torch.autograd.Function):
               "rn_transpose_many")
         w3t, w1t = wts[0], wts[1]
         wdt = wts[2] if wd is not None else None
-        dy2 = pw_forward(g_out, w3t, pro=pro3, epi=epi, tag="pw_conv3_dgrad")
         pending: list = []                  # the block's 1x1 weight gradients: kernels now, one reduction of their splits at the end
-        dw3 = pw_wgrad(g_out, z2, w3, gpro=pro3, xpro=affine_relu(st2[2 * Cm:]), tag="pw_conv3_wgrad", defer=pending)
+        nbp = lib.rn_pw_conv3_backward_walkers(M1, Cm, C4) if (FUSE_CONV3_BWD and DEFER_WGRAD_REDUCE) else 0
+        if nbp > 0:
+            # both gradients of conv3 in ONE pass over (g_out, z3, bits): csrc/pw.hip, pw_conv3_bwd_kernel
+            nb2 = nbp
+            part2 = torch.empty((nb2 * 2 * Cm,), dtype=torch.float32, device=dev)
+            dy2 = torch.empty_like(z2)
+            dw3 = torch.empty_like(w3)
+            ws3 = torch.empty((lib.rn_pw_conv3_backward_workspace_bytes(M1, Cm, C4),), dtype=torch.uint8, device=dev)
+            S3 = C.c_int(0)
+            pg = gr3.data_ptr() + 8 * C4
+            PW_FLOP["pw_conv3_bwd"] = 4.0 * M1 * C4 * Cm
+            with _timed("pw_conv3_bwd", dev):
+                check(lib.rn_pw_conv3_backward(M1, Cm, C4, _DT16[x.dtype], g_out.data_ptr(), z3.data_ptr(), bits.data_ptr(), pg, pg + 4 * C4,
+                                               pg + 8 * C4, w3t.data_ptr(), z2.data_ptr(), p2 + 8 * Cm, p2 + 12 * Cm, p2, p2 + 4 * Cm,
+                                               dy2.data_ptr(), part2.data_ptr(), ws3.data_ptr(), ws3.numel(), C.byref(S3), st),
+                      "rn_pw_conv3_backward")
+            pending.append((ws3, int(S3.value), dw3.numel(), dw3))
+        else:
+            dy2 = pw_forward(g_out, w3t, pro=pro3, epi=epi, tag="pw_conv3_dgrad")
+            dw3 = pw_wgrad(g_out, z2, w3, gpro=pro3, xpro=affine_relu(st2[2 * Cm:]), tag="pw_conv3_wgrad", defer=pending)
         # bn2: finalize from the epilogue sums, apply (conv2's backward is MIOpen's and wants dz2 in memory)
         gr2 = torch.empty((5 * Cm,), dtype=torch.float32, device=dev)
         check(lib.rn_bn_bwd_finalize(part2.data_ptr(), nb2, M1, Cm, g2.data_ptr(), p2, p2 + 4 * Cm, 1, gr2.data_ptr(), gr2.data_ptr() + 4 * Cm,

@@ -231,6 +231,76 @@ def test_weight_gradient_with_both_operand_transforms(c4, cm):
     _close(dw.float().view(c4, cm), ref, 1e-2, "weight gradient with transforms")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("c4,cm,H,W", [(256, 64, 19, 23), (512, 128, 19, 23), (256, 64, 260, 260), (256, 64, 1, 5)])
+def test_conv3_backward_in_one_pass(c4, cm, H, W, dtype):
+    """``rn_pw_conv3_backward``: the data gradient (bn3-backward prologue, ReLU-backward epilogue + bn2-backward sums) and the weight
+    gradient of a bottleneck's conv3 from ONE pass over (g_out, z3, bits) -- against fp32 PyTorch on the same inputs, and against the
+    two separate kernels it replaces (same bars as their own tests).  260 x 260 / 150 x 130: more row tiles than walkers, ragged end."""
+    import ctypes as C
+    from pytorch_retinanet_amd import pwconv
+    from pytorch_retinanet_amd._lib import RN_BF16, RN_F16, lib
+    M = 2 * H * W
+    gup, z3, z2 = (_rand((2, c4, H, W), 1.0, 1).to(dtype), _rand((2, c4, H, W), 1.0, 2).to(dtype), _rand((2, cm, H, W), 1.0, 3).to(dtype))
+    w3 = _rand((c4, cm, 1, 1), 0.05, 4).to(dtype)
+    w3t = _cl(w3.view(c4, cm).t().contiguous().view(cm, c4, 1, 1))
+    coef3 = _bn_bwd_coefs(c4, 5)
+    gen = torch.Generator(device=DEV).manual_seed(6)
+    mask = torch.rand(M, c4, device=DEV, generator=gen) > 0.4
+    bits = (mask.view(M, c4 // 8, 8).to(torch.int32) * (2 ** torch.arange(8, device=DEV, dtype=torch.int32))).sum(-1).to(torch.uint8).contiguous().view(-1)
+    st2 = torch.cat([torch.randn(cm, device=DEV, generator=gen) * 0.2, torch.rand(cm, device=DEV, generator=gen) + 0.5,
+                     torch.rand(cm, device=DEV, generator=gen) + 0.5, torch.randn(cm, device=DEV, generator=gen) * 0.3])    # mean | invstd | a | b
+    nb = lib.rn_pw_conv3_backward_walkers(M, cm, c4)
+    if cm != 64:
+        assert nb == 0          # layer2's shape is refused (register budget, csrc/pw.hip): the caller keeps the two launches
+        return
+    assert nb > 0 and nb <= 512
+    part = torch.full((nb * 2 * cm,), float("nan"), dtype=torch.float32, device=DEV)
+    dy2 = torch.full_like(z2, float("nan"))
+    ws = torch.empty((lib.rn_pw_conv3_backward_workspace_bytes(M, cm, c4),), dtype=torch.uint8, device=DEV)
+    S = C.c_int(0)
+    p3, p2 = coef3.data_ptr(), st2.data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+    rc = lib.rn_pw_conv3_backward(M, cm, c4, RN_F16 if dtype == torch.float16 else RN_BF16, gup.data_ptr(), z3.data_ptr(), bits.data_ptr(), p3,
+                                  p3 + 4 * c4, p3 + 8 * c4, w3t.data_ptr(), z2.data_ptr(), p2 + 8 * cm, p2 + 12 * cm, p2, p2 + 4 * cm,
+                                  dy2.data_ptr(), part.data_ptr(), ws.data_ptr(), ws.numel(), C.byref(S), st)
+    assert rc == 0 and S.value == nb
+    dw = torch.empty_like(w3)
+    pend = [(ws, int(S.value), dw.numel(), dw)]
+    pwconv.pw_wgrad_flush(pend)
+    torch.cuda.synchronize()
+    # fp32 references
+    zr, gr = z3.float().permute(0, 2, 3, 1).reshape(M, c4), gup.float().permute(0, 2, 3, 1).reshape(M, c4)
+    dz = (coef3[:c4] * (gr * mask) + (coef3[2 * c4:] * zr + coef3[c4:2 * c4])).to(dtype).float()
+    z2r = z2.float().permute(0, 2, 3, 1).reshape(M, cm)
+    pre = torch.addcmul(st2[3 * cm:], z2r, st2[2 * cm:3 * cm])
+    alive = pre.to(dtype).float() > 0
+    a2 = F.relu(pre).to(dtype).float()
+    ref_dy = (dz @ w3.float().view(c4, cm)).to(dtype).float() * alive
+    got = dy2.float().permute(0, 2, 3, 1).reshape(M, cm)
+    _close(got, ref_dy, 1.5e-2, "masked data gradient")
+    assert float((got[~alive]).abs().max()) == 0.0
+    sums = part.view(nb, 2, cm).double().sum(0)
+    xhat = ((z2r - st2[:cm]) * st2[cm:2 * cm]).double()
+    np.testing.assert_allclose(sums[0].cpu().numpy(), got.double().sum(0).cpu().numpy(), rtol=1e-3, atol=1e-3 * float(got.abs().sum(0).max()))
+    np.testing.assert_allclose(sums[1].cpu().numpy(), (got.double() * xhat).sum(0).cpu().numpy(), rtol=1e-3,
+                               atol=1e-3 * float((got.double() * xhat).abs().sum(0).max()))
+    _close(dw.float().view(c4, cm), dz.t() @ a2, 1e-2, "weight gradient")
+    # the two kernels it replaces: same data gradient bit for bit (same products in the same order), same weight gradient to f32 summation order
+    from pytorch_retinanet_amd._lib import RN_PW_EPI_RELU_BWD, RnPwEpilogue
+    nb1 = lib.rn_pw_walkers(M)
+    part1 = torch.empty((nb1 * 2 * cm,), dtype=torch.float32, device=DEV)
+    epi = RnPwEpilogue(RN_PW_EPI_RELU_BWD, part1.data_ptr(), 0, 0, z2.data_ptr(), p2 + 8 * cm, p2 + 12 * cm, p2, p2 + 4 * cm)
+    pro = pwconv.bn_bwd(coef3, z3, 3, bits=bits)
+    dy_two = pwconv.pw_forward(gup, w3t, pro=pro, epi=epi)
+    dw_two = pwconv.pw_wgrad(gup, z2, w3, gpro=pro, xpro=pwconv.affine_relu(st2[2 * cm:]))
+    if dtype == torch.bfloat16:
+        assert torch.equal(dy_two, dy2)
+    else:       # fp16: the compiler may round fma + conversion once (v_fma_mixlo_f16) in one kernel and twice in the other: rare 1-ulp differences
+        _close(dy2.float(), dy_two.float(), 1e-3, "data gradient vs the separate kernel")
+    _close(dw.float(), dw_two.float(), 4e-3, "weight gradient vs the separate kernel")
+
+
 def _truth_block(blk, x0, g):
     "The block in plain fp32 PyTorch ops with autograd (bf16 weights up-cast, batch statistics): outputs and every gradient."
     def bn(z, m):
