@@ -563,7 +563,9 @@ struct PairArgs {
     uint16_t *Y;                    // [M][Cm]: dy2 * [a2 alive]
     float *partial_bn;              // [gx][2][Cm]: sums of Y and Y * xhat2
     float *partial_w;               // [gx][C4][Cm]
-    int M, gx, f16;
+    int M, f16;
+    int cm, halves, nwalk;          // cm: row length of Wt's row index range / Z2 / Y / the partials (the conv's Cm); halves = cm / 64 workgroups
+                                    // share a row tile, each owning 64 of its columns; nwalk row-tile walkers (a multiple of 8 when halves == 2)
 };
 #define PW_SWZ2(row) (((((row) >> 1) & 1) << 2) | (((row) >> 2) & 3))
 
@@ -586,6 +588,11 @@ __global__ __launch_bounds__(T, 2) void pw_conv3_bwd_kernel(const PairArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = tid & 7, r0 = tid >> 3;
     const int MT = (a.M + 127) / 128;
+    // halves == 2: the two workgroups of a row tile are 8 apart in launch order -- same XCD (workgroups go round-robin over the 8
+    // XCDs), dispatched back to back -- so the second one's reads of g / z3 / bits find the first one's lines in that XCD's L2
+    const int bid = blockIdx.x;
+    const int half = a.halves == 2 ? (bid >> 3) & 1 : 0, walker = a.halves == 2 ? ((bid >> 4) << 3) | (bid & 7) : bid;
+    const int n0 = half * CM, cmr = a.cm;
     float *const s_coef = (float *)(lds + COEF_OFF);             // [pa | pb | pc][C4], then [ea | eb | emean | einv][CM]
     float *const s_epi = s_coef + 3 * C4;
     for (int q = tid; q < 3 * C4; q += T) {
@@ -594,7 +601,7 @@ __global__ __launch_bounds__(T, 2) void pw_conv3_bwd_kernel(const PairArgs a)
     }
     for (int q = tid; q < 4 * CM; q += T) {
         const int which = q / CM, col = q - which * CM;
-        s_epi[q] = (which == 0 ? a.ea : (which == 1 ? a.eb : (which == 2 ? a.emean : a.einv)))[col];
+        s_epi[q] = (which == 0 ? a.ea : (which == 1 ? a.eb : (which == 2 ? a.emean : a.einv)))[n0 + col];
     }
     __syncthreads();
 
@@ -649,7 +656,7 @@ __global__ __launch_bounds__(T, 2) void pw_conv3_bwd_kernel(const PairArgs a)
             sbits[i] = a.gbits[e >> 3];
         }
 #pragma unroll
-        for (int i = 0; i < WV; ++i) sw[i] = *(const rn::u32x4 *)(a.Wt + (int64_t)(r0 + ARS * i) * C4 + kt * 64 + c * 8);
+        for (int i = 0; i < WV; ++i) sw[i] = *(const rn::u32x4 *)(a.Wt + (int64_t)(n0 + r0 + ARS * i) * C4 + kt * 64 + c * 8);
         skt = kt;
     };
     auto commit = [&](const int stage) {
@@ -669,7 +676,7 @@ __global__ __launch_bounds__(T, 2) void pw_conv3_bwd_kernel(const PairArgs a)
 #pragma unroll
         for (int i = 0; i < EROWS; ++i) {
             const int m = m0 + erl + i * RL, mc = m < a.M ? m : a.M - 1;
-            er[i] = *(const rn::u32x4 *)(a.Z2 + (int64_t)mc * CM + ecg * 8);
+            er[i] = *(const rn::u32x4 *)(a.Z2 + (int64_t)mc * cmr + n0 + ecg * 8);
         }
     };
     auto commit_a2 = [&]() {                                        // a2 = relu(fma(z2, ea, eb)) rounded to DT: the X operand of the weight gradient
@@ -691,9 +698,9 @@ __global__ __launch_bounds__(T, 2) void pw_conv3_bwd_kernel(const PairArgs a)
     };
     const float alive = alive_dt<DT>();
 
-    int mt = blockIdx.x;
+    int mt = walker;
     if (mt < MT) { issue(mt * 128, 0); load_z2(mt * 128); }
-    for (; mt < MT; mt += a.gx) {
+    for (; mt < MT; mt += a.nwalk) {
         const int m0 = mt * 128;
         f32x16 accd[MI][NI];
 #pragma unroll
@@ -707,7 +714,7 @@ __global__ __launch_bounds__(T, 2) void pw_conv3_bwd_kernel(const PairArgs a)
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             if (kt + 1 < KT) issue(m0, kt + 1);
-            else if (mt + a.gx < MT) issue((mt + a.gx) * 128, 0);  // the next row tile's first chunk, in flight under the epilogue
+            else if (mt + a.nwalk < MT) issue((mt + a.nwalk) * 128, 0);   // the next row tile's first chunk, in flight under the epilogue
             const uint32_t sb = (uint32_t)((kt & 1) * STAGE);
             typedef typename rn::mma<DT>::frag frag8;
 #pragma unroll
@@ -775,11 +782,11 @@ __global__ __launch_bounds__(T, 2) void pw_conv3_bwd_kernel(const PairArgs a)
                         qsum[j] = fmaf(v[j], (z[j] - emu[j]) * eis[j], qsum[j]);
                     }
                     o = rn::dt<DT>::pack(v);
-                    *(rn::u32x4 *)(a.Y + (int64_t)m * CM + ecg * 8) = o;
+                    *(rn::u32x4 *)(a.Y + (int64_t)m * cmr + n0 + ecg * 8) = o;
                 }
             }
         }
-        if (mt + a.gx < MT) load_z2((mt + a.gx) * 128);            // consumed by the next tile's commit_a2 and epilogue
+        if (mt + a.nwalk < MT) load_z2((mt + a.nwalk) * 128);      // consumed by the next tile's commit_a2 and epilogue
         __syncthreads();                                            // the tile is the next row tile's staging area
     }
 
@@ -792,17 +799,17 @@ __global__ __launch_bounds__(T, 2) void pw_conv3_bwd_kernel(const PairArgs a)
             float t = 0.0f;
             for (int l = 0; l < RL; ++l) t += red[l * 2 * CM + q];
             const int which = q >= CM ? 1 : 0;
-            a.partial_bn[((int64_t)blockIdx.x * 2 + which) * CM + (q - which * CM)] = t;
+            a.partial_bn[((int64_t)walker * 2 + which) * cmr + n0 + (q - which * CM)] = t;
         }
     }
-    float *__restrict__ outw = a.partial_w + (int64_t)blockIdx.x * C4 * CM;
+    float *__restrict__ outw = a.partial_w + (int64_t)walker * C4 * cmr + n0;
 #pragma unroll
     for (int k = 0; k < KW; ++k) {
         const int col = wc * 32 + (lane & 31);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (k * GROUPS + wk) * 64 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            outw[row * CM + col] = accw[k][r];
+            outw[row * cmr + col] = accw[k][r];
         }
     }
 }
@@ -991,16 +998,18 @@ int check_geometry(const rn_pw_conv *d)
 constexpr int PAIR_THREADS = 512, PAIR_WGS_PER_CU = 1;
 static int pair_walkers(const int64_t M, const int Cm)
 {
-    const int MT = (int)((M + 127) / 128), cap = PAIR_WGS_PER_CU * cu_count();
-    if (MT <= cap) return MT;
-    const int rounds = (MT + cap - 1) / cap;
-    return (MT + rounds - 1) / rounds;
+    const int halves = Cm / 64;
+    const int MT = (int)((M + 127) / 128), cap = PAIR_WGS_PER_CU * cu_count() / halves;
+    int w = MT;
+    if (MT > cap) { const int rounds = (MT + cap - 1) / cap; w = (MT + rounds - 1) / rounds; }
+    if (halves == 2) w = (w + 7) & ~7;          // the pairing of the two column halves works on groups of 8 walkers (idle ones write zero partials)
+    return w;
 }
 static bool pair_shape_ok(const int64_t M, const int Cm, const int C4)
 {
-    // (Cm, C4) = (128, 512) is not offered: its 512 x 128 f32 accumulators (256 KB per workgroup) leave the
-    // transforms no registers -- 134 - 192 VGPRs spilled, 216 us against 105 + 72 for the two separate launches at the layer2 shape.
-    return M > 0 && M < ((int64_t)1 << 31) / (C4 > 0 ? C4 : 1) * 8 && Cm == 64 && C4 == 256;
+    // (Cm, C4) = (128, 512): two workgroups per row tile, 64 columns each (one workgroup would hold 512 x 128 f32 accumulators, 256 KB:
+    // 134 - 192 VGPRs spilled, 216 us against 105 + 72 for the two separate launches at the layer2 shape)
+    return M > 0 && M < ((int64_t)1 << 31) / (C4 > 0 ? C4 : 1) * 8 && ((Cm == 64 && C4 == 256) || (Cm == 128 && C4 == 512));
 }
 template <int DT, int CM, int KT> static int launch_pair(const PairArgs &a, hipStream_t st)
 {
@@ -1008,7 +1017,7 @@ template <int DT, int CM, int KT> static int launch_pair(const PairArgs &a, hipS
     constexpr int lds = main_b + 128 * CM * 2 + 3 * KT * 64 * 4 + 4 * CM * 4;
     static rn::DynLdsOptIn opt_in = {};
     { const int rc = opt_in.ensure((const void *)pw_conv3_bwd_kernel<DT, CM, KT, PAIR_THREADS>, lds); if (rc != RN_OK) return rc; }
-    hipLaunchKernelGGL((pw_conv3_bwd_kernel<DT, CM, KT, PAIR_THREADS>), dim3((unsigned)a.gx), dim3(PAIR_THREADS), lds, st, a);
+    hipLaunchKernelGGL((pw_conv3_bwd_kernel<DT, CM, KT, PAIR_THREADS>), dim3((unsigned)(a.nwalk * a.halves)), dim3(PAIR_THREADS), lds, st, a);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
@@ -1038,10 +1047,11 @@ RN_API int rn_pw_conv3_backward(int64_t M, int Cm, int C4, int dtype, const void
     a.G = (const uint16_t *)g; a.Z3 = (const uint16_t *)z3; a.gbits = bits; a.pa = a3; a.pb = k0; a.pc = k1;
     a.Wt = (const uint16_t *)w3t; a.Z2 = (const uint16_t *)z2; a.ea = ea; a.eb = eb; a.emean = emean; a.einv = einv;
     a.Y = (uint16_t *)dy2; a.partial_bn = partial_bn; a.partial_w = (float *)workspace;
-    a.M = (int)M; a.gx = pair_walkers(M, Cm); a.f16 = dtype == RN_F16;
-    *splits = a.gx;
+    a.M = (int)M; a.nwalk = pair_walkers(M, Cm); a.f16 = dtype == RN_F16; a.cm = Cm; a.halves = Cm / 64;
+    *splits = a.nwalk;
     hipStream_t st = (hipStream_t)stream;
-    return a.f16 ? launch_pair<RN_F16, 64, 4>(a, st) : launch_pair<RN_BF16, 64, 4>(a, st);
+    if (Cm == 64) return a.f16 ? launch_pair<RN_F16, 64, 4>(a, st) : launch_pair<RN_BF16, 64, 4>(a, st);
+    return a.f16 ? launch_pair<RN_F16, 64, 8>(a, st) : launch_pair<RN_BF16, 64, 8>(a, st);
 }
 
 RN_API int rn_pw_walkers(int64_t M) { return M > 0 && M < ((int64_t)1 << 31) ? walkers((int)M) : 0; }

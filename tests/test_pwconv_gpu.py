@@ -232,7 +232,7 @@ def test_weight_gradient_with_both_operand_transforms(c4, cm):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("c4,cm,H,W", [(256, 64, 19, 23), (512, 128, 19, 23), (256, 64, 260, 260), (256, 64, 1, 5)])
+@pytest.mark.parametrize("c4,cm,H,W", [(256, 64, 19, 23), (512, 128, 19, 23), (256, 64, 260, 260), (512, 128, 150, 130), (256, 64, 1, 5), (512, 128, 1, 5)])
 def test_conv3_backward_in_one_pass(c4, cm, H, W, dtype):
     """``rn_pw_conv3_backward``: the data gradient (bn3-backward prologue, ReLU-backward epilogue + bn2-backward sums) and the weight
     gradient of a bottleneck's conv3 from ONE pass over (g_out, z3, bits) -- against fp32 PyTorch on the same inputs, and against the
@@ -251,9 +251,6 @@ def test_conv3_backward_in_one_pass(c4, cm, H, W, dtype):
     st2 = torch.cat([torch.randn(cm, device=DEV, generator=gen) * 0.2, torch.rand(cm, device=DEV, generator=gen) + 0.5,
                      torch.rand(cm, device=DEV, generator=gen) + 0.5, torch.randn(cm, device=DEV, generator=gen) * 0.3])    # mean | invstd | a | b
     nb = lib.rn_pw_conv3_backward_walkers(M, cm, c4)
-    if cm != 64:
-        assert nb == 0          # layer2's shape is refused (register budget, csrc/pw.hip): the caller keeps the two launches
-        return
     assert nb > 0 and nb <= 512
     part = torch.full((nb * 2 * cm,), float("nan"), dtype=torch.float32, device=DEV)
     dy2 = torch.full_like(z2, float("nan"))
