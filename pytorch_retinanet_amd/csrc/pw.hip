@@ -577,7 +577,7 @@ __global__ __launch_bounds__(T, 2) void pw_conv3_bwd_kernel(const PairArgs a)
     // weight gradient: a K-chunk's [64 c4][CM] block is NTILES tiles of 32 x 32, one per wave; with twice as many waves as tiles the
     // two wave groups take the even / the odd chunks (accumulators: KT / GROUPS tiles per wave, nothing held twice)
     constexpr int NTILES = CM / 16, GROUPS = NW / NTILES, KW = KT / GROUPS;
-    static_assert(NW == NTILES * GROUPS && KT == KW * GROUPS && MI * WM == 4, "wave roles");
+    static_assert(NW == NTILES * GROUPS && KT == KW * GROUPS && MI * WM == 4 && (KT & (KT - 1)) == 0 && (KT / 2) % GROUPS == 0, "wave roles");
     constexpr int A_TILE = 128 * 128, W_TILE = CM * 128, STAGE = A_TILE + W_TILE;
     constexpr int AV = 1024 / T, ARS = T / 8, WV = CM * 8 / T;   // staged 16-byte vectors per thread (rows r0 + ARS i)
     constexpr int CG = CM / 8, RL = T / CG, EROWS = 128 / RL;    // epilogue: thread = 8 fixed columns, rows erl + RL i
@@ -593,6 +593,11 @@ __global__ __launch_bounds__(T, 2) void pw_conv3_bwd_kernel(const PairArgs a)
     const int bid = blockIdx.x;
     const int half = a.halves == 2 ? (bid >> 3) & 1 : 0, walker = a.halves == 2 ? ((bid >> 4) << 3) | (bid & 7) : bid;
     const int n0 = half * CM, cmr = a.cm;
+    // ... and walks the K-chunks half a turn ahead of it (chunk (kt + krot) % KT at step kt): the pair then has two DIFFERENT chunks in
+    // flight -- with the same one, the pair's loads merge in L2 and two CUs have the bytes in flight of one (134 us at the layer2 shape,
+    // the latency x concurrency bound).  The column halves of dy2 thus sum their K-chunks in different orders (deterministic; the first
+    // half in pw_gemm_kernel's order).
+    const int krot = half * (KT / 2);
     float *const s_coef = (float *)(lds + COEF_OFF);             // [pa | pb | pc][C4], then [ea | eb | emean | einv][CM]
     float *const s_epi = s_coef + 3 * C4;
     for (int q = tid; q < 3 * C4; q += T) {
@@ -641,36 +646,41 @@ __global__ __launch_bounds__(T, 2) void pw_conv3_bwd_kernel(const PairArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accw[k][r] = 0.0f;
 
-    rn::u32x4 sx[AV], sz[AV], sw[WV], er[EROWS];
-    uint32_t sbits[AV];
-    bool sval[AV];
-    int skt = 0;
-    auto issue = [&](const int m0, const int kt) {
+    // DEPTH register sets of staged chunks: chunk kt of every tile lives in set kt % DEPTH and goes to LDS stage kt & 1; the loads of
+    // chunk kt + DEPTH are issued when chunk kt's MFMAs start.  The kernel is bound by load latency x bytes in flight: at the layer1
+    // shape (KT = 4) two chunks ahead take it from 149 to 140 us, the stream rate of its 722 MB; the KT = 8 form has no registers for
+    // a second set (11 - 33 VGPRs spilled, 121 -> 140 us) and stays one chunk ahead.  `set` is a literal after unrolling.
+    constexpr int DEPTH = KT == 4 ? 2 : 1;
+    rn::u32x4 sx[DEPTH][AV], sz[DEPTH][AV], sw[DEPTH][WV], er[EROWS];
+    uint32_t sbits[DEPTH][AV];
+    bool sval[DEPTH][AV];
+    int skt[DEPTH] = {};
+    auto issue = [&](const int set, const int m0, const int kt) {
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
             const int m = m0 + r0 + ARS * i;
-            sval[i] = m < a.M;
-            const int64_t e = (int64_t)(sval[i] ? m : 0) * C4 + kt * 64 + c * 8;
-            sx[i] = *(const rn::u32x4 *)(a.G + e);
-            sz[i] = *(const rn::u32x4 *)(a.Z3 + e);
-            sbits[i] = a.gbits[e >> 3];
+            sval[set][i] = m < a.M;
+            const int64_t e = (int64_t)(sval[set][i] ? m : 0) * C4 + kt * 64 + c * 8;
+            sx[set][i] = *(const rn::u32x4 *)(a.G + e);
+            sz[set][i] = *(const rn::u32x4 *)(a.Z3 + e);
+            sbits[set][i] = a.gbits[e >> 3];
         }
 #pragma unroll
-        for (int i = 0; i < WV; ++i) sw[i] = *(const rn::u32x4 *)(a.Wt + (int64_t)(n0 + r0 + ARS * i) * C4 + kt * 64 + c * 8);
-        skt = kt;
+        for (int i = 0; i < WV; ++i) sw[set][i] = *(const rn::u32x4 *)(a.Wt + (int64_t)(n0 + r0 + ARS * i) * C4 + kt * 64 + c * 8);
+        skt[set] = kt;
     };
-    auto commit = [&](const int stage) {
+    auto commit = [&](const int set, const int stage) {
         unsigned char *const sb = lds + stage * STAGE;
         ProCoef coef;
-        const int ch = skt * 64 + c * 8;
+        const int ch = skt[set] * 64 + c * 8;
         ld8f(s_coef + ch, coef.a); ld8f(s_coef + C4 + ch, coef.b); ld8f(s_coef + 2 * C4 + ch, coef.c);
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
-            *(rn::u32x4 *)(sb + wa_off[i]) = transform<DT, PRO_BN_BWD>(sx[i], sz[i], sbits[i], coef, 3, sval[i]);
+            *(rn::u32x4 *)(sb + wa_off[i]) = transform<DT, PRO_BN_BWD>(sx[set][i], sz[set][i], sbits[set][i], coef, 3, sval[set][i]);
             __builtin_amdgcn_sched_barrier(0);                      // one vector's 16 floats live at a time (registers)
         }
 #pragma unroll
-        for (int i = 0; i < WV; ++i) *(rn::u32x4 *)(sb + ww_off[i]) = sw[i];
+        for (int i = 0; i < WV; ++i) *(rn::u32x4 *)(sb + ww_off[i]) = sw[set][i];
     };
     auto load_z2 = [&](const int m0) {
 #pragma unroll
@@ -699,7 +709,11 @@ __global__ __launch_bounds__(T, 2) void pw_conv3_bwd_kernel(const PairArgs a)
     const float alive = alive_dt<DT>();
 
     int mt = walker;
-    if (mt < MT) { issue(mt * 128, 0); load_z2(mt * 128); }
+    if (mt < MT) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) issue(d, mt * 128, (krot + d) & (KT - 1));
+        load_z2(mt * 128);
+    }
     for (; mt < MT; mt += a.nwalk) {
         const int m0 = mt * 128;
         f32x16 accd[MI][NI];
@@ -709,12 +723,12 @@ __global__ __launch_bounds__(T, 2) void pw_conv3_bwd_kernel(const PairArgs a)
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accd[i][j][r] = 0.0f;
-        commit(0);
+        commit(0, 0);
         __syncthreads();
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            if (kt + 1 < KT) issue(m0, kt + 1);
-            else if (mt + a.nwalk < MT) issue((mt + a.nwalk) * 128, 0);   // the next row tile's first chunk, in flight under the epilogue
+            if (kt + DEPTH < KT) issue(kt % DEPTH, m0, (kt + DEPTH + krot) & (KT - 1));
+            else if (mt + a.nwalk < MT) issue(kt % DEPTH, (mt + a.nwalk) * 128, (kt + DEPTH + krot) & (KT - 1));   // the next row tile's first chunks
             const uint32_t sb = (uint32_t)((kt & 1) * STAGE);
             typedef typename rn::mma<DT>::frag frag8;
 #pragma unroll
@@ -744,7 +758,7 @@ __global__ __launch_bounds__(T, 2) void pw_conv3_bwd_kernel(const PairArgs a)
                     if (kk & 1) __builtin_amdgcn_sched_barrier(0); // (keeps the fragment reads of all 8 steps from being hoisted: registers)
                 }
             }
-            if (kt + 1 < KT) commit((kt + 1) & 1);
+            if (kt + 1 < KT) commit((kt + 1) % DEPTH, (kt + 1) & 1);
             __syncthreads();
         }
 
@@ -808,7 +822,7 @@ __global__ __launch_bounds__(T, 2) void pw_conv3_bwd_kernel(const PairArgs a)
         const int col = wc * 32 + (lane & 31);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = (k * GROUPS + wk) * 64 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int row = ((k * GROUPS + wk + krot) & (KT - 1)) * 64 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             outw[row * cmr + col] = accw[k][r];
         }
     }

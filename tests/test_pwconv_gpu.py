@@ -291,8 +291,11 @@ def test_conv3_backward_in_one_pass(c4, cm, H, W, dtype):
     pro = pwconv.bn_bwd(coef3, z3, 3, bits=bits)
     dy_two = pwconv.pw_forward(gup, w3t, pro=pro, epi=epi)
     dw_two = pwconv.pw_wgrad(gup, z2, w3, gpro=pro, xpro=pwconv.affine_relu(st2[2 * cm:]))
-    if dtype == torch.bfloat16:
+    if dtype == torch.bfloat16 and cm == 64:
         assert torch.equal(dy_two, dy2)
+    elif dtype == torch.bfloat16:   # two column halves: the first sums its K-chunks in the separate kernel's order, the second half a turn ahead
+        assert torch.equal(dy_two[:, :64], dy2[:, :64])
+        _close(dy2.float(), dy_two.float(), 1e-2, "data gradient vs the separate kernel")
     else:       # fp16: the compiler may round fma + conversion once (v_fma_mixlo_f16) in one kernel and twice in the other: rare 1-ulp differences
         _close(dy2.float(), dy_two.float(), 1e-3, "data gradient vs the separate kernel")
     _close(dw.float(), dw_two.float(), 4e-3, "weight gradient vs the separate kernel")
