@@ -358,6 +358,17 @@ int rn_pw_wgrad_reduce_many(const void *const *partials, const int *splits, cons
  *   *splits = walkers: the (partials, splits) pair rn_pw_wgrad_reduce_many_dt sums into dW3 [C4][Cm].
  * Shapes: (Cm, C4) = (64, 256) and (128, 512) -- layer1 / layer2 of the ResNet-50 trunk; walkers() returns 0 and the call
  * RN_EUNSUPPORTED for anything else (the caller keeps the two separate launches).  dy2 is bit-identical to the separate launch. */
+/* The end of one bottleneck and the start of the next in one pass (forward, ABI 9): the block output
+ *   y = relu(fma(z3, oa, ob) + r),  r = resid (identity block) or round(fma(resid, res_a, res_b)) (resid = the INPUT of the downsample
+ *   branch's BatchNorm; res_a / res_b both NULL otherwise),  ybits [M][C4 / 8] = [y alive]
+ * -- exactly rn_bn_apply(z3, resid, relu = 1, bits) / rn_bn_apply_res_affine (/root/reference/retinanet/backbone.py:132-136) -- is
+ * written AND multiplied, from LDS, into the next block's conv1 (1x1, C4 -> CN; backbone.py:118):  z1 [M][CN] = y . w1^T with
+ * partial f32 [walkers][2][CN] = column sums / sums of squares of z1 as stored (what rn_pw_conv_forward(y, w1, RN_PW_EPI_STATS) returns;
+ * z1 is bit-identical to it).  The separate launches write y and read it straight back.  16-bit elements of `dtype`; oa / ob / res_a /
+ * res_b f32 [C4], 16-byte aligned; w1 [CN][C4].  (C4, CN) = (256, 64), (256, 128), (512, 128): walkers() is 0 for anything else. */
+int rn_pw_block_out_conv1_walkers(int64_t M, int C4, int CN);
+int rn_pw_block_out_conv1(int64_t M, int C4, int CN, int dtype, const void *z3, const void *resid, const float *res_a, const float *res_b,
+                          const float *oa, const float *ob, const void *w1, void *y, uint8_t *ybits, void *z1, float *partial, void *stream);
 int rn_pw_conv3_backward_walkers(int64_t M, int Cm, int C4);
 size_t rn_pw_conv3_backward_workspace_bytes(int64_t M, int Cm, int C4);
 int rn_pw_conv3_backward(int64_t M, int Cm, int C4, int dtype, const void *g, const void *z3, const uint8_t *bits, const float *a3,

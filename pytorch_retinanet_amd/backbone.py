@@ -235,6 +235,8 @@ class ResNetBackbone(nn.Module):
         self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
         self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
         self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        if block is Bottleneck:        # who consumes whose output: a fused block forms the next one's conv1 with its own output (pwconv.FUSE_CHAIN)
+            pwconv.link_blocks(list(self.layer1) + list(self.layer2) + list(self.layer3) + list(self.layer4))
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")

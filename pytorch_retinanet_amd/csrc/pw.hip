@@ -828,6 +828,192 @@ __global__ __launch_bounds__(T, 2) void pw_conv3_bwd_kernel(const PairArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The end of one bottleneck and the start of the next in one pass (forward): the block output
+//     y = relu(bn3(z3) + identity)          (norm.hip's bn_apply_kernel<RELU, RES[, RA]>; retinanet/backbone.py:132-136)
+// is formed chunk by chunk (128 positions x 64 channels) from z3 and the identity, written to memory with its ReLU bits -- and, still
+// in LDS, multiplied into the NEXT block's conv1 (1x1, C4 -> CN channels; backbone.py:118), whose output z1 and bn1 statistics
+// partials leave from the epilogue (pw_gemm_kernel<.., PRO_NONE, EPI_STATS> on y).  The separate launches write y (275 MB at layer1)
+// and read it straight back; here it is only written.  Same products in the same order as pw_gemm_kernel: z1 is bit-identical.
+// 512 threads, a 128-row tile, all CN columns; DEPTH chunks of (z3, identity) in flight in registers.
+struct ChainArgs {
+    const uint16_t *Z3, *R;         // [M][C4]: bn3 input; the identity (RA: the INPUT of the downsample branch's BatchNorm)
+    const float *oa, *ob;           // [C4]: bn3's forward coefficients
+    const float *ra, *rb;           // [C4], RA only: the downsample BatchNorm's
+    const uint16_t *W1;             // [CN][C4]: the next block's conv1 weight
+    uint16_t *Y;                    // [M][C4]
+    uint8_t *ybits;                 // [M][C4 / 8]
+    uint16_t *Z1;                   // [M][CN]
+    float *partial;                 // [gx][2][CN]: column sums / sums of squares of Z1 as stored
+    int M, gx, f16;
+};
+
+template <int DT, int CN, int KT, bool RA>
+__global__ __launch_bounds__(512, 2) void pw_block_out_conv1_kernel(const ChainArgs a)
+{
+    constexpr int T = 512, C4 = KT * 64;
+    constexpr int NI = CN / 64;                                  // 4 x 2 waves of 32 x (CN / 2)
+    constexpr int A_TILE = 128 * 128, W_TILE = CN * 128, STAGE = A_TILE + W_TILE;
+    constexpr int AV = 1024 / T, ARS = T / 8, WV = CN * 8 / T;
+    constexpr int CG = CN / 8, RL = T / CG, EROWS = 128 / RL;
+    constexpr int LDS_MAIN = (2 * STAGE > 128 * CN * 4) ? 2 * STAGE : 128 * CN * 4;
+    constexpr int NCOEF = RA ? 4 : 2, DEPTH = 2;
+    static_assert(WV * ARS == CN && EROWS * RL == 128 && AV * ARS == 128 && KT % DEPTH == 0, "tile split");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = tid & 7, r0 = tid >> 3;
+    const int MT = (a.M + 127) / 128;
+    float *const s_coef = (float *)(lds + LDS_MAIN);             // [oa | ob | ra | rb][C4]
+    for (int q = tid; q < NCOEF * C4; q += T) {
+        const int which = q / C4, ch = q - which * C4;
+        s_coef[q] = (which == 0 ? a.oa : (which == 1 ? a.ob : (which == 2 ? a.ra : a.rb)))[ch];
+    }
+    __syncthreads();
+    uint32_t wa_off[AV], ww_off[WV];
+#pragma unroll
+    for (int i = 0; i < AV; ++i) { const int row = r0 + ARS * i; wa_off[i] = row * 128 + ((c ^ PW_SWZ(row)) << 4); }
+#pragma unroll
+    for (int i = 0; i < WV; ++i) { const int row = r0 + ARS * i; ww_off[i] = A_TILE + row * 128 + ((c ^ PW_SWZ(row)) << 4); }
+    const int wm = wave >> 1, wn = wave & 1;
+    uint32_t a_off[4], b_off[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int chunk = kk * 2 + (lane >> 5);
+        { const int row = wm * 32 + (lane & 31); a_off[kk] = row * 128 + ((chunk ^ PW_SWZ(row)) << 4); }
+        { const int row = wn * (CN / 2) + (lane & 31); b_off[kk] = A_TILE + row * 128 + ((chunk ^ PW_SWZ(row)) << 4); }
+    }
+    const int ecg = tid % CG, erl = tid / CG;
+    float ssum[8], qsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ssum[j] = 0.0f; qsum[j] = 0.0f; }
+    const float alive = alive_dt<DT>();
+
+    rn::u32x4 sx[DEPTH][AV], sr[DEPTH][AV], sw[DEPTH][WV];
+    int srow[DEPTH][AV], skt[DEPTH] = {};                        // (row < 0: past the end)
+    auto issue = [&](const int set, const int m0, const int kt) {
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            const int m = m0 + r0 + ARS * i;
+            srow[set][i] = m < a.M ? m : -1;
+            const int64_t e = (int64_t)(m < a.M ? m : 0) * C4 + kt * 64 + c * 8;
+            sx[set][i] = *(const rn::u32x4 *)(a.Z3 + e);
+            sr[set][i] = *(const rn::u32x4 *)(a.R + e);
+        }
+#pragma unroll
+        for (int i = 0; i < WV; ++i) sw[set][i] = *(const rn::u32x4 *)(a.W1 + (int64_t)(r0 + ARS * i) * C4 + kt * 64 + c * 8);
+        skt[set] = kt;
+    };
+    auto commit = [&](const int set, const int stage) {          // y chunk -> memory (+ bits) and -> the LDS operand tile
+        unsigned char *const sb = lds + stage * STAGE;
+        const int ch = skt[set] * 64 + c * 8;
+        float oa[8], ob[8], ra[8], rb[8];
+        ld8f(s_coef + ch, oa); ld8f(s_coef + C4 + ch, ob);
+        if (RA) { ld8f(s_coef + 2 * C4 + ch, ra); ld8f(s_coef + 3 * C4 + ch, rb); }
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            float f[8], r[8];
+            rn::dt<DT>::unpack(sx[set][i], f);
+            rn::dt<DT>::unpack(sr[set][i], r);
+            unsigned bits = 0;
+            if (RA) {
+                rn::u32x4 rr;
+                float t8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t8[j] = fmaf(r[j], ra[j], rb[j]);
+                rr = rn::dt<DT>::pack(t8);                        // the branch's BatchNorm output as a separate apply pass would have stored it
+                rn::dt<DT>::unpack(rr, r);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float t = fmaf(f[j], oa[j], ob[j]) + r[j];
+                bits |= (t > alive) ? (1u << j) : 0u;
+                f[j] = t > 0.0f ? t : 0.0f;
+            }
+            rn::u32x4 o = rn::dt<DT>::pack(f);
+            const bool ok = srow[set][i] >= 0;
+            if (ok) {
+                const int64_t e = (int64_t)srow[set][i] * C4 + ch;
+                *(rn::u32x4 *)(a.Y + e) = o;
+                a.ybits[e >> 3] = (uint8_t)bits;
+            } else o = rn::u32x4{0u, 0u, 0u, 0u};
+            *(rn::u32x4 *)(sb + wa_off[i]) = o;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < WV; ++i) *(rn::u32x4 *)(sb + ww_off[i]) = sw[set][i];
+    };
+
+    int mt = blockIdx.x;
+    if (mt < MT) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) issue(d, mt * 128, d);
+    }
+    for (; mt < MT; mt += a.gx) {
+        const int m0 = mt * 128;
+        f32x16 acc[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+        commit(0, 0);
+        __syncthreads();
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt + DEPTH < KT) issue(kt % DEPTH, m0, kt + DEPTH);
+            else if (mt + a.gx < MT) issue(kt % DEPTH, (mt + a.gx) * 128, kt + DEPTH - KT);
+            const uint32_t sb = (uint32_t)((kt & 1) * STAGE);
+            typedef typename rn::mma<DT>::frag frag8;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const frag8 fa = *(const frag8 *)(lds + sb + a_off[kk]);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const frag8 fb = *(const frag8 *)(lds + sb + b_off[kk] + ni * 4096);
+                    acc[ni] = rn::mma<DT>::m32(fa, fb, acc[ni]);
+                }
+            }
+            if (kt + 1 < KT) commit((kt + 1) % DEPTH, (kt + 1) & 1);
+            __syncthreads();
+        }
+        // ---- epilogue (pw_gemm_kernel's EPI_STATS): z1 as stored, its column sums / sums of squares
+        float *const tile = (float *)lds;                           // [128][CN]
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = wn * (CN / 2) + ni * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                tile[row * CN + col] = acc[ni][r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < EROWS; ++i) {
+            const int row = erl + i * RL, m = m0 + row;
+            if (m < a.M) {
+                float v[8];
+                ld8f(tile + row * CN + ecg * 8, v);
+                const rn::u32x4 o = rn::dt<DT>::pack(v);
+                rn::dt<DT>::unpack(o, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; qsum[j] = fmaf(v[j], v[j], qsum[j]); }
+                *(rn::u32x4 *)(a.Z1 + (int64_t)m * CN + ecg * 8) = o;
+            }
+        }
+        __syncthreads();
+    }
+    float *const red = (float *)lds;                                // [RL][2][CN]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[(erl * 2 + 0) * CN + ecg * 8 + j] = ssum[j]; red[(erl * 2 + 1) * CN + ecg * 8 + j] = qsum[j]; }
+    __syncthreads();
+    for (int q = tid; q < 2 * CN; q += T) {
+        float t = 0.0f;
+        for (int l = 0; l < RL; ++l) t += red[l * 2 * CN + q];
+        const int which = q >= CN ? 1 : 0;
+        a.partial[((int64_t)blockIdx.x * 2 + which) * CN + (q - which * CN)] = t;
+    }
+}
+
 // dW (bf16) = sum over the splits of partial (f32).  A block owns 32 float4 outputs; its 8 thread rows each sum every 8th
 // split (8 loads in flight per output instead of one serial chain over S), then the 8 sums are combined in a fixed order.
 template <int DT>
@@ -1034,6 +1220,56 @@ template <int DT, int CM, int KT> static int launch_pair(const PairArgs &a, hipS
     hipLaunchKernelGGL((pw_conv3_bwd_kernel<DT, CM, KT, PAIR_THREADS>), dim3((unsigned)(a.nwalk * a.halves)), dim3(PAIR_THREADS), lds, st, a);
     RN_LAUNCH_CHECK();
     return RN_OK;
+}
+
+constexpr int CHAIN_WGS_PER_CU = 1;
+static int chain_walkers(const int64_t M)
+{
+    const int MT = (int)((M + 127) / 128), cap = CHAIN_WGS_PER_CU * cu_count();
+    if (MT <= cap) return MT;
+    const int rounds = (MT + cap - 1) / cap;
+    return (MT + rounds - 1) / rounds;
+}
+static bool chain_shape_ok(const int64_t M, const int C4, const int CN)
+{
+    return M > 0 && M < ((int64_t)1 << 31) / (C4 > 0 ? C4 : 1) * 8 && ((C4 == 256 && (CN == 64 || CN == 128)) || (C4 == 512 && CN == 128));
+}
+template <int DT, int CN, int KT, bool RA> static int launch_chain(const ChainArgs &a, hipStream_t st)
+{
+    constexpr int stage = 128 * 128 + CN * 128, main_b = (2 * stage > 128 * CN * 4) ? 2 * stage : 128 * CN * 4;
+    constexpr int lds = main_b + (RA ? 4 : 2) * KT * 64 * 4;
+    static rn::DynLdsOptIn opt_in = {};
+    { const int rc = opt_in.ensure((const void *)pw_block_out_conv1_kernel<DT, CN, KT, RA>, lds); if (rc != RN_OK) return rc; }
+    hipLaunchKernelGGL((pw_block_out_conv1_kernel<DT, CN, KT, RA>), dim3((unsigned)a.gx), dim3(512), lds, st, a);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+template <int DT, bool RA> static int dispatch_chain(const ChainArgs &a, const int C4, const int CN, hipStream_t st)
+{
+    if (C4 == 256 && CN == 64) return launch_chain<DT, 64, 4, RA>(a, st);
+    if (C4 == 256) return launch_chain<DT, 128, 4, RA>(a, st);
+    return launch_chain<DT, 128, 8, RA>(a, st);
+}
+
+RN_API int rn_pw_block_out_conv1_walkers(int64_t M, int C4, int CN) { return chain_shape_ok(M, C4, CN) ? chain_walkers(M) : 0; }
+
+RN_API int rn_pw_block_out_conv1(int64_t M, int C4, int CN, int dtype, const void *z3, const void *resid, const float *res_a, const float *res_b,
+                                 const float *oa, const float *ob, const void *w1, void *y, uint8_t *ybits, void *z1, float *partial,
+                                 void *stream)
+{
+    if (!z3 || !resid || !oa || !ob || !w1 || !y || !ybits || !z1 || !partial || (!res_a) != (!res_b)) return RN_EINVAL;
+    if (dtype != RN_BF16 && dtype != RN_F16) return RN_EUNSUPPORTED;
+    if (!chain_shape_ok(M, C4, CN)) return RN_EUNSUPPORTED;
+    if (!rn::aligned(z3, 16) || !rn::aligned(resid, 16) || !rn::aligned(w1, 16) || !rn::aligned(y, 16) || !rn::aligned(z1, 16) ||
+        !rn::aligned(oa, 16) || !rn::aligned(ob, 16) || (res_a && (!rn::aligned(res_a, 16) || !rn::aligned(res_b, 16))))
+        return RN_EALIGN;
+    ChainArgs a = {};
+    a.Z3 = (const uint16_t *)z3; a.R = (const uint16_t *)resid; a.oa = oa; a.ob = ob; a.ra = res_a; a.rb = res_b;
+    a.W1 = (const uint16_t *)w1; a.Y = (uint16_t *)y; a.ybits = ybits; a.Z1 = (uint16_t *)z1; a.partial = partial;
+    a.M = (int)M; a.gx = chain_walkers(M); a.f16 = dtype == RN_F16;
+    hipStream_t st = (hipStream_t)stream;
+    if (a.f16) return res_a ? dispatch_chain<RN_F16, true>(a, C4, CN, st) : dispatch_chain<RN_F16, false>(a, C4, CN, st);
+    return res_a ? dispatch_chain<RN_BF16, true>(a, C4, CN, st) : dispatch_chain<RN_BF16, false>(a, C4, CN, st);
 }
 
 RN_API int rn_pw_conv3_backward_walkers(int64_t M, int Cm, int C4) { return pair_shape_ok(M, Cm, C4) ? pair_walkers(M, Cm) : 0; }

@@ -38,6 +38,7 @@ FUSED_BOTTLENECK = os.environ.get("RN_FUSED_BOTTLENECK", "1") != "0"      # 0: t
 # fusion; at layer3 / layer4 (256 / 512 mid channels, K up to 2048) the GEMMs are compute-bound and the 128 x 128 register-staged
 # tiles of csrc/pw.hip run at a third of MIOpen's rate (measured: conv3 data gradient 99 us against 36 + 22 us)
 FUSED_MAX_MID = int(os.environ.get("RN_FUSED_MAX_MID", "128"))
+FUSE_CHAIN = True              # a fused block forms its output together with the NEXT fused block's conv1 (+ bn1 statistics): rn_pw_block_out_conv1
 FUSE_CONV3_BWD = True          # conv3's data and weight gradients in one pass over the block-output gradient (layer1 / layer2 shapes)
 DEFER_WGRAD_REDUCE = True      # a fused block sums the splits of its 1x1 weight gradients in one launch at the end of its backward
 _WG_WS: Dict[tuple, Tensor] = {}
@@ -246,9 +247,14 @@ class _BottleneckFn(torch.autograd.Function):
         dev = x.device
         Nimg, Cin, H, W = x.shape
         M0 = Nimg * H * W
-        # conv1 + bn1 statistics in its epilogue
-        e1, p1, nb1 = stats_epilogue(M0, w1.shape[0], dev)
-        z1 = pw_forward(x, w1, epi=e1, tag="pw_conv1_fwd")
+        # conv1 + bn1 statistics in its epilogue -- unless the block before has already formed them with its output (FUSE_CHAIN)
+        cin = blk.__dict__.pop("_chain_in", None)
+        if (cin is not None and cin[1] == x.data_ptr() and cin[2] == x._version and cin[0][3] == w1.data_ptr() and cin[0][4] == w1._version
+                and tuple(cin[0][0].shape) == (Nimg, w1.shape[0], H, W) and cin[0][0].dtype == x.dtype):
+            z1, p1, nb1 = cin[0][:3]
+        else:
+            e1, p1, nb1 = stats_epilogue(M0, w1.shape[0], dev)
+            z1 = pw_forward(x, w1, epi=e1, tag="pw_conv1_fwd")
         st1 = bn_finalize(p1, nb1, M0, blk.bn1)
         a1, _ = bn_apply(z1, st1, relu=True)                                 # conv2 is MIOpen's: it needs the activation
         from . import biasact
@@ -270,6 +276,30 @@ class _BottleneckFn(torch.autograd.Function):
             ed, pd, nbd = stats_epilogue(M1, wd.shape[0], dev)
             zd = pw_forward(x, wd, stride=blk.downsample[0].stride[0], epi=ed, tag="pw_down_fwd")
             std = bn_finalize(pd, nbd, M1, blk.downsample[1])
+        C4 = int(w3.shape[0])
+        nxt = blk.__dict__.get("_rn_next") if FUSE_CHAIN else None
+        nbn = 0
+        if nxt is not None and nxt[0].conv1.weight.dtype == x.dtype and nxt[0].conv1.weight.is_cuda and bottleneck_fusable(nxt[0], z3, in_forward=True):
+            w1n = nxt[0].conv1.weight
+            if tuple(w1n.shape[1:]) == (C4, 1, 1) and nxt[0].conv1.stride == (1, 1):
+                nbn = lib.rn_pw_block_out_conv1_walkers(M1, C4, int(w1n.shape[0]))
+        if nbn > 0:
+            # the block output AND the next block's conv1 + bn1 statistics in one pass (y is written, not read back): csrc/pw.hip
+            CN = int(w1n.shape[0])
+            out = torch.empty_like(z3)
+            bits = torch.empty((M1 * C4 // 8,), dtype=torch.uint8, device=dev)
+            z1n = torch.empty((z3.shape[0], CN, z3.shape[2], z3.shape[3]), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+            partn = torch.empty((nbn * 2 * CN,), dtype=torch.float32, device=dev)
+            p3o = st3.data_ptr()
+            res = zd if wd is not None else x
+            ra, rb = (std.data_ptr() + 8 * C4, std.data_ptr() + 12 * C4) if wd is not None else (0, 0)
+            PW_FLOP["pw_block_out_conv1"] = 2.0 * M1 * C4 * CN
+            with _timed("pw_block_out_conv1", dev):
+                check(lib.rn_pw_block_out_conv1(M1, C4, CN, _DT16[x.dtype], z3.data_ptr(), res.data_ptr(), ra, rb, p3o + 8 * C4, p3o + 12 * C4,
+                                                w1n.data_ptr(), out.data_ptr(), bits.data_ptr(), z1n.data_ptr(), partn.data_ptr(), _stream(dev)),
+                      "rn_pw_block_out_conv1")
+            blk.__dict__["_chain_tmp"] = (z1n, partn, nbn, w1n.data_ptr(), w1n._version)
+        elif wd is not None:
             # the branch's BatchNorm output is never written: the block-output pass forms it from zd and its coefficients
             out, bits = bn_apply(z3, st3, relu=True, residual=zd, res_stats=std, want_bits=True)
         else:
@@ -390,8 +420,9 @@ class _BottleneckFn(torch.autograd.Function):
         return (None, dx, dw1, gr1[:Cm], gr1[Cm:2 * Cm], dw2, gr2[:Cm], gr2[Cm:2 * Cm], dw3, gr3[:C4], gr3[C4:2 * C4], dwd, dgd, dbd)
 
 
-def bottleneck_fusable(blk, x: Tensor) -> bool:
-    if not (FUSED_BOTTLENECK and x.is_cuda and x.dtype in H16 and _cl(x) and torch.is_grad_enabled()):
+def bottleneck_fusable(blk, x: Tensor, in_forward: bool = False) -> bool:
+    "``in_forward``: asked from inside an autograd Function's forward (grad mode is off there) about the block that will run next"
+    if not (FUSED_BOTTLENECK and x.is_cuda and x.dtype in H16 and _cl(x) and (in_forward or torch.is_grad_enabled())):
         return False
     bns = [blk.bn1, blk.bn2, blk.bn3] + ([blk.downsample[1]] if blk.downsample is not None else [])
     convs = [blk.conv1, blk.conv2, blk.conv3] + ([blk.downsample[0]] if blk.downsample is not None else [])
@@ -415,10 +446,28 @@ def bottleneck_fusable(blk, x: Tensor) -> bool:
 
 def bottleneck(blk, x: Tensor) -> Tensor:
     dn = blk.downsample
-    return _BottleneckFn.apply(blk, x, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias,
-                               blk.conv3.weight, blk.bn3.weight, blk.bn3.bias,
-                               dn[0].weight if dn is not None else None, dn[1].weight if dn is not None else None,
-                               dn[1].bias if dn is not None else None)
+    # FUSE_CHAIN hand-over: the block before left its successor's conv1 output and statistics partials ON the tensor it returned; the
+    # consumer checks that this is that tensor (storage + version) and that conv1's weight is the one the products were formed with
+    hit = x.__dict__.pop("_rn_chain", None)
+    if hit is not None and FUSE_CHAIN:
+        blk.__dict__["_chain_in"] = (hit, x.data_ptr(), x._version)
+    try:
+        out = _BottleneckFn.apply(blk, x, blk.conv1.weight, blk.bn1.weight, blk.bn1.bias, blk.conv2.weight, blk.bn2.weight, blk.bn2.bias,
+                                  blk.conv3.weight, blk.bn3.weight, blk.bn3.bias,
+                                  dn[0].weight if dn is not None else None, dn[1].weight if dn is not None else None,
+                                  dn[1].bias if dn is not None else None)
+    finally:
+        blk.__dict__.pop("_chain_in", None)
+        tmp = blk.__dict__.pop("_chain_tmp", None)
+    if tmp is not None:
+        out._rn_chain = tmp
+    return out
+
+
+def link_blocks(blocks) -> None:
+    "Tell every bottleneck which block consumes its output (plain ``__dict__`` entries: not sub-modules, not in the state dict)."
+    for a, b in zip(blocks[:-1], blocks[1:]):
+        a.__dict__["_rn_next"] = [b]
 
 
 # ---- 1x1 convolutions outside the fused blocks (layer3 / layer4, downsample branches, FPN laterals): the fastest of three ----------

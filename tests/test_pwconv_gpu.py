@@ -301,6 +301,91 @@ def test_conv3_backward_in_one_pass(c4, cm, H, W, dtype):
     _close(dw.float(), dw_two.float(), 4e-3, "weight gradient vs the separate kernel")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("ra", [False, True])
+@pytest.mark.parametrize("c4,cn,H,W", [(256, 64, 19, 23), (256, 128, 19, 23), (512, 128, 19, 23), (256, 64, 260, 260), (512, 128, 1, 5)])
+def test_block_output_and_next_conv1_in_one_pass(c4, cn, H, W, ra, dtype):
+    """``rn_pw_block_out_conv1`` against the launches it replaces: ``rn_bn_apply`` / ``rn_bn_apply_res_affine`` (block output + ReLU bits) and
+    ``rn_pw_conv_forward(.., RN_PW_EPI_STATS)`` on that output (the next block's conv1 + bn1 statistics partials) -- y, bits and z1 bit for
+    bit, the statistics to f32 summation order; plus z1 against fp32 PyTorch."""
+    from pytorch_retinanet_amd import pwconv
+    from pytorch_retinanet_amd._lib import RN_BF16, RN_F16, lib
+    M = 2 * H * W
+    z3, res = _rand((2, c4, H, W), 1.0, 1).to(dtype), _rand((2, c4, H, W), 1.0, 2).to(dtype)
+    w1 = _rand((cn, c4, 1, 1), 0.05, 3).to(dtype)
+    gen = torch.Generator(device=DEV).manual_seed(4)
+    def stats():    # mean | invstd | a | b
+        return torch.cat([torch.randn(c4, device=DEV, generator=gen) * 0.2, torch.rand(c4, device=DEV, generator=gen) + 0.5,
+                          torch.rand(c4, device=DEV, generator=gen) + 0.5, torch.randn(c4, device=DEV, generator=gen) * 0.3])
+    st3, std = stats(), stats()
+    nb = lib.rn_pw_block_out_conv1_walkers(M, c4, cn)
+    assert nb > 0
+    y = torch.full_like(z3, float("nan"))
+    bits = torch.zeros((M * c4 // 8,), dtype=torch.uint8, device=DEV)
+    z1 = torch.full((2, cn, H, W), float("nan"), dtype=dtype, device=DEV).contiguous(memory_format=torch.channels_last)
+    part = torch.full((nb * 2 * cn,), float("nan"), dtype=torch.float32, device=DEV)
+    p3, pd = st3.data_ptr(), std.data_ptr()
+    rc = lib.rn_pw_block_out_conv1(M, c4, cn, RN_F16 if dtype == torch.float16 else RN_BF16, z3.data_ptr(), res.data_ptr(),
+                                   pd + 8 * c4 if ra else 0, pd + 12 * c4 if ra else 0, p3 + 8 * c4, p3 + 12 * c4, w1.data_ptr(), y.data_ptr(),
+                                   bits.data_ptr(), z1.data_ptr(), part.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    y_ref, bits_ref = pwconv.bn_apply(z3, st3, relu=True, residual=res, want_bits=True, res_stats=std if ra else None)
+    e1, p1, nb1 = pwconv.stats_epilogue(M, cn, torch.device(DEV))
+    z1_ref = pwconv.pw_forward(y_ref, w1, epi=e1)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_ref) and torch.equal(bits, bits_ref)
+    assert torch.equal(z1, z1_ref)
+    a, b = part.view(nb, 2, cn).double().sum(0), p1.view(nb1, 2, cn).double().sum(0)
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(b.abs().max()))
+    ref = (y_ref.float().permute(0, 2, 3, 1).reshape(M, c4) @ w1.float().view(cn, c4).t())
+    _close(z1.float().permute(0, 2, 3, 1).reshape(M, cn), ref, 1e-2, "next conv1 output")
+
+
+def test_chained_blocks_equal_the_unchained_ones():
+    """Two consecutive fused bottlenecks (downsample block -> identity block -> identity block) with and without ``pwconv.FUSE_CHAIN``:
+    the same tensors reach the same kernels (only bn1's statistics are summed in another order), so outputs and gradients agree far
+    inside the fused-vs-fp32 bars; the hand-over is consumed (the chained run launches no conv1 GEMM for the later blocks)."""
+    from pytorch_retinanet_amd import backbone as bb
+    from pytorch_retinanet_amd import ops, pwconv
+    torch.manual_seed(5)
+    ds = torch.nn.Sequential(bb._conv1x1(64, 256, 1), bb.FusedBatchNorm2d(256))
+    blocks = [bb.Bottleneck(64, 64, 1, ds), bb.Bottleneck(256, 64), bb.Bottleneck(256, 64)]
+    pwconv.link_blocks(blocks)
+    seq = torch.nn.Sequential(*blocks).to(DEV).to(memory_format=torch.channels_last).train()
+    with torch.no_grad():
+        for m in seq.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
+    for p in seq.parameters():
+        if p.dim() == 4:
+            p.data = p.data.to(torch.bfloat16)
+    x0, g = _rand((2, 64, 40, 44), 1.0, 1), _rand((2, 256, 40, 44), 1.0, 2)
+    init = {n: b.clone() for n, b in seq.named_buffers()}
+    res = {}
+    try:
+        for chain in (False, True):
+            pwconv.FUSE_CHAIN = chain
+            with torch.no_grad():
+                for n, b in seq.named_buffers():
+                    b.copy_(init[n])
+            x = x0.clone().requires_grad_(True)
+            seq.zero_grad()
+            ops.TIMINGS.clear() if hasattr(ops, "TIMINGS") else None
+            mid = []
+            hooks = [b.register_forward_hook(lambda m, i, o: mid.append(hasattr(o, "_rn_chain"))) for b in blocks]
+            y = seq(x)
+            for h in hooks:
+                h.remove()
+            assert mid == [chain, chain, False]         # handed over between the blocks; the last one has no successor
+            y.backward(g)
+            torch.cuda.synchronize()
+            res[chain] = [y.detach().float(), x.grad.float()] + [p.grad.float().clone() for p in seq.parameters()] + [b.float().clone() for b in seq.buffers()]
+    finally:
+        pwconv.FUSE_CHAIN = True
+    for i, (a, b) in enumerate(zip(res[True], res[False])):
+        assert _l2(a, b) <= 1e-2, f"tensor {i}: relative L2 distance {_l2(a, b)}"     # (a1 rounds differently where bn1's statistics differ in their last bits)
+
+
 def _truth_block(blk, x0, g):
     "The block in plain fp32 PyTorch ops with autograd (bf16 weights up-cast, batch statistics): outputs and every gradient."
     def bn(z, m):
