@@ -369,6 +369,16 @@ int rn_pw_wgrad_reduce_many(const void *const *partials, const int *splits, cons
 int rn_pw_block_out_conv1_walkers(int64_t M, int C4, int CN);
 int rn_pw_block_out_conv1(int64_t M, int C4, int CN, int dtype, const void *z3, const void *resid, const float *res_a, const float *res_b,
                           const float *oa, const float *ob, const void *w1, void *y, uint8_t *ybits, void *z1, float *partial, void *stream);
+/* The start of one bottleneck's backward and of the one before it in one pass (ABI 9): conv1's data gradient joined by the identity
+ * branch's,  dx [M][C4] = dz1 [M][Cm] . w1t^T + resid * rbits  -- rn_pw_conv_forward(dz1, w1t, epilogue RN_PW_EPI_RESID(resid, rbits,
+ * res_stride, res_h, res_w)), bit for bit -- and, on the tile just stored, the sums of the PREVIOUS block's bn3 backward over dx (which is
+ * the gradient at that block's output):  partial f32 [walkers][2][C4] = (sum g', sum g' * (prev_z3 - prev_mean) * prev_invstd),
+ * g' = dx * prev_bits -- what rn_bn_bwd_reduce(dx, prev_bits, prev_z3, ..) sums before it finalizes; rn_bn_bwd_finalize(partial, walkers, ..)
+ * completes it.  Saves that launch's read of dx.  Cm = 64 or 128, C4 a multiple of 128; w1t [C4][Cm]; prev_mean / prev_invstd f32 [C4]. */
+int rn_pw_dgrad_resid_sums_walkers(int64_t M, int Cm, int C4);
+int rn_pw_dgrad_resid_sums(int64_t M, int Cm, int C4, int dtype, const void *dz1, const void *w1t, const void *resid, const uint8_t *rbits,
+                           int res_stride, int res_h, int res_w, const void *prev_z3, const uint8_t *prev_bits, const float *prev_mean,
+                           const float *prev_invstd, void *dx, float *partial, void *stream);
 int rn_pw_conv3_backward_walkers(int64_t M, int Cm, int C4);
 size_t rn_pw_conv3_backward_workspace_bytes(int64_t M, int Cm, int C4);
 int rn_pw_conv3_backward(int64_t M, int Cm, int C4, int dtype, const void *g, const void *z3, const uint8_t *bits, const float *a3,

@@ -281,6 +281,7 @@ class ResNetBackbone(nn.Module):
             x = pwconv.stem(self.conv1, self.bn1, x, pool=self.maxpool)      # ... and bn1's apply + ReLU inside the max pooling
         else:
             x = self._stem_inference(x)
+        pwconv._BWD_CHAIN.clear()        # (hand-overs of a backward pass that never ran)
         x = self.layer1(x)
         # C3 / C4 feed the next layer's conv1 + stride-2 downsample conv and an FPN lateral: their data gradients join in one GEMM
         cuts = self.stage_cuts if (self.stage_cuts is not None and torch.is_grad_enabled()) else None

@@ -21,6 +21,7 @@
 // (same fma order, statistics taken from the bf16-ROUNDED output), so fused and unfused layers agree to the bit wherever
 // the GEMM's own summation order does.
 #include "rn_common.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -1014,6 +1015,186 @@ __global__ __launch_bounds__(512, 2) void pw_block_out_conv1_kernel(const ChainA
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The start of one bottleneck's backward and of the one before it in one pass: conv1's data gradient joined by the identity branch
+//     dx = dz1 . W1 + resid * bits            (pw_gemm_kernel<.., PRO_NONE, EPI_RESID>; dx IS the gradient at the previous block's output)
+// and, on the tile just stored, the two sums of that previous block's bn3 backward
+//     sum g', sum g' * xhat3,  g' = dx * prev_bits,  xhat3 = (prev_z3 - mean) * invstd      (norm.hip's bn_bwd_partial_kernel<DT, 3>)
+// which otherwise re-read dx (275 MB at layer1) in a launch of their own.  One 128-column tile of dx per workgroup (its weight rows
+// stay in LDS), 512 threads, row tiles walked with the next tile's operands in flight; same products and expressions as the two
+// kernels: dx is bit-identical, the sums differ in summation order only.
+struct DgradSumsArgs {
+    const uint16_t *A;              // dz1 [M][CM]
+    const uint16_t *Wt;             // [C4][CM]: conv1's data-gradient weight (w1 transposed)
+    const uint16_t *R;              // the identity branch's gradient [M][C4] (rs == 2: on the stride-2 grid, see PwArgs)
+    const uint8_t *rbits;           // [M][C4 / 8] or null (no mask)
+    int rs, rH, rW;
+    const uint16_t *Zp;             // previous block: bn3 input [M][C4]
+    const uint8_t *pbits;           //                 ReLU bits of its output [M][C4 / 8]
+    const float *pmean, *pinv;      //                 bn3 batch statistics [C4]
+    uint16_t *Y;                    // dx [M][C4]
+    float *partial;                 // [gx][2][C4]
+    int M, C4, gx, f16;
+};
+
+template <int DT, int KC>
+__global__ __launch_bounds__(512, 2) void pw_dgrad_sums_kernel(const DgradSumsArgs a)
+{
+    constexpr int T = 512, CM = KC * 64, BN = 128;
+    constexpr int A_BYTES = KC * 128 * 128, B_BYTES = KC * BN * 128, TILE_OFF = A_BYTES + B_BYTES;     // [A | B | f32 tile 128 x 128]
+    constexpr int AV = 2;                                        // 16-byte vectors per thread and 64-channel chunk (rows r0, r0 + 64)
+    constexpr int CG = BN / 8, RL = T / CG, EROWS = 128 / RL;    // 16 column groups, 32 row lanes, 4 rows per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = tid & 7, r0 = tid >> 3;
+    const int n0 = blockIdx.y * BN;
+    const int MT = (a.M + 127) / 128;
+    // this column tile's weight rows, once: chunk kc of row r at B + kc * BN * 128 + r * 128, 16-byte pieces swizzled as PW_SWZ
+    for (int q = tid; q < KC * BN * 8; q += T) {
+        const int kc = q / (BN * 8), rem = q - kc * BN * 8, row = rem >> 3, cc = rem & 7;
+        *(rn::u32x4 *)(lds + A_BYTES + kc * BN * 128 + row * 128 + ((cc ^ PW_SWZ(row)) << 4)) =
+            *(const rn::u32x4 *)(a.Wt + (int64_t)(n0 + row) * CM + kc * 64 + cc * 8);
+    }
+    uint32_t wa_off[AV];
+#pragma unroll
+    for (int i = 0; i < AV; ++i) { const int row = r0 + 64 * i; wa_off[i] = row * 128 + ((c ^ PW_SWZ(row)) << 4); }
+    const int wm = wave >> 1, wn = wave & 1;                     // 4 x 2 waves of 32 x 64
+    uint32_t a_off[4], b_off[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int chunk = kk * 2 + (lane >> 5);
+        { const int row = wm * 32 + (lane & 31); a_off[kk] = row * 128 + ((chunk ^ PW_SWZ(row)) << 4); }
+        { const int row = wn * 64 + (lane & 31); b_off[kk] = A_BYTES + row * 128 + ((chunk ^ PW_SWZ(row)) << 4); }
+    }
+    const int ecg = tid % CG, erl = tid / CG;
+    float ssum[8], qsum[8], mu[8], is[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ssum[j] = 0.0f; qsum[j] = 0.0f; }
+    ld8f(a.pmean + n0 + ecg * 8, mu); ld8f(a.pinv + n0 + ecg * 8, is);
+
+    // two register sets of epilogue operands: the NEXT tile's are requested before this tile's epilogue runs (the tile loop is unrolled by
+    // two through a generic lambda so that the set is a literal)
+    rn::u32x4 sa[KC][AV], er[2][EROWS], ez[2][EROWS];
+    uint32_t eb[2][EROWS], ezb[2][EROWS];
+    auto issue_a = [&](const int m0) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int i = 0; i < AV; ++i) {
+                const int m = m0 + r0 + 64 * i;
+                const rn::u32x4 zero4 = {0u, 0u, 0u, 0u};
+                sa[kc][i] = m < a.M ? *(const rn::u32x4 *)(a.A + (int64_t)m * CM + kc * 64 + c * 8) : zero4;
+            }
+    };
+    auto commit_a = [&]() {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int i = 0; i < AV; ++i) *(rn::u32x4 *)(lds + kc * 128 * 128 + wa_off[i]) = sa[kc][i];
+    };
+    auto load_epi = [&](auto set_c, const int m0) {              // a tile's epilogue operands (pw_gemm_kernel's EPI_RESID addressing)
+        constexpr int S = decltype(set_c)::value;
+#pragma unroll
+        for (int i = 0; i < EROWS; ++i) {
+            const int m = m0 + erl + i * RL, mc = m < a.M ? m : a.M - 1;
+            const int64_t e0 = (int64_t)mc * a.C4 + n0 + ecg * 8;
+            int64_t e = e0;
+            bool on = true;
+            if (a.rs == 2) {
+                const int hw = a.rH * a.rW, n = mc / hw, rem = mc - n * hw, y = rem / a.rW, x = rem - y * a.rW;
+                on = ((y | x) & 1) == 0;
+                e = (((int64_t)n * ((a.rH + 1) >> 1) + (y >> 1)) * ((a.rW + 1) >> 1) + (x >> 1)) * a.C4 + n0 + ecg * 8;
+            }
+            const rn::u32x4 zero4 = {0u, 0u, 0u, 0u};
+            er[S][i] = on ? *(const rn::u32x4 *)(a.R + e) : zero4;
+            eb[S][i] = on ? (a.rbits ? (uint32_t)a.rbits[e >> 3] : 0xffu) : 0u;
+            ez[S][i] = *(const rn::u32x4 *)(a.Zp + e0);
+            ezb[S][i] = a.pbits[e0 >> 3];
+        }
+    };
+
+    int mt = blockIdx.x;
+    if (mt < MT) { issue_a(mt * 128); load_epi(std::integral_constant<int, 0>{}, mt * 128); }
+    __syncthreads();                                               // (the weight rows)
+    auto row_tile = [&](auto set_c) {
+        constexpr int S = decltype(set_c)::value;
+        const int m0 = mt * 128;
+        commit_a();
+        __syncthreads();
+        if (mt + a.gx < MT) {                                       // the next tile's operand rows and epilogue operands: in flight under this tile
+            issue_a((mt + a.gx) * 128);
+            load_epi(std::integral_constant<int, 1 - S>{}, (mt + a.gx) * 128);
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+        typedef typename rn::mma<DT>::frag frag8;
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const frag8 fa = *(const frag8 *)(lds + kc * 128 * 128 + a_off[kk]);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const frag8 fb = *(const frag8 *)(lds + kc * BN * 128 + b_off[kk] + ni * 4096);
+                    acc[ni] = rn::mma<DT>::m32(fa, fb, acc[ni]);
+                }
+            }
+        float *const tile = (float *)(lds + TILE_OFF);              // [128][128]
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = wn * 64 + ni * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                tile[row * BN + col] = acc[ni][r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < EROWS; ++i) {
+            const int row = erl + i * RL, m = m0 + row;
+            if (m < a.M) {
+                float v[8], r[8], z[8];
+                ld8f(tile + row * BN + ecg * 8, v);
+                rn::dt<DT>::unpack(er[S][i], r);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += ((eb[S][i] >> j) & 1u) ? r[j] : 0.0f;
+                const rn::u32x4 o = rn::dt<DT>::pack(v);
+                *(rn::u32x4 *)(a.Y + (int64_t)m * a.C4 + n0 + ecg * 8) = o;
+                rn::dt<DT>::unpack(o, v);                          // the sums are those of the stored gradient
+                rn::dt<DT>::unpack(ez[S][i], z);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float gj = ((ezb[S][i] >> j) & 1u) ? v[j] : 0.0f;
+                    ssum[j] += gj;
+                    qsum[j] = fmaf(gj, (z[j] - mu[j]) * is[j], qsum[j]);
+                }
+            }
+        }
+        __syncthreads();                                            // A and the tile are rewritten by the next row tile
+    };
+    while (mt < MT) {
+        row_tile(std::integral_constant<int, 0>{});
+        mt += a.gx;
+        if (mt >= MT) break;
+        row_tile(std::integral_constant<int, 1>{});
+        mt += a.gx;
+    }
+    float *const red = (float *)(lds + TILE_OFF);                   // [RL][2][BN]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[(erl * 2 + 0) * BN + ecg * 8 + j] = ssum[j]; red[(erl * 2 + 1) * BN + ecg * 8 + j] = qsum[j]; }
+    __syncthreads();
+    for (int q = tid; q < 2 * BN; q += T) {
+        float t = 0.0f;
+        for (int l = 0; l < RL; ++l) t += red[l * 2 * BN + q];
+        const int which = q >= BN ? 1 : 0;
+        a.partial[((int64_t)blockIdx.x * 2 + which) * a.C4 + n0 + (q - which * BN)] = t;
+    }
+}
+
 // dW (bf16) = sum over the splits of partial (f32).  A block owns 32 float4 outputs; its 8 thread rows each sum every 8th
 // split (8 loads in flight per output instead of one serial chain over S), then the 8 sums are combined in a fixed order.
 template <int DT>
@@ -1270,6 +1451,55 @@ RN_API int rn_pw_block_out_conv1(int64_t M, int C4, int CN, int dtype, const voi
     hipStream_t st = (hipStream_t)stream;
     if (a.f16) return res_a ? dispatch_chain<RN_F16, true>(a, C4, CN, st) : dispatch_chain<RN_F16, false>(a, C4, CN, st);
     return res_a ? dispatch_chain<RN_BF16, true>(a, C4, CN, st) : dispatch_chain<RN_BF16, false>(a, C4, CN, st);
+}
+
+static bool dgrad_sums_shape_ok(const int64_t M, const int Cm, const int C4)
+{
+    return M > 0 && M < ((int64_t)1 << 31) / (C4 > 0 ? C4 : 1) * 8 && (Cm == 64 || Cm == 128) && C4 > 0 && C4 % 128 == 0;
+}
+template <int DT, int KC> static int launch_dgrad_sums(const DgradSumsArgs &a, hipStream_t st)
+{
+    constexpr int lds = KC * 128 * 128 * 2 + 128 * 128 * 4;
+    static rn::DynLdsOptIn opt_in = {};
+    { const int rc = opt_in.ensure((const void *)pw_dgrad_sums_kernel<DT, KC>, lds); if (rc != RN_OK) return rc; }
+    hipLaunchKernelGGL((pw_dgrad_sums_kernel<DT, KC>), dim3((unsigned)a.gx, (unsigned)(a.C4 / 128)), dim3(512), lds, st, a);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+// one workgroup per CU over all column tiles: walkers = row-tile walkers per column tile
+static int dgrad_sums_walkers(const int64_t M, const int C4)
+{
+    const int MT = (int)((M + 127) / 128), tiles = C4 / 128;
+    int cap = cu_count() / tiles;
+    if (cap < 1) cap = 1;
+    if (MT <= cap) return MT;
+    const int rounds = (MT + cap - 1) / cap;
+    return (MT + rounds - 1) / rounds;
+}
+
+RN_API int rn_pw_dgrad_resid_sums_walkers(int64_t M, int Cm, int C4) { return dgrad_sums_shape_ok(M, Cm, C4) ? dgrad_sums_walkers(M, C4) : 0; }
+
+RN_API int rn_pw_dgrad_resid_sums(int64_t M, int Cm, int C4, int dtype, const void *dz1, const void *w1t, const void *resid, const uint8_t *rbits,
+                                  int res_stride, int res_h, int res_w, const void *prev_z3, const uint8_t *prev_bits, const float *prev_mean,
+                                  const float *prev_invstd, void *dx, float *partial, void *stream)
+{
+    if (!dz1 || !w1t || !resid || !prev_z3 || !prev_bits || !prev_mean || !prev_invstd || !dx || !partial) return RN_EINVAL;
+    if (dtype != RN_BF16 && dtype != RN_F16) return RN_EUNSUPPORTED;
+    if (!dgrad_sums_shape_ok(M, Cm, C4)) return RN_EUNSUPPORTED;
+    if (res_stride != 0 && res_stride != 1 && res_stride != 2) return RN_EUNSUPPORTED;
+    if (res_stride == 2 && (res_h <= 0 || res_w <= 0 || M % ((int64_t)res_h * res_w))) return RN_EINVAL;
+    if (!rn::aligned(dz1, 16) || !rn::aligned(w1t, 16) || !rn::aligned(resid, 16) || !rn::aligned(prev_z3, 16) || !rn::aligned(dx, 16) ||
+        !rn::aligned(prev_mean, 16) || !rn::aligned(prev_invstd, 16))
+        return RN_EALIGN;
+    DgradSumsArgs a = {};
+    a.A = (const uint16_t *)dz1; a.Wt = (const uint16_t *)w1t; a.R = (const uint16_t *)resid; a.rbits = rbits;
+    a.rs = res_stride == 2 ? 2 : 1; a.rH = res_h; a.rW = res_w;
+    a.Zp = (const uint16_t *)prev_z3; a.pbits = prev_bits; a.pmean = prev_mean; a.pinv = prev_invstd;
+    a.Y = (uint16_t *)dx; a.partial = partial; a.M = (int)M; a.C4 = C4; a.gx = dgrad_sums_walkers(M, C4); a.f16 = dtype == RN_F16;
+    hipStream_t st = (hipStream_t)stream;
+    if (Cm == 64) return a.f16 ? launch_dgrad_sums<RN_F16, 1>(a, st) : launch_dgrad_sums<RN_BF16, 1>(a, st);
+    return a.f16 ? launch_dgrad_sums<RN_F16, 2>(a, st) : launch_dgrad_sums<RN_BF16, 2>(a, st);
 }
 
 RN_API int rn_pw_conv3_backward_walkers(int64_t M, int Cm, int C4) { return pair_shape_ok(M, Cm, C4) ? pair_walkers(M, Cm) : 0; }

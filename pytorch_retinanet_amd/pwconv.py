@@ -38,6 +38,8 @@ FUSED_BOTTLENECK = os.environ.get("RN_FUSED_BOTTLENECK", "1") != "0"      # 0: t
 # fusion; at layer3 / layer4 (256 / 512 mid channels, K up to 2048) the GEMMs are compute-bound and the 128 x 128 register-staged
 # tiles of csrc/pw.hip run at a third of MIOpen's rate (measured: conv3 data gradient 99 us against 36 + 22 us)
 FUSED_MAX_MID = int(os.environ.get("RN_FUSED_MAX_MID", "128"))
+FUSE_BWD_CHAIN = True          # ... and, in backward, the previous block's bn3-backward sums with its own conv1 data gradient: rn_pw_dgrad_resid_sums
+_BWD_CHAIN: Dict[int, tuple] = {}      # data_ptr of a block's input gradient -> (partials, rows, shape, dtype); emptied by every trunk forward
 FUSE_CHAIN = True              # a fused block forms its output together with the NEXT fused block's conv1 (+ bn1 statistics): rn_pw_block_out_conv1
 FUSE_CONV3_BWD = True          # conv3's data and weight gradients in one pass over the block-output gradient (layer1 / layer2 shapes)
 DEFER_WGRAD_REDUCE = True      # a fused block sums the splits of its 1x1 weight gradients in one launch at the end of its backward
@@ -252,7 +254,9 @@ class _BottleneckFn(torch.autograd.Function):
         if (cin is not None and cin[1] == x.data_ptr() and cin[2] == x._version and cin[0][3] == w1.data_ptr() and cin[0][4] == w1._version
                 and tuple(cin[0][0].shape) == (Nimg, w1.shape[0], H, W) and cin[0][0].dtype == x.dtype):
             z1, p1, nb1 = cin[0][:3]
+            prev = cin[0][5:8]             # the producer's z3, ReLU bits and bn3 statistics: its bn3-backward sums ride in this block's backward
         else:
+            prev = (None, None, None)
             e1, p1, nb1 = stats_epilogue(M0, w1.shape[0], dev)
             z1 = pw_forward(x, w1, epi=e1, tag="pw_conv1_fwd")
         st1 = bn_finalize(p1, nb1, M0, blk.bn1)
@@ -298,19 +302,19 @@ class _BottleneckFn(torch.autograd.Function):
                 check(lib.rn_pw_block_out_conv1(M1, C4, CN, _DT16[x.dtype], z3.data_ptr(), res.data_ptr(), ra, rb, p3o + 8 * C4, p3o + 12 * C4,
                                                 w1n.data_ptr(), out.data_ptr(), bits.data_ptr(), z1n.data_ptr(), partn.data_ptr(), _stream(dev)),
                       "rn_pw_block_out_conv1")
-            blk.__dict__["_chain_tmp"] = (z1n, partn, nbn, w1n.data_ptr(), w1n._version)
+            blk.__dict__["_chain_tmp"] = (z1n, partn, nbn, w1n.data_ptr(), w1n._version, z3, bits, st3)
         elif wd is not None:
             # the branch's BatchNorm output is never written: the block-output pass forms it from zd and its coefficients
             out, bits = bn_apply(z3, st3, relu=True, residual=zd, res_stats=std, want_bits=True)
         else:
             out, bits = bn_apply(z3, st3, relu=True, residual=x, want_bits=True)
-        ctx.save_for_backward(x, w1, g1, w2, g2, w3, g3, wd, gd, z1, a1, z2, z3, zd, bits, st1, st2, st3, std)
+        ctx.save_for_backward(x, w1, g1, w2, g2, w3, g3, wd, gd, z1, a1, z2, z3, zd, bits, st1, st2, st3, std, *prev)
         ctx.blk = blk
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        x, w1, g1, w2, g2, w3, g3, wd, gd, z1, a1, z2, z3, zd, bits, st1, st2, st3, std = ctx.saved_tensors
+        x, w1, g1, w2, g2, w3, g3, wd, gd, z1, a1, z2, z3, zd, bits, st1, st2, st3, std, pz3, pbits, pst3 = ctx.saved_tensors
         blk = ctx.blk
         dev = x.device
         st = _stream(dev)
@@ -323,8 +327,14 @@ class _BottleneckFn(torch.autograd.Function):
         gr3 = torch.empty((5 * C4,), dtype=torch.float32, device=dev)            # dgamma | dbeta | a | k0 | k1
         wp, wn = norm._workspace(dev, st, C4)
         p3 = st3.data_ptr()
-        check(lib.rn_bn_bwd_reduce(g_out.data_ptr(), bits.data_ptr(), z3.data_ptr(), _DT16[x.dtype], M1, C4, g3.data_ptr(), p3, p3 + 4 * C4, 0, 1, 2,
-                                   gr3.data_ptr(), gr3.data_ptr() + 4 * C4, gr3.data_ptr() + 8 * C4, wp, wn, st), "rn_bn_bwd_reduce")
+        hit = _BWD_CHAIN.pop(g_out.data_ptr(), None)
+        if hit is not None and FUSE_BWD_CHAIN and hit[2] == tuple(g_out.shape) and hit[3] == g_out.dtype:
+            # the consumer of this block's output formed the two sums together with this very gradient (rn_pw_dgrad_resid_sums)
+            check(lib.rn_bn_bwd_finalize(hit[0].data_ptr(), hit[1], M1, C4, g3.data_ptr(), p3, p3 + 4 * C4, 1, gr3.data_ptr(), gr3.data_ptr() + 4 * C4,
+                                         gr3.data_ptr() + 8 * C4, st), "rn_bn_bwd_finalize")
+        else:
+            check(lib.rn_bn_bwd_reduce(g_out.data_ptr(), bits.data_ptr(), z3.data_ptr(), _DT16[x.dtype], M1, C4, g3.data_ptr(), p3, p3 + 4 * C4, 0, 1, 2,
+                                       gr3.data_ptr(), gr3.data_ptr() + 4 * C4, gr3.data_ptr() + 8 * C4, wp, wn, st), "rn_bn_bwd_reduce")
         pro3 = bn_bwd(gr3[2 * C4:], z3, relu_mode=3, bits=bits)
         # conv3 data gradient with bn3-backward in the operand load; epilogue: ReLU mask of a2 + the two bn2-backward sums
         nb2 = lib.rn_pw_walkers(M1)
@@ -390,8 +400,7 @@ class _BottleneckFn(torch.autograd.Function):
         dwd = dgd = dbd = None
         if wd is None:
             # the identity branch's gradient g_out * bits joins in the data-gradient GEMM's epilogue
-            epi1 = RnPwEpilogue(RN_PW_EPI_RESID, 0, g_out.data_ptr(), bits.data_ptr(), 0, 0, 0, 0, 0)
-            dx = pw_forward(dz1, w1t, epi=epi1, tag="pw_conv1_dgrad")
+            dx = _conv1_dgrad(dz1, w1t, x, g_out, bits, 1, pz3, pbits, pst3)
         else:
             dn = blk.downsample
             grd = torch.empty((5 * C4,), dtype=torch.float32, device=dev)
@@ -409,8 +418,7 @@ class _BottleneckFn(torch.autograd.Function):
             sd = dn[0].stride[0]
             dxd = pw_forward(dzd, wdt, tag="pw_down_dgrad")
             if sd in (1, 2):
-                epi1 = RnPwEpilogue(RN_PW_EPI_RESID, 0, dxd.data_ptr(), 0, 0, 0, 0, 0, 0, sd, x.shape[2], x.shape[3])
-                dx = pw_forward(dz1, w1t, epi=epi1, tag="pw_conv1_dgrad")
+                dx = _conv1_dgrad(dz1, w1t, x, dxd, None, sd, pz3, pbits, pst3)
             else:
                 full = torch.empty_like(x).fill_(0)
                 full[:, :, ::sd, ::sd] = dxd
@@ -418,6 +426,33 @@ class _BottleneckFn(torch.autograd.Function):
         dw1 = pw_wgrad(dz1, x, w1, tag="pw_conv1_wgrad", defer=pending)
         pw_wgrad_flush(pending)
         return (None, dx, dw1, gr1[:Cm], gr1[Cm:2 * Cm], dw2, gr2[:Cm], gr2[Cm:2 * Cm], dw3, gr3[:C4], gr3[C4:2 * C4], dwd, dgd, dbd)
+
+
+def _conv1_dgrad(dz1: Tensor, w1t: Tensor, x: Tensor, resid: Tensor, rbits: Optional[Tensor], rs: int, pz3, pbits, pst3) -> Tensor:
+    """conv1's data gradient joined by the identity / downsample branch's (``RN_PW_EPI_RESID``).  With the producer of ``x`` known
+    (``pz3``, ``pbits``, ``pst3``: its z3, ReLU bits, bn3 statistics) the same pass also takes that block's bn3-backward sums over the
+    gradient it has just formed and leaves them in ``_BWD_CHAIN`` for its backward."""
+    dev = x.device
+    Cm, Cin = int(dz1.shape[1]), int(x.shape[1])
+    M0 = x.shape[0] * x.shape[2] * x.shape[3]
+    nbs = lib.rn_pw_dgrad_resid_sums_walkers(M0, Cm, Cin) if (FUSE_BWD_CHAIN and pz3 is not None and tuple(pz3.shape) == tuple(x.shape)) else 0
+    if nbs > 0:
+        dx = torch.empty_like(x)
+        parts = torch.empty((nbs * 2 * Cin,), dtype=torch.float32, device=dev)
+        pm = pst3.data_ptr()
+        PW_FLOP["pw_conv1_dgrad_sums"] = 2.0 * M0 * Cm * Cin
+        with _timed("pw_conv1_dgrad_sums", dev):
+            check(lib.rn_pw_dgrad_resid_sums(M0, Cm, Cin, _DT16[x.dtype], dz1.data_ptr(), w1t.data_ptr(), resid.data_ptr(),
+                                             rbits.data_ptr() if rbits is not None else 0, rs, x.shape[2], x.shape[3], pz3.data_ptr(),
+                                             pbits.data_ptr(), pm, pm + 4 * Cin, dx.data_ptr(), parts.data_ptr(), _stream(dev)),
+                  "rn_pw_dgrad_resid_sums")
+        _BWD_CHAIN[dx.data_ptr()] = (parts, nbs, tuple(dx.shape), dx.dtype)
+        return dx
+    if rs == 1:
+        epi1 = RnPwEpilogue(RN_PW_EPI_RESID, 0, resid.data_ptr(), rbits.data_ptr() if rbits is not None else 0, 0, 0, 0, 0, 0)
+    else:
+        epi1 = RnPwEpilogue(RN_PW_EPI_RESID, 0, resid.data_ptr(), 0, 0, 0, 0, 0, 0, rs, x.shape[2], x.shape[3])
+    return pw_forward(dz1, w1t, epi=epi1, tag="pw_conv1_dgrad")
 
 
 def bottleneck_fusable(blk, x: Tensor, in_forward: bool = False) -> bool:

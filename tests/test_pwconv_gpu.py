@@ -341,6 +341,50 @@ def test_block_output_and_next_conv1_in_one_pass(c4, cn, H, W, ra, dtype):
     _close(z1.float().permute(0, 2, 3, 1).reshape(M, cn), ref, 1e-2, "next conv1 output")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cm,c4,H,W,rs", [(64, 256, 19, 23, 1), (128, 512, 19, 23, 1), (64, 256, 20, 24, 2), (128, 256, 19, 23, 2), (64, 256, 260, 260, 1),
+                                          (128, 512, 1, 5, 1)])
+def test_conv1_data_gradient_with_the_previous_blocks_bn3_sums(cm, c4, H, W, rs, dtype):
+    """``rn_pw_dgrad_resid_sums``: dx == ``rn_pw_conv_forward(.., RN_PW_EPI_RESID)`` bit for bit (identity branch with ReLU bits, or the
+    stride-2 downsample join), and the previous block's two bn3-backward sums over that dx against float64 PyTorch."""
+    from pytorch_retinanet_amd import pwconv
+    from pytorch_retinanet_amd._lib import RN_BF16, RN_F16, RN_PW_EPI_RESID, RnPwEpilogue, lib
+    M = 2 * H * W
+    dz1 = _rand((2, cm, H, W), 1.0, 1).to(dtype)
+    w1t = _rand((c4, cm, 1, 1), 0.05, 2).to(dtype)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    def make_bits():
+        mask = torch.rand(M, c4, device=DEV, generator=gen) > 0.4
+        return mask, (mask.view(M, c4 // 8, 8).to(torch.int32) * (2 ** torch.arange(8, device=DEV, dtype=torch.int32))).sum(-1).to(torch.uint8).contiguous().view(-1)
+    if rs == 1:
+        resid = _rand((2, c4, H, W), 1.0, 4).to(dtype)
+        _, rbits = make_bits()
+        epi = RnPwEpilogue(RN_PW_EPI_RESID, 0, resid.data_ptr(), rbits.data_ptr(), 0, 0, 0, 0, 0)
+    else:
+        resid = _rand((2, c4, (H + 1) // 2, (W + 1) // 2), 1.0, 4).to(dtype)
+        rbits = None
+        epi = RnPwEpilogue(RN_PW_EPI_RESID, 0, resid.data_ptr(), 0, 0, 0, 0, 0, 0, 2, H, W)
+    pz3 = _rand((2, c4, H, W), 1.0, 5).to(dtype)
+    pmask, pbits = make_bits()
+    pst = torch.cat([torch.randn(c4, device=DEV, generator=gen) * 0.2, torch.rand(c4, device=DEV, generator=gen) + 0.5])     # mean | invstd
+    nb = lib.rn_pw_dgrad_resid_sums_walkers(M, cm, c4)
+    assert nb > 0
+    dx = torch.full((2, c4, H, W), float("nan"), dtype=dtype, device=DEV).contiguous(memory_format=torch.channels_last)
+    part = torch.full((nb * 2 * c4,), float("nan"), dtype=torch.float32, device=DEV)
+    rc = lib.rn_pw_dgrad_resid_sums(M, cm, c4, RN_F16 if dtype == torch.float16 else RN_BF16, dz1.data_ptr(), w1t.data_ptr(), resid.data_ptr(),
+                                    rbits.data_ptr() if rbits is not None else 0, rs, H, W, pz3.data_ptr(), pbits.data_ptr(), pst.data_ptr(),
+                                    pst.data_ptr() + 4 * c4, dx.data_ptr(), part.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    dx_ref = pwconv.pw_forward(dz1, w1t, epi=epi)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref)
+    g = dx.double().permute(0, 2, 3, 1).reshape(M, c4) * pmask
+    xhat = (pz3.double().permute(0, 2, 3, 1).reshape(M, c4) - pst[:c4].double()) * pst[c4:].double()
+    sums = part.view(nb, 2, c4).double().sum(0)
+    np.testing.assert_allclose(sums[0].cpu().numpy(), g.sum(0).cpu().numpy(), rtol=1e-4, atol=1e-4 * float(g.abs().sum(0).max()))
+    np.testing.assert_allclose(sums[1].cpu().numpy(), (g * xhat).sum(0).cpu().numpy(), rtol=1e-4, atol=1e-4 * float((g * xhat).abs().sum(0).max()))
+
+
 def test_chained_blocks_equal_the_unchained_ones():
     """Two consecutive fused bottlenecks (downsample block -> identity block -> identity block) with and without ``pwconv.FUSE_CHAIN``:
     the same tensors reach the same kernels (only bn1's statistics are summed in another order), so outputs and gradients agree far
@@ -363,8 +407,10 @@ def test_chained_blocks_equal_the_unchained_ones():
     init = {n: b.clone() for n, b in seq.named_buffers()}
     res = {}
     try:
-        for chain in (False, True):
-            pwconv.FUSE_CHAIN = chain
+        for chain in (False, True, "forward only"):
+            pwconv.FUSE_CHAIN = bool(chain)
+            pwconv.FUSE_BWD_CHAIN = chain is True
+            pwconv.PW_TIMES.clear() if hasattr(pwconv, "PW_TIMES") else None
             with torch.no_grad():
                 for n, b in seq.named_buffers():
                     b.copy_(init[n])
@@ -376,12 +422,15 @@ def test_chained_blocks_equal_the_unchained_ones():
             y = seq(x)
             for h in hooks:
                 h.remove()
-            assert mid == [chain, chain, False]         # handed over between the blocks; the last one has no successor
+            assert mid == [bool(chain), bool(chain), False]     # handed over between the blocks; the last one has no successor
             y.backward(g)
             torch.cuda.synchronize()
+            assert not pwconv._BWD_CHAIN                 # every backward hand-over was consumed
             res[chain] = [y.detach().float(), x.grad.float()] + [p.grad.float().clone() for p in seq.parameters()] + [b.float().clone() for b in seq.buffers()]
     finally:
-        pwconv.FUSE_CHAIN = True
+        pwconv.FUSE_CHAIN = pwconv.FUSE_BWD_CHAIN = True
+    for i, (a, b) in enumerate(zip(res["forward only"], res[False])):
+        assert _l2(a, b) <= 1e-2, f"forward chain, tensor {i}: relative L2 distance {_l2(a, b)}"
     for i, (a, b) in enumerate(zip(res[True], res[False])):
         assert _l2(a, b) <= 1e-2, f"tensor {i}: relative L2 distance {_l2(a, b)}"     # (a1 rounds differently where bn1's statistics differ in their last bits)
 
