@@ -405,6 +405,13 @@ int rn_stem_conv_forward(const void *x, const void *w, void *xp, void *wk, void 
 size_t rn_stem_wgrad_workspace_bytes(int B, int H, int W);
 int rn_stem_conv_wgrad(const void *g, const void *xp, void *dw, int dtype, int B, int H, int W, void *workspace,
                        size_t workspace_bytes, void *stream);
+/* The same with the BatchNorm + ReLU backward of the layer above in the operand load (ABI 9): g is the gradient at the output of
+ * relu(bn1(conv)) -- /root/reference/retinanet/backbone.py:246-248 -- z the conv output [B][Ho][Wo][64], coef3 f32 [3][64] = (a | k0 | k1)
+ * of rn_bn_bwd_reduce / rn_bn_bwd_finalize, fwd_coef f32 [2][64] the forward (a | b); the conv-output gradient
+ * round(fma(a, g * [fma(z, fa, fb) alive], fma(k1, z, k0))) -- what rn_bn_bwd_apply(relu_mode 2) would have stored -- is formed per
+ * staged row and never written (dw is bit-identical to the two-launch form). */
+int rn_stem_conv_wgrad_bn(const void *g, const void *z, const float *coef3, const float *fwd_coef, const void *xp, void *dw, int dtype,
+                          int B, int H, int W, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Weight gradient of a NARROW 3x3 / stride-1 / pad-1 convolution without bias -- conv2 of the layer1 / layer2 / layer4 bottlenecks
  * (retinanet/backbone.py:112,128, autograd's weight gradient of F.conv2d there): Cout, Cin multiples of 64, bf16 channels-last.

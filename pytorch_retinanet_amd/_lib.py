@@ -141,6 +141,7 @@ SIGNATURES = {
     "rn_stem_conv_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "rn_stem_wgrad_workspace_bytes": (_sz, [C.c_int, C.c_int, C.c_int]),
     "rn_stem_conv_wgrad": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _sz, _vp]),
+    "rn_stem_conv_wgrad_bn": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _sz, _vp]),
     "rn_conv3x3_wgrad_narrow_workspace_bytes": (_sz, [C.c_int, C.c_int]),
     "rn_conv3x3_wgrad_narrow": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _sz, _vp]),
     "rn_conv3x3_narrow_forward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),

@@ -221,14 +221,18 @@ constexpr int SW_SPITCH = 1088;                  // bytes per staged strip (134 
 constexpr int SW_GBYTES = SW_STAGE * SW_GPITCH, SW_BUF = SW_GBYTES + 7 * SW_SPITCH;
 
 struct StemWgradArgs {
-    const uint16_t *g;      // [B][Ho][Wo][64] bf16: gradient at the conv output
+    const uint16_t *g;      // [B][Ho][Wo][64] bf16: gradient at the conv output (BN: at the output of relu(bn1(.)) instead)
     const uint16_t *xp;     // [B][Hp2][Wpp][4]
     float *partial;         // [gridDim.x][64][7][32]
     int B, Ho, Wo, Hp2, Wpp;
     int tiles_x, total_stages, stages_per_wg;
+    // BN: the BatchNorm + ReLU backward of norm.hip's bn_bwd_apply_kernel<DT, 2, false> in the operand load -- z = the conv output,
+    // g' = g * [fma(z, fa, fb) alive], conv-output gradient = round_DT(fma(ba, g', fma(bk1, z, bk0))): the apply pass and its tensor go away
+    const uint16_t *z;
+    const float *ba, *bk0, *bk1, *fa, *fb;      // [64] each
 };
 
-template <int DT>
+template <int DT, bool BN>
 __global__ __launch_bounds__(STEM_THREADS) void stem_wgrad_kernel(const StemWgradArgs a)
 {
     typedef typename rn::mma<DT>::frag el16x8;             // (8 consecutive 16-bit elements: bf16 or fp16)
@@ -248,7 +252,15 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_wgrad_kernel(const StemWgra
 
     const int s_beg = blockIdx.x * a.stages_per_wg, s_end = min(s_beg + a.stages_per_wg, a.total_stages);
     // staging: thread -> two 16-byte chunks of the gradient rows (512 chunks) and two of the strips (7 x 67 = 469 chunks)
-    rn::u32x4 rg[2], rs[2];
+    rn::u32x4 rg[2], rs[2], rz[2];
+    bool gval[2] = {false, false};
+    float cba[8], cbk0[8], cbk1[8], cfa[8], cfb[8];                       // BN: this thread's 8 channels (chunk c -> channels 8 (c % 8) .., c % 8 = tid % 8)
+    if (BN) {
+        const int ch = (tid & 7) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { cba[j] = a.ba[ch + j]; cbk0[j] = a.bk0[ch + j]; cbk1[j] = a.bk1[ch + j]; cfa[j] = a.fa[ch + j]; cfb[j] = a.fb[ch + j]; }
+    }
+    const float alive = __uint_as_float(DT == RN_F16 ? 0x33000000u : 0x00004000u);      // norm.hip: relu_alive_threshold<DT>
     auto fetch = [&](const int s) {
         const int tx = s % a.tiles_x, rowid = s / a.tiles_x, yo = rowid % a.Ho, b = rowid / a.Ho, x0 = tx * SW_STAGE;
         const uint16_t *grow = a.g + (((int64_t)b * a.Ho + yo) * a.Wo + x0) * 64;
@@ -256,7 +268,9 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_wgrad_kernel(const StemWgra
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = i * STEM_THREADS + tid, px = c >> 3;                    // chunk c: pixel c / 8, channels 8 (c % 8) ..
-            rg[i] = (x0 + px < a.Wo) ? *(const rn::u32x4 *)(grow + c * 8) : zero4; // pixels past the row end contribute nothing
+            gval[i] = x0 + px < a.Wo;
+            rg[i] = gval[i] ? *(const rn::u32x4 *)(grow + c * 8) : zero4; // pixels past the row end contribute nothing
+            if (BN) rz[i] = gval[i] ? *(const rn::u32x4 *)(a.z + (grow - a.g) + c * 8) : zero4;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -269,6 +283,17 @@ __global__ __launch_bounds__(STEM_THREADS) void stem_wgrad_kernel(const StemWgra
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int c = i * STEM_THREADS + tid, px = c >> 3, ch8 = c & 7;
+            if (BN) {
+                float g8[8], z8[8];
+                rn::dt<DT>::unpack(rg[i], g8);
+                rn::dt<DT>::unpack(rz[i], z8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float gj = (fmaf(z8[j], cfa[j], cfb[j]) > alive) ? g8[j] : 0.0f;
+                    g8[j] = fmaf(cba[j], gj, fmaf(cbk1[j], z8[j], cbk0[j]));
+                }
+                rg[i] = gval[i] ? rn::dt<DT>::pack(g8) : rn::u32x4{0u, 0u, 0u, 0u};
+            }
             // (136-byte rows: 16-byte chunks are only 8-byte aligned -> two 8-byte stores)
             *(rn::u32x2 *)(buf + px * SW_GPITCH + ch8 * 16) = rn::u32x2{rg[i].x, rg[i].y};
             *(rn::u32x2 *)(buf + px * SW_GPITCH + ch8 * 16 + 8) = rn::u32x2{rg[i].z, rg[i].w};
@@ -425,21 +450,44 @@ RN_API size_t rn_stem_wgrad_workspace_bytes(int B, int H, int W)
     return (size_t)wgs * 64 * 7 * STEM_KROW * sizeof(float);
 }
 
+static int stem_wgrad_impl(const void *g, const void *z, const float *coef3, const float *fwd_coef, const void *xp, void *dw, int dtype, int B,
+                           int H, int W, void *workspace, size_t workspace_bytes, void *stream);
+
 RN_API int rn_stem_conv_wgrad(const void *g, const void *xp, void *dw, int dtype, int B, int H, int W, void *workspace,
                               size_t workspace_bytes, void *stream)
+{
+    return stem_wgrad_impl(g, nullptr, nullptr, nullptr, xp, dw, dtype, B, H, W, workspace, workspace_bytes, stream);
+}
+
+RN_API int rn_stem_conv_wgrad_bn(const void *g, const void *z, const float *coef3, const float *fwd_coef, const void *xp, void *dw, int dtype,
+                                 int B, int H, int W, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!z || !coef3 || !fwd_coef) return RN_EINVAL;
+    if (!rn::aligned(z, 16)) return RN_EALIGN;
+    return stem_wgrad_impl(g, z, coef3, fwd_coef, xp, dw, dtype, B, H, W, workspace, workspace_bytes, stream);
+}
+
+static int stem_wgrad_impl(const void *g, const void *z, const float *coef3, const float *fwd_coef, const void *xp, void *dw, int dtype, int B,
+                           int H, int W, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (!g || !xp || !dw || !workspace || B <= 0 || H <= 0 || W <= 0) return RN_EINVAL;
     if (dtype != RN_BF16 && dtype != RN_F16) return RN_EUNSUPPORTED;
     if (workspace_bytes < rn_stem_wgrad_workspace_bytes(B, H, W)) return RN_EWORKSPACE;
     if (!rn::aligned(g, 16) || !rn::aligned(xp, 16) || !rn::aligned(workspace, 16)) return RN_EALIGN;
-    StemWgradArgs a;
+    StemWgradArgs a = {};
     a.g = (const uint16_t *)g; a.xp = (const uint16_t *)xp; a.partial = (float *)workspace;
+    if (z) { a.z = (const uint16_t *)z; a.ba = coef3; a.bk0 = coef3 + 64; a.bk1 = coef3 + 128; a.fa = fwd_coef; a.fb = fwd_coef + 64; }
     a.B = B; a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1; a.Hp2 = H + 6; a.Wpp = (W + 6 + 1) & ~1;
     a.tiles_x = (a.Wo + SW_STAGE - 1) / SW_STAGE; a.total_stages = B * a.Ho * a.tiles_x;
     const int wgs = stem_wgrad_grid(a.total_stages, &a.stages_per_wg);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == RN_F16) hipLaunchKernelGGL(stem_wgrad_kernel<RN_F16>, dim3((unsigned)wgs), dim3(STEM_THREADS), 0, st, a);
-    else hipLaunchKernelGGL(stem_wgrad_kernel<RN_BF16>, dim3((unsigned)wgs), dim3(STEM_THREADS), 0, st, a);
+    if (z) {
+        if (dtype == RN_F16) hipLaunchKernelGGL((stem_wgrad_kernel<RN_F16, true>), dim3((unsigned)wgs), dim3(STEM_THREADS), 0, st, a);
+        else hipLaunchKernelGGL((stem_wgrad_kernel<RN_BF16, true>), dim3((unsigned)wgs), dim3(STEM_THREADS), 0, st, a);
+    } else {
+        if (dtype == RN_F16) hipLaunchKernelGGL((stem_wgrad_kernel<RN_F16, false>), dim3((unsigned)wgs), dim3(STEM_THREADS), 0, st, a);
+        else hipLaunchKernelGGL((stem_wgrad_kernel<RN_BF16, false>), dim3((unsigned)wgs), dim3(STEM_THREADS), 0, st, a);
+    }
     RN_LAUNCH_CHECK();
     if (dtype == RN_F16) hipLaunchKernelGGL(stem_wgrad_reduce_kernel<RN_F16>, dim3((64 * 7 * STEM_KROW + 15) / 16), dim3(256), 0, st, (const float *)workspace, wgs, (uint16_t *)dw);
     else hipLaunchKernelGGL(stem_wgrad_reduce_kernel<RN_BF16>, dim3((64 * 7 * STEM_KROW + 15) / 16), dim3(256), 0, st, (const float *)workspace, wgs, (uint16_t *)dw);

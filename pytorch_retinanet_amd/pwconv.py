@@ -693,6 +693,7 @@ def conv1x1(conv, x: Tensor) -> Tensor:
 
 # ---- the stem: conv 7x7 / stride 2 (3 -> 64) + BatchNorm (batch statistics) + ReLU on csrc/stem.hip ---------------------------------
 FUSED_STEM = True
+STEM_WGRAD_BN = True   # ... with bn1's backward apply step in its operand load (rn_stem_conv_wgrad_bn)
 STEM_WGRAD = True      # weight gradient on csrc/stem.hip as well (False: MIOpen)
 _STEM_WS: Dict[tuple, Tensor] = {}
 
@@ -756,13 +757,20 @@ class _StemFn(torch.autograd.Function):
             check(lib.rn_maxpool3x3s2_backward(arg.data_ptr(), dpool.data_ptr(), da.data_ptr(), _DT16[z.dtype], z.shape[0], z.shape[2], z.shape[3], Cc, st),
                   "rn_maxpool3x3s2_backward")
         gr = torch.empty((5 * Cc,), dtype=torch.float32, device=dev)
-        dz = torch.empty_like(z)
         sp = stats.data_ptr()
         wp, wn = norm._workspace(dev, st, Cc)
-        check(lib.rn_bn_act_backward(da.data_ptr(), 0, z.data_ptr(), dz.data_ptr(), 0, _DT16[z.dtype], M, Cc, gamma.data_ptr(), sp, sp + 4 * Cc,
-                                     sp + 8 * Cc, 1, 1, gr.data_ptr(), gr.data_ptr() + 4 * Cc, gr.data_ptr() + 8 * Cc, wp, wn, st),
-              "rn_bn_act_backward")
         B, _, H, W = x.shape
+        fused_apply = STEM_WGRAD and STEM_WGRAD_BN
+        if fused_apply:
+            # the two sums and the coefficients only: the apply step rides in the weight gradient's operand load (the image needs no gradient,
+            # so nothing else reads the conv-output gradient -- 275 MB that are neither written nor read back)
+            check(lib.rn_bn_bwd_reduce(da.data_ptr(), 0, z.data_ptr(), _DT16[z.dtype], M, Cc, gamma.data_ptr(), sp, sp + 4 * Cc, sp + 8 * Cc, 1, 1,
+                                       gr.data_ptr(), gr.data_ptr() + 4 * Cc, gr.data_ptr() + 8 * Cc, wp, wn, st), "rn_bn_bwd_reduce")
+        else:
+            dz = torch.empty_like(z)
+            check(lib.rn_bn_act_backward(da.data_ptr(), 0, z.data_ptr(), dz.data_ptr(), 0, _DT16[z.dtype], M, Cc, gamma.data_ptr(), sp, sp + 4 * Cc,
+                                         sp + 8 * Cc, 1, 1, gr.data_ptr(), gr.data_ptr() + 4 * Cc, gr.data_ptr() + 8 * Cc, wp, wn, st),
+                  "rn_bn_act_backward")
         if STEM_WGRAD:
             need = lib.rn_stem_wgrad_workspace_bytes(B, H, W)
             key = (dev.index, st)
@@ -772,8 +780,12 @@ class _StemFn(torch.autograd.Function):
             dw = torch.empty_like(w)
             PW_FLOP["stem_wgrad"] = 2.0 * M * 64 * 147
             with _timed("stem_wgrad", dev):
-                check(lib.rn_stem_conv_wgrad(dz.data_ptr(), xp.data_ptr(), dw.data_ptr(), _DT16[z.dtype], B, H, W, wsb.data_ptr(), wsb.numel(), st),
-                      "rn_stem_conv_wgrad")
+                if fused_apply:
+                    check(lib.rn_stem_conv_wgrad_bn(da.data_ptr(), z.data_ptr(), gr.data_ptr() + 8 * Cc, sp + 8 * Cc, xp.data_ptr(), dw.data_ptr(),
+                                                    _DT16[z.dtype], B, H, W, wsb.data_ptr(), wsb.numel(), st), "rn_stem_conv_wgrad_bn")
+                else:
+                    check(lib.rn_stem_conv_wgrad(dz.data_ptr(), xp.data_ptr(), dw.data_ptr(), _DT16[z.dtype], B, H, W, wsb.data_ptr(), wsb.numel(), st),
+                          "rn_stem_conv_wgrad")
         else:
             dw = torch.ops.aten.convolution_backward(dz, x, w, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         return None, None, None, dw, gr[:Cc], gr[Cc:2 * Cc]

@@ -570,6 +570,42 @@ def test_stem_function_matches_the_layer_by_layer_path():
             _close(a, b, 2e-2, n)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,W,pool", [(2, 64, 96, True), (1, 37, 53, True), (2, 30, 600, False), (1, 7, 7, True)])
+def test_stem_weight_gradient_with_bn_backward_in_its_operand_load(B, H, W, pool, dtype):
+    "``pwconv.STEM_WGRAD_BN``: the stem's backward with the BatchNorm apply step inside ``rn_stem_conv_wgrad_bn`` == the three-launch form, bit for bit."
+    from pytorch_retinanet_amd import backbone as bb
+    from pytorch_retinanet_amd import pwconv
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(3, 64, 7, 2, 3, bias=False).to(DEV).to(memory_format=torch.channels_last)
+    conv.weight.data = conv.weight.data.to(dtype)
+    bn = bb.FusedBatchNorm2d(64).to(DEV).train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2)
+    mp = bb.FusedMaxPool2d(kernel_size=3, stride=2, padding=1) if pool else None
+    x = _rand((B, 3, H, W), 1.0, 1).to(dtype)
+    init = {n: b.clone() for n, b in bn.named_buffers()}
+    res = {}
+    try:
+        for fused in (False, True):
+            pwconv.STEM_WGRAD_BN = fused
+            with torch.no_grad():
+                for n, b in bn.named_buffers():
+                    b.copy_(init[n])
+            conv.zero_grad(); bn.zero_grad()
+            assert pwconv.stem_fusable(conv, bn, x)
+            y = pwconv.stem(conv, bn, x, pool=mp)
+            g = _rand(tuple(y.shape), 1.0, 2).to(dtype)
+            y.backward(g)
+            torch.cuda.synchronize()
+            res[fused] = [conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()]
+    finally:
+        pwconv.STEM_WGRAD_BN = True
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+    assert float(res[True][0].float().abs().max()) > 0
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 64, 96), (1, 37, 53), (2, 30, 600), (1, 7, 7)])
 def test_stem_conv_weight_gradient(B, H, W):
     "rn_stem_conv_wgrad (transposing LDS reads over the raw padded strips) against torch's fp32 weight gradient."
