@@ -512,6 +512,14 @@ int rn_conv3x3_canvas_wgrad_batched(const void *const *gs, const void *const *xs
 int rn_conv3x3_dense_batched(const void *const *xs, const void *const *ws, const float *const *biases, void *const *ys, int P,
                              int dtype, int N, const int *hs, const int *wds, int Cin, int Cout, const void *zeros,
                              void *stream);
+/* One dense 3x3 / stride-1 / pad-1 convolution (no bias) whose K walk -- Cin / 64 channel chunks x 9 taps -- is cut into 2 or 3
+ * contiguous ranges run by different workgroups (ABI 9): f32 partials in `workspace`, summed into y by a second launch.  For
+ * convolutions with few 256-row tiles (conv2 of the layer4 bottlenecks, /root/reference/retinanet/backbone.py:112,128: 8 400 positions x
+ * 512 channels = 66 workgroups of 72 K-tiles) this fills the chip.  _workspace_bytes() returns 0 when a split would not help (the
+ * launch already covers half the CUs): the caller then uses rn_conv3x3_dense_batched or its own fallback.  Cin % 64 == 0, Cout % 256 == 0. */
+size_t rn_conv3x3_dense_splitk_workspace_bytes(int N, int h, int w, int Cout);
+int rn_conv3x3_dense_splitk(const void *x, const void *w, void *y, int dtype, int N, int h, int wd, int Cin, int Cout, const void *zeros,
+                            void *workspace, size_t workspace_bytes, void *stream);
 /* The same with ys[p] = relu(...) when `relu` (inference: conv2 of the layer3 bottlenecks with the folded BatchNorm as bias and the
  * ReLU of retinanet/backbone.py:132 in the epilogue). */
 int rn_conv3x3_dense_batched_act(const void *const *xs, const void *const *ws, const float *const *biases, void *const *ys, int P,

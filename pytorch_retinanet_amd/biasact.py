@@ -1084,10 +1084,44 @@ def conv3x3_dense_bias_act(x: Tensor, w: Tensor, bias: Optional[Tensor], relu: b
     return y
 
 
+DENSE_SPLITK = True     # few-row-tile convolutions (conv2 of layer4: forward and, with flipped weights, data gradient) on the dense MFMA kernel, K split
+_SPLITK_WS: Dict[tuple, Tensor] = {}
+
+
+def dense_splitk_bytes(x: Tensor, w: Tensor) -> int:
+    if not (DENSE_SPLITK and x.is_cuda and x.dtype in H16 and w.dtype == x.dtype and x.dim() == 4 and _cl(x) and _cl(w) and
+            tuple(w.shape[2:]) == (3, 3) and w.shape[1] == x.shape[1] and w.shape[1] % 64 == 0 and w.shape[0] % 256 == 0 and
+            x.shape[0] * x.shape[2] * x.shape[3] < (1 << 22)):
+        return 0
+    return int(lib.rn_conv3x3_dense_splitk_workspace_bytes(x.shape[0], x.shape[2], x.shape[3], int(w.shape[0])))
+
+
+def conv3x3_dense_splitk(x: Tensor, w: Tensor, need: int, tag: str = "mfma_conv2_splitk") -> Tensor:
+    "``F.conv2d(x, w, None, 1, 1)`` on ``rn_conv3x3_dense_splitk`` (``need`` = ``dense_splitk_bytes(x, w)`` > 0); no autograd."
+    dev = x.device
+    if dev.index != torch.cuda.current_device():
+        torch.cuda.set_device(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    N, Cin, h, wd = x.shape
+    Cout = int(w.shape[0])
+    key = (dev.index, stream)
+    ws = _SPLITK_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _SPLITK_WS[key] = torch.empty((need,), dtype=torch.uint8, device=dev)
+    y = torch.empty((N, Cout, h, wd), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+    _mfma_call(tag, dev, 2.0 * N * h * wd * Cout * 9 * Cin,
+               lambda: lib.rn_conv3x3_dense_splitk(x.data_ptr(), w.data_ptr(), y.data_ptr(), _DT[x.dtype], N, h, wd, Cin, Cout, _zero_page(dev).data_ptr(),
+                                                   ws.data_ptr(), ws.numel(), stream), "rn_conv3x3_dense_splitk")
+    return y
+
+
 def conv3x3_same(x: Tensor, w: Tensor) -> Tensor:
-    "``F.conv2d(x, w, None, 1, 1)`` (no autograd): the narrow kernel where it applies, else MIOpen."
+    "``F.conv2d(x, w, None, 1, 1)`` (no autograd): the narrow / K-split dense MFMA kernels where they apply, else MIOpen."
     if narrow_fwd_ok(x, w):
         return conv3x3_narrow_forward(x, w)
+    need = dense_splitk_bytes(x, w)
+    if need > 0:
+        return conv3x3_dense_splitk(x, w if _cl(w) else w.contiguous(memory_format=torch.channels_last), need)
     return F.conv2d(x, w, None, 1, 1)
 
 

@@ -176,6 +176,11 @@ struct ConvArgs {
     int f16;                    // host side only: element type fp16 instead of bf16 (selects the kernel instantiation)
     LevelSet lv;
     DenseGeom dn;               // MODE_DENSE only (M, HWp, Wp, mask unused there)
+    // MODE_DENSE, ksplit > 1: the K walk (channel chunks x taps) is cut into ksplit contiguous ranges, blockIdx.z = range; every workgroup
+    // writes its f32 partial tile to kpartial[z][M][Cout] and dense_ksplit_reduce_kernel sums them (a convolution with few row tiles
+    // -- conv2 of the layer4 bottlenecks: 8 400 positions, 66 workgroups of 72 K-tiles -- fills the chip with 3 x 66 of 24)
+    int ksplit;
+    float *kpartial;
 };
 struct ConvProblem { const uint16_t *X, *W; const float *bias; uint16_t *Y; };
 
@@ -206,7 +211,13 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     const int wm = NARROW ? wave : wave >> 2, wn = NARROW ? 0 : wave & 3;
     const int grp = wave >> 2;                                    // ping-pong group: waves 0-3 / 4-7 (one wave of each per SIMD)
     const int n0 = blockIdx.y * CONV_BN + args.n_base;
-    const int cpt = args.Cin / CONV_BK, KT = 9 * cpt;
+    const int cpt = args.Cin / CONV_BK, KT_ALL = 9 * cpt;
+    int kt0 = 0, KT = KT_ALL;                                     // this workgroup's K-tiles: kt0 .. kt0 + KT - 1 of the walk
+    if (MODE == MODE_DENSE && args.ksplit > 1) {
+        const int z = blockIdx.z;
+        kt0 = z * KT_ALL / args.ksplit;
+        KT = (z + 1) * KT_ALL / args.ksplit - kt0;
+    }
     constexpr int TILE = CONV_BM * CONV_BK * 2;
     // (Round 3 also built a BAND variant for the canvas / to-levels modes: one band of 256 + 2 positions per (channel chunk,
     // kernel row) staged once and read by the three horizontal taps with shifted fragment rows -- activation LDS-DMA traffic
@@ -374,6 +385,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     __builtin_amdgcn_s_barrier();
 
     Walk wa = {0, 0}, wb = {0, 0};                                  // K-tile whose A / B pieces are issued next
+    if (MODE == MODE_DENSE) { wa.tap = wb.tap = kt0 % 9; wa.chunk = wb.chunk = kt0 / 9; }
     int sa = 0;                                                     // its A stage (mod 3)
     if (MODE == MODE_FROM_LEVELS) gather_tap(0);
 #pragma unroll
@@ -437,6 +449,21 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
 #undef RN_MFMA_PHASE
     if (grp == 0) __builtin_amdgcn_s_barrier();                    // group 0 catches up with group 1's extra barrier
 
+    if (MODE == MODE_DENSE && args.ksplit > 1) {                   // f32 partial of this K range, straight from the accumulators
+        float *__restrict__ out = args.kpartial + ((int64_t)blockIdx.z * M + m0) * args.Cout + n0;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                const int col = wn * 64 + ni * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wm * (32 * MI) + mi * 16 + 4 * (lane >> 4) + r;
+                    if (m0 + row < M) out[(int64_t)row * args.Cout + col] = acc[mi][ni][r];
+                }
+            }
+        return;
+    }
     __syncthreads();
     uint16_t *Ys = (uint16_t *)lds;                               // [256][256] bf16 output tile = 128 KiB
     uint16_t **Yrow = (uint16_t **)(lds + CONV_BM * CONV_BN * 2);  // TO_LEVELS: destination row of each tile row (2 KiB)
@@ -1493,6 +1520,72 @@ RN_API int rn_conv3x3_dense_batched_act(const void *const *xs, const void *const
     a.dn.tile_beg[CONV_MAX_PROBLEMS] = 0x7fffffff;
     a.mask = nullptr; a.M = 0; a.HWp = 1; a.Wp = 1; a.Cin = Cin; a.Cout = Cout; a.relu = relu ? 1 : 0; a.zeros = (const uint16_t *)zeros;
     return conv_launch_mode<MODE_DENSE>(a, dim3((unsigned)tiles, (unsigned)(Cout / CONV_BN), 1), (hipStream_t)stream);
+}
+
+// y (16-bit) = sum over the K ranges of kpartial[z][M * Cout] (f32), fixed order
+template <int DT>
+__global__ __launch_bounds__(256) void dense_ksplit_reduce_kernel(const float *__restrict__ partial, const int S, const int64_t n4, uint16_t *__restrict__ y)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        rn::f32x4 s = ((const rn::f32x4 *)partial)[i];
+        for (int z = 1; z < S; ++z) { const rn::f32x4 v = ((const rn::f32x4 *)partial)[z * n4 + i]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+        rn::u32x2 o;
+        o.x = rn::dt<DT>::pk(s.x, s.y); o.y = rn::dt<DT>::pk(s.z, s.w);
+        ((rn::u32x2 *)y)[i] = o;
+    }
+}
+
+// K ranges of a single dense convolution: as many as keep the launch inside one round of the chip, at most 3 (one kernel row each)
+static int dense_ksplit(const int64_t M, const int Cout)
+{
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    const int64_t wgs = ((M + CONV_BM - 1) / CONV_BM) * (Cout / CONV_BN);
+    if (wgs <= 0) return 0;
+    int s = (int)(cus / wgs);
+    return s >= 3 ? 3 : (s >= 2 ? 2 : 1);
+}
+
+RN_API size_t rn_conv3x3_dense_splitk_workspace_bytes(int N, int h, int w, int Cout)
+{
+    if (N <= 0 || h <= 0 || w <= 0 || Cout <= 0 || Cout % CONV_BN) return 0;
+    const int64_t M = (int64_t)N * h * w;
+    const int S = dense_ksplit(M, Cout);
+    return S > 1 ? (size_t)S * M * Cout * sizeof(float) : 0;
+}
+
+RN_API int rn_conv3x3_dense_splitk(const void *x, const void *w, void *y, int dtype, int N, int h, int wd, int Cin, int Cout, const void *zeros,
+                                   void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (!x || !w || !y || !zeros || !workspace || Cin <= 0 || Cout <= 0) return RN_EINVAL;
+    if (!conv_dtype_ok(dtype) || Cin % CONV_BK || Cout % CONV_BN) return RN_EUNSUPPORTED;
+    ConvArgs a = {};
+    a.f16 = dtype == RN_F16;
+    const int hs[1] = {h}, wds[1] = {wd};
+    const int rc = dense_geom(a.dn, 1, N, hs, wds);
+    if (rc != RN_OK) return rc;
+    const int64_t M = a.dn.M[0];
+    const int S = dense_ksplit(M, Cout);
+    if (S < 2 || (M * Cout) % 4) return RN_EUNSUPPORTED;
+    if (workspace_bytes < (size_t)S * M * Cout * sizeof(float)) return RN_EWORKSPACE;
+    if (!rn::aligned(x, 16) || !rn::aligned(w, 16) || !rn::aligned(y, 16) || !rn::aligned(zeros, 16) || !rn::aligned(workspace, 16)) return RN_EALIGN;
+    for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) {
+        a.Xs[p] = (const uint16_t *)x; a.Ws[p] = (const uint16_t *)w; a.Ys[p] = (uint16_t *)y; a.biases[p] = nullptr;
+        a.dn.tile_beg[p] = p == 0 ? 0 : 0x7fffffff;
+    }
+    a.dn.tile_beg[CONV_MAX_PROBLEMS] = 0x7fffffff;
+    const int tiles = (int)((M + CONV_BM - 1) / CONV_BM);
+    a.mask = nullptr; a.M = 0; a.HWp = 1; a.Wp = 1; a.Cin = Cin; a.Cout = Cout; a.relu = 0; a.zeros = (const uint16_t *)zeros;
+    a.ksplit = S; a.kpartial = (float *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    const int rc2 = conv_launch_mode<MODE_DENSE>(a, dim3((unsigned)tiles, (unsigned)(Cout / CONV_BN), (unsigned)S), st);
+    if (rc2 != RN_OK) return rc2;
+    const int64_t n4 = M * Cout / 4;
+    const unsigned blocks = (unsigned)((n4 + 255) / 256 > 4096 ? 4096 : (n4 + 255) / 256);
+    if (a.f16) hipLaunchKernelGGL(dense_ksplit_reduce_kernel<RN_F16>, dim3(blocks), dim3(256), 0, st, (const float *)workspace, S, n4, (uint16_t *)y);
+    else hipLaunchKernelGGL(dense_ksplit_reduce_kernel<RN_BF16>, dim3(blocks), dim3(256), 0, st, (const float *)workspace, S, n4, (uint16_t *)y);
+    RN_LAUNCH_CHECK();
+    return RN_OK;
 }
 
 RN_API int rn_conv3x3_dense_batched(const void *const *xs, const void *const *ws, const float *const *biases, void *const *ys, int P,

@@ -137,6 +137,29 @@ def test_data_gradient_issued_as_a_forward_convolution(cout, cin, hw):
     assert not biasact.conv3x3_dgrad_fwd_fusable(nn.Conv2d(cin, cout, 3, 2, 1, bias=False).to(dev).to(torch.bfloat16), x)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,cout,cin,hw", [(8, 512, 512, (25, 42)), (2, 256, 512, (7, 9)), (1, 512, 64, (3, 130)), (3, 256, 256, (31, 17))])
+def test_k_split_dense_convolution_matches_torch(N, cout, cin, hw, dtype):
+    """``rn_conv3x3_dense_splitk`` (conv2 of the layer4 bottlenecks, backbone.py:112,128; forward and, with flipped weights, data gradient):
+    2 - 3 K ranges of the dense MFMA kernel + the f32 reduction, against fp32 convolution of the same 16-bit inputs; and the entry point says
+    no (0 workspace bytes) when the plain launch already fills half the chip."""
+    from pytorch_retinanet_amd import biasact
+    from pytorch_retinanet_amd._lib import lib
+    dev = torch.device("cuda:0")
+    torch.manual_seed(9)
+    x = torch.randn((N, cin, *hw), device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((cout, cin, 3, 3), device=dev) * 0.05).to(dtype).contiguous(memory_format=torch.channels_last)
+    need = biasact.dense_splitk_bytes(x, w)
+    assert need > 0
+    y = biasact.conv3x3_same(x, w)
+    ref = F.conv2d(x.float().cpu(), w.float().cpu(), None, 1, 1)
+    assert y.shape == ref.shape and y.dtype == dtype
+    assert _rel(y.cpu(), ref) < 4e-3
+    # 33 600 positions x 256 channels = 132 workgroups: more than half the CUs, no split
+    assert lib.rn_conv3x3_dense_splitk_workspace_bytes(8, 50, 84, 256) == 0
+    assert lib.rn_conv3x3_dense_splitk_workspace_bytes(8, 25, 42, 500) == 0          # Cout not a multiple of 256
+
+
 @pytest.mark.parametrize("N,cout,cin,hw", [
     (2, 64, 64, (40, 52)),        # one sub-problem; a row is one stage of two k-steps (52 > 32)
     (1, 64, 64, (3, 30)),         # rows shorter than one k-step, three image rows: every vertical tap leaves the image somewhere
