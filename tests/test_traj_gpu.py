@@ -33,7 +33,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 #           element error / rms(d_ref).
 # With live BatchNorm the deep layers see 4 x 5 positions x 2 images: their batch statistics amplify rounding differences (MIOpen's fp32
 # algorithm choice, 16-bit activations) in a handful of BN parameters, which the per-parameter projections of small tensors show at once.
-_BOUNDS = {("32", "frozen"): dict(total=2e-4, norm=1e-3, proj=1e-2, sample=5e-2),       # measured 1.3e-5 / 6.4e-5 / 1.1e-3 / 4.9e-3
+# fp32 / frozen has TWO outcomes, picked per process by MIOpen's find step (it times its fp32 solvers and keeps the fastest; a Winograd pick
+# carries ~1e-4 of its own): 1.3e-5 / 6.4e-5 / 1.1e-3 / 4.9e-3 or 1.9e-4 / 1.4e-3 / 1.0e-2 / 0.19 (seen for the eager and for the captured
+# leg, 3 of 8 processes).  The bounds admit both; the per-step losses (1e-4, measured 1e-6) do not move with it.
+_BOUNDS = {("32", "frozen"): dict(total=1e-3, norm=5e-3, proj=5e-2, sample=0.5),
            ("32", "live"): dict(total=5e-3, norm=2e-2),                                  # measured 4.0e-4 / 6.3e-3
            ("bf16", "frozen"): dict(total=5e-2, norm=5e-2), ("bf16", "live"): dict(total=0.12, norm=0.3),      # 1.4e-2 / 1.3e-2; 4.0e-2 / 0.12
            ("16", "frozen"): dict(total=4e-2, norm=5e-2), ("16", "live"): dict(total=5e-2, norm=0.15)}         # 1.2e-2 / 1.3e-2; 1.3e-2 / 5.0e-2
