@@ -328,7 +328,8 @@ class _BottleneckFn(torch.autograd.Function):
         wp, wn = norm._workspace(dev, st, C4)
         p3 = st3.data_ptr()
         hit = _BWD_CHAIN.pop(g_out.data_ptr(), None)
-        if hit is not None and FUSE_BWD_CHAIN and hit[2] == tuple(g_out.shape) and hit[3] == g_out.dtype:
+        if (hit is not None and FUSE_BWD_CHAIN and hit[2] == tuple(g_out.shape) and hit[3] == g_out.dtype and hit[4].data_ptr() == g_out.data_ptr()
+                and hit[4]._version == hit[5]):
             # the consumer of this block's output formed the two sums together with this very gradient (rn_pw_dgrad_resid_sums)
             check(lib.rn_bn_bwd_finalize(hit[0].data_ptr(), hit[1], M1, C4, g3.data_ptr(), p3, p3 + 4 * C4, 1, gr3.data_ptr(), gr3.data_ptr() + 4 * C4,
                                          gr3.data_ptr() + 8 * C4, st), "rn_bn_bwd_finalize")
@@ -446,7 +447,10 @@ def _conv1_dgrad(dz1: Tensor, w1t: Tensor, x: Tensor, resid: Tensor, rbits: Opti
                                              rbits.data_ptr() if rbits is not None else 0, rs, x.shape[2], x.shape[3], pz3.data_ptr(),
                                              pbits.data_ptr(), pm, pm + 4 * Cin, dx.data_ptr(), parts.data_ptr(), _stream(dev)),
                   "rn_pw_dgrad_resid_sums")
-        _BWD_CHAIN[dx.data_ptr()] = (parts, nbs, tuple(dx.shape), dx.dtype)
+        # the entry keeps dx itself: a gradient somebody else still references is never accumulated into in place by the autograd engine
+        # (torch/csrc/autograd/input_buffer.cpp: only uniquely owned buffers are), so a second consumer of the producer's output shows up
+        # as a NEW tensor at its backward -- another data_ptr, no hit -- and not as our buffer with a different content
+        _BWD_CHAIN[dx.data_ptr()] = (parts, nbs, tuple(dx.shape), dx.dtype, dx, dx._version)
         return dx
     if rs == 1:
         epi1 = RnPwEpilogue(RN_PW_EPI_RESID, 0, resid.data_ptr(), rbits.data_ptr() if rbits is not None else 0, 0, 0, 0, 0, 0)

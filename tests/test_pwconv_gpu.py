@@ -435,6 +435,45 @@ def test_chained_blocks_equal_the_unchained_ones():
         assert _l2(a, b) <= 1e-2, f"tensor {i}: relative L2 distance {_l2(a, b)}"     # (a1 rounds differently where bn1's statistics differ in their last bits)
 
 
+def test_backward_hand_over_is_not_taken_when_the_block_output_has_a_second_consumer():
+    """``pwconv.FUSE_BWD_CHAIN`` forms a block's bn3-backward sums from the gradient its successor produces.  When the block's output feeds
+    something else as well, the gradient that reaches it is the SUM of two: the hand-over must not be used (the entry holds the
+    successor's tensor, so the engine cannot add into it in place; the sum arrives as another tensor).  Checked against the unchained run."""
+    from pytorch_retinanet_amd import backbone as bb
+    from pytorch_retinanet_amd import pwconv
+    torch.manual_seed(6)
+    blocks = [bb.Bottleneck(256, 64), bb.Bottleneck(256, 64)]
+    pwconv.link_blocks(blocks)
+    for b in blocks:
+        b.to(DEV).to(memory_format=torch.channels_last).train()
+        for p in b.parameters():
+            if p.dim() == 4:
+                p.data = p.data.to(torch.bfloat16)
+    x0, g = _rand((2, 256, 24, 28), 1.0, 1), _rand((2, 256, 24, 28), 1.0, 2)
+    init = {i: {n: t.clone() for n, t in b.named_buffers()} for i, b in enumerate(blocks)}
+    res = {}
+    try:
+        for chain in (False, True):
+            pwconv.FUSE_CHAIN = pwconv.FUSE_BWD_CHAIN = chain
+            for i, b in enumerate(blocks):
+                with torch.no_grad():
+                    for n, t in b.named_buffers():
+                        t.copy_(init[i][n])
+                b.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            mid = blocks[0](x)
+            out = blocks[1](mid)
+            (out.float() * g.float()).sum().add((mid.float() ** 2).sum() * 0.5).backward()      # second consumer of `mid`: d/dmid = mid
+            torch.cuda.synchronize()
+            assert not pwconv._BWD_CHAIN or chain            # (an unconsumed entry may remain: it is dropped by the next trunk forward)
+            pwconv._BWD_CHAIN.clear()
+            res[chain] = [x.grad.float()] + [p.grad.float().clone() for b in blocks for p in b.parameters()]
+    finally:
+        pwconv.FUSE_CHAIN = pwconv.FUSE_BWD_CHAIN = True
+    for i, (a, b) in enumerate(zip(res[True], res[False])):
+        assert _l2(a, b) <= 1e-2, f"tensor {i}: relative L2 distance {_l2(a, b)}"
+
+
 def _truth_block(blk, x0, g):
     "The block in plain fp32 PyTorch ops with autograd (bf16 weights up-cast, batch statistics): outputs and every gradient."
     def bn(z, m):
