@@ -379,6 +379,12 @@ int rn_pw_dgrad_resid_sums_walkers(int64_t M, int Cm, int C4);
 int rn_pw_dgrad_resid_sums(int64_t M, int Cm, int C4, int dtype, const void *dz1, const void *w1t, const void *resid, const uint8_t *rbits,
                            int res_stride, int res_h, int res_w, const void *prev_z3, const uint8_t *prev_bits, const float *prev_mean,
                            const float *prev_invstd, void *dx, float *partial, void *stream);
+/* conv3 of a bottleneck, forward, on the row-tile walker kernel of rn_pw_dgrad_resid_sums (ABI 9): z3 [M][C4] = relu(fma(z2, fa, fb)) . w3^T
+ * with fwd_coef f32 [2][Cm] = (fa | fb) bn2's forward coefficients, partial f32 [walkers][2][C4] = column sums / sums of squares of z3 as
+ * stored -- rn_pw_conv_forward(z2, w3, prologue RN_PW_PRO_AFFINE_RELU, epilogue RN_PW_EPI_STATS), z3 bit for bit.  Cm = 64 / 128, C4 % 128 == 0. */
+int rn_pw_conv3_forward_walkers(int64_t M, int Cm, int C4);
+int rn_pw_conv3_forward(int64_t M, int Cm, int C4, int dtype, const void *z2, const float *fwd_coef, const void *w3, void *z3, float *partial,
+                        void *stream);
 int rn_pw_conv3_backward_walkers(int64_t M, int Cm, int C4);
 size_t rn_pw_conv3_backward_workspace_bytes(int64_t M, int Cm, int C4);
 int rn_pw_conv3_backward(int64_t M, int Cm, int C4, int dtype, const void *g, const void *z3, const uint8_t *bits, const float *a3,

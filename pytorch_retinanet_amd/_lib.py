@@ -156,6 +156,8 @@ SIGNATURES = {
     "rn_pw_block_out_conv1": (C.c_int, [_i64, C.c_int, C.c_int, C.c_int] + [_vp] * 12),
     "rn_pw_dgrad_resid_sums_walkers": (C.c_int, [_i64, C.c_int, C.c_int]),
     "rn_pw_dgrad_resid_sums": (C.c_int, [_i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rn_pw_conv3_forward_walkers": (C.c_int, [_i64, C.c_int, C.c_int]),
+    "rn_pw_conv3_forward": (C.c_int, [_i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rn_pw_conv3_backward_walkers": (C.c_int, [_i64, C.c_int, C.c_int]),
     "rn_pw_conv3_backward_workspace_bytes": (_sz, [_i64, C.c_int, C.c_int]),
     "rn_pw_conv3_backward": (C.c_int, [_i64, C.c_int, C.c_int, C.c_int] + [_vp] * 15 + [_sz, _vp, _vp]),

@@ -1035,9 +1035,12 @@ struct DgradSumsArgs {
     uint16_t *Y;                    // dx [M][C4]
     float *partial;                 // [gx][2][C4]
     int M, C4, gx, f16;
+    // FWD (conv3 of a bottleneck, forward): A = z2 [M][CM] with relu(fma(z2, fa, fb)) in the operand load (bn2's apply + ReLU), Wt = w3 [C4][CM],
+    // Y = z3, partial = column sums / sums of squares of z3 as stored (pw_gemm_kernel<.., PRO_AFFINE_RELU, EPI_STATS>); no epilogue operands
+    const float *fa, *fb;           // [CM]
 };
 
-template <int DT, int KC>
+template <int DT, int KC, bool FWD>
 __global__ __launch_bounds__(512, 2) void pw_dgrad_sums_kernel(const DgradSumsArgs a)
 {
     constexpr int T = 512, CM = KC * 64, BN = 128;
@@ -1069,13 +1072,19 @@ __global__ __launch_bounds__(512, 2) void pw_dgrad_sums_kernel(const DgradSumsAr
     const int ecg = tid % CG, erl = tid / CG;
     float ssum[8], qsum[8], mu[8], is[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { ssum[j] = 0.0f; qsum[j] = 0.0f; }
-    ld8f(a.pmean + n0 + ecg * 8, mu); ld8f(a.pinv + n0 + ecg * 8, is);
+    for (int j = 0; j < 8; ++j) { ssum[j] = 0.0f; qsum[j] = 0.0f; mu[j] = 0.0f; is[j] = 0.0f; }
+    if (!FWD) { ld8f(a.pmean + n0 + ecg * 8, mu); ld8f(a.pinv + n0 + ecg * 8, is); }
+    ProCoef acoef[KC];                                            // FWD: bn2's coefficients of this thread's 8 channels of every chunk
+    if (FWD) {
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) { ld8f(a.fa + kc * 64 + c * 8, acoef[kc].a); ld8f(a.fb + kc * 64 + c * 8, acoef[kc].b); }
+    }
 
     // two register sets of epilogue operands: the NEXT tile's are requested before this tile's epilogue runs (the tile loop is unrolled by
     // two through a generic lambda so that the set is a literal)
     rn::u32x4 sa[KC][AV], er[2][EROWS], ez[2][EROWS];
     uint32_t eb[2][EROWS], ezb[2][EROWS];
+    bool sval[AV] = {false, false};                               // (FWD: rows past the end must stay zero THROUGH the transform)
     auto issue_a = [&](const int m0) {
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc)
@@ -1083,6 +1092,7 @@ __global__ __launch_bounds__(512, 2) void pw_dgrad_sums_kernel(const DgradSumsAr
             for (int i = 0; i < AV; ++i) {
                 const int m = m0 + r0 + 64 * i;
                 const rn::u32x4 zero4 = {0u, 0u, 0u, 0u};
+                sval[i] = m < a.M;
                 sa[kc][i] = m < a.M ? *(const rn::u32x4 *)(a.A + (int64_t)m * CM + kc * 64 + c * 8) : zero4;
             }
     };
@@ -1090,10 +1100,12 @@ __global__ __launch_bounds__(512, 2) void pw_dgrad_sums_kernel(const DgradSumsAr
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc)
 #pragma unroll
-            for (int i = 0; i < AV; ++i) *(rn::u32x4 *)(lds + kc * 128 * 128 + wa_off[i]) = sa[kc][i];
+            for (int i = 0; i < AV; ++i)
+                *(rn::u32x4 *)(lds + kc * 128 * 128 + wa_off[i]) = FWD ? transform<DT, PRO_AFFINE_RELU>(sa[kc][i], sa[kc][i], 0xffu, acoef[kc], 0, sval[i]) : sa[kc][i];
     };
     auto load_epi = [&](auto set_c, const int m0) {              // a tile's epilogue operands (pw_gemm_kernel's EPI_RESID addressing)
         constexpr int S = decltype(set_c)::value;
+        if (FWD) return;
 #pragma unroll
         for (int i = 0; i < EROWS; ++i) {
             const int m = m0 + erl + i * RL, mc = m < a.M ? m : a.M - 1;
@@ -1159,18 +1171,25 @@ __global__ __launch_bounds__(512, 2) void pw_dgrad_sums_kernel(const DgradSumsAr
             if (m < a.M) {
                 float v[8], r[8], z[8];
                 ld8f(tile + row * BN + ecg * 8, v);
-                rn::dt<DT>::unpack(er[S][i], r);
+                if (!FWD) {
+                    rn::dt<DT>::unpack(er[S][i], r);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += ((eb[S][i] >> j) & 1u) ? r[j] : 0.0f;
+                    for (int j = 0; j < 8; ++j) v[j] += ((eb[S][i] >> j) & 1u) ? r[j] : 0.0f;
+                }
                 const rn::u32x4 o = rn::dt<DT>::pack(v);
                 *(rn::u32x4 *)(a.Y + (int64_t)m * a.C4 + n0 + ecg * 8) = o;
-                rn::dt<DT>::unpack(o, v);                          // the sums are those of the stored gradient
-                rn::dt<DT>::unpack(ez[S][i], z);
+                rn::dt<DT>::unpack(o, v);                          // the sums are those of the stored tensor
+                if (FWD) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float gj = ((ezb[S][i] >> j) & 1u) ? v[j] : 0.0f;
-                    ssum[j] += gj;
-                    qsum[j] = fmaf(gj, (z[j] - mu[j]) * is[j], qsum[j]);
+                    for (int j = 0; j < 8; ++j) { ssum[j] += v[j]; qsum[j] = fmaf(v[j], v[j], qsum[j]); }
+                } else {
+                    rn::dt<DT>::unpack(ez[S][i], z);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float gj = ((ezb[S][i] >> j) & 1u) ? v[j] : 0.0f;
+                        ssum[j] += gj;
+                        qsum[j] = fmaf(gj, (z[j] - mu[j]) * is[j], qsum[j]);
+                    }
                 }
             }
         }
@@ -1457,12 +1476,12 @@ static bool dgrad_sums_shape_ok(const int64_t M, const int Cm, const int C4)
 {
     return M > 0 && M < ((int64_t)1 << 31) / (C4 > 0 ? C4 : 1) * 8 && (Cm == 64 || Cm == 128) && C4 > 0 && C4 % 128 == 0;
 }
-template <int DT, int KC> static int launch_dgrad_sums(const DgradSumsArgs &a, hipStream_t st)
+template <int DT, int KC, bool FWD = false> static int launch_dgrad_sums(const DgradSumsArgs &a, hipStream_t st)
 {
     constexpr int lds = KC * 128 * 128 * 2 + 128 * 128 * 4;
     static rn::DynLdsOptIn opt_in = {};
-    { const int rc = opt_in.ensure((const void *)pw_dgrad_sums_kernel<DT, KC>, lds); if (rc != RN_OK) return rc; }
-    hipLaunchKernelGGL((pw_dgrad_sums_kernel<DT, KC>), dim3((unsigned)a.gx, (unsigned)(a.C4 / 128)), dim3(512), lds, st, a);
+    { const int rc = opt_in.ensure((const void *)pw_dgrad_sums_kernel<DT, KC, FWD>, lds); if (rc != RN_OK) return rc; }
+    hipLaunchKernelGGL((pw_dgrad_sums_kernel<DT, KC, FWD>), dim3((unsigned)a.gx, (unsigned)(a.C4 / 128)), dim3(512), lds, st, a);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
@@ -1500,6 +1519,23 @@ RN_API int rn_pw_dgrad_resid_sums(int64_t M, int Cm, int C4, int dtype, const vo
     hipStream_t st = (hipStream_t)stream;
     if (Cm == 64) return a.f16 ? launch_dgrad_sums<RN_F16, 1>(a, st) : launch_dgrad_sums<RN_BF16, 1>(a, st);
     return a.f16 ? launch_dgrad_sums<RN_F16, 2>(a, st) : launch_dgrad_sums<RN_BF16, 2>(a, st);
+}
+
+RN_API int rn_pw_conv3_forward_walkers(int64_t M, int Cm, int C4) { return dgrad_sums_shape_ok(M, Cm, C4) ? dgrad_sums_walkers(M, C4) : 0; }
+
+RN_API int rn_pw_conv3_forward(int64_t M, int Cm, int C4, int dtype, const void *z2, const float *fwd_coef, const void *w3, void *z3, float *partial,
+                               void *stream)
+{
+    if (!z2 || !fwd_coef || !w3 || !z3 || !partial) return RN_EINVAL;
+    if (dtype != RN_BF16 && dtype != RN_F16) return RN_EUNSUPPORTED;
+    if (!dgrad_sums_shape_ok(M, Cm, C4)) return RN_EUNSUPPORTED;
+    if (!rn::aligned(z2, 16) || !rn::aligned(w3, 16) || !rn::aligned(z3, 16) || !rn::aligned(fwd_coef, 16)) return RN_EALIGN;
+    DgradSumsArgs a = {};
+    a.A = (const uint16_t *)z2; a.Wt = (const uint16_t *)w3; a.Y = (uint16_t *)z3; a.partial = partial; a.fa = fwd_coef; a.fb = fwd_coef + Cm;
+    a.rs = 1; a.M = (int)M; a.C4 = C4; a.gx = dgrad_sums_walkers(M, C4); a.f16 = dtype == RN_F16;
+    hipStream_t st = (hipStream_t)stream;
+    if (Cm == 64) return a.f16 ? launch_dgrad_sums<RN_F16, 1, true>(a, st) : launch_dgrad_sums<RN_BF16, 1, true>(a, st);
+    return a.f16 ? launch_dgrad_sums<RN_F16, 2, true>(a, st) : launch_dgrad_sums<RN_BF16, 2, true>(a, st);
 }
 
 RN_API int rn_pw_conv3_backward_walkers(int64_t M, int Cm, int C4) { return pair_shape_ok(M, Cm, C4) ? pair_walkers(M, Cm) : 0; }

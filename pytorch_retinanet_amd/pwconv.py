@@ -40,6 +40,7 @@ FUSED_BOTTLENECK = os.environ.get("RN_FUSED_BOTTLENECK", "1") != "0"      # 0: t
 FUSED_MAX_MID = int(os.environ.get("RN_FUSED_MAX_MID", "128"))
 FUSE_BWD_CHAIN = True          # ... and, in backward, the previous block's bn3-backward sums with its own conv1 data gradient: rn_pw_dgrad_resid_sums
 _BWD_CHAIN: Dict[int, tuple] = {}      # data_ptr of a block's input gradient -> (partials, rows, shape, dtype); emptied by every trunk forward
+CONV3_FWD_WALKER = True        # conv3 forward (+ bn2 apply in the operand load, bn3 statistics) on the row-tile walker kernel instead of pw_gemm_kernel
 FUSE_CHAIN = True              # a fused block forms its output together with the NEXT fused block's conv1 (+ bn1 statistics): rn_pw_block_out_conv1
 FUSE_CONV3_BWD = True          # conv3's data and weight gradients in one pass over the block-output gradient (layer1 / layer2 shapes)
 DEFER_WGRAD_REDUCE = True      # a fused block sums the splits of its 1x1 weight gradients in one launch at the end of its backward
@@ -271,9 +272,20 @@ class _BottleneckFn(torch.autograd.Function):
         st2 = bn_stats(z2, blk.bn2)
         M1 = z2.shape[0] * z2.shape[2] * z2.shape[3]
         # conv3: relu(bn2(z2)) in the operand load, bn3 statistics in the epilogue
-        e3, p3, nb3 = stats_epilogue(M1, w3.shape[0], dev)
         Cm = w2.shape[0]
-        z3 = pw_forward(z2, w3, pro=affine_relu(st2[2 * Cm:]), epi=e3, tag="pw_conv3_fwd")
+        nb3 = lib.rn_pw_conv3_forward_walkers(M1, Cm, int(w3.shape[0])) if CONV3_FWD_WALKER else 0
+        if nb3 > 0:
+            # the row-tile walker kernel (512 threads, one workgroup per CU, weight rows resident in LDS): same z3, statistics partials per walker
+            C4o = int(w3.shape[0])
+            z3 = torch.empty((z2.shape[0], C4o, z2.shape[2], z2.shape[3]), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+            p3 = torch.empty((nb3 * 2 * C4o,), dtype=torch.float32, device=dev)
+            PW_FLOP["pw_conv3_fwd"] = 2.0 * M1 * Cm * C4o
+            with _timed("pw_conv3_fwd", dev):
+                check(lib.rn_pw_conv3_forward(M1, Cm, C4o, _DT16[x.dtype], z2.data_ptr(), st2.data_ptr() + 8 * Cm, w3.data_ptr(), z3.data_ptr(),
+                                              p3.data_ptr(), _stream(dev)), "rn_pw_conv3_forward")
+        else:
+            e3, p3, nb3 = stats_epilogue(M1, w3.shape[0], dev)
+            z3 = pw_forward(z2, w3, pro=affine_relu(st2[2 * Cm:]), epi=e3, tag="pw_conv3_fwd")
         st3 = bn_finalize(p3, nb3, M1, blk.bn3)
         zd = std = None
         if wd is not None:

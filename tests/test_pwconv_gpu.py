@@ -385,6 +385,31 @@ def test_conv1_data_gradient_with_the_previous_blocks_bn3_sums(cm, c4, H, W, rs,
     np.testing.assert_allclose(sums[1].cpu().numpy(), (g * xhat).sum(0).cpu().numpy(), rtol=1e-4, atol=1e-4 * float((g * xhat).abs().sum(0).max()))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cm,c4,H,W", [(64, 256, 19, 23), (128, 512, 19, 23), (64, 256, 260, 260), (128, 512, 1, 5), (64, 128, 9, 7)])
+def test_conv3_forward_on_the_row_tile_walker(cm, c4, H, W, dtype):
+    "``rn_pw_conv3_forward`` == ``rn_pw_conv_forward(z2, w3, RN_PW_PRO_AFFINE_RELU, RN_PW_EPI_STATS)``: z3 bit for bit, statistics to summation order."
+    from pytorch_retinanet_amd import pwconv
+    from pytorch_retinanet_amd._lib import RN_BF16, RN_F16, lib
+    M = 2 * H * W
+    z2 = _rand((2, cm, H, W), 1.0, 1).to(dtype)
+    w3 = _rand((c4, cm, 1, 1), 0.05, 2).to(dtype)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    coef = torch.cat([torch.rand(cm, device=DEV, generator=gen) + 0.5, torch.randn(cm, device=DEV, generator=gen) * 0.3])
+    nb = lib.rn_pw_conv3_forward_walkers(M, cm, c4)
+    assert nb > 0
+    z3 = torch.full((2, c4, H, W), float("nan"), dtype=dtype, device=DEV).contiguous(memory_format=torch.channels_last)
+    part = torch.full((nb * 2 * c4,), float("nan"), dtype=torch.float32, device=DEV)
+    assert lib.rn_pw_conv3_forward(M, cm, c4, RN_F16 if dtype == torch.float16 else RN_BF16, z2.data_ptr(), coef.data_ptr(), w3.data_ptr(), z3.data_ptr(),
+                                   part.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
+    e, p1, nb1 = pwconv.stats_epilogue(M, c4, torch.device(DEV))
+    ref = pwconv.pw_forward(z2, w3, pro=pwconv.affine_relu(coef), epi=e)
+    torch.cuda.synchronize()
+    assert torch.equal(z3, ref)
+    a, b = part.view(nb, 2, c4).double().sum(0), p1.view(nb1, 2, c4).double().sum(0)
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(b.abs().max()))
+
+
 def test_chained_blocks_equal_the_unchained_ones():
     """Two consecutive fused bottlenecks (downsample block -> identity block -> identity block) with and without ``pwconv.FUSE_CHAIN``:
     the same tensors reach the same kernels (only bn1's statistics are summed in another order), so outputs and gradients agree far
