@@ -604,6 +604,12 @@ struct WgradArgs {
     LevelSet lv;                                // GATHER: dense per-level gradient tensors [N][h][w][row_elems]; problem p = output channels 256 p ..
     DenseGeom dn;                               // DENSE: per-problem geometry; tile_beg = first split of the problem (blockIdx.x walks them all)
     int dn_tps[CONV_MAX_PROBLEMS];              //        K-tiles per split of problem p
+    // xcd_units > 0: a 1-D grid of 256 workgroups placed by XCD (workgroups go round-robin over the 8 XCDs: XCD = blockIdx.x % 8).  All
+    // (tap, problem) workgroups of position split s run on XCD s -- they stream the SAME position range, the 4 problems of a tap the
+    // same X tiles and the 9 taps of a problem the same G tiles, in step -- so each XCD's L2 sees its split's operands once instead of
+    // every workgroup fetching its own copy (the gathered class-output gradient + activations are 388 MB, the 36 copies 6.1 GB);
+    // the (xcd_units - 32) units per split that do not fit XCD s's 32 CUs run on XCD 7.  Host: S <= 7, (xcd_units - 32) * S <= 32.
+    int xcd_units;
 };
 
 // GATHER = false: G and X are canvases (the head towers).  GATHER = true: the gradient operand is gathered, position by
@@ -626,7 +632,14 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_wgrad_kernel(const Wgrad
     const int wm = NARROW ? 0 : wave >> 2, wn = NARROW ? wave : wave & 3;       // NARROW: wn counts 32-channel columns
     const int pp = wave >> 2;                                     // ping-pong group: waves 0-3 / 4-7
     int split = blockIdx.x, prob = blockIdx.z, KT = a.tiles_per_split, Wp = a.Wp, dense_h = 0;
-    const int tap = blockIdx.y;
+    int tap = blockIdx.y;
+    if (!DENSE && a.xcd_units > 0) {
+        const int L = blockIdx.x, xcd = L & 7, w = L >> 3;
+        int unit;
+        if (xcd < 7) { split = xcd; unit = w; if (split >= a.S || unit >= a.xcd_units) return; }
+        else { const int spill = a.xcd_units - 32; if (spill <= 0) return; split = w / spill; unit = 32 + w % spill; if (split >= a.S) return; }
+        tap = unit % 9; prob = unit / 9;
+    }
     int64_t M = a.M;
     if (DENSE) {
         prob = 0;
@@ -1370,6 +1383,9 @@ RN_API int rn_conv3x3_levels_to_canvas_relu(const void *const *gs, const rn_canv
     return RN_OK;
 }
 
+#ifndef WGRAD_XCD_MAP
+#define WGRAD_XCD_MAP 1
+#endif
 // Position splits of the weight-gradient kernels: one workgroup per (split, tap, problem), about one wave of the chip.
 static int wgrad_splits(const int P, const int64_t M, int *tiles_per_split)
 {
@@ -1403,6 +1419,11 @@ static int wgrad_launch_dt(WgradArgs &a, uint16_t *const (&dw)[CONV_MAX_PROBLEMS
     const int S = wgrad_splits(P, M, &a.tiles_per_split);
     a.S = S; a.M = M; a.partial = (float *)workspace;
     if (used_floats) *used_floats = (size_t)P * S * 9 * 65536;
+    const int U = 9 * P;
+    a.xcd_units = (GATHER && !NARROW && WGRAD_XCD_MAP && S <= 7 && U >= 32 && (U - 32) * S <= 32 && U <= 36) ? U : 0;
+    if (a.xcd_units > 0)
+        hipLaunchKernelGGL((conv3x3_wgrad_kernel<DT, GATHER, NARROW>), dim3(256, 1, 1), dim3(CONV_THREADS), CONV_LDS_BYTES, st, a);
+    else
     hipLaunchKernelGGL((conv3x3_wgrad_kernel<DT, GATHER, NARROW>), dim3((unsigned)S, 9, (unsigned)P), dim3(CONV_THREADS), CONV_LDS_BYTES, st, a);
     RN_LAUNCH_CHECK();
     hipLaunchKernelGGL(wgrad_reduce_kernel<DT>, dim3(9 * 65536 / 4 / 256, (unsigned)P), dim3(256), 0, st, (const float *)workspace, S, dw[0], dw[1],
