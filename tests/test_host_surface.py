@@ -274,3 +274,25 @@ def test_weight_gradient_partials_stay_at_two_workgroups_per_cu():
         subs = (cout // 64) * (cin // 64)
         assert need % (subs * 64 * 9 * 64 * 4) == 0 and 0 < need <= 256 * 64 * 9 * 64 * 4, (cout, cin, need)
     assert lib.rn_conv3x3_wgrad_narrow_workspace_bytes(96, 64) == 0 and lib.rn_conv3x3_wgrad_narrow_workspace_bytes(0, 64) == 0
+
+
+def test_block_links_are_not_submodules_and_survive_copies():
+    """``pwconv.link_blocks`` (a fused bottleneck forms its successor's conv1 with its own output): the links live in ``__dict__`` -- no
+    extra children, parameters or state-dict keys -- and a deepcopy / pickle round trip points them into the copy."""
+    import copy
+    import io
+    import torch
+    from pytorch_retinanet_amd import backbone
+    m = backbone.resnet50(pretrained=False)
+    keys = list(m.state_dict().keys())
+    assert not any("_rn_next" in k for k in keys)
+    assert [n for n, _ in m.layer1[0].named_children()] == ["conv1", "bn1", "conv2", "bn2", "conv3", "bn3", "relu", "downsample"]
+    assert m.layer1[0].__dict__["_rn_next"][0] is m.layer1[1] and m.layer1[2].__dict__["_rn_next"][0] is m.layer2[0]
+    assert "_rn_next" not in m.layer4[2].__dict__
+    m2 = copy.deepcopy(m)
+    assert list(m2.state_dict().keys()) == keys and m2.layer1[0].__dict__["_rn_next"][0] is m2.layer1[1]
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)
+    assert m3.layer2[3].__dict__["_rn_next"][0] is m3.layer3[0]
