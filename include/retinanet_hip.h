@@ -629,6 +629,14 @@ int rn_bn_relu_maxpool3x3s2_forward(const void *x, const float *coef, void *y, u
                                     void *stream);
 int rn_maxpool3x3s2_backward(const uint8_t *argmax, const void *dy, void *dx, int dtype,
                              int N, int H, int W, int C, void *stream);
+/* The same for the stem (ABI 9), where the pooled tensor was relu(bn1(z)) (/root/reference/retinanet/backbone.py:246-251): besides dx the kernel
+ * takes the two sums of bn1's backward over the gradient it has just formed -- partial f32 [rows][2][C], rows =
+ * rn_maxpool3x3s2_backward_bn_rows(N, H, W, C): what rn_bn_bwd_reduce(dx, NULL, z, .., fwd_coef, training, relu = 1) sums before it finalizes
+ * (g' = dx * [fma(z, fa, fb) alive]; sum g', sum g' * (z - mean) * invstd) -- so that pass does not re-read dx; complete with
+ * rn_bn_bwd_finalize(partial, rows, ..).  fwd_coef f32 [2][C] = (a | b) of the forward.  C % 8 == 0 and (C / 8) | 256. */
+int rn_maxpool3x3s2_backward_bn_rows(int N, int H, int W, int C);
+int rn_maxpool3x3s2_backward_bn(const uint8_t *argmax, const void *dy, const void *z, const float *fwd_coef, const float *mean,
+                                const float *invstd, void *dx, float *partial, int dtype, int N, int H, int W, int C, void *stream);
 
 /* ---- FPN top-down step, channels-last ----------------------------------------------------------------------
  * out = lat + nearest_upsample_2x(top)   (retinanet/layers.py:36,52-53: lateral 1x1 conv + nn.Upsample(scale_factor=2) of the

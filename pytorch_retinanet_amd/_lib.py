@@ -109,6 +109,8 @@ SIGNATURES = {
     "rn_maxpool3x3s2_forward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "rn_bn_relu_maxpool3x3s2_forward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "rn_maxpool3x3s2_backward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "rn_maxpool3x3s2_backward_bn_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rn_maxpool3x3s2_backward_bn": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "rn_sgd_master_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _f32, _f32, _f32, _f32, C.c_int, C.c_int, _vp]),
     "rn_sgd_master_step_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _f32, _f32, _f32, _f32, C.c_int, C.c_int, _vp, _vp, _vp]),
     "rn_conv3x3_canvas_to_levels": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -189,12 +189,27 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const void *__restrict
 // and gradient vectors are fetched once for four outputs (a thread per input element fetched them four times: 132 -> 7x us at the
 // stem's shape).  Even rows / columns lie in one window row / column only, odd ones in two.  The sums run over the windows in
 // (oy, ox) order as before: same values bit for bit.
-template <int DT>
+// BN: the pooled tensor was relu(bn(z)) (the stem: retinanet/backbone.py:246-251) -- the two sums of that BatchNorm's backward over the
+// gradient just formed are taken here (norm.hip's bn_bwd_partial_kernel<DT, 2>: g' = dx * [fma(z, fa, fb) alive]; sum g', sum g' * xhat),
+// which saves that pass its read of dx.  256 % C8 == 0 and the grid stride is a multiple of 256: a thread's channel group is fixed.
+struct PoolBnArgs { const void *z; const float *fa, *fb, *mean, *invstd; float *partial; };
+
+template <int DT, bool BN = false>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t *__restrict__ idx, const void *__restrict__ dy,
-                                                          void *__restrict__ dx, const PoolShape s)
+                                                          void *__restrict__ dx, const PoolShape s, const PoolBnArgs bn = PoolBnArgs{})
 {
     const int HB = (s.H + 1) >> 1, WB = (s.W + 1) >> 1;
     const int64_t total = (int64_t)s.N * HB * WB * s.C8;
+    float ssum[8], qsum[8], cfa[8], cfb[8], cmu[8], cis[8];
+    if (BN) {
+        const int cg0 = threadIdx.x % s.C8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            ssum[j] = 0.0f; qsum[j] = 0.0f;
+            cfa[j] = bn.fa[cg0 * 8 + j]; cfb[j] = bn.fb[cg0 * 8 + j]; cmu[j] = bn.mean[cg0 * 8 + j]; cis[j] = bn.invstd[cg0 * 8 + j];
+        }
+    }
+    const float alive = DT == RN_F32 ? 0.0f : __uint_as_float(DT == RN_F16 ? 0x33000000u : 0x00004000u);      // norm.hip: relu_alive_threshold<DT>
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         int cg, b, a, n;
         split_index(i, total < (1ll << 31), s.C8, WB, HB, cg, b, a, n);
@@ -236,7 +251,36 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const uint8_t *__restr
                     g[j + 4] += (ok[k] && ((d1 >> (8 * j)) & 0xffu) == 0u) ? gv[k][j + 4] : 0.0f;
                 }
             }
-            v8<DT>::st(dx, (((int64_t)n * s.H + iy) * s.W + ix) * s.C8 + cg, g);
+            const int64_t vi = (((int64_t)n * s.H + iy) * s.W + ix) * s.C8 + cg;
+            v8<DT>::st(dx, vi, g);
+            if (BN) {
+                float zz[8], gs[8];
+                v8<DT>::ld(bn.z, vi, zz);
+                if constexpr (DT != RN_F32) { rn::dt<DT>::unpack(rn::dt<DT>::pack(g), gs); }      // the sums are those of the stored gradient
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) gs[j] = g[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float gj = (fmaf(zz[j], cfa[j], cfb[j]) > alive) ? gs[j] : 0.0f;
+                    ssum[j] += gj;
+                    qsum[j] = fmaf(gj, (zz[j] - cmu[j]) * cis[j], qsum[j]);
+                }
+            }
+        }
+    }
+    if (BN) {
+        __shared__ float red[256][17];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[threadIdx.x][j] = ssum[j]; red[threadIdx.x][8 + j] = qsum[j]; }
+        __syncthreads();
+        const int C = s.C8 * 8;
+        for (int q = threadIdx.x; q < 2 * C; q += 256) {
+            const int which = q / C, ch = q - which * C, cgq = ch >> 3, j = ch & 7;
+            float t = 0.0f;
+            for (int l = cgq; l < 256; l += s.C8) t += red[l][which * 8 + j];
+            bn.partial[((int64_t)blockIdx.x * 2 + which) * C + ch] = t;
         }
     }
 }
@@ -346,6 +390,30 @@ RN_API int rn_maxpool3x3s2_backward(const uint8_t *argmax, const void *dy, void 
         case RN_BF16: hipLaunchKernelGGL((maxpool_bwd_kernel<RN_BF16>), g, b, 0, st, argmax, dy, dx, s); break;
         default: hipLaunchKernelGGL((maxpool_bwd_kernel<RN_F16>), g, b, 0, st, argmax, dy, dx, s); break;
     }
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
+RN_API int rn_maxpool3x3s2_backward_bn_rows(int N, int H, int W, int C)
+{
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || 256 % (C / 8)) return 0;
+    const int b = pool_blocks((int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 8));
+    return b > 1024 ? 1024 : b;
+}
+
+RN_API int rn_maxpool3x3s2_backward_bn(const uint8_t *argmax, const void *dy, const void *z, const float *fwd_coef, const float *mean,
+                                       const float *invstd, void *dx, float *partial, int dtype, int N, int H, int W, int C, void *stream)
+{
+    if (!argmax || !dy || !dx || !z || !fwd_coef || !mean || !invstd || !partial || N <= 0 || H <= 0 || W <= 0 || C <= 0) return RN_EINVAL;
+    if (C % 8 || 256 % (C / 8)) return RN_EUNSUPPORTED;
+    if (dtype != RN_BF16 && dtype != RN_F16) return RN_EUNSUPPORTED;
+    if (!rn::aligned(argmax, 8) || !rn::aligned(dy, 16) || !rn::aligned(dx, 16) || !rn::aligned(z, 16)) return RN_EALIGN;
+    const PoolShape s{N, H, W, C / 8, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
+    const PoolBnArgs bn{z, fwd_coef, fwd_coef + C, mean, invstd, partial};
+    const dim3 g((unsigned)rn_maxpool3x3s2_backward_bn_rows(N, H, W, C)), b(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == RN_BF16) hipLaunchKernelGGL((maxpool_bwd_kernel<RN_BF16, true>), g, b, 0, st, argmax, dy, dx, s, bn);
+    else hipLaunchKernelGGL((maxpool_bwd_kernel<RN_F16, true>), g, b, 0, st, argmax, dy, dx, s, bn);
     RN_LAUNCH_CHECK();
     return RN_OK;
 }

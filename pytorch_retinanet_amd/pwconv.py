@@ -709,6 +709,7 @@ def conv1x1(conv, x: Tensor) -> Tensor:
 
 # ---- the stem: conv 7x7 / stride 2 (3 -> 64) + BatchNorm (batch statistics) + ReLU on csrc/stem.hip ---------------------------------
 FUSED_STEM = True
+STEM_POOL_BN_SUMS = True   # ... and bn1's two backward sums inside the max pooling's backward (rn_maxpool3x3s2_backward_bn)
 STEM_WGRAD_BN = True   # ... with bn1's backward apply step in its operand load (rn_stem_conv_wgrad_bn)
 STEM_WGRAD = True      # weight gradient on csrc/stem.hip as well (False: MIOpen)
 _STEM_WS: Dict[tuple, Tensor] = {}
@@ -768,16 +769,27 @@ class _StemFn(torch.autograd.Function):
         M = z.shape[0] * z.shape[2] * z.shape[3]
         if not (da.dtype == z.dtype and _cl(da)):
             da = da.to(z.dtype).contiguous(memory_format=torch.channels_last)
-        if ctx.pool:                                                 # `da` is the pooled gradient: back through the arg-max codes first
-            dpool, da = da, torch.empty_like(z)
-            check(lib.rn_maxpool3x3s2_backward(arg.data_ptr(), dpool.data_ptr(), da.data_ptr(), _DT16[z.dtype], z.shape[0], z.shape[2], z.shape[3], Cc, st),
-                  "rn_maxpool3x3s2_backward")
         gr = torch.empty((5 * Cc,), dtype=torch.float32, device=dev)
         sp = stats.data_ptr()
+        fused_apply = STEM_WGRAD and STEM_WGRAD_BN
+        pool_rows = lib.rn_maxpool3x3s2_backward_bn_rows(z.shape[0], z.shape[2], z.shape[3], Cc) if (ctx.pool and fused_apply and STEM_POOL_BN_SUMS) else 0
+        if ctx.pool:                                                 # `da` is the pooled gradient: back through the arg-max codes first
+            dpool, da = da, torch.empty_like(z)
+            if pool_rows > 0:
+                # ... and bn1's two backward sums over the gradient just formed in the same pass (that pass then does not re-read it)
+                part = torch.empty((pool_rows * 2 * Cc,), dtype=torch.float32, device=dev)
+                check(lib.rn_maxpool3x3s2_backward_bn(arg.data_ptr(), dpool.data_ptr(), z.data_ptr(), sp + 8 * Cc, sp, sp + 4 * Cc, da.data_ptr(),
+                                                      part.data_ptr(), _DT16[z.dtype], z.shape[0], z.shape[2], z.shape[3], Cc, st),
+                      "rn_maxpool3x3s2_backward_bn")
+            else:
+                check(lib.rn_maxpool3x3s2_backward(arg.data_ptr(), dpool.data_ptr(), da.data_ptr(), _DT16[z.dtype], z.shape[0], z.shape[2], z.shape[3], Cc,
+                                                   st), "rn_maxpool3x3s2_backward")
         wp, wn = norm._workspace(dev, st, Cc)
         B, _, H, W = x.shape
-        fused_apply = STEM_WGRAD and STEM_WGRAD_BN
-        if fused_apply:
+        if pool_rows > 0:
+            check(lib.rn_bn_bwd_finalize(part.data_ptr(), pool_rows, M, Cc, gamma.data_ptr(), sp, sp + 4 * Cc, 1, gr.data_ptr(), gr.data_ptr() + 4 * Cc,
+                                         gr.data_ptr() + 8 * Cc, st), "rn_bn_bwd_finalize")
+        elif fused_apply:
             # the two sums and the coefficients only: the apply step rides in the weight gradient's operand load (the image needs no gradient,
             # so nothing else reads the conv-output gradient -- 275 MB that are neither written nor read back)
             check(lib.rn_bn_bwd_reduce(da.data_ptr(), 0, z.data_ptr(), _DT16[z.dtype], M, Cc, gamma.data_ptr(), sp, sp + 4 * Cc, sp + 8 * Cc, 1, 1,
