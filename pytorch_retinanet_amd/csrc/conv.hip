@@ -40,6 +40,10 @@
 #include <type_traits>
 #include <cstdlib>
 
+#ifndef BAND_NARROW_FWD
+#define BAND_NARROW_FWD 1            // the <= 64-column TO_LEVELS launches on conv3x3_band_narrow_kernel (0: the tile kernel's NARROW variant)
+#endif
+
 namespace {
 
 using rn::f32x16;
@@ -577,6 +581,164 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     }
 }
 
+
+// ================================================================================================================
+// Band-staged NARROW forward (canvas in, dense per-level rows out, at most 64 output columns): the box-output conv (36 channels)
+// and the ragged last column tile of the class-output conv (810 = 3 x 256 + 42).  The NARROW variant of the kernel above stages a
+// 256 x 64 activation tile per (channel chunk, tap) -- 36 tiles of 32 KiB per row tile for a quarter of a full tile's MFMAs: it
+// is bound by operand staging (863 MB of L2 -> LDS traffic for a 98 MB input, 131 us).  Here the three horizontal taps of a
+// kernel row read ONE band of 256 + 2 consecutive canvas positions (tap (r, s) of position m is position m + (r - 1) Wp + s - 1:
+// band row = tile row + s), staged once per (chunk, kernel row): 12 bands of 33 KiB instead of 36 tiles.  Two band buffers + two
+// buffers of the band's three weight tiles (24 KiB); one band ahead by LDS-DMA, counted vmcnt, two barriers per band; 8 waves of
+// 32 rows x 64 columns, 48 MFMAs (16x16x32) per wave and band.  Same products in another order than the tile kernel (kernel
+// row outer): results agree to f32 summation order.
+// (a band is CONV_BM + 2 = 258 positions)
+constexpr int BAND_BYTES = (CONV_BM + 8) * 128;                   // 264 rows of 64 channels: pieces are whole 8-row groups
+constexpr int BANDW_BYTES = 3 * 64 * 128;                         // the band's three taps: 64 weight rows x 64 channels each
+constexpr int BAND_LDS = 2 * BAND_BYTES + 2 * BANDW_BYTES;        // 116 736 bytes
+
+template <int DT>
+__global__ __launch_bounds__(CONV_THREADS) void conv3x3_band_narrow_kernel(const ConvArgs args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t m0 = (int64_t)blockIdx.x * CONV_BM, M = args.M;
+    const int Wp = args.Wp, cpt = args.Cin / CONV_BK, NB = 3 * cpt;
+    const int n0 = args.n_base;
+    const uint16_t *__restrict__ X = args.Xs[0], *__restrict__ Wt = args.Ws[0];
+    const LevelRegs lregs = level_regs(args.lv);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+
+    rn::f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0f;
+
+    // fragment addresses: band row of (tile row, tap column s) = row + s
+    uint32_t a_off[3][2][2], b_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int chunk = ks * 4 + (lane >> 4);
+#pragma unroll
+        for (int sft = 0; sft < 3; ++sft)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int row = wave * 32 + mi * 16 + (lane & 15) + sft;
+                a_off[sft][mi][ks] = row * 128 + ((chunk ^ SWZ(row)) << 4);
+            }
+        { const int row = lane & 15; b_off[ks] = row * 128 + ((chunk ^ SWZ(row)) << 4); }
+    }
+
+    auto stage = [&](const int b) {                                // band b and its three weight tiles -> buffers b & 1
+        const int c0 = (b / 3) * CONV_BK, r = b % 3;
+        const int64_t p0 = m0 + (int64_t)(r - 1) * Wp - 1;         // canvas position of band row 0
+        unsigned char *const ab = lds + (b & 1) * BAND_BYTES, *const wb = lds + 2 * BAND_BYTES + (b & 1) * BANDW_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = i * CONV_THREADS + tid, j = q >> 3, cp = q & 7;
+            int64_t p = p0 + j;
+            p = p < 0 ? 0 : (p >= M ? M - 1 : p);                    // (only border / gap outputs see a clamped row; they are never stored)
+            const uint16_t *g = X + p * args.Cin + c0 + ((cp ^ SWZ(j)) << 3);
+            __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)(ab + i * (CONV_THREADS * 16) + wave * (RN_WAVE * 16)), 16, 0, 0);
+        }
+        if (wave == 0) {                                            // band rows 256 .. 263 (257 is the last one read)
+            const int j = 256 + (lane >> 3), cp = lane & 7;
+            int64_t p = p0 + j;
+            p = p < 0 ? 0 : (p >= M ? M - 1 : p);
+            const uint16_t *g = X + p * args.Cin + c0 + ((cp ^ SWZ(j)) << 3);
+            __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)(ab + 4 * (CONV_THREADS * 16)), 16, 0, 0);
+        }
+#pragma unroll
+        for (int sft = 0; sft < 3; ++sft) {
+            const int row = tid >> 3, cp = tid & 7, t = 3 * r + sft;
+            const uint16_t *g = (n0 + row < args.Cout) ? Wt + ((int64_t)(n0 + row) * 9 + t) * args.Cin + c0 + ((cp ^ SWZ(row)) << 3)
+                                                       : args.zeros + ((cp ^ SWZ(row)) << 3);
+            __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)(wb + sft * 8192 + wave * (RN_WAVE * 16)), 16, 0, 0);
+        }
+    };
+
+    typename rn::mma<DT>::frag fa[2], fb[4];
+#define RN_DS_READ(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+    stage(0);
+    for (int b = 0; b < NB; ++b) {
+        if (b + 1 < NB) {
+            stage(b + 1);
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // band b's pieces are older than the 8 (7) just issued
+            else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        const uint32_t aband = lds_base + (uint32_t)((b & 1) * BAND_BYTES), wband = lds_base + (uint32_t)(2 * BAND_BYTES + (b & 1) * BANDW_BYTES);
+#pragma unroll
+        for (int sft = 0; sft < 3; ++sft)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint32_t ba = wband + (uint32_t)(sft * 8192) + b_off[ks];
+                RN_DS_READ(fb[0], ba, 0); RN_DS_READ(fb[1], ba, 2048); RN_DS_READ(fb[2], ba, 4096); RN_DS_READ(fb[3], ba, 6144);
+                RN_DS_READ(fa[0], aband + a_off[sft][0][ks], 0); RN_DS_READ(fa[1], aband + a_off[sft][1][ks], 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = rn::mma<DT>::m16(fa[mi], fb[ni], acc[mi][ni]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        __builtin_amdgcn_s_barrier();                               // buffers b & 1 are free for band b + 2
+    }
+#undef RN_DS_READ
+
+    // ---- epilogue (the tile kernel's TO_LEVELS / NARROW form): bias, 16-bit tile in LDS, dense per-level rows
+    __syncthreads();
+    uint16_t *Ys = (uint16_t *)lds;                               // [256][64]
+    uint16_t **Yrow = (uint16_t **)(lds + CONV_BM * 64 * 2);
+    const float *bias = args.biases[0];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int col = ni * 16 + (lane & 15);
+            const float bv = (bias && n0 + col < args.Cout) ? bias[n0 + col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wave * 32 + mi * 16 + 4 * (lane >> 4) + r;
+                Ys[row * 64 + col] = rn::mma<DT>::dn(acc[mi][ni][r] + bv);
+            }
+        }
+    if (tid < CONV_BM) {
+        const int64_t m = m0 + tid;
+        uint16_t *dst = nullptr;
+        if (m < M) {
+            int n, pos;
+            sheet_coords((int)m, (int)args.HWp, n, pos);
+            dst = level_row(args.lv, lregs, n, args.lv.map[pos]);
+        }
+        Yrow[tid] = dst;
+    }
+    __syncthreads();
+    const int ncols = min(64, args.Cout - n0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = i * CONV_THREADS + tid, row = q >> 3, piece = q & 7;
+        uint16_t *dst = Yrow[row];
+        if (dst && piece * 8 < ncols) {
+            const uint16_t *src = Ys + row * 64 + piece * 8;
+            dst += n0 + piece * 8;
+            if (piece * 8 + 8 <= ncols) {
+                const rn::u32x4 v = *(const rn::u32x4 *)src;
+                asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(v) : "memory");
+            } else {
+                for (int e = 0; e < ncols - piece * 8; e += 2) *(uint32_t *)(dst + e) = *(const uint32_t *)(src + e);
+            }
+        }
+    }
+}
 
 // ================================================================================================================
 // Weight gradient of the same convolution: dW[n][t][c] = sum_m G[m][n] * X[m + off_t][c]   (G = gradient at the conv
@@ -1322,6 +1484,19 @@ RN_API int rn_conv3x3_canvas_to_levels(const void *x, const void *w, const float
             if (rc2 != RN_OK) return rc2;
         }
         a.n_base = full * CONV_BN;
+        if (BAND_NARROW_FWD) {
+            static rn::DynLdsOptIn opt_bf = {}, opt_f = {};
+            hipStream_t st = (hipStream_t)stream;
+            if (a.f16) {
+                const int rc3 = opt_f.ensure((const void *)conv3x3_band_narrow_kernel<RN_F16>, BAND_LDS); if (rc3 != RN_OK) return rc3;
+                hipLaunchKernelGGL(conv3x3_band_narrow_kernel<RN_F16>, dim3(tiles_m), dim3(CONV_THREADS), BAND_LDS, st, a);
+            } else {
+                const int rc3 = opt_bf.ensure((const void *)conv3x3_band_narrow_kernel<RN_BF16>, BAND_LDS); if (rc3 != RN_OK) return rc3;
+                hipLaunchKernelGGL(conv3x3_band_narrow_kernel<RN_BF16>, dim3(tiles_m), dim3(CONV_THREADS), BAND_LDS, st, a);
+            }
+            RN_LAUNCH_CHECK();
+            return RN_OK;
+        }
         return conv_launch_mode<MODE_TO_LEVELS, true>(a, dim3(tiles_m, 1, 1), (hipStream_t)stream);
     }
     const dim3 grid(tiles_m, (unsigned)((Cout + CONV_BN - 1) / CONV_BN), 1);
@@ -1386,6 +1561,7 @@ RN_API int rn_conv3x3_levels_to_canvas_relu(const void *const *gs, const rn_canv
 #ifndef WGRAD_XCD_MAP
 #define WGRAD_XCD_MAP 1
 #endif
+
 // Position splits of the weight-gradient kernels: one workgroup per (split, tap, problem), about one wave of the chip.
 static int wgrad_splits(const int P, const int64_t M, int *tiles_per_split)
 {
