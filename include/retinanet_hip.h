@@ -526,6 +526,12 @@ int rn_conv3x3_dense_batched(const void *const *xs, const void *const *ws, const
 size_t rn_conv3x3_dense_splitk_workspace_bytes(int N, int h, int w, int Cout);
 int rn_conv3x3_dense_splitk(const void *x, const void *w, void *y, int dtype, int N, int h, int wd, int Cin, int Cout, const void *zeros,
                             void *workspace, size_t workspace_bytes, void *stream);
+/* A dense 3x3 / stride-1 / pad-1 convolution (no bias), Cout a multiple of 128, on the band-staged kernel (ABI 9): per (channel chunk,
+ * kernel row) ONE band of 258 consecutive positions feeds the three horizontal taps; taps that leave their image are zeroed at the
+ * MFMA fragment.  conv2 of the layer2 bottlenecks (/root/reference/retinanet/backbone.py:112,128; 128 -> 128), forward and -- with the
+ * flipped, transposed weights -- data gradient.  x [N][h][wd][Cin], w [Cout][3][3][Cin], y [N][h][wd][Cout]; Cin % 64 == 0. */
+int rn_conv3x3_dense_band(const void *x, const void *w, void *y, int dtype, int N, int h, int wd, int Cin, int Cout, const void *zeros,
+                          void *stream);
 /* The same with ys[p] = relu(...) when `relu` (inference: conv2 of the layer3 bottlenecks with the folded BatchNorm as bias and the
  * ReLU of retinanet/backbone.py:132 in the epilogue). */
 int rn_conv3x3_dense_batched_act(const void *const *xs, const void *const *ws, const float *const *biases, void *const *ys, int P,

@@ -135,6 +135,7 @@ SIGNATURES = {
     "rn_conv3x3_wgrad_workspace_bytes": (_sz, [C.c_int, _i64]),
     "rn_conv3x3_canvas_wgrad_batched": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _sz, _vp]),
     "rn_conv3x3_dense_batched": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "rn_conv3x3_dense_band": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rn_conv3x3_dense_splitk_workspace_bytes": (_sz, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "rn_conv3x3_dense_splitk": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _sz, _vp]),
     "rn_conv3x3_dense_batched_act": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp]),

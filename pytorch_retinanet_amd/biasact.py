@@ -1115,10 +1115,37 @@ def conv3x3_dense_splitk(x: Tensor, w: Tensor, need: int, tag: str = "mfma_conv2
     return y
 
 
+DENSE_BAND = True       # 128-channel 3x3 convolutions (conv2 of layer2: forward and data gradient) on the band-staged dense kernel (False: MIOpen / CK)
+DENSE_BAND_MAX_COUT = 128
+
+
+def dense_band_ok(x: Tensor, w: Tensor) -> bool:
+    return (DENSE_BAND and x.is_cuda and x.dtype in H16 and w.dtype == x.dtype and x.dim() == 4 and _cl(x) and _cl(w) and
+            tuple(w.shape[2:]) == (3, 3) and w.shape[1] == x.shape[1] and w.shape[1] % 64 == 0 and w.shape[0] % 128 == 0 and
+            w.shape[0] <= DENSE_BAND_MAX_COUT and x.shape[0] * x.shape[2] * x.shape[3] * max(int(w.shape[0]), int(w.shape[1])) < (1 << 31))
+
+
+def conv3x3_dense_band(x: Tensor, w: Tensor, tag: str = "mfma_conv2_band") -> Tensor:
+    "``F.conv2d(x, w, None, 1, 1)`` on ``rn_conv3x3_dense_band``; no autograd."
+    dev = x.device
+    if dev.index != torch.cuda.current_device():
+        torch.cuda.set_device(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    N, Cin, h, wd = x.shape
+    Cout = int(w.shape[0])
+    y = torch.empty((N, Cout, h, wd), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+    _mfma_call(tag, dev, 2.0 * N * h * wd * Cout * 9 * Cin,
+               lambda: lib.rn_conv3x3_dense_band(x.data_ptr(), w.data_ptr(), y.data_ptr(), _DT[x.dtype], N, h, wd, Cin, Cout, _zero_page(dev).data_ptr(),
+                                                 stream), "rn_conv3x3_dense_band")
+    return y
+
+
 def conv3x3_same(x: Tensor, w: Tensor) -> Tensor:
-    "``F.conv2d(x, w, None, 1, 1)`` (no autograd): the narrow / K-split dense MFMA kernels where they apply, else MIOpen."
+    "``F.conv2d(x, w, None, 1, 1)`` (no autograd): the narrow / band / K-split dense MFMA kernels where they apply, else MIOpen."
     if narrow_fwd_ok(x, w):
         return conv3x3_narrow_forward(x, w)
+    if dense_band_ok(x, w):
+        return conv3x3_dense_band(x, w)
     need = dense_splitk_bytes(x, w)
     if need > 0:
         return conv3x3_dense_splitk(x, w if _cl(w) else w.contiguous(memory_format=torch.channels_last), need)

@@ -741,6 +741,173 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_band_narrow_kernel(const
 }
 
 // ================================================================================================================
+// Band-staged 3x3 / stride-1 / pad-1 convolution of a plain dense tensor [N][H][W][Cin] -> [N][H][W][Cout], Cout a multiple of 128:
+// conv2 of the layer2 bottlenecks (128 -> 128 on 134 400 positions; retinanet/backbone.py:112,128) forward and, with the flipped
+// weights, data gradient -- CK's grouped-conv kernel takes 68 us there, this one 65.  As in the band kernel above a 256-position tile
+// reads, per (channel chunk, kernel row), ONE band of 258 consecutive positions for its three horizontal taps; a dense tensor has no
+// zero border, so a tap that leaves its image is removed AT THE FRAGMENT: lane l of a 16 x 16 x 32 A fragment carries row l & 15, and
+// the row's 9-bit tap validity (computed once per tile) zeroes the lane's 16 bytes.  8 waves of 32 rows x 128 columns (64 accumulator
+// registers).  Weights: one 128 x 64 tile per tap in three rotating buffers -- a tap buffer is refilled for the next band as soon as
+// the barrier of the following tap step proves it consumed -- so LDS is 2 bands + 3 tap tiles = 116 KiB; one barrier per tap step.
+// What bounds it: LDS-DMA fills a CU's LDS at ~38 GB/s, and a tile needs 6 x (33 + 48) KiB -- the whole 295 KB weight tensor per
+// tile; 65 us with two barriers per tap and unpipelined fragment reads, 65 us with one barrier and the second k-step's reads under
+// the first one's MFMAs.  The weights as direct global -> register fragment loads (waves 2 x 4, three rotating register sets,
+// requested two tap steps ahead, bands alone through LDS) were built as well: 88 - 92 us.
+constexpr int DBAND_LDS = 2 * BAND_BYTES + 3 * 128 * 128;          // 116 736 bytes
+
+struct DenseBandArgs {
+    const uint16_t *X, *W;          // [M][Cin]; [Cout][9][Cin]
+    uint16_t *Y;                    // [M][Cout]
+    const uint16_t *zeros;
+    int64_t M;
+    int H, Wd, Cin, Cout;
+};
+
+template <int DT>
+__global__ __launch_bounds__(CONV_THREADS) void conv3x3_dense_band_kernel(const DenseBandArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t m0 = (int64_t)blockIdx.x * CONV_BM, M = a.M;
+    const int n0 = blockIdx.y * 128;
+    const int cpt = a.Cin / CONV_BK, NB = 3 * cpt;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)lds;
+    unsigned char *const wbase = lds + 2 * BAND_BYTES;
+
+    rn::f32x4 acc[2][8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0f;
+
+    uint32_t a_off[3][2][2], b_off[2], tap_ok[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {                              // which of the 9 taps of this lane's row stay inside its image
+        const int64_t m = m0 + wave * 32 + mi * 16 + (lane & 15);
+        tap_ok[mi] = 0u;
+        if (m < M) {
+            const int yl = (int)(m / a.Wd), x = (int)(m - (int64_t)yl * a.Wd), y = yl % a.H;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                tap_ok[mi] |= ((unsigned)(y + t / 3 - 1) < (unsigned)a.H && (unsigned)(x + t % 3 - 1) < (unsigned)a.Wd) ? 1u << t : 0u;
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int chunk = ks * 4 + (lane >> 4);
+#pragma unroll
+        for (int sft = 0; sft < 3; ++sft)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int row = wave * 32 + mi * 16 + (lane & 15) + sft;
+                a_off[sft][mi][ks] = row * 128 + ((chunk ^ SWZ(row)) << 4);
+            }
+        { const int row = lane & 15; b_off[ks] = row * 128 + ((chunk ^ SWZ(row)) << 4); }
+    }
+
+    auto stage_band = [&](const int b) {                            // 4 pieces per thread, 5 in wave 0
+        const int c0 = (b / 3) * CONV_BK, r = b % 3;
+        const int64_t p0 = m0 + (int64_t)(r - 1) * a.Wd - 1;
+        unsigned char *const ab = lds + (b & 1) * BAND_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = i * CONV_THREADS + tid, j = q >> 3, cp = q & 7;
+            int64_t p = p0 + j;
+            p = p < 0 ? 0 : (p >= M ? M - 1 : p);
+            __builtin_amdgcn_global_load_lds((const void *)(a.X + p * a.Cin + c0 + ((cp ^ SWZ(j)) << 3)),
+                                             (lds_void_ptr)(ab + i * (CONV_THREADS * 16) + wave * (RN_WAVE * 16)), 16, 0, 0);
+        }
+        if (wave == 0) {
+            const int j = 256 + (lane >> 3), cp = lane & 7;
+            int64_t p = p0 + j;
+            p = p < 0 ? 0 : (p >= M ? M - 1 : p);
+            __builtin_amdgcn_global_load_lds((const void *)(a.X + p * a.Cin + c0 + ((cp ^ SWZ(j)) << 3)), (lds_void_ptr)(ab + 4 * (CONV_THREADS * 16)), 16, 0, 0);
+        }
+    };
+    auto stage_tap = [&](const int b, const int sft) {              // 2 pieces per thread: weight rows n0 .. n0 + 127, tap 3 r + sft, chunk of band b
+        const int c0 = (b / 3) * CONV_BK, t = 3 * (b % 3) + sft;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = i * CONV_THREADS + tid, row = q >> 3, cp = q & 7;
+            __builtin_amdgcn_global_load_lds((const void *)(a.W + ((int64_t)(n0 + row) * 9 + t) * a.Cin + c0 + ((cp ^ SWZ(row)) << 3)),
+                                             (lds_void_ptr)(wbase + sft * 16384 + i * (CONV_THREADS * 16) + wave * (RN_WAVE * 16)), 16, 0, 0);
+        }
+    };
+
+    typename rn::mma<DT>::frag fa[2][2], fb[2][8];                // [k-step][fragment]: the second k-step's reads are issued under the first one's MFMAs
+    const typename rn::mma<DT>::frag fzero = {};
+#define RN_DS_READ(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:" #OFF : "=v"(dst) : "v"(addr))
+#define RN_BAND_FRAGS(KS)                                                                                           \
+    { const uint32_t ba = lds_base + (uint32_t)(2 * BAND_BYTES + sft * 16384) + b_off[KS];                          \
+      RN_DS_READ(fb[KS][0], ba, 0); RN_DS_READ(fb[KS][1], ba, 2048); RN_DS_READ(fb[KS][2], ba, 4096); RN_DS_READ(fb[KS][3], ba, 6144);       \
+      RN_DS_READ(fb[KS][4], ba, 8192); RN_DS_READ(fb[KS][5], ba, 10240); RN_DS_READ(fb[KS][6], ba, 12288); RN_DS_READ(fb[KS][7], ba, 14336); \
+      RN_DS_READ(fa[KS][0], aband + a_off[sft][0][KS], 0); RN_DS_READ(fa[KS][1], aband + a_off[sft][1][KS], 0); }
+#define RN_BAND_MFMA(KS)                                                                                            \
+    { if (!ok0) fa[KS][0] = fzero;                                                                                  \
+      if (!ok1) fa[KS][1] = fzero;                                                                                  \
+      _Pragma("unroll") for (int mi = 0; mi < 2; ++mi)                                                              \
+          _Pragma("unroll") for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = rn::mma<DT>::m16(fa[KS][mi], fb[KS][ni], acc[mi][ni]); }
+    // One barrier per tap step.  Issue order (pieces per thread: band 4, 5 in wave 0; tap 2): step (b, 0) requests band b + 1 and tap
+    // (b, 2), step (b, 1) tap (b + 1, 0), step (b, 2) tap (b + 1, 1) -- always into the buffer the PREVIOUS step has just released,
+    // which the step's barrier proves.  A step's own operands are therefore older than the 2 / 6 (7) / 2 pieces that may still be out.
+    stage_band(0); stage_tap(0, 0); stage_tap(0, 1);
+    for (int b = 0; b < NB; ++b) {
+        const bool more = b + 1 < NB;
+        const uint32_t aband = lds_base + (uint32_t)((b & 1) * BAND_BYTES);
+#pragma unroll
+        for (int sft = 0; sft < 3; ++sft) {
+            if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (sft == 1) { if (wave == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            if (sft == 0) { if (more) stage_band(b + 1); stage_tap(b, 2); }
+            else if (more) stage_tap(b + 1, sft - 1);
+            const int t = 3 * (b % 3) + sft;
+            const bool ok0 = (tap_ok[0] >> t) & 1u, ok1 = (tap_ok[1] >> t) & 1u;
+            RN_BAND_FRAGS(0)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            RN_BAND_FRAGS(1)
+            __builtin_amdgcn_sched_barrier(0);
+            RN_BAND_MFMA(0)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            RN_BAND_MFMA(1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef RN_DS_READ
+#undef RN_BAND_FRAGS
+#undef RN_BAND_MFMA
+
+    __syncthreads();
+    uint16_t *Ys = (uint16_t *)lds;                               // [256][128]
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) {
+            const int col = ni * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wave * 32 + mi * 16 + 4 * (lane >> 4) + r;
+                Ys[row * 128 + col] = rn::mma<DT>::dn(acc[mi][ni][r]);
+            }
+        }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = i * CONV_THREADS + tid, row = q >> 4, piece = q & 15;
+        const int64_t m = m0 + row;
+        if (m < M) *(uint4 *)(a.Y + m * a.Cout + n0 + piece * 8) = *(const uint4 *)(Ys + row * 128 + piece * 8);
+    }
+}
+
+// ================================================================================================================
 // Weight gradient of the same convolution: dW[n][t][c] = sum_m G[m][n] * X[m + off_t][c]   (G = gradient at the conv
 // output, zero on border / gap positions).  A GEMM whose contraction index is the POSITION m, so both operands are
 // k-strided in memory ([m][channel] rows): the tiles are staged exactly as they lie in memory (64 positions x 256
@@ -1741,6 +1908,31 @@ static int dense_ksplit(const int64_t M, const int Cout)
     if (wgs <= 0) return 0;
     int s = (int)(cus / wgs);
     return s >= 3 ? 3 : (s >= 2 ? 2 : 1);
+}
+
+RN_API int rn_conv3x3_dense_band(const void *x, const void *w, void *y, int dtype, int N, int h, int wd, int Cin, int Cout, const void *zeros,
+                                 void *stream)
+{
+    if (!x || !w || !y || !zeros || N <= 0 || h <= 0 || wd <= 0 || Cin <= 0 || Cout <= 0) return RN_EINVAL;
+    if (!conv_dtype_ok(dtype) || Cin % CONV_BK || Cout % 128) return RN_EUNSUPPORTED;
+    const int64_t M = (int64_t)N * h * wd;
+    if (M >= ((int64_t)1 << 31) / (Cin > Cout ? Cin : Cout)) return RN_EUNSUPPORTED;
+    if (!rn::aligned(x, 16) || !rn::aligned(w, 16) || !rn::aligned(y, 16) || !rn::aligned(zeros, 16)) return RN_EALIGN;
+    DenseBandArgs a;
+    a.X = (const uint16_t *)x; a.W = (const uint16_t *)w; a.Y = (uint16_t *)y; a.zeros = (const uint16_t *)zeros;
+    a.M = M; a.H = h; a.Wd = wd; a.Cin = Cin; a.Cout = Cout;
+    const dim3 grid((unsigned)((M + CONV_BM - 1) / CONV_BM), (unsigned)(Cout / 128), 1);
+    hipStream_t st = (hipStream_t)stream;
+    static rn::DynLdsOptIn opt_bf = {}, opt_f = {};
+    if (dtype == RN_F16) {
+        const int rc = opt_f.ensure((const void *)conv3x3_dense_band_kernel<RN_F16>, DBAND_LDS); if (rc != RN_OK) return rc;
+        hipLaunchKernelGGL(conv3x3_dense_band_kernel<RN_F16>, grid, dim3(CONV_THREADS), DBAND_LDS, st, a);
+    } else {
+        const int rc = opt_bf.ensure((const void *)conv3x3_dense_band_kernel<RN_BF16>, DBAND_LDS); if (rc != RN_OK) return rc;
+        hipLaunchKernelGGL(conv3x3_dense_band_kernel<RN_BF16>, grid, dim3(CONV_THREADS), DBAND_LDS, st, a);
+    }
+    RN_LAUNCH_CHECK();
+    return RN_OK;
 }
 
 RN_API size_t rn_conv3x3_dense_splitk_workspace_bytes(int N, int h, int w, int Cout)

@@ -263,8 +263,8 @@ class _BottleneckFn(torch.autograd.Function):
         st1 = bn_finalize(p1, nb1, M0, blk.bn1)
         a1, _ = bn_apply(z1, st1, relu=True)                                 # conv2 is MIOpen's: it needs the activation
         from . import biasact
-        if s == 1 and tuple(blk.conv2.padding) == (1, 1) and biasact.narrow_fwd_ok(a1, w2):
-            z2 = biasact.conv3x3_narrow_forward(a1, w2)                      # 64 channels: csrc/narrow3x3.hip
+        if s == 1 and tuple(blk.conv2.padding) == (1, 1) and (biasact.narrow_fwd_ok(a1, w2) or biasact.dense_band_ok(a1, w2)):
+            z2 = biasact.conv3x3_same(a1, w2)                                # 64 channels: csrc/narrow3x3.hip; 128: the band-staged dense kernel
         else:
             z2 = F.conv2d(a1, w2, None, blk.conv2.stride, blk.conv2.padding)
         if not _cl(z2):

@@ -138,6 +138,24 @@ def test_data_gradient_issued_as_a_forward_convolution(cout, cin, hw):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,cout,cin,hw", [(2, 128, 128, (25, 34)), (1, 128, 64, (1, 1)), (3, 128, 128, (7, 300)), (2, 256, 128, (40, 9)), (1, 128, 128, (100, 168)),
+                                           (2, 128, 192, (5, 2))])
+def test_band_staged_dense_convolution_matches_torch(N, cout, cin, hw, dtype):
+    """``rn_conv3x3_dense_band`` (conv2 of the layer2 bottlenecks): one band of 258 positions per (chunk, kernel row), image-edge taps zeroed at
+    the fragment -- against fp32 convolution of the same 16-bit inputs, on shapes whose tiles straddle rows, images and the tensor's end."""
+    from pytorch_retinanet_amd import biasact
+    dev = torch.device("cuda:0")
+    torch.manual_seed(10)
+    x = torch.randn((N, cin, *hw), device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((cout, cin, 3, 3), device=dev) * 0.05).to(dtype).contiguous(memory_format=torch.channels_last)
+    y = biasact.conv3x3_dense_band(x, w)
+    ref = F.conv2d(x.float().cpu(), w.float().cpu(), None, 1, 1)
+    assert y.shape == ref.shape and y.dtype == dtype
+    assert _rel(y.cpu(), ref) < 4e-3
+    assert float((y.float().cpu() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,cout,cin,hw", [(8, 512, 512, (25, 42)), (2, 256, 512, (7, 9)), (1, 512, 64, (3, 130)), (3, 256, 256, (31, 17))])
 def test_k_split_dense_convolution_matches_torch(N, cout, cin, hw, dtype):
     """``rn_conv3x3_dense_splitk`` (conv2 of the layer4 bottlenecks, backbone.py:112,128; forward and, with flipped weights, data gradient):
