@@ -391,6 +391,7 @@ struct WgArgs {
     int M, N, Cin, taps, stride, pad, Ho, Wo, H, W_;
     int S, tiles_per_split;         // K-tiles of 64 positions per split
     int f16;                        // host side: fp16 elements (kernel instantiation)
+    int xcd_tiles;                  // > 0: 1-D grid of 8 * ceil(S / 8) * xcd_tiles workgroups, a split's tiles on one XCD (see the kernel)
 };
 
 template <int W> __device__ __forceinline__ int tr_swz(const int row) { return W >= 128 ? ((row & 3) << 2) : (((row >> 1) & 1) << 2); }
@@ -406,9 +407,17 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_wgrad_kernel(const WgArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // [G | X]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int split = blockIdx.x;
     const int tiles_k = a.Cin / TK, tiles_n = a.N / TN;
-    int t = blockIdx.y;
+    int split = blockIdx.x, t = blockIdx.y;
+    if (a.xcd_tiles > 0) {
+        // 1-D grid placed by XCD (workgroups go round-robin over the 8 XCDs): all tiles of a position split run on ONE XCD, next to each
+        // other in time, so that the split's G and X rows -- re-read once per column / row tile: 275 MB for 86 MB of operands at the
+        // layer3 shapes -- come out of that XCD's L2 after the first touch.  XCD x walks splits x, x + 8, ...
+        const int L = blockIdx.x, w = L >> 3;
+        split = (L & 7) + 8 * (w / a.xcd_tiles);
+        t = w % a.xcd_tiles;
+        if (split >= a.S) return;
+    }
     const int tk = t % tiles_k; t /= tiles_k;
     const int tn = t % tiles_n; t /= tiles_n;
     const int tap = t;
@@ -1319,12 +1328,20 @@ template <int BN, int PRO> int dispatch_epi(const PwArgs &a, const int epi, hipS
     }
 }
 
+#ifndef PW_WGRAD_XCD_MAP
+#define PW_WGRAD_XCD_MAP 1
+#endif
 template <int DT, int TN, int TK, int PROG, int PROX> int launch_wgrad_dt(const WgArgs &a, hipStream_t st)
 {
     constexpr int lds = 64 * (TN + TK) * 2;
     static rn::DynLdsOptIn opt_in = {};
     { const int rc = opt_in.ensure((const void *)pw_wgrad_kernel<DT, TN, TK, PROG, PROX>, lds); if (rc != RN_OK) return rc; }
     const unsigned gy = (unsigned)((a.N / TN) * (a.Cin / TK) * a.taps);
+    if (PW_WGRAD_XCD_MAP && gy >= 2 && gy <= 64 && a.S >= 8) {
+        WgArgs b = a;
+        b.xcd_tiles = (int)gy;
+        hipLaunchKernelGGL((pw_wgrad_kernel<DT, TN, TK, PROG, PROX>), dim3(8u * (unsigned)((a.S + 7) / 8) * gy), dim3(PW_THREADS), lds, st, b);
+    } else
     hipLaunchKernelGGL((pw_wgrad_kernel<DT, TN, TK, PROG, PROX>), dim3((unsigned)a.S, gy), dim3(PW_THREADS), lds, st, a);
     RN_LAUNCH_CHECK();
     return RN_OK;
