@@ -185,6 +185,11 @@ struct ConvArgs {
     // -- conv2 of the layer4 bottlenecks: 8 400 positions, 66 workgroups of 72 K-tiles -- fills the chip with 3 x 66 of 24)
     int ksplit;
     float *kpartial;
+    // xcd_ny > 0 (set by conv_launch_dt): a 1-D grid in x placed by XCD (workgroups go round-robin over the 8 XCDs: XCD = blockIdx.x % 8).
+    // XCD c runs the CONSECUTIVE row tiles c * xcd_q + min(c, xcd_r) .. (xcd_q + (c < xcd_r) of them) with their xcd_ny column tiles next
+    // to each other in time: the column tiles of a row tile read the same input rows, and a row tile's upper / lower taps are its
+    // neighbours' centre rows, so an XCD's L2 takes an input line once instead of three XCDs fetching it each.
+    int xcd_ny, xcd_q, xcd_r;
 };
 struct ConvProblem { const uint16_t *X, *W; const float *bias; uint16_t *Y; };
 
@@ -197,14 +202,20 @@ template <int DT, int MODE, bool NARROW = false>
 __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const ConvArgs args)
 {
     constexpr int MI = NARROW ? 1 : 4;                            // 32-row accumulator tiles per wave
-    int prob = blockIdx.z;
-    int64_t m0 = (int64_t)blockIdx.x * CONV_BM, M = args.M, HWp = args.HWp;
+    int prob = blockIdx.z, bx = blockIdx.x, by = blockIdx.y;
+    if (args.xcd_ny > 0) {
+        const int xcd = bx & 7, w = bx >> 3, mt = w / args.xcd_ny;
+        by = w - mt * args.xcd_ny;
+        if (mt >= args.xcd_q + (xcd < args.xcd_r)) return;
+        bx = xcd * args.xcd_q + (xcd < args.xcd_r ? xcd : args.xcd_r) + mt;
+    }
+    int64_t m0 = (int64_t)bx * CONV_BM, M = args.M, HWp = args.HWp;
     int Wp = args.Wp, dense_h = 0;
     if (MODE == MODE_DENSE) {                                     // blockIdx.x walks the problems' row tiles one after the other
         prob = 0;
 #pragma unroll
-        for (int p = 1; p < CONV_MAX_PROBLEMS; ++p) prob = (int)blockIdx.x >= args.dn.tile_beg[p] ? p : prob;
-        m0 = (int64_t)((int)blockIdx.x - args.dn.tile_beg[prob]) * CONV_BM;
+        for (int p = 1; p < CONV_MAX_PROBLEMS; ++p) prob = bx >= args.dn.tile_beg[p] ? p : prob;
+        m0 = (int64_t)(bx - args.dn.tile_beg[prob]) * CONV_BM;
         M = args.dn.M[prob]; Wp = args.dn.w[prob]; dense_h = args.dn.h[prob]; HWp = (int64_t)Wp * dense_h;
     }
     ConvProblem a;
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // wave-uniform: LDS-DMA bases and wave roles live in SGPRs
     const int wm = NARROW ? wave : wave >> 2, wn = NARROW ? 0 : wave & 3;
     const int grp = wave >> 2;                                    // ping-pong group: waves 0-3 / 4-7 (one wave of each per SIMD)
-    const int n0 = blockIdx.y * CONV_BN + args.n_base;
+    const int n0 = by * CONV_BN + args.n_base;
     const int cpt = args.Cin / CONV_BK, KT_ALL = 9 * cpt;
     int kt0 = 0, KT = KT_ALL;                                     // this workgroup's K-tiles: kt0 .. kt0 + KT - 1 of the walk
     if (MODE == MODE_DENSE && args.ksplit > 1) {
@@ -575,7 +586,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
                 float t = 0.0f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) t += s_cs[r * CONV_BN + tid];
-                args.colsums[prob][(int64_t)blockIdx.x * args.Cout + n0 + tid] = t;
+                args.colsums[prob][(int64_t)bx * args.Cout + n0 + tid] = t;
             }
         }
     }
@@ -1408,12 +1419,21 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restr
 
 }  // namespace
 
+#ifndef CONV_XCD_MAP
+#define CONV_XCD_MAP 1
+#endif
 template <int DT, int MODE, bool NARROW>
 static int conv_launch_dt(const ConvArgs &a, const dim3 grid, hipStream_t st)
 {
     // 160 KiB of dynamic LDS needs the opt-in once per device (the attribute lives with the device's code object)
     static rn::DynLdsOptIn opt_in = {};
     { const int rc = opt_in.ensure((const void *)conv3x3_canvas_kernel<DT, MODE, NARROW>, CONV_LDS_BYTES); if (rc != RN_OK) return rc; }
+    if (CONV_XCD_MAP && grid.x >= 16) {
+        ConvArgs b = a;
+        b.xcd_ny = (int)grid.y; b.xcd_q = (int)(grid.x / 8); b.xcd_r = (int)(grid.x % 8);
+        hipLaunchKernelGGL((conv3x3_canvas_kernel<DT, MODE, NARROW>), dim3(8u * (unsigned)(b.xcd_q + (b.xcd_r > 0)) * grid.y, 1, grid.z), dim3(CONV_THREADS),
+                           CONV_LDS_BYTES, st, b);
+    } else
     hipLaunchKernelGGL((conv3x3_canvas_kernel<DT, MODE, NARROW>), grid, dim3(CONV_THREADS), CONV_LDS_BYTES, st, a);
     RN_LAUNCH_CHECK();
     return RN_OK;
