@@ -532,6 +532,13 @@ int rn_conv3x3_dense_splitk(const void *x, const void *w, void *y, int dtype, in
  * flipped, transposed weights -- data gradient.  x [N][h][wd][Cin], w [Cout][3][3][Cin], y [N][h][wd][Cout]; Cin % 64 == 0. */
 int rn_conv3x3_dense_band(const void *x, const void *w, void *y, int dtype, int N, int h, int wd, int Cin, int Cout, const void *zeros,
                           void *stream);
+/* The same with the per-channel sums of the output AS STORED in the epilogue (no second pass over y): partial f32 [tiles][2][Cout] =
+ * (sum y, sum y^2) per 256-position row tile, tiles = rn_conv3x3_dense_band_tiles(N, h, wd) -- what rn_bn_stats' first launch computes;
+ * rn_bn_stats_finalize(partial, tiles, N*h*wd, ..) completes the statistics of the BatchNorm after the convolution (bn2 of a
+ * bottleneck, /root/reference/retinanet/backbone.py:129).  y is bit-identical to rn_conv3x3_dense_band's. */
+int rn_conv3x3_dense_band_tiles(int N, int h, int wd);
+int rn_conv3x3_dense_band_stats(const void *x, const void *w, void *y, float *partial, int dtype, int N, int h, int wd, int Cin, int Cout,
+                                const void *zeros, void *stream);
 /* The same with ys[p] = relu(...) when `relu` (inference: conv2 of the layer3 bottlenecks with the folded BatchNorm as bias and the
  * ReLU of retinanet/backbone.py:132 in the epilogue). */
 int rn_conv3x3_dense_batched_act(const void *const *xs, const void *const *ws, const float *const *biases, void *const *ys, int P,

@@ -136,6 +136,8 @@ SIGNATURES = {
     "rn_conv3x3_canvas_wgrad_batched": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _i64, C.c_int, C.c_int, C.c_int, _vp, _vp, _sz, _vp]),
     "rn_conv3x3_dense_batched": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "rn_conv3x3_dense_band": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "rn_conv3x3_dense_band_tiles": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "rn_conv3x3_dense_band_stats": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rn_conv3x3_dense_splitk_workspace_bytes": (_sz, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "rn_conv3x3_dense_splitk": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _sz, _vp]),
     "rn_conv3x3_dense_batched_act": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, C.c_int, _vp]),

@@ -1140,6 +1140,27 @@ def conv3x3_dense_band(x: Tensor, w: Tensor, tag: str = "mfma_conv2_band") -> Te
     return y
 
 
+DENSE_BAND_STATS = True   # ... with the statistics of the BatchNorm that follows (bn2 of the layer2 blocks) in its epilogue
+
+
+def conv3x3_dense_band_stats(x: Tensor, w: Tensor, tag: str = "mfma_conv2_band"):
+    """``conv3x3_dense_band`` + (sum y, sum y^2) per channel of the stored output, no second pass over it -> (y, partial f32
+    [tiles, 2, Cout], tiles) for ``rn_bn_stats_finalize``."""
+    dev = x.device
+    if dev.index != torch.cuda.current_device():
+        torch.cuda.set_device(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    N, Cin, h, wd = x.shape
+    Cout = int(w.shape[0])
+    tiles = int(lib.rn_conv3x3_dense_band_tiles(N, h, wd))
+    y = torch.empty((N, Cout, h, wd), dtype=x.dtype, device=dev, memory_format=torch.channels_last)
+    partial = torch.empty((tiles * 2 * Cout,), dtype=torch.float32, device=dev)
+    _mfma_call(tag, dev, 2.0 * N * h * wd * Cout * 9 * Cin,
+               lambda: lib.rn_conv3x3_dense_band_stats(x.data_ptr(), w.data_ptr(), y.data_ptr(), partial.data_ptr(), _DT[x.dtype], N, h, wd, Cin, Cout,
+                                                       _zero_page(dev).data_ptr(), stream), "rn_conv3x3_dense_band_stats")
+    return y, partial, tiles
+
+
 def conv3x3_same(x: Tensor, w: Tensor) -> Tensor:
     "``F.conv2d(x, w, None, 1, 1)`` (no autograd): the narrow / band / K-split dense MFMA kernels where they apply, else MIOpen."
     if narrow_fwd_ok(x, w):

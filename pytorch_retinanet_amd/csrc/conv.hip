@@ -772,6 +772,11 @@ struct DenseBandArgs {
     const uint16_t *zeros;
     int64_t M;
     int H, Wd, Cin, Cout;
+    // partial != nullptr: the per-channel sums (sum y, sum y^2) of the tile AS STORED ride in the epilogue, partial f32 [row tiles][2][Cout] --
+    // the statistics pass of the BatchNorm that follows the convolution (bn2 of a bottleneck).  (The two BatchNorm-BACKWARD sums of the
+    // layer in front, for the data-gradient launch, were built the same way -- Z tile and constants prefetched before the walk -- and cost
+    // as much as the pass they replace: 15 us of VALU work per launch that nothing overlaps with one workgroup per CU.  Removed.)
+    float *partial;
 };
 
 template <int DT>
@@ -910,11 +915,37 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_dense_band_kernel(const 
             }
         }
     __syncthreads();
+    const int piece = tid & 15, rt = tid >> 4;                    // thread = 8 columns of rows rt, rt + 32, ..
+    float cs[8], cq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { cs[j] = 0.0f; cq[j] = 0.0f; }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int q = i * CONV_THREADS + tid, row = q >> 4, piece = q & 15;
+        const int row = i * 32 + rt;
         const int64_t m = m0 + row;
-        if (m < M) *(uint4 *)(a.Y + m * a.Cout + n0 + piece * 8) = *(const uint4 *)(Ys + row * 128 + piece * 8);
+        if (m < M) {
+            const rn::u32x4 v = *(const rn::u32x4 *)(Ys + row * 128 + piece * 8);
+            *(rn::u32x4 *)(a.Y + m * a.Cout + n0 + piece * 8) = v;
+            if (a.partial) {
+                float y[8];
+                rn::dt<DT>::unpack(v, y);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { cs[j] += y[j]; cq[j] = fmaf(y[j], y[j], cq[j]); }
+            }
+        }
+    }
+    if (a.partial) {                                              // 32 row threads per column -> one partial row per tile (fixed order)
+        float *red = (float *)(lds + 65536);                      // [32][2][128] f32 behind the staged tile
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[(rt * 2 + 0) * 128 + piece * 8 + j] = cs[j]; red[(rt * 2 + 1) * 128 + piece * 8 + j] = cq[j]; }
+        __syncthreads();
+        if (tid < 256) {
+            const int which = tid >> 7, c = tid & 127;
+            float t = 0.0f;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) t += red[(r * 2 + which) * 128 + c];
+            a.partial[((int64_t)blockIdx.x * 2 + which) * a.Cout + n0 + c] = t;
+        }
     }
 }
 
@@ -1930,8 +1961,8 @@ static int dense_ksplit(const int64_t M, const int Cout)
     return s >= 3 ? 3 : (s >= 2 ? 2 : 1);
 }
 
-RN_API int rn_conv3x3_dense_band(const void *x, const void *w, void *y, int dtype, int N, int h, int wd, int Cin, int Cout, const void *zeros,
-                                 void *stream)
+static int dense_band_launch(const void *x, const void *w, void *y, float *partial, int dtype, int N, int h, int wd, int Cin, int Cout,
+                             const void *zeros, void *stream)
 {
     if (!x || !w || !y || !zeros || N <= 0 || h <= 0 || wd <= 0 || Cin <= 0 || Cout <= 0) return RN_EINVAL;
     if (!conv_dtype_ok(dtype) || Cin % CONV_BK || Cout % 128) return RN_EUNSUPPORTED;
@@ -1940,7 +1971,7 @@ RN_API int rn_conv3x3_dense_band(const void *x, const void *w, void *y, int dtyp
     if (!rn::aligned(x, 16) || !rn::aligned(w, 16) || !rn::aligned(y, 16) || !rn::aligned(zeros, 16)) return RN_EALIGN;
     DenseBandArgs a;
     a.X = (const uint16_t *)x; a.W = (const uint16_t *)w; a.Y = (uint16_t *)y; a.zeros = (const uint16_t *)zeros;
-    a.M = M; a.H = h; a.Wd = wd; a.Cin = Cin; a.Cout = Cout;
+    a.M = M; a.H = h; a.Wd = wd; a.Cin = Cin; a.Cout = Cout; a.partial = partial;
     const dim3 grid((unsigned)((M + CONV_BM - 1) / CONV_BM), (unsigned)(Cout / 128), 1);
     hipStream_t st = (hipStream_t)stream;
     static rn::DynLdsOptIn opt_bf = {}, opt_f = {};
@@ -1953,6 +1984,23 @@ RN_API int rn_conv3x3_dense_band(const void *x, const void *w, void *y, int dtyp
     }
     RN_LAUNCH_CHECK();
     return RN_OK;
+}
+
+RN_API int rn_conv3x3_dense_band(const void *x, const void *w, void *y, int dtype, int N, int h, int wd, int Cin, int Cout, const void *zeros,
+                                 void *stream)
+{
+    return dense_band_launch(x, w, y, nullptr, dtype, N, h, wd, Cin, Cout, zeros, stream);
+}
+RN_API int rn_conv3x3_dense_band_tiles(int N, int h, int wd)
+{
+    if (N <= 0 || h <= 0 || wd <= 0) return 0;
+    return (int)(((int64_t)N * h * wd + CONV_BM - 1) / CONV_BM);
+}
+RN_API int rn_conv3x3_dense_band_stats(const void *x, const void *w, void *y, float *partial, int dtype, int N, int h, int wd, int Cin, int Cout,
+                                       const void *zeros, void *stream)
+{
+    if (!partial) return RN_EINVAL;
+    return dense_band_launch(x, w, y, partial, dtype, N, h, wd, Cin, Cout, zeros, stream);
 }
 
 RN_API size_t rn_conv3x3_dense_splitk_workspace_bytes(int N, int h, int w, int Cout)

@@ -263,13 +263,19 @@ class _BottleneckFn(torch.autograd.Function):
         st1 = bn_finalize(p1, nb1, M0, blk.bn1)
         a1, _ = bn_apply(z1, st1, relu=True)                                 # conv2 is MIOpen's: it needs the activation
         from . import biasact
-        if s == 1 and tuple(blk.conv2.padding) == (1, 1) and (biasact.narrow_fwd_ok(a1, w2) or biasact.dense_band_ok(a1, w2)):
-            z2 = biasact.conv3x3_same(a1, w2)                                # 64 channels: csrc/narrow3x3.hip; 128: the band-staged dense kernel
+        st2 = None
+        if s == 1 and tuple(blk.conv2.padding) == (1, 1) and biasact.DENSE_BAND_STATS and not biasact.narrow_fwd_ok(a1, w2) and biasact.dense_band_ok(a1, w2):
+            # 128 channels: the band-staged dense kernel, bn2's statistics in its epilogue
+            z2, pp2, nbb2 = biasact.conv3x3_dense_band_stats(a1, w2)
+            st2 = bn_finalize(pp2, nbb2, z2.shape[0] * z2.shape[2] * z2.shape[3], blk.bn2)
+        elif s == 1 and tuple(blk.conv2.padding) == (1, 1) and (biasact.narrow_fwd_ok(a1, w2) or biasact.dense_band_ok(a1, w2)):
+            z2 = biasact.conv3x3_same(a1, w2)                                # 64 channels: csrc/narrow3x3.hip
         else:
             z2 = F.conv2d(a1, w2, None, blk.conv2.stride, blk.conv2.padding)
         if not _cl(z2):
             z2 = z2.contiguous(memory_format=torch.channels_last)
-        st2 = bn_stats(z2, blk.bn2)
+        if st2 is None:
+            st2 = bn_stats(z2, blk.bn2)
         M1 = z2.shape[0] * z2.shape[2] * z2.shape[3]
         # conv3: relu(bn2(z2)) in the operand load, bn3 statistics in the epilogue
         Cm = w2.shape[0]

@@ -156,6 +156,38 @@ def test_band_staged_dense_convolution_matches_torch(N, cout, cin, hw, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,hw", [(2, (50, 84)), (3, (9, 30)), (1, (1, 300)), (1, (2, 2))])
+def test_band_staged_dense_convolution_with_statistics_in_the_epilogue(N, hw, dtype):
+    """``rn_conv3x3_dense_band_stats``: the output is bit-identical to the plain launch and the per-tile partial sums finalize to what
+    ``rn_bn_stats`` gives over the stored output (mean | invstd | a | b, running statistics)."""
+    from pytorch_retinanet_amd import biasact, pwconv
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    Cc = 128
+    M = N * hw[0] * hw[1]
+    x = torch.randn((N, Cc, *hw), device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((Cc, Cc, 3, 3), device=dev) * 0.05).to(dtype).contiguous(memory_format=torch.channels_last)
+    y0 = biasact.conv3x3_dense_band(x, w)
+    bn = nn.BatchNorm2d(Cc).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(Cc, device=dev) + 0.5)
+        bn.bias.copy_(torch.randn(Cc, device=dev) * 0.1)
+    y1, part, tiles = biasact.conv3x3_dense_band_stats(x, w)
+    assert torch.equal(y1, y0) and tiles == (M + 255) // 256 and part.numel() == tiles * 2 * Cc
+    bn_a = nn.BatchNorm2d(Cc).to(dev)
+    bn_a.load_state_dict(bn.state_dict())
+    bn_b = nn.BatchNorm2d(Cc).to(dev)
+    bn_b.load_state_dict(bn.state_dict())
+    got = pwconv.bn_finalize(part, tiles, M, bn_a)
+    want = pwconv.bn_stats(y0, bn_b)
+    torch.cuda.synchronize()
+    assert torch.allclose(got, want, rtol=2e-5, atol=2e-6), float((got - want).abs().max())
+    assert torch.allclose(bn_a.running_mean, bn_b.running_mean, rtol=2e-5, atol=1e-7)
+    assert torch.allclose(bn_a.running_var, bn_b.running_var, rtol=2e-5, atol=1e-7)
+    assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,cout,cin,hw", [(8, 512, 512, (25, 42)), (2, 256, 512, (7, 9)), (1, 512, 64, (3, 130)), (3, 256, 256, (31, 17))])
 def test_k_split_dense_convolution_matches_torch(N, cout, cin, hw, dtype):
     """``rn_conv3x3_dense_splitk`` (conv2 of the layer4 bottlenecks, backbone.py:112,128; forward and, with flipped weights, data gradient):
