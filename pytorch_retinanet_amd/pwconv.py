@@ -654,10 +654,13 @@ class _Conv1x1(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+DOWN_WGRAD_PW = True      # weight gradient of the unfused blocks' 1x1 / stride-2 downsample convs on pw_wgrad_kernel (False: MIOpen + its zero fill + cast)
+
+
 class _Conv1x1S2(torch.autograd.Function):
     """A 1x1 / stride-2 convolution without bias (the downsample branch of layer2 .. layer4's first blocks): MIOpen forward; the data
     gradient is a GEMM on the OUTPUT grid (hipBLASLt) that stays compact when a `_GradJoin` receiver will add it at its pixels; the
-    weight gradient stays on MIOpen."""
+    weight gradient is csrc/pw.hip's (``DOWN_WGRAD_PW``)."""
 
     @staticmethod
     def forward(ctx, x, w, join):
@@ -684,7 +687,10 @@ class _Conv1x1S2(torch.autograd.Function):
                 dx = torch.empty_like(x).fill_(0)
                 dx[:, :, ::2, ::2] = comp
         if ctx.needs_input_grad[1]:
-            dw = torch.ops.aten.convolution_backward(g, x, w, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+            if DOWN_WGRAD_PW and x.shape[1] % 64 == 0 and Cout % 64 == 0 and _cl(x):
+                dw = pw_wgrad(g, x, w, stride=2, tag="pw_down_wgrad")       # csrc/pw.hip: rows of x picked at stride 2 in the operand load
+            else:
+                dw = torch.ops.aten.convolution_backward(g, x, w, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
         return dx, dw, None
 
 
