@@ -403,6 +403,9 @@ class _BottleneckFn(torch.autograd.Function):
             # stride 1: the data gradient as a forward convolution with the flipped weights (CK's forward kernel, no zero fill)
             da1 = biasact.conv3x3_dgrad_as_fwd(dz2, w2)
             dw2 = biasact.conv3x3_weight_gradient(dz2, a1, w2)
+        elif STRIDED_WGRAD_PW and tuple(blk.conv2.stride) == (2, 2) and tuple(blk.conv2.padding) == (1, 1) and _cl(w2):
+            da1 = torch.ops.aten.convolution_backward(dz2, a1, w2, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+            dw2 = pw_wgrad(dz2, a1, w2, stride=2, tag="pw_conv2_s2_wgrad")
         else:
             da1, dw2 = torch.ops.aten.convolution_backward(dz2, a1, w2, None, list(blk.conv2.stride), list(blk.conv2.padding), [1, 1], False,
                                                            [0, 0], 1, [True, True, False])[:2]
@@ -654,6 +657,7 @@ class _Conv1x1(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+STRIDED_WGRAD_PW = True   # weight gradient of the 3x3 / stride-2 conv2 of layer2's .. layer4's first blocks on pw_wgrad_kernel (taps = 9; False: MIOpen)
 DOWN_WGRAD_PW = True      # weight gradient of the unfused blocks' 1x1 / stride-2 downsample convs on pw_wgrad_kernel (False: MIOpen + its zero fill + cast)
 
 
@@ -694,6 +698,29 @@ class _Conv1x1S2(torch.autograd.Function):
         return dx, dw, None
 
 
+class _Conv3x3S2(torch.autograd.Function):
+    """A 3x3 / stride-2 / pad-1 convolution without bias (conv2 of layer3's / layer4's first blocks, retinanet/backbone.py:112,128):
+    MIOpen forward and data gradient; the weight gradient on csrc/pw.hip's position-contraction kernel (taps = 9, the rows of x picked at
+    stride 2 in the operand load) instead of MIOpen's kernel + zero fill + cast."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return F.conv2d(x, w, None, 2, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        if g.dtype != x.dtype or not _cl(g):
+            g = g.to(x.dtype).contiguous(memory_format=torch.channels_last)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.aten.convolution_backward(g, x, w, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            dw = pw_wgrad(g, x, w if _cl(w) else w.contiguous(memory_format=torch.channels_last), stride=2, tag="pw_conv2_s2_wgrad")
+        return dx, dw
+
+
 def conv1x1(conv, x: Tensor) -> Tensor:
     """``conv(x)`` for a 1x1 / stride-1 ``nn.Conv2d`` on bf16 channels-last activations with every product on the fastest of
     MIOpen / hipBLASLt / csrc/pw.hip (``_Conv1x1``); anything else is ``conv(x)``."""
@@ -711,6 +738,10 @@ def conv1x1(conv, x: Tensor) -> Tensor:
             and conv.out_channels % 64 == 0 and torch.is_grad_enabled() and x.requires_grad and getattr(x, "_rn_join", None) is not None
             and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 24)):
         return _Conv1x1S2.apply(x, w, x._rn_join)          # a stride-2 consumer of a tensor that already has a receiver
+    if (STRIDED_WGRAD_PW and x.is_cuda and x.dtype in H16 and w.dtype == x.dtype and _cl(x) and conv.kernel_size == (3, 3) and conv.stride == (2, 2)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and conv.in_channels % 64 == 0
+            and conv.out_channels % 64 == 0 and torch.is_grad_enabled() and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 24)):
+        return _Conv3x3S2.apply(x, w)
     from . import biasact
     if biasact.conv3x3_bwd_fusable(conv, x):        # 3x3 / 256 -> 256 (layer3's conv2): MIOpen forward, gradients on csrc/conv.hip
         return biasact.conv3x3_mfma_bwd(conv, x)
