@@ -69,7 +69,11 @@ class FeaturePyramid(nn.Module):
         ``torch.cuda.synchronize()`` scale the losses by 1 / garbage; ``tests/test_graph_gpu.py``).  The captured step holds no memset
         node any more."""
         if x.is_cuda and conv.bias is not None and conv.bias.dtype == torch.float32 and torch.is_grad_enabled() and conv.bias.requires_grad:
-            y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+            from . import pwconv
+            if pwconv.conv3x3_s2_ok(conv, x, bias_ok=True):
+                y = pwconv._Conv3x3S2.apply(x, conv.weight)          # P6 / P7: weight gradient on csrc/pw.hip
+            else:
+                y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
             if biasact.fusable(y, conv.bias):
                 return biasact.bias_act(y, conv.bias, None, relu=False)
             return y + conv.bias.to(y.dtype)[None, :, None, None]

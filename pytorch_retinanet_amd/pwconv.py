@@ -721,6 +721,14 @@ class _Conv3x3S2(torch.autograd.Function):
         return dx, dw
 
 
+def conv3x3_s2_ok(conv, x: Tensor, bias_ok: bool = False) -> bool:
+    "``_Conv3x3S2`` applies (``bias_ok``: the caller adds the bias itself)."
+    w = conv.weight
+    return (STRIDED_WGRAD_PW and x.is_cuda and x.dtype in H16 and w.dtype == x.dtype and _cl(x) and conv.kernel_size == (3, 3) and conv.stride == (2, 2)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and (bias_ok or conv.bias is None) and conv.in_channels % 64 == 0
+            and conv.out_channels % 64 == 0 and torch.is_grad_enabled() and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 24))
+
+
 def conv1x1(conv, x: Tensor) -> Tensor:
     """``conv(x)`` for a 1x1 / stride-1 ``nn.Conv2d`` on bf16 channels-last activations with every product on the fastest of
     MIOpen / hipBLASLt / csrc/pw.hip (``_Conv1x1``); anything else is ``conv(x)``."""
@@ -738,9 +746,7 @@ def conv1x1(conv, x: Tensor) -> Tensor:
             and conv.out_channels % 64 == 0 and torch.is_grad_enabled() and x.requires_grad and getattr(x, "_rn_join", None) is not None
             and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 24)):
         return _Conv1x1S2.apply(x, w, x._rn_join)          # a stride-2 consumer of a tensor that already has a receiver
-    if (STRIDED_WGRAD_PW and x.is_cuda and x.dtype in H16 and w.dtype == x.dtype and _cl(x) and conv.kernel_size == (3, 3) and conv.stride == (2, 2)
-            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and conv.in_channels % 64 == 0
-            and conv.out_channels % 64 == 0 and torch.is_grad_enabled() and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 24)):
+    if conv3x3_s2_ok(conv, x):
         return _Conv3x3S2.apply(x, w)
     from . import biasact
     if biasact.conv3x3_bwd_fusable(conv, x):        # 3x3 / 256 -> 256 (layer3's conv2): MIOpen forward, gradients on csrc/conv.hip

@@ -171,7 +171,7 @@ def test_data_gradient_joined_by_the_stride2_downsample_gradient(H, W, cm, cin):
 
 
 @pytest.mark.parametrize("n_out,cin,k,stride", [(64, 256, 1, 1), (256, 64, 1, 1), (128, 512, 1, 1), (512, 128, 1, 1), (64, 64, 3, 1), (128, 128, 3, 2),
-                                               (512, 256, 1, 2), (256, 1024, 1, 1), (2048, 512, 1, 1), (256, 256, 3, 2), (512, 512, 3, 2), (1024, 512, 1, 2)])
+                                               (512, 256, 1, 2), (256, 1024, 1, 1), (2048, 512, 1, 1), (256, 256, 3, 2), (512, 512, 3, 2), (1024, 512, 1, 2), (256, 2048, 3, 2)])
 def test_weight_gradient_plain(n_out, cin, k, stride):
     from pytorch_retinanet_amd import pwconv
     H, W = (21, 25) if n_out * cin < 512 * 512 else (9, 11)
