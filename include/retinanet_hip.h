@@ -494,6 +494,12 @@ int rn_conv3x3_canvas(const void *x, const void *w, const float *bias, const uin
 int rn_conv3x3_canvas_batched(const void *const *xs, const void *const *ws, const float *const *biases,
                               const uint8_t *mask, void *const *ys, int P, int dtype, int64_t M, int64_t HWp,
                               int Wp, int Cin, int Cout, int relu, void *stream);
+/* y = conv3x3(x, w[.., 0:C]) + conv3x3(x2, w[.., C:2C]) on the canvas in ONE accumulator (ABI 9): the contraction walks the C channels of x, then
+ * those of x2, against w [Cout][3][3][2 C] (no bias, no ReLU; `mask` as above).  The two head towers read the same FPN canvas in their
+ * first layer (/root/reference/retinanet/layers.py:163-167, 235-251), so its gradient is the SUM of their first-layer data gradients:
+ * this is that sum without the two separate outputs and autograd's add pass over them. */
+int rn_conv3x3_canvas_sum2(const void *x, const void *x2, const void *w, const uint8_t *mask, void *y, int dtype, int64_t M, int64_t HWp,
+                           int Wp, int C, int Cout, void *stream);
 
 /* Weight gradient of the canvas convolution for P <= 4 problems (256 -> 256 channels, bf16):
  *   dw[p][n][3][3][c] = sum_m g[p][m][n] * x[p][m + tap offset][c]

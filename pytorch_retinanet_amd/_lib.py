@@ -104,6 +104,7 @@ SIGNATURES = {
     "rn_bias_act_forward": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _i64, C.c_int, _i64, C.c_int, _vp]),
     "rn_bias_act_backward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _i64, C.c_int, _i64, C.c_int, _vp, _sz, _vp]),
     "rn_conv3x3_canvas": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, _i64, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "rn_conv3x3_canvas_sum2": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, _vp]),
     "rn_conv3x3_canvas_batched": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _i64, _i64, C.c_int, C.c_int, C.c_int,
                                             C.c_int, _vp]),
     "rn_maxpool3x3s2_forward": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),

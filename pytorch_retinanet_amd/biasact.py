@@ -185,6 +185,9 @@ def _ptr_array(ts):
     return (C.c_void_p * len(ts))(*[t.data_ptr() if t is not None else 0 for t in ts])
 
 
+TOWER_SUM2 = True        # first tower layer: the shared input's gradient as ONE two-source data-gradient launch (rn_conv3x3_canvas_sum2)
+
+
 class TowerLink:
     """Hand-over between consecutive ``_TowerConvPair`` layers of one tower pair in backward.  When layer l's inputs are the
     ReLU outputs of layer l - 1 and feed nothing else (``tower_conv_pair(..., prev=link)``), layer l's data-gradient kernel
@@ -273,8 +276,17 @@ class _TowerConvPair(torch.autograd.Function):
         dxs = [None, None]
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             wts = dgrad_weights([w0, w1], stream)                      # [Cin, Cout, 3, 3], taps reversed (the step's table, or one launch for both)
-            dxs = [torch.empty_like(x0), torch.empty_like(x1)]
-            if prev is not None and prev.relu_masks is not None and Cin == Cout:
+            same_input = (TOWER_SUM2 and x0.data_ptr() == x1.data_ptr() and tuple(x0.shape) == tuple(x1.shape) and x0.stride() == x1.stride()
+                          and not (prev is not None and prev.relu_masks is not None))
+            dxs = [torch.empty_like(x0), None if same_input else torch.empty_like(x1)]
+            if same_input:
+                # both towers read the SAME canvas (their first layer): its gradient is the sum of the two data gradients -- one launch whose
+                # contraction walks gs[0]'s channels, then gs[1]'s, against the two weights side by side; no second output, no add pass
+                wcat = torch.cat([wts[0], wts[1]], dim=1).contiguous(memory_format=torch.channels_last)
+                _mfma_call("mfma_tower_dgrad_x2", dev, 2 * 2.0 * _real_positions(N, Hp, Wp) * Cout * 9 * Cin,
+                           lambda: lib.rn_conv3x3_canvas_sum2(gs[0].data_ptr(), gs[1].data_ptr(), wcat.data_ptr(), mask.data_ptr(), dxs[0].data_ptr(),
+                                                              _DT[x0.dtype], M, Hp * Wp, Wp, Cout, Cin, stream), "rn_conv3x3_canvas_sum2")
+            elif prev is not None and prev.relu_masks is not None and Cin == Cout:
                 need = lib.rn_conv3x3_colsum_workspace_bytes(2, M, Cin)
                 key = (dev.index, stream)
                 wsb = _CS_WS.get(key)

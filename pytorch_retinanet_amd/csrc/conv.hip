@@ -190,6 +190,11 @@ struct ConvArgs {
     // to each other in time: the column tiles of a row tile read the same input rows, and a row tile's upper / lower taps are its
     // neighbours' centre rows, so an XCD's L2 takes an input line once instead of three XCDs fetching it each.
     int xcd_ny, xcd_q, xcd_r;
+    // MODE_CANVAS, x_split > 0: the contraction runs over TWO activation tensors of x_ld channels each -- channel chunks 0 .. x_split - 1 from
+    // Xs[p], the rest from X2s[p] -- against weights [Cout][9][Cin], Cin = both widths together: y = conv(x, w[.., :x_ld]) + conv(x2, w[.., x_ld:])
+    // in one accumulator (the two towers' first-layer data gradients, which autograd would add)
+    const uint16_t *X2s[CONV_MAX_PROBLEMS];
+    int x_split, x_ld;
 };
 struct ConvProblem { const uint16_t *X, *W; const float *bias; uint16_t *Y; };
 
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int q = i * CONV_THREADS + tid, row = q >> 3, cp = q & 7;
-        voff_a[i] = (uint32_t)(row * args.Cin + ((cp ^ SWZ(row)) << 3)) * 2u;
+        voff_a[i] = (uint32_t)(row * (MODE == MODE_CANVAS && args.x_split > 0 ? args.x_ld : args.Cin) + ((cp ^ SWZ(row)) << 3)) * 2u;
         voff_b[i] = (uint32_t)(row * 9 * args.Cin + ((cp ^ SWZ(row)) << 3)) * 2u;
     }
     const bool a_edge = m0 - (Wp + 1) < 0 || m0 + CONV_BM + Wp + 1 > M;             // wave-uniform
@@ -353,14 +358,22 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
                 const unsigned char *base = (const unsigned char *)a.X + ((m0 + off) * args.Cin + c0) * 2;
                 const void *src = (tap_ok[i] >> t) & 1u ? (const void *)(base + voff_a[i]) : (const void *)args.zeros;
                 __builtin_amdgcn_global_load_lds(src, (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
-            } else if (!a_edge) {
-                const unsigned char *base = (const unsigned char *)a.X + ((m0 + off) * args.Cin + c0) * 2;
-                __builtin_amdgcn_global_load_lds((const void *)(base + voff_a[i]), (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
             } else {
-                int64_t m = m0 + row + off;
-                m = m < 0 ? 0 : (m >= M ? M - 1 : m);
-                const uint16_t *g = a.X + m * args.Cin + c0 + ((cp ^ SWZ(row)) << 3);
-                __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
+                const uint16_t *X = a.X;
+                int ld = args.Cin, cs = c0;
+                if (MODE == MODE_CANVAS && args.x_split > 0) {             // (wave-uniform)
+                    ld = args.x_ld;
+                    if (w.chunk >= args.x_split) { X = args.X2s[prob]; cs = c0 - args.x_split * CONV_BK; }
+                }
+                if (!a_edge) {
+                    const unsigned char *base = (const unsigned char *)X + ((m0 + off) * ld + cs) * 2;
+                    __builtin_amdgcn_global_load_lds((const void *)(base + voff_a[i]), (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
+                } else {
+                    int64_t m = m0 + row + off;
+                    m = m < 0 ? 0 : (m >= M ? M - 1 : m);
+                    const uint16_t *g = X + m * ld + cs + ((cp ^ SWZ(row)) << 3);
+                    __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_ptr)lds_piece(sb, i), 16, 0, 0);
+                }
             }
         }
     };
@@ -1524,6 +1537,23 @@ RN_API int rn_conv3x3_canvas_batched_ex(const void *const *xs, const void *const
     }
     a.mask = mask; a.M = M; a.HWp = HWp; a.Cin = Cin; a.Cout = Cout; a.Wp = Wp; a.relu = relu ? 1 : 0; a.zeros = nullptr;
     const dim3 grid((unsigned)((M + CONV_BM - 1) / CONV_BM), (unsigned)(Cout / CONV_BN), (unsigned)P);
+    return conv_launch_mode<MODE_CANVAS>(a, grid, (hipStream_t)stream);
+}
+
+RN_API int rn_conv3x3_canvas_sum2(const void *x, const void *x2, const void *w, const uint8_t *mask, void *y, int dtype, int64_t M,
+                                  int64_t HWp, int Wp, int C, int Cout, void *stream)
+{
+    if (!x || !x2 || !w || !y || M <= 0 || HWp <= 0 || Wp <= 0 || C <= 0 || Cout <= 0) return RN_EINVAL;
+    if (!conv_dtype_ok(dtype) || C % CONV_BK || Cout % CONV_BN) return RN_EUNSUPPORTED;
+    if (!rn::aligned(x, 16) || !rn::aligned(x2, 16) || !rn::aligned(w, 16) || !rn::aligned(y, 16)) return RN_EALIGN;
+    ConvArgs a = {};
+    a.f16 = dtype == RN_F16;
+    for (int p = 0; p < CONV_MAX_PROBLEMS; ++p) {
+        a.Xs[p] = (const uint16_t *)x; a.X2s[p] = (const uint16_t *)x2; a.Ws[p] = (const uint16_t *)w; a.Ys[p] = (uint16_t *)y;
+    }
+    a.x_split = C / CONV_BK; a.x_ld = C;
+    a.mask = mask; a.M = M; a.HWp = HWp; a.Cin = 2 * C; a.Cout = Cout; a.Wp = Wp; a.relu = 0; a.zeros = nullptr;
+    const dim3 grid((unsigned)((M + CONV_BM - 1) / CONV_BM), (unsigned)(Cout / CONV_BN), 1);
     return conv_launch_mode<MODE_CANVAS>(a, grid, (hipStream_t)stream);
 }
 

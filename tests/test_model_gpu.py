@@ -526,6 +526,48 @@ def test_tower_relu_backward_fused_into_the_data_gradient_kernel(N, shapes):
             assert torch.equal(got2[1][l][k], ref2[1][l][k]), (l, k)
 
 
+@pytest.mark.parametrize("N,shapes", [(2, [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)]), (3, [(40, 31), (7, 9)])])
+def test_first_tower_layer_sums_both_data_gradients_in_one_launch(N, shapes):
+    """``rn_conv3x3_canvas_sum2``: both towers read the same canvas, so its gradient is dgrad(cls) + dgrad(box).  One launch with a two-source
+    contraction (f32 sum, one rounding) against the two-output launch + autograd's bf16 add, and against fp32 convolutions of the same values;
+    weight / bias gradients are untouched (bit-equal)."""
+    from pytorch_retinanet_amd import biasact
+    torch.manual_seed(4)
+    feats = [torch.randn(N, 256, h, w, device=DEV).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for h, w in shapes]
+    cv = biasact.Canvas.of(feats, pad=1)
+    ws = [(torch.randn(256, 256, 3, 3, device=DEV) * 0.02).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True) for _ in range(2)]
+    bs = [(torch.randn(256, device=DEV) * 0.1).requires_grad_(True) for _ in range(2)]
+    x0 = biasact.pack_levels(cv, feats)
+    g0, g1 = torch.randn_like(x0), torch.randn_like(x0)
+
+    def run(flag):
+        old = biasact.TOWER_SUM2
+        biasact.TOWER_SUM2 = flag
+        try:
+            x = x0.clone().requires_grad_(True)
+            for t in ws + bs:
+                t.grad = None
+            a, b = biasact.tower_conv_pair(x, x, ws[0], ws[1], bs[0], bs[1], cv.mask)
+            torch.autograd.backward([a, b], [g0, g1])
+            return x.grad.clone(), [w.grad.clone() for w in ws], [t.grad.clone() for t in bs], a.detach(), b.detach()
+        finally:
+            biasact.TOWER_SUM2 = old
+
+    one, two = run(True), run(False)
+    for k in range(2):
+        assert torch.equal(one[1][k], two[1][k]) and torch.equal(one[2][k], two[2][k])
+    # fp32 reference of the input gradient from the same 16-bit operands: g' = g * [y > 0] * mask, dx = sum of two transposed convolutions
+    m = cv.mask.view(1, 1, x0.shape[2], x0.shape[3]).float()
+    ref = torch.zeros_like(x0, dtype=torch.float32)
+    for g, y, w in ((g0, one[3], ws[0]), (g1, one[4], ws[1])):
+        gp = (g.float() * (y.float() > 0) * m).to(torch.bfloat16).float()
+        ref += torch.ops.aten.convolution_backward(gp, x0.float(), w.detach().float(), None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0]
+    ref = ref * m
+    rel = lambda t: float((t.float() - ref).norm() / ref.norm())
+    assert rel(one[0]) < 4e-3 and rel(one[0]) <= rel(two[0]) * 1.02, (rel(one[0]), rel(two[0]))
+    assert float((one[0].float() - two[0].float()).norm() / two[0].float().norm()) < 1e-2
+
+
 @pytest.mark.parametrize("N,K,shapes,slots", [(2, 6, [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)], 1),   # Cout = 54: one tile, 54 % 8 = 6
                                               (2, 6, [(16, 20), (8, 10), (4, 5), (2, 3), (1, 2)], 2),   # the same, both images on one sheet
                                               (1, 90, [(13, 17), (7, 9), (4, 5)], 1),                 # Cout = 810: 4 tiles, 810 % 8 = 2
