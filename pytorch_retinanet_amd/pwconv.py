@@ -540,8 +540,13 @@ def link_blocks(blocks) -> None:
 MM_1X1 = os.environ.get("RN_MM_1X1", "1") != "0"
 
 
-def _fwd_by_mm(M: int, cin: int, cout: int) -> bool:
-    return cin >= 1024 and M <= 40000
+BIAS_1X1_MM = True        # a 1x1 conv WITH bias and >= 512 input channels goes to hipBLASLt (bias in the GEMM's epilogue) at any size
+
+
+def _fwd_by_mm(M: int, cin: int, cout: int, has_bias: bool = False) -> bool:
+    # (the FPN's C3 lateral, 512 -> 256 on 134 400 positions with bias: MIOpen's kernel 66 us + a strided elementwise bias add over the
+    # output 30 us in the step; isolated: conv2d + bias 136 us, hipBLASLt addmm 63, pw_gemm_kernel with a bias epilogue 84)
+    return (cin >= 1024 and M <= 40000) or (BIAS_1X1_MM and has_bias and cin >= 512)
 
 
 def _dgrad_by_mm(M: int, cin: int, cout: int) -> bool:
@@ -606,7 +611,7 @@ class _Conv1x1(torch.autograd.Function):
         Nimg, Cin, H, W = x.shape
         Cout = w.shape[0]
         M = Nimg * H * W
-        if _fwd_by_mm(M, Cin, Cout):
+        if _fwd_by_mm(M, Cin, Cout, bias is not None):
             x2, w2 = x.permute(0, 2, 3, 1).reshape(M, Cin), w.reshape(Cout, Cin)
             y2 = torch.addmm(bias.to(x.dtype), x2, w2.t()) if bias is not None else x2 @ w2.t()
             y = y2.view(Nimg, H, W, Cout).permute(0, 3, 1, 2)

@@ -170,6 +170,36 @@ def test_data_gradient_joined_by_the_stride2_downsample_gradient(H, W, cm, cin):
         _close(dx.float(), ref, 1e-2, f"data gradient + stride-{sd} branch gradient")
 
 
+@pytest.mark.parametrize("shape,cout", [((2, 512, 25, 34), 256), ((1, 256, 9, 7), 256), ((3, 512, 13, 21), 128)])
+def test_1x1_with_bias_in_the_gemm_epilogue(shape, cout):
+    """``pwconv.conv1x1`` of a 1x1 convolution WITH bias (the FPN's C3 lateral, retinanet/layers.py:31): forward as one GEMM with the bias in its
+    epilogue (one rounding of conv + bias) instead of a convolution + an add pass; gradients as for every ``_Conv1x1`` -- against fp32."""
+    from pytorch_retinanet_amd import pwconv
+    torch.manual_seed(6)
+    conv = torch.nn.Conv2d(shape[1], cout, 1).to(DEV)
+    conv.weight.data = _cl(conv.weight.data.to(torch.bfloat16))
+    torch.nn.init.normal_(conv.bias, std=0.5)
+    x = _rand(shape, 1.0, 1).requires_grad_(True)
+    g = _rand((shape[0], cout, shape[2], shape[3]), 1.0, 2)
+    outs = {}
+    for flag in (True, False):
+        pwconv.BIAS_1X1_MM = flag
+        try:
+            x.grad = None
+            conv.zero_grad()
+            y = pwconv.conv1x1(conv, x)
+            y.backward(g)
+            outs[flag] = (y.detach().clone(), x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone())
+        finally:
+            pwconv.BIAS_1X1_MM = True
+    ref = F.conv2d(x.detach().float(), conv.weight.detach().float(), conv.bias.detach().float())
+    _close(outs[True][0], ref, 6e-3, "1x1 + bias forward")
+    err = lambda t: float((t.float() - ref).norm())
+    assert err(outs[True][0]) <= err(outs[False][0]) * 1.05, (err(outs[True][0]), err(outs[False][0]))      # one rounding instead of two
+    for k, what in ((1, "dx"), (2, "dw"), (3, "dbias")):            # the gradients do not depend on who ran the forward
+        _close(outs[True][k], outs[False][k], 1e-3, what)
+
+
 @pytest.mark.parametrize("n_out,cin,k,stride", [(64, 256, 1, 1), (256, 64, 1, 1), (128, 512, 1, 1), (512, 128, 1, 1), (64, 64, 3, 1), (128, 128, 3, 2),
                                                (512, 256, 1, 2), (256, 1024, 1, 1), (2048, 512, 1, 1), (256, 256, 3, 2), (512, 512, 3, 2), (1024, 512, 1, 2), (256, 2048, 3, 2)])
 def test_weight_gradient_plain(n_out, cin, k, stride):
