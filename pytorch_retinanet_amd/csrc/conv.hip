@@ -436,6 +436,32 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     if (grp == 1) __builtin_amdgcn_s_barrier();                    // group 1 runs one barrier interval behind group 0
 
 
+    // The epilogue's per-column bias, requested here -- K-tile 0 has landed, the walk is about to start; these loads are younger than the
+    // staged pieces and older than every piece issued in the loop, so the loop's first counted wait retires them under K-tile 0's MFMAs.
+    // (Fetched after the walk their latency is on every tile's tail; issued before the FIRST pieces they delay the prologue by 2.6 us.)
+    float bias_pre[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int col = wn * 64 + ni * 16 + (lane & 15);
+        bias_pre[ni] = (a.bias && (MODE != MODE_TO_LEVELS || n0 + col < args.Cout)) ? a.bias[n0 + col] : 0.0f;
+    }
+    // ... and the keep-mask bytes of the 16 rows this thread will store (row i * 16 + (tid >> 5)).  Read one by one inside the store loop they
+    // were 16 dependent L2 round trips on every tile's tail (5.4 us of a 79 us tile, in-kernel stamps); the tile's position on its sheet
+    // is a 32-bit modulo here (the 64-bit one is a ~3 us software division per tile).
+    uint32_t keep[16];                                              // (one register each: packed into bytes the compiler waits for every load in turn)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) keep[i] = 1;
+    if (MODE != MODE_TO_LEVELS && args.mask) {
+        const int64_t pos0 = (int64_t)((uint32_t)m0 % (uint32_t)HWp);       // (host: M < 2^31; a 64-bit modulo is a ~3 us software division)
+        const bool one_wrap = HWp >= CONV_BM;                      // the tile crosses at most one sheet boundary
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = i * 16 + (tid >> 5);
+            int64_t pos = pos0 + row;
+            if (one_wrap) pos = pos >= HWp ? pos - HWp : pos; else pos = (int64_t)((uint32_t)pos % (uint32_t)HWp);
+            keep[i] = args.mask[pos];                                 // (pos < HWp whatever the row: no branch, the 16 loads fly together; rows past M are not stored)
+        }
+    }
     int scur = 0;                                                   // A stage of K-tile kt (mod 3)
     for (int kt = 0; kt < KT; ++kt) {
         const uint32_t abase = lds_base + (uint32_t)(scur * TILE), bbase = lds_base + (uint32_t)(3 * TILE + (kt & 1) * TILE);
@@ -508,7 +534,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
             const int col = wn * 64 + ni * 16 + (lane & 15);          // 16 x 16 result tile: column = lane & 15, rows 4 (lane >> 4) + r
-            const float b = (a.bias && (MODE != MODE_TO_LEVELS || n0 + col < args.Cout)) ? a.bias[n0 + col] : 0.0f;
+            const float b = bias_pre[ni];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = wm * (32 * MI) + mi * 16 + 4 * (lane >> 4) + r;
@@ -549,22 +575,15 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
             }
         }
     } else {
-        // position of the tile's first row on its sheet: one scalar 64-bit modulo per tile, then 32-bit steps
-        const int64_t pos0 = m0 % HWp;
         uint8_t *rmask_out = MODE == MODE_TO_LEVELS ? nullptr : args.relu_mask_outs[prob];
         float cs[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        const bool one_wrap = HWp >= CONV_BM;                  // the tile crosses at most one sheet boundary
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int q = i * CONV_THREADS + tid, row = q >> 5, piece = q & 31;
             const int64_t m = m0 + row;
             if (m < M) {
                 uint4 v = *(const uint4 *)(Ys + row * CONV_BN + piece * 8);
-                if (args.mask) {
-                    int64_t pos = pos0 + row;
-                    if (one_wrap) pos = pos >= HWp ? pos - HWp : pos; else pos %= HWp;
-                    if (!args.mask[pos]) v = make_uint4(0, 0, 0, 0);
-                }
+                if (!keep[i]) v = make_uint4(0, 0, 0, 0);
                 if (relu_mask) {
                     const uint32_t bits = s_rmask[row * 32 + piece];
                     uint32_t vw[4] = {v.x, v.y, v.z, v.w};
@@ -1469,6 +1488,7 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restr
 template <int DT, int MODE, bool NARROW>
 static int conv_launch_dt(const ConvArgs &a, const dim3 grid, hipStream_t st)
 {
+    if (MODE != MODE_DENSE && (a.M >= ((int64_t)1 << 31) || a.HWp >= ((int64_t)1 << 31))) return RN_EUNSUPPORTED;      // 32-bit position arithmetic in the kernel
     // 160 KiB of dynamic LDS needs the opt-in once per device (the attribute lives with the device's code object)
     static rn::DynLdsOptIn opt_in = {};
     { const int rc = opt_in.ensure((const void *)conv3x3_canvas_kernel<DT, MODE, NARROW>, CONV_LDS_BYTES); if (rc != RN_OK) return rc; }
