@@ -296,3 +296,31 @@ def test_block_links_are_not_submodules_and_survive_copies():
     buf.seek(0)
     m3 = torch.load(buf, weights_only=False)
     assert m3.layer2[3].__dict__["_rn_next"][0] is m3.layer3[0]
+
+
+def test_round5_entry_points_reject_bad_arguments_before_any_gpu_call():
+    """Argument validation of the entry points round 5 added (include/retinanet_hip.h): null pointers, unsupported shapes and misaligned pointers are
+    refused with their error codes before a HIP call is made -- checked here, where there is no GPU."""
+    from pytorch_retinanet_amd._lib import lib
+    EINVAL, EALIGN, EUNSUP = -1, -2, -4
+    p = 4096                                                          # a 16-byte-aligned non-null "pointer": never dereferenced on these paths
+    # band-staged dense 3x3 (+ statistics partials)
+    assert lib.rn_conv3x3_dense_band(0, p, p, 1, 1, 8, 8, 128, 128, p, 0) == EINVAL
+    assert lib.rn_conv3x3_dense_band(p, p, p, 1, 1, 8, 8, 96, 128, p, 0) == EUNSUP          # Cin % 64
+    assert lib.rn_conv3x3_dense_band(p, p, p, 1, 1, 8, 8, 128, 192, p, 0) == EUNSUP         # Cout % 128
+    assert lib.rn_conv3x3_dense_band(p + 2, p, p, 1, 1, 8, 8, 128, 128, p, 0) == EALIGN
+    assert lib.rn_conv3x3_dense_band_stats(p, p, p, 0, 1, 1, 8, 8, 128, 128, p, 0) == EINVAL  # no partial buffer
+    assert lib.rn_conv3x3_dense_band_tiles(8, 100, 168) == 525 and lib.rn_conv3x3_dense_band_tiles(0, 100, 168) == 0
+    # K-split dense 3x3: the workspace query says when a split does not help
+    assert lib.rn_conv3x3_dense_splitk_workspace_bytes(8, 25, 42, 512) > 0
+    assert lib.rn_conv3x3_dense_splitk_workspace_bytes(8, 50, 84, 256) == 0
+    assert lib.rn_conv3x3_dense_splitk(p, p, p, 1, 8, 25, 42, 512, 512, p, 0, 0, 0) == EINVAL
+    # the two-source data gradient of the first tower layer
+    assert lib.rn_conv3x3_canvas_sum2(p, 0, p, 0, p, 1, 1000, 500, 20, 256, 256, 0) == EINVAL
+    assert lib.rn_conv3x3_canvas_sum2(p, p, p, 0, p, 1, 1000, 500, 20, 96, 256, 0) == EUNSUP
+    assert lib.rn_conv3x3_canvas_sum2(p, p + 8, p, 0, p, 1, 1000, 500, 20, 256, 256, 0) == EALIGN
+    # the bottleneck seam kernels: walkers() == 0 outside their shapes
+    assert lib.rn_pw_conv3_backward_walkers(134400, 128, 512) > 0 and lib.rn_pw_conv3_backward_walkers(33600, 256, 1024) == 0
+    assert lib.rn_pw_block_out_conv1_walkers(537600, 256, 64) > 0 and lib.rn_pw_block_out_conv1_walkers(33600, 1024, 256) == 0
+    assert lib.rn_pw_dgrad_resid_sums_walkers(537600, 64, 256) > 0 and lib.rn_pw_dgrad_resid_sums_walkers(33600, 256, 1024) == 0
+    assert lib.rn_pw_conv3_forward_walkers(134400, 128, 512) > 0 and lib.rn_pw_conv3_forward_walkers(134400, 96, 512) == 0
