@@ -436,32 +436,33 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     if (grp == 1) __builtin_amdgcn_s_barrier();                    // group 1 runs one barrier interval behind group 0
 
 
-    // The epilogue's per-column bias, requested here -- K-tile 0 has landed, the walk is about to start; these loads are younger than the
-    // staged pieces and older than every piece issued in the loop, so the loop's first counted wait retires them under K-tile 0's MFMAs.
-    // (Fetched after the walk their latency is on every tile's tail; issued before the FIRST pieces they delay the prologue by 2.6 us.)
-    float bias_pre[4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int col = wn * 64 + ni * 16 + (lane & 15);
-        bias_pre[ni] = (a.bias && (MODE != MODE_TO_LEVELS || n0 + col < args.Cout)) ? a.bias[n0 + col] : 0.0f;
-    }
-    // ... and the keep-mask bytes of the 16 rows this thread will store (row i * 16 + (tid >> 5)).  Read one by one inside the store loop they
-    // were 16 dependent L2 round trips on every tile's tail (5.4 us of a 79 us tile, in-kernel stamps); the tile's position on its sheet
-    // is a 32-bit modulo here (the 64-bit one is a ~3 us software division per tile).
+    // The epilogue's per-column bias and the keep-mask bytes of the 16 rows this thread will store (row i * 16 + (tid >> 5)) are requested
+    // INSIDE the walk, in K-tile 0's first load phase: younger than the staged pieces, older than every later piece, so the next counted wait
+    // retires them under K-tile 0's MFMAs.  (In-kernel stamps, tools/probes: read inside the store loop the mask bytes were 16 dependent L2
+    // round trips -- 5.4 us of a 79 us tile; requested before the FIRST staged pieces they delay the prologue by 2.6 us, right before the walk
+    // by 0.9.  The tile's position on its sheet is a 32-bit modulo: the 64-bit one is a ~3 us software division per tile.)
+    float bias_pre[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     uint32_t keep[16];                                              // (one register each: packed into bytes the compiler waits for every load in turn)
 #pragma unroll
     for (int i = 0; i < 16; ++i) keep[i] = 1;
-    if (MODE != MODE_TO_LEVELS && args.mask) {
-        const int64_t pos0 = (int64_t)((uint32_t)m0 % (uint32_t)HWp);       // (host: M < 2^31; a 64-bit modulo is a ~3 us software division)
-        const bool one_wrap = HWp >= CONV_BM;                      // the tile crosses at most one sheet boundary
+    auto epilogue_prefetch = [&]() {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = i * 16 + (tid >> 5);
-            int64_t pos = pos0 + row;
-            if (one_wrap) pos = pos >= HWp ? pos - HWp : pos; else pos = (int64_t)((uint32_t)pos % (uint32_t)HWp);
-            keep[i] = args.mask[pos];                                 // (pos < HWp whatever the row: no branch, the 16 loads fly together; rows past M are not stored)
+        for (int ni = 0; ni < 4; ++ni) {
+            const int col = wn * 64 + ni * 16 + (lane & 15);
+            bias_pre[ni] = (a.bias && (MODE != MODE_TO_LEVELS || n0 + col < args.Cout)) ? a.bias[n0 + col] : 0.0f;
         }
-    }
+        if (MODE != MODE_TO_LEVELS && args.mask) {
+            const int64_t pos0 = (int64_t)((uint32_t)m0 % (uint32_t)HWp);       // (host: M < 2^31)
+            const bool one_wrap = HWp >= CONV_BM;                      // the tile crosses at most one sheet boundary
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = i * 16 + (tid >> 5);
+                int64_t pos = pos0 + row;
+                if (one_wrap) pos = pos >= HWp ? pos - HWp : pos; else pos = (int64_t)((uint32_t)pos % (uint32_t)HWp);
+                keep[i] = args.mask[pos];                             // (pos < HWp whatever the row: no branch, the 16 loads fly together; rows past M are not stored)
+            }
+        }
+    };
     int scur = 0;                                                   // A stage of K-tile kt (mod 3)
     for (int kt = 0; kt < KT; ++kt) {
         const uint32_t abase = lds_base + (uint32_t)(scur * TILE), bbase = lds_base + (uint32_t)(3 * TILE + (kt & 1) * TILE);
@@ -474,6 +475,7 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
             for (int i = 0; i < 4; ++i) piece_b(wb, (kt + 1) & 1, i);
             advance(wb);
         }
+        if (kt == 0) epilogue_prefetch();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         RN_MFMA_PHASE()
