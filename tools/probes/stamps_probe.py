@@ -14,14 +14,43 @@ x = biasact.pack_levels(cv, feats)
 ws = [(torch.randn(256, 256, 3, 3, device=dev) * 0.02).to(torch.bfloat16).contiguous(memory_format=torch.channels_last) for _ in range(2)]
 bs = [torch.randn(256, device=dev) * 0.1 for _ in range(2)]
 stamps = torch.zeros((8192, 12), dtype=torch.int64, device=dev)
-with torch.no_grad():
-    for _ in range(3):
-        biasact.tower_conv_pair(x, x, ws[0], ws[1], bs[0], bs[1], cv.mask)
-    torch.cuda.synchronize()
+import sys
+variant = sys.argv[1] if len(sys.argv) > 1 else "plain"
+ws2 = [(torch.randn(256, 256, 3, 3, device=dev) * 0.02).to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True) for _ in range(2)]
+bs2 = [(torch.randn(256, device=dev) * 0.1).requires_grad_(True) for _ in range(2)]
+
+
+def run_once(arm):
+    """plain: forward without ReLU bits (no grad).  fwd_bits: the forward of a linked layer (writes the ReLU bits of its output).
+    dgrad_relu: the data gradient of the layer above it (applies those bits, sums the columns for the bias gradient)."""
+    if variant == "plain":
+        with torch.no_grad():
+            if arm:
+                so.rn_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
+            biasact.tower_conv_pair(x, x, ws[0], ws[1], bs[0], bs[1], cv.mask)
+        return
+    link = biasact.TowerLink()
+    w0 = [w.detach().requires_grad_(True) for w in ws]
+    a, b = biasact.tower_conv_pair(x, x.clone(), w0[0], w0[1], bs2[0], bs2[1], cv.mask, None, link)      # layer 0: inputs need no gradient
+    if variant == "fwd_bits":
+        return                                                      # (the caller armed the stamps before: layer 0's forward is the last tile launch)
+    a2, b2 = biasact.tower_conv_pair(a, b, ws2[0], ws2[1], bs2[0], bs2[1], cv.mask, link, None)
+    loss = (a2.float().sum() + b2.float().sum())
+    if arm:
+        torch.cuda.synchronize()
+        so.rn_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
+    loss.backward()                                                 # tile launches in backward: layer 1's data gradient only (layer 0's inputs are leaves without grad)
+
+
+for _ in range(3):
+    run_once(False)
+torch.cuda.synchronize()
+if variant == "fwd_bits":
     so.rn_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
-    biasact.tower_conv_pair(x, x, ws[0], ws[1], bs[0], bs[1], cv.mask)
-    torch.cuda.synchronize()
-    so.rn_debug_set_stamps(ctypes.c_void_p(0))
+run_once(True)
+torch.cuda.synchronize()
+so.rn_debug_set_stamps(ctypes.c_void_p(0))
+print("variant", variant)
 s = stamps.cpu().numpy()
 s = s[s[:, 4] != 0]
 print("workgroups stamped", len(s), "canvas", tuple(x.shape))
