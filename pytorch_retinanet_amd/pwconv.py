@@ -540,13 +540,14 @@ def link_blocks(blocks) -> None:
 MM_1X1 = os.environ.get("RN_MM_1X1", "1") != "0"
 
 
+MANY_ROWS_MM = True       # 512-channel contraction on >= 100 000 rows without bias (conv1 of layer3's first block: CK 87 us, hipBLASLt 63 - 72)
 BIAS_1X1_MM = True        # a 1x1 conv WITH bias and >= 512 input channels goes to hipBLASLt (bias in the GEMM's epilogue) at any size
 
 
 def _fwd_by_mm(M: int, cin: int, cout: int, has_bias: bool = False) -> bool:
     # (the FPN's C3 lateral, 512 -> 256 on 134 400 positions with bias: MIOpen's kernel 66 us + a strided elementwise bias add over the
     # output 30 us in the step; isolated: conv2d + bias 136 us, hipBLASLt addmm 63, pw_gemm_kernel with a bias epilogue 84)
-    return (cin >= 1024 and M <= 40000) or (BIAS_1X1_MM and has_bias and cin >= 512)
+    return (cin >= 1024 and M <= 40000) or (BIAS_1X1_MM and has_bias and cin >= 512) or (MANY_ROWS_MM and cin >= 512 and M >= 100000)
 
 
 def _dgrad_by_mm(M: int, cin: int, cout: int) -> bool:
