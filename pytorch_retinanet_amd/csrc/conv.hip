@@ -525,6 +525,8 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
     uint16_t **Yrow = (uint16_t **)(lds + CONV_BM * CONV_BN * 2);  // TO_LEVELS: destination row of each tile row (2 KiB)
     float *s_cs = (float *)(lds + CONV_BM * CONV_BN * 2 + 2048);  // fused ReLU backward: column sums [16][256] f32 (16 KiB)
     uint8_t *s_rmask = lds + CONV_BM * CONV_BN * 2 + 2048 + 16384; //   and the tile's ReLU bits [256][32] bytes (8 KiB)
+    uint4 *s_lut = (uint4 *)(lds + CONV_BM * CONV_BN * 2 + 2048 + 16384 + 8192);   //   and the 256 byte -> four-word-masks table (4 KiB)
+    static_assert(CONV_BM * CONV_BN * 2 + 2048 + 16384 + 8192 + 4096 <= CONV_LDS_BYTES, "epilogue LDS");
     const uint8_t *relu_mask = MODE == MODE_TO_LEVELS ? nullptr : args.relu_masks[prob];
     uint4 rm_pre = make_uint4(0, 0, 0, 0);
     if (relu_mask) {                                              // fetched now, consumed after the staging below: latency hidden
@@ -555,7 +557,15 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
         }
         Yrow[tid] = dst;
     }
-    if (relu_mask) *(uint4 *)(s_rmask + tid * 16) = rm_pre;
+    if (relu_mask) {
+        *(uint4 *)(s_rmask + tid * 16) = rm_pre;
+        if (tid < 256) {                                            // entry e: word j keeps its low / high half where bit 2j / 2j + 1 of e is set
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = ((tid >> (2 * j)) & 1 ? 0x0000ffffu : 0u) | ((tid >> (2 * j + 1)) & 1 ? 0xffff0000u : 0u);
+            s_lut[tid] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
     __syncthreads();
     if (MODE == MODE_TO_LEVELS) {
         // dense rows of Cout elements start on 4-byte boundaries only (Cout even): 16-byte stores to dword-aligned
@@ -587,23 +597,27 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
                 uint4 v = *(const uint4 *)(Ys + row * CONV_BN + piece * 8);
                 if (!keep[i]) v = make_uint4(0, 0, 0, 0);
                 if (relu_mask) {
-                    const uint32_t bits = s_rmask[row * 32 + piece];
-                    uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+                    // (the byte's four word masks come out of a 256-entry LDS table: expanded with shifts and selects they were ~24 of the
+                    //  ~60 VALU instructions per piece of a loop that takes 4.9 us per tile, tools/probes)
+                    const uint4 mk = s_lut[s_rmask[row * 32 + piece]];
+                    uint32_t vw[4] = {v.x & mk.x, v.y & mk.y, v.z & mk.z, v.w & mk.w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {                    // two bf16 per word
-                        vw[j] &= ((bits >> (2 * j)) & 1u ? 0x0000ffffu : 0u) | ((bits >> (2 * j + 1)) & 1u ? 0xffff0000u : 0u);
                         cs[2 * j] += rn::mma<DT>::lo(vw[j]);
                         cs[2 * j + 1] += rn::mma<DT>::hi(vw[j]);
                     }
                     v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
                 }
                 if (rmask_out) {                                     // forward: the ReLU bits of what is stored (y > 0 as floats: NaN no)
+                    // (what is stored went through the ReLU: never negative, never NaN, never -0 -- so y > 0 is "the 16-bit pattern is not
+                    //  zero": one packed unsigned min with 1 per word instead of two conversions and two compares)
+                    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
                     const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
                     uint32_t bits = 0;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        bits |= (rn::mma<DT>::lo(vw[j]) > 0.0f ? 1u : 0u) << (2 * j);
-                        bits |= (rn::mma<DT>::hi(vw[j]) > 0.0f ? 1u : 0u) << (2 * j + 1);
+                        const uint32_t nz = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, vw[j]), us2{1, 1}));
+                        bits |= ((nz | (nz >> 15)) & 3u) << (2 * j);
                     }
                     rmask_out[m * (args.Cout >> 3) + (n0 >> 3) + piece] = (uint8_t)bits;
                 }

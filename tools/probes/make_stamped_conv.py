@@ -28,8 +28,9 @@ rep("    int scur = 0;                                                   // A st
 rep("    if (grp == 0) __builtin_amdgcn_s_barrier();                    // group 0 catches up with group 1's extra barrier\n",
     "    if (grp == 0) __builtin_amdgcn_s_barrier();                    // group 0 catches up with group 1's extra barrier\n    st2 = __builtin_amdgcn_s_memrealtime();\n")
 rep("    __syncthreads();\n    uint16_t *Ys = (uint16_t *)lds;", "    __syncthreads();\n    st2b = __builtin_amdgcn_s_memrealtime();\n    uint16_t *Ys = (uint16_t *)lds;")
-rep("    if (relu_mask) *(uint4 *)(s_rmask + tid * 16) = rm_pre;\n    __syncthreads();\n",
-    "    st2c = __builtin_amdgcn_s_memrealtime();\n    if (relu_mask) *(uint4 *)(s_rmask + tid * 16) = rm_pre;\n    __syncthreads();\n    st3 = __builtin_amdgcn_s_memrealtime();\n")
+rep("    if (relu_mask) {\n        *(uint4 *)(s_rmask + tid * 16) = rm_pre;\n", "    st2c = __builtin_amdgcn_s_memrealtime();\n    if (relu_mask) {\n        *(uint4 *)(s_rmask + tid * 16) = rm_pre;\n")
+rep("            s_lut[tid] = make_uint4(w[0], w[1], w[2], w[3]);\n        }\n    }\n    __syncthreads();\n",
+    "            s_lut[tid] = make_uint4(w[0], w[1], w[2], w[3]);\n        }\n    }\n    __syncthreads();\n    st3 = __builtin_amdgcn_s_memrealtime();\n")
 k = k[:-2] + """    if (args.stamps && threadIdx.x == 0) {
         const unsigned long long st4 = __builtin_amdgcn_s_memrealtime();
         unsigned hw = 0, xcc = 0;
