@@ -533,6 +533,13 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
         const int row = tid >> 1, half = tid & 1;
         if (m0 + row < M) rm_pre = *(const uint4 *)(relu_mask + (m0 + row) * (args.Cout >> 3) + (n0 >> 3) + half * 16);
     }
+    // accumulators -> the staged tile.  VALU-bound (128 elements per thread, two waves per SIMD: 3.3 us of a 72 us tile on the stamp probe), so two
+    // rows share one packed conversion, and the ReLU is one packed signed-16-bit max on the converted pair -- a negative or -0 pattern is a negative
+    // integer, so max(., 0) is what round(relu(x)) gives (floor 0x8000 = no ReLU); a compare, a select and a conversion per ELEMENT before.
+    // (A positive NaN passes through, as torch.relu does; the compare form used to zero it.)
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    uint32_t relu_floor = (args.relu & 1) ? 0u : 0x80008000u;
+    asm volatile("" : "+v"(relu_floor));                            // (opaque: one v_pk_max_i16 with a register operand, not a max with 0 + a select)
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -540,11 +547,15 @@ __global__ __launch_bounds__(CONV_THREADS) void conv3x3_canvas_kernel(const Conv
             const int col = wn * 64 + ni * 16 + (lane & 15);          // 16 x 16 result tile: column = lane & 15, rows 4 (lane >> 4) + r
             const float b = bias_pre[ni];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < 4; r += 2) {
                 const int row = wm * (32 * MI) + mi * 16 + 4 * (lane >> 4) + r;
-                float v = acc[mi][ni][r] + b;
-                if (args.relu & 1) v = v > 0.0f ? v : 0.0f;
-                Ys[row * CONV_BN + col] = rn::mma<DT>::dn(v);
+                const float x0 = acc[mi][ni][r] + b, x1 = acc[mi][ni][r + 1] + b;
+                uint32_t raw;
+                if (DT == RN_BF16) asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(raw) : "v"(x0), "v"(x1));      // (rn::dt::pk converts each half on its own + v_perm)
+                else raw = rn::dt<DT>::pk(x0, x1);
+                const uint32_t pk = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, raw), __builtin_bit_cast(s16x2, relu_floor)));
+                Ys[row * CONV_BN + col] = (uint16_t)pk;
+                Ys[(row + 1) * CONV_BN + col] = (uint16_t)(pk >> 16);
             }
         }
     if (MODE == MODE_TO_LEVELS && tid < CONV_BM) {
