@@ -7,9 +7,10 @@ tag=${1:-r03}
 out=$GRAFT_REPO_ROOT/gpurun_out/profile_$tag
 mkdir -p $out; rm -f $out/k3_pmc.txt
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -- python bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-detect --timing-steps 2 > $out/bench_kernel_trace.log 2>&1
-cp /tmp/pb/*/*kernel_stats.csv $out/bench_kernel_stats.csv
-python tools/steady_stats.py /tmp/pb/*/*kernel_trace.csv $out/bench_kernel_stats_steady.csv 4 2 | tee $out/steady_summary.txt
+rm -rf /tmp/pb; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pb -- python bench.py --steps 5 --warmup 3 --no-cpu-baseline --no-detect --timing-steps 2 > $out/bench_kernel_trace.log 2>&1
+# (a helper process of the run can leave a second, tiny trace: take the largest file of each kind)
+cp "$(ls -S /tmp/pb/*/*kernel_stats.csv | head -1)" $out/bench_kernel_stats.csv
+python tools/steady_stats.py "$(ls -S /tmp/pb/*/*kernel_trace.csv | head -1)" $out/bench_kernel_stats_steady.csv 4 2 | tee $out/steady_summary.txt
 grep "^{\"metric" $out/bench_kernel_trace.log | tail -1 > $out/bench_line_under_rocprof.json
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -f $out/k3_pmc.txt.tmp; rm -rf /tmp/pc; rocprofv3 --pmc $ctr --output-format csv -d /tmp/pc -- python bench.py --steps 3 --warmup 3 --no-cpu-baseline --no-detect --timing-steps 1 > /tmp/pc.log 2>&1
