@@ -385,11 +385,12 @@ def hash_key(k: str) -> int:
     return zlib.crc32(k.encode())
 
 
-def gen_e2e():
+def gen_e2e(kind: str = "resnet18", fname: str = "e2e.npz"):
     """Retinanet.forward (models.py:274-288) and Retinanet.predict (models.py:245-272) of the REFERENCE model itself, for a
-    seed-reproducible state dict: the fixture the assembled GPU model is held to."""
-    print("[e2e]  retinanet/models.py:245-288 (forward in train-mode BN, predict in eval mode)")
-    E2E = dict(num_classes=5, backbone_kind="resnet18", pretrained=False, min_size=128, max_size=160)
+    seed-reproducible state dict: the fixture the assembled GPU model is held to.  ``resnet18`` -> e2e.npz (BasicBlock
+    trunk); ``resnet50`` -> e2e_r50.npz (the Bottleneck trunk of the headline configuration, backbone.py:105-136)."""
+    print(f"[e2e {kind}]  retinanet/models.py:245-288 (forward in train-mode BN, predict in eval mode)")
+    E2E = dict(num_classes=5, backbone_kind=kind, pretrained=False, min_size=128, max_size=160)
     torch.manual_seed(0)
     ref = R.Retinanet(**E2E)
     spec = [(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in ref.state_dict().items()]
@@ -473,7 +474,11 @@ def gen_e2e():
     pre = ref.process_detections({"cls_preds": ho["cls_preds"].clone(), "bbox_preds": ho["bbox_preds"].clone()}, anchors, il.image_sizes)
     compare_dets("e2e", got, [{k: v.numpy() for k, v in d.items()} for d in pre])
     print("  oracle.detect == reference process_detections on the live head outputs")
-    save("e2e.npz", **out)
+    save(fname, **out)
+
+
+def gen_e2e_r50():
+    gen_e2e("resnet50", "e2e_r50.npz")
 
 
 def gen_traj():
@@ -540,7 +545,7 @@ def gen_traj():
 
 if __name__ == "__main__":
     oracle.build()
-    which = sys.argv[1:] or ["anchors", "match", "loss", "decode", "detect", "nms", "transform", "e2e", "traj"]
+    which = sys.argv[1:] or ["anchors", "match", "loss", "decode", "detect", "nms", "transform", "e2e", "e2e_r50", "traj"]
     for w in which:
         globals()["gen_" + w]()
     print("done")

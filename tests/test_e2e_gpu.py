@@ -10,6 +10,11 @@ regenerate the same weights from the seed, load them into ``pytorch_retinanet_am
 
 Tolerances: fp32 losses rel <= 1e-4; detections >= 99 % box-set agreement at IoU >= 0.999 with equal
 labels, scores abs <= 1e-4; bf16-autocast losses rel <= 2e-2.
+
+Round 5: a second fixture, ``e2e_r50.npz`` (``gen_golden.py e2e_r50``: the same seed-reproducible recipe on the reference's
+``resnet50`` -- the Bottleneck trunk of the headline configuration), runs through the same tests, and
+``test_r50_trunk_on_the_fused_bottleneck_kernels_holds_the_reference_bf16`` holds the fused layer1 / layer2 kernels, the stem and the
+head to the reference's own losses and gradient norms.
 """
 import numpy as np
 import pytest
@@ -18,6 +23,14 @@ import torch
 import synth
 
 E2E = dict(num_classes=5, backbone_kind="resnet18", pretrained=False, min_size=128, max_size=160)
+# the same for the Bottleneck trunk of the headline configuration (tests/golden/gen_golden.py e2e_r50; reference backbone.py:105-136)
+FIXTURES = {"e2e.npz": E2E, "e2e_r50.npz": dict(E2E, backbone_kind="resnet50")}
+# fp32 gradient bars per fixture: (norm rtol, projection / norm, sample atol in units of the gradient's rms, probe-norm rtol, probe-head atol / rms).
+# The R50 trunk at 128 x 160 px ends in 4 x 5 feature maps of a batch of two: BatchNorm over 40 - 160 values per channel and 53 layers of
+# ReLU boundaries amplify the fp32 summation-order differences between the CPU reference and the GPU libraries (losses agree to 4e-7;
+# measured over all 161 parameters: norm 6.0e-3 max / 1.2e-3 p90, projection 3.7e-2 / 1.6e-2, samples 0.36 rms max / 0.04 p90).
+GRAD_BARS = {"e2e.npz": (3e-3, 1e-2, 2e-2, 2e-3, 1e-2), "e2e_r50.npz": (1.2e-2, 6e-2, 6e-1, 1.2e-2, 3e-1)}
+BOTH = pytest.mark.parametrize("fixture", list(FIXTURES))
 DEV = "cuda:0"
 
 
@@ -41,9 +54,9 @@ def _inputs(g, device):
     return timgs, ttgts
 
 
-def _model(g, device):
+def _model(g, device, cfg=None):
     import pytorch_retinanet_amd as P
-    net = P.Retinanet(**E2E)
+    net = P.Retinanet(**(cfg or E2E))
     sd = net.state_dict()
     assert [k for k, _, _ in _spec(g)] == list(sd), "state-dict keys differ from the reference's"
     for k, v in _weights(g).items():
@@ -53,9 +66,10 @@ def _model(g, device):
     return net.to(device).to(memory_format=torch.channels_last)
 
 
-def test_fixture_weights_and_inputs_regenerate_from_the_seed(golden):
+@BOTH
+def test_fixture_weights_and_inputs_regenerate_from_the_seed(golden, fixture):
     "CPU: the seed reproduces the exact weights / images the reference was run on (sha256 recorded in the fixture)."
-    g = golden("e2e.npz")
+    g = golden(fixture)
     vals = _weights(g)
     assert len(vals) == len(_spec(g)) - 5                      # all entries but the 5 cell-anchor buffers
     images, targets = synth.e2e_inputs()
@@ -83,22 +97,24 @@ def box_set_agreement(got, ref, iou_thr=0.999):
 
 
 @pytest.mark.gpu
-def test_forward_losses_and_gradients_match_the_reference_fp32(golden):
+@BOTH
+def test_forward_losses_and_gradients_match_the_reference_fp32(golden, fixture):
     "Retinanet.forward in train-mode BN, fp32: loss dict rel <= 1e-4; EVERY parameter gradient: norm 3e-3, a seeded projection, 32 elements."
-    g = golden("e2e.npz")
-    net = _model(g, DEV).train()
+    g = golden(fixture)
+    net = _model(g, DEV, FIXTURES[fixture]).train()
     images, targets = _inputs(g, DEV)
     out = net(images, targets)
     got = np.array([float(out["classification_loss"].detach()), float(out["regression_loss"].detach())])
     np.testing.assert_allclose(got, g["train_losses"], rtol=1e-4)
     (out["classification_loss"] + out["regression_loss"]).backward()
     named = dict(net.named_parameters())
+    bar_norm, bar_proj, bar_samp, bar_pnorm, bar_phead = GRAD_BARS[fixture]
     for k, norm, head in zip(g["grad_probe_keys"], g["grad_probe_norms"], g["grad_probe_head"]):
         gr = named[str(k)].grad
         assert gr is not None, k
-        np.testing.assert_allclose(float(gr.double().norm()), norm, rtol=2e-3, err_msg=str(k))
+        np.testing.assert_allclose(float(gr.double().norm()), norm, rtol=bar_pnorm, err_msg=str(k))
         # (single elements: fp32 convolutions whose algorithm MIOpen picks per run -- compare against the gradient's rms)
-        np.testing.assert_allclose(gr.reshape(-1)[:8].double().cpu().numpy(), head, rtol=5e-2, atol=1e-2 * norm / np.sqrt(gr.numel()),
+        np.testing.assert_allclose(gr.reshape(-1)[:8].double().cpu().numpy(), head, rtol=5e-2, atol=bar_phead * norm / np.sqrt(gr.numel()),
                                    err_msg=str(k))
     # every parameter: gradient norm, projection on a seeded random direction, 32 seeded elements (fixture: the reference's autograd)
     import zlib
@@ -109,8 +125,8 @@ def test_forward_losses_and_gradients_match_the_reference_fp32(golden):
         flat = gr.reshape(-1).double().cpu().numpy()
         r = np.random.default_rng(zlib.crc32(str(k).encode())).standard_normal(flat.size)
         rms = norm / np.sqrt(flat.size)
-        ok = (abs(np.linalg.norm(flat) - norm) <= 3e-3 * norm + 1e-9 and abs(flat @ r - proj) <= 1e-2 * norm + 1e-9
-              and np.all(np.abs(flat[pos] - samp) <= 5e-2 * np.abs(samp) + 2e-2 * rms + 1e-12))
+        ok = (abs(np.linalg.norm(flat) - norm) <= bar_norm * norm + 1e-9 and abs(flat @ r - proj) <= bar_proj * norm + 1e-9
+              and np.all(np.abs(flat[pos] - samp) <= 5e-2 * np.abs(samp) + bar_samp * rms + 1e-12))
         if not ok:
             bad.append((str(k), float(np.linalg.norm(flat)), float(norm), float(flat @ r), float(proj)))
     assert not bad, bad[:5]
@@ -120,9 +136,10 @@ def test_forward_losses_and_gradients_match_the_reference_fp32(golden):
 
 
 @pytest.mark.gpu
-def test_forward_losses_eval_bn_fp32(golden):
-    g = golden("e2e.npz")
-    net = _model(g, DEV).eval()
+@BOTH
+def test_forward_losses_eval_bn_fp32(golden, fixture):
+    g = golden(fixture)
+    net = _model(g, DEV, FIXTURES[fixture]).eval()
     images, targets = _inputs(g, DEV)
     with torch.no_grad():
         out = net(images, targets)
@@ -131,10 +148,11 @@ def test_forward_losses_eval_bn_fp32(golden):
 
 
 @pytest.mark.gpu
-def test_predict_matches_the_reference_fp32(golden):
+@BOTH
+def test_predict_matches_the_reference_fp32(golden, fixture):
     "Retinanet.predict in eval mode, fp32: >= 99 % box-set agreement at IoU 0.999 + label equality; scores 1e-4."
-    g = golden("e2e.npz")
-    net = _model(g, DEV).eval()
+    g = golden(fixture)
+    net = _model(g, DEV, FIXTURES[fixture]).eval()
     images, _ = _inputs(g, DEV)
     dets = net.predict(images)
     assert len(dets) == 2
@@ -208,19 +226,21 @@ def test_forward_and_predict_fp16_autocast(golden):
 
 
 @pytest.mark.gpu
-def test_forward_and_predict_bf16_autocast(golden):
+@BOTH
+def test_forward_and_predict_bf16_autocast(golden, fixture):
     """The headline numeric configuration (bf16 autocast, MFMA towers, fp32 masters): losses within 2e-2 of the fp32
     reference; detections: >= 85 % of the reference's confident boxes have a same-label partner at IoU >= 0.9 with a score
     within 5e-3, median IoU >= 0.97 -- bf16 logits move scores near the 0.05 threshold, the top-100 cut-off and near-tie NMS
     decisions, so the fp32 criterion (99 % at IoU 0.999) does not apply; the exact check is the oracle test below."""
-    g = golden("e2e.npz")
-    net = _model(g, DEV).train()
+    g = golden(fixture)
+    net = _model(g, DEV, FIXTURES[fixture]).train()
     images, targets = _inputs(g, DEV)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         out = net(images, targets)
     got = np.array([float(out["classification_loss"].detach()), float(out["regression_loss"].detach())])
-    np.testing.assert_allclose(got, g["train_losses"], rtol=2e-2)
-    net = _model(g, DEV).eval()
+    # (R50 fixture: the regression loss of its few matched anchors sits 1.6 - 2.1 % off from run to run -- the library picks its bf16 solvers per process)
+    np.testing.assert_allclose(got, g["train_losses"], rtol=2e-2 if fixture == "e2e.npz" else 4e-2)
+    net = _model(g, DEV, FIXTURES[fixture]).eval()
     with torch.autocast("cuda", dtype=torch.bfloat16):
         dets = net.predict(images)
     n_top = 0
@@ -246,12 +266,50 @@ def test_forward_and_predict_bf16_autocast(golden):
 
 
 @pytest.mark.gpu
-def test_bf16_head_outputs_through_the_oracle_give_the_models_detections(golden, oracle_lib):
+def test_r50_trunk_on_the_fused_bottleneck_kernels_holds_the_reference_bf16(golden):
+    """The headline configuration's TRUNK against the reference's own R50 (``e2e_r50.npz``): bf16 conv weights + bf16 autocast put layer1 / layer2
+    on the fused bottleneck kernels of csrc/pw.hip (conv1 + statistics, conv3 walker, block output + next conv1, conv3's two gradients in one pass,
+    conv1's data gradient + the previous block's sums), the stem on csrc/stem.hip and conv2 on the narrow / band kernels -- asserted through the
+    launch tags -- and the result is held to the reference's fp32 losses (4e-2; measured 1.7e-3 / 1.6e-2, the regression loss up to 2.1e-2 in other processes) and to every parameter's gradient norm.
+    Bars: convolution weights 0.25 (measured: median 0.015, p90 0.045, max 0.115 at P7's 1 x 2 map -- and once above 0.15 on another box: the
+    library picks its bf16 solvers per process), BatchNorm weights / biases and conv biases 0.4 (median 0.035, p90 0.088, max 0.18): a per-channel gradient is a SUM over 160 - 2 560 positions of terms that nearly cancel, so bf16's
+    2^-9 per term becomes sqrt(N) 2^-9 of the sum."""
+    from pytorch_retinanet_amd import biasact, pwconv
+    from pytorch_retinanet_amd.optim import use_16bit_conv_weights
+    g = golden("e2e_r50.npz")
+    net = _model(g, DEV, FIXTURES["e2e_r50.npz"]).train()
+    assert use_16bit_conv_weights(net, torch.bfloat16) > 0
+    images, targets = _inputs(g, DEV)
+    biasact.MFMA_FLOP.clear(); pwconv.PW_FLOP.clear()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = net(images, targets)
+        total = out["classification_loss"] + out["regression_loss"]
+    got = np.array([float(out["classification_loss"].detach()), float(out["regression_loss"].detach())])
+    np.testing.assert_allclose(got, g["train_losses"], rtol=4e-2)
+    total.backward()
+    ran = set(biasact.MFMA_FLOP) | set(pwconv.PW_FLOP)
+    for tag in ("stem_fwd", "stem_wgrad", "pw_conv1_fwd", "pw_conv3_fwd", "pw_conv3_bwd", "pw_block_out_conv1", "pw_conv1_dgrad_sums", "pw_conv1_wgrad",
+                "mfma_tower_fwd_x2", "mfma_tower_dgrad_x2", "mfma_tower_wgrad_x2"):
+        assert tag in ran, (tag, sorted(ran))
+    named = dict(net.named_parameters())
+    bad = []
+    for k, norm in zip(g["grad_all_keys"], g["grad_all_norms"]):
+        gr = named[str(k)].grad
+        assert gr is not None and bool(torch.isfinite(gr.float()).all()), k
+        rel = abs(float(gr.double().norm()) - norm) / (norm + 1e-12)
+        if rel > (0.25 if gr.dim() == 4 else 0.4):
+            bad.append((str(k), rel))
+    assert not bad, bad[:8]
+
+
+@pytest.mark.gpu
+@BOTH
+def test_bf16_head_outputs_through_the_oracle_give_the_models_detections(golden, oracle_lib, fixture):
     """The detection chain (K4-K7) of the headline numeric configuration, exactly: the model's OWN bf16 head outputs (packed
     canvas, MFMA towers, dense class-output conv) fed to the CPU oracle's process_detections (reference models.py:160-243)
     must give the labels, boxes and scores ``process_detections_levels`` returns for them -- no tolerance on labels and order."""
-    g = golden("e2e.npz")
-    net = _model(g, DEV).eval()
+    g = golden(fixture)
+    net = _model(g, DEV, FIXTURES[fixture]).eval()
     images, _ = _inputs(g, DEV)
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         il, _ = net.transform(images, None, **net._batch_layout())
@@ -273,7 +331,8 @@ def test_bf16_head_outputs_through_the_oracle_give_the_models_detections(golden,
 
 
 @pytest.mark.reference
-def test_fixture_is_what_the_reference_computes_now(golden):
+@BOTH
+def test_fixture_is_what_the_reference_computes_now(golden, fixture):
     """Build container only: re-run the reference on the regenerated weights and compare with the committed fixture
     (guards against a stale e2e.npz)."""
     import os
@@ -281,8 +340,8 @@ def test_fixture_is_what_the_reference_computes_now(golden):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     import _tv_standin
     R = _tv_standin.import_reference()
-    g = golden("e2e.npz")
-    ref = R.Retinanet(**E2E)
+    g = golden(fixture)
+    ref = R.Retinanet(**FIXTURES[fixture])
     sd = ref.state_dict()
     for k, v in _weights(g).items():
         sd[k] = torch.from_numpy(v)
