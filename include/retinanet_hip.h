@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define RN_ABI_VERSION 9
+#define RN_ABI_VERSION 10
 #define RN_MAX_LEVELS 8
 
 enum rn_dtype { RN_F32 = 0, RN_BF16 = 1, RN_F16 = 2 };
@@ -188,6 +188,27 @@ int rn_loss_fwd_bwd_levels_fin(const void *const *cls_levels, const void *const 
                                const uint64_t *special_rows, const int32_t *num_fg, const rn_loss_params *params,
                                float *out_loss, void *const *grad_cls_levels, void *const *grad_box_levels, void *workspace,
                                size_t workspace_bytes, void *state, void *stream, void *event_start, void *event_stop);
+/* rn_loss_fwd_bwd_levels_fin with two more arguments (ABI 10; reference: retinanet/losses.py:49-111, and the fp16 run of
+ * demo.ipynb, Lightning precision = 16):
+ *   grad_prescale  nullable device f32[1].  Every GRADIENT the call writes (not the two losses) is multiplied by *grad_prescale
+ *                  BEFORE it is rounded to the I/O dtype.  A torch.amp.GradScaler multiplies the fp32 loss by its scale before
+ *                  backward, so the reference's fp16 class-head gradients (0.25 p^3 / (num_fg B) ~ 4e-10 for a background
+ *                  element at the prior) are stored as ~2.6e-5; written unscaled they would flush to zero below fp16's
+ *                  smallest subnormal (6e-8) before any later multiplication.  The caller multiplies by upstream / prescale
+ *                  in backward (a no-op when upstream == prescale).
+ *   repair_pass    0: one launch, the special rows repaired inside the streaming kernel (the _fin form).
+ *                  1: TWO launches -- a pure background stream over the logits (no row logic) and a repair kernel that walks
+ *                  the flag words (`special_rows`, required), gives every lane one special row and finishes the sums; `workspace`
+ *                  may be NULL.  Same arithmetic; the event pair brackets both kernels.  Losses equal the one-launch form to the
+ *                  last bits of the 2^-32 fixed-point sums, gradients bit for bit. */
+int rn_loss_fwd_bwd_levels_rp(const void *const *cls_levels, const void *const *box_levels,
+                              const int64_t *level_anchors, int L, int dtype, int B, int K,
+                              const float *anchors, int64_t anchor_bstride, const float *gt_boxes,
+                              const int64_t *gt_labels, const int32_t *gt_off, const int64_t *matches,
+                              const uint64_t *special_rows, const int32_t *num_fg, const rn_loss_params *params,
+                              const float *grad_prescale, int repair_pass, float *out_loss, void *const *grad_cls_levels,
+                              void *const *grad_box_levels, void *workspace, size_t workspace_bytes, void *state,
+                              void *stream, void *event_start, void *event_stop);
 /* K2 + K3 in ONE launch (round 4): the matcher of retinanet/box_utils.py:51-80 runs in the loss kernel's prologue -- every wave
  * matches the anchor rows of its own range against the image's GT boxes (one box per lane, so max_gt_per_image <= 64), the
  * per-image foreground counts meet in device-scope counters behind a grid barrier (the launch uses the resident grid only), and

@@ -70,6 +70,9 @@ SIGNATURES = {
     "rn_loss_fwd_bwd_levels_fin": (C.c_int, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i64), C.c_int, C.c_int, C.c_int, C.c_int,
                                              _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(RnLossParams), _vp,
                                              C.POINTER(_vp), C.POINTER(_vp), _vp, _sz, _vp, _vp, _vp, _vp]),
+    "rn_loss_fwd_bwd_levels_rp": (C.c_int, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i64), C.c_int, C.c_int, C.c_int, C.c_int,
+                                            _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(RnLossParams), _vp, C.c_int, _vp,
+                                            C.POINTER(_vp), C.POINTER(_vp), _vp, _sz, _vp, _vp, _vp, _vp]),
     "rn_loss_match_state_bytes": (_sz, [C.c_int]),
     "rn_loss_match_fwd_bwd_levels": (C.c_int, [C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i64), C.c_int, C.c_int, C.c_int, C.c_int,
                                                _vp, _i64, _vp, _vp, _vp, C.c_int, _f32, _f32, _vp, _vp, C.POINTER(RnLossParams), _vp,

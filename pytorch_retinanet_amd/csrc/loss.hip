@@ -70,6 +70,8 @@ struct LossArgs {
     float2 *part_stream;     // [blocks] (cls, reg) partial sums
     unsigned *fin;           // nullable: state words of the in-kernel finalize (rn_loss_fwd_bwd_levels_fin): [0] arrivals, [2..5] two int64 sums
     float *out_loss;         // f32[2], written by workgroup 0 when `fin` is set
+    const float *gscale;     // nullable device f32[1]: every GRADIENT (not the losses) is multiplied by it before the rounding to the I/O dtype
+                             // (a GradScaler's scale: fp16 gradients of ~4e-10 would flush to zero if the scale came after the store)
     // fused matching (loss_stream_kernel<.., FUSED = true>): the IoU matcher of box_utils.py:51-80 runs in this kernel's prologue
     float fg_thr, bg_thr;
     int32_t *nfg_acc;        // [B] foreground counts of this launch: zero on entry (the finalize kernel re-zeroes them), device-scope atomics
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
     const int64_t gv_beg = gwave * a.vec_per_wave;                // this wave's range in the virtual vector space
     const int64_t gv_end = min(gv_beg + a.vec_per_wave, a.total_vec);  // (levels laid end to end)
     const int K = a.K;
-
+    const float gs = a.gscale ? *a.gscale : 1.0f;                 // gradient pre-scale (wave-uniform: a scalar load)
 
     // ---- Fused matching (FUSED): box_utils.py:51-80 for the rows of THIS wave's range, before anything else.  At the train shape
     // (T <= 64 GT boxes per image) a row's match is ~T x 25 VALU instructions, while a separate K2 launch is bound by launch latency and
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                     bg_elem<GAMMA2>(xp, a.p, wb, gbg);
                     focal_elem<GAMMA2>(xp, true, a, l, gr);
                     acc += (double)l * (double)scale - (double)wb * (double)(a.p.alpha * scale);
-                    gr *= scale;
+                    gr *= scale * gs;
                 }
                 const unsigned long long below = (1ull << lane) - 1ull;
                 const unsigned long long pmask = __ballot(pos_ok);
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                         const float l = reg_row(a.gt_boxes[t0 + pmv], a.anchors[(int64_t)b * a.anchor_bstride4 + ag], pred, a.p, gb);
                         reg += l * scale;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) gb[j] *= scale;
+                        for (int j = 0; j < 4; ++j) gb[j] *= scale * gs;
                         if (WRITE_GRAD) box4<DT>::st(lv.gbox, r, gb);
                     }
                 }
@@ -565,6 +567,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
             int b = (int)(e_beg / lv.per_image);                      // image of the first element
             int64_t img_end_v = ((int64_t)(b + 1) * lv.per_image) / VEC;   // vectors [.., img_end_v) lie entirely in image b
             float gmul = image_gmul<FUSED>(a, b);
+            float gmul_g = gmul * gs;                                 // the gradients' multiplier (loss multiplier x pre-scale)
 
             const int64_t last = v_end - 1;
             const int64_t groups = (v_end - v_beg) / (PF * RN_WAVE);      // full groups of PF wave-iterations
@@ -595,7 +598,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                             float wb, gg;
                             bg_elem<GAMMA2>(x[j], a.p, wb, gg);
                             acc_g += wb;
-                            g[j] = gg * gmul;
+                            g[j] = gg * gmul_g;
                         }
                         if (WRITE_GRAD) { if (NT & 2) __builtin_nontemporal_store(D::pack(g), &dst[v0 + u * RN_WAVE + lane]); else dst[v0 + u * RN_WAVE + lane] = D::pack(g); }
                     }
@@ -622,11 +625,11 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                             if (one_seam) {
                                 s_all += wb;
                                 s_hi += j >= k ? wb : 0.0f;
-                                g[j] = gg * (j >= k ? gmul_next : gmul);
+                                g[j] = gg * (j >= k ? gmul_next * gs : gmul_g);
                             } else {
                                 const float gm = image_gmul<FUSED>(a, (int)((v * VEC + j) / lv.per_image));
                                 acc += (double)wb * (double)gm;
-                                g[j] = gg * gm;
+                                g[j] = gg * (gm * gs);
                             }
                         }
                         if (one_seam) acc += (double)s_all * (double)gmul + (double)s_hi * ((double)gmul_next - (double)gmul);
@@ -636,6 +639,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                     if (b > a.B - 1) b = a.B - 1;
                     img_end_v = ((int64_t)(b + 1) * lv.per_image) / VEC;
                     gmul = image_gmul<FUSED>(a, b);
+                    gmul_g = gmul * gs;
                 }
 #pragma unroll
                 for (int u = 0; u < PF; ++u) q[u] = qn[u];
@@ -651,7 +655,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                     float wb, gg;
                     bg_elem<GAMMA2>(x[j], a.p, wb, gg);
                     acc += (double)wb * (double)gm;
-                    g[j] = gg * gm;
+                    g[j] = gg * (gm * gs);
                 }
                 if (WRITE_GRAD) dst[v] = D::pack(g);
             }
@@ -664,7 +668,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                 float wb, gg;
                 bg_elem<GAMMA2>(D::ld(lv.cls, e), a.p, wb, gg);
                 acc += (double)wb * (double)gm;
-                if (WRITE_GRAD) D::st(lv.gcls, e, gg * gm);
+                if (WRITE_GRAD) D::st(lv.gcls, e, gg * (gm * gs));
             }
         }
 
@@ -724,7 +728,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                                 bg_elem<GAMMA2>(x, a.p, wb, gbg);
                                 focal_elem<GAMMA2>(x, true, a, l, gr);
                                 acc += (double)l * (double)scale - (double)wb * (double)gmul;
-                                if (WRITE_GRAD) D::st(lv.gcls, e_pos, gr * scale);
+                                if (WRITE_GRAD) D::st(lv.gcls, e_pos, gr * (scale * gs));
                             }
                             if (own_row) {
                                 float pred[4];
@@ -732,7 +736,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                                 const float l = reg_row(a.gt_boxes[gi], a.anchors[(int64_t)b * a.anchor_bstride4 + ag], pred, a.p, gb);
                                 reg += l * scale;
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) gb[j] *= scale;
+                                for (int j = 0; j < 4; ++j) gb[j] *= scale * gs;
                             }
                         } else {
                             ignored = true;
@@ -845,6 +849,420 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
 #pragma unroll
             for (int w = 0; w < LOSS_WAVES; ++w) { c += s_part[w][0]; rg += s_part[w][1]; }
             a.part_stream[blockIdx.x] = make_float2(c, rg);
+        }
+    }
+}
+
+// =========================== K3 as stream + repair (round 6) ===========================
+// The same arithmetic split over two launches (rn_loss_fwd_bwd_levels_rp):
+//
+//   loss_bg_kernel      phase A alone: every class element as a plain background element of its image, the zero box gradients
+//                       of the rows a wave owns, the partial sums into the 64 state lines.  No row logic at all: no flag words,
+//                       no lists, no LDS beyond the block reduction.
+//   loss_repair_kernel  walks the flag words of rn_iou_match_special (one strip of REPAIR_WORDS words = 512 anchor rows per
+//                       wave), compacts the flagged rows of its strip into an LDS list and gives every LANE one special row:
+//                       match code -> label / GT box -> positive logit, the chains of 64 rows in flight together instead of one
+//                       64-row chunk after the other inside a streaming wave.  Matched rows: the positive element's loss
+//                       correction and gradient, the regression term and the box gradient.  Ignored rows: their background terms
+//                       come out of the sum again and their gradient rows are zeroed, elements spread over all lanes.  The
+//                       stores overwrite what loss_bg_kernel wrote (stream order).  The workgroup that arrives last sums the 64
+//                       lines, writes the two losses and leaves the state zeroed.
+//
+// Why: inside the streaming kernel the repair is a per-wave serial prefix whose length follows the LOCAL density of special rows
+// (at 500 GT boxes per image ~25 special rows per wave on average, several times that where the boxes cluster), and the whole chip
+// waits for the slowest wave; here the special rows are balanced over the chip by construction.  Every sum leaves a workgroup as
+// 2^-32 fixed point converted from the DOUBLE partial, so the cancellation between a row's background term (added by the first
+// kernel) and its removal (second kernel) is exact to 2.3e-10 whatever the logits.
+constexpr int REPAIR_WORDS = 8;                       // flag words per wave: 512 anchor rows
+constexpr int REPAIR_ROWS = REPAIR_WORDS * 64;
+constexpr int REPAIR_BLOCK = 256;
+constexpr int REPAIR_WAVES = REPAIR_BLOCK / RN_WAVE;
+constexpr int REPAIR_IGN_U = 8;                      // independent loads per lane per round in the ignored-row pass
+
+__device__ __forceinline__ long long loss_fix_d(const double v, unsigned &flags)
+{
+    if (!(fabs(v) < 2147483648.0)) {
+        flags |= (v != v) ? 1u : (v > 0.0 ? 2u : 4u);
+        return 0;
+    }
+    return __double2ll_rn(v * 4294967296.0);
+}
+
+// a workgroup's two partial sums -> its state line (returning adds: the values are PERFORMED at the device-scope coherence point
+// when the results come back, which is what orders them before a later arrival count without an L2 write-back)
+__device__ __forceinline__ void fin_add(unsigned *const fin, const double c, const double rg, const bool wait)
+{
+    unsigned *const line = fin + (blockIdx.x & (FIN_LINES - 1)) * 16;
+    unsigned long long *const sums = (unsigned long long *)(line + 2);
+    unsigned fl_c = 0u, fl_r = 0u;
+    const long long fc = loss_fix_d(c, fl_c), fr = loss_fix_d(rg, fl_r);
+    if (wait) {
+        const unsigned long long o0 = __hip_atomic_fetch_add(sums + 0, (unsigned long long)fc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long o1 = __hip_atomic_fetch_add(sums + 1, (unsigned long long)fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned o2 = 0u;
+        if (fl_c | fl_r) o2 = __hip_atomic_fetch_or(line + 1, fl_c | (fl_r << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(o0), "v"(o1), "v"(o2));
+    } else {                                                   // (the kernel's end performs them: the next kernel on the stream reads them)
+        __hip_atomic_fetch_add(sums + 0, (unsigned long long)fc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(sums + 1, (unsigned long long)fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (fl_c | fl_r) __hip_atomic_fetch_or(line + 1, fl_c | (fl_r << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int DT, bool GAMMA2, bool WRITE_GRAD, int PF, int NT>
+__global__ __launch_bounds__(LOSS_BLOCK) void loss_bg_kernel(const LossArgs a)
+{
+    typedef rn::dt<DT> D;
+    constexpr int VEC = D::VEC;
+    __shared__ double s_part[LOSS_WAVES];
+    const int lane = threadIdx.x & (RN_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t gwave_raw = (int64_t)blockIdx.x * LOSS_WAVES + wave;
+    const int64_t gwave = (a.reverse & 1) ? (int64_t)gridDim.x * LOSS_WAVES - 1 - gwave_raw : gwave_raw;
+    const int64_t gv_beg = gwave * a.vec_per_wave;
+    const int64_t gv_end = min(gv_beg + a.vec_per_wave, a.total_vec);
+    const int K = a.K;
+    const float gs = a.gscale ? *a.gscale : 1.0f;
+    double acc = 0.0;
+
+    for (int li = 0; li < a.L; ++li) {
+        const LossLevel &lv = a.lv[li];
+        const int64_t nvec = lv.nvec;
+        if (gv_end <= lv.voff && nvec > 0) break;
+        const int64_t v_beg = max(gv_beg, lv.voff) - lv.voff;
+        const int64_t v_end = min(gv_end, lv.voff + nvec) - lv.voff;
+        const bool active = (nvec > 0) ? (v_beg < v_end) : (gwave == 0);
+        if (!active) continue;
+        const rn::u32x4 *src = (const rn::u32x4 *)lv.cls;
+        rn::u32x4 *dst = (rn::u32x4 *)lv.gcls;
+        const int64_t e_beg = v_beg * VEC;
+        const int64_t e_end = (nvec == 0 || v_end == nvec) ? lv.N : v_end * VEC;
+
+        rn::u32x4 q[PF];
+        const int64_t last = v_end - 1;
+        if (v_beg < v_end) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) q[u] = (NT & 1) ? __builtin_nontemporal_load(&src[min(v_beg + u * RN_WAVE + lane, last)]) : src[min(v_beg + u * RN_WAVE + lane, last)];
+        }
+        if (WRITE_GRAD) {
+            // zero box gradients of the rows whose first class element lies in this range (the repair kernel overwrites the matched ones)
+            constexpr int RB = 4 * (int)sizeof(typename D::elem);
+            const int64_t own_lo = (e_beg + K - 1) / K;
+            const int64_t own_hi = e_end > e_beg ? (e_end - 1) / K : own_lo - 1;
+            if (own_lo <= own_hi) {
+                unsigned char *const gb0 = (unsigned char *)lv.gbox;
+                const int64_t b0 = own_lo * RB, b1 = (own_hi + 1) * RB;
+                const int64_t v0 = (b0 + 15) >> 4, v1 = b1 >> 4;
+                for (int64_t v = v0 + lane; v < v1; v += RN_WAVE) ((rn::u32x4 *)gb0)[v] = rn::u32x4{0u, 0u, 0u, 0u};
+                if (RB == 8) {
+                    if (lane == 0 && (b0 & 15)) *(rn::u32x2 *)(gb0 + b0) = rn::u32x2{0u, 0u};
+                    if (lane == 1 && (b1 & 15) && (v1 << 4) >= b0) *(rn::u32x2 *)(gb0 + (v1 << 4)) = rn::u32x2{0u, 0u};
+                }
+            }
+        }
+        if (v_beg < v_end) {
+            int b = (int)(e_beg / lv.per_image);
+            int64_t img_end_v = ((int64_t)(b + 1) * lv.per_image) / VEC;
+            float gmul = image_gmul<false>(a, b);
+            float gmul_g = gmul * gs;
+            const int64_t groups = (v_end - v_beg) / (PF * RN_WAVE);
+            int64_t v0 = v_beg;
+            for (int64_t gi = 0; gi < groups; ++gi, v0 += PF * RN_WAVE) {
+                rn::u32x4 qn[PF];
+#pragma unroll
+                for (int u = 0; u < PF; ++u) qn[u] = (NT & 1) ? __builtin_nontemporal_load(&src[min(v0 + (PF + u) * RN_WAVE + lane, last)]) : src[min(v0 + (PF + u) * RN_WAVE + lane, last)];
+                if (v0 + PF * RN_WAVE <= img_end_v) {
+                    float acc_g = 0.0f;
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) {
+                        float x[VEC], g[VEC];
+                        D::unpack(q[u], x);
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) {
+                            float wb, gg;
+                            bg_elem<GAMMA2>(x[j], a.p, wb, gg);
+                            acc_g += wb;
+                            g[j] = gg * gmul_g;
+                        }
+                        if (WRITE_GRAD) { if (NT & 2) __builtin_nontemporal_store(D::pack(g), &dst[v0 + u * RN_WAVE + lane]); else dst[v0 + u * RN_WAVE + lane] = D::pack(g); }
+                    }
+                    acc += (double)acc_g * (double)gmul;
+                } else {
+                    const int64_t e_seam = (int64_t)(b + 1) * lv.per_image;
+                    const bool one_seam = lv.per_image >= (int64_t)PF * RN_WAVE * VEC && b + 1 < a.B;
+                    const float gmul_next = one_seam ? image_gmul<false>(a, b + 1) : 0.0f;
+#pragma unroll 1
+                    for (int u = 0; u < PF; ++u) {
+                        const int64_t v = v0 + u * RN_WAVE + lane;
+                        float x[VEC], g[VEC];
+                        D::unpack(src[v], x);
+                        const int k = one_seam ? (int)max(min(e_seam - v * VEC, (int64_t)VEC), (int64_t)0) : VEC;
+                        float s_all = 0.0f, s_hi = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) {
+                            float wb, gg;
+                            bg_elem<GAMMA2>(x[j], a.p, wb, gg);
+                            if (one_seam) {
+                                s_all += wb;
+                                s_hi += j >= k ? wb : 0.0f;
+                                g[j] = gg * (j >= k ? gmul_next * gs : gmul_g);
+                            } else {
+                                const float gm = image_gmul<false>(a, (int)((v * VEC + j) / lv.per_image));
+                                acc += (double)wb * (double)gm;
+                                g[j] = gg * (gm * gs);
+                            }
+                        }
+                        if (one_seam) acc += (double)s_all * (double)gmul + (double)s_hi * ((double)gmul_next - (double)gmul);
+                        if (WRITE_GRAD) dst[v] = D::pack(g);
+                    }
+                    b = (int)(((v0 + PF * RN_WAVE) * VEC) / lv.per_image);
+                    if (b > a.B - 1) b = a.B - 1;
+                    img_end_v = ((int64_t)(b + 1) * lv.per_image) / VEC;
+                    gmul = image_gmul<false>(a, b);
+                    gmul_g = gmul * gs;
+                }
+#pragma unroll
+                for (int u = 0; u < PF; ++u) q[u] = qn[u];
+            }
+#pragma unroll 1
+            for (int64_t v = v0 + lane; v < v_end; v += RN_WAVE) {
+                float x[VEC], g[VEC];
+                D::unpack(src[v], x);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const float gm = image_gmul<false>(a, (int)((v * VEC + j) / lv.per_image));
+                    float wb, gg;
+                    bg_elem<GAMMA2>(x[j], a.p, wb, gg);
+                    acc += (double)wb * (double)gm;
+                    g[j] = gg * (gm * gs);
+                }
+                if (WRITE_GRAD) dst[v] = D::pack(g);
+            }
+        }
+        if (nvec == 0 || v_end == nvec) {
+            const int64_t e = nvec * VEC + lane;
+            if (lane < VEC && e < lv.N) {
+                const float gm = image_gmul<false>(a, (int)(e / lv.per_image));
+                float wb, gg;
+                bg_elem<GAMMA2>(D::ld(lv.cls, e), a.p, wb, gg);
+                acc += (double)wb * (double)gm;
+                if (WRITE_GRAD) D::st(lv.gcls, e, gg * (gm * gs));
+            }
+        }
+    }
+    const double accw = rn::wave_sum_d(acc);
+    if (lane == 0) s_part[wave] = accw;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double c = 0.0;
+#pragma unroll
+        for (int w = 0; w < LOSS_WAVES; ++w) c += s_part[w];
+        fin_add(a.fin, c, 0.0, false);
+    }
+}
+
+struct RepairLevelTab { const void *cls, *box; void *gcls, *gbox; };
+
+template <int DT, bool GAMMA2, bool WRITE_GRAD>
+__global__ __launch_bounds__(REPAIR_BLOCK) void loss_repair_kernel(const LossArgs a, const int strips_per_image, const int total_strips)
+{
+    typedef rn::dt<DT> D;
+    constexpr int VEC = D::VEC;
+    __shared__ unsigned short s_rows[REPAIR_WAVES][REPAIR_ROWS];     // flagged rows of the strip (offsets from its first anchor)
+    __shared__ int s_ign_r[REPAIR_WAVES][REPAIR_ROWS];               // ignored rows: row index inside the level tensor (b * A_l + a_local)
+    __shared__ unsigned char s_ign_l[REPAIR_WAVES][REPAIR_ROWS];     //   and their level
+    __shared__ double s_part[REPAIR_WAVES][2];
+    __shared__ RepairLevelTab s_lv[RN_MAX_LEVELS];
+    __shared__ unsigned s_last;
+    const int lane = threadIdx.x & (RN_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (threadIdx.x < RN_MAX_LEVELS) {
+        const LossLevel &lv = a.lv[threadIdx.x];
+        s_lv[threadIdx.x] = RepairLevelTab{lv.cls, lv.box, lv.gcls, lv.gbox};
+    }
+    __syncthreads();
+    const int K = a.K;
+    const float gs = a.gscale ? *a.gscale : 1.0f;
+    double acc = 0.0, reg = 0.0;
+    const int strip = (int)blockIdx.x * REPAIR_WAVES + wave;
+    if (strip < total_strips) {
+        const int b = strip / strips_per_image;
+        const int64_t w0 = (int64_t)(strip - b * strips_per_image) * REPAIR_WORDS;
+        const int t0 = a.gt_off[b], T = a.gt_off[b + 1] - t0;
+        unsigned long long word = 0ull;
+        if (T > 0 && lane < REPAIR_WORDS && w0 + lane < a.special_W) word = a.special[(int64_t)b * a.special_W + w0 + lane];
+        unsigned long long nz = __ballot(word != 0ull);               // (T <= 0: an image without GT contributes nothing; the stream wrote zeros)
+        if (nz) {
+            const int nf = a.num_fg[b];
+            const float scale = (1.0f / (float)(nf > 1 ? nf : 1)) * a.inv_B;
+            const float gm_ign = a.p.alpha * scale;
+            const unsigned long long below = (1ull << lane) - 1ull;
+            int n = 0;
+            while (nz) {
+                const int it = __ffsll((long long)nz) - 1;
+                nz &= nz - 1;
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(word & 0xffffffffull), it);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(word >> 32), it);
+                const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+                if ((m >> lane) & 1ull) s_rows[wave][n + __popcll(m & below)] = (unsigned short)(it * 64 + lane);
+                n += __popcll(m);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            int n_ign = 0;
+#pragma unroll 1
+            for (int i0 = 0; i0 < n; i0 += RN_WAVE) {
+                const bool have = i0 + lane < n;
+                const int64_t ag = w0 * 64 + (have ? (int64_t)s_rows[wave][i0 + lane] : 0);
+                const bool ok = have && ag < a.A;
+                int li = 0;
+                int64_t base = 0, A_l = 1;
+#pragma unroll 1
+                for (int l = 0; l < a.L; ++l) {
+                    const bool in = ag >= a.lv[l].base && ag < a.lv[l].base + a.lv[l].A_l;
+                    if (in) { li = l; base = a.lv[l].base; A_l = a.lv[l].A_l; }
+                }
+                const int64_t r = (int64_t)b * A_l + (ag - base);             // row inside the level tensor
+                int pmv = -1;
+                rn::f32x4 an = {0.f, 0.f, 0.f, 0.f};
+                float pred[4] = {0.f, 0.f, 0.f, 0.f};
+                if (ok) {
+                    pmv = (int)a.matches[(int64_t)b * a.A + ag];
+                    an = a.anchors[(int64_t)b * a.anchor_bstride4 + ag];
+                    box4<DT>::ld(s_lv[li].box, r, pred);
+                }
+                const bool matched = ok && pmv >= 0, ign = ok && pmv == -2;
+                int code = -1;
+                rn::f32x4 g = {0.f, 0.f, 1.f, 1.f};
+                if (matched) { code = (int)a.gt_labels[t0 + pmv] - 1; g = a.gt_boxes[t0 + pmv]; }
+                const bool pos_ok = matched && code >= 0 && code < K;
+                const int64_t e_pos = r * K + code;
+                float xp = 0.0f;
+                if (pos_ok) xp = D::ld(s_lv[li].cls, e_pos);
+                if (pos_ok) {
+                    float wb, gbg, l, gr;
+                    bg_elem<GAMMA2>(xp, a.p, wb, gbg);
+                    focal_elem<GAMMA2>(xp, true, a, l, gr);
+                    acc += (double)l * (double)scale - (double)wb * (double)gm_ign;
+                    if (WRITE_GRAD) D::st(s_lv[li].gcls, e_pos, gr * (scale * gs));
+                }
+                if (matched) {
+                    float gb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    const float l = reg_row(g, an, pred, a.p, gb);
+                    reg += (double)(l * scale);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) gb[j] *= scale * gs;
+                    if (WRITE_GRAD) box4<DT>::st(s_lv[li].gbox, r, gb);
+                }
+                const unsigned long long imask = __ballot(ign);
+                if (ign) {
+                    const int pos = n_ign + __popcll(imask & below);
+                    s_ign_r[wave][pos] = (int)r;
+                    s_ign_l[wave][pos] = (unsigned char)li;
+                }
+                n_ign += __popcll(imask);
+            }
+            if (n_ign) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (VEC == 8 && !(K & 1)) {
+                    // 16-bit logits, even K: a row is K / 2 whole dwords -- two elements per memory instruction
+                    const int K2 = K >> 1, total2 = n_ign * K2;
+#pragma unroll 1
+                    for (int tb = 0; tb < total2; tb += RN_WAVE * REPAIR_IGN_U) {
+                        uint32_t xs[REPAIR_IGN_U];
+                        uint32_t *gp[REPAIR_IGN_U];
+                        bool okk[REPAIR_IGN_U];
+#pragma unroll
+                        for (int u = 0; u < REPAIR_IGN_U; ++u) {
+                            const int tt = tb + u * RN_WAVE + lane;
+                            const int t = min(tt, total2 - 1);
+                            const int j = t / K2, k2 = t - j * K2;
+                            const int l = s_ign_l[wave][j];
+                            const int64_t d = ((int64_t)s_ign_r[wave][j] * K >> 1) + k2;
+                            okk[u] = tt < total2;
+                            xs[u] = ((const uint32_t *)s_lv[l].cls)[d];
+                            gp[u] = (uint32_t *)s_lv[l].gcls + d;
+                        }
+#pragma unroll
+                        for (int u = 0; u < REPAIR_IGN_U; ++u) {
+                            if (okk[u]) {
+                                const float x0 = DT == RN_BF16 ? __uint_as_float(xs[u] << 16) : rn::half_lo(xs[u]);
+                                const float x1 = DT == RN_BF16 ? __uint_as_float(xs[u] & 0xffff0000u) : rn::half_hi(xs[u]);
+                                float wb0, wb1, gbg;
+                                bg_elem<GAMMA2>(x0, a.p, wb0, gbg);
+                                bg_elem<GAMMA2>(x1, a.p, wb1, gbg);
+                                acc -= (double)(wb0 + wb1) * (double)gm_ign;
+                                if (WRITE_GRAD) *gp[u] = 0u;
+                            }
+                        }
+                    }
+                } else {
+                    const int total = n_ign * K;
+#pragma unroll 1
+                    for (int tb = 0; tb < total; tb += RN_WAVE * REPAIR_IGN_U) {
+                        float xs[REPAIR_IGN_U];
+                        int64_t es[REPAIR_IGN_U];
+                        int ls[REPAIR_IGN_U];
+                        bool okk[REPAIR_IGN_U];
+#pragma unroll
+                        for (int u = 0; u < REPAIR_IGN_U; ++u) {
+                            const int tt = tb + u * RN_WAVE + lane;
+                            const int t = min(tt, total - 1);
+                            const int j = t / K, k = t - j * K;
+                            ls[u] = s_ign_l[wave][j];
+                            es[u] = (int64_t)s_ign_r[wave][j] * K + k;
+                            okk[u] = tt < total;
+                            xs[u] = D::ld(s_lv[ls[u]].cls, es[u]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < REPAIR_IGN_U; ++u) {
+                            if (okk[u]) {
+                                float wb, gbg;
+                                bg_elem<GAMMA2>(xs[u], a.p, wb, gbg);
+                                acc -= (double)wb * (double)gm_ign;
+                                if (WRITE_GRAD) D::st(s_lv[ls[u]].gcls, es[u], 0.0f);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const double accw = rn::wave_sum_d(acc), regw = rn::wave_sum_d(reg);
+    if (lane == 0) { s_part[wave][0] = accw; s_part[wave][1] = regw; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double c = 0.0, rg = 0.0;
+#pragma unroll
+        for (int w = 0; w < REPAIR_WAVES; ++w) { c += s_part[w][0]; rg += s_part[w][1]; }
+        if (c != 0.0 || rg != 0.0) fin_add(a.fin, c, rg, true);     // (a NaN partial compares unequal: it is added)
+        // arrival: the sums above have been performed (returning adds); the workgroup that takes the last ticket finishes the call
+        const unsigned ticket = __hip_atomic_fetch_add(a.fin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (ticket == gridDim.x - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last && wave == 0) {
+        static_assert(FIN_LINES == RN_WAVE, "one line per lane");
+        unsigned *const mine = a.fin + lane * 16;
+        unsigned long long *const msum = (unsigned long long *)(mine + 2);
+        long long sc = (long long)__hip_atomic_load(msum + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long long sr = (long long)__hip_atomic_load(msum + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned fl = __hip_atomic_load(mine + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            sc += shfl_xor_ll(sc, o); sr += shfl_xor_ll(sr, o);
+            fl |= (unsigned)__shfl_xor((int)fl, o, RN_WAVE);
+        }
+        __hip_atomic_store(msum + 0, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(msum + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+            a.out_loss[0] = loss_unfix(sc, fl & 0xffu);
+            a.out_loss[1] = loss_unfix(sr, (fl >> 8) & 0xffu);
         }
     }
 }
@@ -1018,6 +1436,34 @@ int launch_loss(LossArgs &a, bool gamma2, bool wg, hipStream_t st, int *ns, cons
     return RN_OK;
 }
 
+template <int DT>
+int launch_loss_rp(LossArgs &a, bool gamma2, bool wg, hipStream_t st)
+{
+    constexpr int VEC = rn::dt<DT>::VEC;
+    int n_stream = 0, rc;
+    if (gamma2) {
+        if (wg) rc = launch_stream(loss_bg_kernel<DT, true, true, 2, 1>, a, VEC, st, &n_stream);
+        else rc = launch_stream(loss_bg_kernel<DT, true, false, 2, 1>, a, VEC, st, &n_stream);
+    } else {
+        if (wg) rc = launch_stream(loss_bg_kernel<DT, false, true, 2, 1>, a, VEC, st, &n_stream);
+        else rc = launch_stream(loss_bg_kernel<DT, false, false, 2, 1>, a, VEC, st, &n_stream);
+    }
+    if (rc != RN_OK) return rc;
+    const int spi = (int)((a.special_W + REPAIR_WORDS - 1) / REPAIR_WORDS);
+    const int64_t total = (int64_t)a.B * spi;
+    if (total >= ((int64_t)1 << 30)) return RN_EUNSUPPORTED;
+    const dim3 grid((unsigned)((total + REPAIR_WAVES - 1) / REPAIR_WAVES));
+    if (gamma2) {
+        if (wg) hipLaunchKernelGGL((loss_repair_kernel<DT, true, true>), grid, dim3(REPAIR_BLOCK), 0, st, a, spi, (int)total);
+        else hipLaunchKernelGGL((loss_repair_kernel<DT, true, false>), grid, dim3(REPAIR_BLOCK), 0, st, a, spi, (int)total);
+    } else {
+        if (wg) hipLaunchKernelGGL((loss_repair_kernel<DT, false, true>), grid, dim3(REPAIR_BLOCK), 0, st, a, spi, (int)total);
+        else hipLaunchKernelGGL((loss_repair_kernel<DT, false, false>), grid, dim3(REPAIR_BLOCK), 0, st, a, spi, (int)total);
+    }
+    RN_LAUNCH_CHECK();
+    return RN_OK;
+}
+
 }  // namespace
 
 RN_API size_t rn_loss_workspace_bytes(int B, int64_t A, int K)
@@ -1035,20 +1481,23 @@ static int loss_levels_core(const void *const *cls_levels, const void *const *bo
                             const int64_t *gt_labels, const int32_t *gt_off, const int64_t *matches, const uint64_t *special_rows,
                             const int32_t *num_fg, const rn_loss_params *params, float *out_loss,
                             void *const *grad_cls_levels, void *const *grad_box_levels, void *workspace,
-                            size_t workspace_bytes, void *stream, const FusedMatch *fm = nullptr, void *fin_state = nullptr)
+                            size_t workspace_bytes, void *stream, const FusedMatch *fm = nullptr, void *fin_state = nullptr,
+                            const float *grad_prescale = nullptr, const bool repair_pass = false)
 {
     if (fin_state && (fm || !rn::aligned(fin_state, 64))) return fm ? RN_EINVAL : RN_EALIGN;
-    if (!cls_levels || !box_levels || !level_anchors || !anchors || !gt_off || !params || !out_loss || !workspace) return RN_EINVAL;
+    if (repair_pass && (!fin_state || !special_rows)) return RN_EINVAL;
+    if (!cls_levels || !box_levels || !level_anchors || !anchors || !gt_off || !params || !out_loss || (!workspace && !repair_pass)) return RN_EINVAL;
     if (!fm && (!matches || !num_fg)) return RN_EINVAL;
     if (L <= 0 || L > RN_MAX_LEVELS || B <= 0 || K <= 0) return RN_EINVAL;
     if ((grad_cls_levels == nullptr) != (grad_box_levels == nullptr)) return RN_EINVAL;
     if (dtype != RN_F32 && dtype != RN_BF16 && dtype != RN_F16) return RN_EINVAL;
     if (K > 4096) return RN_EUNSUPPORTED;
-    if (workspace_bytes < rn_loss_workspace_bytes(B, 1, K)) return RN_EWORKSPACE;
+    if (!repair_pass && workspace_bytes < rn_loss_workspace_bytes(B, 1, K)) return RN_EWORKSPACE;
     const size_t box_al = (dtype == RN_F32) ? 16 : 8;
     const int vec = (dtype == RN_F32) ? 4 : 8;
-    if (!rn::aligned(anchors, 16) || (gt_boxes && !rn::aligned(gt_boxes, 16)) || !rn::aligned(workspace, 16) || (anchor_bstride & 3))
+    if (!rn::aligned(anchors, 16) || (gt_boxes && !rn::aligned(gt_boxes, 16)) || (workspace && !rn::aligned(workspace, 16)) || (anchor_bstride & 3))
         return RN_EALIGN;
+    if (grad_prescale && !rn::aligned(grad_prescale, 4)) return RN_EALIGN;
 
     LossArgs a;
     a.L = L;
@@ -1088,6 +1537,7 @@ static int loss_levels_core(const void *const *cls_levels, const void *const *bo
     a.part_stream = (float2 *)workspace;
     a.fin = fin_state ? (unsigned *)fin_state + 64 : nullptr;           // 64 cache lines from byte 256 on (words 0, 1: the fused form's barrier words)
     a.out_loss = out_loss;
+    a.gscale = grad_prescale;
     a.fg_thr = a.bg_thr = 0.0f; a.nfg_acc = nullptr; a.bar = nullptr; a.matches_out = nullptr;
     if (fm) {
         a.fg_thr = fm->fg_thr; a.bg_thr = fm->bg_thr; a.matches_out = fm->matches_out;
@@ -1100,6 +1550,20 @@ static int loss_levels_core(const void *const *cls_levels, const void *const *bo
     const bool wg = grad_cls_levels != nullptr;
     hipStream_t st = (hipStream_t)stream;
     int ns = 0, rc;
+    if (repair_pass) {
+        // two launches: the pure background stream, then the repair of the special rows + the finalize.  The caller's event pair
+        // brackets BOTH (the whole of K3's device time): the stop event is recorded here, behind the repair kernel.
+        const hipEvent_t stop = g_prof.stop;
+        g_prof.stop = nullptr;
+        switch (dtype) {
+            case RN_F32: rc = launch_loss_rp<RN_F32>(a, gamma2, wg, st); break;
+            case RN_BF16: rc = launch_loss_rp<RN_BF16>(a, gamma2, wg, st); break;
+            default: rc = launch_loss_rp<RN_F16>(a, gamma2, wg, st); break;
+        }
+        if (rc != RN_OK) return rc;
+        if (stop) RN_HIP(hipEventRecord(stop, st));
+        return RN_OK;
+    }
     switch (dtype) {
         case RN_F32: rc = launch_loss<RN_F32>(a, gamma2, wg, st, &ns, fm != nullptr); break;
         case RN_BF16: rc = launch_loss<RN_BF16>(a, gamma2, wg, st, &ns, fm != nullptr); break;
@@ -1154,6 +1618,24 @@ RN_API int rn_loss_fwd_bwd_levels_fin(const void *const *cls_levels, const void 
     const int rc = loss_levels_core(cls_levels, box_levels, level_anchors, L, dtype, B, K, anchors, anchor_bstride, gt_boxes, gt_labels,
                                     gt_off, matches, special_rows, num_fg, params, out_loss, grad_cls_levels, grad_box_levels, workspace,
                                     workspace_bytes, stream, nullptr, state);
+    g_prof.start = g_prof.stop = nullptr;
+    return rc;
+}
+
+RN_API int rn_loss_fwd_bwd_levels_rp(const void *const *cls_levels, const void *const *box_levels,
+                                     const int64_t *level_anchors, int L, int dtype, int B, int K,
+                                     const float *anchors, int64_t anchor_bstride, const float *gt_boxes,
+                                     const int64_t *gt_labels, const int32_t *gt_off, const int64_t *matches,
+                                     const uint64_t *special_rows, const int32_t *num_fg, const rn_loss_params *params,
+                                     const float *grad_prescale, int repair_pass, float *out_loss, void *const *grad_cls_levels,
+                                     void *const *grad_box_levels, void *workspace, size_t workspace_bytes, void *state,
+                                     void *stream, void *event_start, void *event_stop)
+{
+    if (!state) return RN_EINVAL;
+    g_prof.start = (hipEvent_t)event_start; g_prof.stop = (hipEvent_t)event_stop;
+    const int rc = loss_levels_core(cls_levels, box_levels, level_anchors, L, dtype, B, K, anchors, anchor_bstride, gt_boxes, gt_labels,
+                                    gt_off, matches, special_rows, num_fg, params, out_loss, grad_cls_levels, grad_box_levels, workspace,
+                                    workspace_bytes, stream, nullptr, state, grad_prescale, repair_pass != 0);
     g_prof.start = g_prof.stop = nullptr;
     return rc;
 }

@@ -215,7 +215,10 @@ class CapturedTrainStep:
         else:
             opt.zero_grad(set_to_none=True)
         dev_type = images[0].device.type
-        with torch.autocast(dev_type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None, cache_enabled=False):
+        from .losses import grad_prescale, scaler_prescale
+        # fp16: the loss kernel multiplies the GradScaler's scale into its gradients before it rounds them to fp16 (losses.grad_prescale)
+        pre = scaler_prescale(self.scaler, images[0].device) if images[0].is_cuda else None
+        with torch.autocast(dev_type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None, cache_enabled=False), grad_prescale(pre):
             losses = net(list(images), [dict(t) for t in targets])
             total = losses["classification_loss"] + losses["regression_loss"]
         if self.scaler is not None:

@@ -72,6 +72,43 @@ FUSE_MATCH = os.environ.get("RN_FUSE_MATCH", "0") == "1"
 # The two batch losses from the streaming kernel itself instead of a one-block finalize launch behind it (rn_loss_fwd_bwd_levels_fin:
 # fixed-point partial sums through device-scope atomics, workgroup 0 waits for the last arrival): same bits, one dependent launch less
 IN_KERNEL_FINALIZE = True
+# K3 as TWO launches (round 6, rn_loss_fwd_bwd_levels_rp): a pure background stream over the logits and a repair kernel that walks
+# K2's flag words with one special row per lane (and finishes the sums).  Inside the streaming kernel the repair is a serial prefix
+# of every wave whose length follows the local density of special rows; split off, the special rows are balanced over the chip.
+K3_REPAIR_PASS = True
+
+# Gradient pre-scale (fp16 training): a device f32 scalar -- a torch.amp.GradScaler's ``_scale`` -- that K3 multiplies into every
+# gradient BEFORE rounding it to fp16.  K3 writes d loss / d logits in the forward pass; a background element at the prior has
+# 0.25 p^3 / (num_fg B) ~ 4e-10, below fp16's smallest subnormal (6e-8): stored unscaled it is zero whatever backward multiplies in
+# later.  The reference's native-AMP run scales the fp32 loss first and keeps them (~2.6e-5 at a scale of 65 536).  backward then
+# multiplies by upstream / prescale (exactly 1 under ``scaler.scale(loss).backward()``).
+_GRAD_PRESCALE = None
+
+
+class grad_prescale:
+    "``with grad_prescale(scaler_scale_tensor):`` -- fused loss calls inside the block pre-scale their gradients by it."
+
+    def __init__(self, scale: Optional[Tensor]):
+        self.scale = scale
+
+    def __enter__(self):
+        global _GRAD_PRESCALE
+        self.prev, _GRAD_PRESCALE = _GRAD_PRESCALE, self.scale
+        return self
+
+    def __exit__(self, *exc):
+        global _GRAD_PRESCALE
+        _GRAD_PRESCALE = self.prev
+        return False
+
+
+def scaler_prescale(scaler, dev) -> Optional[Tensor]:
+    "The device scalar of a ``torch.amp.GradScaler`` (created on first use), or None when there is no enabled scaler."
+    if scaler is None or not scaler.is_enabled():
+        return None
+    if getattr(scaler, "_scale", None) is None:
+        scaler._lazy_init_scale_growth_tracker(torch.device(dev))
+    return scaler._scale
 
 
 def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
@@ -99,6 +136,7 @@ class _FusedDenseHeadLossLevels(torch.autograd.Function):
             fused = ops.loss_match_fwd_bwd_levels(cls_levels, box_levels, anchors, gt_boxes, gt_labels, gt_off, int(ahead), fg_thr,
                                                   bg_thr, params, want_grad)
             ahead = None
+        ctx.prescale = None
         if fused is not None:
             loss, gcls, gbox = fused[0], fused[1], fused[2]
         else:
@@ -109,8 +147,11 @@ class _FusedDenseHeadLossLevels(torch.autograd.Function):
                 # `matches` goes nowhere but into the loss kernel, which reads it through the flag words: K2 writes the flagged rows only
                 matches, num_fg, special = ops.iou_match(anchors, gt_boxes, gt_off, B, fg_thr, bg_thr, want_special=True, flagged_only=True,
                                                          zeroed_num_fg=pack.num_fg if pack is not None else None)
+            pre = _GRAD_PRESCALE if (want_grad and _GRAD_PRESCALE is not None and _GRAD_PRESCALE.device == cls_levels[0].device) else None
             loss, gcls, gbox = ops.loss_fwd_bwd_levels(cls_levels, box_levels, anchors, gt_boxes, gt_labels, gt_off, matches,
-                                                       num_fg, params, want_grad, special=special, in_kernel_finalize=IN_KERNEL_FINALIZE)
+                                                       num_fg, params, want_grad, special=special, in_kernel_finalize=IN_KERNEL_FINALIZE,
+                                                       grad_prescale=pre, repair_pass=K3_REPAIR_PASS and special is not None)
+            ctx.prescale = pre
         ctx.grads = (gcls, gbox)
         ctx.meta = [(c.shape, c.dtype) for c in cls_levels] + [(b.shape, b.dtype) for b in box_levels]
         # two scalar outputs (views of the kernel's f32[2]): backward then receives the two upstream scalars directly, without
@@ -127,6 +168,9 @@ class _FusedDenseHeadLossLevels(torch.autograd.Function):
         dev = gcls[0].device
         g0 = torch.full((1,), 0.0, device=dev) if g0 is None else g0.reshape(1)
         g1 = torch.full((1,), 0.0, device=dev) if g1 is None else g1.reshape(1)
+        pre = getattr(ctx, "prescale", None)
+        if pre is not None:                 # the gradients already carry the pre-scale: what is left is upstream / prescale (1 under a GradScaler)
+            g0, g1 = g0.float() / pre.reshape(1), g1.float() / pre.reshape(1)
         ops.scale_inplace_batched(list(gcls) + list(gbox), [g0] * len(gcls) + [g1] * len(gbox))      # one launch
         outs = [t.view(shape) if t.dtype == dt else t.to(dt).view(shape) for t, (shape, dt) in zip(list(gcls) + list(gbox), ctx.meta)]
         return (None,) * 9 + tuple(outs)

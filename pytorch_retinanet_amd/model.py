@@ -250,7 +250,8 @@ class SimpleTrainer:
                                                  for t in targets])
                     self.captured_steps = stepper.replays
                 else:
-                    with self._autocast():
+                    from .losses import grad_prescale, scaler_prescale
+                    with self._autocast(), grad_prescale(scaler_prescale(scaler, self.device)):
                         out = model.training_step(batch, i)
                     ddp.zero_grad() if ddp else optimizer.zero_grad(set_to_none=False)
                     if scaler is not None:

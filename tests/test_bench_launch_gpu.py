@@ -38,3 +38,21 @@ def test_bench_two_ranks_through_self_launch_on_one_gpu():
     assert 0 < line["config"]["final_loss"] < 100
     assert "cpu_baseline" not in line                               # rank 0 at N = 1 only
     assert line["roofline"]["frac"] and line["roofline"]["bound"] == "hbm"
+
+
+def test_bench_fp16_matcher_stress_line_with_the_cpu_baseline():
+    """BASELINE configs[4] as the documented command (`bench.py --amp fp16 --gt 500`) WITH the CPU baseline: round 5's
+    line crashed with a NameError behind the timed region (a pasted block in `cpu_train_step_baseline`), and no test ran the flag."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--amp", "fp16", "--gt", "500", "--steps", "3", "--warmup", "3", "--no-detect",
+           "--cpu-baseline-reps", "2", "--timing-steps", "1"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=2400)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.strip()][-1])
+    assert line["dtype"] == "fp16" and "T=500" in line["config"]["workload"] and "GradScaler" in line["config"]["workload"]
+    assert "fp16" in line["roofline"]["kernel"] and "bf16" not in line["roofline"]["kernel"]
+    assert line["roofline"]["frac"] > 0.2 and 0 < line["config"]["final_loss"] < 100
+    cb = line["cpu_baseline"]
+    assert cb["value"] > 0 and cb["kind"] == "port" and cb["train_step"]["value"] > 0 and "T=500" in cb["sample"]

@@ -22,7 +22,7 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     for name in declared:
         assert hasattr(_lib.lib, name), name
-    assert _lib.lib.rn_version() == 9
+    assert _lib.lib.rn_version() == 10
     assert b"alignment" in _lib.lib.rn_status_string(-2)
 
 
