@@ -451,6 +451,9 @@ def predict_e2e_line(args, device, with_cpu):
     return line
 
 
+K3_FORM_NAMES = {0: "rn_loss_fwd_bwd_levels_fin (one launch, special rows chunk by chunk, in-kernel finalize)",
+                 1: "rn_loss_fwd_bwd_levels_rp form 1 (background stream + repair kernel + finalize: two launches)",
+                 2: "rn_loss_fwd_bwd_levels_rp form 2 (one launch, special rows through one compact list, in-kernel finalize)"}
 VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector peak (256 CUs x 128 lanes x 2 flop x 2.4 GHz)
 
 
@@ -520,7 +523,7 @@ def match_plus_loss_line(device, B, T, dtype, label):
     def pair():
         (m, nfg, sp), gt_boxes, gt_labels, off = k2_only()
         return ops.loss_fwd_bwd_levels(cls, box, anc, gt_boxes, gt_labels, off, m, nfg, params, True, special=sp,
-                                       in_kernel_finalize=L.IN_KERNEL_FINALIZE, repair_pass=L.K3_REPAIR_PASS)
+                                       in_kernel_finalize=L.IN_KERNEL_FINALIZE, form=L.k3_form(B * T, B))
 
     def writer_then_pair():
         writer()
@@ -532,7 +535,7 @@ def match_plus_loss_line(device, B, T, dtype, label):
 
     def k3_only():
         return ops.loss_fwd_bwd_levels(cls, box, anc, gt_boxes, gt_labels, off, m, nfg, params, True, special=sp,
-                                       in_kernel_finalize=L.IN_KERNEL_FINALIZE, repair_pass=L.K3_REPAIR_PASS)
+                                       in_kernel_finalize=L.IN_KERNEL_FINALIZE, form=L.k3_form(B * T, B))
 
     t_k2 = graph_replay_ms(k2_only)
     t_k3 = graph_replay_ms(k3_only)
@@ -545,8 +548,7 @@ def match_plus_loss_line(device, B, T, dtype, label):
     pairs = B * A * T
     return {"bound": "hbm (K2 at T = 500: fp32 VALU)", "workload": f"{label}: B={B} A={A} K={K} T={T} {str(dtype).replace('torch.', '')}, {n_fg // B} matched rows/image"
             + (f", {n_special // B} special rows/image" if n_special is not None else ""),
-            "kernels": "rn_copy_many (gt_pack) + rn_iou_match_special_ex (flagged rows only) + rn_loss_fwd_bwd_levels_rp (background stream + repair + finalize)"
-                       if L.K3_REPAIR_PASS else "gt_pack + rn_iou_match_special_ex + rn_loss_fwd_bwd_levels_fin",
+            "kernels": "rn_copy_many (gt_pack) + rn_iou_match_special_ex (flagged rows only) + K3 " + K3_FORM_NAMES[L.k3_form(B * T, B)],
             "timing": "hipGraph of the calls replayed 20 x back to back between one event pair, median of 5 loops / 20",
             "k2_ms": round(t_k2, 4), "k3_ms": round(t_k3, 4), "pair_ms": round(t_pair, 4),
             "pair_ms_after_writer": round(t_wp - t_w, 4), "writer_ms": round(t_w, 4),
@@ -584,7 +586,7 @@ def k3_cold_line(device, B, T, nbytes):
     for _ in range(13):
         evict.fill_(1)
         ops.loss_fwd_bwd_levels(cls, box, anc, gt_boxes, gt_labels, off, matches, num_fg, params, special=special,
-                                in_kernel_finalize=L.IN_KERNEL_FINALIZE, repair_pass=L.K3_REPAIR_PASS)
+                                in_kernel_finalize=L.IN_KERNEL_FINALIZE, form=L.k3_form(B * T, B))
     torch.cuda.synchronize()
     ev = ops.timing_events()["loss_stream_kernel"][3:]
     ops.enable_timing(False)
@@ -734,9 +736,10 @@ def main():
             except Exception:          # noqa: BLE001
                 traffic = None
         from pytorch_retinanet_amd import losses as L_
+        form_run = L_.k3_form(args.batch * args.gt, args.batch)
         k3_name = (f"loss_bg_kernel<{args.amp}> + loss_repair_kernel<{args.amp}> (K3 focal + smooth-L1 loss, forward + gradients + finalize: background stream, "
-                   f"then the special rows; HIP events around the PAIR of kernels)") if L_.K3_REPAIR_PASS else \
-            f"loss_stream_kernel<{args.amp}> (K3 focal + smooth-L1 loss, forward + gradients; HIP events right around the kernel)"
+                   f"then the special rows; HIP events around the PAIR of kernels)") if form_run == 1 else \
+            f"loss_stream_kernel<{args.amp}{', list form' if form_run == 2 else ''}> (K3 focal + smooth-L1 loss, forward + gradients + in-kernel finalize; HIP events right around the kernel)"
         roof = {"bound": "hbm", "kernel": k3_name,
                 "achieved": round(nbytes / (k3_ms * 1e-3) / 1e9, 1) if k3_ms else None, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(nbytes / (k3_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k3_ms else None,

@@ -196,17 +196,28 @@ int rn_loss_fwd_bwd_levels_fin(const void *const *cls_levels, const void *const 
  *                  element at the prior) are stored as ~2.6e-5; written unscaled they would flush to zero below fp16's
  *                  smallest subnormal (6e-8) before any later multiplication.  The caller multiplies by upstream / prescale
  *                  in backward (a no-op when upstream == prescale).
- *   repair_pass    0: one launch, the special rows repaired inside the streaming kernel (the _fin form).
- *                  1: TWO launches -- a pure background stream over the logits (no row logic) and a repair kernel that walks
- *                  the flag words (`special_rows`, required), gives every lane one special row and finishes the sums; `workspace`
- *                  may be NULL.  Same arithmetic; the event pair brackets both kernels.  Losses equal the one-launch form to the
- *                  last bits of the 2^-32 fixed-point sums, gradients bit for bit. */
+ *   form           how the special rows (matched / ignored: the flag words) are repaired.  Same arithmetic in all three; gradients
+ *                  bit for bit, losses to the last bits of the 2^-32 fixed-point sums:
+ *                  RN_LOSS_FORM_CHUNKS (0)       one launch; every streaming wave repairs its own range before / after its stream,
+ *                                                64-row chunk by chunk (the _fin form).  Best at the train shape (~0.3 % special rows).
+ *                  RN_LOSS_FORM_REPAIR_PASS (1)  TWO launches -- a pure background stream over the logits (no row logic) and a repair
+ *                                                kernel that walks the flag words (`special_rows` required), one special row per lane,
+ *                                                and finishes the sums; `workspace` may be NULL; the event pair brackets both.
+ *                                                Measured slower on MI355X (the repair's dependent loads have nothing to hide under);
+ *                                                kept for A/B.
+ *                  RN_LOSS_FORM_LIST (2)         one launch; the flagged rows of ALL of a wave's chunks go through one compact list
+ *                                                (the dependent loads run once per 64 special rows, not once per chunk) and ignored rows
+ *                                                move as 16-byte pieces.  Best from ~32 GT boxes per image on (BASELINE configs[4]:
+ *                                                500 per image, ~19 k special rows per image). */
+#define RN_LOSS_FORM_CHUNKS 0
+#define RN_LOSS_FORM_REPAIR_PASS 1
+#define RN_LOSS_FORM_LIST 2
 int rn_loss_fwd_bwd_levels_rp(const void *const *cls_levels, const void *const *box_levels,
                               const int64_t *level_anchors, int L, int dtype, int B, int K,
                               const float *anchors, int64_t anchor_bstride, const float *gt_boxes,
                               const int64_t *gt_labels, const int32_t *gt_off, const int64_t *matches,
                               const uint64_t *special_rows, const int32_t *num_fg, const rn_loss_params *params,
-                              const float *grad_prescale, int repair_pass, float *out_loss, void *const *grad_cls_levels,
+                              const float *grad_prescale, int form, float *out_loss, void *const *grad_cls_levels,
                               void *const *grad_box_levels, void *workspace, size_t workspace_bytes, void *state,
                               void *stream, void *event_start, void *event_stop);
 /* K2 + K3 in ONE launch (round 4): the matcher of retinanet/box_utils.py:51-80 runs in the loss kernel's prologue -- every wave

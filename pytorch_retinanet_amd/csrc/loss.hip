@@ -204,6 +204,8 @@ __device__ __forceinline__ float image_gmul(const LossArgs &a, const int b)
 constexpr int LIST_CAP_PLAIN = 320;  // rows of a wave's range whose repair goes through the LDS lists (5 chunks of 64; 273 at the train shape)
 constexpr int LIST_CAP_FUSED = 384;  // fused matching: EVERY row of the range must fit (it runs at 5 workgroups per CU: 319 rows at the train shape)
 constexpr int IGN_U = 4;            // independent element loads per lane per round in the ignored-row repair
+constexpr int IGN_V = 2;            // independent 16-byte pieces per lane per round there
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));   // a 16-byte access at a dword-aligned address
 
 // Per-workgroup loss partials as 2^-32 fixed point (|partial| < 2^31: a workgroup sums at most a few 10^5 elements of O(10) each):
 // the sum over the workgroups is then an INTEGER sum -- the same bits in any order -- so neither the finalize kernel nor the
@@ -232,14 +234,15 @@ __device__ __forceinline__ float loss_unfix(const long long s, const unsigned fl
     if (flags & 4u) return -__builtin_inff();
     return (float)((double)s * (1.0 / 4294967296.0));
 }
-template <int DT, bool GAMMA2, bool WRITE_GRAD, int PF, int NT, bool FUSED = false>
-__global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs a)
+template <int DT, bool GAMMA2, bool WRITE_GRAD, int PF, int NT, bool FUSED = false, bool LIST = false>
+__global__ __launch_bounds__(LOSS_BLOCK) __attribute__((amdgpu_waves_per_eu((FUSED || !GAMMA2) ? 5 : 6))) void loss_stream_kernel(const LossArgs a)
 {
     typedef rn::dt<DT> D;
     constexpr int VEC = D::VEC;
     constexpr int LIST_CAP = FUSED ? LIST_CAP_FUSED : LIST_CAP_PLAIN;
     __shared__ float s_part[LOSS_WAVES][2];
     __shared__ signed char s_pmv[FUSED ? LOSS_WAVES : 1][FUSED ? LIST_CAP : 1];   // fused matching: match code of every row of the wave's range
+    __shared__ unsigned short s_flag[LIST ? LOSS_WAVES : 1][LIST ? LIST_CAP : 1];   // (LIST) flagged rows of the wave's range (offsets from its first row), all chunks in one list
     __shared__ unsigned short s_ign_row[LOSS_WAVES][LIST_CAP];   // ignored rows of the wave's range (offsets from its first row)
     __shared__ float s_ign_gm[LOSS_WAVES][LIST_CAP];            // their alpha/(max(nfg,1)*B)
     __shared__ int s_pos_off[LOSS_WAVES][LIST_CAP];             // positive elements of matched rows: offset from the range's first element
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
         // final here.  A chunk of 64 rows costs two SCALAR loads when it has no special row (5 chunks of 6): the words of
         // rn_iou_match_special; `matches` is read only by the lanes whose flag is set.
         const int64_t cap_hi = min(row_hi, row_lo + (int64_t)LIST_CAP - 1);        // rows [row_lo, cap_hi] go through the lists
-        int n_pos = 0, n_ign = 0;
+        int n_pos = 0, n_ign = 0, n_ign_b = 0;                                     // (n_ign_b: ignored rows shared with a neighbouring wave, listed from the back)
         auto prep = [&]() {
             if (WRITE_GRAD) {
                 // zero box gradients of the rows this wave owns, as 16-byte vectors (two 16-bit rows per lane); matched rows
@@ -407,6 +410,222 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                     }
                 }
             }
+            if constexpr (LIST) {
+            // ---- (1) which rows of the range are special: a 64-row chunk's flags are two SCALAR loads (the words of rn_iou_match_special);
+            // the flagged rows of ALL chunks go into ONE compact list.  The kernel is bound by its memory INSTRUCTIONS, not its bytes
+            // (an 8-byte access of three active lanes costs what a 16-byte access of 64 costs): at 500 GT boxes per image every chunk of
+            // a wave holds a few special rows, and chunk by chunk each paid the whole chain below -- match code, label, GT box, anchor,
+            // prediction, positive logit -- for a handful of lanes; from the list the chain runs once per 64 SPECIAL rows.
+            int n_flag = 0;
+            const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll 1
+            for (int64_t r0 = row_lo; r0 <= cap_hi; r0 += RN_WAVE) {                 // wave-uniform
+                const int n = (int)min((int64_t)RN_WAVE, cap_hi - r0 + 1);
+                unsigned long long m = ~0ull;                                      // no words (old entry points): look every row up
+                if (FUSED) {
+                    int pmv_l = -1;
+                    if (lane < n) pmv_l = s_pmv[wave][seg_off + (int)(r0 - row_lo) + lane];
+                    m = __ballot(pmv_l != -1);
+                } else if (a.special) {
+                    const int b0 = (int)((uint32_t)r0 / (uint32_t)lv.A_l);
+                    const int64_t a0 = r0 - (int64_t)b0 * lv.A_l;
+                    if (a0 + n <= lv.A_l) {                                        // the chunk lies inside one image
+                        const int64_t ag0 = lv.base + a0, w = ag0 >> 6;
+                        const int sh = (int)(ag0 & 63);
+                        const unsigned long long *p = a.special + (int64_t)b0 * a.special_W + w;
+                        const unsigned long long lo = p[0];
+                        const unsigned long long hi = (sh && w + 1 < a.special_W) ? p[1] : 0ull;
+                        m = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+                    } else {
+                        // the chunk straddles an image seam of this level: every lane looks its own bit up (`matches` may hold
+                        // NOTHING at rows without a flag: rn_iou_match_special_ex, RN_MATCH_FLAGGED_ONLY)
+                        bool f = false;
+                        if (lane < n) {
+                            const int64_t rr = r0 + lane;
+                            const int bb = (int)((uint32_t)rr / (uint32_t)lv.A_l);
+                            const int64_t agl = lv.base + (rr - (int64_t)bb * lv.A_l);
+                            f = (a.special[(int64_t)bb * a.special_W + (agl >> 6)] >> (agl & 63)) & 1ull;
+                        }
+                        m = __ballot(f);
+                    }
+                }
+                if (n < RN_WAVE) m &= (1ull << n) - 1ull;
+                if (!m) continue;
+                if ((m >> lane) & 1ull) s_flag[wave][n_flag + __popcll(m & below)] = (unsigned short)((int)(r0 - row_lo) + lane);
+                n_flag += __popcll(m);
+            }
+            if (n_flag) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            // ---- (2) the special rows, one per lane
+#pragma unroll 1
+            for (int i0 = 0; i0 < n_flag; i0 += RN_WAVE) {                          // wave-uniform
+                const bool flagged = i0 + lane < n_flag;
+                const int ro = (int)s_flag[wave][min(i0 + lane, n_flag - 1)];
+                const int64_t r = row_lo + ro;
+                int pmv = -1, b = 0;
+                int64_t ag = 0;
+                if (flagged) {
+                    b = (int)((uint32_t)r / (uint32_t)lv.A_l);
+                    ag = lv.base + (r - (int64_t)b * lv.A_l);
+                    pmv = FUSED ? (int)s_pmv[wave][seg_off + ro] : (int)a.matches[(int64_t)b * a.A + ag];
+                }
+                const bool special = flagged && pmv != -1;
+                int t0 = 0, T = 0, nf = 1;
+                if (special) { t0 = a.gt_off[b]; T = a.gt_off[b + 1] - t0; nf = load_nfg<FUSED>(a, b); }
+                const bool live = special && T > 0;                                // images without GT: phase A writes zeros
+                const bool matched = live && pmv >= 0, ign = live && pmv < 0;
+                const float scale = (1.0f / (float)(nf > 1 ? nf : 1)) * a.inv_B;
+                int code = -1;
+                if (matched) code = (int)a.gt_labels[t0 + pmv] - 1;
+                const int64_t e_pos = r * K + code;
+                const bool pos_ok = matched && code >= 0 && code < K && e_pos >= e_beg && e_pos < e_end;
+                float xp = 0.0f;
+                if (pos_ok) xp = D::ld(lv.cls, e_pos);
+                float gr = 0.0f;
+                if (pos_ok) {                                                      // matched row: only the positive element differs from what phase A does
+                    float wb, gbg, l;
+                    bg_elem<GAMMA2>(xp, a.p, wb, gbg);
+                    focal_elem<GAMMA2>(xp, true, a, l, gr);
+                    acc += (double)l * (double)scale - (double)wb * (double)(a.p.alpha * scale);
+                    gr *= scale * gs;
+                }
+                const unsigned long long pmask = __ballot(pos_ok);
+                if (pos_ok) {
+                    const int pos = n_pos + __popcll(pmask & below);
+                    s_pos_off[wave][pos] = (int)(e_pos - e_beg);
+                    s_pos_val[wave][pos] = gr;
+                }
+                n_pos += __popcll(pmask);
+                const bool mo = matched && r * K >= e_beg;                         // the row's first element is ours: its box gradient too
+                if (__any(mo)) {                                                   // wave-uniform
+                    if (mo) {
+                        float gb[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pred[4];
+                        box4<DT>::ld(lv.box, r, pred);
+                        const float l = reg_row(a.gt_boxes[t0 + pmv], a.anchors[(int64_t)b * a.anchor_bstride4 + ag], pred, a.p, gb);
+                        reg += l * scale;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) gb[j] *= scale * gs;
+                        if (WRITE_GRAD) box4<DT>::st(lv.gbox, r, gb);
+                    }
+                }
+                // ignored rows: those that lie wholly inside the range fill the list from the front (whole 16-byte pieces below), the
+                // at most two that another wave shares from the back (element-wise, clipped to the range)
+                const bool inner = r * K >= e_beg && (r + 1) * K <= e_end;
+                const unsigned long long imask = __ballot(ign && inner), bmask = __ballot(ign && !inner);
+                if (ign) {
+                    const int pos = inner ? n_ign + __popcll(imask & below) : LIST_CAP - 1 - (n_ign_b + __popcll(bmask & below));
+                    s_ign_row[wave][pos] = (unsigned short)ro;
+                    s_ign_gm[wave][pos] = a.p.alpha * scale;
+                }
+                n_ign += __popcll(imask);
+                n_ign_b += __popcll(bmask);
+            }
+            if (n_ign | n_ign_b) {                                                 // wave-uniform
+                // ignored rows: their background terms (which phase A will add) come out again; reads only -- the zero stores
+                // follow the stream.
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (VEC == 8 && !(K & 1)) {
+                    // 16-bit logits, even K: a row is K / 2 whole dwords starting on a 4-byte boundary.  Whole rows move as 16-BYTE pieces
+                    // (dword-aligned global_load_dwordx4: fine on gfx950, tools/misalign_probe.hip) + K / 2 mod 4 single dwords: a row of
+                    // K = 90 logits is 11 + 1 accesses instead of 45 -- at 500 GT boxes per image a wave has ~14 ignored rows, whose dword
+                    // accesses were as many memory instructions as a tenth of its stream, read side and store side each
+                    const int K2 = K >> 1, P = K2 >> 2, R = K2 & 3;
+                    const uint32_t *const src32 = (const uint32_t *)lv.cls;
+                    const int total_p = n_ign * P;
+#pragma unroll 1
+                    for (int tb = 0; tb < total_p; tb += RN_WAVE * IGN_V) {
+                        u32x4_a4 xs[IGN_V];
+                        float gms[IGN_V];
+                        bool ok[IGN_V];
+#pragma unroll
+                        for (int u = 0; u < IGN_V; ++u) {
+                            const int tt = tb + u * RN_WAVE + lane;
+                            const int t = min(tt, total_p - 1);
+                            const int j = t / P, pi = t - j * P;
+                            const int64_t d = (((row_lo + s_ign_row[wave][j]) * K) >> 1) + 4 * pi;
+                            gms[u] = s_ign_gm[wave][j];
+                            ok[u] = tt < total_p;
+                            xs[u] = *(const u32x4_a4 *)(src32 + d);
+                        }
+#pragma unroll
+                        for (int u = 0; u < IGN_V; ++u) {
+                            if (ok[u]) {
+                                float x[VEC], s = 0.0f;
+                                D::unpack(rn::u32x4{xs[u].x, xs[u].y, xs[u].z, xs[u].w}, x);
+#pragma unroll
+                                for (int q8 = 0; q8 < VEC; ++q8) {
+                                    float wb, gbg;
+                                    bg_elem<GAMMA2>(x[q8], a.p, wb, gbg);
+                                    s += wb;
+                                }
+                                acc -= (double)s * (double)gms[u];
+                            }
+                        }
+                    }
+                    // single dwords: the K / 2 mod 4 tail of every inner row, then all of the (<= 2) shared rows, clipped to the range
+                    const int total_r = n_ign * R, total_b = n_ign_b * K2;
+#pragma unroll 1
+                    for (int tb = 0; tb < total_r + total_b; tb += RN_WAVE * IGN_U) {
+                        uint32_t xs[IGN_U];
+                        float gms[IGN_U];
+                        bool ok[IGN_U];
+#pragma unroll
+                        for (int u = 0; u < IGN_U; ++u) {
+                            const int tt = tb + u * RN_WAVE + lane;
+                            const int t = min(tt, total_r + total_b - 1);
+                            int j, k2;
+                            if (t < total_r) { j = t / R; k2 = 4 * P + (t - j * R); }
+                            else { const int tq = t - total_r; const int jb = tq / K2; k2 = tq - jb * K2; j = LIST_CAP - 1 - jb; }
+                            const int64_t e = (row_lo + s_ign_row[wave][j]) * K + 2 * k2;
+                            gms[u] = s_ign_gm[wave][j];
+                            ok[u] = tt < total_r + total_b && e >= e_beg && e < e_end;
+                            xs[u] = src32[e >> 1];
+                        }
+#pragma unroll
+                        for (int u = 0; u < IGN_U; ++u) {
+                            if (ok[u]) {
+                                const float x0 = DT == RN_BF16 ? __uint_as_float(xs[u] << 16) : rn::half_lo(xs[u]);
+                                const float x1 = DT == RN_BF16 ? __uint_as_float(xs[u] & 0xffff0000u) : rn::half_hi(xs[u]);
+                                float wb0, wb1, gbg;
+                                bg_elem<GAMMA2>(x0, a.p, wb0, gbg);
+                                bg_elem<GAMMA2>(x1, a.p, wb1, gbg);
+                                acc -= (double)wb0 * (double)gms[u];
+                                acc -= (double)wb1 * (double)gms[u];
+                            }
+                        }
+                    }
+                } else {
+                    const int total = (n_ign + n_ign_b) * K;
+                    for (int t0 = 0; t0 < total; t0 += RN_WAVE * IGN_U) {
+                        float xs[IGN_U], gms[IGN_U];
+                        bool ok[IGN_U];
+#pragma unroll
+                        for (int u = 0; u < IGN_U; ++u) {
+                            const int t = min(t0 + u * RN_WAVE + lane, total - 1);
+                            const int jj = t / K, k = t - jj * K;
+                            const int j = jj < n_ign ? jj : LIST_CAP - 1 - (jj - n_ign);
+                            const int64_t e = (row_lo + s_ign_row[wave][j]) * K + k;
+                            gms[u] = s_ign_gm[wave][j];
+                            ok[u] = (t0 + u * RN_WAVE + lane < total) && e >= e_beg && e < e_end;
+                            xs[u] = D::ld(lv.cls, e);
+                        }
+#pragma unroll
+                        for (int u = 0; u < IGN_U; ++u) {
+                            if (ok[u]) {
+                                float wb, gbg;
+                                bg_elem<GAMMA2>(xs[u], a.p, wb, gbg);
+                                acc -= (double)wb * (double)gms[u];
+                            }
+                        }
+                    }
+                }
+            }
+            } else {
 #pragma unroll 1
             for (int64_t r0 = row_lo; r0 <= cap_hi; r0 += RN_WAVE) {                 // wave-uniform
                 const int n = (int)min((int64_t)RN_WAVE, cap_hi - r0 + 1);
@@ -560,6 +779,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
                     }
                 }
             }
+            }
         };
         if (v_beg >= v_end) prep();
 
@@ -673,6 +893,42 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
         }
 
         // ---- Phase B, part 2 (after the stream): the stores that overwrite what phase A wrote, from the two lists -- no loads
+        if constexpr (LIST) {
+        if (WRITE_GRAD && (n_pos | n_ign | n_ign_b)) {                             // wave-uniform
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int i = lane; i < n_pos; i += RN_WAVE) D::st(lv.gcls, e_beg + s_pos_off[wave][i], s_pos_val[wave][i]);
+            if (VEC == 8 && !(K & 1)) {                                            // (16-byte zero pieces + single dwords: see the read side)
+                const int K2 = K >> 1, P = K2 >> 2, R = K2 & 3;
+                uint32_t *const dst32 = (uint32_t *)lv.gcls;
+                const int total_p = n_ign * P;
+                for (int t = lane; t < total_p; t += RN_WAVE) {
+                    const int j = t / P, pi = t - j * P;
+                    const int64_t d = (((row_lo + s_ign_row[wave][j]) * K) >> 1) + 4 * pi;
+                    *(u32x4_a4 *)(dst32 + d) = u32x4_a4{0u, 0u, 0u, 0u};
+                }
+                const int total_r = n_ign * R, total_b = n_ign_b * K2;
+                for (int t = lane; t < total_r + total_b; t += RN_WAVE) {
+                    int j, k2;
+                    if (t < total_r) { j = t / R; k2 = 4 * P + (t - j * R); }
+                    else { const int tq = t - total_r; const int jb = tq / K2; k2 = tq - jb * K2; j = LIST_CAP - 1 - jb; }
+                    const int64_t e = (row_lo + s_ign_row[wave][j]) * K + 2 * k2;
+                    if (e >= e_beg && e < e_end) dst32[e >> 1] = 0u;
+                }
+            } else {
+                const int total = (n_ign + n_ign_b) * K;
+                for (int t = lane; t < total; t += RN_WAVE) {
+                    const int jj = t / K, k = t - jj * K;
+                    const int j = jj < n_ign ? jj : LIST_CAP - 1 - (jj - n_ign);
+                    const int64_t e = (row_lo + s_ign_row[wave][j]) * K + k;
+                    if (e >= e_beg && e < e_end) D::st(lv.gcls, e, 0.0f);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        } else {
         if (WRITE_GRAD && (n_pos | n_ign)) {                                       // wave-uniform
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -695,6 +951,7 @@ __global__ __launch_bounds__(LOSS_BLOCK) void loss_stream_kernel(const LossArgs 
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+        }
         }
         if (FUSED) seg_off += (int)(row_hi - row_lo + 1);       // (the host admits the fused form only when every range fits the lists)
         // rows past the lists' capacity (ranges longer than LIST_CAP rows: small K or few waves), chunk by chunk after the stream
@@ -1411,7 +1668,7 @@ int launch_stream(StreamT stream_k, LossArgs &a, int vec, hipStream_t st, int *n
 }
 
 template <int DT>
-int launch_loss(LossArgs &a, bool gamma2, bool wg, hipStream_t st, int *ns, const bool fused = false)
+int launch_loss(LossArgs &a, bool gamma2, bool wg, hipStream_t st, int *ns, const bool fused = false, const bool list = false)
 {
     constexpr int VEC = rn::dt<DT>::VEC;
     // PF = 2 groups of loads in flight, non-temporal loads: the best of the (2|4|8) x (nt|plain) sweep on MI355X
@@ -1423,6 +1680,15 @@ int launch_loss(LossArgs &a, bool gamma2, bool wg, hipStream_t st, int *ns, cons
         } else {
             if (wg) rc = launch_stream(loss_stream_kernel<DT, false, true, 2, 1, true>, a, VEC, st, &n_stream, true);
             else rc = launch_stream(loss_stream_kernel<DT, false, false, 2, 1, true>, a, VEC, st, &n_stream, true);
+        }
+    } else if (list) {
+        // the special rows of ALL chunks through one compact list (many special rows per wave: RN_LOSS_FORM_LIST)
+        if (gamma2) {
+            if (wg) rc = launch_stream(loss_stream_kernel<DT, true, true, 2, 1, false, true>, a, VEC, st, &n_stream);
+            else rc = launch_stream(loss_stream_kernel<DT, true, false, 2, 1, false, true>, a, VEC, st, &n_stream);
+        } else {
+            if (wg) rc = launch_stream(loss_stream_kernel<DT, false, true, 2, 1, false, true>, a, VEC, st, &n_stream);
+            else rc = launch_stream(loss_stream_kernel<DT, false, false, 2, 1, false, true>, a, VEC, st, &n_stream);
         }
     } else if (gamma2) {
         if (wg) rc = launch_stream(loss_stream_kernel<DT, true, true, 2, 1>, a, VEC, st, &n_stream);
@@ -1482,8 +1748,10 @@ static int loss_levels_core(const void *const *cls_levels, const void *const *bo
                             const int32_t *num_fg, const rn_loss_params *params, float *out_loss,
                             void *const *grad_cls_levels, void *const *grad_box_levels, void *workspace,
                             size_t workspace_bytes, void *stream, const FusedMatch *fm = nullptr, void *fin_state = nullptr,
-                            const float *grad_prescale = nullptr, const bool repair_pass = false)
+                            const float *grad_prescale = nullptr, const int form = RN_LOSS_FORM_CHUNKS)
 {
+    if (form != RN_LOSS_FORM_CHUNKS && form != RN_LOSS_FORM_REPAIR_PASS && form != RN_LOSS_FORM_LIST) return RN_EINVAL;
+    const bool repair_pass = form == RN_LOSS_FORM_REPAIR_PASS, list = form == RN_LOSS_FORM_LIST && !fm;
     if (fin_state && (fm || !rn::aligned(fin_state, 64))) return fm ? RN_EINVAL : RN_EALIGN;
     if (repair_pass && (!fin_state || !special_rows)) return RN_EINVAL;
     if (!cls_levels || !box_levels || !level_anchors || !anchors || !gt_off || !params || !out_loss || (!workspace && !repair_pass)) return RN_EINVAL;
@@ -1565,9 +1833,9 @@ static int loss_levels_core(const void *const *cls_levels, const void *const *bo
         return RN_OK;
     }
     switch (dtype) {
-        case RN_F32: rc = launch_loss<RN_F32>(a, gamma2, wg, st, &ns, fm != nullptr); break;
-        case RN_BF16: rc = launch_loss<RN_BF16>(a, gamma2, wg, st, &ns, fm != nullptr); break;
-        default: rc = launch_loss<RN_F16>(a, gamma2, wg, st, &ns, fm != nullptr); break;
+        case RN_F32: rc = launch_loss<RN_F32>(a, gamma2, wg, st, &ns, fm != nullptr, list); break;
+        case RN_BF16: rc = launch_loss<RN_BF16>(a, gamma2, wg, st, &ns, fm != nullptr, list); break;
+        default: rc = launch_loss<RN_F16>(a, gamma2, wg, st, &ns, fm != nullptr, list); break;
     }
     if (rc != RN_OK) return rc;
     if (a.fin) return RN_OK;                                            // (workgroup 0 of the stream kernel has written out_loss)
@@ -1627,7 +1895,7 @@ RN_API int rn_loss_fwd_bwd_levels_rp(const void *const *cls_levels, const void *
                                      const float *anchors, int64_t anchor_bstride, const float *gt_boxes,
                                      const int64_t *gt_labels, const int32_t *gt_off, const int64_t *matches,
                                      const uint64_t *special_rows, const int32_t *num_fg, const rn_loss_params *params,
-                                     const float *grad_prescale, int repair_pass, float *out_loss, void *const *grad_cls_levels,
+                                     const float *grad_prescale, int form, float *out_loss, void *const *grad_cls_levels,
                                      void *const *grad_box_levels, void *workspace, size_t workspace_bytes, void *state,
                                      void *stream, void *event_start, void *event_stop)
 {
@@ -1635,7 +1903,7 @@ RN_API int rn_loss_fwd_bwd_levels_rp(const void *const *cls_levels, const void *
     g_prof.start = (hipEvent_t)event_start; g_prof.stop = (hipEvent_t)event_stop;
     const int rc = loss_levels_core(cls_levels, box_levels, level_anchors, L, dtype, B, K, anchors, anchor_bstride, gt_boxes, gt_labels,
                                     gt_off, matches, special_rows, num_fg, params, out_loss, grad_cls_levels, grad_box_levels, workspace,
-                                    workspace_bytes, stream, nullptr, state, grad_prescale, repair_pass != 0);
+                                    workspace_bytes, stream, nullptr, state, grad_prescale, form);
     g_prof.start = g_prof.stop = nullptr;
     return rc;
 }

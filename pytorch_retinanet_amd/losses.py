@@ -72,10 +72,20 @@ FUSE_MATCH = os.environ.get("RN_FUSE_MATCH", "0") == "1"
 # The two batch losses from the streaming kernel itself instead of a one-block finalize launch behind it (rn_loss_fwd_bwd_levels_fin:
 # fixed-point partial sums through device-scope atomics, workgroup 0 waits for the last arrival): same bits, one dependent launch less
 IN_KERNEL_FINALIZE = True
-# K3 as TWO launches (round 6, rn_loss_fwd_bwd_levels_rp): a pure background stream over the logits and a repair kernel that walks
-# K2's flag words with one special row per lane (and finishes the sums).  Inside the streaming kernel the repair is a serial prefix
-# of every wave whose length follows the local density of special rows; split off, the special rows are balanced over the chip.
-K3_REPAIR_PASS = True
+# How K3 repairs its special rows (``ops.LOSS_FORM_*``, rn_loss_fwd_bwd_levels_rp).  "auto": the chunk form at the train shape, the
+# list form from K3_LIST_MIN_GT boxes per image on (same-box A/B on MI355X, round 6, isolated graph replays, one-launch forms: T = 8
+# 116.8 us chunks / 119.0 list; T = 64 131.7 / 127.9; T = 500 fp16 149.3 / 143.2).  The two-launch form (a pure background stream + a
+# repair kernel over K2's flag words, one special row per lane) is correct and slower -- 145 / 170 / 198 us at T = 8 / 64 / 500: the
+# repair's dependent loads have nothing to hide under once they leave the streaming kernel -- and stays for A/B: K3_FORM = 1.
+K3_FORM = "auto"
+K3_LIST_MIN_GT = 32
+
+
+def k3_form(total_gt: int, B: int) -> int:
+    if K3_FORM != "auto":
+        return int(K3_FORM)
+    return ops.LOSS_FORM_LIST if total_gt >= K3_LIST_MIN_GT * max(B, 1) else ops.LOSS_FORM_CHUNKS
+
 
 # Gradient pre-scale (fp16 training): a device f32 scalar -- a torch.amp.GradScaler's ``_scale`` -- that K3 multiplies into every
 # gradient BEFORE rounding it to fp16.  K3 writes d loss / d logits in the forward pass; a background element at the prior has
@@ -150,7 +160,7 @@ class _FusedDenseHeadLossLevels(torch.autograd.Function):
             pre = _GRAD_PRESCALE if (want_grad and _GRAD_PRESCALE is not None and _GRAD_PRESCALE.device == cls_levels[0].device) else None
             loss, gcls, gbox = ops.loss_fwd_bwd_levels(cls_levels, box_levels, anchors, gt_boxes, gt_labels, gt_off, matches,
                                                        num_fg, params, want_grad, special=special, in_kernel_finalize=IN_KERNEL_FINALIZE,
-                                                       grad_prescale=pre, repair_pass=K3_REPAIR_PASS and special is not None)
+                                                       grad_prescale=pre, form=k3_form(int(gt_boxes.shape[0]), B) if special is not None else None)
             ctx.prescale = pre
         ctx.grads = (gcls, gbox)
         ctx.meta = [(c.shape, c.dtype) for c in cls_levels] + [(b.shape, b.dtype) for b in box_levels]

@@ -15,6 +15,7 @@ from . import _lib
 from ._lib import RN_BF16, RN_F16, RN_F32, RnDetectParams, RnLevel, RnLossParams, check, lib
 
 RN_MATCH_NUM_FG_ZEROED, RN_MATCH_FLAGGED_ONLY = 1, 2          # include/retinanet_hip.h
+LOSS_FORM_CHUNKS, LOSS_FORM_REPAIR_PASS, LOSS_FORM_LIST = 0, 1, 2   # RN_LOSS_FORM_*
 
 _DT = {torch.float32: RN_F32, torch.bfloat16: RN_BF16, torch.float16: RN_F16}
 
@@ -264,15 +265,20 @@ def loss_fwd_bwd(cls: Tensor, box: Tensor, anchors: Tensor, gt_boxes: Tensor, gt
 def loss_fwd_bwd_levels(cls_levels: Sequence[Tensor], box_levels: Sequence[Tensor], anchors: Tensor, gt_boxes: Tensor,
                         gt_labels: Tensor, gt_off: Tensor, matches: Tensor, num_fg: Tensor, params: RnLossParams,
                         want_grad: bool = True, special: Optional[Tensor] = None, in_kernel_finalize: bool = False,
-                        grad_prescale: Optional[Tensor] = None, repair_pass: bool = False):
+                        grad_prescale: Optional[Tensor] = None, repair_pass: bool = False, form: Optional[int] = None):
     """K3 on per-level head outputs (no concatenation): cls_levels[l] [B,A_l,K], box_levels[l] [B,A_l,4].
     -> (loss f32[2], [grad_cls_l], [grad_box_l]).  ``special``: the third output of ``iou_match(want_special=True)`` --
     the kernel then reads ``matches`` only at the rows flagged there instead of streaming all of it.
     ``in_kernel_finalize``: no finalize launch -- the streaming kernel's workgroup 0 writes the two losses
     (``rn_loss_fwd_bwd_levels_fin``; same bits; uses this device's / capture's state words, ``_match_state``).
     ``grad_prescale``: device f32 scalar every gradient is multiplied by BEFORE its rounding to the I/O dtype (a GradScaler's
-    scale: fp16 class gradients of ~4e-10 would otherwise flush to zero); ``repair_pass`` (needs ``special``): K3 as a pure
-    background stream + a repair kernel over the flag words (``rn_loss_fwd_bwd_levels_rp``)."""
+    scale: fp16 class gradients of ~4e-10 would otherwise flush to zero).  ``form`` (``rn_loss_fwd_bwd_levels_rp``):
+    ``LOSS_FORM_CHUNKS`` (default; the one-launch kernel repairing its special rows chunk by chunk), ``LOSS_FORM_LIST`` (one launch, the
+    special rows of a wave through one compact list: faster from ~32 GT boxes per image on) or ``LOSS_FORM_REPAIR_PASS`` (= ``repair_pass``;
+    needs ``special``: a pure background stream + a repair kernel over the flag words; slower, kept for A/B)."""
+    if form is None:
+        form = LOSS_FORM_REPAIR_PASS if repair_pass else LOSS_FORM_CHUNKS
+    repair_pass = form == LOSS_FORM_REPAIR_PASS
     L = len(cls_levels)
     if L == 0 or L > _lib.RN_MAX_LEVELS or len(box_levels) != L:
         raise ValueError("need 1..8 levels of (cls, box) outputs")
@@ -310,11 +316,11 @@ def loss_fwd_bwd_levels(cls_levels: Sequence[Tensor], box_levels: Sequence[Tenso
             if not (grad_prescale.is_cuda and grad_prescale.dtype == torch.float32 and grad_prescale.numel() == 1):
                 raise TypeError("grad_prescale must be a CUDA fp32 scalar")
             _need_dev(grad_prescale, cls_levels[0])
-        if repair_pass or grad_prescale is not None:
+        if form != LOSS_FORM_CHUNKS or grad_prescale is not None:
             check(lib.rn_loss_fwd_bwd_levels_rp(arr(cls_levels), arr(box_levels), (C.c_int64 * L)(*counts), L, _dtype_code(cls_levels[0]),
                                                  B, K, _ptr(anchors), bstride, _ptr(gt_boxes), _ptr(gt_labels), _ptr(gt_off),
                                                  _ptr(matches), _ptr(special), _ptr(num_fg), C.byref(params), _ptr(grad_prescale),
-                                                 int(bool(repair_pass)), _ptr(out),
+                                                 int(form), _ptr(out),
                                                  arr(gcls) if want_grad else None, arr(gbox) if want_grad else None,
                                                  _ptr(ws), ws_bytes, _ptr(_match_state(dev)), _stream(dev), k0.cuda_event if k0 else None,
                                                  k1.cuda_event if k1 else None), "rn_loss_fwd_bwd_levels_rp")
