@@ -941,6 +941,10 @@ RN_API int rn_detect_levels(const void *const *cls_levels, const void *const *bo
     na.seg_start = w.seg_start; na.seg_len = w.seg_len; na.kept_count = w.kept_count;
     na.scratch_boxes = w.sbox; na.scratch_supp = w.supp;
     na.S = B * K; na.box_mode = 1; na.K = K; na.A = A; na.iou_thr = params->nms_thr;
+    // only the first max_det survivors of a class can reach the image's top max_det (the merge below reads min(kept_count, max_det) of
+    // them): a long segment's greedy scan stops once it has kept that many -- the reference (no pre-NMS top-k, models.py:193-219) runs
+    // O(n^2) over ~7 k boxes per class in SURVEY 8d's stress regime; the detections are the same rows
+    na.max_keep = params->max_det;
     rc = rn::launch_nms(na, st);
     if (rc != RN_OK) return rc;
     hipLaunchKernelGGL(topk_kernel, dim3((unsigned)B), dim3(TOPK_THREADS), 0, st, w.cand, w.seg_start, w.kept_count, w.boxes,

@@ -231,7 +231,7 @@ __device__ __forceinline__ void nms_lds_body(const rn::NmsLaunch &a, unsigned ch
     uint16_t *s_kept = (uint16_t *)(smem + nms_lds_mask_offset(CAP, THREADS) + (size_t)MASK_CAP * MASK_WORDS * 8);   // sorted positions of the kept boxes
     uint64_t *s_keepw = (uint64_t *)(smem + nms_lds_mask_offset(CAP, THREADS) + (size_t)MASK_CAP * MASK_WORDS * 8 + (size_t)CAP * 2);
     const int lane = threadIdx.x & (RN_WAVE - 1);
-    int nkept = 0;
+    int nkept = 0, n_done = 0;                                                     // n_done: sorted boxes the scan has decided
     for (int t0 = 0; t0 < n; t0 += MASK_CAP) {
         const int m = min(MASK_CAP, n - t0);
         if (nkept > 0) {                                                          // 1. (uniform)
@@ -270,10 +270,12 @@ __device__ __forceinline__ void nms_lds_body(const rn::NmsLaunch &a, unsigned ch
             nkept += total;
         }
         __syncthreads();
+        n_done = t0 + m;
+        if (a.max_keep > 0 && nkept >= a.max_keep) break;                          // (uniform) the rest of the segment cannot reach the caller's top max_keep
     }
 
-    const int per = (n + THREADS - 1) / THREADS;
-    const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+    const int per = (n_done + THREADS - 1) / THREADS;
+    const int lo = min(n_done, (int)threadIdx.x * per), hi = min(n_done, lo + per);
     int cnt = 0;
     for (int i = lo; i < hi; ++i) cnt += s_supp[i] ? 0 : 1;
     int total;
@@ -470,9 +472,14 @@ __device__ __forceinline__ void nms_big_body(const rn::NmsLaunch &a, unsigned ch
 
     f32x4 *g_box = a.scratch_boxes + start;
     uint8_t *g_supp = a.scratch_supp + start;
-    for (int i = threadIdx.x; i < n; i += BIG_THREADS) {
-        g_box[i] = a.boxes[box_base + (uint32_t)buf0[i]];
-        g_supp[i] = 0;
+    int n_done = 0;
+    // (max_keep > 0: the scan usually ends within the first tiles -- each tile gathers its own boxes and clears its own flags instead
+    // of a pass over the whole segment up front; g_box then only holds the compacted kept boxes)
+    if (a.max_keep <= 0) {
+        for (int i = threadIdx.x; i < n; i += BIG_THREADS) {
+            g_box[i] = a.boxes[box_base + (uint32_t)buf0[i]];
+            g_supp[i] = 0;
+        }
     }
     __syncthreads();
     // The blocked greedy scan of nms_lds_body with the sorted boxes in HBM: a tile of MASK_CAP boxes at a time in LDS; the boxes kept so
@@ -493,7 +500,7 @@ __device__ __forceinline__ void nms_big_body(const rn::NmsLaunch &a, unsigned ch
         for (int t0 = 0; t0 < n; t0 += MASK_CAP) {
             const int m = min(MASK_CAP, n - t0);
             if ((int)threadIdx.x < m) {
-                const f32x4 b = g_box[t0 + threadIdx.x];
+                const f32x4 b = a.max_keep > 0 ? a.boxes[box_base + (uint32_t)buf0[t0 + threadIdx.x]] : g_box[t0 + threadIdx.x];
                 s_tbox[threadIdx.x] = b;
                 s_tarea[threadIdx.x] = (b.z - b.x) * (b.w - b.y);
                 s_tsupp[threadIdx.x] = 0;
@@ -531,16 +538,19 @@ __device__ __forceinline__ void nms_big_body(const rn::NmsLaunch &a, unsigned ch
                 }
                 if ((int)threadIdx.x < m) {
                     const uint64_t mine = s_keepw[tw];
-                    if ((mine >> lane) & 1ull) g_box[nkept + before + __popcll(mine & ((1ull << lane) - 1ull))] = s_tbox[threadIdx.x];
-                    else g_supp[t0 + threadIdx.x] = 1;
+                    const bool kp = (mine >> lane) & 1ull;
+                    if (kp) g_box[nkept + before + __popcll(mine & ((1ull << lane) - 1ull))] = s_tbox[threadIdx.x];
+                    g_supp[t0 + threadIdx.x] = kp ? 0 : 1;
                 }
                 nkept += total;
             }
             __syncthreads();
+            n_done = t0 + m;
+            if (a.max_keep > 0 && nkept >= a.max_keep) break;                                // (uniform) see nms_lds_body
         }
     }
-    const int per = (n + BIG_THREADS - 1) / BIG_THREADS;
-    const int lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+    const int per = (n_done + BIG_THREADS - 1) / BIG_THREADS;
+    const int lo = min(n_done, (int)threadIdx.x * per), hi = min(n_done, lo + per);
     int cnt = 0;
     for (int i = lo; i < hi; ++i) cnt += g_supp[i] ? 0 : 1;
     int total;
@@ -631,7 +641,7 @@ RN_API int rn_nms_segments(const float *boxes, const float *scores, const int32_
     a.keep_idx = keep;
     a.boxes = (const rn::f32x4 *)boxes;
     a.seg_start = seg_start; a.seg_len = seg_len; a.kept_count = keep_count;
-    a.S = S; a.box_mode = 0; a.K = 1; a.A = 0; a.iou_thr = iou_thr;
+    a.S = S; a.box_mode = 0; a.K = 1; a.A = 0; a.iou_thr = iou_thr; a.max_keep = 0;
     hipStream_t st = (hipStream_t)stream;
     const int64_t work = N > S ? N : S;
     hipLaunchKernelGGL(nms_prep_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, scores, seg_off, S, N,

@@ -24,6 +24,7 @@ static __host__ __device__ __forceinline__ float score_of(const uint32_t inv) {
 //   kept     u64[..]: on exit kept[seg_start[s] .. +kept_count[s]) = keys of the survivors in sorted order.
 //   keep_idx i64[..] (nullable): same positions, payload only.
 //   scratch_boxes f32x4[..], scratch_supp u8[..]: same indexing as keys; used by segments longer than 2048.
+//   max_keep: see the field.
 struct NmsLaunch {
     uint64_t *keys;
     uint64_t *kept;
@@ -39,6 +40,9 @@ struct NmsLaunch {
     int K;
     int64_t A;
     float iou_thr;
+    int max_keep;            // > 0: a segment's scan may stop once it has kept this many boxes (the detect chain: only the first max_det
+                             // survivors of a class can reach the image's top max_det, models.py:222-240); kept_count is then >= max_keep
+                             // for such a segment and the kept list holds its best survivors in order.  0: the full greedy scan (the op).
 };
 int launch_nms(const NmsLaunch &a, hipStream_t st);
 
