@@ -108,7 +108,7 @@ int launch_decode(const void *deltas, const int dtype, const int B, const int64_
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_WAVES = SCAN_THREADS / RN_WAVE;
 constexpr int SCAN_CAP = 128;            // wave-private list entries (>= 64: one ballot's worth always fits after a flush)
-constexpr int SCAN_PF = 2;
+constexpr int SCAN_PF = 4;
 constexpr int SCAN_QCAP = 128;           // parked vectors per wave
 constexpr int SCAN_SHARDS = 128;         // candidate-list shards per image
 
@@ -630,9 +630,16 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const uint64_t *__re
     for (int k = t; k < K; k += TOPK_THREADS) s_pre[k + 1] = min(kept_count[(int64_t)b * K + k], max_det);
     if (t == 0) s_pre[0] = 0;
     __syncthreads();
-    if (t == 0) {
+    if (t < RN_WAVE) {                                       // wave 0: inclusive scan, 64 classes per step (a serial loop of one thread cost K LDS round trips)
         int run = 0;
-        for (int k = 1; k <= K; ++k) { run += s_pre[k]; s_pre[k] = run; }
+        for (int k0 = 1; k0 <= K; k0 += RN_WAVE) {
+            const int k = k0 + t;
+            int incl = k <= K ? s_pre[k] : 0;
+#pragma unroll
+            for (int dd = 1; dd < RN_WAVE; dd <<= 1) { const int up = __shfl_up(incl, dd, RN_WAVE); if (t >= dd) incl += up; }
+            if (k <= K) s_pre[k] = run + incl;
+            run += __shfl(incl, RN_WAVE - 1, RN_WAVE);
+        }
     }
     for (int i = t; i < TOPK_SURV; i += TOPK_THREADS) s_surv[i] = ~0ull;
     __syncthreads();

@@ -318,8 +318,17 @@ __global__ __launch_bounds__(MASK_CAP) void nms_mask_kernel(const rn::NmsLaunch 
     s_in[t] = key;
     __syncthreads();
     if (t < n) {                                       // rank sort: keys are unique
+        // s_in is padded with ~0 up to MASK_CAP (never < key): eight independent LDS reads per step, no guards (a rolled loop of
+        // single reads waited out one LDS latency per key: ~120 of them in a row on every thread)
         int rank = 0;
-        for (int j = 0; j < n; ++j) rank += (s_in[j] < key) ? 1 : 0;
+        const int n8 = (n + 7) & ~7;
+        for (int j = 0; j < n8; j += 8) {
+            uint64_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = s_in[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rank += (v[u] < key) ? 1 : 0;
+        }
         s_key[rank] = key;
     }
     __syncthreads();
@@ -340,9 +349,13 @@ __global__ __launch_bounds__(MASK_CAP) void nms_mask_kernel(const rn::NmsLaunch 
         const int j = min(w * 64 + lane, n - 1);
         bj[w] = s_box[j]; aj[w] = s_area[j];
     }
+    f32x4 bi_n = s_box[min(wave, n - 1)];
+    float ai_n = s_area[min(wave, n - 1)];
     for (int i = wave; i < n; i += MASK_CAP / RN_WAVE) {
-        const f32x4 bi = s_box[i];
-        const float ai = s_area[i];
+        const f32x4 bi = bi_n;                               // (the next row's box is requested before this row's arithmetic)
+        const float ai = ai_n;
+        bi_n = s_box[min(i + MASK_CAP / RN_WAVE, n - 1)];
+        ai_n = s_area[min(i + MASK_CAP / RN_WAVE, n - 1)];
         const int w0 = (i + 1) >> 6;                         // words entirely at or below the diagonal hold no j > i
         uint64_t mine = 0ull;
 #pragma unroll
