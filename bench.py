@@ -650,9 +650,12 @@ def main():
     amp_dtype = torch.float16 if args.amp == "fp16" else torch.bfloat16
     # fp16: dynamic loss scaling like the reference's precision=16 run; the scale, the growth tracker, the unscale and the skip all
     # live on the device (optim.MasterSGD._step_supports_amp_scaling), so the step captures like the bf16 one
-    scaler = torch.amp.GradScaler("cuda", init_scale=4096.0) if args.amp == "fp16" else None
-    if scaler is not None and (world > 1 or args.force_ddp or args.torch_sgd):
-        raise SystemExit("bench.py --amp fp16 is the single-GPU MasterSGD line (loss scaling is not wired through the gradient exchange)")
+    # under a gradient exchange: parallel.ExchangeGradScaler (found_inf from the exchanged buckets: one decision for all ranks)
+    scaler = None
+    if args.amp == "fp16":
+        if args.torch_sgd:
+            raise SystemExit("bench.py --amp fp16 runs on optim.MasterSGD (fp16 working copies of fp32 masters)")
+        scaler = P.ExchangeGradScaler("cuda", init_scale=4096.0) if (world > 1 or args.force_ddp) else torch.amp.GradScaler("cuda", init_scale=4096.0)
     net = P.Retinanet(num_classes=90, backbone_kind=args.backbone, pretrained=False, min_size=800, max_size=1333)
     net = net.to(device).to(memory_format=torch.channels_last).train()
     if args.torch_sgd:

@@ -16,9 +16,9 @@ from .datasets import CSVDetectionDataset
 from .losses import RetinaNetLosses
 from .model import RetinaNetModel, SimpleTrainer, SyntheticDetectionDataset
 from .models import Retinanet
-from .parallel import BucketedGradAllReduce
+from .parallel import BucketedGradAllReduce, ExchangeGradScaler
 from .utils import collate_fn, load_hparams, load_obj
 
 __all__ = ["Retinanet", "AnchorGenerator", "RetinaNetLosses", "RetinaNetModel", "SimpleTrainer",
-           "SyntheticDetectionDataset", "BucketedGradAllReduce", "matcher", "bbox_2_activ", "activ_2_bbox",
+           "SyntheticDetectionDataset", "BucketedGradAllReduce", "ExchangeGradScaler", "matcher", "bbox_2_activ", "activ_2_bbox",
            "collate_fn", "load_obj", "load_hparams", "ops", "CocoEvaluator", "CSVDetectionDataset"]

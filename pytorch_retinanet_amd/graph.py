@@ -148,10 +148,11 @@ class CapturedTrainStep:
         self.net, self.optimizer, self.ddp = net, optimizer, ddp
         # fp16 autocast: a torch.amp.GradScaler (the reference's precision=16 run is native AMP, demo.ipynb).  Its scale / growth
         # tracker are device tensors and optim.MasterSGD takes grad_scale / found_inf on the device, so scale -> backward -> step ->
-        # update records into the graph like the rest of the step.  Single-process steps only.
+        # update records into the graph like the rest of the step.  Under a gradient exchange: parallel.ExchangeGradScaler.
         self.scaler = scaler
-        if scaler is not None and ddp is not None:
-            raise ValueError("loss scaling is wired for the single-process step only")
+        if scaler is not None and ddp is not None and not hasattr(scaler, "step_exchanged"):
+            raise ValueError("under a gradient exchange the loss scaler must be a parallel.ExchangeGradScaler: found_inf has to come "
+                             "from the exchanged buckets, or one rank skips a step the others take")
         self.segmented = (ddp is not None) if segmented is None else (bool(segmented) and ddp is not None)
         if self.segmented:
             ddp.deferred = True
@@ -172,13 +173,17 @@ class CapturedTrainStep:
         cuts = StageCuts()
         ddp.zero_grad()
         trunk.stage_cuts = cuts
+        from .losses import grad_prescale, scaler_prescale
+        pre = scaler_prescale(self.scaler, images[0].device) if images[0].is_cuda else None
         try:
-            with torch.autocast(images[0].device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None, cache_enabled=False):
+            with torch.autocast(images[0].device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None, cache_enabled=False), \
+                    grad_prescale(pre):
                 losses = net(list(images), [dict(t) for t in targets])
                 total = losses["classification_loss"] + losses["regression_loss"]
         finally:
             trunk.stage_cuts = None
-        total.backward()                                          # stage 0: head + FPN; gradients of the cut leaves
+        # stage 0: head + FPN; gradients of the cut leaves.  fp16: the scaled loss -- every later stage starts from scaled leaf gradients
+        (self.scaler.scale(total) if self.scaler is not None else total).backward()
         mark(0)
         pairs = cuts.pairs                                        # [(C3, leaf), (C4, leaf), (C5, leaf)] in forward order
         # C3 / C4 join the data gradients of their consumers in the receiver's GEMM (pwconv._GradJoin); the FPN lateral's gradient was
@@ -198,7 +203,10 @@ class CapturedTrainStep:
             pairs[0][1].grad = None
         mark(2)
         ddp.finish()
-        if type(opt).__name__ == "MasterSGD":
+        if self.scaler is not None:
+            self.scaler.step_exchanged(opt, ddp)                  # found_inf from the exchanged buckets: the same on every rank
+            self.scaler.update()
+        elif type(opt).__name__ == "MasterSGD":
             opt.step(grads=ddp.grad_views())
         else:
             opt.step()
@@ -223,7 +231,11 @@ class CapturedTrainStep:
             total = losses["classification_loss"] + losses["regression_loss"]
         if self.scaler is not None:
             self.scaler.scale(total).backward()
-            self.scaler.step(opt)
+            if ddp is not None:
+                ddp.finish()
+                self.scaler.step_exchanged(opt, ddp)
+            else:
+                self.scaler.step(opt)
             self.scaler.update()
             return {"classification_loss": losses["classification_loss"].detach(), "regression_loss": losses["regression_loss"].detach(),
                     "loss": total.detach()}

@@ -227,9 +227,10 @@ class SimpleTrainer:
         ddp = BucketedGradAllReduce(model.net) if dist.is_available() and dist.is_initialized() else None
         # precision "16" = fp16 autocast WITH dynamic loss scaling, like the reference's native-AMP run (Lightning precision=16):
         # fp16 gradients of a focal loss normalised by num_fg underflow without it
-        scaler = torch.amp.GradScaler("cuda") if (self.amp_dtype == torch.float16 and self.device.type == "cuda") else None
-        if scaler is not None and ddp is not None:
-            raise NotImplementedError("precision='16' (loss scaling) is single-process; use precision='bf16' under torch.distributed")
+        # (under a gradient exchange: parallel.ExchangeGradScaler -- found_inf from the exchanged buckets, one decision for all ranks)
+        from .parallel import ExchangeGradScaler
+        scaler = (ExchangeGradScaler("cuda") if ddp is not None else torch.amp.GradScaler("cuda")) \
+            if (self.amp_dtype == torch.float16 and self.device.type == "cuda") else None
         stepper = None
         if (self.capture and self.device.type == "cuda" and ddp is None and type(model).training_step is RetinaNetModel.training_step
                 and not any(s["interval"] == "step" and "monitor" not in s for s in schedulers)):
@@ -256,7 +257,11 @@ class SimpleTrainer:
                     ddp.zero_grad() if ddp else optimizer.zero_grad(set_to_none=False)
                     if scaler is not None:
                         scaler.scale(out["loss"]).backward()
-                        scaler.step(optimizer)
+                        if ddp:
+                            ddp.finish()
+                            scaler.step_exchanged(optimizer, ddp)
+                        else:
+                            scaler.step(optimizer)
                         scaler.update()
                     else:
                         out["loss"].backward()

@@ -99,16 +99,19 @@ class BucketedGradAllReduce:
         self._owner = {}
         cap = int(bucket_mb * (1 << 20))
         group, size = [], 0
+        self._bucket_stage: List[int] = []
         for p in params:
             nbytes = self._padded(p.numel()) * self._grad_dtype(p).itemsize
             if group and (size + nbytes > cap or self._grad_dtype(p) != self._grad_dtype(group[0]) or p.device != group[0].device
                           or stage[id(p)] != stage[id(group[0])]):
                 self._make_bucket(group)
+                self._bucket_stage.append(stage[id(group[0])])
                 group, size = [], 0
             group.append(p)
             size += nbytes
         if group:
             self._make_bucket(group)
+            self._bucket_stage.append(stage[id(group[0])])
         if sync_params and self.world > 1:
             self.sync_parameters()
 
@@ -239,9 +242,80 @@ class BucketedGradAllReduce:
         except (ImportError, OSError, RuntimeError):              # CPU-only host (gloo tests): no HIP library, nothing cached
             pass
 
+    def found_inf(self) -> torch.Tensor:
+        """f32[1] on the buckets' device: 1 if any EXCHANGED gradient is non-finite, else 0 (call after ``finish()``).  An overflow on ONE
+        rank reaches every rank's averaged bucket (inf + x = inf, inf - inf = NaN), so every rank computes the same flag from its own
+        copy of the reduced buckets -- one decision per step without a further collective, where the rank-local check of a stock
+        ``GradScaler`` (it looks at ``param.grad``, the 16-bit gradients BEFORE the exchange) would let one rank skip a step the
+        others take.  One multi-tensor pass over the buckets (``_amp_foreach_non_finite_check_and_unscale_`` with a scale of 1);
+        capturable."""
+        dev = self.buckets[0].flat.device
+        found = torch.zeros(1, dtype=torch.float32, device=dev)
+        one = getattr(self, "_one", None)
+        if one is None or one.device != dev:
+            one = self._one = torch.ones(1, dtype=torch.float32, device=dev)
+        by_dtype = {}
+        for b in self.buckets:
+            by_dtype.setdefault(b.flat.dtype, []).append(b.flat)
+        for flats in by_dtype.values():
+            torch._amp_foreach_non_finite_check_and_unscale_(flats, found, one)
+        return found
+
+    def plan(self) -> dict:
+        "The exchange as the N-rank run issues it: bucket count, bytes per backward stage and in total (bench.py prints it)."
+        per_stage = {}
+        for b, st in zip(self.buckets, getattr(self, "_bucket_stage", [0] * len(self.buckets))):
+            per_stage[st] = per_stage.get(st, 0) + b.flat.numel() * b.flat.element_size()
+        return {"buckets": len(self.buckets), "bytes_total": sum(self.bucket_bytes()), "bytes_per_stage": [per_stage[k] for k in sorted(per_stage)],
+                "bucket_bytes": self.bucket_bytes()}
+
     @property
     def num_buckets(self) -> int:
         return len(self.buckets)
 
     def bucket_bytes(self) -> List[int]:
         return [b.flat.numel() * b.flat.element_size() for b in self.buckets]
+
+
+class ExchangeGradScaler(torch.amp.GradScaler):
+    """``torch.amp.GradScaler`` for steps whose gradients go through ``BucketedGradAllReduce`` (fp16 autocast under data parallelism: the
+    reference's only published run is Lightning ``precision=16``, ``demo.ipynb``; under DDP Lightning drives the same GradScaler).
+
+        scaler.scale(loss).backward(); ddp.finish(); scaler.step_exchanged(optimizer, ddp); scaler.update()
+
+    ``step_exchanged`` takes found_inf from the EXCHANGED buckets (``BucketedGradAllReduce.found_inf``: identical on every rank, so all
+    ranks skip or step together and ``update()`` moves every rank's scale the same way -- one scale per step on every rank without a
+    second collective) and steps on the buckets' views.  With ``optim.MasterSGD`` the unscale and the skip happen on the device
+    (``rn_sgd_master_step_ex`` reads scale and flag): nothing synchronises and the whole sequence captures into the optimizer segment of
+    ``graph.CapturedTrainStep``.  Other optimizers: the buckets are unscaled in place and the flag is read on the host, as the stock
+    scaler does."""
+
+    def step_exchanged(self, optimizer, ddp: BucketedGradAllReduce):
+        if not self._enabled:
+            return optimizer.step(grads=ddp.grad_views()) if type(optimizer).__name__ == "MasterSGD" else optimizer.step()
+        from torch.amp.grad_scaler import OptState
+        self._check_scale_growth_tracker("step_exchanged")
+        state = self._per_optimizer_states[id(optimizer)]
+        if state["stage"] is OptState.STEPPED:
+            raise RuntimeError("step_exchanged() has already been called since the last update().")
+        found = ddp.found_inf()
+        state["found_inf_per_device"] = {found.device: found}
+        retval = None
+        if getattr(optimizer, "_step_supports_amp_scaling", False):
+            optimizer.grad_scale, optimizer.found_inf = self._scale, found
+            try:
+                retval = optimizer.step(grads=ddp.grad_views()) if type(optimizer).__name__ == "MasterSGD" else optimizer.step()
+            finally:
+                del optimizer.grad_scale, optimizer.found_inf
+        else:
+            inv = self._scale.double().reciprocal().float()
+            by_dtype = {}
+            for b in ddp.buckets:
+                by_dtype.setdefault(b.flat.dtype, []).append(b.flat)
+            dummy = torch.zeros_like(found)
+            for flats in by_dtype.values():
+                torch._amp_foreach_non_finite_check_and_unscale_(flats, dummy, inv)
+            if not float(found.item()):
+                retval = optimizer.step()
+        state["stage"] = OptState.STEPPED
+        return retval

@@ -385,12 +385,12 @@ def hash_key(k: str) -> int:
     return zlib.crc32(k.encode())
 
 
-def gen_e2e(kind: str = "resnet18", fname: str = "e2e.npz"):
+def gen_e2e(kind: str = "resnet18", fname: str = "e2e.npz", cfg=None, inputs=None):
     """Retinanet.forward (models.py:274-288) and Retinanet.predict (models.py:245-272) of the REFERENCE model itself, for a
     seed-reproducible state dict: the fixture the assembled GPU model is held to.  ``resnet18`` -> e2e.npz (BasicBlock
     trunk); ``resnet50`` -> e2e_r50.npz (the Bottleneck trunk of the headline configuration, backbone.py:105-136)."""
     print(f"[e2e {kind}]  retinanet/models.py:245-288 (forward in train-mode BN, predict in eval mode)")
-    E2E = dict(num_classes=5, backbone_kind=kind, pretrained=False, min_size=128, max_size=160)
+    E2E = dict(cfg) if cfg is not None else dict(num_classes=5, backbone_kind=kind, pretrained=False, min_size=128, max_size=160)
     torch.manual_seed(0)
     ref = R.Retinanet(**E2E)
     spec = [(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in ref.state_dict().items()]
@@ -399,7 +399,7 @@ def gen_e2e(kind: str = "resnet18", fname: str = "e2e.npz"):
     for k, v in vals.items():
         sd[k] = torch.from_numpy(v)
     ref.load_state_dict(sd)
-    images, targets = synth.e2e_inputs()
+    images, targets = (inputs or synth.e2e_inputs)()
     timgs = [torch.from_numpy(i) for i in images]
     ttgts = [{"boxes": torch.from_numpy(b), "labels": torch.from_numpy(l)} for b, l in targets]
     out = {"spec_keys": np.array([k for k, _, _ in spec]), "spec_shapes": np.array([",".join(map(str, s)) for _, s, _ in spec]),
@@ -479,6 +479,14 @@ def gen_e2e(kind: str = "resnet18", fname: str = "e2e.npz"):
 
 def gen_e2e_r50():
     gen_e2e("resnet50", "e2e_r50.npz")
+
+
+def gen_e2e_full():
+    """The HEADLINE configuration end to end (BASELINE configs[1]'s model and per-image shape): the reference's
+    ``Retinanet(num_classes=90, "resnet50", min_size=800, max_size=1333)`` on the seed-reproducible state dict and two 3 x 800 x 1333
+    images with 8 GT boxes each -- train-mode loss dict + every parameter's gradient fingerprint, eval-mode losses, ``predict``.  At this
+    size the assembled GPU model runs the kernels at their real tile counts (two-image canvas sheets, band / split-K / chain kernels)."""
+    gen_e2e("resnet50", "e2e_full.npz", cfg=synth.E2E_FULL, inputs=synth.e2e_full_inputs)
 
 
 def gen_traj():

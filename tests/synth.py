@@ -137,6 +137,19 @@ def e2e_inputs(seed: int = 31):
     return images, targets
 
 
+# The headline configuration end to end (tests/golden/e2e_full.npz, gen_golden.py e2e_full): BASELINE configs[1]'s model and image size
+E2E_FULL = dict(num_classes=90, backbone_kind="resnet50", pretrained=False, min_size=800, max_size=1333)
+
+
+def e2e_full_inputs(seed: int = 47):
+    """Two images of exactly 3 x 800 x 1333 (the transform's identity scale; padded to 800 x 1344) with 8 GT boxes each, labels in
+    1..90 -- BASELINE configs[1]'s per-image shape.  Regenerated from the seed (25.6 MB of pixels: the fixture records their sha256)."""
+    rng = np.random.default_rng(seed)
+    images = [rng.random((3, 800, 1333), dtype=np.float32) for _ in range(2)]
+    targets = [gt_boxes(rng, 8, 800, 1333) for _ in range(2)]
+    return images, targets
+
+
 TRAJ = dict(num_classes=5, backbone_kind="resnet18", pretrained=False, min_size=128, max_size=160)
 # The reference's optimizer (hparams.yaml:63-68: SGD, weight decay 1e-3, momentum 0.9) at a learning rate of 2e-5 instead of its 1e-3:
 # on this synthetic state dict 1e-3 diverges (total loss 3.2 -> 18.9 / 212.9 at step 1) and the 5-step map amplifies a 1e-6 relative

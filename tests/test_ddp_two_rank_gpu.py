@@ -144,3 +144,25 @@ def test_two_ranks_through_the_segmented_graphs_equal_the_global_batch(tmp_path)
     for s in range(len(single["losses"])):
         noise = abs(single["losses"][s] - single2["losses"][s])
         assert abs(single["losses"][s] - 0.5 * (r0["losses"][s] + r1["losses"][s])) <= NOISE_X * noise + 2e-2 * abs(single["losses"][s])
+
+
+def test_two_ranks_fp16_loss_scaling_one_decision_for_all_ranks(tmp_path):
+    """fp16 autocast + dynamic loss scaling THROUGH the exchange (the reference's published run is Lightning precision=16,
+    demo.ipynb).  Rank 1 overflows at step 1 (loss x inf): with ``parallel.ExchangeGradScaler`` found_inf comes from the exchanged buckets,
+    so BOTH ranks skip that step and halve their scale (1024 -> 512) and stay bit-equal; the single-process counterpart -- the stock
+    ``torch.amp.GradScaler`` on ``MasterSGD``, no buckets, poisoned at the same step -- ends at the same parameters within fp16 gradient
+    rounding (the floor of the bf16 leg) and the same scale."""
+    out = str(tmp_path)
+    _launch_ranks(out, "--precision", "16", "--steps", "4", "--poison-step", "1")
+    single, single2 = _single_twice(tmp_path, "--precision", "16", "--steps", "4", "--poison-step", "1")
+    r0 = torch.load(os.path.join(out, "rank0.pt"))
+    r1 = torch.load(os.path.join(out, "rank1.pt"))
+    assert r0["scale"] == r1["scale"] == 512.0 == single["scale"], (r0["scale"], r1["scale"], single["scale"])
+    worst = (0.0, None)
+    for k, a in r0["params"].items():
+        assert torch.equal(a, r1["params"][k]), f"ranks diverged at {k}"
+        assert bool(torch.isfinite(a).all()), k
+        ok, err, bound, spread = _close(a, single["params"][k], single2["params"][k], 2e-3)
+        assert ok, (k, err, bound, spread)
+        worst = max(worst, (err / bound, k))
+    print(f"[ddp fp16] worst err/bound {worst[0]:.3f} at {worst[1]}")

@@ -214,3 +214,58 @@ def test_staged_deferred_exchange_equals_the_hook_driven_one(tmp_path):
     for a, b, c in zip(ref, s0, s1):
         assert torch.equal(b, c), "ranks diverged"
         assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)         # (rank 1 of the reference run starts from shifted weights and is synced; same maths after)
+
+
+def _scaler_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pytorch_retinanet_amd.parallel import BucketedGradAllReduce, ExchangeGradScaler
+    model = _model()
+    ddp = BucketedGradAllReduce(model, bucket_mb=0.002)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    scaler = ExchangeGradScaler("cpu", init_scale=256.0, growth_interval=2, backoff_factor=0.5, growth_factor=2.0)
+    g = torch.Generator().manual_seed(100)
+    data = torch.randn(4, 4, 3, 6, 6, generator=g)
+    tgt = torch.randn(4, 4, 5, generator=g)
+    log = []
+    for step in range(4):
+        x, y = data[step, rank * 2:(rank + 1) * 2], tgt[step, rank * 2:(rank + 1) * 2]
+        ddp.zero_grad()
+        loss = ((model(x) - y) ** 2).mean()
+        if step == 1 and rank == 1:                       # ONE rank overflows: its gradients are inf / NaN, the other rank's are finite
+            loss = loss * float("inf")
+        before = [p.detach().clone() for p in model.parameters()]
+        scaler.scale(loss).backward()
+        ddp.finish()
+        scaler.step_exchanged(opt, ddp)
+        scaler.update()
+        moved = any(not torch.equal(a, p.detach()) for a, p in zip(before, model.parameters()))
+        log.append((moved, float(scaler.get_scale())))
+    torch.save({"params": [p.detach().clone() for p in model.parameters()], "log": log}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_exchange_grad_scaler_takes_found_inf_from_the_exchanged_buckets(tmp_path):
+    """fp16-style dynamic loss scaling under the exchange: rank 1 overflows at step 1.  The stock GradScaler checks
+    the rank-LOCAL gradients, so rank 0 would step and rank 1 would skip; ``ExchangeGradScaler.step_exchanged`` reads the flag off the
+    all-reduced buckets (inf + x = inf on every rank): BOTH ranks skip step 1, both halve their scale, both grow it again after two clean
+    steps, and the parameters stay bit-equal and equal to a single process that skips the same step."""
+    world, port = 2, _free_port()
+    mp.spawn(_scaler_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b), "ranks diverged"
+    assert r0["log"] == r1["log"]
+    assert [m for m, _ in r0["log"]] == [True, False, True, True]                 # step 1 skipped on BOTH ranks
+    assert [s for _, s in r0["log"]] == [256.0, 128.0, 128.0, 256.0]              # halved at the overflow, doubled after two clean steps
+    model = _model()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    g = torch.Generator().manual_seed(100)
+    data = torch.randn(4, 4, 3, 6, 6, generator=g)
+    tgt = torch.randn(4, 4, 5, generator=g)
+    for step in (0, 2, 3):                                                         # the single process that skips the same step
+        opt.zero_grad()
+        ((model(data[step]) - tgt[step]) ** 2).mean().backward()
+        opt.step()
+    for a, b in zip(r0["params"], model.parameters()):
+        assert torch.allclose(a, b.detach(), rtol=1e-5, atol=1e-6)

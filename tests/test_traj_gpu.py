@@ -205,7 +205,7 @@ def _free_port():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["32", "bf16"])
+@pytest.mark.parametrize("precision", ["32", "bf16", "16"])
 def test_two_ranks_on_the_split_batch_reproduce_the_reference_trajectory(tmp_path, precision):
     """(c): the frozen-BatchNorm trajectory of the reference on four images per step == two ranks with two images each through
     ``BucketedGradAllReduce`` + the segmented ``CapturedTrainStep`` (2 eager staged steps + capture + 2 replays), ranks bit-equal."""
@@ -226,3 +226,6 @@ def test_two_ranks_on_the_split_batch_reproduce_the_reference_trajectory(tmp_pat
     initial = {k: v.double().numpy() for k, v in r0["initial"].items()}
     final = {k: v.double().numpy() for k, v in r0["params"].items()}
     check_run(g, "frozen", precision, losses, initial, final)
+    if precision == "16":
+        # fp16 under the exchange: parallel.ExchangeGradScaler (found_inf from the exchanged buckets); no step skipped, one scale on both ranks
+        assert r0["scale"] == r1["scale"] == 1024.0, (r0["scale"], r1["scale"])

@@ -35,7 +35,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", required=True)
     ap.add_argument("--single", action="store_true")
-    ap.add_argument("--precision", default="32", choices=["32", "bf16"])
+    ap.add_argument("--precision", default="32", choices=["32", "bf16", "16"],
+                    help="16: fp16 autocast + fp16 working copies + dynamic loss scaling (ranks: parallel.ExchangeGradScaler, found_inf from the "
+                         "exchanged buckets; --single: torch.amp.GradScaler); --poison-step N makes rank 1 overflow at step N")
+    ap.add_argument("--poison-step", type=int, default=-1, help="precision 16: rank 1 (ranks) / the process (--single) multiplies its loss by "
+                    "inf at this step: EVERY rank must skip it and halve its scale")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--global-batch", type=int, default=4)
     ap.add_argument("--bn", default="frozen", choices=["frozen", "train"])
@@ -53,7 +57,7 @@ def main():
 
     import synth
     import pytorch_retinanet_amd as P
-    from pytorch_retinanet_amd.optim import MasterSGD, use_bf16_conv_weights
+    from pytorch_retinanet_amd.optim import MasterSGD, use_16bit_conv_weights
 
     torch.manual_seed(1234)
     net = P.Retinanet(num_classes=5, backbone_kind="resnet18", pretrained=False, min_size=128, max_size=160)
@@ -78,15 +82,21 @@ def main():
         for m in net.modules():
             if isinstance(m, torch.nn.BatchNorm2d):
                 m.eval()
-    bf16 = args.precision == "bf16"
+    bf16 = args.precision != "32"                  # (a 16-bit autocast run: bf16 or fp16)
+    amp_dtype = {"32": None, "bf16": torch.bfloat16, "16": torch.float16}[args.precision]
     if bf16:
-        use_bf16_conv_weights(net)
+        use_16bit_conv_weights(net, amp_dtype)
     opt = MasterSGD(net.parameters(), **(synth.TRAJ_OPT if args.fixture == "traj" else dict(lr=1e-2, momentum=0.9, weight_decay=1e-3)))
     emulate = args.ranks if (args.single and live_bn) else 0
     from pytorch_retinanet_amd.graph import CapturedTrainStep, retinanet_stage_of
-    ddp = None if emulate else P.BucketedGradAllReduce(net, bucket_mb=8.0, stage_of=retinanet_stage_of if args.segmented else None)   # several buckets for a 20 M-parameter model
-    stepper = CapturedTrainStep(net, opt, ddp, amp_dtype=torch.bfloat16 if bf16 else None, eager_steps=2) if (args.segmented and ddp is not None) else None
-    assert emulate or ddp.num_buckets >= 3
+    # (--single at precision 16: no buckets at all -- the stock torch.amp.GradScaler on MasterSGD is the independent counterpart)
+    plain16 = args.single and args.precision == "16"
+    ddp = None if (emulate or plain16) else P.BucketedGradAllReduce(net, bucket_mb=8.0, stage_of=retinanet_stage_of if args.segmented else None)   # several buckets for a 20 M-parameter model
+    scaler = None
+    if args.precision == "16":      # a start value that needs no back-off on this model: every step is a real step unless poisoned
+        scaler = (P.ExchangeGradScaler if ddp is not None else torch.amp.GradScaler)("cuda", init_scale=1024.0, growth_interval=10 ** 6)
+    stepper = CapturedTrainStep(net, opt, ddp, amp_dtype=amp_dtype, eager_steps=2, scaler=scaler) if (args.segmented and ddp is not None) else None
+    assert emulate or plain16 or ddp.num_buckets >= 3
 
     def bn_buffers():
         return {n: b.detach().clone() for n, b in net.named_buffers() if "running_" in n or "num_batches_tracked" in n}
@@ -122,7 +132,7 @@ def main():
                 imgs = [i.to(dev) for i in images[mine]]
                 tgts = [{k: v.to(dev) for k, v in t.items()} for t in targets[mine]]
                 load_bn_buffers(rank_bufs[r])
-                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+                with torch.autocast("cuda", dtype=amp_dtype, enabled=bf16):
                     out = net(imgs, tgts)
                     loss = out["classification_loss"] + out["regression_loss"]
                 (loss / emulate).backward()                 # gradients accumulate: the average the exchange computes
@@ -139,13 +149,30 @@ def main():
             losses.append(float(o["loss"]))
             loss_dicts.append([float(o["classification_loss"]), float(o["regression_loss"])])
             continue
-        ddp.zero_grad()
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+        from pytorch_retinanet_amd.losses import grad_prescale, scaler_prescale
+        if ddp is not None:
+            ddp.zero_grad()
+        else:
+            opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=amp_dtype, enabled=bf16), grad_prescale(scaler_prescale(scaler, dev)):
             out = net(imgs, tgts)
             loss = out["classification_loss"] + out["regression_loss"]
-        loss.backward()
-        ddp.finish()
-        opt.step(grads=ddp.grad_views())
+        poisoned = step == args.poison_step and (args.single or rank == 1)
+        if scaler is not None:
+            scaler.scale(loss * float("inf") if poisoned else loss).backward()
+            if ddp is not None:
+                ddp.finish()
+                scaler.step_exchanged(opt, ddp)
+            else:
+                scaler.step(opt)
+            scaler.update()
+        else:
+            loss.backward()
+            if ddp is not None:
+                ddp.finish()
+                opt.step(grads=ddp.grad_views())
+            else:
+                opt.step()
         losses.append(float(loss.detach()))
         loss_dicts.append([float(out["classification_loss"].detach()), float(out["regression_loss"].detach())])
     torch.cuda.synchronize()
@@ -154,7 +181,7 @@ def main():
     bufs = [{n: b.float().cpu() for n, b in rb.items()} for rb in rank_bufs] if emulate else [{n: b.float().cpu() for n, b in bn_buffers().items()}]
     torch.save({"params": state, "losses": losses, "buckets": ddp.bucket_bytes() if ddp else [], "bn_buffers": bufs, "loss_dicts": loss_dicts,
                 "initial": {n: v.float().cpu() for n, v in initial.items()} if args.fixture == "traj" else {},
-                "replays": stepper.replays if stepper is not None else 0},
+                "replays": stepper.replays if stepper is not None else 0, "scale": float(scaler.get_scale()) if scaler is not None else None},
                os.path.join(args.out, "single.pt" if args.single else f"rank{rank}.pt"))
     if not args.single:
         dist.barrier()
