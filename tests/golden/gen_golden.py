@@ -385,7 +385,7 @@ def hash_key(k: str) -> int:
     return zlib.crc32(k.encode())
 
 
-def gen_e2e(kind: str = "resnet18", fname: str = "e2e.npz", cfg=None, inputs=None):
+def gen_e2e(kind: str = "resnet18", fname: str = "e2e.npz", cfg=None, inputs=None, cls_std: float = 0.0016, fp64: bool = False):
     """Retinanet.forward (models.py:274-288) and Retinanet.predict (models.py:245-272) of the REFERENCE model itself, for a
     seed-reproducible state dict: the fixture the assembled GPU model is held to.  ``resnet18`` -> e2e.npz (BasicBlock
     trunk); ``resnet50`` -> e2e_r50.npz (the Bottleneck trunk of the headline configuration, backbone.py:105-136)."""
@@ -394,7 +394,7 @@ def gen_e2e(kind: str = "resnet18", fname: str = "e2e.npz", cfg=None, inputs=Non
     torch.manual_seed(0)
     ref = R.Retinanet(**E2E)
     spec = [(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in ref.state_dict().items()]
-    vals = synth.state_dict_values(spec, seed=4242)
+    vals = synth.state_dict_values(spec, seed=4242, cls_std=cls_std)
     sd = ref.state_dict()
     for k, v in vals.items():
         sd[k] = torch.from_numpy(v)
@@ -405,7 +405,7 @@ def gen_e2e(kind: str = "resnet18", fname: str = "e2e.npz", cfg=None, inputs=Non
     out = {"spec_keys": np.array([k for k, _, _ in spec]), "spec_shapes": np.array([",".join(map(str, s)) for _, s, _ in spec]),
            "spec_dtypes": np.array([d for _, _, d in spec]),
            "weights_sha": np.array(synth.sha(np.concatenate([vals[k].astype(np.float64).reshape(-1) for k in sorted(vals)]))),
-           "inputs_sha": np.array(synth.sha(np.concatenate([i.reshape(-1) for i in images])))}
+           "inputs_sha": np.array(synth.sha(np.concatenate([i.reshape(-1) for i in images]))), "cls_std": np.array(cls_std)}
     # (1) training forward: the whole module in train() -- BatchNorm uses batch statistics (Q18: train() un-freezes BN)
     ref.train()
     losses = ref(timgs, [{k: v.clone() for k, v in t.items()} for t in ttgts])
@@ -436,6 +436,31 @@ def gen_e2e(kind: str = "resnet18", fname: str = "e2e.npz", cfg=None, inputs=Non
     out["grad_all_proj"] = np.array(projs)
     out["grad_all_samples"] = np.stack(samples)
     out["grad_all_pos"] = np.stack(pos).astype(np.int64)
+    if fp64:
+        # The same training forward + backward of the reference in DOUBLE precision: what the fp32 numbers above approximate.  Through
+        # ~50 train-mode BatchNorm backward steps (each subtracts the mean and the x-hat component of its incoming gradient) the fp32
+        # run's own gradients sit 1 - 6 % (projection on a random direction, in units of the gradient's norm) off the fp64 ones at this
+        # shape -- the yardstick a GPU fp32 run is measured with (tests/test_e2e_gpu.py), instead of a bar tuned until it passes.
+        import copy
+        ref64 = copy.deepcopy(ref).to(torch.float64)
+        ref64.load_state_dict({k: v.to(torch.float64) if v.is_floating_point() else v for k, v in sd.items()})
+        ref64.zero_grad()
+        ref64.train()
+        l64 = ref64([t.to(torch.float64) for t in timgs], [{"boxes": t["boxes"].to(torch.float64), "labels": t["labels"].clone()} for t in ttgts])
+        (l64["classification_loss"] + l64["regression_loss"]).backward()
+        named64 = dict(ref64.named_parameters())
+        out["train_losses64"] = np.array([float(l64["classification_loss"].detach()), float(l64["regression_loss"].detach())], np.float64)
+        n64, p64 = [], []
+        for k in keys:
+            gflat = named64[k].grad.reshape(-1).double().numpy()
+            r = np.random.default_rng(abs(hash_key(k)) % (1 << 32)).standard_normal(gflat.size)
+            n64.append(float(np.linalg.norm(gflat))); p64.append(float(gflat @ r))
+        out["grad64_all_norms"], out["grad64_all_proj"] = np.array(n64), np.array(p64)
+        e_n = np.abs(np.array(norms) - out["grad64_all_norms"]) / out["grad64_all_norms"]
+        e_p = np.abs(np.array(projs) - out["grad64_all_proj"]) / out["grad64_all_norms"]
+        print(f"  fp64 reference: cls={out['train_losses64'][0]:.8f} reg={out['train_losses64'][1]:.8f}; the fp32 reference's gradients against it: "
+              f"norm median {np.median(e_n):.2e} max {e_n.max():.2e}, projection / norm median {np.median(e_p):.2e} p90 {np.percentile(e_p, 90):.2e} max {e_p.max():.2e}")
+        del ref64, named64
     # running statistics after that ONE training forward (momentum update of every BN layer)
     out["bn1_running_mean_after"] = ref.backbone.backbone.bn1.running_mean.numpy().copy()
     print(f"  train: cls={out['train_losses'][0]:.6f} reg={out['train_losses'][1]:.6f}")
@@ -486,7 +511,7 @@ def gen_e2e_full():
     ``Retinanet(num_classes=90, "resnet50", min_size=800, max_size=1333)`` on the seed-reproducible state dict and two 3 x 800 x 1333
     images with 8 GT boxes each -- train-mode loss dict + every parameter's gradient fingerprint, eval-mode losses, ``predict``.  At this
     size the assembled GPU model runs the kernels at their real tile counts (two-image canvas sheets, band / split-K / chain kernels)."""
-    gen_e2e("resnet50", "e2e_full.npz", cfg=synth.E2E_FULL, inputs=synth.e2e_full_inputs)
+    gen_e2e("resnet50", "e2e_full.npz", cfg=synth.E2E_FULL, inputs=synth.e2e_full_inputs, cls_std=synth.E2E_FULL_CLS_STD, fp64=True)
 
 
 def gen_traj():

@@ -427,18 +427,24 @@ def test_mfma_canvas_conv_forward_backward_vs_torch(shape):
     wr = w.detach().to(torch.bfloat16).float().requires_grad_(True)       # the kernel sees the bf16-rounded weights
     br = b.detach().clone().requires_grad_(True)
     yr = _canvas_conv_reference(xr, wr, br, mask2d)
-    scale = float(yr.detach().abs().max())
-    torch.testing.assert_close(y.float(), yr.detach(), rtol=2e-2, atol=1e-2 * scale)
+    # ONE bf16 rounding of the fp32 result (the old bars -- 2e-2 relative + 1e-2 of the maximum, 5e-2 + 3e-2 on the
+    # gradients -- would have let a wrong ragged-tile column through): 2^-9 per element => ~1.1e-3 in L2; bars 2.5e-3 in L2 and 2^-8 of
+    # the tensor's largest magnitude per element, as tests/test_fp16_kernels_gpu.py does at fp16
+    def one_rounding(got, ref, what):
+        got, ref = got.float(), ref.float()
+        rel = float((got - ref).norm() / (ref.norm() + 1e-20))
+        err, top = float((got - ref).abs().max()), float(ref.abs().max())
+        assert rel < 2.5e-3 and err <= 2.0 ** -8 * top + 1e-6, (what, shape, rel, err, top)
+    one_rounding(y, yr.detach(), "forward")
     assert not y.float()[:, :, mask2d == 0].any()                         # border and gaps are exact zeros
     # gradients: through the ReLU decisions the KERNEL took (y > 0 on its bf16 output) -- a pre-activation within rounding of 0
     # may fall on the other side in fp32, and at 75 000 positions x 256 channels a few always do
     pre = torch.nn.functional.conv2d(xr, wr, br, padding=1)
     (pre * (y.detach().float() > 0) * mask2d[None, None].float()).backward(g.float())
-    gs = float(xr.grad.abs().max())
     interior = mask2d[None, None].bool().expand_as(xr.grad)
-    torch.testing.assert_close(x.grad.float()[interior], xr.grad[interior], rtol=5e-2, atol=3e-2 * gs)
-    torch.testing.assert_close(w.grad.float(), wr.grad, rtol=5e-2, atol=3e-2 * float(wr.grad.abs().max()))
-    torch.testing.assert_close(b.grad, br.grad, rtol=5e-2, atol=3e-2 * float(br.grad.abs().max()))
+    one_rounding(x.grad.float()[interior], xr.grad[interior], "data gradient")
+    one_rounding(w.grad, wr.grad, "weight gradient")
+    one_rounding(b.grad, br.grad, "bias gradient")
 
 
 def test_head_mfma_towers_equal_miopen_towers_bf16():
