@@ -804,6 +804,9 @@ def main():
             "roofline": roof, "roofline_other": roof_other, "conv_mfma": conv_mfma,
             "rccl_ranks": dist.get_world_size() if (dist.is_initialized() and args.backend == "nccl") else 0,
             "exchange_backend": (args.backend + (" (all ranks on cuda:0)" if args.share_gpu else "")) if dist.is_initialized() else None,
+            # the gradient exchange of an N-rank run of this model (stage-aligned 32 MiB fp32 buckets: head + FPN | layer4, layer3 |
+            # layer2 .. stem): what travels over xGMI per step and rank -- printed at N = 1 too, where nothing is exchanged
+            "exchange_plan": ddp.plan() if ddp is not None else P.BucketedGradAllReduce.plan_for(net, stage_of=retinanet_stage_of),
             "gpu_state_during_timed_region": gpu_state,
             "step_launch": {"mode": ("4 linear hipGraph segments + eager all-reduces between them" if stepper.segmented else "hipGraph replay") if graph_replays else "eager",
                             "graph_replays_in_run": graph_replays, "buckets": ddp.num_buckets if ddp is not None else 0,

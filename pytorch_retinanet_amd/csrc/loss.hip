@@ -1061,13 +1061,19 @@ __global__ __launch_bounds__(LOSS_BLOCK) __attribute__((amdgpu_waves_per_eu((FUS
             // atomics that return nothing; a line's three words are performed in program order at its channel.  Integer addition is
             // order-independent, so the result is the same whoever adds first.  Wave 0 of workgroup 0 polls the 64 counters (one per
             // lane), sums the lines when all workgroups have arrived, converts, and leaves every word zeroed for the next launch.
+            // Ordering: the two sums are RETURNING adds whose results this thread waits for -- a device-scope atomic is
+            // performed at the coherence point when its result comes back -- and only then is the arrival published; the poller reads
+            // arrivals, then sums, with device-scope loads.  Nothing rests on fire-and-forget atomics to one line being performed in
+            // program order, and no L2 write-back (an agent-scope release fence) is paid.
             unsigned *const line = a.fin + (blockIdx.x & (FIN_LINES - 1)) * 16;
             unsigned long long *const sums = (unsigned long long *)(line + 2);
             unsigned fl_c = 0u, fl_r = 0u;
             const long long fc = loss_fix(c, fl_c), fr = loss_fix(rg, fl_r);
-            __hip_atomic_fetch_add(sums + 0, (unsigned long long)fc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(sums + 1, (unsigned long long)fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (fl_c | fl_r) __hip_atomic_fetch_or(line + 1, fl_c | (fl_r << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (rare: non-finite logits)
+            const unsigned long long o0 = __hip_atomic_fetch_add(sums + 0, (unsigned long long)fc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long o1 = __hip_atomic_fetch_add(sums + 1, (unsigned long long)fr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned o2 = 0u;
+            if (fl_c | fl_r) o2 = __hip_atomic_fetch_or(line + 1, fl_c | (fl_r << 8), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (rare: non-finite logits)
+            asm volatile("" ::"v"(o0), "v"(o1), "v"(o2));
             __hip_atomic_fetch_add(line, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -1075,13 +1081,22 @@ __global__ __launch_bounds__(LOSS_BLOCK) __attribute__((amdgpu_waves_per_eu((FUS
         static_assert(FIN_LINES == RN_WAVE, "one line per lane");
         unsigned *const mine = a.fin + lane * 16;
         unsigned long long *const msum = (unsigned long long *)(mine + 2);
+        // STICKY poison (state word 1, shared with the fused form's barrier flag): a launch whose workgroups did not all arrive leaves
+        // the lines dirty -- late arrivals would add into re-zeroed words and every later launch would finish early on stale counts with
+        // finite, wrong losses.  Instead the words stay as they are, the poison word is set, and every later call on this state
+        // returns NaN losses until the host replaces the state buffer (ops.reset_match_state).
+        unsigned *const poison = a.fin - 64 + 1;
         unsigned spins = 0;
-        bool ok = true;
-        while (true) {
+        bool ok = __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+        while (ok) {
             const int arrived = rn::wave_sum_i((int)__hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             if (arrived >= (int)gridDim.x) break;
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1u << 22)) { ok = false; break; }      // (a workgroup that never arrives = a faulted launch: poison, do not hang)
+            if (++spins > (1u << 22)) { ok = false; __hip_atomic_store(poison, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // (a workgroup that never arrives = a faulted launch)
+        }
+        if (!ok) {
+            if (lane == 0) { a.out_loss[0] = __builtin_nanf(""); a.out_loss[1] = __builtin_nanf(""); }
+            return;
         }
         long long sc = (long long)__hip_atomic_load(msum + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         long long sr = (long long)__hip_atomic_load(msum + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1096,8 +1111,8 @@ __global__ __launch_bounds__(LOSS_BLOCK) __attribute__((amdgpu_waves_per_eu((FUS
         __hip_atomic_store(mine + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane == 0) {
-            a.out_loss[0] = ok ? loss_unfix(sc, fl & 0xffu) : __builtin_nanf("");
-            a.out_loss[1] = ok ? loss_unfix(sr, (fl >> 8) & 0xffu) : __builtin_nanf("");
+            a.out_loss[0] = loss_unfix(sc, fl & 0xffu);
+            a.out_loss[1] = loss_unfix(sr, (fl >> 8) & 0xffu);
         }
     }
     if (!a.fin && threadIdx.x == 0) {
@@ -1660,7 +1675,23 @@ int launch_stream(StreamT stream_k, LossArgs &a, int vec, hipStream_t st, int *n
         if ((vpw * vec + (int64_t)a.L * (vec - 1)) / a.K + 2 * (int64_t)a.L + 1 > LIST_CAP_FUSED) return RN_EUNSUPPORTED;
     }
     if (g_prof.start) RN_HIP(hipEventRecord(g_prof.start, st));
-    hipLaunchKernelGGL(stream_k, dim3((unsigned)need), dim3(LOSS_BLOCK), 0, st, a);
+    bool launched = false;
+    if (fused) {
+        // the grid barrier needs every workgroup on the chip: a COOPERATIVE launch makes the runtime check that (it refuses a grid that
+        // is not co-resident: RN_EUNSUPPORTED up front, the caller takes the two-launch path) instead of this library trusting its
+        // occupancy estimate and the kernel timing out into NaN losses.  Under stream capture the plain launch is kept (its grid was
+        // sized from the occupancy query above, and the kernel's bounded barrier still fails loudly).
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs == hipStreamCaptureStatusNone) {
+            void *kargs[] = {(void *)&a};
+            const hipError_t e = hipLaunchCooperativeKernel((const void *)stream_k, dim3((unsigned)need), dim3(LOSS_BLOCK), kargs, 0, st);
+            if (e == hipErrorCooperativeLaunchTooLarge || e == hipErrorInvalidConfiguration) { (void)hipGetLastError(); return RN_EUNSUPPORTED; }
+            if (e != hipSuccess) return (int)e;
+            launched = true;
+        }
+    }
+    if (!launched) hipLaunchKernelGGL(stream_k, dim3((unsigned)need), dim3(LOSS_BLOCK), 0, st, a);
     RN_LAUNCH_CHECK();
     if (g_prof.stop) RN_HIP(hipEventRecord(g_prof.stop, st));
     *n_stream = (int)need;

@@ -375,6 +375,14 @@ class use_match_state:
         return False
 
 
+def reset_match_state(dev: Optional[torch.device] = None) -> None:
+    """Drop the cached state buffers (all devices, or ``dev``'s): the next loss call allocates zero-filled ones.  For after a POISONED call
+    -- the in-kernel finalize met a launch whose workgroups did not all arrive (a faulted launch) and set the sticky word: every later
+    call on that state returns NaN losses, loudly, instead of finishing early on stale counters."""
+    for key in [k for k in _MATCH_STATE if dev is None or k[0] == torch.device(dev).index]:
+        del _MATCH_STATE[key]
+
+
 def _match_state(dev: torch.device) -> Tensor:
     if _MATCH_STATE_OVERRIDE is not None and _MATCH_STATE_OVERRIDE.device == dev:
         return _MATCH_STATE_OVERRIDE

@@ -101,8 +101,12 @@ class MasterSGD(torch.optim.Optimizer):
                 st = self.state[p]
                 if "momentum_buffer" not in st:
                     # (under a GradScaler the very first step may be SKIPPED by found_inf: the buffer then has to hold zeros, with
-                    # which the next step's momentum * buf + g is torch's first-step buf = g; a fill kernel, not a memset: graph.py)
+                    # which the next step's momentum * buf + (1 - dampening) * g is torch's first-step buf = g -- for dampening == 0
+                    # only; a fill kernel, not a memset: graph.py)
                     amp = getattr(self, "found_inf", None) is not None
+                    if amp and group["momentum"] != 0 and group["dampening"] != 0:
+                        raise ValueError("MasterSGD under loss scaling needs dampening == 0: a first step skipped by found_inf leaves a zero "
+                                         "momentum buffer, and the next step's momentum * 0 + (1 - dampening) * g is not torch.optim.SGD's first-step buf = g")
                     st["momentum_buffer"] = (torch.empty_like(w).fill_(0) if amp else torch.empty_like(w)) if group["momentum"] != 0 else None
                     st["steps"] = 0
                 if first is None:

@@ -269,6 +269,28 @@ class BucketedGradAllReduce:
         return {"buckets": len(self.buckets), "bytes_total": sum(self.bucket_bytes()), "bytes_per_stage": [per_stage[k] for k in sorted(per_stage)],
                 "bucket_bytes": self.bucket_bytes()}
 
+    @classmethod
+    def plan_for(cls, module: nn.Module, bucket_mb: float = 32.0, stage_of=None) -> dict:
+        """``plan()`` of the exchange this module WOULD get, without building it (no buffers, no hooks): what an N-rank run of the same
+        model exchanges per step.  ``bench.py`` prints it in the single-GPU line, where no exchange exists."""
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        named.reverse()
+        cap = int(bucket_mb * (1 << 20))
+        buckets, stages, size, cur = [], [], 0, None
+        for n, p in named:
+            nbytes = cls._padded(p.numel()) * cls._grad_dtype(p).itemsize
+            key = (cls._grad_dtype(p), p.device, int(stage_of(n)) if stage_of is not None else 0)
+            if cur is not None and (size + nbytes > cap or key != cur):
+                buckets.append(size); stages.append(cur[2]); size = 0
+            cur = key
+            size += nbytes
+        if cur is not None:
+            buckets.append(size); stages.append(cur[2])
+        per_stage = {}
+        for b, st in zip(buckets, stages):
+            per_stage[st] = per_stage.get(st, 0) + b
+        return {"buckets": len(buckets), "bytes_total": sum(buckets), "bytes_per_stage": [per_stage[k] for k in sorted(per_stage)], "bucket_bytes": buckets}
+
     @property
     def num_buckets(self) -> int:
         return len(self.buckets)

@@ -269,3 +269,13 @@ def test_exchange_grad_scaler_takes_found_inf_from_the_exchanged_buckets(tmp_pat
         opt.step()
     for a, b in zip(r0["params"], model.parameters()):
         assert torch.allclose(a, b.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_exchange_plan_is_the_bucket_layout_without_building_it():
+    "``plan_for`` (what bench.py prints at N = 1) == ``plan()`` of the built exchange: bucket count, bytes per backward stage, total."
+    from pytorch_retinanet_amd.parallel import BucketedGradAllReduce
+    stage_of = lambda n: 0 if n.startswith("5") else (1 if n.startswith("2") else 2)
+    want = BucketedGradAllReduce.plan_for(_model(), bucket_mb=0.002, stage_of=stage_of)
+    ddp = BucketedGradAllReduce(_model(), bucket_mb=0.002, stage_of=stage_of)
+    assert ddp.plan() == want and want["buckets"] == ddp.num_buckets >= 3
+    assert sum(want["bytes_per_stage"]) == want["bytes_total"] == sum(ddp.bucket_bytes()) and len(want["bytes_per_stage"]) == 3
