@@ -15,7 +15,8 @@ agg = defaultdict(lambda: defaultdict(list))
 for f in glob.glob("/tmp/pc/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        if any(k in n for k in ("conv3x3_canvas_kernel", "conv3x3_wgrad_kernel", "stem_fwd_kernel", "stem_wgrad_kernel", "wgrad3x3_kernel", "conv3x3_narrow64_kernel", "pw_gemm_kernel<128, 1, 1>")):
+        if any(k in n for k in ("conv3x3_", "stem_fwd_kernel", "stem_wgrad_kernel", "wgrad3x3_kernel", "pw_gemm_kernel", "pw_wgrad_kernel", "pw_conv3_bwd_kernel",
+                                "pw_block_out_conv1_kernel", "pw_dgrad_sums_kernel")):
             agg[n[:95]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in sorted(agg.items()):
     print(k)
