@@ -190,8 +190,12 @@ __device__ __forceinline__ void tile_scan(uint64_t (*s_mask)[MASK_WORDS], const 
 __host__ __device__ constexpr size_t nms_lds_mask_offset(const int cap, const int threads) { return (((size_t)cap * 29 + sizeof(int) * (threads + 1)) + 7) / 8 * 8; }
 __host__ __device__ constexpr size_t nms_lds_bytes(const int cap, const int threads) { return nms_lds_mask_offset(cap, threads) + (size_t)MASK_CAP * MASK_WORDS * 8 + (size_t)cap * 2 + MASK_WORDS * 8; }
 
+// `n` keys: the whole segment (read from a.keys), or -- `preselected` -- the n BEST keys of a longer segment of n_total entries, already in
+// s_key (nms_select_body).  Returns false, having written nothing, when the scan ran out of preselected boxes before it had kept
+// max_keep of them (the caller then runs the full path); true otherwise.  The return value is workgroup-uniform.
 template <int THREADS, int CAP>
-__device__ __forceinline__ void nms_lds_body(const rn::NmsLaunch &a, unsigned char *smem)
+__device__ __forceinline__ bool nms_lds_body(const rn::NmsLaunch &a, unsigned char *smem, const int n, const bool preselected = false,
+                                             const int n_total = 0)
 {
     f32x4 *s_box = (f32x4 *)smem;
     uint64_t *s_key = (uint64_t *)(smem + (size_t)CAP * 16);
@@ -200,13 +204,16 @@ __device__ __forceinline__ void nms_lds_body(const rn::NmsLaunch &a, unsigned ch
     int *s_scan = (int *)(smem + (size_t)CAP * 29);        // CAP % 4 == 0
 
     const int s = blockIdx.x;
-    const int n = a.seg_len[s];
     const int64_t start = a.seg_start[s];
     const int64_t box_base = a.box_mode ? (int64_t)(s / a.K) * a.A : start;
 
     int n_pad = 1;
     while (n_pad < n) n_pad <<= 1;
-    for (int i = threadIdx.x; i < n_pad; i += THREADS) s_key[i] = (i < n) ? a.keys[start + i] : ~0ull;
+    if (!preselected) {
+        for (int i = threadIdx.x; i < n_pad; i += THREADS) s_key[i] = (i < n) ? a.keys[start + i] : ~0ull;
+    } else {
+        for (int i = n + threadIdx.x; i < n_pad; i += THREADS) s_key[i] = ~0ull;      // s_key[0 .. n) holds the selected keys
+    }
     __syncthreads();
     bitonic_sort_lds<THREADS>(s_key, n_pad);
 
@@ -274,6 +281,7 @@ __device__ __forceinline__ void nms_lds_body(const rn::NmsLaunch &a, unsigned ch
         if (a.max_keep > 0 && nkept >= a.max_keep) break;                          // (uniform) the rest of the segment cannot reach the caller's top max_keep
     }
 
+    if (preselected && n < n_total && !(a.max_keep > 0 && nkept >= a.max_keep)) return false;      // (uniform: nkept is the same in every thread)
     const int per = (n_done + THREADS - 1) / THREADS;
     const int lo = min(n_done, (int)threadIdx.x * per), hi = min(n_done, lo + per);
     int cnt = 0;
@@ -288,6 +296,63 @@ __device__ __forceinline__ void nms_lds_body(const rn::NmsLaunch &a, unsigned ch
         }
     }
     if (threadIdx.x == 0) a.kept_count[s] = total;
+    return true;
+}
+
+// A segment longer than MED_CAP whose scan may stop after max_keep kept boxes (the detect chain): the greedy scan walks the boxes in
+// score order and usually ends within the first few hundred -- so only the BEST <= MED_CAP keys are selected (a 2048-bin histogram of
+// the score field over [min, max] finds the largest bin prefix that fits), sorted and scanned in LDS like a short segment; a.keys is only
+// read.  SURVEY 8d's stress regime (~7 k candidates per class, 1 440 segments) paid a full sort of every segment through HBM merge
+// passes: 949 us per batch of 16 images.  Returns false (uniform; nothing written) when the selection cannot be made (more than MED_CAP
+// keys share the best bin: mass ties) or did not reach max_keep kept boxes: the caller runs nms_big_body.
+template <int THREADS, int CAP>
+__device__ __forceinline__ bool nms_select_body(const rn::NmsLaunch &a, unsigned char *smem)
+{
+    constexpr int BINS = 2048;
+    static_assert(THREADS * 2 == BINS && (BINS + 8) * 4 <= CAP * 16, "two bins per thread; the histogram aliases the box area");
+    uint64_t *s_key = (uint64_t *)(smem + (size_t)CAP * 16);
+    int *s_hist = (int *)smem;                                   // [BINS] | [BINS .. BINS + 8): min, max, bin, count, fill
+    const int s = blockIdx.x, t = threadIdx.x;
+    const int n = a.seg_len[s];
+    const uint64_t *keys = a.keys + a.seg_start[s];
+    for (int i = t; i < BINS + 8; i += THREADS) s_hist[i] = (i == BINS) ? (int)0x7fffffff : (i == BINS + 2 ? -1 : 0);
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    for (int i = t; i < n; i += THREADS) { const uint32_t h = (uint32_t)(keys[i] >> 32); lo = min(lo, h); hi = max(hi, h); }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { lo = min(lo, (uint32_t)__shfl_xor((int)lo, d, RN_WAVE)); hi = max(hi, (uint32_t)__shfl_xor((int)hi, d, RN_WAVE)); }
+    __syncthreads();
+    if ((t & (RN_WAVE - 1)) == 0 && lo <= hi) { atomicMin(&s_hist[BINS], (int)(lo >> 1)); atomicMax(&s_hist[BINS + 1], (int)(hi >> 1)); }
+    __syncthreads();
+    const uint32_t lo1 = (uint32_t)s_hist[BINS], range = (uint32_t)s_hist[BINS + 1] - lo1;      // in units of 2 ulps of the field (non-negative ints)
+    const int shift = range >= (uint32_t)BINS ? (32 - __clz((int)range)) - 11 : 0;
+    for (int i = t; i < n; i += THREADS) atomicAdd(&s_hist[(((uint32_t)(keys[i] >> 33)) - lo1) >> shift], 1);
+    __syncthreads();
+    // inclusive scan over the bins, two per thread (as topk_kernel): the last bin whose cumulative count still fits MED_CAP
+    const int h0 = s_hist[2 * t], h1 = s_hist[2 * t + 1];
+    int incl = h0 + h1;
+    const int lane = t & (RN_WAVE - 1), wv = t >> 6;
+#pragma unroll
+    for (int d = 1; d < RN_WAVE; d <<= 1) { const int up = __shfl_up(incl, d, RN_WAVE); if (lane >= d) incl += up; }
+    __shared__ int s_wtot[THREADS / RN_WAVE];
+    if (lane == RN_WAVE - 1) s_wtot[wv] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wv; ++w) before += s_wtot[w];
+    // cum(b) = keys in bins 0 .. b never decreases: tb = the LAST bin with cum(tb) <= CAP (none when the best bin alone exceeds CAP).
+    // Thread t owns bins 2t and 2t + 1 and knows cum(2t - 1), cum(2t), cum(2t + 1); exactly one of the three tests below fires.
+    const int c1 = before + incl, c0 = c1 - h1, prev = c0 - h0;
+    if (c0 <= CAP && c1 > CAP) { s_hist[BINS + 2] = 2 * t; s_hist[BINS + 3] = c0; }
+    if (t > 0 && prev <= CAP && c0 > CAP) { s_hist[BINS + 2] = 2 * t - 1; s_hist[BINS + 3] = prev; }
+    if (t == THREADS - 1 && c1 <= CAP) { s_hist[BINS + 2] = BINS - 1; s_hist[BINS + 3] = c1; }
+    __syncthreads();
+    const int tb = s_hist[BINS + 2], m = s_hist[BINS + 3];
+    if (tb < 0 || m <= 0) return false;                          // the best bin alone holds more than MED_CAP keys
+    for (int i = t; i < n; i += THREADS) {
+        const uint64_t k = keys[i];
+        if ((int)((((uint32_t)(k >> 33)) - lo1) >> shift) <= tb) s_key[atomicAdd(&s_hist[BINS + 4], 1)] = k;
+    }
+    __syncthreads();
+    return nms_lds_body<THREADS, CAP>(a, smem, m, true, n);
 }
 
 // Segments of up to MASK_CAP entries (the common case: ~100 candidates per (image, class) at the
@@ -601,8 +666,10 @@ __global__ __launch_bounds__(BIG_THREADS) void nms_large_kernel(const rn::NmsLau
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n = a.seg_len[blockIdx.x];
     if (n <= MASK_CAP) return;
-    if (n <= MED_CAP) nms_lds_body<BIG_THREADS, MED_CAP>(a, smem);
-    else nms_big_body(a, smem);
+    if (n <= MED_CAP) { nms_lds_body<BIG_THREADS, MED_CAP>(a, smem, n); return; }
+    if (a.max_keep > 0 && nms_select_body<BIG_THREADS, MED_CAP>(a, smem)) return;
+    __syncthreads();
+    nms_big_body(a, smem);
 }
 
 }  // namespace
