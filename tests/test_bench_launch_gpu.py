@@ -18,11 +18,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def test_bench_two_ranks_through_self_launch_on_one_gpu():
+@pytest.mark.parametrize("amp", ["bf16", "fp16"])
+def test_bench_two_ranks_through_self_launch_on_one_gpu(amp):
+    "(fp16: the same path with parallel.ExchangeGradScaler -- found_inf from the exchanged buckets -- captured into the optimizer segment)"
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "4", "--warmup", "3",
-           "--no-cpu-baseline", "--no-detect", "--timing-steps", "1"]
+           "--no-cpu-baseline", "--no-detect", "--timing-steps", "1", "--amp", amp]
     r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1800)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     lines = [l for l in r.stdout.strip().splitlines() if l.strip()]
@@ -37,6 +39,9 @@ def test_bench_two_ranks_through_self_launch_on_one_gpu():
     assert gn.get("memset", 0) == gn.get("memset_replaced", 0) and gn.get("kernel", 0) > 500
     assert 0 < line["config"]["final_loss"] < 100
     assert "cpu_baseline" not in line                               # rank 0 at N = 1 only
+    assert line["dtype"] == amp and line["exchange_plan"]["buckets"] == sl["buckets"] and line["exchange_plan"]["bytes_total"] > 150e6
+    if amp == "fp16":
+        assert "GradScaler (scale 4096" in line["config"]["workload"]  # no step was skipped: every rank kept the initial scale
     assert line["roofline"]["frac"] and line["roofline"]["bound"] == "hbm"
 
 
