@@ -574,7 +574,8 @@ def detect(cls: Tensor, deltas: Tensor, anchors, image_sizes: Sequence[Tuple[int
 
 def detect_levels(cls_levels: Sequence[Tensor], box_levels: Sequence[Tensor], anchors, image_sizes: Sequence[Tuple[int, int]],
                   score_thr: float, min_box: float, nms_thr: float, max_det: int,
-                  reg_w: Sequence[float] = (1.0, 1.0, 1.0, 1.0), max_candidates: Optional[int] = None) -> List[dict]:
+                  reg_w: Sequence[float] = (1.0, 1.0, 1.0, 1.0), max_candidates: Optional[int] = None,
+                  enqueue_only: Optional[list] = None) -> List[dict]:
     """``detect`` on per-level head outputs (cls_levels[l] [B,A_l,K], box_levels[l] [B,A_l,4]) without
     concatenating them; identical results to ``detect(torch.cat(cls_levels, 1), torch.cat(box_levels, 1), ...)``."""
     L = len(cls_levels)
@@ -606,11 +607,18 @@ def detect_levels(cls_levels: Sequence[Tensor], box_levels: Sequence[Tensor], an
     while True:
         ws_bytes = lib.rn_detect_workspace_bytes(B, A, K, cap)
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev), _timed("detect", dev):
+
+        def enqueue():
             check(lib.rn_detect_levels(arr(cls_levels), arr(box_levels), (C.c_int64 * L)(*counts), L, _dtype_code(cls_levels[0]),
                                        B, K, _ptr(anchors), bstride, _ptr(hw), C.byref(params), cap, _ptr(out_boxes),
                                        _ptr(out_scores), _ptr(out_labels), _ptr(meta[0]), _ptr(meta[1]), _ptr(ws), ws_bytes,
                                        _stream(dev)), "rn_detect_levels")
+        if enqueue_only is not None:          # (bench.py: the chain's launches as a closure -- for a hipGraph capture -- instead of running them)
+            enqueue_only.append(enqueue)
+            enqueue_only.append((out_boxes, out_scores, out_labels, meta, ws, hw, anchors, cls_levels, box_levels))     # keep-alive
+            return []
+        with torch.cuda.device(dev), _timed("detect", dev):
+            enqueue()
         meta_h = meta.cpu()                                              # the one sync
         if not bool(meta_h[1].any()) or cap >= A * K:
             break
