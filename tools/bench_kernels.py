@@ -90,7 +90,11 @@ def bench_k3(reps, dtype, B=8, want_grad=True, T=8):
     m, nfg, sp = ops.iou_match(anc, gt, off, B, 0.5, 0.4, want_special=True)
     p = ops.make_loss_params(0.25, 2.0, 0.1)
     # (the model's path: special-row words from K2, `matches` read only at flagged rows)
-    ms = timeit(lambda: ops.loss_fwd_bwd_levels([cls], [box], anc, gt, gl, off, m, nfg, p, want_grad, special=sp), reps)
+    # (... in the form the model picks for this GT count: losses.k3_form -- chunk by chunk at the train shape, the compact list from 32 GT
+    # boxes per image on -- and with the in-kernel finalize, as RetinaNetLosses calls it)
+    from pytorch_retinanet_amd import losses as L
+    ms = timeit(lambda: ops.loss_fwd_bwd_levels([cls], [box], anc, gt, gl, off, m, nfg, p, want_grad, special=sp,
+                                                in_kernel_finalize=L.IN_KERNEL_FINALIZE, form=L.k3_form(B * T, B)), reps)
     s = cls.element_size()
     nbytes = B * ((2 if want_grad else 1) * (A * K * s + A * 4 * s) + A * 8 + T * 24)
     report(f"K3 loss_{'fwd_bwd' if want_grad else 'fwd'} {str(dtype).split('.')[-1]} B={B} A={A} K={K} T={T}", ms, nbytes,
