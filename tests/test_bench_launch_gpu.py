@@ -23,18 +23,18 @@ def test_bench_two_ranks_through_self_launch_on_one_gpu(amp):
     "(fp16: the same path with parallel.ExchangeGradScaler -- found_inf from the exchanged buckets -- captured into the optimizer segment)"
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "4", "--warmup", "3",
-           "--no-cpu-baseline", "--no-detect", "--timing-steps", "1", "--amp", amp]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "2", "--warmup", "3",
+           "--no-cpu-baseline", "--no-detect", "--timing-steps", "1", "--amp", amp]      # (a gloo step moves 153 MB through the host: ~7 s)
     r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1800)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     lines = [l for l in r.stdout.strip().splitlines() if l.strip()]
     line = json.loads(lines[-1])                                   # the JSON line is the LAST line of the job's stdout
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 16
-    assert line["scaling"] == "weak" and line["steps"] == 4 and line["value"] > 0 and line["ms_per_step"] > 0
+    assert line["scaling"] == "weak" and line["steps"] == 2 and line["value"] > 0 and line["ms_per_step"] > 0
     assert abs(line["value"] - 16 * 1e3 / line["ms_per_step"]) <= 1e-2 * line["value"]      # value = ALL ranks' images / the max-over-ranks time
     assert line["exchange_backend"].startswith("gloo") and line["rccl_ranks"] == 0
     sl = line["step_launch"]
-    assert sl["mode"].startswith("4 linear hipGraph segments") and sl["graph_replays_in_run"] >= 4 and sl["buckets"] >= 4
+    assert sl["mode"].startswith("4 linear hipGraph segments") and sl["graph_replays_in_run"] >= 2 and sl["buckets"] >= 4
     gn = sl["graph_nodes"]                                          # (census BEFORE the repair: every memset node found was replaced by a kernel node)
     assert gn.get("memset", 0) == gn.get("memset_replaced", 0) and gn.get("kernel", 0) > 500
     assert 0 < line["config"]["final_loss"] < 100
