@@ -23,6 +23,13 @@
 #include "rn_common.hpp"
 #include <type_traits>
 
+#ifndef PW_GEMM_DEEP
+#define PW_GEMM_DEEP 0         // pw_gemm_kernel without an operand transform: two K-tiles of loads in flight per workgroup
+#endif
+#ifndef PW_GEMM_XCD_MAP
+#define PW_GEMM_XCD_MAP 1      // pw_gemm_kernel: the column tiles of a row-tile walker on one XCD
+#endif
+
 namespace {
 
 using rn::f32x16;
@@ -57,6 +64,7 @@ struct PwArgs {
     int relu_mode;                  // PRO_BN_BWD: 0 none, 2 recomputed from X2, 3 bits
     int stride, pad, Ho, Wo, H, W_; // position decode of output row m = (n, ho, wo) -> input (n, ho * stride - pad + dy, ...)
     int gx;                         // row-tile walkers per column tile
+    int xcd_cols;                   // > 0: 1-D grid of 8 * ceil(gx / 8) * xcd_cols workgroups, a walker's column tiles on one XCD (see the kernel)
     int f16;                        // host side: fp16 elements instead of bf16 (kernel instantiation)
 };
 
@@ -122,7 +130,8 @@ __device__ __forceinline__ rn::u32x4 transform(const rn::u32x4 x, const rn::u32x
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-template <int DT, int BN, int PRO, int EPI>
+// PLAIN: 1x1 / stride 1 (every bottleneck GEMM) -- no position decode anywhere, see the staging addresses below.
+template <int DT, int BN, int PRO, int EPI, bool PLAIN>
 __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
 {
     constexpr int MI = 2, NI = BN / 64;                         // 2 x 2 waves of 64 x (BN / 2)
@@ -131,7 +140,17 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // 2 stages of [A | B]; the epilogue's f32 tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int n0 = blockIdx.y * BN;
+    // (walker, column tile) of this workgroup.  xcd_cols > 0: a 1-D grid placed by XCD (workgroups go round-robin over the 8 XCDs) -- the
+    // column tiles of a walker run on ONE XCD, next to each other in time, so the walker's X rows enter that XCD's L2 once instead of once
+    // per column tile from HBM (the inference conv3 of layer3: 8 column tiles of 57.8 MB of rows = 462 MB of reads for 520 MB of operands)
+    int walker = blockIdx.x, ctile = blockIdx.y;
+    if (a.xcd_cols > 0) {
+        const int L = blockIdx.x, t = L >> 3;
+        ctile = t % a.xcd_cols;
+        walker = (t / a.xcd_cols) * 8 + (L & 7);
+        if (walker >= a.gx) return;
+    }
+    const int n0 = ctile * BN;
     const int cpt = a.Cin / PW_BK, KT = a.taps * cpt, Ktot = a.taps * a.Cin;
     const int c = tid & 7, r0 = tid >> 3;                       // this thread stages 16-byte chunk c of rows r0 + 32 i
     const int MT = (a.M + PW_BM - 1) / PW_BM;
@@ -160,11 +179,33 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
     // flight): the first K-tile of tile t+1 is loaded while tile t's epilogue runs, and the epilogue's own operands (residual +
     // bits, or the activation whose ReLU mask / BN sums it forms) are loaded at the top of the tile, under its MFMAs.
     constexpr int EROWS = PW_BM / RL;                           // epilogue rows per thread
-    rn::u32x4 sx[4], sz[4], sw[BROWS];
-    uint32_t sbits[4] = {0xffu, 0xffu, 0xffu, 0xffu};
-    bool sval[4];
-    int sc0 = 0;                                                // first channel of the staged K-tile
-    RowPos rp[4];
+    // Staging registers of one K-tile.  DEEP (no operand transform, an even number of K-tiles): TWO K-tiles in flight -- K-tile j of a
+    // row tile travels in set j & 1.  With one set a K-tile's loads go out at the top of the iteration that ends with their commit:
+    // they have 16 MFMAs (0.3 us) to land, and the s_memrealtime stamps (tools/probes/make_stamped_pw.py) show 1.5 - 1.6 us per
+    // K-tile at every shape, whatever the MFMAs, the residual, the stores or the cache level of X cost: an L2 round trip per K-tile.
+    struct Stg {
+        rn::u32x4 sx[4], sz[4], sw[BROWS];
+        uint32_t sbits[4];
+        bool sval[4];
+        int sc0;                                                // first channel of the staged K-tile
+    };
+    Stg S0, S1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { S0.sbits[i] = 0xffu; S1.sbits[i] = 0xffu; }
+    S0.sc0 = 0; S1.sc0 = 0;
+    constexpr bool DEEP_OK = PW_GEMM_DEEP && PRO == PRO_NONE;
+    const bool deep = DEEP_OK && KT >= 2 && (KT & 1) == 0;       // (workgroup-uniform)
+    RowPos rp[4];                                                // (!PLAIN: the decoded rows of the tile being requested)
+    // PLAIN: the source of a staged vector is a WAVE-UNIFORM 64-bit base -- tile origin + channel chunk, scalar work -- plus a per-thread
+    // 32-bit offset computed once per kernel.  The general path forms every address from the row's decoded position (a 64-bit multiply +
+    // clamp chain per vector, 12 vectors per K-tile): the s_memrealtime stamps of the K loop showed 0.68 - 0.78 us of the 1.5 us per
+    // K-tile in that issue phase, more than the fragment reads + MFMAs (0.39 - 0.45).  Weights: the same in both forms.
+    uint32_t xoff[4], woff[BROWS];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xoff[i] = (uint32_t)((r0 + 32 * i) * a.Cin + c * 8) * 2u;              // (host: 128 rows of Cin channels < 2^31 bytes)
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i) woff[i] = (uint32_t)((r0 + 32 * i) * Ktot + c * 8) * 2u;
+    int stage_m0 = 0;                                            // first row of the row tile whose K-tiles are being requested
     // the prologue's per-channel coefficients live in LDS behind the staging area: [a | b | c | fa | fb][Cin] f32
     constexpr int LDS_MAIN = (2 * STAGE > PW_BM * BN * 4) ? 2 * STAGE : PW_BM * BN * 4;
     float *const s_coef = (float *)(lds + LDS_MAIN);
@@ -177,33 +218,52 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
         }
         __syncthreads();
     }
-    auto issue = [&](const int kt) {
+    auto issue = [&](const int kt, Stg &s) {
         const int tap = kt / cpt, c0 = (kt - tap * cpt) * PW_BK;
         const int dy = a.taps == 1 ? 0 : tap / 3, dx = a.taps == 1 ? 0 : tap - (tap / 3) * 3;
+        {
+            const unsigned char *const wb = (const unsigned char *)a.W + ((int64_t)n0 * Ktot + kt * PW_BK) * 2;
+#pragma unroll
+            for (int i = 0; i < BROWS; ++i) s.sw[i] = *(const rn::u32x4 *)(wb + woff[i]);
+        }
+        s.sc0 = c0;
+        if (PLAIN) {
+            const int64_t e0 = (int64_t)stage_m0 * a.Cin + c0;
+            const unsigned char *const xb = (const unsigned char *)a.X + e0 * 2;
+            const bool ragged = stage_m0 + PW_BM > a.M;          // (uniform) the last row tile: rows past the end read row M - 1 and stage zeros
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool v = !ragged || stage_m0 + r0 + 32 * i < a.M;
+                const uint32_t o = v ? xoff[i] : (uint32_t)((a.M - 1 - stage_m0) * a.Cin + c * 8) * 2u;
+                s.sval[i] = v;
+                s.sx[i] = *(const rn::u32x4 *)(xb + o);
+                if (PRO == PRO_BN_BWD) {
+                    s.sz[i] = *(const rn::u32x4 *)((const unsigned char *)a.X2 + e0 * 2 + o);
+                    s.sbits[i] = a.xbits ? (a.xbits + (e0 >> 3))[o >> 4] : 0xffu;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int y = rp[i].y0 + dy, x = rp[i].x0 + dx;
             const bool v = rp[i].ok && (a.taps == 1 && a.stride == 1 ? true : (y >= 0 && y < a.H && x >= 0 && x < a.W_));
-            sval[i] = v;
+            s.sval[i] = v;
             const int64_t row = v ? (int64_t)rp[i].base + (a.taps == 1 && a.stride == 1 ? 0 : y * a.W_ + x) : 0;      // clamped: always a valid address
             const int64_t e = row * a.Cin + c0 + c * 8;
-            sx[i] = *(const rn::u32x4 *)(a.X + e);
+            s.sx[i] = *(const rn::u32x4 *)(a.X + e);
             if (PRO == PRO_BN_BWD) {
-                sz[i] = *(const rn::u32x4 *)(a.X2 + e);
+                s.sz[i] = *(const rn::u32x4 *)(a.X2 + e);
                 // (the byte is fetched whatever the mode -- a load behind a run-time condition would serialise the batch)
-                sbits[i] = a.xbits ? a.xbits[e >> 3] : 0xffu;
+                s.sbits[i] = a.xbits ? a.xbits[e >> 3] : 0xffu;
             }
         }
-#pragma unroll
-        for (int i = 0; i < BROWS; ++i)
-            sw[i] = *(const rn::u32x4 *)(a.W + (int64_t)(n0 + r0 + 32 * i) * Ktot + kt * PW_BK + c * 8);
-        sc0 = c0;
     };
-    auto commit = [&](const int stage) {
+    auto commit = [&](const int stage, const Stg &s) {
         unsigned char *const sb = lds + stage * STAGE;
         ProCoef coef;                                           // from the LDS copy: nothing held in registers across the MFMAs
         if (PRO != PRO_NONE) {
-            const int ch = sc0 + c * 8;
+            const int ch = s.sc0 + c * 8;
             ld8f(s_coef + ch, coef.a); ld8f(s_coef + a.Cin + ch, coef.b);
             if (PRO == PRO_BN_BWD) {
                 ld8f(s_coef + 2 * a.Cin + ch, coef.c);
@@ -211,9 +271,10 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *(rn::u32x4 *)(sb + wa_off[i]) = transform<DT, PRO>(sx[i], sz[i], sbits[i], coef, a.relu_mode, sval[i]);
+        for (int i = 0; i < 4; ++i)
+            *(rn::u32x4 *)(sb + wa_off[i]) = transform<DT, PRO>(s.sx[i], PRO == PRO_BN_BWD ? s.sz[i] : s.sx[i], s.sbits[i], coef, a.relu_mode, s.sval[i]);
 #pragma unroll
-        for (int i = 0; i < BROWS; ++i) *(rn::u32x4 *)(sb + wb_off[i]) = sw[i];
+        for (int i = 0; i < BROWS; ++i) *(rn::u32x4 *)(sb + wb_off[i]) = s.sw[i];
     };
     // EPI_RELU_BWD: the four per-column vectors of the epilogue, in LDS behind the prologue coefficients: [ea | eb | emean | einv][BN]
     float *const s_epi = s_coef + (PRO == PRO_NONE ? 0 : (PRO == PRO_AFFINE_RELU ? 2 : 5) * a.Cin);
@@ -229,11 +290,12 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
 
     float ebias[8];                                             // EPI_BIAS: this thread's 8 fixed columns of the bias
     if (EPI & EPI_BIAS) ld8f(a.bias + n0 + ecg * 8, ebias);
-    int mt = blockIdx.x;
+    int mt = walker;
     if (mt < MT) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rp[i] = decode_row(a, mt * PW_BM + r0 + 32 * i);
-        issue(0);
+        for (int i = 0; i < 4; ++i) if (!PLAIN) rp[i] = decode_row(a, mt * PW_BM + r0 + 32 * i);
+        stage_m0 = mt * PW_BM;
+        issue(0, S0);
     }
     for (; mt < MT; mt += a.gx) {
         const int m0 = mt * PW_BM;
@@ -261,7 +323,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
                 }
             }
         };
-        if (EPI_EARLY) load_epi();
+        if (EPI_EARLY && !(DEEP_OK && deep)) load_epi();
         f32x16 acc[MI][NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -269,17 +331,8 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-        commit(0);
-        __syncthreads();
-        for (int kt = 0; kt < KT; ++kt) {
-            if (kt + 1 < KT) issue(kt + 1);                     // in flight under this K-tile's MFMAs
-            else if (mt + a.gx < MT) {                          // the NEXT row tile's first K-tile, in flight under the epilogue
-#pragma unroll
-                for (int i = 0; i < 4; ++i) rp[i] = decode_row(a, (mt + a.gx) * PW_BM + r0 + 32 * i);
-                issue(0);
-            }
-            const unsigned char *const sb = lds + (kt & 1) * STAGE;
+        auto mma_stage = [&](const int stage) {                 // the 16 MFMAs per wave of the K-tile in LDS stage `stage`
+            const unsigned char *const sb = lds + stage * STAGE;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 typedef typename rn::mma<DT>::frag frag8;
@@ -294,12 +347,46 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
                     for (int ni = 0; ni < NI; ++ni)
                         acc[mi][ni] = rn::mma<DT>::m32(fa[mi], fb[ni], acc[mi][ni]);
             }
-            if (kt + 1 < KT) commit((kt + 1) & 1);
+        };
+        auto issue_next_tile = [&]() {                          // the NEXT row tile's first K-tile (set 0), in flight under the epilogue
+            if (mt + a.gx < MT) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) if (!PLAIN) rp[i] = decode_row(a, (mt + a.gx) * PW_BM + r0 + 32 * i);
+                stage_m0 = (mt + a.gx) * PW_BM;
+                issue(0, S0);
+            }
+        };
+
+        if (DEEP_OK && deep) {
+            // K-tile 0 is in set 0 (issued under the previous tile's epilogue), K-tile 1 goes out now; inside the walk every K-tile is
+            // requested two iterations before its commit.  The epilogue's own operands go out two K-tiles before the end -- in the
+            // registers of the set that has nothing left to fetch (their live range starts after the loop) -- and the next row tile's
+            // K-tile 0 in the last one.
+            issue(1, S1);
+            commit(0, S0);
             __syncthreads();
+            for (int kt = 0; kt + 2 < KT; kt += 2) {
+                issue(kt + 2, S0); mma_stage(0); commit(1, S1); __syncthreads();
+                issue(kt + 3, S1); mma_stage(1); commit(0, S0); __syncthreads();
+            }
+            load_epi();
+            mma_stage(0); commit(1, S1); __syncthreads();
+            issue_next_tile();
+            mma_stage(1); __syncthreads();
+        } else {
+            commit(0, S0);
+            __syncthreads();
+            for (int kt = 0; kt < KT; ++kt) {
+                if (kt + 1 < KT) issue(kt + 1, S0);             // in flight under this K-tile's MFMAs
+                else issue_next_tile();
+                mma_stage(kt & 1);
+                if (kt + 1 < KT) commit((kt + 1) & 1, S0);
+                __syncthreads();
+            }
         }
 
         // ---- epilogue: accumulators -> f32 tile in LDS -> rows of 8-channel vectors
-        if (!EPI_EARLY) load_epi();
+        if (!EPI_EARLY && !(DEEP_OK && deep)) load_epi();
         float *const tile = (float *)lds;                       // [128][BN]
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -370,7 +457,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
             float t = 0.0f;
             for (int l = 0; l < RL; ++l) t += red[l * 2 * BN + q];
             const int which = q >= BN ? 1 : 0;
-            a.partial[((int64_t)blockIdx.x * 2 + which) * a.N + n0 + (q - which * BN)] = t;
+            a.partial[((int64_t)walker * 2 + which) * a.N + n0 + (q - which * BN)] = t;
         }
     }
 }
@@ -1304,9 +1391,20 @@ template <int DT, int BN, int PRO, int EPI> int launch_gemm_dt(const PwArgs &a, 
     constexpr int lds_main = 2 * (PW_BM * PW_BK * 2 + BN * PW_BK * 2) > PW_BM * BN * 4 ? 2 * (PW_BM * PW_BK * 2 + BN * PW_BK * 2) : PW_BM * BN * 4;
     const int lds = lds_main + (PRO == PRO_NONE ? 0 : (PRO == PRO_AFFINE_RELU ? 2 : 5) * a.Cin * 4) + ((EPI & EPI_RELU_BWD) ? 4 * BN * 4 : 0);
     if (lds > 160 * 1024) return RN_EUNSUPPORTED;
-    static rn::DynLdsOptIn opt_in = {};
-    { const int rc = opt_in.ensure((const void *)pw_gemm_kernel<DT, BN, PRO, EPI>, lds); if (rc != RN_OK) return rc; }
-    hipLaunchKernelGGL((pw_gemm_kernel<DT, BN, PRO, EPI>), dim3((unsigned)a.gx, (unsigned)(a.N / BN)), dim3(PW_THREADS), lds, st, a);
+    const int ny = a.N / BN;
+    PwArgs b = a;
+    const bool by_xcd = PW_GEMM_XCD_MAP && ny >= 2;
+    if (by_xcd) b.xcd_cols = ny;
+    const dim3 grid = by_xcd ? dim3(8u * (unsigned)((a.gx + 7) / 8) * (unsigned)ny) : dim3((unsigned)a.gx, (unsigned)ny);
+    if (a.taps == 1 && a.stride == 1) {
+        static rn::DynLdsOptIn opt_in = {};
+        { const int rc = opt_in.ensure((const void *)pw_gemm_kernel<DT, BN, PRO, EPI, true>, lds); if (rc != RN_OK) return rc; }
+        hipLaunchKernelGGL((pw_gemm_kernel<DT, BN, PRO, EPI, true>), grid, dim3(PW_THREADS), lds, st, b);
+    } else {
+        static rn::DynLdsOptIn opt_in = {};
+        { const int rc = opt_in.ensure((const void *)pw_gemm_kernel<DT, BN, PRO, EPI, false>, lds); if (rc != RN_OK) return rc; }
+        hipLaunchKernelGGL((pw_gemm_kernel<DT, BN, PRO, EPI, false>), grid, dim3(PW_THREADS), lds, st, b);
+    }
     RN_LAUNCH_CHECK();
     return RN_OK;
 }
