@@ -23,9 +23,6 @@
 #include "rn_common.hpp"
 #include <type_traits>
 
-#ifndef PW_GEMM_DEEP
-#define PW_GEMM_DEEP 0         // pw_gemm_kernel without an operand transform: two K-tiles of loads in flight per workgroup
-#endif
 #ifndef PW_GEMM_XCD_MAP
 #define PW_GEMM_XCD_MAP 1      // pw_gemm_kernel: the column tiles of a row-tile walker on one XCD
 #endif
@@ -179,22 +176,18 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
     // flight): the first K-tile of tile t+1 is loaded while tile t's epilogue runs, and the epilogue's own operands (residual +
     // bits, or the activation whose ReLU mask / BN sums it forms) are loaded at the top of the tile, under its MFMAs.
     constexpr int EROWS = PW_BM / RL;                           // epilogue rows per thread
-    // Staging registers of one K-tile.  DEEP (no operand transform, an even number of K-tiles): TWO K-tiles in flight -- K-tile j of a
-    // row tile travels in set j & 1.  With one set a K-tile's loads go out at the top of the iteration that ends with their commit:
-    // they have 16 MFMAs (0.3 us) to land, and the s_memrealtime stamps (tools/probes/make_stamped_pw.py) show 1.5 - 1.6 us per
-    // K-tile at every shape, whatever the MFMAs, the residual, the stores or the cache level of X cost: an L2 round trip per K-tile.
+    // Staging registers of one K-tile.  (A second set -- two K-tiles in flight, K-tile j in set j & 1 -- was measured in round 6: the
+    // bias-only variants gain 2 - 10 % at 231 - 249 VGPRs, the residual variant spills; every shape it helps is hipBLASLt's anyway.)
     struct Stg {
         rn::u32x4 sx[4], sz[4], sw[BROWS];
         uint32_t sbits[4];
         bool sval[4];
         int sc0;                                                // first channel of the staged K-tile
     };
-    Stg S0, S1;
+    Stg S0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { S0.sbits[i] = 0xffu; S1.sbits[i] = 0xffu; }
-    S0.sc0 = 0; S1.sc0 = 0;
-    constexpr bool DEEP_OK = PW_GEMM_DEEP && PRO == PRO_NONE;
-    const bool deep = DEEP_OK && KT >= 2 && (KT & 1) == 0;       // (workgroup-uniform)
+    for (int i = 0; i < 4; ++i) S0.sbits[i] = 0xffu;
+    S0.sc0 = 0;
     RowPos rp[4];                                                // (!PLAIN: the decoded rows of the tile being requested)
     // PLAIN: the source of a staged vector is a WAVE-UNIFORM 64-bit base -- tile origin + channel chunk, scalar work -- plus a per-thread
     // 32-bit offset computed once per kernel.  The general path forms every address from the row's decoded position (a 64-bit multiply +
@@ -323,7 +316,7 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
                 }
             }
         };
-        if (EPI_EARLY && !(DEEP_OK && deep)) load_epi();
+        if (EPI_EARLY) load_epi();
         f32x16 acc[MI][NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -357,36 +350,18 @@ __global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PwArgs a)
             }
         };
 
-        if (DEEP_OK && deep) {
-            // K-tile 0 is in set 0 (issued under the previous tile's epilogue), K-tile 1 goes out now; inside the walk every K-tile is
-            // requested two iterations before its commit.  The epilogue's own operands go out two K-tiles before the end -- in the
-            // registers of the set that has nothing left to fetch (their live range starts after the loop) -- and the next row tile's
-            // K-tile 0 in the last one.
-            issue(1, S1);
-            commit(0, S0);
+        commit(0, S0);
+        __syncthreads();
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt + 1 < KT) issue(kt + 1, S0);                 // in flight under this K-tile's MFMAs
+            else issue_next_tile();
+            mma_stage(kt & 1);
+            if (kt + 1 < KT) commit((kt + 1) & 1, S0);
             __syncthreads();
-            for (int kt = 0; kt + 2 < KT; kt += 2) {
-                issue(kt + 2, S0); mma_stage(0); commit(1, S1); __syncthreads();
-                issue(kt + 3, S1); mma_stage(1); commit(0, S0); __syncthreads();
-            }
-            load_epi();
-            mma_stage(0); commit(1, S1); __syncthreads();
-            issue_next_tile();
-            mma_stage(1); __syncthreads();
-        } else {
-            commit(0, S0);
-            __syncthreads();
-            for (int kt = 0; kt < KT; ++kt) {
-                if (kt + 1 < KT) issue(kt + 1, S0);             // in flight under this K-tile's MFMAs
-                else issue_next_tile();
-                mma_stage(kt & 1);
-                if (kt + 1 < KT) commit((kt + 1) & 1, S0);
-                __syncthreads();
-            }
         }
 
         // ---- epilogue: accumulators -> f32 tile in LDS -> rows of 8-channel vectors
-        if (!EPI_EARLY && !(DEEP_OK && deep)) load_epi();
+        if (!EPI_EARLY) load_epi();
         float *const tile = (float *)lds;                       // [128][BN]
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)

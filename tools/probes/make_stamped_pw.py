@@ -22,19 +22,19 @@ rep("    for (; mt < MT; mt += a.gx) {\n        const int m0 = mt * PW_BM;\n",
     "    int tile_no = 0;\n    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;\n"
     "    for (; mt < MT; mt += a.gx) {\n        const int m0 = mt * PW_BM;\n        const unsigned long long s0 = __builtin_amdgcn_s_memrealtime();\n"
     "        unsigned long long s1 = 0, s2 = 0, s3 = 0, s4 = 0, d_issue = 0, d_mma = 0, d_commit = 0, d_bar = 0, tA, tB;\n")
-# the classic K loop (one staging set): per-phase sums
-rep("            commit(0, S0);\n            __syncthreads();\n            for (int kt = 0; kt < KT; ++kt) {\n"
-    "                if (kt + 1 < KT) issue(kt + 1, S0);             // in flight under this K-tile's MFMAs\n"
-    "                else issue_next_tile();\n                mma_stage(kt & 1);\n                if (kt + 1 < KT) commit((kt + 1) & 1, S0);\n                __syncthreads();\n            }\n",
-    "            commit(0, S0);\n            __syncthreads();\n            s1 = __builtin_amdgcn_s_memrealtime();\n            for (int kt = 0; kt < KT; ++kt) {\n"
-    "                tA = __builtin_amdgcn_s_memrealtime();\n"
-    "                if (kt + 1 < KT) issue(kt + 1, S0);\n                else issue_next_tile();\n"
-    "                __builtin_amdgcn_sched_barrier(0); tB = __builtin_amdgcn_s_memrealtime(); d_issue += tB - tA; tA = tB; __builtin_amdgcn_sched_barrier(0);\n"
-    "                mma_stage(kt & 1);\n"
-    "                __builtin_amdgcn_sched_barrier(0); asm volatile(\"s_nop 0\" ::: \"memory\"); tB = __builtin_amdgcn_s_memrealtime(); d_mma += tB - tA; tA = tB; __builtin_amdgcn_sched_barrier(0);\n"
-    "                if (kt + 1 < KT) commit((kt + 1) & 1, S0);\n"
-    "                __builtin_amdgcn_sched_barrier(0); asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\"); tB = __builtin_amdgcn_s_memrealtime(); d_commit += tB - tA; tA = tB; __builtin_amdgcn_sched_barrier(0);\n"
-    "                __syncthreads();\n                tB = __builtin_amdgcn_s_memrealtime(); d_bar += tB - tA;\n            }\n")
+# the K loop: per-phase sums
+rep("        commit(0, S0);\n        __syncthreads();\n        for (int kt = 0; kt < KT; ++kt) {\n"
+    "            if (kt + 1 < KT) issue(kt + 1, S0);                 // in flight under this K-tile's MFMAs\n"
+    "            else issue_next_tile();\n            mma_stage(kt & 1);\n            if (kt + 1 < KT) commit((kt + 1) & 1, S0);\n            __syncthreads();\n        }\n",
+    "        commit(0, S0);\n        __syncthreads();\n        s1 = __builtin_amdgcn_s_memrealtime();\n        for (int kt = 0; kt < KT; ++kt) {\n"
+    "            tA = __builtin_amdgcn_s_memrealtime();\n"
+    "            if (kt + 1 < KT) issue(kt + 1, S0);\n            else issue_next_tile();\n"
+    "            __builtin_amdgcn_sched_barrier(0); tB = __builtin_amdgcn_s_memrealtime(); d_issue += tB - tA; tA = tB; __builtin_amdgcn_sched_barrier(0);\n"
+    "            mma_stage(kt & 1);\n"
+    "            __builtin_amdgcn_sched_barrier(0); asm volatile(\"s_nop 0\" ::: \"memory\"); tB = __builtin_amdgcn_s_memrealtime(); d_mma += tB - tA; tA = tB; __builtin_amdgcn_sched_barrier(0);\n"
+    "            if (kt + 1 < KT) commit((kt + 1) & 1, S0);\n"
+    "            __builtin_amdgcn_sched_barrier(0); asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\"); tB = __builtin_amdgcn_s_memrealtime(); d_commit += tB - tA; tA = tB; __builtin_amdgcn_sched_barrier(0);\n"
+    "            __syncthreads();\n            tB = __builtin_amdgcn_s_memrealtime(); d_bar += tB - tA;\n        }\n")
 rep("        // ---- epilogue: accumulators -> f32 tile in LDS -> rows of 8-channel vectors\n",
     "        s2 = __builtin_amdgcn_s_memrealtime();\n        // ---- epilogue: accumulators -> f32 tile in LDS -> rows of 8-channel vectors\n")
 rep("        __syncthreads();\n#pragma unroll\n        for (int i = 0; i < EROWS; ++i) {\n            const int row = erl + i * RL;\n            const int m = m0 + row;\n            if (m < a.M) {\n                float v[8];\n                ld8f(tile + row * BN + ecg * 8, v);",
