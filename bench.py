@@ -568,6 +568,23 @@ def match_plus_loss_line(device, B, T, dtype, label):
             "k2_frac_of_fp32_valu_peak_at_25_flop_per_pair": round(25.0 * pairs / (t_k2 * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)}
 
 
+def vendor_gemm_yardstick(device):
+    """What the vendor GEMM (hipBLASLt through torch.mm, bf16) reaches on THIS box: a large square, and the head's 3x3 convolutions written as
+    the explicit GEMMs they are -- positions x 2304 -> 256 / 810, the im2col matrix given for free -- beside `conv_mfma.own_kernels` (which gather
+    their operand from the canvas).  Graph-replayed; tools/gemm_ceiling_probe.py is the longer table."""
+    g = torch.Generator(device=device).manual_seed(0)
+    out = {"timing": "torch.mm(bf16) captured in a hipGraph, 10 replays between one event pair, median of 3"}
+    for key, M, K, N in (("square_8192", 8192, 8192, 8192), ("tower_pair_as_gemm", 2 * 179200, 2304, 256), ("cls_output_as_gemm", 179200, 2304, 810)):
+        a = torch.randn((M, K), device=device, generator=g).to(torch.bfloat16)
+        b = (torch.randn((N, K), device=device, generator=g) * 0.05).to(torch.bfloat16)
+        ms = graph_replay_ms(lambda: torch.mm(a, b.t()), reps=10, rounds=3)
+        out[key] = {"M": M, "K": K, "N": N, "ms": round(ms, 4), "tflops": round(2.0 * M * K * N / (ms * 1e-3) / 1e12, 1),
+                    "frac_of_mfma_peak": round(2.0 * M * K * N / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+        del a, b
+    torch.cuda.empty_cache()
+    return out
+
+
 def k3_cold_line(device, B, T, nbytes):
     """K3 at the train shape on COLD logits (the isolated kernel: the in-step figure of `roofline` reads logits the
     class-output conv has just left in the 256 MiB Infinity Cache, walking them back to front).  Per-level bf16 tensors as
@@ -828,6 +845,7 @@ def main():
             del net, optimizer, stepper
             torch.cuda.empty_cache()
             line["roofline"].update(k3_cold_line(device, args.batch, args.gt, nbytes))
+            line["conv_mfma"]["vendor_gemm_yardstick"] = vendor_gemm_yardstick(device)
             # the pair as graph replays (no per-call events): the train shape, and BASELINE configs[4] (fp16, 500 GT boxes per image)
             line["roofline_other"].setdefault("match_plus_loss", {})["graph_replay"] = match_plus_loss_line(device, args.batch, args.gt, amp_dtype, "train shape")
             line["roofline_other"]["cfg5"] = match_plus_loss_line(device, args.batch, 500, torch.float16, "BASELINE configs[4] (IoU-matcher stress)")
