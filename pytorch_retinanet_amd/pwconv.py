@@ -131,7 +131,10 @@ def eval_conv1x1(conv, x: Tensor, w: Tensor, bias: Tensor, relu: bool, residual:
     Cout = int(w.shape[0])
     if s == 1 and residual is None and MM_1X1 and _fwd_by_mm(N * H * W, Cin, Cout):
         x2, w2 = x.permute(0, 2, 3, 1).reshape(-1, Cin), w.reshape(Cout, Cin)
-        b16 = bias.to(x.dtype)
+        b16 = getattr(bias, "_rn_b16", None)                     # (the folded bias lives as long as its fold-cache entry: cast it once, not per call)
+        if b16 is None or b16.dtype != x.dtype:
+            b16 = bias.to(x.dtype)
+            bias._rn_b16 = b16
         y2 = torch._addmm_activation(b16, x2, w2.t()) if relu else torch.addmm(b16, x2, w2.t())
         return y2.view(N, H, W, Cout).permute(0, 3, 1, 2)
     return pw_forward(x, w, stride=s, epi=bias_act_epilogue(bias, relu, residual), tag="pw_eval_1x1")
